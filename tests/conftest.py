@@ -1,0 +1,35 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CASES = ["tiny", "sym200", "deep3", "single", "mol8"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def golden_params(g):
+    """(weights, biases) lists in layer order from the reference state-dict keys."""
+    L = len(g["hidden"])
+    Ws = [g[f"sd/layers.{i}.apply_mod.linear.weight"] for i in range(L)]
+    bs = [g[f"sd/layers.{i}.apply_mod.linear.bias"] for i in range(L)]
+    return Ws, bs
+
+
+@pytest.fixture(params=CASES)
+def golden(request):
+    g = load_golden(request.param)
+    g["name"] = request.param
+    return g
