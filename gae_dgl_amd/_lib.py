@@ -1,0 +1,81 @@
+"""ctypes binding of libgae_hip.so (the C ABI declared in include/gae_hip.h).
+
+There is NO fallback: if the shared library is missing or cannot be loaded
+every op raises -- the product path never routes through PyTorch/CPU code."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgae_hip.so")
+
+F32, BF16 = 0, 1
+ACT_IDENTITY, ACT_RELU = 0, 1
+
+_i32, _i64, _u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
+_p, _f, _int = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+
+
+class DeviceInfo(ctypes.Structure):
+    _fields_ = [("compute_units", _i32), ("wavefront_size", _i32), ("lds_bytes_per_cu", _i32),
+                ("l2_bytes", _i32), ("hbm_bytes", _i64), ("clock_khz", _i32),
+                ("gfx_major_minor", _i32), ("name", ctypes.c_char * 64)]
+
+
+# name -> (restype, argtypes); mirrors include/gae_hip.h one to one
+SIGNATURES = {
+    "gae_version": (_int, []),
+    "gae_last_error": (ctypes.c_char_p, []),
+    "gae_device_info_get": (_int, [_int, ctypes.POINTER(DeviceInfo)]),
+    "gae_csr_from_coo_workspace_bytes": (_i64, [_i64, _i64]),
+    "gae_csr_from_coo": (_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _i64, _p, _p]),
+    "gae_degree_norm": (_int, [_p, _i64, _p, _p, _p]),
+    "gae_csr_to_dense": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
+    "gae_batch_gather": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _p, _i64, _i64,
+                                _p, _p, _p, _i64, _p]),
+    "gae_spmm_csr": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _int, _p, _p, _p]),
+    "gae_linear_fwd": (_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p]),
+    "gae_linear_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "gae_linear_bwd": (_int, [_p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _i64, _i64,
+                              _p, _p, _p, _i64, _p, _i64, _p]),
+    "gae_dropout_mask": (_int, [_p, _i64, _f, _u64, _u64, _p]),
+    "gae_decoder_dense": (_int, [_p, _p, _i64, _i64, _i64, _p, _i64, _p]),
+    "gae_decoder_dense_bwd_workspace_bytes": (_i64, [_i64, _i64]),
+    "gae_decoder_dense_bwd": (_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),
+}
+
+_lib = None
+
+
+class GaeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgae_hip.so (once).  Raises GaeHipError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GaeHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(gae_dgl_amd has no CPU / PyTorch fallback)")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise GaeHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gae_last_error().decode(errors="replace")
+        kind = "argument error" if rc < 0 else "hipError_t"
+        raise GaeHipError(f"{what} failed ({kind} {rc}): {msg}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

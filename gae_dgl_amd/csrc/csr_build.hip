@@ -1,0 +1,263 @@
+// Graph-structure kernels: COO -> CSR, degrees / norm, dense adjacency (debug),
+// block-diagonal batch gather from a device-resident dataset CSR.
+//
+// Replaces the DGL graph index the reference builds with DGLGraph.add_edges /
+// dgl.batch and traverses in g.update_all (gae_dgl/gae.py:28,
+// gae_dgl/train_inductive.py:31-35,44; gae_dgl/train_transductive.py:55-59).
+// Integer work only: results are exact and order-deterministic.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace {
+
+using gae::kWave;
+
+__host__ __device__ inline int bits_for(int64_t n)
+{
+    int b = 1;
+    while ((int64_t(1) << b) < n) ++b;
+    return b;
+}
+
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// key = row << col_bits | col ; out-of-range ids are clamped and flagged
+__global__ __launch_bounds__(256) void pack_keys_kernel(const int64_t *__restrict__ row,
+                                                        const int64_t *__restrict__ col, int64_t n_edges,
+                                                        int64_t n_rows, int64_t n_cols, int col_bits,
+                                                        uint64_t *__restrict__ keys, int32_t *status)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    bool bad = false;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n_edges; e += stride) {
+        int64_t r = row[e], c = col[e];
+        if (r < 0 || r >= n_rows) { bad = true; r = r < 0 ? 0 : n_rows - 1; }
+        if (c < 0 || c >= n_cols) { bad = true; c = c < 0 ? 0 : n_cols - 1; }
+        keys[e] = (uint64_t(r) << col_bits) | uint64_t(c);
+    }
+    if (bad && status) atomicExch(status, 1);
+}
+
+// sorted keys -> indices (low bits) and indptr (first position of every row;
+// empty rows inherit the next row's start).  One thread per edge + one extra
+// sweep for the tail rows.
+__global__ __launch_bounds__(256) void unpack_fill_kernel(const uint64_t *__restrict__ keys, int64_t n_edges,
+                                                          int64_t n_rows, int col_bits,
+                                                          int32_t *__restrict__ indptr,
+                                                          int32_t *__restrict__ indices)
+{
+    const uint64_t cmask = (uint64_t(1) << col_bits) - 1;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const int64_t t0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    for (int64_t e = t0; e < n_edges; e += stride) {
+        const uint64_t k = keys[e];
+        indices[e] = int32_t(k & cmask);
+        const int64_t r = int64_t(k >> col_bits);
+        const int64_t rp = e == 0 ? -1 : int64_t(keys[e - 1] >> col_bits);
+        for (int64_t q = rp + 1; q <= r; ++q) indptr[q] = int32_t(e);
+    }
+    // rows after the last non-empty row (and indptr[n_rows]) = n_edges
+    const int64_t last = n_edges == 0 ? -1 : int64_t(keys[n_edges - 1] >> col_bits);
+    for (int64_t q = last + 1 + t0; q <= n_rows; q += stride) indptr[q] = int32_t(n_edges);
+}
+
+__global__ __launch_bounds__(256) void degree_norm_kernel(const int32_t *__restrict__ indptr, int64_t n,
+                                                          int32_t *__restrict__ deg, float *__restrict__ norm)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; v < n; v += stride) {
+        const int32_t d = indptr[v + 1] - indptr[v];
+        if (deg) deg[v] = d;
+        // train_transductive.py:56-57: pow(deg, -0.5), inf -> 0
+        if (norm) norm[v] = d > 0 ? 1.0f / sqrtf(float(d)) : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void zero2d_kernel(float *__restrict__ out, int64_t n_rows, int64_t n_cols,
+                                                     int64_t ld)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const int64_t total = n_rows * n_cols;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride)
+        out[(i / n_cols) * ld + (i % n_cols)] = 0.f;
+}
+
+// one wave per row; counts are small integers so the float atomics are exact
+__global__ __launch_bounds__(256) void csr_to_dense_kernel(const int32_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices, int64_t n_rows,
+                                                           float *__restrict__ out, int64_t ld)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
+    const int64_t nwaves = int64_t(gridDim.x) * blockDim.x / kWave;
+    for (int64_t r = wave; r < n_rows; r += nwaves)
+        for (int32_t e = indptr[r] + lane; e < indptr[r + 1]; e += kWave)
+            atomicAdd(&out[r * ld + indices[e]], 1.0f);
+}
+
+// One wave per selected graph: rebase its indptr slice, its column ids and copy
+// its feature rows into the batch (block-diagonal) arrays.
+template <typename T>
+__global__ __launch_bounds__(256) void batch_gather_kernel(
+    const int64_t *__restrict__ graph_ptr, const int32_t *__restrict__ ds_indptr,
+    const int32_t *__restrict__ ds_indices, const T *__restrict__ ds_feat, int64_t ld_feat, int64_t F,
+    const int64_t *__restrict__ graph_ids, int64_t n_graphs, const int64_t *__restrict__ out_node_ptr,
+    const int64_t *__restrict__ out_edge_ptr, int32_t *__restrict__ out_indptr,
+    int32_t *__restrict__ out_indices, T *__restrict__ out_feat, int64_t ld_out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t b = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
+    if (b >= n_graphs) return;
+    const int64_t g = graph_ids[b];
+    const int64_t n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
+    const int64_t on = out_node_ptr[b], oe = out_edge_ptr[b];
+    const int32_t e0 = ds_indptr[n0], e1 = ds_indptr[n1];
+    const int64_t nn = n1 - n0;
+    for (int64_t i = lane; i < nn; i += kWave)
+        out_indptr[on + i] = int32_t(ds_indptr[n0 + i] - e0 + oe);
+    if (b == n_graphs - 1 && lane == 0) out_indptr[on + nn] = int32_t(oe + (e1 - e0));
+    const int64_t shift = on - n0;
+    for (int32_t e = e0 + lane; e < e1; e += kWave)
+        out_indices[oe + (e - e0)] = int32_t(ds_indices[e] + shift);
+    const int64_t total = nn * F;
+    for (int64_t i = lane; i < total; i += kWave) {
+        const int64_t r = i / F, c = i - r * F;
+        out_feat[(on + r) * ld_out + c] = ds_feat[(n0 + r) * ld_feat + c];
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256, int cap = 256 * 8)
+{
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return int(g);
+}
+
+size_t sort_temp_bytes(int64_t n_edges, int end_bit)
+{
+    size_t bytes = 0;
+    uint64_t *nul = nullptr;
+    (void)rocprim::radix_sort_keys(nullptr, bytes, nul, nul, size_t(n_edges), 0u, unsigned(end_bit),
+                                   hipStream_t(0));
+    return bytes;
+}
+
+} // namespace
+
+extern "C" int64_t gae_csr_from_coo_workspace_bytes(int64_t n_edges, int64_t n_rows)
+{
+    if (n_edges < 0 || n_rows < 0) return GAE_E_SIZE;
+    (void)n_rows;
+    const int64_t keys = align_up(n_edges * 8, 256);
+    // temp size depends (weakly) on the bit range; query with the widest one
+    return 2 * keys + align_up(int64_t(sort_temp_bytes(n_edges > 0 ? n_edges : 1, 64)), 256) + 256;
+}
+
+extern "C" int gae_csr_from_coo(const int64_t *row, const int64_t *col, int64_t n_edges, int64_t n_rows,
+                                int64_t n_cols, int32_t *indptr, int32_t *indices, void *workspace,
+                                int64_t workspace_bytes, int32_t *status_dev, void *stream)
+{
+    GAE_REQUIRE(n_edges >= 0 && n_rows >= 0 && n_cols >= 0, GAE_E_SIZE, "gae_csr_from_coo: negative size");
+    GAE_REQUIRE(n_edges < (int64_t(1) << 31) && n_rows < (int64_t(1) << 31) - 1 && n_cols < (int64_t(1) << 31),
+                GAE_E_SIZE, "gae_csr_from_coo: int32 CSR supports < 2^31 edges/rows/cols");
+    GAE_REQUIRE(indptr != nullptr, GAE_E_NULL, "gae_csr_from_coo: indptr is NULL");
+    GAE_REQUIRE(n_edges == 0 || (row && col && indices && workspace), GAE_E_NULL,
+                "gae_csr_from_coo: NULL pointer with n_edges > 0");
+    GAE_REQUIRE(n_edges == 0 || (n_rows > 0 && n_cols > 0), GAE_E_SIZE,
+                "gae_csr_from_coo: edges given for an empty graph");
+    hipStream_t s = gae::as_stream(stream);
+    if (n_edges == 0) {
+        hipLaunchKernelGGL(unpack_fill_kernel, dim3(grid_for(n_rows + 1)), dim3(256), 0, s, nullptr, int64_t(0),
+                           n_rows, 1, indptr, indices);
+        GAE_CHECK_LAUNCH("unpack_fill_kernel");
+        return GAE_OK;
+    }
+    const int col_bits = bits_for(n_cols);
+    const int end_bit = col_bits + bits_for(n_rows);
+    const int64_t keys_bytes = align_up(n_edges * 8, 256);
+    size_t temp_bytes = sort_temp_bytes(n_edges, end_bit);
+    GAE_REQUIRE(workspace_bytes >= 2 * keys_bytes + int64_t(temp_bytes), GAE_E_WORKSPACE,
+                "gae_csr_from_coo: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                (long long)(2 * keys_bytes + int64_t(temp_bytes)));
+    GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_csr_from_coo: workspace not 16-byte aligned");
+    char *ws = static_cast<char *>(workspace);
+    uint64_t *keys_a = reinterpret_cast<uint64_t *>(ws);
+    uint64_t *keys_b = reinterpret_cast<uint64_t *>(ws + keys_bytes);
+    void *temp = ws + 2 * keys_bytes;
+    hipLaunchKernelGGL(pack_keys_kernel, dim3(grid_for(n_edges)), dim3(256), 0, s, row, col, n_edges, n_rows,
+                       n_cols, col_bits, keys_a, status_dev);
+    GAE_CHECK_LAUNCH("pack_keys_kernel");
+    GAE_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys_a, keys_b, size_t(n_edges), 0u, unsigned(end_bit), s));
+    hipLaunchKernelGGL(unpack_fill_kernel, dim3(grid_for(n_edges)), dim3(256), 0, s, keys_b, n_edges, n_rows,
+                       col_bits, indptr, indices);
+    GAE_CHECK_LAUNCH("unpack_fill_kernel");
+    return GAE_OK;
+}
+
+extern "C" int gae_degree_norm(const int32_t *indptr, int64_t n_rows, int32_t *deg_out, float *norm_out,
+                               void *stream)
+{
+    GAE_REQUIRE(n_rows >= 0, GAE_E_SIZE, "gae_degree_norm: negative n_rows");
+    GAE_REQUIRE(indptr != nullptr, GAE_E_NULL, "gae_degree_norm: indptr is NULL");
+    if (n_rows == 0 || (!deg_out && !norm_out)) return GAE_OK;
+    hipLaunchKernelGGL(degree_norm_kernel, dim3(grid_for(n_rows)), dim3(256), 0, gae::as_stream(stream), indptr,
+                       n_rows, deg_out, norm_out);
+    GAE_CHECK_LAUNCH("degree_norm_kernel");
+    return GAE_OK;
+}
+
+extern "C" int gae_csr_to_dense(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                                float *out, int64_t ld, void *stream)
+{
+    GAE_REQUIRE(n_rows >= 0 && n_cols >= 0 && ld >= n_cols, GAE_E_SIZE, "gae_csr_to_dense: bad sizes");
+    if (n_rows == 0 || n_cols == 0) return GAE_OK;
+    GAE_REQUIRE(indptr && out, GAE_E_NULL, "gae_csr_to_dense: NULL pointer");
+    hipStream_t s = gae::as_stream(stream);
+    hipLaunchKernelGGL(zero2d_kernel, dim3(grid_for(n_rows * n_cols)), dim3(256), 0, s, out, n_rows, n_cols, ld);
+    GAE_CHECK_LAUNCH("zero2d_kernel");
+    hipLaunchKernelGGL(csr_to_dense_kernel, dim3(grid_for(n_rows * kWave)), dim3(256), 0, s, indptr, indices,
+                       n_rows, out, ld);
+    GAE_CHECK_LAUNCH("csr_to_dense_kernel");
+    return GAE_OK;
+}
+
+extern "C" int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_indices,
+                                const void *ds_feat, int64_t ld_feat, int64_t F, int dtype,
+                                const int64_t *graph_ids, int64_t n_graphs, const int64_t *out_node_ptr,
+                                const int64_t *out_edge_ptr, int64_t n_batch_nodes, int64_t n_batch_edges,
+                                int32_t *out_indptr, int32_t *out_indices, void *out_feat, int64_t ld_out,
+                                void *stream)
+{
+    GAE_REQUIRE(n_graphs >= 0 && F >= 0 && n_batch_nodes >= 0 && n_batch_edges >= 0, GAE_E_SIZE,
+                "gae_batch_gather: negative size");
+    GAE_REQUIRE(ld_feat >= F && ld_out >= F, GAE_E_SIZE, "gae_batch_gather: leading dimension < F");
+    GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16, GAE_E_DTYPE, "gae_batch_gather: dtype %d", dtype);
+    GAE_REQUIRE(out_indptr != nullptr, GAE_E_NULL, "gae_batch_gather: out_indptr is NULL");
+    hipStream_t s = gae::as_stream(stream);
+    if (n_graphs == 0) {
+        GAE_HIP(hipMemsetAsync(out_indptr, 0, sizeof(int32_t), s));
+        return GAE_OK;
+    }
+    GAE_REQUIRE(graph_ptr && ds_indptr && graph_ids && out_node_ptr && out_edge_ptr, GAE_E_NULL,
+                "gae_batch_gather: NULL pointer");
+    GAE_REQUIRE(n_batch_edges == 0 || (ds_indices && out_indices), GAE_E_NULL,
+                "gae_batch_gather: NULL index pointer");
+    GAE_REQUIRE(F == 0 || n_batch_nodes == 0 || (ds_feat && out_feat), GAE_E_NULL,
+                "gae_batch_gather: NULL feature pointer");
+    const int64_t blocks = (n_graphs * kWave + 255) / 256;
+    if (dtype == GAE_F32)
+        hipLaunchKernelGGL(batch_gather_kernel<float>, dim3(unsigned(blocks)), dim3(256), 0, s, graph_ptr,
+                           ds_indptr, ds_indices, static_cast<const float *>(ds_feat), ld_feat, F, graph_ids,
+                           n_graphs, out_node_ptr, out_edge_ptr, out_indptr, out_indices,
+                           static_cast<float *>(out_feat), ld_out);
+    else
+        hipLaunchKernelGGL(batch_gather_kernel<unsigned short>, dim3(unsigned(blocks)), dim3(256), 0, s,
+                           graph_ptr, ds_indptr, ds_indices, static_cast<const unsigned short *>(ds_feat),
+                           ld_feat, F, graph_ids, n_graphs, out_node_ptr, out_edge_ptr, out_indptr, out_indices,
+                           static_cast<unsigned short *>(out_feat), ld_out);
+    GAE_CHECK_LAUNCH("batch_gather_kernel");
+    return GAE_OK;
+}

@@ -1,0 +1,532 @@
+// Dense contractions of the hot path on the fp32 matrix cores of gfx950.
+//
+//   K3/K5  Y  = act(M W^T + b)        NodeApplyModule.forward  gae_dgl/gae.py:13-16
+//   K4     dW = dYm^T M, db, dM = dYm W   (autograd of the above)
+//   K6     inverted-dropout mask         InnerProductDecoder    gae_dgl/gae.py:70
+//   K7     logits = Zt Zt^T              InnerProductDecoder    gae_dgl/gae.py:71
+//          dZ = ((G + G^T) Zt) (.) mask  (its autograd, dense parity path)
+//
+// All products use v_mfma_f32_32x32x2_f32: f32 in / f32 accumulate, exact f32
+// (bitwise a k-ordered fmaf chain), which keeps the 1e-5 parity budget.
+// Operand map of the instruction (wave64, lane l):
+//   A[i = l & 31][k = l >> 5],  B[k = l >> 5][j = l & 31],
+//   D reg r -> row (r & 3) + 8 (r >> 2) + 4 (l >> 5), col l & 31.
+#include "common.h"
+
+namespace {
+
+using gae::kWave;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
+
+// ---------------------------------------------------------------------------
+// out[n, J] = epi( proA(A)[n, K] * proB(B) )      B given as [J, K] (BT) or [K, J]
+// Block = 4 waves, 128 rows x (NT * 32) columns, K staged through LDS in tiles
+// of 32 (row stride 33 floats: conflict-free ds_read_b32 fragment reads).
+// ---------------------------------------------------------------------------
+constexpr int BM = 128, KT = 32, LDS_LD = KT + 1;
+
+template <int NT, bool BT, int PRO_A, bool MASK_B, bool VEC_A>
+__global__ __launch_bounds__(256) void gemm_kernel(
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ Amask, int64_t ldam,
+    const float *__restrict__ B, int64_t ldb, const float *__restrict__ Bmask, int64_t ldbm,
+    const float *__restrict__ bias, int act, float *__restrict__ out, int64_t ldo, int64_t n, int K, int64_t J)
+{
+    __shared__ float As[BM * LDS_LD];
+    __shared__ float Bs[NT * 32 * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row0 = int64_t(blockIdx.x) * BM;
+    const int64_t col0 = int64_t(blockIdx.y) * (NT * 32);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += KT) {
+        // ---- stage A tile [128][32]
+        if (VEC_A) {
+            const int c4 = (tid & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (tid >> 3) + 32 * i;
+                const int64_t gr = row0 + r;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (gr < n) {
+                    const int k = k0 + c4;
+                    if (k + 4 <= K) {
+                        const float4 t = *reinterpret_cast<const float4 *>(A + gr * lda + k);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                        if (PRO_A != PRO_NONE) {
+                            const float4 m = *reinterpret_cast<const float4 *>(Amask + gr * ldam + k);
+                            if (PRO_A == PRO_RELU_MASK) {
+                                v[0] = m.x > 0.f ? v[0] : 0.f; v[1] = m.y > 0.f ? v[1] : 0.f;
+                                v[2] = m.z > 0.f ? v[2] : 0.f; v[3] = m.w > 0.f ? v[3] : 0.f;
+                            } else {
+                                v[0] *= m.x; v[1] *= m.y; v[2] *= m.z; v[3] *= m.w;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (k + q < K) {
+                                float a = A[gr * lda + k + q];
+                                if (PRO_A == PRO_RELU_MASK) a = Amask[gr * ldam + k + q] > 0.f ? a : 0.f;
+                                if (PRO_A == PRO_MUL_MASK) a *= Amask[gr * ldam + k + q];
+                                v[q] = a;
+                            }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) As[r * LDS_LD + c4 + q] = v[q];
+            }
+        } else {
+            const int c = tid & 31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (tid >> 5) + 8 * i;
+                const int64_t gr = row0 + r;
+                float a = 0.f;
+                if (gr < n && k0 + c < K) {
+                    a = A[gr * lda + k0 + c];
+                    if (PRO_A == PRO_RELU_MASK) a = Amask[gr * ldam + k0 + c] > 0.f ? a : 0.f;
+                    if (PRO_A == PRO_MUL_MASK) a *= Amask[gr * ldam + k0 + c];
+                }
+                As[r * LDS_LD + c] = a;
+            }
+        }
+        // ---- stage B tile as Bs[j][k]
+        if (BT) {
+            const int c = tid & 31;
+#pragma unroll
+            for (int i = 0; i < NT * 4; ++i) {
+                const int j = (tid >> 5) + 8 * i;
+                const int64_t gj = col0 + j;
+                float b = 0.f;
+                if (gj < J && k0 + c < K) {
+                    b = B[gj * ldb + k0 + c];
+                    if (MASK_B) b *= Bmask[gj * ldbm + k0 + c];
+                }
+                Bs[j * LDS_LD + c] = b;
+            }
+        } else {
+            // B[k][j]: consecutive lanes read consecutive j (coalesced), write transposed
+            constexpr int JW = NT * 32;
+#pragma unroll
+            for (int i = 0; i < (JW * KT) / 256; ++i) {
+                const int idx = tid + 256 * i;
+                const int j = idx % JW, k = idx / JW;
+                const int64_t gj = col0 + j;
+                float b = 0.f;
+                if (gj < J && k0 + k < K) {
+                    b = B[int64_t(k0 + k) * ldb + gj];
+                    if (MASK_B) b *= Bmask[int64_t(k0 + k) * ldbm + gj];
+                }
+                Bs[j * LDS_LD + k] = b;
+            }
+        }
+        __syncthreads();
+        const float *ap = As + (wave * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
+        const float *bp = Bs + (lane & 31) * LDS_LD + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < KT / 2; ++kk) {
+            const float a = ap[2 * kk];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float b = bp[t * 32 * LDS_LD + 2 * kk];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int64_t col = col0 + t * 32 + (lane & 31);
+        if (col >= J) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < n) {
+                float y = acc[t][r] + bv;
+                if (act == GAE_ACT_RELU) y = y > 0.f ? y : 0.f;
+                out[row * ldo + col] = y;
+            }
+        }
+    }
+}
+
+template <int NT, bool BT, int PRO_A, bool MASK_B>
+int launch_gemm(const float *A, int64_t lda, const float *Amask, int64_t ldam, const float *B, int64_t ldb,
+                const float *Bmask, int64_t ldbm, const float *bias, int act, float *out, int64_t ldo, int64_t n,
+                int K, int64_t J, hipStream_t s)
+{
+    const dim3 grid(unsigned((n + BM - 1) / BM), unsigned((J + NT * 32 - 1) / (NT * 32)));
+    bool vec = (lda % 4 == 0) && gae::aligned16(A);
+    if (PRO_A != PRO_NONE) vec = vec && (ldam % 4 == 0) && gae::aligned16(Amask);
+    if (vec)
+        hipLaunchKernelGGL((gemm_kernel<NT, BT, PRO_A, MASK_B, true>), grid, dim3(256), 0, s, A, lda, Amask, ldam, B,
+                           ldb, Bmask, ldbm, bias, act, out, ldo, n, K, J);
+    else
+        hipLaunchKernelGGL((gemm_kernel<NT, BT, PRO_A, MASK_B, false>), grid, dim3(256), 0, s, A, lda, Amask, ldam,
+                           B, ldb, Bmask, ldbm, bias, act, out, ldo, n, K, J);
+    GAE_CHECK_LAUNCH("gemm_kernel");
+    return GAE_OK;
+}
+
+template <bool BT, int PRO_A, bool MASK_B>
+int dispatch_gemm(const float *A, int64_t lda, const float *Amask, int64_t ldam, const float *B, int64_t ldb,
+                  const float *Bmask, int64_t ldbm, const float *bias, int act, float *out, int64_t ldo, int64_t n,
+                  int K, int64_t J, hipStream_t s)
+{
+    if (J <= 32)
+        return launch_gemm<1, BT, PRO_A, MASK_B>(A, lda, Amask, ldam, B, ldb, Bmask, ldbm, bias, act, out, ldo, n, K, J, s);
+    if (J <= 64)
+        return launch_gemm<2, BT, PRO_A, MASK_B>(A, lda, Amask, ldam, B, ldb, Bmask, ldbm, bias, act, out, ldo, n, K, J, s);
+    return launch_gemm<4, BT, PRO_A, MASK_B>(A, lda, Amask, ldam, B, ldb, Bmask, ldbm, bias, act, out, ldo, n, K, J, s);
+}
+
+// ---------------------------------------------------------------------------
+// out[O, I] (+)= sum_r proP(P)[r, O]^T Q[r, I]   -- reduction over rows.
+// Both operands are read in their natural row-major layout straight into the
+// MFMA fragments (lane = column, k = row parity): no LDS.  Each wave owns a row
+// slot and one 32 x (IT*32) output tile and writes a partial; a second kernel
+// sums the partials in slot order (deterministic, no float atomics).
+// ---------------------------------------------------------------------------
+template <int IT, int PRO_P>
+__global__ __launch_bounds__(256) void atb_partial_kernel(
+    const float *__restrict__ P, int64_t ldp, const float *__restrict__ Pmask, int64_t ldpm,
+    const float *__restrict__ Q, int64_t ldq, int64_t n, int O, int I, int64_t rows_per_slot,
+    float *__restrict__ partial, float *__restrict__ colsum_partial)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t slot = int64_t(blockIdx.x) * 4 + wave;
+    const int o = blockIdx.z * 32 + (lane & 31);
+    const int i0 = blockIdx.y * (IT * 32);
+    const int h = lane >> 5;
+    const int64_t r_begin = slot * rows_per_slot;
+    int64_t r_end = r_begin + rows_per_slot;
+    if (r_end > n) r_end = n;
+
+    f32x16 acc[IT];
+#pragma unroll
+    for (int t = 0; t < IT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float csum = 0.f;
+
+    for (int64_t r = r_begin + h; r < r_end + h; r += 2) {
+        const bool rv = r < r_end;  // rows_per_slot is even; the odd tail lane contributes 0
+        float a = 0.f;
+        if (rv && o < O) {
+            a = P[r * ldp + o];
+            if (PRO_P == PRO_RELU_MASK) a = Pmask[r * ldpm + o] > 0.f ? a : 0.f;
+            if (PRO_P == PRO_MUL_MASK) a *= Pmask[r * ldpm + o];
+        }
+        csum += a;
+#pragma unroll
+        for (int t = 0; t < IT; ++t) {
+            const int i = i0 + t * 32 + (lane & 31);
+            const float b = (rv && i < I) ? Q[r * ldq + i] : 0.f;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    // partial[slot][O][I]
+    float *pp = partial + slot * int64_t(O) * I;
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+        const int i = i0 + t * 32 + (lane & 31);
+        if (i >= I) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oo = blockIdx.z * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (oo < O) pp[int64_t(oo) * I + i] = acc[t][r];
+        }
+    }
+    if (colsum_partial && blockIdx.y == 0) {
+        csum += __shfl_down(csum, 32, 64);
+        if (h == 0 && o < O) colsum_partial[slot * O + o] = csum;
+    }
+}
+
+// out[e] = sum_slot partial[slot][e]  (+ optional accumulate into out, optional mask multiply)
+__global__ __launch_bounds__(256) void reduce_slots_kernel(const float *__restrict__ partial, int64_t n_slots,
+                                                           int64_t n_elems, float *__restrict__ out,
+                                                           int64_t out_cols, int64_t ldo, int accumulate,
+                                                           const float *__restrict__ mulmask, int64_t ldmask)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
+        float s = 0.f;
+        for (int64_t k = 0; k < n_slots; ++k) s += partial[k * n_elems + e];
+        const int64_t r = e / out_cols, c = e - r * out_cols;
+        float *op = out + r * ldo + c;
+        if (accumulate) s += *op;
+        if (mulmask) s *= mulmask[r * ldmask + c];
+        *op = s;
+    }
+}
+
+// dst[i, k] = (dst[i, k] + sum_slot partial[slot][k][i]) * mask[i, k]   (partial is [slots][d][n])
+__global__ __launch_bounds__(256) void reduce_slots_transposed_kernel(const float *__restrict__ partial,
+                                                                      int64_t n_slots, int64_t d, int64_t n,
+                                                                      float *__restrict__ dst, int64_t ldd,
+                                                                      const float *__restrict__ mask, int64_t ldmask)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const int64_t total = n * d;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t k = e / n, i = e - k * n;  // consecutive threads -> consecutive i (coalesced partial reads)
+        float s = 0.f;
+        for (int64_t q = 0; q < n_slots; ++q) s += partial[q * total + e];
+        float v = dst[i * ldd + k] + s;
+        if (mask) v *= mask[i * ldmask + k];
+        dst[i * ldd + k] = v;
+    }
+}
+
+struct AtbPlan {
+    int64_t n_slots, rows_per_slot, blocks;
+};
+
+// shared by the workspace query and the launcher
+AtbPlan atb_plan(int64_t n, int64_t O, int64_t I)
+{
+    AtbPlan p;
+    int64_t want = (n + 255) / 256;                  // ~256 rows per wave
+    int64_t cap = (int64_t(32) << 20) / (O * I > 0 ? O * I : 1);  // <= 128 MiB of partials
+    if (cap > 2048) cap = 2048;
+    if (cap < 4) cap = 4;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    p.blocks = (want + 3) / 4;
+    p.n_slots = p.blocks * 4;
+    int64_t rps = (n + p.n_slots - 1) / p.n_slots;
+    rps += rps & 1;
+    if (rps < 2) rps = 2;
+    p.rows_per_slot = rps;
+    return p;
+}
+
+template <int PRO_P>
+int launch_atb(const float *P, int64_t ldp, const float *Pmask, int64_t ldpm, const float *Q, int64_t ldq,
+               int64_t n, int O, int I, float *partial, float *colsum_partial, const AtbPlan &pl, hipStream_t s)
+{
+    constexpr int IT = 4;
+    const unsigned gy = I > 0 ? unsigned((I + IT * 32 - 1) / (IT * 32)) : 1u;  // I == 0: column sums only
+    const dim3 grid(unsigned(pl.blocks), gy, unsigned((O + 31) / 32));
+    hipLaunchKernelGGL((atb_partial_kernel<IT, PRO_P>), grid, dim3(256), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n, O, I,
+                       pl.rows_per_slot, partial, colsum_partial);
+    GAE_CHECK_LAUNCH("atb_partial_kernel");
+    return GAE_OK;
+}
+
+int launch_reduce(const float *partial, int64_t n_slots, int64_t n_elems, float *out, int64_t out_cols, int64_t ldo,
+                  int accumulate, const float *mulmask, int64_t ldmask, hipStream_t s)
+{
+    int64_t g = (n_elems + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(reduce_slots_kernel, dim3(unsigned(g)), dim3(256), 0, s, partial, n_slots, n_elems, out,
+                       out_cols, ldo, accumulate, mulmask, ldmask);
+    GAE_CHECK_LAUNCH("reduce_slots_kernel");
+    return GAE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 counter RNG -> inverted dropout multiplier
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+    const uint64_t p0 = uint64_t(0xD2511F53u) * c[0];
+    const uint64_t p1 = uint64_t(0xCD9E8D57u) * c[2];
+    const uint32_t n0 = uint32_t(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n2 = uint32_t(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = uint32_t(p1); c[3] = uint32_t(p0); c[0] = n0; c[2] = n2;
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float *__restrict__ mask, int64_t n, float p, float scale,
+                                                           uint64_t seed, uint64_t offset)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const int64_t nquad = (n + 3) / 4;
+    for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < nquad; q += stride) {
+        const uint64_t ctr = offset + uint64_t(q);
+        uint32_t c[4] = {uint32_t(ctr), uint32_t(ctr >> 32), 0u, 0u};
+        uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t e = q * 4 + i;
+            if (e < n) {
+                const float u = float(c[i] >> 8) * (1.0f / 16777216.0f);  // [0,1)
+                mask[e] = u >= p ? scale : 0.f;
+            }
+        }
+    }
+}
+
+} // namespace
+
+// ===========================================================================
+extern "C" int gae_linear_fwd(const float *M, int64_t ldm, int64_t n, int64_t f_in, const float *W, const float *b,
+                              int64_t f_out, int act, float *Y, int64_t ldy, void *stream)
+{
+    GAE_REQUIRE(n >= 0 && f_in >= 0 && f_out >= 0, GAE_E_SIZE, "gae_linear_fwd: negative size");
+    GAE_REQUIRE(f_in < (1 << 24) && f_out < (1 << 24), GAE_E_SIZE, "gae_linear_fwd: feature width too large");
+    GAE_REQUIRE(ldm >= f_in && ldy >= f_out, GAE_E_SIZE, "gae_linear_fwd: leading dimension too small");
+    GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_DTYPE, "gae_linear_fwd: activation %d", act);
+    if (n == 0 || f_out == 0) return GAE_OK;
+    GAE_REQUIRE(Y && (f_in == 0 || (M && W)), GAE_E_NULL, "gae_linear_fwd: NULL pointer");
+    return dispatch_gemm<true, PRO_NONE, false>(M, ldm, nullptr, 0, W, f_in, nullptr, 0, b, act, Y, ldy, n, int(f_in),
+                                                f_out, gae::as_stream(stream));
+}
+
+static int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+
+extern "C" int64_t gae_linear_bwd_workspace_bytes(int64_t n, int64_t f_in, int64_t f_out)
+{
+    if (n < 0 || f_in < 0 || f_out < 0) return GAE_E_SIZE;
+    const AtbPlan pl = atb_plan(n, f_out, f_in);
+    return align256(pl.n_slots * f_out * f_in * 4) + align256(pl.n_slots * f_out * 4) + 256;
+}
+
+extern "C" int gae_linear_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, int act, const float *M,
+                              int64_t ldm, const float *W, int64_t n, int64_t f_in, int64_t f_out, float *dW,
+                              float *db, float *dM, int64_t lddm, void *workspace, int64_t workspace_bytes,
+                              void *stream)
+{
+    GAE_REQUIRE(n >= 0 && f_in >= 0 && f_out >= 0, GAE_E_SIZE, "gae_linear_bwd: negative size");
+    GAE_REQUIRE(f_in < (1 << 24) && f_out < (1 << 24), GAE_E_SIZE, "gae_linear_bwd: feature width too large");
+    GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_DTYPE, "gae_linear_bwd: activation %d", act);
+    GAE_REQUIRE(lddy >= f_out, GAE_E_SIZE, "gae_linear_bwd: lddy < f_out");
+    GAE_REQUIRE(act != GAE_ACT_RELU || (Y && ldy >= f_out), GAE_E_NULL, "gae_linear_bwd: RELU needs Y");
+    hipStream_t s = gae::as_stream(stream);
+    if (f_out == 0 || (f_in == 0 && !db)) return GAE_OK;
+    GAE_REQUIRE(n == 0 || dY, GAE_E_NULL, "gae_linear_bwd: dY is NULL");
+    const bool relu = act == GAE_ACT_RELU;
+    if (dW || db) {
+        GAE_REQUIRE(!dW || (ldm >= f_in && (n == 0 || M)), GAE_E_NULL, "gae_linear_bwd: dW needs M");
+        const AtbPlan pl = atb_plan(n, f_out, f_in);
+        const int64_t need = align256(pl.n_slots * f_out * f_in * 4) + align256(pl.n_slots * f_out * 4);
+        GAE_REQUIRE(workspace && workspace_bytes >= need, GAE_E_WORKSPACE,
+                    "gae_linear_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+        float *partial = static_cast<float *>(workspace);
+        float *cpartial = reinterpret_cast<float *>(static_cast<char *>(workspace) +
+                                                    align256(pl.n_slots * f_out * f_in * 4));
+        // dW = dYm^T M : P = dY [n, f_out] (O = f_out), Q = M [n, f_in] (I = f_in)
+        const float *Q = dW ? M : dY;  // db only: any readable Q, I = 0 tiles skipped
+        const int I = dW ? int(f_in) : 0;
+        int rc;
+        if (I == 0) {
+            // column sums only: run with a single (masked-out) tile
+            rc = relu ? launch_atb<PRO_RELU_MASK>(dY, lddy, Y, ldy, Q, lddy, n, int(f_out), 0, partial, cpartial, pl, s)
+                      : launch_atb<PRO_NONE>(dY, lddy, nullptr, 0, Q, lddy, n, int(f_out), 0, partial, cpartial, pl, s);
+        } else {
+            rc = relu ? launch_atb<PRO_RELU_MASK>(dY, lddy, Y, ldy, Q, ldm, n, int(f_out), I, partial, db ? cpartial : nullptr, pl, s)
+                      : launch_atb<PRO_NONE>(dY, lddy, nullptr, 0, Q, ldm, n, int(f_out), I, partial, db ? cpartial : nullptr, pl, s);
+        }
+        if (rc) return rc;
+        if (dW) {
+            rc = launch_reduce(partial, pl.n_slots, f_out * f_in, dW, f_in, f_in, 0, nullptr, 0, s);
+            if (rc) return rc;
+        }
+        if (db) {
+            rc = launch_reduce(cpartial, pl.n_slots, f_out, db, f_out, f_out, 0, nullptr, 0, s);
+            if (rc) return rc;
+        }
+    }
+    if (dM && n > 0) {
+        GAE_REQUIRE(lddm >= f_in && W, GAE_E_NULL, "gae_linear_bwd: dM needs W and lddm >= f_in");
+        // dM[n, f_in] = dYm[n, f_out] * W[f_out, f_in]   (B given as [K, J])
+        if (relu)
+            return dispatch_gemm<false, PRO_RELU_MASK, false>(dY, lddy, Y, ldy, W, f_in, nullptr, 0, nullptr,
+                                                              GAE_ACT_IDENTITY, dM, lddm, n, int(f_out), f_in, s);
+        return dispatch_gemm<false, PRO_NONE, false>(dY, lddy, nullptr, 0, W, f_in, nullptr, 0, nullptr,
+                                                     GAE_ACT_IDENTITY, dM, lddm, n, int(f_out), f_in, s);
+    }
+    return GAE_OK;
+}
+
+extern "C" int gae_dropout_mask(float *mask, int64_t n_elems, float p, uint64_t seed, uint64_t offset, void *stream)
+{
+    GAE_REQUIRE(n_elems >= 0, GAE_E_SIZE, "gae_dropout_mask: negative size");
+    GAE_REQUIRE(p >= 0.f && p < 1.f, GAE_E_RANGE, "gae_dropout_mask: p = %g outside [0, 1)", double(p));
+    if (n_elems == 0) return GAE_OK;
+    GAE_REQUIRE(mask, GAE_E_NULL, "gae_dropout_mask: mask is NULL");
+    int64_t g = ((n_elems + 3) / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(unsigned(g)), dim3(256), 0, gae::as_stream(stream), mask, n_elems, p,
+                       1.0f / (1.0f - p), seed, offset);
+    GAE_CHECK_LAUNCH("dropout_mask_kernel");
+    return GAE_OK;
+}
+
+extern "C" int gae_decoder_dense(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d, float *out,
+                                 int64_t ldo, void *stream)
+{
+    GAE_REQUIRE(n >= 0 && d >= 0, GAE_E_SIZE, "gae_decoder_dense: negative size");
+    GAE_REQUIRE(d < (1 << 24), GAE_E_SIZE, "gae_decoder_dense: d too large");
+    GAE_REQUIRE(ldz >= d && ldo >= n, GAE_E_SIZE, "gae_decoder_dense: leading dimension too small");
+    if (n == 0) return GAE_OK;
+    GAE_REQUIRE(out && (d == 0 || Z), GAE_E_NULL, "gae_decoder_dense: NULL pointer");
+    hipStream_t s = gae::as_stream(stream);
+    if (mask)
+        return launch_gemm<4, true, PRO_MUL_MASK, true>(Z, ldz, mask, ldz, Z, ldz, mask, ldz, nullptr,
+                                                        GAE_ACT_IDENTITY, out, ldo, n, int(d), n, s);
+    return launch_gemm<4, true, PRO_NONE, false>(Z, ldz, nullptr, 0, Z, ldz, nullptr, 0, nullptr, GAE_ACT_IDENTITY,
+                                                 out, ldo, n, int(d), n, s);
+}
+
+extern "C" int64_t gae_decoder_dense_bwd_workspace_bytes(int64_t n, int64_t d)
+{
+    if (n < 0 || d < 0) return GAE_E_SIZE;
+    const AtbPlan pl = atb_plan(n, d, n);
+    return align256(pl.n_slots * n * d * 4) + 256;
+}
+
+extern "C" int gae_decoder_dense_bwd(const float *G, int64_t ldg, const float *Z, const float *mask, int64_t ldz,
+                                     int64_t n, int64_t d, float *dZ, int64_t lddz, void *workspace,
+                                     int64_t workspace_bytes, void *stream)
+{
+    GAE_REQUIRE(n >= 0 && d >= 0, GAE_E_SIZE, "gae_decoder_dense_bwd: negative size");
+    GAE_REQUIRE(n < (1 << 24) && d < (1 << 24), GAE_E_SIZE, "gae_decoder_dense_bwd: too large for the dense path");
+    GAE_REQUIRE(ldg >= n && ldz >= d && lddz >= d, GAE_E_SIZE, "gae_decoder_dense_bwd: leading dimension too small");
+    if (n == 0 || d == 0) return GAE_OK;
+    GAE_REQUIRE(G && Z && dZ, GAE_E_NULL, "gae_decoder_dense_bwd: NULL pointer");
+    hipStream_t s = gae::as_stream(stream);
+    const AtbPlan pl = atb_plan(n, d, n);
+    const int64_t need = align256(pl.n_slots * n * d * 4);
+    GAE_REQUIRE(workspace && workspace_bytes >= need, GAE_E_WORKSPACE,
+                "gae_decoder_dense_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    int rc;
+    // term 1: dZ = G Zt              (A = G [n, n], B = Zt given as [K = n, J = d])
+    if (mask)
+        rc = dispatch_gemm<false, PRO_NONE, true>(G, ldg, nullptr, 0, Z, ldz, mask, ldz, nullptr, GAE_ACT_IDENTITY, dZ,
+                                                  lddz, n, int(n), d, s);
+    else
+        rc = dispatch_gemm<false, PRO_NONE, false>(G, ldg, nullptr, 0, Z, ldz, nullptr, 0, nullptr, GAE_ACT_IDENTITY,
+                                                   dZ, lddz, n, int(n), d, s);
+    if (rc) return rc;
+    // term 2: (G^T Zt)^T [d, n] = Zt^T G   (P = Z with the mask folded in, Q = G), partials per row slot
+    float *partial = static_cast<float *>(workspace);
+    if (mask)
+        rc = launch_atb<PRO_MUL_MASK>(Z, ldz, mask, ldz, G, ldg, n, int(d), int(n), partial, nullptr, pl, s);
+    else
+        rc = launch_atb<PRO_NONE>(Z, ldz, nullptr, 0, G, ldg, n, int(d), int(n), partial, nullptr, pl, s);
+    if (rc) return rc;
+    // dZ[i, k] = (dZ[i, k] + sum_slot partial[slot][k][i]) * mask[i, k]
+    int64_t g = (n * d + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(reduce_slots_transposed_kernel, dim3(unsigned(g)), dim3(256), 0, s, partial, pl.n_slots, d, n,
+                       dZ, lddz, mask, ldz);
+    GAE_CHECK_LAUNCH("reduce_slots_transposed_kernel");
+    return GAE_OK;
+}

@@ -1,0 +1,139 @@
+"""Host-side mirror of the reference model file gae_dgl/gae.py: same class
+names, constructor arguments, attribute names and state-dict keys
+(``layers.{i}.apply_mod.linear.{weight,bias}``), same side effects on
+``g.ndata['h']`` -- with every arithmetic op executed by the HIP kernels of
+libgae_hip.so (SpMM, fp32-MFMA Linear+activation, inner-product decoder).
+
+Extensions over the reference are keyword-only and default to its behaviour:
+``norm="none"|"both"`` (gae.py applies no normalisation although
+train_transductive.py:55-58 computes one) and an injectable dropout mask/seed
+for reproducible tests."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import function as fn
+from . import ops
+from ._lib import ACT_IDENTITY, ACT_RELU
+
+
+def identity(x):
+    return x
+
+
+def _act_code(activation):
+    """fused-epilogue code of an activation callable, or None (apply it after)"""
+    if activation is None or activation is identity:
+        return ACT_IDENTITY
+    if activation is F.relu or activation is torch.relu:
+        return ACT_RELU
+    if getattr(activation, "__name__", "") == "<lambda>":
+        # the reference spells identity as ``lambda x: x`` (gae.py:43,45,47)
+        code = getattr(activation, "__code__", None)
+        if code is not None and code.co_argcount == 1 and code.co_code == (lambda x: x).__code__.co_code:
+            return ACT_IDENTITY
+    return None
+
+
+class NodeApplyModule(nn.Module):
+    """gae.py:7-16 -- Linear (+bias) then activation, as one fused HIP kernel."""
+
+    def __init__(self, in_feats, out_feats, activation):
+        super().__init__()
+        self.linear = nn.Linear(in_feats, out_feats)  # default init, weight [out, in] (gae.py:10)
+        self.activation = activation
+
+    def forward(self, node):
+        code = _act_code(self.activation)
+        x = node.data['h']
+        if code is None:
+            h = self.activation(ops.linear(x, self.linear.weight, self.linear.bias, ACT_IDENTITY))
+        else:
+            h = ops.linear(x, self.linear.weight, self.linear.bias, code)
+        return {'h': h}
+
+
+gcn_msg = fn.copy_src(src='h', out='m')
+gcn_reduce = fn.sum(msg='m', out='h')  # sum aggregation (gae.py:18-19)
+
+
+class GCN(nn.Module):
+    """gae.py:21-31 -- aggregate over in-edges (HIP SpMM) -> NodeApplyModule."""
+
+    def __init__(self, in_feats, out_feats, activation, norm=None):
+        super().__init__()
+        self.apply_mod = NodeApplyModule(in_feats, out_feats, activation)
+        self.norm = norm
+
+    def forward(self, g, feature):
+        g.ndata['h'] = feature
+        g.update_all(gcn_msg, gcn_reduce, norm=self.norm)
+        g.apply_nodes(func=self.apply_mod)
+        h = g.ndata.pop('h')
+        return h
+
+
+class GAE(nn.Module):
+    """gae.py:33-61.  ReLU on layers 0..L-2, identity on the last layer; a
+    single hidden dim gives one identity layer (gae.py:36-45)."""
+
+    def __init__(self, in_dim, hidden_dims, *, norm=None):
+        super().__init__()
+        hidden_dims = list(hidden_dims)
+        if len(hidden_dims) >= 2:
+            layers = [GCN(in_dim, hidden_dims[0], F.relu, norm)]
+            for i in range(1, len(hidden_dims)):
+                if i != len(hidden_dims) - 1:
+                    layers.append(GCN(hidden_dims[i - 1], hidden_dims[i], F.relu, norm))
+                else:
+                    layers.append(GCN(hidden_dims[i - 1], hidden_dims[i], identity, norm))
+        else:
+            layers = [GCN(in_dim, hidden_dims[0], identity, norm)]
+        self.layers = nn.ModuleList(layers)
+        self.decoder = InnerProductDecoder(activation=identity)
+
+    def forward(self, g):
+        h = g.ndata['h']
+        for conv in self.layers:
+            h = conv(g, h)
+        g.ndata['h'] = h
+        adj_rec = self.decoder(h)
+        return adj_rec
+
+    def encode(self, g):
+        h = g.ndata['h']
+        for conv in self.layers:
+            h = conv(g, h)
+        return h
+
+
+class InnerProductDecoder(nn.Module):
+    """gae.py:63-72.  Dropout is applied regardless of train()/eval() exactly
+    like the reference (``F.dropout(z, self.dropout)`` omits ``training=``).
+    The mask comes from the library's Philox counter RNG; set ``self.mask`` to
+    inject a precomputed multiplier (0 or 1/(1-p)) instead."""
+
+    def __init__(self, activation=torch.sigmoid, dropout=0.1, seed=None):
+        super().__init__()
+        self.dropout = dropout
+        self.activation = activation
+        self.mask = None
+        self.seed = seed
+        self._calls = 0
+        self.last_mask = None
+
+    def _draw_mask(self, z):
+        if self.mask is not None:
+            return self.mask
+        if not self.dropout:
+            return None
+        seed = self.seed if self.seed is not None else int(torch.initial_seed())
+        offset = self._calls * ((z.numel() + 3) // 4)
+        self._calls += 1
+        return ops.dropout_mask(tuple(z.shape), self.dropout, seed, offset, z.device)
+
+    def forward(self, z):
+        mask = self._draw_mask(z)
+        self.last_mask = mask
+        adj = self.activation(ops.decoder_dense(z, mask))
+        return adj

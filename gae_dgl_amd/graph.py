@@ -1,0 +1,225 @@
+"""Graph container exposing the subset of the DGL 0.4 API the reference uses
+(SURVEY.md section 8(b)), backed by a device CSR and the HIP kernels of
+libgae_hip.so.
+
+Reference call sites mirrored here:
+  DGLGraph() / add_nodes / add_edges          gae_dgl/prepare_data.py:48,53,65
+  DGLGraph(networkx graph)                    gae_dgl/train_transductive.py:45
+  g.ndata[...] get/set/pop                    gae_dgl/gae.py:27,30,50,53,58
+  g.update_all(copy_src, sum)                 gae_dgl/gae.py:28       -> HIP SpMM
+  g.apply_nodes(func)                         gae_dgl/gae.py:29
+  g.in_degrees()                              gae_dgl/train_transductive.py:55
+  g.adjacency_matrix().to_dense()             gae_dgl/train_inductive.py:44
+  dgl.batch(samples), g.to(device)            gae_dgl/train_inductive.py:31-35
+  set_n_initializer / set_e_initializer       gae_dgl/train_inductive.py:93-94
+"""
+import numpy as np
+import torch
+
+from . import function as fn
+from ._lib import GaeHipError
+
+
+class NodeBatch:
+    """what DGL hands to an apply_nodes UDF: ``nodes.data`` is the ndata frame"""
+
+    def __init__(self, data):
+        self.data = data
+
+
+def _as_index(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.int64).reshape(-1)
+    return torch.as_tensor(np.asarray(x, dtype=np.int64).reshape(-1), device=device)
+
+
+class Graph:
+    """Directed multigraph with node features; edges are (src -> dst)."""
+
+    def __init__(self, graph_data=None, num_nodes=None, device=None):
+        self._device = torch.device(device) if device is not None else torch.device("cpu")
+        self._n = 0
+        self._src = torch.zeros(0, dtype=torch.int64, device=self._device)
+        self._dst = torch.zeros(0, dtype=torch.int64, device=self._device)
+        self.ndata = {}
+        self.edata = {}
+        self.norm_mode = "none"      # "none" = reference behaviour, "both" = D^-1/2 A D^-1/2
+        self.batch_num_nodes = None  # node counts per member graph when built by batch()
+        self._cache = {}
+        if graph_data is not None:
+            self._init_from(graph_data, num_nodes)
+        elif num_nodes:
+            self._n = int(num_nodes)
+
+    # ------------------------------------------------------------ construction
+    def _init_from(self, data, num_nodes):
+        if isinstance(data, (tuple, list)) and len(data) == 2:
+            src, dst = data
+        elif hasattr(data, "edges") and hasattr(data, "number_of_nodes"):  # networkx
+            g = data if data.is_directed() else data.to_directed()
+            num_nodes = g.number_of_nodes() if num_nodes is None else num_nodes
+            e = np.asarray(list(g.edges()), dtype=np.int64).reshape(-1, 2)
+            src, dst = e[:, 0], e[:, 1]
+        else:
+            raise TypeError(f"cannot build a Graph from {type(data)}")
+        src = _as_index(src, self._device); dst = _as_index(dst, self._device)
+        if num_nodes is None:
+            num_nodes = int(max(src.max().item(), dst.max().item())) + 1 if src.numel() else 0
+        self._n = int(num_nodes)
+        self._src, self._dst = src, dst
+
+    def add_nodes(self, num):
+        self._n += int(num)
+        self._cache.clear()
+
+    def add_edges(self, u, v):
+        u = _as_index(u, self._device); v = _as_index(v, self._device)
+        if u.numel() != v.numel():
+            raise ValueError("add_edges: src/dst length mismatch")
+        if u.numel() and (int(u.max()) >= self._n or int(v.max()) >= self._n or int(u.min()) < 0 or int(v.min()) < 0):
+            raise ValueError("add_edges: node id out of range (add_nodes first)")
+        self._src = torch.cat([self._src, u]); self._dst = torch.cat([self._dst, v])
+        self._cache.clear()
+
+    # ------------------------------------------------------------ queries
+    def number_of_nodes(self):
+        return self._n
+
+    def number_of_edges(self):
+        return int(self._src.numel())
+
+    def __len__(self):
+        return self._n
+
+    @property
+    def device(self):
+        return self._device
+
+    def edges(self):
+        return self._src, self._dst
+
+    def to(self, device):
+        """in place like DGL 0.4 (the reference discards the result, train_inductive.py:33)"""
+        device = torch.device(device)
+        if device != self._device:
+            self._device = device
+            self._src = self._src.to(device); self._dst = self._dst.to(device)
+            self.ndata = {k: v.to(device) for k, v in self.ndata.items()}
+            self.edata = {k: v.to(device) for k, v in self.edata.items()}
+            self._cache.clear()
+        return self
+
+    def set_n_initializer(self, initializer, field=None):
+        return None  # zero rows are what the SpMM writes for message-less nodes
+
+    def set_e_initializer(self, initializer, field=None):
+        return None
+
+    # ------------------------------------------------------------ device structure
+    def _require_gpu(self, what):
+        if self._device.type != "cuda":
+            raise GaeHipError(f"Graph.{what} runs HIP kernels and needs the graph on an AMD GPU "
+                              f"(graph is on {self._device}); gae_dgl_amd has no CPU fallback")
+
+    def _follow(self, tensor):
+        """move the structure next to the features (the reference's collate leaves
+        that to DGL, train_inductive.py:33)"""
+        if isinstance(tensor, torch.Tensor) and tensor.is_cuda and self._device != tensor.device:
+            self.to(tensor.device)
+
+    def csr(self):
+        """(indptr, indices) of A: rows = destination, cols = source"""
+        if "csr" not in self._cache:
+            from . import ops
+            self._require_gpu("csr")
+            self._cache["csr"] = ops.csr_from_coo(self._dst, self._src, self._n, self._n)
+        return self._cache["csr"]
+
+    def csc(self):
+        """CSR of A^T (rows = source): the structure of the backward SpMM"""
+        if "csc" not in self._cache:
+            from . import ops
+            self._require_gpu("csc")
+            self._cache["csc"] = ops.csr_from_coo(self._src, self._dst, self._n, self._n)
+        return self._cache["csc"]
+
+    def set_csr(self, indptr, indices, t_indptr=None, t_indices=None):
+        """adopt an already-built device CSR (used by the device dataset batcher)"""
+        self._cache["csr"] = (indptr, indices)
+        if t_indptr is not None:
+            self._cache["csc"] = (t_indptr, t_indices)
+
+    def in_degrees(self):
+        from . import ops
+        self._require_gpu("in_degrees")
+        if "deg" not in self._cache:
+            self._cache["deg"], self._cache["norm"] = ops.degree_norm(self.csr()[0])
+        return self._cache["deg"].to(torch.int64)
+
+    def norm(self):
+        """in_degree^-1/2 with inf -> 0  (train_transductive.py:55-58), fp32 [N]"""
+        self.in_degrees()
+        return self._cache["norm"]
+
+    def adjacency_matrix(self, transpose=False):
+        """sparse COO [N, N]; rows = destination, cols = source (DGL 0.4
+        ``transpose=False``); ``.to_dense()`` adds duplicate edges."""
+        r, c = (self._src, self._dst) if transpose else (self._dst, self._src)
+        vals = torch.ones(r.numel(), dtype=torch.float32, device=self._device)
+        return torch.sparse_coo_tensor(torch.stack([r, c]), vals, (self._n, self._n))
+
+    def dense_adjacency(self):
+        """the same label through the HIP kernel (duplicates add)"""
+        from . import ops
+        indptr, indices = self.csr()
+        return ops.csr_to_dense(indptr, indices, self._n, self._n)
+
+    # ------------------------------------------------------------ message passing
+    def update_all(self, message_func, reduce_func, norm=None):
+        if not (isinstance(message_func, fn.CopySrc) and isinstance(reduce_func, fn.SumReduce)
+                and message_func.out == reduce_func.msg):
+            raise NotImplementedError("only update_all(copy_src(src, m), sum(m, out)) is implemented "
+                                      "(the pair gae.py:18-19 uses)")
+        from . import ops
+        h = self.ndata[message_func.src]
+        self._follow(h)
+        self._require_gpu("update_all")
+        mode = self.norm_mode if norm is None else norm
+        if mode not in ("none", "both"):
+            raise ValueError(f"norm must be 'none' or 'both', got {mode!r}")
+        self.ndata[reduce_func.out] = ops.spmm(self, h, use_norm=(mode == "both"))
+
+    def apply_nodes(self, func):
+        self.ndata.update(func(NodeBatch(self.ndata)))
+
+
+DGLGraph = Graph
+
+
+def batch(graphs):
+    """dgl.batch (train_inductive.py:34): block-diagonal union, node ids offset
+    by the exclusive prefix sum of node counts, ndata concatenated on dim 0.
+
+    Samples drawn from a :class:`gae_dgl_amd.dataset.DeviceGraphDataset` are
+    gathered by one HIP kernel from the device-resident dataset CSR."""
+    graphs = list(graphs)
+    if graphs and all(getattr(g, "_ds", None) is not None for g in graphs) \
+            and len({id(g._ds) for g in graphs}) == 1:
+        return graphs[0]._ds.batch([g._gid for g in graphs])
+    if not graphs:
+        return Graph()
+    dev = graphs[0].device
+    counts = np.asarray([g.number_of_nodes() for g in graphs], dtype=np.int64)
+    offs = np.zeros(len(graphs) + 1, dtype=np.int64)
+    np.cumsum(counts, out=offs[1:])
+    bg = Graph(device=dev)
+    bg._n = int(offs[-1])
+    bg._src = torch.cat([g.to(dev)._src + int(o) for g, o in zip(graphs, offs[:-1])])
+    bg._dst = torch.cat([g._dst + int(o) for g, o in zip(graphs, offs[:-1])])
+    keys = set(graphs[0].ndata)
+    for k in keys:
+        if all(k in g.ndata for g in graphs):
+            bg.ndata[k] = torch.cat([g.ndata[k] for g in graphs], dim=0)
+    bg.batch_num_nodes = counts.tolist()
+    bg.norm_mode = graphs[0].norm_mode
+    return bg

@@ -1,0 +1,265 @@
+"""Torch-facing wrappers of the C ABI (include/gae_hip.h).
+
+Tensors are only carriers of device pointers here: every op below launches
+hand-written HIP kernels from libgae_hip.so on PyTorch's current HIP stream.
+There is no CPU / eager fallback -- a CPU tensor raises."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_IDENTITY, ACT_RELU, BF16, F32, GaeHipError
+
+_vp = ctypes.c_void_p
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def _gpu(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise GaeHipError(f"{name}: expected a tensor on an AMD GPU (gae_dgl_amd has no CPU fallback), "
+                          f"got {getattr(t, 'device', type(t))}")
+    return t
+
+
+def _rowmajor(t, name):
+    """(tensor, ld) with unit inner stride; copies only when needed."""
+    _gpu(t, name)
+    if t.dim() != 2:
+        raise GaeHipError(f"{name}: expected a 2-D tensor, got {tuple(t.shape)}")
+    if t.shape[1] > 0 and t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+    return t, max(ld, t.shape[1], 1)
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise GaeHipError(f"unsupported dtype {t.dtype} (fp32 and bf16 storage are supported)")
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def device_info(device=0):
+    info = _lib.DeviceInfo()
+    _lib.call("gae_device_info_get", int(device), ctypes.byref(info))
+    return {f: (getattr(info, f).decode() if f == "name" else getattr(info, f)) for f, _ in info._fields_}
+
+
+# ------------------------------------------------------------------ structure
+def csr_from_coo(row, col, n_rows, n_cols, validate=True):
+    """CSR (int32 indptr, int32 indices) with rows ascending, columns ascending
+    inside a row, duplicates kept.  ``row``/``col`` are int64 device tensors."""
+    _gpu(row, "row"); _gpu(col, "col")
+    row = row.to(torch.int64).contiguous(); col = col.to(torch.int64).contiguous()
+    E = row.numel()
+    if col.numel() != E:
+        raise GaeHipError("csr_from_coo: row/col length mismatch")
+    dev = row.device
+    with torch.cuda.device(dev):
+        indptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+        indices = torch.empty(E, dtype=torch.int32, device=dev)
+        nbytes = _lib.load().gae_csr_from_coo_workspace_bytes(E, n_rows)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "gae_csr_from_coo_workspace_bytes")
+        ws = _workspace(nbytes, dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.call("gae_csr_from_coo", _ptr(row), _ptr(col), E, n_rows, n_cols, _ptr(indptr), _ptr(indices),
+                  _ptr(ws), ws.numel(), _ptr(status), _stream())
+        if validate and E and int(status.item()) != 0:
+            raise GaeHipError("csr_from_coo: edge endpoint outside [0, n_rows) x [0, n_cols)")
+    return indptr, indices
+
+
+def degree_norm(indptr, want_deg=True, want_norm=True):
+    _gpu(indptr, "indptr")
+    n = indptr.numel() - 1
+    dev = indptr.device
+    deg = torch.empty(n, dtype=torch.int32, device=dev) if want_deg else None
+    norm = torch.empty(n, dtype=torch.float32, device=dev) if want_norm else None
+    with torch.cuda.device(dev):
+        _lib.call("gae_degree_norm", _ptr(indptr), n, _ptr(deg), _ptr(norm), _stream())
+    return deg, norm
+
+
+def csr_to_dense(indptr, indices, n_rows, n_cols):
+    _gpu(indptr, "indptr")
+    out = torch.empty(n_rows, n_cols, dtype=torch.float32, device=indptr.device)
+    with torch.cuda.device(indptr.device):
+        _lib.call("gae_csr_to_dense", _ptr(indptr), _ptr(indices), n_rows, n_cols, _ptr(out), max(n_cols, 1),
+                  _stream())
+    return out
+
+
+def batch_gather(graph_ptr, ds_indptr, ds_indices, ds_feat, graph_ids, node_ptr, edge_ptr, n_nodes, n_edges):
+    feat, ldf = _rowmajor(ds_feat, "ds_feat")
+    F = feat.shape[1]
+    dev = feat.device
+    out_indptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+    out_indices = torch.empty(n_edges, dtype=torch.int32, device=dev)
+    out_feat = torch.empty(n_nodes, F, dtype=feat.dtype, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("gae_batch_gather", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_indices), _ptr(feat), ldf, F,
+                  _dtype_code(feat), _ptr(graph_ids), graph_ids.numel(), _ptr(node_ptr), _ptr(edge_ptr),
+                  n_nodes, n_edges, _ptr(out_indptr), _ptr(out_indices), _ptr(out_feat), max(F, 1), _stream())
+    return out_indptr, out_indices, out_feat
+
+
+# ------------------------------------------------------------------ raw kernels
+def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=None):
+    """M = diag(row_scale) A diag(col_scale) H  (K1/K2)."""
+    H, ldh = _rowmajor(H, "H")
+    _gpu(indptr, "indptr")
+    n_cols, F = H.shape
+    if out is None:
+        out = torch.empty(n_rows, F, dtype=H.dtype, device=H.device)
+    out2, ldm = _rowmajor(out, "out")
+    if out2 is not out:
+        raise GaeHipError("spmm: `out` must be row-major with unit inner stride")
+    with torch.cuda.device(H.device):
+        _lib.call("gae_spmm_csr", _ptr(indptr), _ptr(indices), n_rows, n_cols, _ptr(H), ldh, _ptr(out), ldm, F,
+                  _dtype_code(H), _ptr(row_scale), _ptr(col_scale), _stream())
+    return out
+
+
+def linear_fwd_raw(M, W, b, act):
+    M, ldm = _rowmajor(M, "M")
+    W = _gpu(W, "W").contiguous()
+    n, f_in = M.shape
+    f_out = W.shape[0]
+    Y = torch.empty(n, f_out, dtype=torch.float32, device=M.device)
+    with torch.cuda.device(M.device):
+        _lib.call("gae_linear_fwd", _ptr(M), ldm, n, f_in, _ptr(W), _ptr(b), f_out, act, _ptr(Y), max(f_out, 1),
+                  _stream())
+    return Y
+
+
+def linear_bwd_raw(dY, Y, act, M, W, need_dW=True, need_db=True, need_dM=True):
+    dY, lddy = _rowmajor(dY, "dY")
+    M, ldm = _rowmajor(M, "M")
+    W = W.contiguous()
+    n, f_in = M.shape
+    f_out = W.shape[0]
+    dev = M.device
+    dW = torch.empty(f_out, f_in, dtype=torch.float32, device=dev) if need_dW else None
+    db = torch.empty(f_out, dtype=torch.float32, device=dev) if need_db else None
+    dM = torch.empty(n, f_in, dtype=torch.float32, device=dev) if need_dM else None
+    ldy = 0
+    if Y is not None:
+        Y, ldy = _rowmajor(Y, "Y")
+    with torch.cuda.device(dev):
+        ws = _workspace(_lib.load().gae_linear_bwd_workspace_bytes(n, f_in, f_out), dev)
+        _lib.call("gae_linear_bwd", _ptr(dY), lddy, _ptr(Y), ldy, act, _ptr(M), ldm, _ptr(W), n, f_in, f_out,
+                  _ptr(dW), _ptr(db), _ptr(dM), max(f_in, 1), _ptr(ws), ws.numel(), _stream())
+    return dW, db, dM
+
+
+def dropout_mask(shape, p, seed, offset=0, device="cuda"):
+    mask = torch.empty(shape, dtype=torch.float32, device=device)
+    with torch.cuda.device(mask.device):
+        _lib.call("gae_dropout_mask", _ptr(mask), mask.numel(), float(p), int(seed) & (2 ** 64 - 1),
+                  int(offset) & (2 ** 64 - 1), _stream())
+    return mask
+
+
+def decoder_dense_raw(Z, mask=None):
+    Z, ldz = _rowmajor(Z, "Z")
+    if mask is not None:
+        mask = _gpu(mask, "mask").contiguous()
+        if Z.stride(0) != mask.stride(0) and Z.shape[0] > 1:
+            Z = Z.contiguous(); ldz = max(Z.shape[1], 1)
+    n, d = Z.shape
+    out = torch.empty(n, n, dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        _lib.call("gae_decoder_dense", _ptr(Z), _ptr(mask), ldz, n, d, _ptr(out), max(n, 1), _stream())
+    return out
+
+
+def decoder_dense_bwd_raw(G, Z, mask=None):
+    G, ldg = _rowmajor(G, "G")
+    Z = _gpu(Z, "Z").contiguous()
+    if mask is not None:
+        mask = mask.contiguous()
+    n, d = Z.shape
+    dZ = torch.empty(n, d, dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        ws = _workspace(_lib.load().gae_decoder_dense_bwd_workspace_bytes(n, d), Z.device)
+        _lib.call("gae_decoder_dense_bwd", _ptr(G), ldg, _ptr(Z), _ptr(mask), max(d, 1), n, d, _ptr(dZ), max(d, 1),
+                  _ptr(ws), ws.numel(), _stream())
+    return dZ
+
+
+# ------------------------------------------------------------------ autograd glue
+class SpMMFunction(torch.autograd.Function):
+    """update_all(copy_src, sum) with its backward  dH = A^T dM  (gae.py:28)."""
+
+    @staticmethod
+    def forward(ctx, H, graph, use_norm):
+        indptr, indices = graph.csr()
+        norm = graph.norm() if use_norm else None
+        ctx.graph, ctx.use_norm = graph, use_norm
+        return spmm_raw(indptr, indices, H, graph.number_of_nodes(), norm, norm)
+
+    @staticmethod
+    def backward(ctx, dM):
+        g = ctx.graph
+        t_indptr, t_indices = g.csc()
+        norm = g.norm() if ctx.use_norm else None
+        return spmm_raw(t_indptr, t_indices, dM, g.number_of_nodes(), norm, norm), None, None
+
+
+class LinearFunction(torch.autograd.Function):
+    """NodeApplyModule: act(M W^T + b)  (gae.py:13-16)."""
+
+    @staticmethod
+    def forward(ctx, M, W, b, act):
+        Y = linear_fwd_raw(M, W, b, act)
+        ctx.act = act
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(M, W, Y if act == ACT_RELU else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        M, W, Y = ctx.saved_tensors
+        need_dM, need_dW = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dW, db, dM = linear_bwd_raw(dY, Y, ctx.act, M, W, need_dW, need_db, need_dM)
+        return dM, dW, db, None
+
+
+class DecoderDenseFunction(torch.autograd.Function):
+    """InnerProductDecoder: (Z m)(Z m)^T  (gae.py:70-71)."""
+
+    @staticmethod
+    def forward(ctx, Z, mask):
+        ctx.save_for_backward(Z, mask)
+        return decoder_dense_raw(Z, mask)
+
+    @staticmethod
+    def backward(ctx, G):
+        Z, mask = ctx.saved_tensors
+        return decoder_dense_bwd_raw(G, Z, mask), None
+
+
+def spmm(graph, H, use_norm=False):
+    return SpMMFunction.apply(H, graph, use_norm)
+
+
+def linear(M, W, b, act=ACT_IDENTITY):
+    return LinearFunction.apply(M, W, b, act)
+
+
+def decoder_dense(Z, mask=None):
+    return DecoderDenseFunction.apply(Z, mask)

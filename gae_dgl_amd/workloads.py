@@ -1,0 +1,98 @@
+"""Seeded synthetic workloads with the shapes of the reference's datasets
+(SURVEY.md section 8(d)); the real Planetoid / ZINC-250k files are not
+available offline.  Generators return host numpy arrays (citation, zinc) or
+device tensors (rmat)."""
+import numpy as np
+import torch
+
+CITATION = {  # N, E (directed, symmetric), F
+    "cora": (2708, 10556, 1433),
+    "citeseer": (3327, 9228, 3703),
+    "pubmed": (19717, 88651, 500),
+}
+
+
+def citation_graph(name, seed=0):
+    """E/2 undirected pairs sampled uniformly, mirrored, no self-loops; X =
+    sparse non-negative rows normalised to sum 1 (as DGL's citation loader)."""
+    n, e, f = CITATION[name]
+    rng = np.random.default_rng(seed)
+    half = e // 2
+    a = rng.integers(0, n, half); b = rng.integers(0, n, half)
+    same = a == b
+    b[same] = (b[same] + 1 + rng.integers(0, n - 1, int(same.sum()))) % n
+    src = np.concatenate([a, b]); dst = np.concatenate([b, a])
+    if e % 2:  # Pubmed's directed count is odd: one extra directed edge
+        src = np.append(src, a[0]); dst = np.append(dst, (a[0] + 1) % n)
+    nnz_per_row = max(1, int(0.0127 * f) if name != "pubmed" else 50)
+    X = np.zeros((n, f), np.float32)
+    cols = rng.integers(0, f, (n, nnz_per_row))
+    vals = rng.random((n, nnz_per_row)).astype(np.float32) + 0.05
+    np.put_along_axis(X, cols, vals, axis=1)
+    X /= X.sum(1, keepdims=True)
+    return n, src.astype(np.int64), dst.astype(np.int64), X
+
+
+def zinc_like(n_graphs=249455, seed=0):
+    """ZINC-250k-shaped molecule set as one block-diagonal dataset:
+    n ~ clip(round(N(23.2, 4.6)), 6, 38) atoms; a random tree whose parents lie
+    1..3 positions back (degree <= 4) plus Poisson(2.75) ring-closing bonds to
+    the atom 5 back; both bond directions (prepare_data.py:56-65); 39 one-hot
+    style binary features (prepare_data.py:14-16,31-36).
+    Returns graph_ptr[int64 G+1], src, dst (GLOBAL node ids, int64), X[N,39]."""
+    rng = np.random.default_rng(seed)
+    sizes = np.clip(np.rint(rng.normal(23.2, 4.6, n_graphs)), 6, 38).astype(np.int64)
+    gptr = np.zeros(n_graphs + 1, np.int64)
+    np.cumsum(sizes, out=gptr[1:])
+    N = int(gptr[-1])
+    gid = np.repeat(np.arange(n_graphs), sizes)
+    local = np.arange(N) - gptr[gid]
+    # tree bonds
+    child = np.nonzero(local > 0)[0]
+    back = np.minimum(rng.integers(1, 4, child.size), local[child])
+    parent = child - back
+    # ring closures
+    n_ring = np.minimum(rng.poisson(2.75, n_graphs), np.maximum(sizes - 5, 0))
+    rg = np.repeat(np.arange(n_graphs), n_ring)
+    rl = 5 + (rng.random(rg.size) * (sizes[rg] - 5)).astype(np.int64)
+    ra = gptr[rg] + rl
+    rb = ra - 5
+    a = np.concatenate([child, ra]); b = np.concatenate([parent, rb])
+    # interleave both directions per bond like prepare_data.py:61-64
+    src = np.stack([a, b], 1).reshape(-1); dst = np.stack([b, a], 1).reshape(-1)
+    X = np.zeros((N, 39), np.float32)
+    for lo, w in ((0, 23), (23, 6), (29, 5), (34, 4)):
+        X[np.arange(N), lo + rng.integers(0, w, N)] = 1.0
+    X[:, 38] = rng.random(N) < 0.3
+    return gptr, src.astype(np.int64), dst.astype(np.int64), X
+
+
+def rmat_edges(scale=24, edge_factor=16, abcd=(0.57, 0.19, 0.19, 0.05), seed=0, device="cuda",
+               chunk=1 << 26):
+    """R-MAT edge list on the device (directed, duplicates kept).  Returns
+    (src, dst) int64 of length edge_factor * 2^scale."""
+    n_edges = edge_factor << scale
+    a, b, c, _ = abcd
+    gen = torch.Generator(device=device).manual_seed(seed)
+    src = torch.empty(n_edges, dtype=torch.int64, device=device)
+    dst = torch.empty(n_edges, dtype=torch.int64, device=device)
+    for lo in range(0, n_edges, chunk):
+        m = min(chunk, n_edges - lo)
+        s = torch.zeros(m, dtype=torch.int64, device=device)
+        d = torch.zeros(m, dtype=torch.int64, device=device)
+        for _ in range(scale):
+            r = torch.rand(m, device=device, generator=gen)
+            sbit = (r >= a + b).to(torch.int64)                       # quadrants c, d -> row bit 1
+            dbit = ((r >= a) & (r < a + b) | (r >= a + b + c)).to(torch.int64)  # quadrants b, d -> col bit 1
+            s = (s << 1) | sbit
+            d = (d << 1) | dbit
+        src[lo:lo + m] = s; dst[lo:lo + m] = d
+    return src, dst
+
+
+def spmm_alg_bytes(n_rows, n_cols, nnz, F, elem=4, scaled=False):
+    """compulsory bytes of one SpMM launch (int32 CSR)."""
+    b = 4 * (n_rows + 1) + 4 * nnz + elem * F * n_cols + elem * F * n_rows
+    if scaled:
+        b += 4 * n_rows + 4 * n_cols
+    return b

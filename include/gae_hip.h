@@ -1,0 +1,163 @@
+/* gae_hip.h -- C ABI of libgae_hip.so: the MI355X (gfx950) implementation of
+ * the GCN-encoder hot path of shionhonda/gae-dgl.
+ *
+ * The reference has no FFI of its own; its boundary is its Python module API
+ * (gae_dgl/gae.py) plus the handful of calls it makes into the third-party
+ * `dgl` package.  Each entry point below names the reference call it replaces
+ * (paths relative to the upstream tree).  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes; every pointer is a DEVICE pointer unless the
+ *     name ends in `_host`; the caller owns every buffer (inputs, outputs and
+ *     workspace) -- the library never allocates, frees or retains memory;
+ *   - `stream` is a hipStream_t passed as void*; every launch is asynchronous
+ *     on it, there is no internal synchronisation;
+ *   - return 0 = OK, negative = argument error detected before any launch
+ *     (GAE_E_*), positive = hipError_t from the runtime; a thread-local
+ *     message is available from gae_last_error(); nothing throws or exits;
+ *   - row-major matrices with an explicit leading dimension (elements);
+ *   - sparse structure is CSR with int32 `indptr[n_rows+1]`, int32 `indices[nnz]`;
+ *     rows = destination nodes, columns = source nodes (in-edge aggregation).
+ */
+#ifndef GAE_HIP_H
+#define GAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAE_VERSION 100 /* 0.1.0 */
+
+enum {
+    GAE_OK = 0,
+    GAE_E_NULL = -1,      /* required pointer is NULL */
+    GAE_E_SIZE = -2,      /* negative / overflowing / inconsistent size */
+    GAE_E_ALIGN = -3,     /* pointer or leading dimension not aligned as required */
+    GAE_E_DTYPE = -4,     /* unsupported dtype / activation code */
+    GAE_E_WORKSPACE = -5, /* workspace too small */
+    GAE_E_RANGE = -6      /* value out of the supported range */
+};
+
+enum { GAE_F32 = 0, GAE_BF16 = 1 };     /* storage dtype; accumulation is always fp32 */
+enum { GAE_ACT_IDENTITY = 0, GAE_ACT_RELU = 1 };
+
+typedef struct gae_device_info {
+    int32_t compute_units;
+    int32_t wavefront_size;
+    int32_t lds_bytes_per_cu;
+    int32_t l2_bytes;
+    int64_t hbm_bytes;
+    int32_t clock_khz;
+    int32_t gfx_major_minor; /* e.g. 950 */
+    char name[64];
+} gae_device_info;
+
+/* ---- library ------------------------------------------------------------ */
+int gae_version(void);
+const char *gae_last_error(void);
+int gae_device_info_get(int device, gae_device_info *out_host);
+
+/* ---- graph structure -------------------------------------------------------
+ * Replaces the DGL graph index built by DGLGraph.add_edges / dgl.batch
+ * (gae_dgl/prepare_data.py:53,65; gae_dgl/train_inductive.py:34) that
+ * g.update_all traverses (gae_dgl/gae.py:28). */
+
+/* bytes of workspace gae_csr_from_coo needs for n_edges edges */
+int64_t gae_csr_from_coo_workspace_bytes(int64_t n_edges, int64_t n_rows);
+
+/* COO (row[e], col[e]) int64 -> CSR; rows ascending, columns ascending inside
+ * a row, duplicates kept.  Pass (dst, src) for the aggregation matrix A and
+ * (src, dst) for A^T (the backward structure).  Returns GAE_E_RANGE through a
+ * device flag only for ids outside [0,n_rows) x [0,n_cols): out-of-range
+ * edges set *status_dev (int32, may be NULL) to 1 and are clamped. */
+int gae_csr_from_coo(const int64_t *row, const int64_t *col, int64_t n_edges,
+                     int64_t n_rows, int64_t n_cols,
+                     int32_t *indptr, int32_t *indices,
+                     void *workspace, int64_t workspace_bytes,
+                     int32_t *status_dev, void *stream);
+
+/* g.in_degrees() + norm = deg^-1/2, inf -> 0 (gae_dgl/train_transductive.py:55-58).
+ * deg_out (int32, may be NULL), norm_out (fp32, may be NULL). */
+int gae_degree_norm(const int32_t *indptr, int64_t n_rows, int32_t *deg_out,
+                    float *norm_out, void *stream);
+
+/* g.adjacency_matrix().to_dense() (gae_dgl/train_inductive.py:44,
+ * gae_dgl/train_transductive.py:59): out[r, c] = #edges (duplicates add).
+ * Parity/debug path only; out is n_rows x n_cols fp32, ld in elements. */
+int gae_csr_to_dense(const int32_t *indptr, const int32_t *indices, int64_t n_rows,
+                     int64_t n_cols, float *out, int64_t ld, void *stream);
+
+/* dgl.batch(samples) (gae_dgl/train_inductive.py:31-35) on a device-resident
+ * dataset CSR: builds the block-diagonal CSR + feature matrix of the graphs
+ * graph_ids[0..n_graphs) (in that order).
+ *   dataset: graph_ptr[n_total_graphs+1] (int64 node offsets), ds_indptr/ds_indices
+ *            (CSR over all dataset nodes, column ids GLOBAL dataset node ids),
+ *            ds_feat [n_total_nodes, F] (ld_feat)
+ *   plan   : out_node_ptr[n_graphs+1] / out_edge_ptr[n_graphs+1] (int64): exclusive
+ *            prefix sums of the selected graphs' node / edge counts (the caller
+ *            computes them from its host copy of the per-graph sizes)
+ *   outputs: out_indptr[N_b+1], out_indices[E_b], out_feat [N_b, F] (ld_out). */
+int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_indices,
+                     const void *ds_feat, int64_t ld_feat, int64_t F, int dtype,
+                     const int64_t *graph_ids, int64_t n_graphs,
+                     const int64_t *out_node_ptr, const int64_t *out_edge_ptr,
+                     int64_t n_batch_nodes, int64_t n_batch_edges,
+                     int32_t *out_indptr, int32_t *out_indices,
+                     void *out_feat, int64_t ld_out, void *stream);
+
+/* ---- K1/K2: sparse aggregation ---------------------------------------------
+ * M = diag(row_scale) * A * diag(col_scale) * H,  A given as CSR.
+ * Forward  = g.update_all(copy_src('h','m'), sum('m','h'))   gae_dgl/gae.py:18-19,28
+ * Backward = its autograd (gae_dgl/train_inductive.py:51): same call on the CSR of A^T.
+ * row_scale / col_scale (fp32, length n_rows / n_cols) may be NULL (= the
+ * reference's un-normalised sum); passing norm for both gives D^-1/2 A D^-1/2
+ * (gae_dgl/train_transductive.py:55-57).
+ * H: [n_cols, F] ld ldh, M: [n_rows, F] ld ldm, dtype GAE_F32 or GAE_BF16
+ * (same dtype in and out, fp32 accumulate in CSR order: deterministic). */
+int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                 const void *H, int64_t ldh, void *M, int64_t ldm, int64_t F, int dtype,
+                 const float *row_scale, const float *col_scale, void *stream);
+
+/* ---- K3-K5: node-apply (Linear + activation) -------------------------------
+ * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16
+ * M [n, f_in] (ldm), W [f_out, f_in] row-major contiguous (nn.Linear.weight,
+ * gae_dgl/gae.py:10), b [f_out] (may be NULL), Y [n, f_out] (ldy). fp32. */
+int gae_linear_fwd(const float *M, int64_t ldm, int64_t n, int64_t f_in,
+                   const float *W, const float *b, int64_t f_out, int act,
+                   float *Y, int64_t ldy, void *stream);
+
+/* autograd of the above.  dYm = dY (.) [Y > 0] when act = RELU.
+ *   dW [f_out, f_in] = dYm^T M      (NULL to skip)
+ *   db [f_out]       = colsum(dYm)  (NULL to skip)
+ *   dM [n, f_in]     = dYm W        (NULL to skip; layer 1 never needs it)
+ * workspace: gae_linear_bwd_workspace_bytes(n, f_in, f_out). */
+int64_t gae_linear_bwd_workspace_bytes(int64_t n, int64_t f_in, int64_t f_out);
+int gae_linear_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, int act,
+                   const float *M, int64_t ldm, const float *W,
+                   int64_t n, int64_t f_in, int64_t f_out,
+                   float *dW, float *db, float *dM, int64_t lddm,
+                   void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---- K6/K7: inner-product decoder ------------------------------------------
+ * InnerProductDecoder.forward, gae_dgl/gae.py:69-72 with the identity
+ * activation GAE passes (gae_dgl/gae.py:47).
+ * gae_dropout_mask: inverted-dropout multiplier (0 or 1/(1-p)), Philox4x32-10
+ * counter RNG keyed by (seed, offset + element index): reproducible for bwd.
+ * gae_decoder_dense: out = Zt Zt^T with Zt = Z (.) mask (mask may be NULL). */
+int gae_dropout_mask(float *mask, int64_t n_elems, float p, uint64_t seed, uint64_t offset,
+                     void *stream);
+int gae_decoder_dense(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
+                      float *out, int64_t ldo, void *stream);
+/* dZ = ((G + G^T) Zt) (.) mask,  G = dL/dlogits [n, n]  (autograd of gae.py:70-71) */
+int64_t gae_decoder_dense_bwd_workspace_bytes(int64_t n, int64_t d);
+int gae_decoder_dense_bwd(const float *G, int64_t ldg, const float *Z, const float *mask,
+                          int64_t ldz, int64_t n, int64_t d, float *dZ, int64_t lddz,
+                          void *workspace, int64_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAE_HIP_H */

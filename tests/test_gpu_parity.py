@@ -1,0 +1,363 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle
+and the committed golden vectors.  Integer/index work is bit-exact; fp32 work
+is checked to the north-star tolerance 1e-5 (relative to the output scale)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_params, load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def O():
+    from oracle import gae_oracle
+    return gae_oracle
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).detach().double().cpu(); b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1.0))
+
+
+def t(x, dev, dtype=None):
+    x = torch.as_tensor(np.asarray(x))
+    return x.to(device=dev, dtype=dtype) if dtype else x.to(dev)
+
+
+def rand_graph(rng, n, e, dup=True, hub=False):
+    src = rng.integers(0, n, e); dst = rng.integers(0, n, e)
+    if hub and n > 2:
+        dst[: e // 3] = 1          # one heavy row
+        src[e // 3: e // 2] = 2    # one heavy column
+    if dup and e > 4:
+        src[:2] = src[2:4]; dst[:2] = dst[2:4]
+    return src.astype(np.int64), dst.astype(np.int64)
+
+
+# ----------------------------------------------------------------- structure
+def test_csr_exact_golden(golden, dev):
+    from gae_dgl_amd import ops
+    g = golden; n = int(g["n"])
+    ip, ix = O().csr_from_coo(g["src"], g["dst"], n)
+    dip, dix = ops.csr_from_coo(t(g["dst"], dev), t(g["src"], dev), n, n)
+    assert dip.dtype == torch.int32 and dix.dtype == torch.int32
+    assert np.array_equal(dip.cpu().numpy(), ip) and np.array_equal(dix.cpu().numpy(), ix)
+    tp, tx = O().csc_from_coo(g["src"], g["dst"], n)
+    dtp, dtx = ops.csr_from_coo(t(g["src"], dev), t(g["dst"], dev), n, n)
+    assert np.array_equal(dtp.cpu().numpy(), tp) and np.array_equal(dtx.cpu().numpy(), tx)
+    deg, norm = ops.degree_norm(dip)
+    assert np.array_equal(deg.cpu().numpy().astype(np.int64), g["in_degrees"])
+    assert np.array_equal(norm.cpu().numpy().reshape(-1, 1), g["norm"])
+    assert np.array_equal(ops.csr_to_dense(dip, dix, n, n).cpu().numpy(), g["adj"])
+
+
+@pytest.mark.parametrize("n,e", [(1, 0), (1, 3), (5, 0), (7, 1), (64, 64), (1000, 5000), (4097, 70001), (200000, 1500000)])
+def test_csr_exact_random(n, e, dev):
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(n * 31 + e)
+    src, dst = rand_graph(rng, n, e, hub=True)
+    ip, ix = O().csr_from_coo(src, dst, n)
+    dip, dix = ops.csr_from_coo(t(dst, dev), t(src, dev), n, n)
+    assert np.array_equal(dip.cpu().numpy(), ip) and np.array_equal(dix.cpu().numpy(), ix)
+
+
+def test_csr_rectangular_and_bad_ids(dev):
+    from gae_dgl_amd import ops
+    from gae_dgl_amd._lib import GaeHipError
+    rng = np.random.default_rng(5)
+    row = rng.integers(0, 37, 500); col = rng.integers(0, 1000, 500)
+    ip, ix = O().csr_from_coo(col, row, 37, 1000)
+    dip, dix = ops.csr_from_coo(t(row, dev), t(col, dev), 37, 1000)
+    assert np.array_equal(dip.cpu().numpy(), ip) and np.array_equal(dix.cpu().numpy(), ix)
+    with pytest.raises(GaeHipError):
+        ops.csr_from_coo(t(np.array([0, 99]), dev), t(np.array([0, 1]), dev), 10, 10)
+
+
+# ----------------------------------------------------------------- K1/K2 SpMM
+@pytest.mark.parametrize("F", [1, 3, 4, 16, 32, 39, 40, 64, 100, 256, 500, 1433])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_spmm_fp32(F, scaled, dev):
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(F)
+    n, e = 777, 6000
+    src, dst = rand_graph(rng, n, e, hub=True)
+    dst[dst == 5] = 6  # row 5 has zero in-degree
+    H = rng.standard_normal((n, F)).astype(np.float32)
+    ip, ix = O().csr_from_coo(src, dst, n)
+    norm = O().norm_from_in_degrees(O().in_degrees(dst, n)).numpy() if scaled else None
+    ref = O().spmm_csr(ip, ix, torch.from_numpy(H).double(), norm, norm)
+    out = ops.spmm_raw(t(ip, dev), t(ix, dev), t(H, dev), n, t(norm, dev) if scaled else None,
+                       t(norm, dev) if scaled else None)
+    assert rel_err(out, ref) < TOL
+    assert float(out[5].abs().max()) == 0.0
+    if not scaled:
+        # same summation order as the C oracle => bit-exact for the un-normalised sum
+        from oracle import c_oracle
+        assert np.array_equal(out.cpu().numpy(), c_oracle.spmm_csr(ip, ix, H))
+
+
+def test_spmm_padded_ld_and_views(dev):
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(1)
+    n, e, F = 300, 2000, 39
+    src, dst = rand_graph(rng, n, e)
+    H = rng.standard_normal((n, F)).astype(np.float32)
+    ip, ix = O().csr_from_coo(src, dst, n)
+    ref = O().spmm_csr(ip, ix, H)
+    Hp = torch.full((n, 40), float("nan"), device=dev)
+    Hp[:, :F] = t(H, dev)
+    outp = torch.full((n, 40), 7.0, device=dev)
+    ops.spmm_raw(t(ip, dev), t(ix, dev), Hp[:, :F], n, out=outp[:, :F])   # vector path, ld = 40
+    assert rel_err(outp[:, :F], ref) < TOL
+    assert float((outp[:, F:] - 7.0).abs().max()) == 0.0                  # padding untouched
+    out = ops.spmm_raw(t(ip, dev), t(ix, dev), t(H, dev), n)              # scalar path, ld = 39
+    assert rel_err(out, ref) < TOL
+
+
+def test_spmm_bf16(dev):
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(2)
+    n, e = 500, 4000
+    src, dst = rand_graph(rng, n, e)
+    ip, ix = O().csr_from_coo(src, dst, n)
+    for F in (16, 39, 128, 3703):
+        H = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).bfloat16()
+        ref = O().spmm_csr(ip, ix, H.float())
+        out = ops.spmm_raw(t(ip, dev), t(ix, dev), H.to(dev), n)
+        assert out.dtype == torch.bfloat16
+        assert rel_err(out.float(), ref) < 1e-2  # bf16 storage: 8 mantissa bits
+
+
+def test_spmm_rectangular_and_empty(dev):
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(3)
+    row = rng.integers(0, 50, 400); col = rng.integers(0, 300, 400)
+    ip, ix = O().csr_from_coo(col, row, 50, 300)
+    H = rng.standard_normal((300, 32)).astype(np.float32)
+    assert rel_err(ops.spmm_raw(t(ip, dev), t(ix, dev), t(H, dev), 50), O().spmm_csr(ip, ix, H)) < TOL
+    # graph without edges: all-zero aggregate
+    ip0 = torch.zeros(11, dtype=torch.int32, device=dev); ix0 = torch.zeros(0, dtype=torch.int32, device=dev)
+    out = ops.spmm_raw(ip0, ix0, torch.randn(10, 32, device=dev), 10)
+    assert float(out.abs().max()) == 0.0
+    # zero rows / zero features
+    assert ops.spmm_raw(torch.zeros(1, dtype=torch.int32, device=dev), ix0, torch.randn(0, 8, device=dev), 0).shape == (0, 8)
+
+
+def test_spmm_properties_large(dev):
+    """size-independent properties at a size the oracle would not finish quickly:
+    A 1 = in-degree, linearity, transpose identity <A x, y> = <x, A^T y>."""
+    from gae_dgl_amd import ops
+    n, e, F = 1 << 20, 1 << 24, 32
+    gen = torch.Generator(device=dev).manual_seed(0)
+    src = torch.randint(0, n, (e,), device=dev, generator=gen)
+    dst = (torch.randint(0, n, (e,), device=dev, generator=gen) ** 2 // n)  # skewed degrees
+    ip, ix = ops.csr_from_coo(dst, src, n, n)
+    tp, tx = ops.csr_from_coo(src, dst, n, n)
+    assert int(ip[-1]) == e and int(tp[-1]) == e
+    assert bool((ip[1:] >= ip[:-1]).all())
+    deg, _ = ops.degree_norm(ip)
+    ones = torch.ones(n, F, device=dev)
+    out = ops.spmm_raw(ip, ix, ones, n)
+    assert torch.equal(out[:, 0], deg.float()) and torch.equal(out[:, F - 1], deg.float())
+    x = torch.randn(n, F, device=dev, generator=gen); y = torch.randn(n, F, device=dev, generator=gen)
+    ax, ay = ops.spmm_raw(ip, ix, x, n), ops.spmm_raw(ip, ix, y, n)
+    axy = ops.spmm_raw(ip, ix, 2 * x + y, n)
+    assert rel_err(axy, 2 * ax + ay) < TOL
+    aty = ops.spmm_raw(tp, tx, y, n)
+    lhs = float((ax.double() * y.double()).sum()); rhs = float((x.double() * aty.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+
+
+# ----------------------------------------------------------------- K3-K5 linear
+@pytest.mark.parametrize("n,fin,fout", [(1, 1, 1), (5, 7, 3), (200, 39, 32), (333, 32, 16), (1000, 500, 32),
+                                         (513, 1433, 32), (129, 100, 200), (4099, 16, 256)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_linear_fwd_bwd(n, fin, fout, act, dev):
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(n + fin)
+    M = rng.standard_normal((n, fin)).astype(np.float32)
+    W = (rng.standard_normal((fout, fin)) / np.sqrt(fin)).astype(np.float32)
+    b = rng.standard_normal(fout).astype(np.float32)
+    dY = rng.standard_normal((n, fout)).astype(np.float32)
+    Mt = torch.tensor(M, dtype=torch.float64, requires_grad=True)
+    Wt = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    Yref = Mt @ Wt.t() + bt
+    if act:
+        Yref = torch.relu(Yref)
+    Yref.backward(torch.tensor(dY, dtype=torch.float64))
+    Md = t(M, dev).requires_grad_(True); Wd = t(W, dev).requires_grad_(True); bd = t(b, dev).requires_grad_(True)
+    Y = ops.linear(Md, Wd, bd, act)
+    assert rel_err(Y, Yref) < TOL
+    # compare gradients where the ReLU mask agrees (fp32 vs fp64 sign flips at ~0 are measure-zero)
+    Y.backward(t(dY, dev))
+    assert rel_err(Wd.grad, Wt.grad) < 5 * TOL
+    assert rel_err(bd.grad, bt.grad) < 5 * TOL
+    assert rel_err(Md.grad, Mt.grad) < 5 * TOL
+
+
+def test_linear_odd_ld_and_no_bias(dev):
+    from gae_dgl_amd import ops
+    M = torch.randn(70, 45, device=dev)[:, :39]  # ld 45: scalar staging path
+    W = torch.randn(32, 39, device=dev)
+    Y = ops.linear(M, W, None, 1)
+    assert rel_err(Y, torch.relu(M.double().cpu() @ W.double().cpu().t())) < TOL
+
+
+# ----------------------------------------------------------------- K6/K7 decoder
+@pytest.mark.parametrize("n,d", [(1, 1), (6, 3), (200, 16), (1000, 16), (515, 48), (300, 130)])
+def test_decoder_dense_fwd_bwd(n, d, dev):
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(n)
+    Z = rng.standard_normal((n, d)).astype(np.float32)
+    mask = ((rng.random((n, d)) >= 0.1) / 0.9).astype(np.float32)
+    G = rng.standard_normal((n, n)).astype(np.float32)  # non-symmetric upstream gradient
+    for m in (None, mask):
+        Zt = torch.tensor(Z, dtype=torch.float64, requires_grad=True)
+        zz = Zt if m is None else Zt * torch.tensor(m, dtype=torch.float64)
+        ref = zz @ zz.t()
+        ref.backward(torch.tensor(G, dtype=torch.float64))
+        Zd = t(Z, dev).requires_grad_(True)
+        out = ops.decoder_dense(Zd, None if m is None else t(m, dev))
+        assert rel_err(out, ref) < TOL
+        assert rel_err(out, O().decoder_logits(Z, m)) < TOL
+        out.backward(t(G, dev))
+        assert rel_err(Zd.grad, Zt.grad) < 5 * TOL
+
+
+def test_dropout_mask_statistics_and_reproducibility(dev):
+    from gae_dgl_amd import ops
+    m1 = ops.dropout_mask((100000, 16), 0.1, seed=7, offset=0, device=dev)
+    m2 = ops.dropout_mask((100000, 16), 0.1, seed=7, offset=0, device=dev)
+    m3 = ops.dropout_mask((100000, 16), 0.1, seed=8, offset=0, device=dev)
+    assert torch.equal(m1, m2) and not torch.equal(m1, m3)
+    vals = torch.unique(m1).cpu().numpy()
+    assert len(vals) == 2 and vals[0] == 0.0 and np.isclose(vals[1], 1 / 0.9)
+    keep = float((m1 > 0).float().mean())
+    assert abs(keep - 0.9) < 2e-3
+    # counter-based: a shifted offset continues the same stream
+    a = ops.dropout_mask((4096,), 0.3, seed=1, offset=0, device=dev)
+    b = ops.dropout_mask((2048,), 0.3, seed=1, offset=512, device=dev)
+    assert torch.equal(a[2048:], b)
+    assert float(ops.dropout_mask((1000,), 0.0, 1, 0, dev).min()) == 1.0
+
+
+# ----------------------------------------------------------------- module-level parity (golden vectors)
+def build_model(g, dev):
+    import gae_dgl_amd as G
+    hidden = [int(h) for h in g["hidden"]]
+    model = G.GAE(g["X"].shape[1], hidden)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")}
+    model.load_state_dict(sd)  # reference checkpoint keys round-trip
+    return model.to(dev)
+
+
+def fresh_graph(g, dev):
+    import gae_dgl_amd as G
+    gr = G.DGLGraph()
+    gr.add_nodes(int(g["n"]))
+    gr.add_edges(g["src"], g["dst"])
+    gr.to(dev)
+    gr.ndata['h'] = t(g["X"], dev)
+    return gr
+
+
+def test_gae_encode_forward_side_effects(golden, dev):
+    g = golden
+    model = build_model(g, dev)
+    gr = fresh_graph(g, dev)
+    Z = model.encode(gr)
+    assert rel_err(Z, g["Z"]) < TOL
+    assert 'h' not in gr.ndata                      # A9: encode pops 'h'
+    model.decoder.dropout = 0.0
+    gr = fresh_graph(g, dev)
+    logits = model(gr)
+    assert rel_err(logits, g["logits_p0"]) < TOL
+    assert rel_err(gr.ndata['h'], g["Z"]) < TOL     # A9: forward leaves Z in ndata['h']
+    # injected reference mask (always-on dropout, also in eval mode: A8)
+    model.decoder.dropout = 0.1
+    model.decoder.mask = t(g["mask"], dev)
+    model.eval()
+    assert rel_err(model(fresh_graph(g, dev)), g["logits_p01"]) < TOL
+    model.decoder.mask = None
+    l1, l2 = model(fresh_graph(g, dev)), model(fresh_graph(g, dev))
+    if g["Z"].size > 40:
+        assert not torch.equal(l1, l2)              # dropout stays on in eval mode
+
+
+def test_gae_loss_and_grads(golden, dev):
+    import torch.nn.functional as F
+    g = golden
+    for tag, mask in (("p0", None), ("p01", g["mask"])):
+        model = build_model(g, dev)
+        model.decoder.dropout = 0.0 if mask is None else 0.1
+        model.decoder.mask = None if mask is None else t(mask, dev)
+        gr = fresh_graph(g, dev)
+        adj = gr.adjacency_matrix().to_dense()
+        assert np.array_equal(adj.cpu().numpy(), g["adj"])
+        assert torch.equal(adj, gr.dense_adjacency())
+        pw = (adj.shape[0] * adj.shape[0] - adj.sum()) / adj.sum()
+        assert rel_err(pw, g["pos_weight"]) < 1e-6
+        loss = F.binary_cross_entropy_with_logits(model(gr), adj, pos_weight=pw)
+        assert rel_err(loss, g["loss_" + tag]) < TOL
+        loss.backward()
+        for k, p in model.named_parameters():
+            assert rel_err(p.grad, g[f"grad_{tag}/{k}"]) < 5 * TOL, k
+
+
+def test_gae_three_adam_steps(golden, dev):
+    import torch.nn.functional as F
+    g = golden
+    model = build_model(g, dev)
+    model.decoder.dropout = 0.0
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    adj = t(g["adj"], dev); pw = t(g["pos_weight"], dev)
+    losses = []
+    for _ in range(3):
+        loss = F.binary_cross_entropy_with_logits(model(fresh_graph(g, dev)), adj, pos_weight=pw)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, g["adam3_losses"], rtol=5e-5)
+    for k, v in model.state_dict().items():
+        assert rel_err(v, g["sd_after3/" + k]) < 1e-4, k
+
+
+def test_norm_both_matches_oracle(dev):
+    import gae_dgl_amd as G
+    g = load_golden("sym200")
+    Ws, bs = golden_params(g)
+    n = int(g["n"])
+    ip, ix = O().csr_from_coo(g["src"], g["dst"], n)
+    norm = g["norm"].ravel()
+    ref = O().gae_encode(ip, ix, g["X"], Ws, bs, norm)
+    model = G.GAE(39, [32, 16], norm="both")
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")})
+    model.to(dev)
+    gr = fresh_graph(g, dev)
+    assert rel_err(model.encode(gr), ref) < TOL
+    assert np.array_equal(gr.in_degrees().cpu().numpy(), g["in_degrees"])
+
+
+def test_batch_on_device_matches_golden(dev):
+    import gae_dgl_amd as G
+    parts = load_golden("mol8_parts"); whole = load_golden("mol8")
+    gs = []
+    for i in range(int(parts["n_graphs"])):
+        gr = G.DGLGraph()
+        gr.add_nodes(int(parts[f"g{i}/n"])); gr.add_edges(parts[f"g{i}/src"], parts[f"g{i}/dst"])
+        gr.ndata['h'] = torch.from_numpy(parts[f"g{i}/X"])
+        gs.append(gr.to(dev))
+    bg = G.batch(gs)
+    model = build_model(whole, dev)
+    assert rel_err(model.encode(bg), whole["Z"]) < TOL
