@@ -116,6 +116,30 @@ def batch_gather(graph_ptr, ds_indptr, ds_indices, ds_feat, graph_ids, node_ptr,
     return out_indptr, out_indices, out_feat
 
 
+# ------------------------------------------------------------------ profiling hook
+class EventProfiler:
+    """Records a HIP event pair (on the launch stream) around selected C-ABI
+    calls; used by bench.py for the live per-kernel roofline numbers."""
+
+    def __init__(self):
+        self.records = {}
+
+    def wrap(self, key, fn):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.records.setdefault(key, []).append((e0, e1))
+        return out
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: [a.elapsed_time(b) * 1e-3 for a, b in v] for k, v in self.records.items()}
+
+
+profiler = None  # set to an EventProfiler to time launches
+
+
 # ------------------------------------------------------------------ raw kernels
 def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=None):
     """M = diag(row_scale) A diag(col_scale) H  (K1/K2)."""
@@ -128,8 +152,13 @@ def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=Non
     if out2 is not out:
         raise GaeHipError("spmm: `out` must be row-major with unit inner stride")
     with torch.cuda.device(H.device):
-        _lib.call("gae_spmm_csr", _ptr(indptr), _ptr(indices), n_rows, n_cols, _ptr(H), ldh, _ptr(out), ldm, F,
-                  _dtype_code(H), _ptr(row_scale), _ptr(col_scale), _stream())
+        def launch():
+            _lib.call("gae_spmm_csr", _ptr(indptr), _ptr(indices), n_rows, n_cols, _ptr(H), ldh, _ptr(out), ldm, F,
+                      _dtype_code(H), _ptr(row_scale), _ptr(col_scale), _stream())
+        if profiler is not None:
+            profiler.wrap(("spmm", n_rows, n_cols, F, str(H.dtype)), launch)
+        else:
+            launch()
     return out
 
 
