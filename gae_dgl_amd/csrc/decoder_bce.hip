@@ -1,0 +1,397 @@
+// K7+K8+K9 fused: inner-product decoder + weighted BCE-with-logits (mean) and
+// its gradient, without ever materialising the N x N logits or labels.
+//
+// Replaces, for training, the chain of gae_dgl/train_inductive.py:44-51
+//     adj = g.adjacency_matrix().to_dense(); pos_weight = (N^2 - sum adj)/sum adj
+//     adj_logits = model.forward(g)        (gae_dgl/gae.py:70-71: Zt Zt^T)
+//     loss = binary_cross_entropy_with_logits(adj_logits, adj, pos_weight=...)
+//     loss.backward()
+//
+// Math.  x_ij = zt_i . zt_j,  y_ij = #edges j->i  (CSR rows = destination):
+//   N^2 loss = sum_ij [(1 - y) x + (1 + (pw - 1) y) softplus(-x)]
+//            = sum_ij softplus(x_ij)                       <- dense, label-free
+//            + sum_{edges (i,j)} [-x_ij + (pw - 1) softplus(-x_ij)]   <- sparse
+//   dL/dx_ij = [sigmoid(x_ij) + y_ij ((pw - 1) sigmoid(x_ij) - pw)] / N^2
+//   dZt = (G + G^T) Zt   ->  dense part 2 sigmoid(X) Zt / N^2 (X symmetric)
+//                            sparse part over in-edges (CSR) and out-edges (CSR of A^T).
+//
+// Dense kernel: flash-style.  Wave owns RI 16-row subtiles, streams column tiles
+// through LDS, S^T = Zj Zi^T on v_mfma_f32_16x16x4_f32 (exact fp32), softplus /
+// sigmoid on the VALU, O += sigmoid(S) Zj on the same MFMA shape: the S^T
+// accumulator registers are directly the A fragments of the second product
+// (lane = row i, reg r <-> j = 4 (lane >> 4) + r), so P never leaves registers.
+// MFMA-bound (fp32 matrix rate), not HBM-bound: 4 KS (S) + 4 KS (PV) MFMAs per
+// 256 logits with KS = ceil(d / 16).
+// Reductions are two-stage and ordered: bit-stable run to run.
+#include "common.h"
+
+namespace {
+
+using gae::kWave;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TJ = 64;   // columns staged per iteration
+constexpr int RI = 2;    // 16-row subtiles per wave  -> 32 rows / wave, 128 rows / block
+constexpr int ROWS_PER_BLOCK = 4 * RI * 16;
+
+__device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
+{
+    const float e = __expf(-fabsf(x));
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    sp = fmaxf(x, 0.f) + __logf(1.0f + e);
+    sg = (x >= 0.f ? 1.0f : e) * r;
+}
+
+// ---------------------------------------------------------------------------
+template <int KS, bool WITH_GRAD>
+__global__ __launch_bounds__(256) void bce_dense_kernel(
+    const float *__restrict__ Z, const float *__restrict__ mask, int64_t ldz, int64_t n, int d,
+    int64_t cols_per_split, float *__restrict__ O_partial /*[splits][n][KS*16]*/,
+    double *__restrict__ loss_partial /*[gridDim.x * gridDim.y]*/)
+{
+    constexpr int DP = KS * 16;          // padded feature width
+    constexpr int LDA = DP + 4;          // Zs row stride (floats)
+    constexpr int LDT = TJ + 4;          // ZsT row stride
+    __shared__ __attribute__((aligned(16))) float Zs[TJ * LDA];    // [j][k]
+    __shared__ __attribute__((aligned(16))) float ZsT[DP * LDT];   // [k][j]
+    __shared__ double red[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int64_t row_base = int64_t(blockIdx.x) * ROWS_PER_BLOCK + wave * (RI * 16);
+    const int64_t col_begin = int64_t(blockIdx.y) * cols_per_split;
+    int64_t col_end = col_begin + cols_per_split;
+    if (col_end > n) col_end = n;
+
+    // B fragments of S^T = Zj Zi^T: lane (i = l15, g) holds Zt[i][16 c + 4 g + r]
+    f32x4 bfrag[RI][KS];
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri) {
+        const int64_t i = row_base + ri * 16 + l15;
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * c + 4 * g + r;
+                float v = 0.f;
+                if (i < n && k < d) {
+                    v = Z[i * ldz + k];
+                    if (mask) v *= mask[i * ldz + k];
+                }
+                bfrag[ri][c][r] = v;
+            }
+        }
+    }
+    f32x4 oacc[RI][KS];
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+        for (int c = 0; c < KS; ++c) oacc[ri][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    double lsum = 0.0;
+
+    for (int64_t j0 = col_begin; j0 < col_end; j0 += TJ) {
+        // ---- stage Zt[j0 .. j0+TJ) in both layouts (zero beyond n / d)
+        for (int idx = tid; idx < TJ * DP; idx += 256) {
+            const int jj = idx / DP, k = idx - jj * DP;
+            const int64_t j = j0 + jj;
+            float v = 0.f;
+            if (j < col_end && k < d) {
+                v = Z[j * ldz + k];
+                if (mask) v *= mask[j * ldz + k];
+            }
+            Zs[jj * LDA + k] = v;
+            ZsT[k * LDT + jj] = v;
+        }
+        __syncthreads();
+        const bool full = j0 + TJ <= col_end;
+#pragma unroll
+        for (int jt = 0; jt < TJ / 16; ++jt) {
+            // A fragments: lane (j = l15, g) -> Zs[jt*16 + j][16 c + 4 g .. +3]
+            f32x4 afrag[KS];
+#pragma unroll
+            for (int c = 0; c < KS; ++c)
+                afrag[c] = *reinterpret_cast<const f32x4 *>(&Zs[(jt * 16 + l15) * LDA + 16 * c + 4 * g]);
+            f32x4 sacc[RI];
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri) sacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < KS; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ri = 0; ri < RI; ++ri)
+                        sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[c][r], bfrag[ri][c][r], sacc[ri], 0, 0, 0);
+            // sacc[ri][r] = x(i = l15, j = jt*16 + 4 g + r)
+            f32x4 p[RI];
+            float tsum = 0.f;
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sp, sg;
+                    softplus_sigmoid(sacc[ri][r], sp, sg);
+                    if (!full) {
+                        const bool jv = j0 + jt * 16 + 4 * g + r < col_end;
+                        sp = jv ? sp : 0.f;
+                        sg = jv ? sg : 0.f;
+                    }
+                    tsum += sp * ((row_base + ri * 16 + l15) < n ? 1.f : 0.f);
+                    p[ri][r] = sg;
+                }
+            lsum += double(tsum);
+            if (WITH_GRAD) {
+                // B fragments of O += P V: lane (nn = l15, g) -> V[jt*16 + 4 g + r][16 c + nn] = ZsT[16 c + nn][jt*16 + 4 g ..]
+#pragma unroll
+                for (int c = 0; c < KS; ++c) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(&ZsT[(16 * c + l15) * LDT + jt * 16 + 4 * g]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int ri = 0; ri < RI; ++ri)
+                            oacc[ri][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[ri][r], v[r], oacc[ri][c], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- O partial: oacc[ri][c][r] = O(i = 4 g + r, nn = l15) of subtile ri, feature 16 c + nn
+    if (WITH_GRAD) {
+        float *op = O_partial + int64_t(blockIdx.y) * n * DP;
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = row_base + ri * 16 + 4 * g + r;
+                if (i < n) {
+#pragma unroll
+                    for (int c = 0; c < KS; ++c) op[i * DP + 16 * c + l15] = oacc[ri][c][r];
+                }
+            }
+    }
+    // ---- loss partial: wave reduce (fixed tree) -> block
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) loss_partial[int64_t(blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------
+// Sparse part + assembly.  A group of LPR lanes owns node i (VEC features per
+// lane): in-edges from the CSR give the loss terms and G_s Zt, out-edges from
+// the CSR of A^T give G_s^T Zt; then
+//   dZ[i] = mask[i] * ( 2 sum_splits O[s][i] + sparse ) / N^2.
+// ---------------------------------------------------------------------------
+template <int VEC, int LPR, bool WITH_GRAD>
+__global__ __launch_bounds__(256) void bce_edges_kernel(
+    const float *__restrict__ Z, const float *__restrict__ mask, int64_t ldz, int64_t n, int d,
+    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const int32_t *__restrict__ t_indptr, const int32_t *__restrict__ t_indices, float pw, float inv_n2,
+    const float *__restrict__ O_partial, int n_splits, int DP, float *__restrict__ dZ, int64_t lddz,
+    double *__restrict__ loss_partial)
+{
+    __shared__ double red[4];
+    constexpr int RPB = 256 / LPR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lig = tid % LPR;
+    const int64_t i = int64_t(blockIdx.x) * RPB + tid / LPR;
+    const int f0 = lig * VEC;
+    const bool rowv = i < n;
+
+    float zi[VEC], acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        acc[q] = 0.f;
+        float v = 0.f;
+        if (rowv && f0 + q < d) {
+            v = Z[i * ldz + f0 + q];
+            if (mask) v *= mask[i * ldz + f0 + q];
+        }
+        zi[q] = v;
+    }
+    double lsum = 0.0;
+    auto edge = [&](int32_t j, bool with_loss) {
+        float zj[VEC];
+        float dot = 0.f;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float v = 0.f;
+            if (f0 + q < d) {
+                v = Z[int64_t(j) * ldz + f0 + q];
+                if (mask) v *= mask[int64_t(j) * ldz + f0 + q];
+            }
+            zj[q] = v;
+            dot = fmaf(zi[q], v, dot);
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+        const float x = dot;
+        float spn, sgn;               // softplus(-x), sigmoid(-x)
+        softplus_sigmoid(-x, spn, sgn);
+        const float sg = 1.0f - sgn;  // sigmoid(x)
+        if (with_loss && lig == 0) lsum += double(-x + (pw - 1.0f) * spn);
+        const float c = (pw - 1.0f) * sg - pw;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = fmaf(c, zj[q], acc[q]);
+    };
+    if (rowv) {
+        for (int32_t e = indptr[i]; e < indptr[i + 1]; ++e) edge(indices[e], true);
+        if (WITH_GRAD)
+            for (int32_t e = t_indptr[i]; e < t_indptr[i + 1]; ++e) edge(t_indices[e], false);
+    }
+    if (WITH_GRAD && rowv) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int f = f0 + q;
+            if (f < d) {
+                float o = 0.f;
+                for (int s = 0; s < n_splits; ++s) o += O_partial[(int64_t(s) * n + i) * DP + f];
+                float v = (2.0f * o + acc[q]) * inv_n2;
+                if (mask) v *= mask[i * ldz + f];
+                dZ[i * lddz + f] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) loss_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// single block: ordered sum of all partials -> mean
+__global__ __launch_bounds__(256) void bce_finalize_kernel(const double *__restrict__ partial, int64_t count,
+                                                           double inv_n2, float *__restrict__ loss_out)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t k = threadIdx.x; k < count; k += 256) s += partial[k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (int(threadIdx.x) < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_out = float(red[0] * inv_n2);
+}
+
+struct BcePlan {
+    int64_t row_blocks, n_splits, cols_per_split, edge_blocks;
+    int KS, DP, LPR, VEC;
+    int64_t o_bytes, loss_count, total_bytes;
+};
+
+inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+
+bool bce_plan(int64_t n, int64_t d, bool vec_ok, BcePlan &p)
+{
+    if (d > 64) return false;
+    p.KS = int((d + 15) / 16);
+    if (p.KS == 3) p.KS = 4;
+    if (p.KS < 1) p.KS = 1;
+    p.DP = p.KS * 16;
+    p.row_blocks = (n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    if (p.row_blocks < 1) p.row_blocks = 1;
+    int64_t col_tiles = (n + TJ - 1) / TJ;
+    if (col_tiles < 1) col_tiles = 1;
+    int64_t want = (2048 + p.row_blocks - 1) / p.row_blocks;  // ~8 blocks per CU
+    if (want > col_tiles) want = col_tiles;
+    if (want > 64) want = 64;
+    if (want < 1) want = 1;
+    const int64_t tiles_per_split = (col_tiles + want - 1) / want;
+    p.cols_per_split = tiles_per_split * TJ;
+    p.n_splits = (col_tiles + tiles_per_split - 1) / tiles_per_split;
+    p.VEC = vec_ok ? 4 : 1;
+    const int nvec = int((d + p.VEC - 1) / p.VEC);
+    int lpr = 1;
+    while (lpr < nvec) lpr <<= 1;
+    p.LPR = lpr;
+    p.edge_blocks = (n + (256 / lpr) - 1) / (256 / lpr);
+    if (p.edge_blocks < 1) p.edge_blocks = 1;
+    p.o_bytes = align256(p.n_splits * n * p.DP * 4);
+    p.loss_count = p.row_blocks * p.n_splits + p.edge_blocks;
+    p.total_bytes = p.o_bytes + align256(p.loss_count * 8);
+    return true;
+}
+
+template <bool WITH_GRAD>
+int launch_dense(const BcePlan &p, const float *Z, const float *mask, int64_t ldz, int64_t n, int d, float *O,
+                 double *lp, hipStream_t s)
+{
+    const dim3 grid(unsigned(p.row_blocks), unsigned(p.n_splits));
+    switch (p.KS) {
+    case 1: hipLaunchKernelGGL((bce_dense_kernel<1, WITH_GRAD>), grid, dim3(256), 0, s, Z, mask, ldz, n, d, p.cols_per_split, O, lp); break;
+    case 2: hipLaunchKernelGGL((bce_dense_kernel<2, WITH_GRAD>), grid, dim3(256), 0, s, Z, mask, ldz, n, d, p.cols_per_split, O, lp); break;
+    default: hipLaunchKernelGGL((bce_dense_kernel<4, WITH_GRAD>), grid, dim3(256), 0, s, Z, mask, ldz, n, d, p.cols_per_split, O, lp); break;
+    }
+    GAE_CHECK_LAUNCH("bce_dense_kernel");
+    return GAE_OK;
+}
+
+template <int VEC, bool WITH_GRAD>
+int launch_edges(const BcePlan &p, const float *Z, const float *mask, int64_t ldz, int64_t n, int d,
+                 const int32_t *ip, const int32_t *ix, const int32_t *tp, const int32_t *tx, float pw, float inv_n2,
+                 const float *O, float *dZ, int64_t lddz, double *lp, hipStream_t s)
+{
+#define GAE_EDGE(LPR)                                                                                              \
+    hipLaunchKernelGGL((bce_edges_kernel<VEC, LPR, WITH_GRAD>), dim3(unsigned(p.edge_blocks)), dim3(256), 0, s, Z,  \
+                       mask, ldz, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, dZ, lddz, lp)
+    switch (p.LPR) {
+    case 1: GAE_EDGE(1); break;
+    case 2: GAE_EDGE(2); break;
+    case 4: GAE_EDGE(4); break;
+    case 8: GAE_EDGE(8); break;
+    case 16: GAE_EDGE(16); break;
+    case 32: GAE_EDGE(32); break;
+    default: GAE_EDGE(64); break;
+    }
+#undef GAE_EDGE
+    GAE_CHECK_LAUNCH("bce_edges_kernel");
+    return GAE_OK;
+}
+
+} // namespace
+
+extern "C" int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t d)
+{
+    if (n < 0 || d < 0) return GAE_E_SIZE;
+    BcePlan p;
+    if (!bce_plan(n, d, true, p)) return GAE_E_RANGE;
+    return p.total_bytes + 256;
+}
+
+extern "C" int gae_decoder_bce(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
+                               const int32_t *indptr, const int32_t *indices, const int32_t *t_indptr,
+                               const int32_t *t_indices, float pos_weight, float *loss_out, float *dZ, int64_t lddz,
+                               void *workspace, int64_t workspace_bytes, void *stream)
+{
+    GAE_REQUIRE(n > 0 && d > 0, GAE_E_SIZE, "gae_decoder_bce: n and d must be positive");
+    GAE_REQUIRE(d <= 64, GAE_E_RANGE, "gae_decoder_bce: d = %lld > 64 not supported by the fused kernel",
+                (long long)d);
+    GAE_REQUIRE(n < (int64_t(1) << 31), GAE_E_SIZE, "gae_decoder_bce: n too large");
+    GAE_REQUIRE(ldz >= d && (!dZ || lddz >= d), GAE_E_SIZE, "gae_decoder_bce: leading dimension too small");
+    GAE_REQUIRE(Z && indptr && loss_out && workspace, GAE_E_NULL, "gae_decoder_bce: NULL pointer");
+    GAE_REQUIRE(!dZ || t_indptr, GAE_E_NULL, "gae_decoder_bce: the gradient needs the CSR of A^T");
+    const bool vec_ok = true;  // the edge kernel uses scalar loads per feature; VEC only sets lanes per row
+    BcePlan p;
+    bce_plan(n, d, vec_ok, p);
+    GAE_REQUIRE(workspace_bytes >= p.total_bytes, GAE_E_WORKSPACE, "gae_decoder_bce: workspace %lld < %lld bytes",
+                (long long)workspace_bytes, (long long)p.total_bytes);
+    GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_decoder_bce: workspace not 16-byte aligned");
+    hipStream_t s = gae::as_stream(stream);
+    float *O = static_cast<float *>(workspace);
+    double *lp = reinterpret_cast<double *>(static_cast<char *>(workspace) + p.o_bytes);
+    const double inv_n2 = 1.0 / (double(n) * double(n));
+    int rc = dZ ? launch_dense<true>(p, Z, mask, ldz, n, int(d), O, lp, s)
+                : launch_dense<false>(p, Z, mask, ldz, n, int(d), O, lp, s);
+    if (rc) return rc;
+    double *lpe = lp + p.row_blocks * p.n_splits;
+    rc = dZ ? launch_edges<4, true>(p, Z, mask, ldz, n, int(d), indptr, indices, t_indptr, t_indices, pos_weight,
+                                    float(inv_n2), O, dZ, lddz, lpe, s)
+            : launch_edges<4, false>(p, Z, mask, ldz, n, int(d), indptr, indices, t_indptr, t_indices, pos_weight,
+                                     float(inv_n2), O, dZ, lddz, lpe, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(256), 0, s, lp, p.loss_count, inv_n2, loss_out);
+    GAE_CHECK_LAUNCH("bce_finalize_kernel");
+    return GAE_OK;
+}

@@ -106,6 +106,18 @@ class GAE(nn.Module):
             h = conv(g, h)
         return h
 
+    def reconstruction_loss(self, g):
+        """The training loss of train_inductive.py:44-48 (dense label from g,
+        pos_weight, BCE-with-logits mean over all N^2 ordered pairs) evaluated
+        by the fused HIP kernel: numerically the same quantity as
+        ``BCELoss(self.forward(g), adj, pos_weight)`` without the N x N logits /
+        label matrices.  Side effect on ``g.ndata['h']`` as in forward()."""
+        h = g.ndata['h']
+        for conv in self.layers:
+            h = conv(g, h)
+        g.ndata['h'] = h
+        return self.decoder.loss(h, g)
+
 
 class InnerProductDecoder(nn.Module):
     """gae.py:63-72.  Dropout is applied regardless of train()/eval() exactly
@@ -137,3 +149,9 @@ class InnerProductDecoder(nn.Module):
         self.last_mask = mask
         adj = self.activation(ops.decoder_dense(z, mask))
         return adj
+
+    def loss(self, z, g):
+        """fused decoder + weighted BCE (identity activation = logits, gae.py:47)"""
+        mask = self._draw_mask(z)
+        self.last_mask = mask
+        return ops.decoder_bce(z, mask, g)

@@ -55,6 +55,9 @@ class Graph:
     def _init_from(self, data, num_nodes):
         if isinstance(data, (tuple, list)) and len(data) == 2:
             src, dst = data
+        elif hasattr(data, "src") and hasattr(data, "dst") and hasattr(data, "number_of_nodes"):
+            src, dst = data.src, data.dst
+            num_nodes = data.number_of_nodes() if num_nodes is None else num_nodes
         elif hasattr(data, "edges") and hasattr(data, "number_of_nodes"):  # networkx
             g = data if data.is_directed() else data.to_directed()
             num_nodes = g.number_of_nodes() if num_nodes is None else num_nodes
@@ -73,6 +76,7 @@ class Graph:
         self._cache.clear()
 
     def add_edges(self, u, v):
+        self._edge_list()
         u = _as_index(u, self._device); v = _as_index(v, self._device)
         if u.numel() != v.numel():
             raise ValueError("add_edges: src/dst length mismatch")
@@ -86,6 +90,8 @@ class Graph:
         return self._n
 
     def number_of_edges(self):
+        if self._src is None:
+            return int(self._cache["csr"][1].numel())
         return int(self._src.numel())
 
     def __len__(self):
@@ -95,13 +101,24 @@ class Graph:
     def device(self):
         return self._device
 
-    def edges(self):
+    def _edge_list(self):
+        """(src, dst) int64; expanded from the CSR when the graph was built by the
+        device batcher (rows = destination, CSR order)"""
+        if self._src is None:
+            indptr, indices = self._cache["csr"]
+            counts = (indptr[1:] - indptr[:-1]).to(torch.int64)
+            self._dst = torch.repeat_interleave(torch.arange(self._n, device=self._device), counts)
+            self._src = indices.to(torch.int64)
         return self._src, self._dst
+
+    def edges(self):
+        return self._edge_list()
 
     def to(self, device):
         """in place like DGL 0.4 (the reference discards the result, train_inductive.py:33)"""
         device = torch.device(device)
         if device != self._device:
+            self._edge_list()
             self._device = device
             self._src = self._src.to(device); self._dst = self._dst.to(device)
             self.ndata = {k: v.to(device) for k, v in self.ndata.items()}
@@ -132,6 +149,7 @@ class Graph:
         if "csr" not in self._cache:
             from . import ops
             self._require_gpu("csr")
+            self._edge_list()
             self._cache["csr"] = ops.csr_from_coo(self._dst, self._src, self._n, self._n)
         return self._cache["csr"]
 
@@ -140,6 +158,7 @@ class Graph:
         if "csc" not in self._cache:
             from . import ops
             self._require_gpu("csc")
+            self._edge_list()
             self._cache["csc"] = ops.csr_from_coo(self._src, self._dst, self._n, self._n)
         return self._cache["csc"]
 
@@ -164,6 +183,7 @@ class Graph:
     def adjacency_matrix(self, transpose=False):
         """sparse COO [N, N]; rows = destination, cols = source (DGL 0.4
         ``transpose=False``); ``.to_dense()`` adds duplicate edges."""
+        self._edge_list()
         r, c = (self._src, self._dst) if transpose else (self._dst, self._src)
         vals = torch.ones(r.numel(), dtype=torch.float32, device=self._device)
         return torch.sparse_coo_tensor(torch.stack([r, c]), vals, (self._n, self._n))

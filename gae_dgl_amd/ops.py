@@ -229,6 +229,34 @@ def decoder_dense_bwd_raw(G, Z, mask=None):
     return dZ
 
 
+def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True):
+    """fused decoder + weighted BCE (mean): returns (loss[1], dZ or None)"""
+    Z = _gpu(Z, "Z").contiguous()
+    if mask is not None:
+        mask = _gpu(mask, "mask").contiguous()
+    n, d = Z.shape
+    dev = Z.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dZ = torch.empty(n, d, dtype=torch.float32, device=dev) if want_grad else None
+    indptr, indices = csr
+    t_indptr, t_indices = csc if csc is not None else (None, None)
+    with torch.cuda.device(dev):
+        nbytes = _lib.load().gae_decoder_bce_workspace_bytes(n, d)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "gae_decoder_bce_workspace_bytes")
+        ws = _workspace(nbytes, dev)
+
+        def launch():
+            _lib.call("gae_decoder_bce", _ptr(Z), _ptr(mask), max(d, 1), n, d, _ptr(indptr), _ptr(indices),
+                      _ptr(t_indptr), _ptr(t_indices), float(pos_weight), _ptr(loss), _ptr(dZ), max(d, 1),
+                      _ptr(ws), ws.numel(), _stream())
+        if profiler is not None:
+            profiler.wrap(("decoder_bce", n, d, want_grad), launch)
+        else:
+            launch()
+    return loss, dZ
+
+
 # ------------------------------------------------------------------ autograd glue
 class SpMMFunction(torch.autograd.Function):
     """update_all(copy_src, sum) with its backward  dH = A^T dM  (gae.py:28)."""
@@ -280,6 +308,31 @@ class DecoderDenseFunction(torch.autograd.Function):
     def backward(ctx, G):
         Z, mask = ctx.saved_tensors
         return decoder_dense_bwd_raw(G, Z, mask), None
+
+
+class DecoderBCEFunction(torch.autograd.Function):
+    """train_inductive.py:44-48 fused: label from the graph's CSR, pos_weight,
+    (Z m)(Z m)^T, BCE-with-logits mean.  The gradient w.r.t. Z is produced by
+    the same launch sequence as the loss (flash-style) and scaled in backward."""
+
+    @staticmethod
+    def forward(ctx, Z, mask, graph):
+        n = graph.number_of_nodes()
+        nnz = graph.number_of_edges()
+        pw = (float(n) * float(n) - float(nnz)) / float(nnz)      # train_inductive.py:46
+        need = ctx.needs_input_grad[0]
+        loss, dZ = decoder_bce_raw(Z, mask, graph.csr(), graph.csc() if need else None, pw, want_grad=need)
+        ctx.save_for_backward(dZ)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dZ,) = ctx.saved_tensors
+        return dZ * g, None, None
+
+
+def decoder_bce(Z, mask, graph):
+    return DecoderBCEFunction.apply(Z, mask, graph)
 
 
 def spmm(graph, H, use_norm=False):

@@ -157,6 +157,23 @@ int gae_decoder_dense_bwd(const float *G, int64_t ldg, const float *Z, const flo
                           int64_t ldz, int64_t n, int64_t d, float *dZ, int64_t lddz,
                           void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- K7+K8+K9 fused: decoder + weighted BCE-with-logits, never materialising N x N
+ * Replaces, for training, gae_dgl/train_inductive.py:44-51:
+ *   adj = g.adjacency_matrix().to_dense(); pos_weight = (N^2 - sum(adj)) / sum(adj)
+ *   loss = binary_cross_entropy_with_logits(model.forward(g), adj, pos_weight=pos_weight); loss.backward()
+ * loss = mean_ij [(1-y) x + (1 + (pw-1) y) softplus(-x)],  x = (Zt Zt^T)_ij, Zt = Z (.) mask,
+ * y_ij = #edges j->i read from the CSR (rows = destination; duplicates count).
+ *   loss_out : 1 fp32 on the device
+ *   dZ       : d loss / d Z  [n, d] (NULL = loss only, e.g. validation); needs the
+ *              CSR of A^T (t_indptr, t_indices) for the G^T term
+ *   d <= 64.  Ordered two-stage reductions: deterministic. */
+int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t d);
+int gae_decoder_bce(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
+                    const int32_t *indptr, const int32_t *indices,
+                    const int32_t *t_indptr, const int32_t *t_indices, float pos_weight,
+                    float *loss_out, float *dZ, int64_t lddz,
+                    void *workspace, int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
