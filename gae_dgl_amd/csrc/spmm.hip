@@ -15,6 +15,8 @@
 // 8 lanes x float4 = one 128-B line).  Sums run in CSR order in fp32 without
 // atomics: results are bit-stable run to run.  Block ids are remapped so that
 // each XCD (private L2) owns a contiguous row range.
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -35,11 +37,17 @@ struct VecIO<float, 4> {
     {
         *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    static __device__ __forceinline__ void store_nt(float *p, const float (&v)[4])
+    {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4 *>(p));
+    }
 };
 template <>
 struct VecIO<float, 1> {
     static __device__ __forceinline__ void load(const float *p, float (&v)[1]) { v[0] = *p; }
     static __device__ __forceinline__ void store(float *p, const float (&v)[1]) { *p = v[0]; }
+    static __device__ __forceinline__ void store_nt(float *p, const float (&v)[1]) { __builtin_nontemporal_store(v[0], p); }
 };
 template <>
 struct VecIO<unsigned short, 8> {
@@ -61,6 +69,7 @@ struct VecIO<unsigned short, 8> {
             w[i] = unsigned(gae::f32_to_bf16(v[2 * i])) | (unsigned(gae::f32_to_bf16(v[2 * i + 1])) << 16);
         *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    static __device__ __forceinline__ void store_nt(unsigned short *p, const float (&v)[8]) { store(p, v); }
 };
 template <>
 struct VecIO<unsigned short, 1> {
@@ -72,6 +81,7 @@ struct VecIO<unsigned short, 1> {
     {
         *p = gae::f32_to_bf16(v[0]);
     }
+    static __device__ __forceinline__ void store_nt(unsigned short *p, const float (&v)[1]) { store(p, v); }
 };
 
 __device__ __forceinline__ void store_scalar(float *p, float v) { *p = v; }
@@ -161,6 +171,213 @@ __global__ __launch_bounds__(256) void spmm_rowgroup_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// v2 "rowgroup2": same ownership (LPR lanes own RPG rows), but
+//   * neighbour ids are fetched by ONE coalesced load per group and batch (lane
+//     u of the group loads indices[pos + u]) and broadcast with ds_bpermute /
+//     readlane instead of every lane re-loading them;
+//   * the neighbour rows of a batch (up to NB per owned row, RPG rows) are all
+//     issued before the first is consumed, with predication instead of a
+//     serial tail loop: one HBM round trip per batch instead of one per edge;
+//   * for LPR == 64 the row, its edge range and the neighbour base addresses
+//     are wave-uniform (SGPR) values.
+// Summation order is unchanged (CSR order), so results are bit-identical to v1.
+// ---------------------------------------------------------------------------
+template <typename T, int VEC, int LPR, int CH, int RPG, bool SCALED, bool NT_STORE>
+__global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
+    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t n_rows,
+    const T *__restrict__ H, int64_t ldh, T *__restrict__ M, int64_t ldm, int F,
+    const float *__restrict__ row_scale, const float *__restrict__ col_scale, unsigned n_row_blocks,
+    unsigned n_ftiles, int xcd_tiled)
+{
+    constexpr int GPB = 256 / LPR;            // groups per block
+    constexpr int RPB = GPB * RPG;            // rows per block
+    constexpr int TILE = LPR * VEC;
+    constexpr int NB = LPR >= 4 ? 4 : LPR;    // neighbours per batch and row
+    unsigned blk, ftile;
+    if (xcd_tiled) {
+        // Feature-tiled XCD mapping: XCD x (= blockIdx % 8) owns feature tiles x, x+8, ... and sweeps all
+        // row blocks of one tile before the next, so the tile's slice of H (n_cols * TILE * 4 bytes) stays
+        // resident in that XCD's private 4 MiB L2 while it is gathered.
+        const unsigned xcd = blockIdx.x % gae::kNumXcd, k = blockIdx.x / gae::kNumXcd;
+        const unsigned tl = k / n_row_blocks;
+        blk = k - tl * n_row_blocks;
+        ftile = xcd + gae::kNumXcd * tl;
+        if (ftile >= n_ftiles) return;
+    } else {
+        blk = gae::xcd_remap(blockIdx.x, gridDim.x);
+        ftile = blockIdx.y;
+    }
+    const int lig = threadIdx.x % LPR;
+    int grp = threadIdx.x / LPR;
+    if (LPR == 64) grp = __builtin_amdgcn_readfirstlane(grp);
+    const int glane0 = (threadIdx.x & 63) - lig;  // first lane of this group inside the wave
+    const int f0 = ftile * (CH * TILE) + lig * VEC;
+
+    bool live[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) live[c] = (f0 + c * TILE) < F;
+
+    int64_t row[RPG];
+    int32_t pos[RPG], end[RPG];
+    float acc[RPG][CH][VEC];
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        row[r] = int64_t(blk) * RPB + r * GPB + grp;
+        const bool rv = row[r] < n_rows;
+        pos[r] = rv ? indptr[row[r]] : 0;
+        end[r] = rv ? indptr[row[r] + 1] : 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[r][c][i] = 0.f;
+    }
+
+    for (;;) {
+        int rem_max = 0;
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) rem_max = max(rem_max, end[r] - pos[r]);
+        if (rem_max <= 0) break;
+        // ---- one coalesced index load per owned row
+        int32_t myidx[RPG];
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) {
+            const int32_t e = pos[r] + (LPR >= 4 ? (lig & 3) : lig);
+            myidx[r] = e < end[r] ? indices[e] : 0;
+        }
+        float v[RPG][NB][CH][VEC];
+        float cs[RPG][NB];
+#pragma unroll
+        for (int r = 0; r < RPG; ++r)
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                int32_t j;
+                if (LPR == 64) j = __builtin_amdgcn_readlane(myidx[r], u);
+                else j = __shfl(myidx[r], glane0 + u, 64);
+                const bool ev = pos[r] + u < end[r];
+                if (SCALED) cs[r][u] = ev ? col_scale[j] : 0.f;
+                const T *hp = H + int64_t(j) * ldh + f0;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if (ev && live[c]) {
+                        VecIO<T, VEC>::load(hp + c * TILE, v[r][u][c]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[r][u][c][i] = 0.f;
+                    }
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const bool ev = pos[r] + u < end[r];
+                if (ev) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i)
+                            acc[r][c][i] = SCALED ? fmaf(cs[r][u], v[r][u][c][i], acc[r][c][i])
+                                                  : acc[r][c][i] + v[r][u][c][i];
+                }
+            }
+            pos[r] = min(pos[r] + NB, end[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        if (row[r] >= n_rows) continue;
+        const float rs = SCALED ? row_scale[row[r]] : 1.f;
+        T *mp = M + row[r] * ldm + f0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (!live[c]) continue;
+            if (SCALED) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[r][c][i] *= rs;
+            }
+            const int f = f0 + c * TILE;
+            if (VEC == 1 || f + VEC <= F) {
+                if (NT_STORE) VecIO<T, VEC>::store_nt(mp + c * TILE, acc[r][c]);
+                else VecIO<T, VEC>::store(mp + c * TILE, acc[r][c]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    if (f + i < F) store_scalar(mp + c * TILE + i, acc[r][c][i]);
+            }
+        }
+    }
+}
+
+// tuning knobs (gae_tuning_set): read-mostly process-wide integers
+int g_spmm_variant = 2;   // 1 = v1 rowgroup, 2 = v2 rowgroup2
+int g_spmm_rpg = 2;       // rows per group (v2)
+int g_spmm_nt = 1;        // non-temporal stores of M (v2)
+int g_spmm_tile_vecs = 0; // 16-byte vectors per XCD feature tile (0 auto, -1 off)
+
+template <typename T, int VEC, int LPR, int CH, int RPG>
+int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
+                     int64_t ldm, int F, const float *rs, const float *cs, bool nt, bool tiled, hipStream_t s)
+{
+    constexpr int RPB = (256 / LPR) * RPG;
+    const int nvec = (F + VEC - 1) / VEC;
+    const unsigned nrb = unsigned((n_rows + RPB - 1) / RPB), nft = unsigned((nvec + LPR * CH - 1) / (LPR * CH));
+    const dim3 grid = tiled ? dim3(gae::kNumXcd * ((nft + gae::kNumXcd - 1) / gae::kNumXcd) * nrb) : dim3(nrb, nft);
+    const int xt = tiled ? 1 : 0;
+#define GAE_L2(SC, NT)                                                                                              \
+    hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, NT>), grid, dim3(256), 0, s, indptr, indices, \
+                       n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt)
+    if (rs || cs) { if (nt) GAE_L2(true, true); else GAE_L2(true, false); }
+    else { if (nt) GAE_L2(false, true); else GAE_L2(false, false); }
+#undef GAE_L2
+    GAE_CHECK_LAUNCH("spmm_rowgroup2_kernel");
+    return GAE_OK;
+}
+
+template <typename T, int VEC>
+int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
+                       int64_t ldm, int F, const float *rs, const float *cs, int rpg, bool nt, int64_t n_cols,
+                       hipStream_t s)
+{
+    const int nvec = (F + VEC - 1) / VEC;
+    bool tiled = false;
+#define GAE_RG2(LPR, CH)                                                                                          \
+    do {                                                                                                          \
+        if (rpg >= 2 && CH == 1)                                                                                  \
+            return launch_rowgroup2<T, VEC, LPR, CH, 2>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt,   \
+                                                        tiled, s);                                                \
+        return launch_rowgroup2<T, VEC, LPR, CH, 1>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt, tiled, \
+                                                    s);                                                           \
+    } while (0)
+    // Wide rows whose per-tile slice of H fits one XCD's L2: feature-tiled XCD mapping.
+    {
+        int tv = g_spmm_tile_vecs;  // vectors (16 B) per feature tile; 0 = auto, < 0 = off
+        if (tv == 0 && nvec > 16) {
+            const int64_t budget = int64_t(5) << 19;  // 2.5 MiB of a 4 MiB L2
+            for (int cand : {32, 16, 8, 4})
+                if (n_cols * cand * 16 <= budget && (nvec + cand - 1) / cand >= 8) { tv = cand; break; }
+        }
+        if (tv > 0 && (nvec + tv - 1) / tv >= 2) {
+            tiled = true;
+            if (tv <= 4) GAE_RG2(4, 1);
+            if (tv <= 8) GAE_RG2(8, 1);
+            if (tv <= 16) GAE_RG2(16, 1);
+            if (tv <= 32) GAE_RG2(32, 1);
+            GAE_RG2(64, 1);
+        }
+    }
+    if (nvec <= 4) GAE_RG2(4, 1);
+    if (nvec <= 8) GAE_RG2(8, 1);
+    if (nvec <= 16) GAE_RG2(16, 1);
+    if (nvec <= 32) GAE_RG2(32, 1);
+    if (nvec <= 64) GAE_RG2(64, 1);
+    if (nvec <= 128) GAE_RG2(64, 2);
+    GAE_RG2(64, 4);
+#undef GAE_RG2
+}
+
+
 template <typename T, int VEC, int LPR, int CH>
 int launch_rowgroup(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
                     int64_t ldm, int F, const float *rs, const float *cs, hipStream_t s)
@@ -220,13 +437,43 @@ extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64
         const float *h = static_cast<const float *>(H);
         float *m = static_cast<float *>(M);
         const bool vec = (ldh % 4 == 0) && (ldm % 4 == 0) && gae::aligned16(H) && gae::aligned16(M);
-        if (vec) return dispatch_rowgroup<float, 4>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale, s);
+        if (vec) {
+            if (g_spmm_variant == 2 && f > 12)
+                return dispatch_rowgroup2<float, 4>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale,
+                                                    g_spmm_rpg, g_spmm_nt != 0, n_cols, s);
+            return dispatch_rowgroup<float, 4>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale, s);
+        }
+        if (g_spmm_variant == 2 && f > 3)
+            return dispatch_rowgroup2<float, 1>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale,
+                                                g_spmm_rpg, g_spmm_nt != 0, n_cols, s);
         return dispatch_rowgroup<float, 1>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale, s);
     }
     const unsigned short *h = static_cast<const unsigned short *>(H);
     unsigned short *m = static_cast<unsigned short *>(M);
     const bool vec = (ldh % 8 == 0) && (ldm % 8 == 0) && gae::aligned16(H) && gae::aligned16(M);
-    if (vec)
+    if (vec) {
+        if (g_spmm_variant == 2 && f > 24)
+            return dispatch_rowgroup2<unsigned short, 8>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale,
+                                                         col_scale, g_spmm_rpg, false, n_cols, s);
         return dispatch_rowgroup<unsigned short, 8>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale, s);
+    }
+    if (g_spmm_variant == 2 && f > 3)
+        return dispatch_rowgroup2<unsigned short, 1>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale,
+                                                     g_spmm_rpg, false, n_cols, s);
     return dispatch_rowgroup<unsigned short, 1>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale, s);
+}
+
+extern "C" int gae_tuning_set(const char *name, int64_t value)
+{
+    GAE_REQUIRE(name != nullptr, GAE_E_NULL, "gae_tuning_set: name is NULL");
+    const struct { const char *k; int *v; } knobs[] = {
+        {"spmm_variant", &g_spmm_variant}, {"spmm_rpg", &g_spmm_rpg}, {"spmm_nt", &g_spmm_nt},
+        {"spmm_tile_vecs", &g_spmm_tile_vecs}};
+    for (const auto &kv : knobs)
+        if (strcmp(kv.k, name) == 0) {
+            *kv.v = int(value);
+            return GAE_OK;
+        }
+    gae::set_error("gae_tuning_set: unknown knob '%s'", name);
+    return GAE_E_RANGE;
 }

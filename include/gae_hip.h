@@ -59,6 +59,9 @@ typedef struct gae_device_info {
 int gae_version(void);
 const char *gae_last_error(void);
 int gae_device_info_get(int device, gae_device_info *out_host);
+/* performance-tuning knobs (process-wide integers; results never depend on them):
+ * "spmm_variant" (1|2), "spmm_rpg" (rows per lane group), "spmm_nt" (non-temporal stores) */
+int gae_tuning_set(const char *name, int64_t value);
 
 /* ---- graph structure -------------------------------------------------------
  * Replaces the DGL graph index built by DGLGraph.add_edges / dgl.batch

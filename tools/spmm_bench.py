@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Within-process interleaved A/B of SpMM kernel variants on the BASELINE
+shapes (cdna guide rule 24: interleave variants in one process, report median
+and min).  Usage: python tools/spmm_bench.py [--rmat-scale 22] [--shapes ...]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gae_dgl_amd import _lib, ops, workloads as W  # noqa: E402
+
+
+def knob(name, v):
+    _lib.call("gae_tuning_set", name.encode(), int(v))
+
+
+def time_once(fn, iters):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rmat-scale", type=int, default=22)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--variants", default="v1:1:0,v2:1:0,v2:2:0,v2:1:1,v2:2:1")
+    ap.add_argument("--shapes", default="pubmed500,pubmed32,zincb39,zincb32,zinc39,zinc32,rmat32")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    shapes = {}
+    want = args.shapes.split(",")
+    if any(s.startswith("pubmed") for s in want):
+        n, src, dst, _ = W.citation_graph("pubmed")
+        ip, ix = ops.csr_from_coo(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n)
+        shapes["pubmed500"] = (ip, ix, n, 500, 500)
+        shapes["pubmed32"] = (ip, ix, n, 32, 32)
+    if any(s.startswith("pband") for s in want) or any(s.startswith("pself") for s in want):
+        n, src, dst, _ = W.citation_graph("pubmed")
+        rng = np.random.default_rng(1)
+        srcb = np.clip(dst + rng.integers(-32, 33, dst.size), 0, n - 1)
+        ipb, ixb = ops.csr_from_coo(torch.from_numpy(dst).to(dev), torch.from_numpy(srcb).to(dev), n, n)
+        ips, ixs = ops.csr_from_coo(torch.from_numpy(dst).to(dev), torch.from_numpy(dst).to(dev), n, n)
+        shapes["pband500"] = (ipb, ixb, n, 500, 500); shapes["pband32"] = (ipb, ixb, n, 32, 32)
+        shapes["pself500"] = (ips, ixs, n, 500, 500); shapes["pself32"] = (ips, ixs, n, 32, 32)
+    if any(s.startswith("zinc") for s in want):
+        gp, src, dst, _ = W.zinc_like(249455)
+        N = int(gp[-1])
+        ip, ix = ops.csr_from_coo(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), N, N)
+        nb = int(gp[4096]); eb = int(ip[nb])
+        shapes["zincb39"] = (ip[:nb + 1].clone(), ix[:eb].clone(), nb, 39, 40)
+        shapes["zincb32"] = (shapes["zincb39"][0], shapes["zincb39"][1], nb, 32, 32)
+        shapes["zinc39"] = (ip, ix, N, 39, 40)
+        shapes["zinc32"] = (ip, ix, N, 32, 32)
+    if "rmat32" in want:
+        src, dst = W.rmat_edges(args.rmat_scale, 16, device=dev)
+        n = 1 << args.rmat_scale
+        ip, ix = ops.csr_from_coo(dst, src, n, n)
+        del src, dst
+        shapes["rmat32"] = (ip, ix, n, 32, 32)
+    variants = []
+    for v in args.variants.split(","):
+        parts = v.split(":")
+        name, rpg, nt = parts[:3]
+        tv = int(parts[3]) if len(parts) > 3 else 0
+        variants.append((v, 1 if name == "v1" else 2, int(rpg), int(nt), tv))
+    for sname in want:
+        ip, ix, n, F, ld = shapes[sname]
+        H = torch.rand(n, ld, device=dev)[:, :F]
+        out = torch.empty(n, ld, device=dev)[:, :F]
+        nnz = int(ix.numel())
+        alg = W.spmm_alg_bytes(n, n, nnz, F)
+        iters = max(3, min(200, int(2e-2 / max(alg / 3e12, 1e-6))))
+        res = {v[0]: [] for v in variants}
+        ref = None
+        for rnd in range(args.rounds + 1):
+            for (label, var, rpg, nt, tv) in variants:
+                knob("spmm_variant", var); knob("spmm_rpg", rpg); knob("spmm_nt", nt); knob("spmm_tile_vecs", tv)
+                fn = lambda: ops.spmm_raw(ip, ix, H, n, out=out)
+                fn(); torch.cuda.synchronize()
+                if rnd == 0:
+                    if ref is None:
+                        ref = out.clone()
+                    else:
+                        assert torch.equal(out, ref), f"variant {label} differs on {sname}"
+                    continue
+                res[label].append(time_once(fn, iters))
+        print(f"== {sname}: n={n} nnz={nnz} F={F} ld={ld} alg={alg/1e6:.1f} MB iters={iters}")
+        Hc = torch.rand(n, F, device=dev); oc = torch.empty_like(Hc)
+        tc = min(time_once(lambda: oc.copy_(Hc), iters) for _ in range(3))
+        print(f"   [copy H->M  {tc*1e6:9.1f} us  {2*Hc.numel()*4/tc/1e9:8.1f} GB/s : device copy of the same H/M bytes]")
+        del Hc, oc
+        for label, ts in res.items():
+            med, mn = float(np.median(ts)), float(np.min(ts))
+            print(f"   {label:10s} median {med*1e6:9.1f} us  min {mn*1e6:9.1f} us  "
+                  f"{alg/med/1e9:8.1f} GB/s ({alg/med/8e12*100:5.1f}% of 8 TB/s)  {nnz/med/1e9:7.2f} Gedge/s")
+
+
+if __name__ == "__main__":
+    main()
