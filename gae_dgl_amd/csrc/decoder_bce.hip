@@ -23,6 +23,8 @@
 // MFMA-bound (fp32 matrix rate), not HBM-bound: 4 KS (S) + 4 KS (PV) MFMAs per
 // 256 logits with KS = ceil(d / 16).
 // Reductions are two-stage and ordered: bit-stable run to run.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -36,24 +38,44 @@ constexpr int ROWS_PER_BLOCK = 4 * RI * 16;
 
 __device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
 {
-    const float e = __expf(-fabsf(x));
-    const float r = __builtin_amdgcn_rcpf(1.0f + e);
-    sp = fmaxf(x, 0.f) + __logf(1.0f + e);
+    // e = exp(-|x|) in (0, 1]; raw v_exp/v_log/v_rcp: an underflowing e flushes to 0, which is the
+    // correctly rounded answer for both outputs (no denormal fix-up code needed)
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(x));
+    const float t = 1.0f + e;
+    const float r = __builtin_amdgcn_rcpf(t);
+    sp = fmaf(__builtin_amdgcn_logf(t), 0.69314718055994531f, fmaxf(x, 0.f));
     sg = (x >= 0.f ? 1.0f : e) * r;
+}
+
+// Zt[n][DP] = Z (.) mask, zero padded to DP = 16 KS columns: the dense kernel then reads
+// clean 16-byte aligned rows without mask loads or feature bounds checks.
+__global__ __launch_bounds__(256) void bce_prepare_kernel(const float *__restrict__ Z, const float *__restrict__ mask,
+                                                          int64_t ldz, int64_t n, int d, int DP,
+                                                          float *__restrict__ Zt)
+{
+    const int64_t total = n * DP, stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / DP;
+        const int k = int(e - i * DP);
+        float v = 0.f;
+        if (k < d) {
+            v = Z[i * ldz + k];
+            if (mask) v *= mask[i * ldz + k];
+        }
+        Zt[e] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------
 template <int KS, bool WITH_GRAD>
 __global__ __launch_bounds__(256) void bce_dense_kernel(
-    const float *__restrict__ Z, const float *__restrict__ mask, int64_t ldz, int64_t n, int d,
-    int64_t cols_per_split, float *__restrict__ O_partial /*[splits][n][KS*16]*/,
-    double *__restrict__ loss_partial /*[gridDim.x * gridDim.y]*/)
+    const float *__restrict__ Zt /*[n][16 KS]*/, int64_t n, int64_t cols_per_split,
+    float *__restrict__ O_partial /*[splits][n][KS*16]*/, double *__restrict__ loss_partial /*[gridDim.x * gridDim.y]*/)
 {
     constexpr int DP = KS * 16;          // padded feature width
-    constexpr int LDA = DP + 4;          // Zs row stride (floats)
-    constexpr int LDT = TJ + 4;          // ZsT row stride
-    __shared__ __attribute__((aligned(16))) float Zs[TJ * LDA];    // [j][k]
-    __shared__ __attribute__((aligned(16))) float ZsT[DP * LDT];   // [k][j]
+    constexpr int LDA = DP + 4;          // LDS row stride (floats): 16-byte aligned, breaks the power of two
+    constexpr int V4 = TJ * DP / 4 / 256;  // float4 per thread and staged tile (1, 2, 4)
+    __shared__ __attribute__((aligned(16))) float Zs[2][TJ * LDA];   // double-buffered column tile [j][k]
     __shared__ double red[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,48 +91,46 @@ __global__ __launch_bounds__(256) void bce_dense_kernel(
     for (int ri = 0; ri < RI; ++ri) {
         const int64_t i = row_base + ri * 16 + l15;
 #pragma unroll
-        for (int c = 0; c < KS; ++c) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = 16 * c + 4 * g + r;
-                float v = 0.f;
-                if (i < n && k < d) {
-                    v = Z[i * ldz + k];
-                    if (mask) v *= mask[i * ldz + k];
-                }
-                bfrag[ri][c][r] = v;
-            }
-        }
+        for (int c = 0; c < KS; ++c)
+            bfrag[ri][c] = i < n ? *reinterpret_cast<const f32x4 *>(Zt + i * DP + 16 * c + 4 * g)
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     f32x4 oacc[RI][KS];
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri)
 #pragma unroll
         for (int c = 0; c < KS; ++c) oacc[ri][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    double lsum = 0.0;
+    double lsum[RI];
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri) lsum[ri] = 0.0;
 
-    for (int64_t j0 = col_begin; j0 < col_end; j0 += TJ) {
-        // ---- stage Zt[j0 .. j0+TJ) in both layouts (zero beyond n / d)
-        for (int idx = tid; idx < TJ * DP; idx += 256) {
-            const int jj = idx / DP, k = idx - jj * DP;
-            const int64_t j = j0 + jj;
-            float v = 0.f;
-            if (j < col_end && k < d) {
-                v = Z[j * ldz + k];
-                if (mask) v *= mask[j * ldz + k];
-            }
-            Zs[jj * LDA + k] = v;
-            ZsT[k * LDT + jj] = v;
+    // staging: thread -> float4 #(tid + 256 q) of the tile; tile rows are contiguous in Zt
+    auto load_tile = [&](int64_t j0, f32x4 (&reg)[V4]) {
+#pragma unroll
+        for (int q = 0; q < V4; ++q) {
+            const int idx = tid + 256 * q;            // float4 index inside the tile
+            const int jj = idx / (DP / 4);
+            reg[q] = (j0 + jj < col_end) ? *reinterpret_cast<const f32x4 *>(Zt + (j0 + jj) * DP + (idx % (DP / 4)) * 4)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __syncthreads();
-        const bool full = j0 + TJ <= col_end;
+    };
+    auto store_tile = [&](int buf, const f32x4 (&reg)[V4]) {
+#pragma unroll
+        for (int q = 0; q < V4; ++q) {
+            const int idx = tid + 256 * q;
+            *reinterpret_cast<f32x4 *>(&Zs[buf][(idx / (DP / 4)) * LDA + (idx % (DP / 4)) * 4]) = reg[q];
+        }
+    };
+
+    auto compute_tile = [&](const float *zs, int64_t j0, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
         for (int jt = 0; jt < TJ / 16; ++jt) {
-            // A fragments: lane (j = l15, g) -> Zs[jt*16 + j][16 c + 4 g .. +3]
+            // A fragments: lane (j = l15, g) -> zs[jt*16 + j][16 c + 4 g .. +3]
             f32x4 afrag[KS];
 #pragma unroll
             for (int c = 0; c < KS; ++c)
-                afrag[c] = *reinterpret_cast<const f32x4 *>(&Zs[(jt * 16 + l15) * LDA + 16 * c + 4 * g]);
+                afrag[c] = *reinterpret_cast<const f32x4 *>(&zs[(jt * 16 + l15) * LDA + 16 * c + 4 * g]);
             f32x4 sacc[RI];
 #pragma unroll
             for (int ri = 0; ri < RI; ++ri) sacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -121,29 +141,32 @@ __global__ __launch_bounds__(256) void bce_dense_kernel(
 #pragma unroll
                     for (int ri = 0; ri < RI; ++ri)
                         sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[c][r], bfrag[ri][c][r], sacc[ri], 0, 0, 0);
-            // sacc[ri][r] = x(i = l15, j = jt*16 + 4 g + r)
+            // sacc[ri][r] = x(i = l15 of subtile ri, j = jt*16 + 4 g + r)
             f32x4 p[RI];
-            float tsum = 0.f;
 #pragma unroll
-            for (int ri = 0; ri < RI; ++ri)
+            for (int ri = 0; ri < RI; ++ri) {
+                float tsum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float sp, sg;
                     softplus_sigmoid(sacc[ri][r], sp, sg);
-                    if (!full) {
+                    if (!FULL) {
                         const bool jv = j0 + jt * 16 + 4 * g + r < col_end;
                         sp = jv ? sp : 0.f;
                         sg = jv ? sg : 0.f;
                     }
-                    tsum += sp * ((row_base + ri * 16 + l15) < n ? 1.f : 0.f);
+                    tsum += sp;
                     p[ri][r] = sg;
                 }
-            lsum += double(tsum);
+                lsum[ri] += double(tsum);
+            }
             if (WITH_GRAD) {
-                // B fragments of O += P V: lane (nn = l15, g) -> V[jt*16 + 4 g + r][16 c + nn] = ZsT[16 c + nn][jt*16 + 4 g ..]
+                // B fragments of O += P V: lane (nn = l15, g) -> V[jt*16 + 4 g + r][16 c + nn]
 #pragma unroll
                 for (int c = 0; c < KS; ++c) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(&ZsT[(16 * c + l15) * LDT + jt * 16 + 4 * g]);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = zs[(jt * 16 + 4 * g + r) * LDA + 16 * c + l15];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -152,6 +175,21 @@ __global__ __launch_bounds__(256) void bce_dense_kernel(
                 }
             }
         }
+    };
+
+    f32x4 stage[V4];
+    if (col_begin < col_end) {
+        load_tile(col_begin, stage);
+        store_tile(0, stage);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int64_t j0 = col_begin; j0 < col_end; j0 += TJ, buf ^= 1) {
+        const bool more = j0 + TJ < col_end;
+        if (more) load_tile(j0 + TJ, stage);        // in flight while this tile is consumed
+        if (j0 + TJ <= col_end) compute_tile(Zs[buf], j0, std::true_type{});
+        else compute_tile(Zs[buf], j0, std::false_type{});
+        if (more) store_tile(buf ^ 1, stage);
         __syncthreads();
     }
     // ---- O partial: oacc[ri][c][r] = O(i = 4 g + r, nn = l15) of subtile ri, feature 16 c + nn
@@ -168,10 +206,13 @@ __global__ __launch_bounds__(256) void bce_dense_kernel(
                 }
             }
     }
-    // ---- loss partial: wave reduce (fixed tree) -> block
+    // ---- loss partial: drop rows >= n, wave reduce (fixed tree) -> block
+    double ls = 0.0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
-    if (lane == 0) red[wave] = lsum;
+    for (int ri = 0; ri < RI; ++ri) ls += (row_base + ri * 16 + l15) < n ? lsum[ri] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ls += __shfl_down(ls, off, 64);
+    if (lane == 0) red[wave] = ls;
     __syncthreads();
     if (tid == 0) loss_partial[int64_t(blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
@@ -278,7 +319,7 @@ __global__ __launch_bounds__(256) void bce_finalize_kernel(const double *__restr
 struct BcePlan {
     int64_t row_blocks, n_splits, cols_per_split, edge_blocks;
     int KS, DP, LPR, VEC;
-    int64_t o_bytes, loss_count, total_bytes;
+    int64_t o_bytes, zt_bytes, loss_count, total_bytes;
 };
 
 inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
@@ -309,20 +350,20 @@ bool bce_plan(int64_t n, int64_t d, bool vec_ok, BcePlan &p)
     p.edge_blocks = (n + (256 / lpr) - 1) / (256 / lpr);
     if (p.edge_blocks < 1) p.edge_blocks = 1;
     p.o_bytes = align256(p.n_splits * n * p.DP * 4);
+    p.zt_bytes = align256(n * p.DP * 4);
     p.loss_count = p.row_blocks * p.n_splits + p.edge_blocks;
-    p.total_bytes = p.o_bytes + align256(p.loss_count * 8);
+    p.total_bytes = p.o_bytes + p.zt_bytes + align256(p.loss_count * 8);
     return true;
 }
 
 template <bool WITH_GRAD>
-int launch_dense(const BcePlan &p, const float *Z, const float *mask, int64_t ldz, int64_t n, int d, float *O,
-                 double *lp, hipStream_t s)
+int launch_dense(const BcePlan &p, const float *Zt, int64_t n, float *O, double *lp, hipStream_t s)
 {
     const dim3 grid(unsigned(p.row_blocks), unsigned(p.n_splits));
     switch (p.KS) {
-    case 1: hipLaunchKernelGGL((bce_dense_kernel<1, WITH_GRAD>), grid, dim3(256), 0, s, Z, mask, ldz, n, d, p.cols_per_split, O, lp); break;
-    case 2: hipLaunchKernelGGL((bce_dense_kernel<2, WITH_GRAD>), grid, dim3(256), 0, s, Z, mask, ldz, n, d, p.cols_per_split, O, lp); break;
-    default: hipLaunchKernelGGL((bce_dense_kernel<4, WITH_GRAD>), grid, dim3(256), 0, s, Z, mask, ldz, n, d, p.cols_per_split, O, lp); break;
+    case 1: hipLaunchKernelGGL((bce_dense_kernel<1, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, p.cols_per_split, O, lp); break;
+    case 2: hipLaunchKernelGGL((bce_dense_kernel<2, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, p.cols_per_split, O, lp); break;
+    default: hipLaunchKernelGGL((bce_dense_kernel<4, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, p.cols_per_split, O, lp); break;
     }
     GAE_CHECK_LAUNCH("bce_dense_kernel");
     return GAE_OK;
@@ -380,10 +421,16 @@ extern "C" int gae_decoder_bce(const float *Z, const float *mask, int64_t ldz, i
     GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_decoder_bce: workspace not 16-byte aligned");
     hipStream_t s = gae::as_stream(stream);
     float *O = static_cast<float *>(workspace);
-    double *lp = reinterpret_cast<double *>(static_cast<char *>(workspace) + p.o_bytes);
+    float *Zt = reinterpret_cast<float *>(static_cast<char *>(workspace) + p.o_bytes);
+    double *lp = reinterpret_cast<double *>(static_cast<char *>(workspace) + p.o_bytes + p.zt_bytes);
     const double inv_n2 = 1.0 / (double(n) * double(n));
-    int rc = dZ ? launch_dense<true>(p, Z, mask, ldz, n, int(d), O, lp, s)
-                : launch_dense<false>(p, Z, mask, ldz, n, int(d), O, lp, s);
+    {
+        int64_t gb = (n * p.DP + 255) / 256;
+        if (gb > 2048) gb = 2048;
+        hipLaunchKernelGGL(bce_prepare_kernel, dim3(unsigned(gb)), dim3(256), 0, s, Z, mask, ldz, n, int(d), p.DP, Zt);
+        GAE_CHECK_LAUNCH("bce_prepare_kernel");
+    }
+    int rc = dZ ? launch_dense<true>(p, Zt, n, O, lp, s) : launch_dense<false>(p, Zt, n, O, lp, s);
     if (rc) return rc;
     double *lpe = lp + p.row_blocks * p.n_splits;
     rc = dZ ? launch_edges<4, true>(p, Z, mask, ldz, n, int(d), indptr, indices, t_indptr, t_indices, pos_weight,

@@ -11,6 +11,8 @@
 // Operand map of the instruction (wave64, lane l):
 //   A[i = l & 31][k = l >> 5],  B[k = l >> 5][j = l & 31],
 //   D reg r -> row (r & 3) + 8 (r >> 2) + 4 (l >> 5), col l & 31.
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -19,6 +21,7 @@ using gae::kWave;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
+int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
 
 // ---------------------------------------------------------------------------
 // out[n, J] = epi( proA(A)[n, K] * proB(B) )      B given as [J, K] (BT) or [K, J]
@@ -177,16 +180,148 @@ int launch_gemm(const float *A, int64_t lda, const float *Amask, int64_t ldam, c
     return GAE_OK;
 }
 
+template <int NT, bool BT, int PRO_A>
+int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t ldam, const float *B, int64_t ldb,
+                       const float *bias, int act, float *out, int64_t ldo, int64_t n, int K, int64_t J, hipStream_t s);
+
 template <bool BT, int PRO_A, bool MASK_B>
 int dispatch_gemm(const float *A, int64_t lda, const float *Amask, int64_t ldam, const float *B, int64_t ldb,
                   const float *Bmask, int64_t ldbm, const float *bias, int act, float *out, int64_t ldo, int64_t n,
                   int K, int64_t J, hipStream_t s)
 {
+    if (!MASK_B && J <= 128 && g_gemm_stream) {
+        if (J <= 32) return launch_gemm_stream<1, BT, PRO_A>(A, lda, Amask, ldam, B, ldb, bias, act, out, ldo, n, K, J, s);
+        if (J <= 64) return launch_gemm_stream<2, BT, PRO_A>(A, lda, Amask, ldam, B, ldb, bias, act, out, ldo, n, K, J, s);
+        return launch_gemm_stream<4, BT, PRO_A>(A, lda, Amask, ldam, B, ldb, bias, act, out, ldo, n, K, J, s);
+    }
     if (J <= 32)
         return launch_gemm<1, BT, PRO_A, MASK_B>(A, lda, Amask, ldam, B, ldb, Bmask, ldbm, bias, act, out, ldo, n, K, J, s);
     if (J <= 64)
         return launch_gemm<2, BT, PRO_A, MASK_B>(A, lda, Amask, ldam, B, ldb, Bmask, ldbm, bias, act, out, ldo, n, K, J, s);
     return launch_gemm<4, BT, PRO_A, MASK_B>(A, lda, Amask, ldam, B, ldb, Bmask, ldbm, bias, act, out, ldo, n, K, J, s);
+}
+
+// ---------------------------------------------------------------------------
+// Tall-skinny variant (J <= 128, the Linear layers): out[n, J] = epi(proA(A) * B).
+// A is streamed exactly once: a block owns 32 rows, its 4 waves split K into
+// contiguous quarters and read their A slab straight into MFMA fragments
+// (lane (i, h) loads the 16 bytes A[i][k + 4h .. k + 4h + 3]; the 4 values feed
+// 4 consecutive MFMAs, B uses the same k permutation), no LDS staging and no
+// barrier in the K loop; the 4 partial accumulators meet in LDS once, in fixed
+// order.  n / 32 blocks keep all CUs busy where 128-row tiles would not.
+// ---------------------------------------------------------------------------
+template <int NT, bool BT, int PRO_A>
+__global__ __launch_bounds__(256) void gemm_stream_kernel(
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ Amask, int64_t ldam,
+    const float *__restrict__ B, int64_t ldb, const float *__restrict__ bias, int act, float *__restrict__ out,
+    int64_t ldo, int64_t n, int K, int J, int avec, int bvec)
+{
+    __shared__ float red[4 * NT * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t row = int64_t(blockIdx.x) * 32 + i;
+    const bool rv = row < n;
+    const int kblocks = (K + 7) / 8, per = (kblocks + 3) / 4;
+    const int kb0 = wave * per, kb1 = min(kb0 + per, kblocks);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const float *ap = A + row * lda;
+    const float *mp = PRO_A != PRO_NONE ? Amask + row * ldam : nullptr;
+#pragma unroll 2
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int k = kb * 8 + 4 * h;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rv) {
+            if (avec && k + 4 <= K) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(ap + k);
+                a[0] = t4.x; a[1] = t4.y; a[2] = t4.z; a[3] = t4.w;
+                if (PRO_A != PRO_NONE) {
+                    const float4 m4 = *reinterpret_cast<const float4 *>(mp + k);
+                    const float m[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        a[q] = PRO_A == PRO_RELU_MASK ? (m[q] > 0.f ? a[q] : 0.f) : a[q] * m[q];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (k + q < K) {
+                        float v = ap[k + q];
+                        if (PRO_A == PRO_RELU_MASK) v = mp[k + q] > 0.f ? v : 0.f;
+                        if (PRO_A == PRO_MUL_MASK) v *= mp[k + q];
+                        a[q] = v;
+                    }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = t * 32 + i;
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (j < J) {
+                if (BT) {
+                    const float *bp = B + int64_t(j) * ldb + k;
+                    if (bvec && k + 4 <= K) {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(bp);
+                        b[0] = t4.x; b[1] = t4.y; b[2] = t4.z; b[3] = t4.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (k + q < K) b[q] = bp[q];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (k + q < K) b[q] = B[int64_t(k + q) * ldb + j];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc[t], 0, 0, 0);
+        }
+    }
+    // ---- fixed-order cross-wave reduction: red[wave][t][r][lane]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+    // wave w finalises accumulator registers 4w .. 4w+3  (rows 8w + {0..3} + 4h)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = t * 32 + i;
+        const float bv = (bias && col < J) ? bias[col] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            float y = red[((0 * NT + t) * 16 + r) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) y += red[((w * NT + t) * 16 + r) * 64 + lane];
+            const int64_t orow = int64_t(blockIdx.x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (orow < n && col < J) {
+                y += bv;
+                if (act == GAE_ACT_RELU) y = y > 0.f ? y : 0.f;
+                out[orow * ldo + col] = y;
+            }
+        }
+    }
+}
+
+template <int NT, bool BT, int PRO_A>
+int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t ldam, const float *B, int64_t ldb,
+                       const float *bias, int act, float *out, int64_t ldo, int64_t n, int K, int64_t J, hipStream_t s)
+{
+    bool avec = (lda % 4 == 0) && gae::aligned16(A);
+    if (PRO_A != PRO_NONE) avec = avec && (ldam % 4 == 0) && gae::aligned16(Amask);
+    const bool bvec = BT && (ldb % 4 == 0) && gae::aligned16(B);
+    hipLaunchKernelGGL((gemm_stream_kernel<NT, BT, PRO_A>), dim3(unsigned((n + 31) / 32)), dim3(256), 0, s, A, lda,
+                       Amask, ldam, B, ldb, bias, act, out, ldo, n, K, int(J), avec ? 1 : 0, bvec ? 1 : 0);
+    GAE_CHECK_LAUNCH("gemm_stream_kernel");
+    return GAE_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -218,20 +353,31 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float csum = 0.f;
 
-    for (int64_t r = r_begin + h; r < r_end + h; r += 2) {
-        const bool rv = r < r_end;  // rows_per_slot is even; the odd tail lane contributes 0
-        float a = 0.f;
-        if (rv && o < O) {
-            a = P[r * ldp + o];
-            if (PRO_P == PRO_RELU_MASK) a = Pmask[r * ldpm + o] > 0.f ? a : 0.f;
-            if (PRO_P == PRO_MUL_MASK) a *= Pmask[r * ldpm + o];
-        }
-        csum += a;
+    // 4 k-steps (8 rows) per iteration: all loads of the iteration are issued before its first MFMA
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 8) {
+        float a[4], b[4][IT];
 #pragma unroll
-        for (int t = 0; t < IT; ++t) {
-            const int i = i0 + t * 32 + (lane & 31);
-            const float b = (rv && i < I) ? Q[r * ldq + i] : 0.f;
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = r0 + 2 * u + h;
+            const bool rv = r < r_end;
+            float av = 0.f;
+            if (rv && o < O) {
+                av = P[r * ldp + o];
+                if (PRO_P == PRO_RELU_MASK) av = Pmask[r * ldpm + o] > 0.f ? av : 0.f;
+                if (PRO_P == PRO_MUL_MASK) av *= Pmask[r * ldpm + o];
+            }
+            a[u] = av;
+#pragma unroll
+            for (int t = 0; t < IT; ++t) {
+                const int i = i0 + t * 32 + (lane & 31);
+                b[u][t] = (rv && i < I) ? Q[r * ldq + i] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            csum += a[u];
+#pragma unroll
+            for (int t = 0; t < IT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
         }
     }
     // partial[slot][O][I]
@@ -252,21 +398,38 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(
     }
 }
 
-// out[e] = sum_slot partial[slot][e]  (+ optional accumulate into out, optional mask multiply)
+// out[e] = sum_slot partial[slot][e]  (+ optional accumulate into out, optional mask multiply).
+// 64 elements per block; the 4 waves take slots q, q+4, q+8, ... and meet in LDS in fixed order.
 __global__ __launch_bounds__(256) void reduce_slots_kernel(const float *__restrict__ partial, int64_t n_slots,
                                                            int64_t n_elems, float *__restrict__ out,
                                                            int64_t out_cols, int64_t ldo, int accumulate,
                                                            const float *__restrict__ mulmask, int64_t ldmask)
 {
-    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
-        float s = 0.f;
-        for (int64_t k = 0; k < n_slots; ++k) s += partial[k * n_elems + e];
-        const int64_t r = e / out_cols, c = e - r * out_cols;
-        float *op = out + r * ldo + c;
-        if (accumulate) s += *op;
-        if (mulmask) s *= mulmask[r * ldmask + c];
-        *op = s;
+    __shared__ float red[4][64];
+    const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int64_t base = int64_t(blockIdx.x) * 64; base < n_elems; base += int64_t(gridDim.x) * 64) {
+        const int64_t e = base + el;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (e < n_elems) {
+            int64_t k = q;
+            for (; k + 12 < n_slots; k += 16) {
+                const float v0 = partial[k * n_elems + e], v1 = partial[(k + 4) * n_elems + e];
+                const float v2 = partial[(k + 8) * n_elems + e], v3 = partial[(k + 12) * n_elems + e];
+                s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+            }
+            for (; k < n_slots; k += 4) s0 += partial[k * n_elems + e];
+        }
+        red[q][el] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (q == 0 && e < n_elems) {
+            float s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+            const int64_t r = e / out_cols, c = e - r * out_cols;
+            float *op = out + r * ldo + c;
+            if (accumulate) s += *op;
+            if (mulmask) s *= mulmask[r * ldmask + c];
+            *op = s;
+        }
+        __syncthreads();
     }
 }
 
@@ -296,7 +459,7 @@ struct AtbPlan {
 AtbPlan atb_plan(int64_t n, int64_t O, int64_t I)
 {
     AtbPlan p;
-    int64_t want = (n + 255) / 256;                  // ~256 rows per wave
+    int64_t want = (n + 127) / 128;                  // ~128 rows per wave
     int64_t cap = (int64_t(32) << 20) / (O * I > 0 ? O * I : 1);  // <= 128 MiB of partials
     if (cap > 2048) cap = 2048;
     if (cap < 4) cap = 4;
@@ -305,8 +468,8 @@ AtbPlan atb_plan(int64_t n, int64_t O, int64_t I)
     p.blocks = (want + 3) / 4;
     p.n_slots = p.blocks * 4;
     int64_t rps = (n + p.n_slots - 1) / p.n_slots;
-    rps += rps & 1;
-    if (rps < 2) rps = 2;
+    rps = (rps + 7) / 8 * 8;
+    if (rps < 8) rps = 8;
     p.rows_per_slot = rps;
     return p;
 }
@@ -327,7 +490,7 @@ int launch_atb(const float *P, int64_t ldp, const float *Pmask, int64_t ldpm, co
 int launch_reduce(const float *partial, int64_t n_slots, int64_t n_elems, float *out, int64_t out_cols, int64_t ldo,
                   int accumulate, const float *mulmask, int64_t ldmask, hipStream_t s)
 {
-    int64_t g = (n_elems + 255) / 256;
+    int64_t g = (n_elems + 63) / 64;
     if (g > 4096) g = 4096;
     if (g < 1) g = 1;
     hipLaunchKernelGGL(reduce_slots_kernel, dim3(unsigned(g)), dim3(256), 0, s, partial, n_slots, n_elems, out,
@@ -374,6 +537,14 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float *__restrict__ m
 }
 
 } // namespace
+
+namespace gae {
+int *dense_knob(const char *name)
+{
+    if (strcmp(name, "gemm_stream") == 0) return &g_gemm_stream;
+    return nullptr;
+}
+} // namespace gae
 
 // ===========================================================================
 extern "C" int gae_linear_fwd(const float *M, int64_t ldm, int64_t n, int64_t f_in, const float *W, const float *b,

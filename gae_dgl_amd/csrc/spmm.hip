@@ -463,6 +463,8 @@ extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64
     return dispatch_rowgroup<unsigned short, 1>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale, s);
 }
 
+namespace gae { int *dense_knob(const char *name); }
+
 extern "C" int gae_tuning_set(const char *name, int64_t value)
 {
     GAE_REQUIRE(name != nullptr, GAE_E_NULL, "gae_tuning_set: name is NULL");
@@ -474,6 +476,10 @@ extern "C" int gae_tuning_set(const char *name, int64_t value)
             *kv.v = int(value);
             return GAE_OK;
         }
+    if (int *k = gae::dense_knob(name)) {
+        *k = int(value);
+        return GAE_OK;
+    }
     gae::set_error("gae_tuning_set: unknown knob '%s'", name);
     return GAE_E_RANGE;
 }
