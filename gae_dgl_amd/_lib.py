@@ -21,6 +21,11 @@ class DeviceInfo(ctypes.Structure):
                 ("gfx_major_minor", _i32), ("name", ctypes.c_char * 64)]
 
 
+class SpmmPlan(ctypes.Structure):
+    _fields_ = [("threshold", _i32), ("segment_edges", _i32), ("n_heavy", _i64), ("n_segments", _i64),
+                ("heavy_rows", _p), ("heavy_seg_base", _p), ("seg_heavy", _p)]
+
+
 # name -> (restype, argtypes); mirrors include/gae_hip.h one to one
 SIGNATURES = {
     "gae_version": (_int, []),
@@ -33,7 +38,11 @@ SIGNATURES = {
     "gae_csr_to_dense": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
     "gae_batch_gather": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _p, _i64, _i64,
                                 _p, _p, _p, _i64, _p]),
-    "gae_spmm_csr": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _int, _p, _p, _p]),
+    "gae_spmm_plan_count": (_int, [_p, _i64, _i32, _i32, _p, _p]),
+    "gae_spmm_plan_fill": (_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
+    "gae_spmm_workspace_bytes": (_i64, [ctypes.POINTER(SpmmPlan), _i64]),
+    "gae_spmm_csr": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _int, _p, _p,
+                            ctypes.POINTER(SpmmPlan), _p, _i64, _p]),
     "gae_linear_fwd": (_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p]),
     "gae_linear_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gae_linear_bwd": (_int, [_p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _i64, _i64,

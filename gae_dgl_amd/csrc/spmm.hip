@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
     const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t n_rows,
     const T *__restrict__ H, int64_t ldh, T *__restrict__ M, int64_t ldm, int F,
     const float *__restrict__ row_scale, const float *__restrict__ col_scale, unsigned n_row_blocks,
-    unsigned n_ftiles, int xcd_tiled)
+    unsigned n_ftiles, int xcd_tiled, int skip_deg)
 {
     constexpr int GPB = 256 / LPR;            // groups per block
     constexpr int RPB = GPB * RPG;            // rows per block
@@ -228,6 +228,10 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
         const bool rv = row[r] < n_rows;
         pos[r] = rv ? indptr[row[r]] : 0;
         end[r] = rv ? indptr[row[r] + 1] : 0;
+        if (end[r] - pos[r] > skip_deg) {  // heavy row: produced by the segment kernels (plan)
+            row[r] = n_rows;
+            end[r] = pos[r];
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -318,7 +322,8 @@ int g_spmm_tile_vecs = 0; // 16-byte vectors per XCD feature tile (0 auto, -1 of
 
 template <typename T, int VEC, int LPR, int CH, int RPG>
 int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
-                     int64_t ldm, int F, const float *rs, const float *cs, bool nt, bool tiled, hipStream_t s)
+                     int64_t ldm, int F, const float *rs, const float *cs, bool nt, bool tiled, int skip_deg,
+                     hipStream_t s)
 {
     constexpr int RPB = (256 / LPR) * RPG;
     const int nvec = (F + VEC - 1) / VEC;
@@ -327,7 +332,7 @@ int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_ro
     const int xt = tiled ? 1 : 0;
 #define GAE_L2(SC, NT)                                                                                              \
     hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, NT>), grid, dim3(256), 0, s, indptr, indices, \
-                       n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt)
+                       n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, skip_deg)
     if (rs || cs) { if (nt) GAE_L2(true, true); else GAE_L2(true, false); }
     else { if (nt) GAE_L2(false, true); else GAE_L2(false, false); }
 #undef GAE_L2
@@ -338,7 +343,7 @@ int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_ro
 template <typename T, int VEC>
 int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
                        int64_t ldm, int F, const float *rs, const float *cs, int rpg, bool nt, int64_t n_cols,
-                       hipStream_t s)
+                       int skip_deg, hipStream_t s)
 {
     const int nvec = (F + VEC - 1) / VEC;
     bool tiled = false;
@@ -346,9 +351,9 @@ int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_
     do {                                                                                                          \
         if (rpg >= 2 && CH == 1)                                                                                  \
             return launch_rowgroup2<T, VEC, LPR, CH, 2>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt,   \
-                                                        tiled, s);                                                \
+                                                        tiled, skip_deg, s);                                      \
         return launch_rowgroup2<T, VEC, LPR, CH, 1>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt, tiled, \
-                                                    s);                                                           \
+                                                    skip_deg, s);                                                 \
     } while (0)
     // Wide rows whose per-tile slice of H fits one XCD's L2: feature-tiled XCD mapping.
     {
@@ -414,11 +419,266 @@ int dispatch_rowgroup(const int32_t *indptr, const int32_t *indices, int64_t n_r
 #undef GAE_RG
 }
 
+// ---------------------------------------------------------------------------
+// Degree-skew plan (power-law graphs).  Rows with more than `threshold`
+// in-edges ("heavy") are skipped by the row-group kernel; each is cut into
+// segments of `segment_edges` edges, one wave per segment gathers its edges
+// with all 64/LPR lane groups in parallel (fixed butterfly reduction across
+// the groups), and a combine kernel adds a row's segment partials in segment
+// order.  No float atomics anywhere: the result does not depend on which wave
+// ran which segment.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plan_count_kernel(const int32_t *__restrict__ indptr, int64_t n_rows,
+                                                         int threshold, int seg, unsigned long long *counts)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    unsigned long long nh = 0, ns = 0;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        const int d = indptr[r + 1] - indptr[r];
+        if (d > threshold) { nh += 1; ns += (d + seg - 1) / seg; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { nh += __shfl_down(nh, off, 64); ns += __shfl_down(ns, off, 64); }
+    if ((threadIdx.x & 63) == 0 && nh) { atomicAdd(&counts[0], nh); atomicAdd(&counts[1], ns); }
+}
+
+__global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t *__restrict__ indptr, int64_t n_rows,
+                                                        int threshold, int seg, unsigned long long *cursors,
+                                                        int32_t *__restrict__ heavy_rows,
+                                                        int32_t *__restrict__ heavy_seg_base,
+                                                        int32_t *__restrict__ seg_heavy)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        const int d = indptr[r + 1] - indptr[r];
+        if (d > threshold) {
+            const int ns = (d + seg - 1) / seg;
+            const int h = int(atomicAdd(&cursors[0], 1ull));
+            const int base = int(atomicAdd(&cursors[1], (unsigned long long)ns));
+            heavy_rows[h] = int32_t(r);
+            heavy_seg_base[h] = base;
+            for (int k = 0; k < ns; ++k) seg_heavy[base + k] = h;
+        }
+    }
+}
+
+// one wave per segment; partial[s][0..F)
+template <typename T, int VEC, int LPR, int CH, bool SCALED>
+__global__ __launch_bounds__(256) void spmm_segment_kernel(
+    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const T *__restrict__ H, int64_t ldh,
+    int F, const float *__restrict__ col_scale, const int32_t *__restrict__ heavy_rows,
+    const int32_t *__restrict__ heavy_seg_base, const int32_t *__restrict__ seg_heavy, int64_t n_segments, int seg,
+    float *__restrict__ partial, int ldp)
+{
+    constexpr int G = 64 / LPR;       // lane groups per wave = edges gathered per load instruction
+    constexpr int TILE = LPR * VEC;
+    constexpr int NB = 4;             // edges in flight per group
+    const int lane = threadIdx.x & 63, lig = lane % LPR, g = lane / LPR;
+    const int64_t sidx = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (sidx >= n_segments) return;
+    const int h = seg_heavy[sidx];
+    const int64_t row = heavy_rows[h];
+    const int k = int(sidx - heavy_seg_base[h]);
+    const int32_t e0 = indptr[row] + k * seg;
+    const int32_t e1 = min(e0 + seg, indptr[row + 1]);
+    const int f0 = blockIdx.y * (CH * TILE) + lig * VEC;
+    bool live[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) live[c] = (f0 + c * TILE) < F;
+    float acc[CH][VEC];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[c][i] = 0.f;
+
+    for (int32_t base = e0; base < e1; base += 64) {
+        const int32_t myidx = base + lane < e1 ? indices[base + lane] : 0;   // 64 neighbour ids, coalesced
+#pragma unroll
+        for (int ub = 0; ub < LPR; ub += NB) {        // 64 / G = LPR edges per group and index batch
+            if (base + ub * G >= e1) break;
+            float v[NB][CH][VEC];
+            float cs[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int slot = (ub + u) * G + g;    // edge handled by this group
+                const bool ev = (ub + u) < LPR && base + slot < e1;
+                const int32_t j = __shfl(myidx, slot & 63, 64);
+                if (SCALED) cs[u] = ev ? col_scale[j] : 0.f;
+                const T *hp = H + int64_t(j) * ldh + f0;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if (ev && live[c]) {
+                        VecIO<T, VEC>::load(hp + c * TILE, v[u][c]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[u][c][i] = 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        acc[c][i] = SCALED ? fmaf(cs[u], v[u][c][i], acc[c][i]) : acc[c][i] + v[u][c][i];
+        }
+    }
+    // fixed butterfly across the G groups (lanes with equal lig)
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[c][i] += __shfl_xor(acc[c][i], off, 64);
+    if (g == 0) {
+        float *pp = partial + sidx * ldp + f0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (f0 + c * TILE + i < F) pp[c * TILE + i] = acc[c][i];
+    }
+}
+
+// M[row] = rs[row] * sum_k partial[base + k]   (segment order)
+template <typename T>
+__global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ heavy_rows,
+                                                           const int32_t *__restrict__ heavy_seg_base,
+                                                           int64_t n_heavy, int seg, const float *__restrict__ partial,
+                                                           int ldp, int F, const float *__restrict__ row_scale,
+                                                           T *__restrict__ M, int64_t ldm)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t h = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (h >= n_heavy) return;
+    const int64_t row = heavy_rows[h];
+    const int ns = (indptr[row + 1] - indptr[row] + seg - 1) / seg;
+    const float *pp = partial + int64_t(heavy_seg_base[h]) * ldp;
+    const float rs = row_scale ? row_scale[row] : 1.f;
+    for (int f = lane; f < F; f += 64) {
+        float s = 0.f;
+        for (int k = 0; k < ns; ++k) s += pp[int64_t(k) * ldp + f];
+        store_scalar(M + row * ldm + f, s * rs);
+    }
+}
+
+template <typename T, int VEC, int LPR, int CH>
+int launch_segments(const int32_t *indptr, const int32_t *indices, const T *H, int64_t ldh, int F, const float *cs,
+                    const gae_spmm_plan *plan, float *partial, int ldp, hipStream_t s)
+{
+    const int nvec = (F + VEC - 1) / VEC;
+    const dim3 grid(unsigned((plan->n_segments + 3) / 4), unsigned((nvec + LPR * CH - 1) / (LPR * CH)));
+    if (cs)
+        hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, true>), grid, dim3(256), 0, s, indptr, indices, H, ldh,
+                           F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
+                           plan->segment_edges, partial, ldp);
+    else
+        hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, false>), grid, dim3(256), 0, s, indptr, indices, H,
+                           ldh, F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
+                           plan->segment_edges, partial, ldp);
+    GAE_CHECK_LAUNCH("spmm_segment_kernel");
+    return GAE_OK;
+}
+
+template <typename T, int VEC>
+int dispatch_segments(const int32_t *indptr, const int32_t *indices, const T *H, int64_t ldh, int F, const float *cs,
+                      const gae_spmm_plan *plan, float *partial, int ldp, hipStream_t s)
+{
+    const int nvec = (F + VEC - 1) / VEC;
+#define GAE_SEG(LPR, CH) return launch_segments<T, VEC, LPR, CH>(indptr, indices, H, ldh, F, cs, plan, partial, ldp, s)
+    if (nvec <= 4) GAE_SEG(4, 1);
+    if (nvec <= 8) GAE_SEG(8, 1);
+    if (nvec <= 16) GAE_SEG(16, 1);
+    if (nvec <= 32) GAE_SEG(32, 1);
+    if (nvec <= 64) GAE_SEG(64, 1);
+    GAE_SEG(64, 2);
+#undef GAE_SEG
+}
+
+inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+inline int plan_ldp(int64_t F) { return int((F + 3) / 4 * 4); }
+
+template <typename T, int VEC>
+int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols, const T *h, int64_t ldh,
+             T *m, int64_t ldm, int f, const float *rs, const float *cs, bool vec, const gae_spmm_plan *plan,
+             void *workspace, hipStream_t s)
+{
+    const bool heavy = plan && plan->n_heavy > 0;
+    const int skip = heavy ? plan->threshold : 0x7fffffff;
+    const int min_f = vec ? (sizeof(T) == 4 ? 12 : 24) : 3;
+    int rc;
+    if (g_spmm_variant == 2 && f > min_f)
+        rc = dispatch_rowgroup2<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, g_spmm_rpg,
+                                        g_spmm_nt != 0 && sizeof(T) == 4, n_cols, skip, s);
+    else {
+        GAE_REQUIRE(!heavy, GAE_E_RANGE, "gae_spmm_csr: a skew plan needs F > %d for this layout", min_f);
+        rc = dispatch_rowgroup<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, s);
+    }
+    if (rc || !heavy) return rc;
+    float *partial = static_cast<float *>(workspace);
+    const int ldp = plan_ldp(f);
+    rc = dispatch_segments<T, VEC>(indptr, indices, h, ldh, f, cs, plan, partial, ldp, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((spmm_combine_kernel<T>), dim3(unsigned((plan->n_heavy + 3) / 4)), dim3(256), 0, s, indptr,
+                       plan->heavy_rows, plan->heavy_seg_base, plan->n_heavy, plan->segment_edges, partial, ldp, f, rs,
+                       m, ldm);
+    GAE_CHECK_LAUNCH("spmm_combine_kernel");
+    return GAE_OK;
+}
+
 } // namespace
+
+extern "C" int gae_spmm_plan_count(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
+                                   uint64_t *counts_dev, void *stream)
+{
+    GAE_REQUIRE(n_rows >= 0, GAE_E_SIZE, "gae_spmm_plan_count: negative n_rows");
+    GAE_REQUIRE(threshold >= 1 && segment_edges >= 64 && segment_edges % 64 == 0, GAE_E_RANGE,
+                "gae_spmm_plan_count: threshold >= 1 and segment_edges a positive multiple of 64 required");
+    GAE_REQUIRE(indptr && counts_dev, GAE_E_NULL, "gae_spmm_plan_count: NULL pointer");
+    hipStream_t s = gae::as_stream(stream);
+    GAE_HIP(hipMemsetAsync(counts_dev, 0, 2 * sizeof(uint64_t), s));
+    if (n_rows == 0) return GAE_OK;
+    int64_t g = (n_rows + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(plan_count_kernel, dim3(unsigned(g)), dim3(256), 0, s, indptr, n_rows, threshold, segment_edges,
+                       reinterpret_cast<unsigned long long *>(counts_dev));
+    GAE_CHECK_LAUNCH("plan_count_kernel");
+    return GAE_OK;
+}
+
+extern "C" int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
+                                  uint64_t *cursors_dev, int32_t *heavy_rows, int32_t *heavy_seg_base,
+                                  int32_t *seg_heavy, void *stream)
+{
+    GAE_REQUIRE(n_rows >= 0, GAE_E_SIZE, "gae_spmm_plan_fill: negative n_rows");
+    GAE_REQUIRE(threshold >= 1 && segment_edges >= 64 && segment_edges % 64 == 0, GAE_E_RANGE,
+                "gae_spmm_plan_fill: threshold >= 1 and segment_edges a positive multiple of 64 required");
+    GAE_REQUIRE(indptr && cursors_dev && heavy_rows && heavy_seg_base && seg_heavy, GAE_E_NULL,
+                "gae_spmm_plan_fill: NULL pointer");
+    hipStream_t s = gae::as_stream(stream);
+    GAE_HIP(hipMemsetAsync(cursors_dev, 0, 2 * sizeof(uint64_t), s));
+    if (n_rows == 0) return GAE_OK;
+    int64_t g = (n_rows + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(plan_fill_kernel, dim3(unsigned(g)), dim3(256), 0, s, indptr, n_rows, threshold, segment_edges,
+                       reinterpret_cast<unsigned long long *>(cursors_dev), heavy_rows, heavy_seg_base, seg_heavy);
+    GAE_CHECK_LAUNCH("plan_fill_kernel");
+    return GAE_OK;
+}
+
+extern "C" int64_t gae_spmm_workspace_bytes(const gae_spmm_plan *plan, int64_t F)
+{
+    if (F < 0) return GAE_E_SIZE;
+    if (!plan || plan->n_heavy <= 0) return 0;
+    return align256(plan->n_segments * plan_ldp(F) * 4);
+}
 
 extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                             const void *H, int64_t ldh, void *M, int64_t ldm, int64_t F, int dtype,
-                            const float *row_scale, const float *col_scale, void *stream)
+                            const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
+                            void *workspace, int64_t workspace_bytes, void *stream)
 {
     GAE_REQUIRE(n_rows >= 0 && n_cols >= 0 && F >= 0, GAE_E_SIZE, "gae_spmm_csr: negative size");
     GAE_REQUIRE(F < (int64_t(1) << 24), GAE_E_SIZE, "gae_spmm_csr: F too large");
@@ -431,36 +691,29 @@ extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64
     // `indices` may be NULL only for an edge-less graph (indptr all zero): it is never dereferenced then
     GAE_REQUIRE(n_cols == 0 || H, GAE_E_NULL, "gae_spmm_csr: H is NULL with n_cols > 0");
     GAE_REQUIRE((n_rows + 3) / 4 < (int64_t(1) << 31), GAE_E_SIZE, "gae_spmm_csr: too many rows for one launch");
+    if (plan && plan->n_heavy > 0) {
+        GAE_REQUIRE(plan->heavy_rows && plan->heavy_seg_base && plan->seg_heavy && plan->n_segments >= plan->n_heavy &&
+                        plan->threshold >= 1 && plan->segment_edges >= 64 && plan->segment_edges % 64 == 0,
+                    GAE_E_RANGE, "gae_spmm_csr: malformed plan");
+        const int64_t need = gae_spmm_workspace_bytes(plan, F);
+        GAE_REQUIRE(workspace && workspace_bytes >= need, GAE_E_WORKSPACE, "gae_spmm_csr: workspace %lld < %lld bytes",
+                    (long long)workspace_bytes, (long long)need);
+        GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_spmm_csr: workspace not 16-byte aligned");
+    }
     hipStream_t s = gae::as_stream(stream);
     const int f = int(F);
     if (dtype == GAE_F32) {
         const float *h = static_cast<const float *>(H);
         float *m = static_cast<float *>(M);
         const bool vec = (ldh % 4 == 0) && (ldm % 4 == 0) && gae::aligned16(H) && gae::aligned16(M);
-        if (vec) {
-            if (g_spmm_variant == 2 && f > 12)
-                return dispatch_rowgroup2<float, 4>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale,
-                                                    g_spmm_rpg, g_spmm_nt != 0, n_cols, s);
-            return dispatch_rowgroup<float, 4>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale, s);
-        }
-        if (g_spmm_variant == 2 && f > 3)
-            return dispatch_rowgroup2<float, 1>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale,
-                                                g_spmm_rpg, g_spmm_nt != 0, n_cols, s);
-        return dispatch_rowgroup<float, 1>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale, s);
+        if (vec) return run_spmm<float, 4>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, true, plan, workspace, s);
+        return run_spmm<float, 1>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, false, plan, workspace, s);
     }
     const unsigned short *h = static_cast<const unsigned short *>(H);
     unsigned short *m = static_cast<unsigned short *>(M);
     const bool vec = (ldh % 8 == 0) && (ldm % 8 == 0) && gae::aligned16(H) && gae::aligned16(M);
-    if (vec) {
-        if (g_spmm_variant == 2 && f > 24)
-            return dispatch_rowgroup2<unsigned short, 8>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale,
-                                                         col_scale, g_spmm_rpg, false, n_cols, s);
-        return dispatch_rowgroup<unsigned short, 8>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale, s);
-    }
-    if (g_spmm_variant == 2 && f > 3)
-        return dispatch_rowgroup2<unsigned short, 1>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale,
-                                                     g_spmm_rpg, false, n_cols, s);
-    return dispatch_rowgroup<unsigned short, 1>(indptr, indices, n_rows, h, ldh, m, ldm, f, row_scale, col_scale, s);
+    if (vec) return run_spmm<unsigned short, 8>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, true, plan, workspace, s);
+    return run_spmm<unsigned short, 1>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, false, plan, workspace, s);
 }
 
 namespace gae { int *dense_knob(const char *name); }

@@ -70,6 +70,9 @@ class DeviceGraphDataset(Dataset):
         tp = self.t_indptr.cpu().numpy().astype(np.int64)
         self.t_edges_host = tp[gp[1:]] - tp[gp[:-1]]
         self.feat = torch.as_tensor(feat).to(dev).contiguous()
+        maxdeg = max(int((self.indptr[1:] - self.indptr[:-1]).max()) if N else 0,
+                     int((self.t_indptr[1:] - self.t_indptr[:-1]).max()) if N else 0)
+        self.no_heavy_rows = maxdeg <= ops.SKEW_THRESHOLD
         self.ids = np.arange(len(gp) - 1, dtype=np.int64) if ids is None else np.asarray(ids, dtype=np.int64)
 
     # -------------------------------------------------------------- Dataset protocol
@@ -108,6 +111,7 @@ class DeviceGraphDataset(Dataset):
         g.set_csr(ip, ix, tp, tx)
         g.ndata['h'] = feat
         g.batch_num_nodes = self.sizes_host[gids].tolist()
+        g.no_heavy_rows = self.no_heavy_rows
         return g
 
     # -------------------------------------------------------------- flat on-disk format

@@ -45,6 +45,7 @@ class Graph:
         self.edata = {}
         self.norm_mode = "none"      # "none" = reference behaviour, "both" = D^-1/2 A D^-1/2
         self.batch_num_nodes = None  # node counts per member graph when built by batch()
+        self.no_heavy_rows = False   # set by builders that know max degree <= ops.SKEW_THRESHOLD (skips the plan)
         self._cache = {}
         if graph_data is not None:
             self._init_from(graph_data, num_nodes)
@@ -161,6 +162,15 @@ class Graph:
             self._edge_list()
             self._cache["csc"] = ops.csr_from_coo(self._src, self._dst, self._n, self._n)
         return self._cache["csc"]
+
+    def spmm_plan(self, transposed=False):
+        """degree-skew plan of the CSR (or of the CSR of A^T); None when no row is heavy"""
+        key = "plan_t" if transposed else "plan"
+        if key not in self._cache:
+            from . import ops
+            indptr = (self.csc() if transposed else self.csr())[0]
+            self._cache[key] = None if self.no_heavy_rows else ops.spmm_plan(indptr)
+        return self._cache[key]
 
     def set_csr(self, indptr, indices, t_indptr=None, t_indices=None):
         """adopt an already-built device CSR (used by the device dataset batcher)"""

@@ -141,7 +141,43 @@ profiler = None  # set to an EventProfiler to time launches
 
 
 # ------------------------------------------------------------------ raw kernels
-def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=None):
+SKEW_THRESHOLD = 8       # rows with more in-edges than this go through the segment kernels
+SKEW_SEGMENT = 256       # edges per segment (multiple of 64)
+
+
+class SpmmPlan:
+    """degree-skew plan of one CSR (see gae_spmm_plan in include/gae_hip.h)"""
+
+    def __init__(self, threshold, segment, n_heavy, n_segments, heavy_rows, heavy_seg_base, seg_heavy):
+        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy)  # keep the device arrays alive
+        self.n_heavy, self.n_segments = n_heavy, n_segments
+        self.c = _lib.SpmmPlan(threshold, segment, n_heavy, n_segments, heavy_rows.data_ptr(),
+                               heavy_seg_base.data_ptr(), seg_heavy.data_ptr())
+
+
+def spmm_plan(indptr, threshold=None, segment=None):
+    """Build the skew plan of a CSR, or None when no row exceeds the threshold
+    (one host read-back of two counters; done once per graph)."""
+    threshold = SKEW_THRESHOLD if threshold is None else threshold
+    segment = SKEW_SEGMENT if segment is None else segment
+    _gpu(indptr, "indptr")
+    dev = indptr.device
+    n = indptr.numel() - 1
+    with torch.cuda.device(dev):
+        counts = torch.zeros(2, dtype=torch.int64, device=dev)
+        _lib.call("gae_spmm_plan_count", _ptr(indptr), n, threshold, segment, _ptr(counts), _stream())
+        n_heavy, n_seg = (int(v) for v in counts.tolist())
+        if n_heavy == 0:
+            return None
+        hr = torch.empty(n_heavy, dtype=torch.int32, device=dev)
+        hb = torch.empty(n_heavy, dtype=torch.int32, device=dev)
+        sh = torch.empty(n_seg, dtype=torch.int32, device=dev)
+        _lib.call("gae_spmm_plan_fill", _ptr(indptr), n, threshold, segment, _ptr(counts), _ptr(hr), _ptr(hb),
+                  _ptr(sh), _stream())
+    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh)
+
+
+def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=None, plan=None):
     """M = diag(row_scale) A diag(col_scale) H  (K1/K2)."""
     H, ldh = _rowmajor(H, "H")
     _gpu(indptr, "indptr")
@@ -152,9 +188,15 @@ def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=Non
     if out2 is not out:
         raise GaeHipError("spmm: `out` must be row-major with unit inner stride")
     with torch.cuda.device(H.device):
+        pc, ws, ws_bytes = None, None, 0
+        if plan is not None:
+            pc = ctypes.byref(plan.c)
+            ws_bytes = _lib.load().gae_spmm_workspace_bytes(pc, F)
+            ws = _workspace(ws_bytes, H.device)
+
         def launch():
             _lib.call("gae_spmm_csr", _ptr(indptr), _ptr(indices), n_rows, n_cols, _ptr(H), ldh, _ptr(out), ldm, F,
-                      _dtype_code(H), _ptr(row_scale), _ptr(col_scale), _stream())
+                      _dtype_code(H), _ptr(row_scale), _ptr(col_scale), pc, _ptr(ws), ws_bytes, _stream())
         if profiler is not None:
             profiler.wrap(("spmm", n_rows, n_cols, F, str(H.dtype)), launch)
         else:
@@ -266,14 +308,14 @@ class SpMMFunction(torch.autograd.Function):
         indptr, indices = graph.csr()
         norm = graph.norm() if use_norm else None
         ctx.graph, ctx.use_norm = graph, use_norm
-        return spmm_raw(indptr, indices, H, graph.number_of_nodes(), norm, norm)
+        return spmm_raw(indptr, indices, H, graph.number_of_nodes(), norm, norm, plan=graph.spmm_plan(False))
 
     @staticmethod
     def backward(ctx, dM):
         g = ctx.graph
         t_indptr, t_indices = g.csc()
         norm = g.norm() if ctx.use_norm else None
-        return spmm_raw(t_indptr, t_indices, dM, g.number_of_nodes(), norm, norm), None, None
+        return spmm_raw(t_indptr, t_indices, dM, g.number_of_nodes(), norm, norm, plan=g.spmm_plan(True)), None, None
 
 
 class LinearFunction(torch.autograd.Function):

@@ -119,10 +119,38 @@ int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indptr, const i
  * reference's un-normalised sum); passing norm for both gives D^-1/2 A D^-1/2
  * (gae_dgl/train_transductive.py:55-57).
  * H: [n_cols, F] ld ldh, M: [n_rows, F] ld ldm, dtype GAE_F32 or GAE_BF16
- * (same dtype in and out, fp32 accumulate in CSR order: deterministic). */
+ * (same dtype in and out, fp32 accumulate, no float atomics: deterministic).
+ *
+ * Degree-skew plan (optional, for power-law graphs): rows with more than
+ * `threshold` edges are cut into segments of `segment_edges` edges that
+ * separate waves gather; segment partial sums are added in segment order.
+ * Build: gae_spmm_plan_count -> read the two counters -> allocate ->
+ * gae_spmm_plan_fill; the plan is valid as long as indptr is.  plan = NULL (or
+ * n_heavy = 0): every row is summed by one lane group in CSR order. */
+typedef struct gae_spmm_plan {
+    int32_t threshold;              /* rows with degree > threshold are heavy */
+    int32_t segment_edges;          /* multiple of 64 */
+    int64_t n_heavy;                /* heavy rows */
+    int64_t n_segments;             /* sum over heavy rows of ceil(degree / segment_edges) */
+    const int32_t *heavy_rows;      /* [n_heavy]    row ids                       (device) */
+    const int32_t *heavy_seg_base;  /* [n_heavy]    first segment of the row      (device) */
+    const int32_t *seg_heavy;       /* [n_segments] heavy-row slot of the segment (device) */
+} gae_spmm_plan;
+
+/* counts_dev[0] = number of heavy rows, counts_dev[1] = number of segments (uint64, device) */
+int gae_spmm_plan_count(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
+                        uint64_t *counts_dev, void *stream);
+/* cursors_dev: 2 x uint64 scratch (zeroed by the call); output arrays sized from the counts */
+int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
+                       uint64_t *cursors_dev, int32_t *heavy_rows, int32_t *heavy_seg_base,
+                       int32_t *seg_heavy, void *stream);
+/* bytes of workspace gae_spmm_csr needs with this plan (0 without one) */
+int64_t gae_spmm_workspace_bytes(const gae_spmm_plan *plan_host, int64_t F);
+
 int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                  const void *H, int64_t ldh, void *M, int64_t ldm, int64_t F, int dtype,
-                 const float *row_scale, const float *col_scale, void *stream);
+                 const float *row_scale, const float *col_scale,
+                 const gae_spmm_plan *plan_host, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16

@@ -107,6 +107,40 @@ def test_spmm_fp32(F, scaled, dev):
         assert np.array_equal(out.cpu().numpy(), c_oracle.spmm_csr(ip, ix, H))
 
 
+@pytest.mark.parametrize("F,dtype", [(32, torch.float32), (39, torch.float32), (16, torch.float32),
+                                      (500, torch.float32), (64, torch.bfloat16)])
+@pytest.mark.parametrize("thr,seg", [(1, 64), (8, 128), (64, 512)])
+def test_spmm_skew_plan(F, dtype, thr, seg, dev):
+    """heavy rows cut into segments (power-law graphs): same result as the oracle, deterministic"""
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(F + thr)
+    n, e = 3000, 60000
+    src = rng.integers(0, n, e)
+    dst = (rng.integers(0, n, e).astype(np.float64) ** 3 / n ** 2).astype(np.int64)   # heavy head, long tail
+    dst[:5000] = 7                                                                    # one 5000+-edge hub
+    H = rng.standard_normal((n, F)).astype(np.float32)
+    ip, ix = O().csr_from_coo(src, dst, n)
+    norm = O().norm_from_in_degrees(O().in_degrees(dst, n)).numpy()
+    dip, dix = t(ip, dev), t(ix, dev)
+    plan = ops.spmm_plan(dip, threshold=thr, segment=seg)
+    assert plan is not None and plan.n_heavy > 0 and plan.n_segments >= plan.n_heavy
+    deg = np.diff(ip)
+    assert plan.n_heavy == int((deg > thr).sum())
+    assert plan.n_segments == int(np.ceil(deg[deg > thr] / seg).sum())
+    Hd = t(H, dev).to(dtype)
+    tol = TOL if dtype == torch.float32 else 1e-2
+    for scaled in (False, True):
+        sc = t(norm, dev) if scaled else None
+        ref = O().spmm_csr(ip, ix, Hd.float().cpu().double(), norm if scaled else None, norm if scaled else None)
+        out = ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=plan)
+        assert rel_err(out.float(), ref) < tol
+        out2 = ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=plan)
+        assert torch.equal(out, out2)                         # bit-stable run to run
+        base = ops.spmm_raw(dip, dix, Hd, n, sc, sc)          # no plan: CSR-order sums
+        assert rel_err(out.float(), base.float()) < tol
+    assert ops.spmm_plan(dip, threshold=10 ** 6) is None      # nothing heavy -> no plan
+
+
 def test_spmm_padded_ld_and_views(dev):
     from gae_dgl_amd import ops
     rng = np.random.default_rng(1)
@@ -171,10 +205,14 @@ def test_spmm_properties_large(dev):
     out = ops.spmm_raw(ip, ix, ones, n)
     assert torch.equal(out[:, 0], deg.float()) and torch.equal(out[:, F - 1], deg.float())
     x = torch.randn(n, F, device=dev, generator=gen); y = torch.randn(n, F, device=dev, generator=gen)
-    ax, ay = ops.spmm_raw(ip, ix, x, n), ops.spmm_raw(ip, ix, y, n)
-    axy = ops.spmm_raw(ip, ix, 2 * x + y, n)
+    plan, tplan = ops.spmm_plan(ip), ops.spmm_plan(tp)
+    assert plan is not None                                    # skewed in-degrees
+    assert torch.equal(ops.spmm_raw(ip, ix, ones, n, plan=plan)[:, 3], deg.float())
+    ax, ay = ops.spmm_raw(ip, ix, x, n, plan=plan), ops.spmm_raw(ip, ix, y, n, plan=plan)
+    axy = ops.spmm_raw(ip, ix, 2 * x + y, n, plan=plan)
     assert rel_err(axy, 2 * ax + ay) < TOL
-    aty = ops.spmm_raw(tp, tx, y, n)
+    assert rel_err(ax, ops.spmm_raw(ip, ix, x, n)) < TOL       # plan vs CSR-order sums
+    aty = ops.spmm_raw(tp, tx, y, n, plan=tplan)
     lhs = float((ax.double() * y.double()).sum()); rhs = float((x.double() * aty.double()).sum())
     assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
 

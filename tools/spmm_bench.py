@@ -31,6 +31,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rmat-scale", type=int, default=22)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--no-plan", action="store_true")
+    ap.add_argument("--thr", type=int, default=64)
+    ap.add_argument("--seg", type=int, default=512)
     ap.add_argument("--variants", default="v1:1:0,v2:1:0,v2:2:0,v2:1:1,v2:2:1")
     ap.add_argument("--shapes", default="pubmed500,pubmed32,zincb39,zincb32,zinc39,zinc32,rmat32")
     args = ap.parse_args()
@@ -65,6 +68,11 @@ def main():
         ip, ix = ops.csr_from_coo(dst, src, n, n)
         del src, dst
         shapes["rmat32"] = (ip, ix, n, 32, 32)
+    plans = {}
+    if "rmat32" in shapes and not args.no_plan:
+        plans["rmat32"] = ops.spmm_plan(shapes["rmat32"][0], args.thr, args.seg)
+        pl = plans["rmat32"]
+        print(f"rmat plan: thr={args.thr} seg={args.seg} heavy rows={pl.n_heavy} segments={pl.n_segments}")
     variants = []
     for v in args.variants.split(","):
         parts = v.split(":")
@@ -83,12 +91,12 @@ def main():
         for rnd in range(args.rounds + 1):
             for (label, var, rpg, nt, tv) in variants:
                 knob("spmm_variant", var); knob("spmm_rpg", rpg); knob("spmm_nt", nt); knob("spmm_tile_vecs", tv)
-                fn = lambda: ops.spmm_raw(ip, ix, H, n, out=out)
+                fn = lambda: ops.spmm_raw(ip, ix, H, n, out=out, plan=plans.get(sname))
                 fn(); torch.cuda.synchronize()
                 if rnd == 0:
                     if ref is None:
                         ref = out.clone()
-                    else:
+                    elif plans.get(sname) is None:
                         assert torch.equal(out, ref), f"variant {label} differs on {sname}"
                     continue
                 res[label].append(time_once(fn, iters))
