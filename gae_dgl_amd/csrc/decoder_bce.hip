@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256) void bce_prepare_kernel(const float *__restric
 // ---------------------------------------------------------------------------
 template <int KS, bool WITH_GRAD>
 __global__ __launch_bounds__(256) void bce_dense_kernel(
-    const float *__restrict__ Zt /*[n][16 KS]*/, int64_t n, int64_t cols_per_split,
-    float *__restrict__ O_partial /*[splits][n][KS*16]*/, double *__restrict__ loss_partial /*[gridDim.x * gridDim.y]*/)
+    const float *__restrict__ Zt /*[n][16 KS]*/, int64_t n, int64_t row_begin, int64_t n_local,
+    int64_t cols_per_split, float *__restrict__ O_partial /*[splits][n_local][KS*16]*/,
+    double *__restrict__ loss_partial /*[gridDim.x * gridDim.y]*/)
 {
     constexpr int DP = KS * 16;          // padded feature width
     constexpr int LDA = DP + 4;          // LDS row stride (floats): 16-byte aligned, breaks the power of two
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void bce_dense_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
+    // rows are LOCAL ids (0 .. n_local) of the window [row_begin, row_begin + n_local) of Zt
     const int64_t row_base = int64_t(blockIdx.x) * ROWS_PER_BLOCK + wave * (RI * 16);
     const int64_t col_begin = int64_t(blockIdx.y) * cols_per_split;
     int64_t col_end = col_begin + cols_per_split;
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(256) void bce_dense_kernel(
         const int64_t i = row_base + ri * 16 + l15;
 #pragma unroll
         for (int c = 0; c < KS; ++c)
-            bfrag[ri][c] = i < n ? *reinterpret_cast<const f32x4 *>(Zt + i * DP + 16 * c + 4 * g)
-                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+            bfrag[ri][c] = i < n_local ? *reinterpret_cast<const f32x4 *>(Zt + (row_begin + i) * DP + 16 * c + 4 * g)
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     f32x4 oacc[RI][KS];
 #pragma unroll
@@ -194,13 +196,13 @@ __global__ __launch_bounds__(256) void bce_dense_kernel(
     }
     // ---- O partial: oacc[ri][c][r] = O(i = 4 g + r, nn = l15) of subtile ri, feature 16 c + nn
     if (WITH_GRAD) {
-        float *op = O_partial + int64_t(blockIdx.y) * n * DP;
+        float *op = O_partial + int64_t(blockIdx.y) * n_local * DP;
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t i = row_base + ri * 16 + 4 * g + r;
-                if (i < n) {
+                if (i < n_local) {
 #pragma unroll
                     for (int c = 0; c < KS; ++c) op[i * DP + 16 * c + l15] = oacc[ri][c][r];
                 }
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void bce_dense_kernel(
     // ---- loss partial: drop rows >= n, wave reduce (fixed tree) -> block
     double ls = 0.0;
 #pragma unroll
-    for (int ri = 0; ri < RI; ++ri) ls += (row_base + ri * 16 + l15) < n ? lsum[ri] : 0.0;
+    for (int ri = 0; ri < RI; ++ri) ls += (row_base + ri * 16 + l15) < n_local ? lsum[ri] : 0.0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ls += __shfl_down(ls, off, 64);
     if (lane == 0) red[wave] = ls;
@@ -225,8 +227,8 @@ __global__ __launch_bounds__(256) void bce_dense_kernel(
 // ---------------------------------------------------------------------------
 template <int VEC, int LPR, bool WITH_GRAD>
 __global__ __launch_bounds__(256) void bce_edges_kernel(
-    const float *__restrict__ Z, const float *__restrict__ mask, int64_t ldz, int64_t n, int d,
-    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ Z, const float *__restrict__ mask, int64_t ldz, int64_t row_begin, int64_t n_local,
+    int d, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
     const int32_t *__restrict__ t_indptr, const int32_t *__restrict__ t_indices, float pw, float inv_n2,
     const float *__restrict__ O_partial, int n_splits, int DP, float *__restrict__ dZ, int64_t lddz,
     double *__restrict__ loss_partial)
@@ -235,7 +237,9 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
     constexpr int RPB = 256 / LPR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lig = tid % LPR;
-    const int64_t i = int64_t(blockIdx.x) * RPB + tid / LPR;
+    const int64_t i = int64_t(blockIdx.x) * RPB + tid / LPR;   // local row
+    const int64_t gi = row_begin + i;                          // its row in Z / mask
+    const int64_t n = n_local;
     const int f0 = lig * VEC;
     const bool rowv = i < n;
 
@@ -245,8 +249,8 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
         acc[q] = 0.f;
         float v = 0.f;
         if (rowv && f0 + q < d) {
-            v = Z[i * ldz + f0 + q];
-            if (mask) v *= mask[i * ldz + f0 + q];
+            v = Z[gi * ldz + f0 + q];
+            if (mask) v *= mask[gi * ldz + f0 + q];
         }
         zi[q] = v;
     }
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
                 float o = 0.f;
                 for (int s = 0; s < n_splits; ++s) o += O_partial[(int64_t(s) * n + i) * DP + f];
                 float v = (2.0f * o + acc[q]) * inv_n2;
-                if (mask) v *= mask[i * ldz + f];
+                if (mask) v *= mask[gi * ldz + f];
                 dZ[i * lddz + f] = v;
             }
         }
@@ -324,14 +328,14 @@ struct BcePlan {
 
 inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
-bool bce_plan(int64_t n, int64_t d, bool vec_ok, BcePlan &p)
+bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
 {
     if (d > 64) return false;
     p.KS = int((d + 15) / 16);
     if (p.KS == 3) p.KS = 4;
     if (p.KS < 1) p.KS = 1;
     p.DP = p.KS * 16;
-    p.row_blocks = (n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    p.row_blocks = (n_local + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     if (p.row_blocks < 1) p.row_blocks = 1;
     int64_t col_tiles = (n + TJ - 1) / TJ;
     if (col_tiles < 1) col_tiles = 1;
@@ -347,9 +351,9 @@ bool bce_plan(int64_t n, int64_t d, bool vec_ok, BcePlan &p)
     int lpr = 1;
     while (lpr < nvec) lpr <<= 1;
     p.LPR = lpr;
-    p.edge_blocks = (n + (256 / lpr) - 1) / (256 / lpr);
+    p.edge_blocks = (n_local + (256 / lpr) - 1) / (256 / lpr);
     if (p.edge_blocks < 1) p.edge_blocks = 1;
-    p.o_bytes = align256(p.n_splits * n * p.DP * 4);
+    p.o_bytes = align256(p.n_splits * n_local * p.DP * 4);
     p.zt_bytes = align256(n * p.DP * 4);
     p.loss_count = p.row_blocks * p.n_splits + p.edge_blocks;
     p.total_bytes = p.o_bytes + p.zt_bytes + align256(p.loss_count * 8);
@@ -357,26 +361,27 @@ bool bce_plan(int64_t n, int64_t d, bool vec_ok, BcePlan &p)
 }
 
 template <bool WITH_GRAD>
-int launch_dense(const BcePlan &p, const float *Zt, int64_t n, float *O, double *lp, hipStream_t s)
+int launch_dense(const BcePlan &p, const float *Zt, int64_t n, int64_t row_begin, int64_t n_local, float *O,
+                 double *lp, hipStream_t s)
 {
     const dim3 grid(unsigned(p.row_blocks), unsigned(p.n_splits));
     switch (p.KS) {
-    case 1: hipLaunchKernelGGL((bce_dense_kernel<1, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, p.cols_per_split, O, lp); break;
-    case 2: hipLaunchKernelGGL((bce_dense_kernel<2, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, p.cols_per_split, O, lp); break;
-    default: hipLaunchKernelGGL((bce_dense_kernel<4, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, p.cols_per_split, O, lp); break;
+    case 1: hipLaunchKernelGGL((bce_dense_kernel<1, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, row_begin, n_local, p.cols_per_split, O, lp); break;
+    case 2: hipLaunchKernelGGL((bce_dense_kernel<2, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, row_begin, n_local, p.cols_per_split, O, lp); break;
+    default: hipLaunchKernelGGL((bce_dense_kernel<4, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, row_begin, n_local, p.cols_per_split, O, lp); break;
     }
     GAE_CHECK_LAUNCH("bce_dense_kernel");
     return GAE_OK;
 }
 
 template <int VEC, bool WITH_GRAD>
-int launch_edges(const BcePlan &p, const float *Z, const float *mask, int64_t ldz, int64_t n, int d,
+int launch_edges(const BcePlan &p, const float *Z, const float *mask, int64_t ldz, int64_t row_begin, int64_t n, int d,
                  const int32_t *ip, const int32_t *ix, const int32_t *tp, const int32_t *tx, float pw, float inv_n2,
                  const float *O, float *dZ, int64_t lddz, double *lp, hipStream_t s)
 {
 #define GAE_EDGE(LPR)                                                                                              \
     hipLaunchKernelGGL((bce_edges_kernel<VEC, LPR, WITH_GRAD>), dim3(unsigned(p.edge_blocks)), dim3(256), 0, s, Z,  \
-                       mask, ldz, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, dZ, lddz, lp)
+                       mask, ldz, row_begin, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, dZ, lddz, lp)
     switch (p.LPR) {
     case 1: GAE_EDGE(1); break;
     case 2: GAE_EDGE(2); break;
@@ -393,29 +398,31 @@ int launch_edges(const BcePlan &p, const float *Z, const float *mask, int64_t ld
 
 } // namespace
 
-extern "C" int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t d)
+extern "C" int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t n_local, int64_t d)
 {
-    if (n < 0 || d < 0) return GAE_E_SIZE;
+    if (n < 0 || d < 0 || n_local < 0 || n_local > n) return GAE_E_SIZE;
     BcePlan p;
-    if (!bce_plan(n, d, true, p)) return GAE_E_RANGE;
+    if (!bce_plan(n, n_local, d, true, p)) return GAE_E_RANGE;
     return p.total_bytes + 256;
 }
 
-extern "C" int gae_decoder_bce(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
-                               const int32_t *indptr, const int32_t *indices, const int32_t *t_indptr,
-                               const int32_t *t_indices, float pos_weight, float *loss_out, float *dZ, int64_t lddz,
-                               void *workspace, int64_t workspace_bytes, void *stream)
+extern "C" int gae_decoder_bce_rows(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
+                                    int64_t row_begin, int64_t n_local, const int32_t *indptr,
+                                    const int32_t *indices, const int32_t *t_indptr, const int32_t *t_indices,
+                                    float pos_weight, float *loss_out, float *dZ, int64_t lddz, void *workspace,
+                                    int64_t workspace_bytes, void *stream)
 {
     GAE_REQUIRE(n > 0 && d > 0, GAE_E_SIZE, "gae_decoder_bce: n and d must be positive");
+    GAE_REQUIRE(row_begin >= 0 && n_local >= 0 && row_begin + n_local <= n, GAE_E_SIZE,
+                "gae_decoder_bce: row window outside [0, n)");
     GAE_REQUIRE(d <= 64, GAE_E_RANGE, "gae_decoder_bce: d = %lld > 64 not supported by the fused kernel",
                 (long long)d);
     GAE_REQUIRE(n < (int64_t(1) << 31), GAE_E_SIZE, "gae_decoder_bce: n too large");
     GAE_REQUIRE(ldz >= d && (!dZ || lddz >= d), GAE_E_SIZE, "gae_decoder_bce: leading dimension too small");
-    GAE_REQUIRE(Z && indptr && loss_out && workspace, GAE_E_NULL, "gae_decoder_bce: NULL pointer");
-    GAE_REQUIRE(!dZ || t_indptr, GAE_E_NULL, "gae_decoder_bce: the gradient needs the CSR of A^T");
-    const bool vec_ok = true;  // the edge kernel uses scalar loads per feature; VEC only sets lanes per row
+    GAE_REQUIRE(Z && loss_out && workspace && (n_local == 0 || indptr), GAE_E_NULL, "gae_decoder_bce: NULL pointer");
+    GAE_REQUIRE(!dZ || n_local == 0 || t_indptr, GAE_E_NULL, "gae_decoder_bce: the gradient needs the CSR of A^T");
     BcePlan p;
-    bce_plan(n, d, vec_ok, p);
+    bce_plan(n, n_local, d, true, p);
     GAE_REQUIRE(workspace_bytes >= p.total_bytes, GAE_E_WORKSPACE, "gae_decoder_bce: workspace %lld < %lld bytes",
                 (long long)workspace_bytes, (long long)p.total_bytes);
     GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_decoder_bce: workspace not 16-byte aligned");
@@ -424,21 +431,35 @@ extern "C" int gae_decoder_bce(const float *Z, const float *mask, int64_t ldz, i
     float *Zt = reinterpret_cast<float *>(static_cast<char *>(workspace) + p.o_bytes);
     double *lp = reinterpret_cast<double *>(static_cast<char *>(workspace) + p.o_bytes + p.zt_bytes);
     const double inv_n2 = 1.0 / (double(n) * double(n));
+    if (n_local == 0) {
+        GAE_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), s));
+        return GAE_OK;
+    }
     {
         int64_t gb = (n * p.DP + 255) / 256;
         if (gb > 2048) gb = 2048;
         hipLaunchKernelGGL(bce_prepare_kernel, dim3(unsigned(gb)), dim3(256), 0, s, Z, mask, ldz, n, int(d), p.DP, Zt);
         GAE_CHECK_LAUNCH("bce_prepare_kernel");
     }
-    int rc = dZ ? launch_dense<true>(p, Zt, n, O, lp, s) : launch_dense<false>(p, Zt, n, O, lp, s);
+    int rc = dZ ? launch_dense<true>(p, Zt, n, row_begin, n_local, O, lp, s)
+                : launch_dense<false>(p, Zt, n, row_begin, n_local, O, lp, s);
     if (rc) return rc;
     double *lpe = lp + p.row_blocks * p.n_splits;
-    rc = dZ ? launch_edges<4, true>(p, Z, mask, ldz, n, int(d), indptr, indices, t_indptr, t_indices, pos_weight,
-                                    float(inv_n2), O, dZ, lddz, lpe, s)
-            : launch_edges<4, false>(p, Z, mask, ldz, n, int(d), indptr, indices, t_indptr, t_indices, pos_weight,
-                                     float(inv_n2), O, dZ, lddz, lpe, s);
+    rc = dZ ? launch_edges<4, true>(p, Z, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr, t_indices,
+                                    pos_weight, float(inv_n2), O, dZ, lddz, lpe, s)
+            : launch_edges<4, false>(p, Z, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr,
+                                     t_indices, pos_weight, float(inv_n2), O, dZ, lddz, lpe, s);
     if (rc) return rc;
     hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(256), 0, s, lp, p.loss_count, inv_n2, loss_out);
     GAE_CHECK_LAUNCH("bce_finalize_kernel");
     return GAE_OK;
+}
+
+extern "C" int gae_decoder_bce(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
+                               const int32_t *indptr, const int32_t *indices, const int32_t *t_indptr,
+                               const int32_t *t_indices, float pos_weight, float *loss_out, float *dZ, int64_t lddz,
+                               void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return gae_decoder_bce_rows(Z, mask, ldz, n, d, 0, n, indptr, indices, t_indptr, t_indices, pos_weight, loss_out,
+                                dZ, lddz, workspace, workspace_bytes, stream);
 }

@@ -271,27 +271,30 @@ def decoder_dense_bwd_raw(G, Z, mask=None):
     return dZ
 
 
-def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True):
-    """fused decoder + weighted BCE (mean): returns (loss[1], dZ or None)"""
+def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, n_local=None):
+    """fused decoder + weighted BCE (mean): returns (loss[1], dZ or None).
+    ``row_begin/n_local`` select a row window (row-sharded form): Z/mask stay the
+    full [n, d] arrays, csr/csc are the window's local row blocks."""
     Z = _gpu(Z, "Z").contiguous()
     if mask is not None:
         mask = _gpu(mask, "mask").contiguous()
     n, d = Z.shape
+    n_local = n if n_local is None else int(n_local)
     dev = Z.device
     loss = torch.empty(1, dtype=torch.float32, device=dev)
-    dZ = torch.empty(n, d, dtype=torch.float32, device=dev) if want_grad else None
+    dZ = torch.empty(n_local, d, dtype=torch.float32, device=dev) if want_grad else None
     indptr, indices = csr
     t_indptr, t_indices = csc if csc is not None else (None, None)
     with torch.cuda.device(dev):
-        nbytes = _lib.load().gae_decoder_bce_workspace_bytes(n, d)
+        nbytes = _lib.load().gae_decoder_bce_workspace_bytes(n, n_local, d)
         if nbytes < 0:
             _lib.check(int(nbytes), "gae_decoder_bce_workspace_bytes")
         ws = _workspace(nbytes, dev)
 
         def launch():
-            _lib.call("gae_decoder_bce", _ptr(Z), _ptr(mask), max(d, 1), n, d, _ptr(indptr), _ptr(indices),
-                      _ptr(t_indptr), _ptr(t_indices), float(pos_weight), _ptr(loss), _ptr(dZ), max(d, 1),
-                      _ptr(ws), ws.numel(), _stream())
+            _lib.call("gae_decoder_bce_rows", _ptr(Z), _ptr(mask), max(d, 1), n, d, int(row_begin), n_local,
+                      _ptr(indptr), _ptr(indices), _ptr(t_indptr), _ptr(t_indices), float(pos_weight), _ptr(loss),
+                      _ptr(dZ), max(d, 1), _ptr(ws), ws.numel(), _stream())
         if profiler is not None:
             profiler.wrap(("decoder_bce", n, d, want_grad), launch)
         else:
@@ -375,6 +378,43 @@ class DecoderBCEFunction(torch.autograd.Function):
 
 def decoder_bce(Z, mask, graph):
     return DecoderBCEFunction.apply(Z, mask, graph)
+
+
+class ShardedDecoderBCEFunction(torch.autograd.Function):
+    """Row block of the fused loss on a row-sharded graph (parallel.ShardedGraph):
+    Zt = Z (.) mask is all-gathered (N x d, small), each rank evaluates its rows
+    against all columns, the partial means are summed with a scalar all-reduce."""
+
+    @staticmethod
+    def forward(ctx, z_local, mask_local, sg, n_edges_global):
+        p = sg.part
+        zt_local = z_local if mask_local is None else z_local * mask_local
+        full = sg.allgather_rows(zt_local)
+        n = p.n
+        pw = (float(n) * float(n) - float(n_edges_global)) / float(n_edges_global)
+        need = ctx.needs_input_grad[0]
+        if p.mode != "allgather":
+            raise GaeHipError("sharded_decoder_bce needs global column ids (exchange mode 'allgather')")
+        loss, dzt = decoder_bce_raw(full[:n], None, sg.csr("fwd"), sg.csr("bwd") if need else None, pw,
+                                    want_grad=need, row_begin=p.r0, n_local=p.n_local)
+        sg.allreduce_sum(loss)
+        ctx.save_for_backward(dzt, mask_local)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dzt, mask_local = ctx.saved_tensors
+        dz = dzt * g
+        if mask_local is not None:
+            dz = dz * mask_local
+        return dz, None, None, None
+
+
+def sharded_decoder_bce(z_local, mask_local, sg, n_edges_global=None):
+    if n_edges_global is None:
+        t = sg.allreduce_sum(torch.tensor([sg.n_edges("fwd")], dtype=torch.int64, device=z_local.device))
+        n_edges_global = int(t)
+    return ShardedDecoderBCEFunction.apply(z_local, mask_local, sg, n_edges_global)
 
 
 def spmm(graph, H, use_norm=False):

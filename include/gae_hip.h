@@ -198,12 +198,25 @@ int gae_decoder_dense_bwd(const float *G, int64_t ldg, const float *Z, const flo
  *   dZ       : d loss / d Z  [n, d] (NULL = loss only, e.g. validation); needs the
  *              CSR of A^T (t_indptr, t_indices) for the G^T term
  *   d <= 64.  Ordered two-stage reductions: deterministic. */
-int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t d);
+int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t n_local, int64_t d);
 int gae_decoder_bce(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
                     const int32_t *indptr, const int32_t *indices,
                     const int32_t *t_indptr, const int32_t *t_indices, float pos_weight,
                     float *loss_out, float *dZ, int64_t lddz,
                     void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Row-sharded form (one rank of a 1-D row partition): rows
+ * [row_begin, row_begin + n_local) of the N x N loss against ALL n columns.
+ * Z / mask are the full (all-gathered) [n, d] arrays; indptr / t_indptr are the
+ * rank's LOCAL row blocks of A and A^T (n_local + 1 entries, global column ids);
+ * loss_out receives this block's share of the mean (sum over ranks = the loss);
+ * dZ [n_local, d] is the gradient of the GLOBAL loss w.r.t. the local rows. */
+int gae_decoder_bce_rows(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
+                         int64_t row_begin, int64_t n_local,
+                         const int32_t *indptr, const int32_t *indices,
+                         const int32_t *t_indptr, const int32_t *t_indices, float pos_weight,
+                         float *loss_out, float *dZ, int64_t lddz,
+                         void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }
