@@ -1,19 +1,30 @@
 #!/usr/bin/env python3
-"""Benchmark of the GCN-encoder hot path on MI355X (contract: see the task
-statement; metric and configs: BASELINE.json).
+"""Benchmark of the GCN-encoder hot path on MI355X (metric / configs: BASELINE.json).
 
   python bench.py --gpus 1 --steps K --warmup W [--workload pubmed|cora|citeseer|zinc|rmat]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic input:
-  * citation workloads (pubmed = BASELINE configs[1], default at N=1): one
-    full-graph training step = encoder forward (2 HIP SpMM + 2 fused Linear),
-    inner-product decoder + weighted BCE, backward (HIP SpMM on A^T, Linear
-    backward), Adam -- i.e. one transductive epoch.
-  * value = SpMM edges aggregated per step (fwd + bwd launches) / step time,
-    whole job, inputs resident in HBM.
-The JSON line also carries `roofline` (dominant SpMM kernel, live HIP-event
-timing inside the timed region), `cpu_baseline` (the CPU oracle's step timed on
-this host) and `extra` (kernel-only SpMM numbers for the other BASELINE shapes).
+
+  pubmed / cora / citeseer (N=1 default: pubmed = BASELINE configs[1])
+      one full-graph training step = one transductive epoch: encoder forward
+      (2 HIP SpMM + 2 fp32-MFMA Linear), fused inner-product decoder + weighted
+      BCE (never materialises N x N), backward (HIP SpMM on A^T, Linear
+      backward), Adam.
+  zinc    one inductive training step on a batch of 4096 ZINC-shaped molecules:
+      on-device dgl.batch (HIP gather from the dataset CSR) + the same step.
+  rmat    (default for N>1) RMAT scale 24 / edge factor 16, F=32, graph
+      row-sharded over the N ranks with an RCCL all-gather of H before every
+      SpMM: encoder forward + backward + gradient all-reduce + Adam.  The
+      O(N^2) decoder is not part of this config (2.8e14 logits); the encoder's
+      upstream gradient dZ is a fixed synthetic tensor.  Strong scaling.
+
+value = SpMM edges aggregated per step (forward + backward launches, all ranks)
+/ step time: whole-job, inputs resident in HBM, max over ranks.
+`roofline`  : the step's dominant SpMM launch, HIP-event timed inside the timed
+              region on the launch stream, against SURVEY.md 8(d)'s B_alg.
+`cpu_baseline`: the CPU oracle's restatement of the same step on this host.
+`extra`     : kernel-only SpMM numbers for the other BASELINE shapes.
 """
 import argparse
 import json
@@ -42,6 +53,9 @@ def parse():
     ap.add_argument("--loss", choices=["fused", "dense"], default="fused",
                     help="fused = HIP decoder+BCE kernel (never materialises N x N); dense = reference-shaped "
                          "N x N logits/labels with torch BCE")
+    ap.add_argument("--rmat-scale", type=int, default=24)
+    ap.add_argument("--batch-graphs", type=int, default=4096)
+    ap.add_argument("--exchange", choices=["allgather", "boundary"], default="allgather")
     return ap.parse_args()
 
 
@@ -59,105 +73,188 @@ def time_launches(fn, iters=50, warmup=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def spmm_probe(indptr, indices, n, F, dtype=torch.float32, label=""):
-    """kernel-only SpMM throughput for one shape (fwd structure only)"""
+def spmm_probe(indptr, indices, n, F, ld=None, plan=None, label="", iters=50):
+    """kernel-only SpMM throughput for one shape"""
     from gae_dgl_amd import ops, workloads as W
-    H = torch.rand(n, F, device=indptr.device).to(dtype)
-    out = torch.empty_like(H)
-    t = time_launches(lambda: ops.spmm_raw(indptr, indices, H, n, out=out))
+    ld = ld or F
+    H = torch.rand(n, ld, device=indptr.device)[:, :F]
+    out = torch.empty(n, ld, device=indptr.device)[:, :F]
+    t = time_launches(lambda: ops.spmm_raw(indptr, indices, H, n, out=out, plan=plan), iters=iters)
     nnz = int(indices.numel())
-    b = W.spmm_alg_bytes(n, n, nnz, F, H.element_size())
-    return {"shape": label, "n": n, "nnz": nnz, "F": F, "dtype": str(dtype).replace("torch.", ""),
-            "us_per_launch": t * 1e6, "edges_per_s": nnz / t, "alg_bytes": b, "achieved_GBs": b / t / 1e9,
+    b = W.spmm_alg_bytes(n, n, nnz, F, 4)
+    return {"shape": label, "n": n, "nnz": nnz, "F": F, "ld": ld, "dtype": "float32", "us_per_launch": t * 1e6,
+            "edges_per_s": nnz / t, "alg_bytes": b, "achieved_GBs": b / t / 1e9,
             "frac_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS}
 
 
-def citation_workload(name, args, dev):
-    import gae_dgl_amd as G
-    from gae_dgl_amd import ops, workloads as W
-    n, src, dst, X = W.citation_graph(name, seed=0)
-    F_in = X.shape[1]
-    hidden = [32, 16]
-    torch.manual_seed(0)
-    model = G.GAE(F_in, hidden).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2)       # train_transductive.py:43
-    g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
-    Xd = torch.from_numpy(X).to(dev)
-    g.csr(); g.csc()                                          # structure is static across epochs
-    E = g.number_of_edges()
-    bce = torch.nn.functional.binary_cross_entropy_with_logits
+# ---------------------------------------------------------------------------------------------- workloads
+class CitationWorkload:
+    def __init__(self, name, args, dev):
+        import gae_dgl_amd as G
+        from gae_dgl_amd import workloads as W
+        self.args, self.dev = args, dev
+        n, src, dst, X = W.citation_graph(name, seed=0)
+        self.n, self.src, self.dst, self.X = n, src, dst, X
+        self.F_in, self.hidden = X.shape[1], [32, 16]
+        torch.manual_seed(0)
+        self.model = G.GAE(self.F_in, self.hidden).to(dev)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-2)        # train_transductive.py:43
+        self.g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+        self.Xd = torch.from_numpy(X).to(dev)
+        self.g.csr(); self.g.csc(); self.g.spmm_plan(False); self.g.spmm_plan(True)   # structure is static
+        E = self.g.number_of_edges()
+        self.edges_per_step = E * (2 * len(self.hidden) - 1)                   # L fwd + (L-1) bwd SpMM launches
+        self.meta = {"workload": f"{name}-transductive-gae", "n_nodes": n, "n_edges": E, "in_dim": self.F_in,
+                     "hidden_dims": self.hidden, "norm": "none", "loss": args.loss + "-bce",
+                     "optimizer": "adam lr=1e-2", "parallelism": "1 GPU"}
+        self.dominant = ("spmm", n, n, self.F_in, "torch.float32")
+        self.dominant_desc = f"spmm F={self.F_in} (layer-1 aggregation A*X, {n} rows, {E} edges)"
+        self.alg_bytes = W.spmm_alg_bytes(n, n, E, self.F_in, 4)
+        self.scaling = "weak"
 
-    def step_dense():
-        g.ndata['h'] = Xd
-        adj = g.dense_adjacency()                             # train_transductive.py:59
-        pw = (n * n - adj.sum()) / adj.sum()                  # :60
-        logits = model(g)
-        loss = bce(logits, adj, pos_weight=pw)
-        opt.zero_grad(); loss.backward(); opt.step()
+    def step(self):
+        g, model = self.g, self.model
+        g.ndata['h'] = self.Xd
+        if self.args.loss == "fused":
+            loss = model.reconstruction_loss(g)                               # same quantity, fused HIP kernel
+        else:
+            adj = g.dense_adjacency()                                         # train_transductive.py:59
+            pw = (self.n * self.n - adj.sum()) / adj.sum()                    # :60
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(model(g), adj, pos_weight=pw)
+        self.opt.zero_grad(); loss.backward(); self.opt.step()
         return loss
 
-    def step_fused():
-        g.ndata['h'] = Xd
-        loss = model.reconstruction_loss(g)                   # same quantity, fused HIP kernel
-        opt.zero_grad(); loss.backward(); opt.step()
+    def cpu_baseline(self, seconds):
+        from oracle import gae_oracle as O
+        ref = O.CpuReferenceStep(self.src, self.dst, self.n, self.X, self.F_in, self.hidden, lr=1e-2, seed=0)
+        ref.step()  # warm-up
+        t0 = time.perf_counter(); k = 0
+        while True:
+            ref.step(); k += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or k >= 50:
+                break
+        return {"value": self.edges_per_step * k / el, "unit": "edges/s", "cores": torch.get_num_threads(),
+                "kind": "port", "ms_per_step": el / k * 1e3,
+                "sample": f"{k} full training steps of the same workload by oracle/gae_oracle.py:CpuReferenceStep "
+                          f"(dense N x N label/logits/BCE as train_inductive.py:44-52, torch CPU, "
+                          f"{torch.get_num_threads()} threads, host cpu_count={os.cpu_count()})"}
+
+
+class ZincWorkload:
+    """inductive step, batch of B molecules gathered on the device (train_inductive.py:31-53)"""
+
+    def __init__(self, args, dev, n_graphs=None):
+        import gae_dgl_amd as G
+        from gae_dgl_amd import workloads as W
+        from gae_dgl_amd.dataset import DeviceGraphDataset
+        self.args, self.dev = args, dev
+        B = args.batch_graphs
+        n_graphs = n_graphs or max(4 * B, 32768)
+        self.ds = DeviceGraphDataset.synthetic_zinc(n_graphs, seed=0, device=dev)
+        self.B = B
+        torch.manual_seed(0)
+        self.model = G.GAE(39, [32, 16]).to(dev)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3)        # train_inductive.py:25
+        self.rng = np.random.default_rng(0)
+        self.perm = self.rng.permutation(n_graphs)
+        self.cursor = 0
+        nb = int(self.ds.sizes_host[:B].sum()); eb = int(self.ds.edges_host[:B].sum())
+        self.edges_per_step = 3 * eb                                          # nominal (batch 0); varies < 1 % per batch
+        self.meta = {"workload": "zinc250k-inductive-gae", "batch_graphs": B, "nodes_per_batch~": nb,
+                     "edges_per_batch~": eb, "in_dim": 39, "hidden_dims": [32, 16], "loss": "fused-bce",
+                     "optimizer": "adam lr=1e-3", "dataset_graphs": n_graphs, "parallelism": "1 GPU",
+                     "batches_per_epoch_at_239455_graphs": int(np.ceil(239455 / B))}
+        self.dominant = None
+        self.W = W
+        self.scaling = "weak"
+        self._edges_done = 0
+
+    def step(self):
+        ids = self.perm[self.cursor:self.cursor + self.B]
+        self.cursor = (self.cursor + self.B) % (len(self.perm) - self.B)
+        bg = self.ds.batch(ids)                                               # dgl.batch on the device (K10)
+        loss = self.model.reconstruction_loss(bg)
+        self.opt.zero_grad(); loss.backward(); self.opt.step()
         return loss
 
-    step = step_fused if args.loss == "fused" else step_dense
 
-    edges_per_step = E * (len(hidden) + len(hidden) - 1)      # L fwd + (L-1) bwd SpMM launches
-    meta = {"workload": f"{name}-transductive-gae", "n_nodes": n, "n_edges": E, "in_dim": F_in,
-            "hidden_dims": hidden, "norm": "none", "loss": args.loss + "-bce", "optimizer": "adam lr=1e-2"}
-    dominant = ("spmm", n, n, F_in, "torch.float32")
-    alg = W.spmm_alg_bytes(n, n, E, F_in, 4)
-    return step, edges_per_step, meta, dominant, alg, (n, src, dst, X, F_in, hidden)
+class RmatShardedWorkload:
+    def __init__(self, args, dev, rank, world, group):
+        import gae_dgl_amd as G
+        from gae_dgl_amd import workloads as W
+        from gae_dgl_amd.parallel import ShardedGraph
+        self.args, self.dev, self.rank, self.world, self.group = args, dev, rank, world, group
+        scale = args.rmat_scale
+        n = 1 << scale
+        src, dst = W.rmat_edges(scale, 16, seed=0, device=dev)               # same list on every rank (seeded)
+        E = int(src.numel())
+        self.sg = ShardedGraph(n, src, dst, rank=rank, world=world, group=group, mode=args.exchange, device=dev)
+        del src, dst
+        for w in ("fwd", "bwd"):
+            self.sg.csr(w); self.sg.plan(w)
+        self.sg.part.fwd_rows = self.sg.part.fwd_cols = self.sg.part.bwd_rows = self.sg.part.bwd_cols = None
+        torch.cuda.empty_cache()
+        p = self.sg.part
+        F, hidden = 32, [32, 16]
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        self.X = torch.rand(p.n_local, F, device=dev, generator=gen)
+        self.dZ = torch.randn(p.n_local, hidden[-1], device=dev, generator=gen) / n
+        torch.manual_seed(0)
+        self.model = G.GAE(F, hidden).to(dev)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-2)
+        self.params = list(self.model.parameters())
+        self.n, self.E = n, E
+        self.edges_per_step = 3 * E
+        ip, ix = self.sg.csr("fwd")
+        e_local = int(ix.numel())
+        self.meta = {"workload": f"rmat-s{scale}-ef16-row-sharded-encoder", "n_nodes": n, "n_edges": E, "in_dim": F,
+                     "hidden_dims": hidden, "parallelism": f"row-shard x{world}", "exchange": args.exchange,
+                     "exchange_bytes_per_spmm_per_rank": self.sg.exchange_bytes(F),
+                     "decoder": "excluded (O(N^2) = 2.8e14 logits at N = 2^24); synthetic dZ",
+                     "local_rows": p.n_local, "local_edges_fwd": e_local}
+        self.dominant = ("spmm", p.n_local, p.n_cols["fwd"], F, "torch.float32")
+        self.dominant_desc = f"spmm F=32 on this rank's row block ({p.n_local} rows, {e_local} edges, skew plan)"
+        # compulsory bytes of the local launch: local indptr/indices + the referenced H + the local output
+        self.alg_bytes = 4 * (p.n_local + 1) + 4 * e_local + 4 * F * min(n, p.n_cols["fwd"]) + 4 * F * p.n_local
+        self.scaling = "strong"
 
-
-def cpu_baseline(cpu_args, edges_per_step, seconds):
-    from oracle import gae_oracle as O
-    n, src, dst, X, F_in, hidden = cpu_args
-    ref = O.CpuReferenceStep(src, dst, n, X, F_in, hidden, lr=1e-2, seed=0)
-    ref.step()  # warm-up
-    t0 = time.perf_counter(); k = 0
-    while True:
-        ref.step(); k += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or k >= 50:
-            break
-    return {"value": edges_per_step * k / el, "unit": "edges/s", "cores": torch.get_num_threads(),
-            "kind": "port", "ms_per_step": el / k * 1e3,
-            "sample": f"{k} full training steps of the same workload by oracle/gae_oracle.py:CpuReferenceStep "
-                      f"(torch CPU, {torch.get_num_threads()} threads, host cpu_count={os.cpu_count()})"}
+    def step(self):
+        from gae_dgl_amd.parallel import allreduce_grads, sharded_encode
+        z = sharded_encode(self.model, self.sg, self.X)
+        self.opt.zero_grad()
+        z.backward(self.dZ)
+        if self.world > 1:
+            allreduce_grads(self.params, self.group)
+        self.opt.step()
+        return z
 
 
 def extras(dev):
     """kernel-only SpMM numbers on the other BASELINE shapes (F quoted with each)"""
     from gae_dgl_amd import ops, workloads as W
     out = []
-    # ZINC: batch of 4096 graphs and the whole set as one block-diagonal launch
     gptr, src, dst, X = W.zinc_like(249455, seed=0)
     N = int(gptr[-1])
     s = torch.from_numpy(src).to(dev); d = torch.from_numpy(dst).to(dev)
     ip, ix = ops.csr_from_coo(d, s, N, N)
     nb = int(gptr[4096]); eb = int(ip[nb])
     ipb, ixb = ip[:nb + 1].clone(), ix[:eb].clone()
-    for F in (39, 32):
-        out.append(spmm_probe(ipb, ixb, nb, F, label="zinc-batch4096"))
-    Xp = torch.zeros(N, 40, device=dev); Xp[:, :39] = torch.from_numpy(X).to(dev)
-    Hv = Xp[:, :39]
-    o = torch.empty(N, 40, device=dev)[:, :39]
-    t = time_launches(lambda: ops.spmm_raw(ip, ix, Hv, N, out=o), iters=20)
-    b = W.spmm_alg_bytes(N, N, int(ix.numel()), 39, 4)
-    out.append({"shape": "zinc-whole-set(ld=40)", "n": N, "nnz": int(ix.numel()), "F": 39, "us_per_launch": t * 1e6,
-                "edges_per_s": ix.numel() / t, "alg_bytes": b, "achieved_GBs": b / t / 1e9,
-                "frac_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS})
-    out.append(spmm_probe(ip, ix, N, 32, label="zinc-whole-set"))
-    del s, d, ip, ix, Xp, o
-    # RMAT scale 24
+    out.append(spmm_probe(ipb, ixb, nb, 39, ld=40, label="zinc-batch4096 layer1"))
+    out.append(spmm_probe(ipb, ixb, nb, 32, label="zinc-batch4096 layer2"))
+    out.append(spmm_probe(ip, ix, N, 39, ld=40, label="zinc-250k whole set, one launch, layer1", iters=20))
+    out.append(spmm_probe(ip, ix, N, 32, label="zinc-250k whole set, one launch, layer2", iters=20))
+    del s, d, ip, ix
+    torch.cuda.empty_cache()
     src, dst = W.rmat_edges(24, 16, device=dev)
     n = 1 << 24
     ip, ix = ops.csr_from_coo(dst, src, n, n)
     del src, dst
-    out.append(spmm_probe(ip, ix, n, 32, label="rmat-s24-ef16"))
+    plan = ops.spmm_plan(ip)
+    r = spmm_probe(ip, ix, n, 32, plan=plan, label="rmat-s24-ef16 (1 GPU, skew plan)", iters=10)
+    r["gather_bytes_no_reuse"] = 4 * (n + 1) + 4 * r["nnz"] + 4 * 32 * r["nnz"] + 4 * 32 * n
+    r["achieved_GBs_no_reuse_model"] = r["gather_bytes_no_reuse"] / (r["us_per_launch"] * 1e-6) / 1e9
+    out.append(r)
     return out
 
 
@@ -169,65 +266,98 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl")
+    workload = args.workload or ("pubmed" if world == 1 else "rmat")
+    import torch.distributed as dist
+    group = None
+    if world > 1 or workload == "rmat":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
+    if world > 1:
+        dist.barrier()
     from gae_dgl_amd import ops
 
-    workload = args.workload or "pubmed"
-    step, edges_per_step, meta, dominant, alg_bytes, cpu_args = citation_workload(workload, args, dev)
+    if workload == "rmat":
+        wl = RmatShardedWorkload(args, dev, rank, world, group)
+    elif workload == "zinc":
+        wl = ZincWorkload(args, dev)
+    else:
+        wl = CitationWorkload(workload, args, dev)
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        wl.step()
     prof = ops.EventProfiler()
     ops.profiler = prof
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        wl.step()
     barrier()
     elapsed = time.perf_counter() - t0
     ops.profiler = None
     if world > 1:
-        import torch.distributed as dist
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
     if rank != 0:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
         return
     times = prof.summary()
-    dom = times.get(dominant, [])
+    spmm_keys = [k for k in times if k[0] == "spmm"]
+    if wl.dominant is None and spmm_keys:   # zinc: batch shapes vary slightly; take the F=39 launches
+        dom = [t for k in spmm_keys if k[3] == 39 for t in times[k]]
+        k39 = [k for k in spmm_keys if k[3] == 39]
+        nb = int(np.mean([k[1] for k in k39])); eb = wl.edges_per_step // 3
+        wl.alg_bytes = 4 * (nb + 1) + 4 * eb + 2 * 4 * 39 * nb
+        wl.dominant_desc = f"spmm F=39 (layer-1 aggregation of a {wl.B}-molecule batch, ~{nb} rows, ~{eb} edges)"
+    else:
+        dom = times.get(wl.dominant, [])
     t_dom = float(np.mean(dom)) if dom else float("nan")
-    spmm_t = sum(sum(v) for k, v in times.items() if k[0] == "spmm")
-    value = edges_per_step * args.steps / elapsed
+    spmm_t = sum(sum(times[k]) for k in spmm_keys)
+    value = wl.edges_per_step * args.steps / elapsed
     line = {
         "metric": "edges aggregated/sec (SpMM fwd+bwd)", "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": meta,
-        "epoch_time_s": elapsed / args.steps,
-        "spmm_only": {"edges_per_s": edges_per_step * args.steps / spmm_t if spmm_t else None,
-                      "sum_event_time_s": spmm_t, "launches": sum(len(v) for k, v in times.items() if k[0] == "spmm"),
-                      "note": "HIP-event time of the SpMM launches inside the timed steps"},
-        "roofline": {"bound": "hbm", "kernel": f"spmm_rowgroup F={dominant[3]} (layer-1 aggregation)",
-                     "achieved": alg_bytes / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "alg_bytes_per_launch": alg_bytes, "avg_launch_us": t_dom * 1e6, "launches_timed": len(dom)},
+        "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": wl.meta,
+        "epoch_time_s": elapsed / args.steps * (wl.meta.get("batches_per_epoch_at_239455_graphs", 1)),
+        "spmm_only": {"edges_per_s": wl.edges_per_step / max(world, 1) * args.steps / spmm_t if spmm_t else None,
+                      "sum_event_time_s": spmm_t, "launches": sum(len(times[k]) for k in spmm_keys),
+                      "note": "rank-0 HIP-event time of its SpMM launches inside the timed steps"
+                              + (" (per-rank share of the edges)" if world > 1 else "")},
+        "roofline": {"bound": "hbm", "kernel": wl.dominant_desc,
+                     "achieved": wl.alg_bytes / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": wl.alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "alg_bytes_per_launch": wl.alg_bytes, "avg_launch_us": t_dom * 1e6, "launches_timed": len(dom)},
     }
-    if not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(cpu_args, edges_per_step, args.cpu_seconds)
-    if not args.no_extra:
+    if "decoder_bce" in {k[0] for k in times}:
+        kb = [k for k in times if k[0] == "decoder_bce"]
+        tb = float(np.mean([t for k in kb for t in times[k]]))
+        n = kb[0][1]; d = kb[0][2]
+        flops = n * n * (2 * d + 2 * d)      # S = Zt Zt^T and O = sigmoid(S) Zt on the fp32 matrix cores
+        line["decoder_loss"] = {"kernel": "fused decoder+BCE fwd+bwd (prepare + dense + edges + finalize)",
+                                "avg_us": tb * 1e6, "logits_per_s": n * n / tb, "bound": "mfma(f32)+valu",
+                                "mfma_tflops": flops / tb / 1e12, "mfma_f32_peak_tflops": 157.3}
+    if not args.no_cpu_baseline and hasattr(wl, "cpu_baseline"):
+        line["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
+    if not args.no_extra and world == 1 and workload not in ("rmat",):
+        del wl
+        torch.cuda.empty_cache()
         line["extra"] = {"spmm_kernel_only": extras(dev)}
     print(json.dumps(line))
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
