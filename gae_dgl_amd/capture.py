@@ -1,0 +1,47 @@
+"""HIP-graph capture of the transductive training step.
+
+The full-graph step (encoder forward, fused decoder+BCE, backward, Adam) is a
+fixed sequence of ~30 launches on static buffers, so it is captured once in a
+hipGraph (through torch.cuda.CUDAGraph, which records every launch on the
+capture stream -- including the ctypes launches of libgae_hip.so, which use
+PyTorch's current stream) and replayed per epoch: no Python / launch overhead
+between kernels.  The decoder's dropout mask still changes every replay
+because its Philox draw counter lives in device memory (gae_dropout_mask)."""
+import torch
+
+
+class CapturedTrainStep:
+    def __init__(self, model, optimizer, graph, features, loss_fn=None, warmup=3):
+        self.model, self.opt, self.g, self.x = model, optimizer, graph, features
+        self.loss_fn = loss_fn or (lambda m, g: m.reconstruction_loss(g))
+        for group in optimizer.param_groups:           # Adam must keep its step counter on the device
+            if "capturable" in group and not group["capturable"]:
+                raise ValueError("build the optimizer with capturable=True to capture its step")
+        # structure is static: build it outside the capture (CSR build sorts and reads back a status word)
+        graph.csr(); graph.csc(); graph.spmm_plan(False); graph.spmm_plan(True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = self._fwd_bwd_step()
+
+    def _fwd_bwd_step(self):
+        self.g.ndata['h'] = self.x
+        loss = self.loss_fn(self.model, self.g)
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def _eager_step(self):
+        self.opt.zero_grad(set_to_none=True)
+        return self._fwd_bwd_step()
+
+    def __call__(self):
+        """one training step; returns the (static) loss tensor of this replay"""
+        self.graph.replay()
+        return self.loss

@@ -512,10 +512,12 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
 }
 
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float *__restrict__ mask, int64_t n, float p, float scale,
-                                                           uint64_t seed, uint64_t offset)
+                                                           uint64_t seed, uint64_t offset,
+                                                           const uint64_t *__restrict__ draw_dev)
 {
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     const int64_t nquad = (n + 3) / 4;
+    if (draw_dev) offset += *draw_dev * uint64_t(nquad);   // device-side draw counter: graph replays advance the stream
     for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < nquad; q += stride) {
         const uint64_t ctr = offset + uint64_t(q);
         uint32_t c[4] = {uint32_t(ctr), uint32_t(ctr >> 32), 0u, 0u};
@@ -626,7 +628,8 @@ extern "C" int gae_linear_bwd(const float *dY, int64_t lddy, const float *Y, int
     return GAE_OK;
 }
 
-extern "C" int gae_dropout_mask(float *mask, int64_t n_elems, float p, uint64_t seed, uint64_t offset, void *stream)
+extern "C" int gae_dropout_mask(float *mask, int64_t n_elems, float p, uint64_t seed, uint64_t offset,
+                                const uint64_t *draw_dev, void *stream)
 {
     GAE_REQUIRE(n_elems >= 0, GAE_E_SIZE, "gae_dropout_mask: negative size");
     GAE_REQUIRE(p >= 0.f && p < 1.f, GAE_E_RANGE, "gae_dropout_mask: p = %g outside [0, 1)", double(p));
@@ -635,7 +638,7 @@ extern "C" int gae_dropout_mask(float *mask, int64_t n_elems, float p, uint64_t 
     int64_t g = ((n_elems + 3) / 4 + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(unsigned(g)), dim3(256), 0, gae::as_stream(stream), mask, n_elems, p,
-                       1.0f / (1.0f - p), seed, offset);
+                       1.0f / (1.0f - p), seed, offset, draw_dev);
     GAE_CHECK_LAUNCH("dropout_mask_kernel");
     return GAE_OK;
 }

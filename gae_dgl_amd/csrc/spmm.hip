@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void spmm_rowgroup_kernel(
 //     are wave-uniform (SGPR) values.
 // Summation order is unchanged (CSR order), so results are bit-identical to v1.
 // ---------------------------------------------------------------------------
-template <typename T, int VEC, int LPR, int CH, int RPG, bool SCALED, bool NT_STORE>
+template <typename T, int VEC, int LPR, int CH, int RPG, bool SCALED, bool NT_STORE, int NBW = 4>
 __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
     const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t n_rows,
     const T *__restrict__ H, int64_t ldh, T *__restrict__ M, int64_t ldm, int F,
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
     constexpr int GPB = 256 / LPR;            // groups per block
     constexpr int RPB = GPB * RPG;            // rows per block
     constexpr int TILE = LPR * VEC;
-    constexpr int NB = LPR >= 4 ? 4 : LPR;    // neighbours per batch and row
+    constexpr int NB = LPR >= NBW ? NBW : (LPR >= 4 ? 4 : LPR);    // neighbours per batch and row
     unsigned blk, ftile;
     if (xcd_tiled) {
         // Feature-tiled XCD mapping: XCD x (= blockIdx % 8) owns feature tiles x, x+8, ... and sweeps all
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
         int32_t myidx[RPG];
 #pragma unroll
         for (int r = 0; r < RPG; ++r) {
-            const int32_t e = pos[r] + (LPR >= 4 ? (lig & 3) : lig);
+            const int32_t e = pos[r] + (LPR >= 4 ? (lig & (NB - 1)) : lig);
             myidx[r] = e < end[r] ? indices[e] : 0;
         }
         float v[RPG][NB][CH][VEC];
@@ -318,7 +318,8 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
 int g_spmm_variant = 2;   // 1 = v1 rowgroup, 2 = v2 rowgroup2
 int g_spmm_rpg = 2;       // rows per group (v2)
 int g_spmm_nt = 1;        // non-temporal stores of M (v2)
-int g_spmm_tile_vecs = 0; // 16-byte vectors per XCD feature tile (0 auto, -1 off)
+int g_spmm_tile_vecs = -1; // 16-byte vectors per XCD feature tile (0 auto, -1 off: measured gain <= 8 % on random graphs, loss on local ones)
+int g_spmm_nb = 4;        // neighbour rows in flight per owned row for wide rows (4 | 8)
 
 template <typename T, int VEC, int LPR, int CH, int RPG>
 int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
@@ -330,11 +331,16 @@ int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_ro
     const unsigned nrb = unsigned((n_rows + RPB - 1) / RPB), nft = unsigned((nvec + LPR * CH - 1) / (LPR * CH));
     const dim3 grid = tiled ? dim3(gae::kNumXcd * ((nft + gae::kNumXcd - 1) / gae::kNumXcd) * nrb) : dim3(nrb, nft);
     const int xt = tiled ? 1 : 0;
-#define GAE_L2(SC, NT)                                                                                              \
-    hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, NT>), grid, dim3(256), 0, s, indptr, indices, \
-                       n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, skip_deg)
-    if (rs || cs) { if (nt) GAE_L2(true, true); else GAE_L2(true, false); }
-    else { if (nt) GAE_L2(false, true); else GAE_L2(false, false); }
+#define GAE_L2(SC, NT, NBW)                                                                                         \
+    hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, NT, NBW>), grid, dim3(256), 0, s, indptr,   \
+                       indices, n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, skip_deg)
+    if (LPR >= 16 && CH <= 2 && g_spmm_nb == 8) {   // wide rows: 8 neighbour rows in flight per owned row
+        if (rs || cs) { if (nt) GAE_L2(true, true, 8); else GAE_L2(true, false, 8); }
+        else { if (nt) GAE_L2(false, true, 8); else GAE_L2(false, false, 8); }
+    } else {
+        if (rs || cs) { if (nt) GAE_L2(true, true, 4); else GAE_L2(true, false, 4); }
+        else { if (nt) GAE_L2(false, true, 4); else GAE_L2(false, false, 4); }
+    }
 #undef GAE_L2
     GAE_CHECK_LAUNCH("spmm_rowgroup2_kernel");
     return GAE_OK;
@@ -723,7 +729,7 @@ extern "C" int gae_tuning_set(const char *name, int64_t value)
     GAE_REQUIRE(name != nullptr, GAE_E_NULL, "gae_tuning_set: name is NULL");
     const struct { const char *k; int *v; } knobs[] = {
         {"spmm_variant", &g_spmm_variant}, {"spmm_rpg", &g_spmm_rpg}, {"spmm_nt", &g_spmm_nt},
-        {"spmm_tile_vecs", &g_spmm_tile_vecs}};
+        {"spmm_tile_vecs", &g_spmm_tile_vecs}, {"spmm_nb", &g_spmm_nb}};
     for (const auto &kv : knobs)
         if (strcmp(kv.k, name) == 0) {
             *kv.v = int(value);

@@ -131,7 +131,7 @@ class InnerProductDecoder(nn.Module):
         self.activation = activation
         self.mask = None
         self.seed = seed
-        self._calls = 0
+        self._draws = None       # device-side draw counter (int64[1]); advanced by a device op per forward
         self.last_mask = None
 
     def _draw_mask(self, z):
@@ -140,9 +140,11 @@ class InnerProductDecoder(nn.Module):
         if not self.dropout:
             return None
         seed = self.seed if self.seed is not None else int(torch.initial_seed())
-        offset = self._calls * ((z.numel() + 3) // 4)
-        self._calls += 1
-        return ops.dropout_mask(tuple(z.shape), self.dropout, seed, offset, z.device)
+        if self._draws is None or self._draws.device != z.device:
+            self._draws = torch.zeros(1, dtype=torch.int64, device=z.device)
+        mask = ops.dropout_mask(tuple(z.shape), self.dropout, seed, 0, z.device, draw_counter=self._draws)
+        self._draws += 1         # device op: a captured HIP graph draws a fresh mask every replay
+        return mask
 
     def forward(self, z):
         mask = self._draw_mask(z)

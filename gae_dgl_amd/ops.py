@@ -236,11 +236,13 @@ def linear_bwd_raw(dY, Y, act, M, W, need_dW=True, need_db=True, need_dM=True):
     return dW, db, dM
 
 
-def dropout_mask(shape, p, seed, offset=0, device="cuda"):
+def dropout_mask(shape, p, seed, offset=0, device="cuda", draw_counter=None):
+    """inverted-dropout multiplier; ``draw_counter`` (int64 device tensor [1]) selects the
+    draw on the device so that captured HIP graphs advance the stream between replays"""
     mask = torch.empty(shape, dtype=torch.float32, device=device)
     with torch.cuda.device(mask.device):
         _lib.call("gae_dropout_mask", _ptr(mask), mask.numel(), float(p), int(seed) & (2 ** 64 - 1),
-                  int(offset) & (2 ** 64 - 1), _stream())
+                  int(offset) & (2 ** 64 - 1), _ptr(draw_counter), _stream())
     return mask
 
 

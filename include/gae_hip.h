@@ -177,9 +177,12 @@ int gae_linear_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, i
  * activation GAE passes (gae_dgl/gae.py:47).
  * gae_dropout_mask: inverted-dropout multiplier (0 or 1/(1-p)), Philox4x32-10
  * counter RNG keyed by (seed, offset + element index): reproducible for bwd.
+ * draw_dev (device uint64, may be NULL): number of masks drawn so far; the
+ * counter base becomes offset + *draw_dev * ceil(n_elems / 4), so a captured
+ * HIP graph draws a fresh mask on every replay once the caller bumps it.
  * gae_decoder_dense: out = Zt Zt^T with Zt = Z (.) mask (mask may be NULL). */
 int gae_dropout_mask(float *mask, int64_t n_elems, float p, uint64_t seed, uint64_t offset,
-                     void *stream);
+                     const uint64_t *draw_dev, void *stream);
 int gae_decoder_dense(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
                       float *out, int64_t ldo, void *stream);
 /* dZ = ((G + G^T) Zt) (.) mask,  G = dL/dlogits [n, n]  (autograd of gae.py:70-71) */

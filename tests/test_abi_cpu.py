@@ -49,7 +49,7 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.gae_spmm_plan_count(None, 8, 0, 512, None, None) == -6
     rc = lib.gae_linear_fwd(None, 4, 4, 4, None, None, 4, 9, None, 4, None)
     assert rc == -4
-    rc = lib.gae_dropout_mask(None, 8, ctypes.c_float(1.5), 0, 0, None)
+    rc = lib.gae_dropout_mask(None, 8, ctypes.c_float(1.5), 0, 0, None, None)
     assert rc == -6
     assert lib.gae_linear_bwd_workspace_bytes(1000, 39, 32) > 0
 

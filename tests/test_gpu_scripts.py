@@ -76,3 +76,41 @@ def test_train_transductive_runs(tmp_path):
     losses_n = TT.main(["--dataset", "cora", "-e", "5", "-s", str(tmp_path), "--seed", "0", "--norm", "both",
                         "--log_every", "100"])
     assert np.isfinite(losses_n).all()
+
+
+def test_hipgraph_captured_step_matches_eager():
+    """replaying the captured step trains exactly like the eager step (dropout off), and the
+    decoder mask still changes between replays (device-side draw counter) when dropout is on"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import workloads as W
+    from gae_dgl_amd.capture import CapturedTrainStep
+    dev = torch.device("cuda:0")
+    n, src, dst, X = W.citation_graph("cora", seed=0)
+    Xd = torch.from_numpy(X).to(dev)
+    losses = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        model = G.GAE(X.shape[1], [32, 16]).to(dev)
+        model.decoder.dropout = 0.0
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True)
+        g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+        out = []
+        if mode == "eager":
+            for _ in range(8):
+                g.ndata['h'] = Xd
+                loss = model.reconstruction_loss(g)
+                opt.zero_grad(); loss.backward(); opt.step()
+                out.append(float(loss.detach()))
+        else:
+            step = CapturedTrainStep(model, opt, g, Xd, warmup=3)     # 3 eager warm-up steps are real steps
+            out = [None] * 3 + [float(step().clone()) for _ in range(5)]
+        losses[mode] = out
+    np.testing.assert_allclose(losses["graph"][3:], losses["eager"][3:], rtol=2e-5)
+    # dropout on: consecutive replays see different masks
+    torch.manual_seed(0)
+    model = G.GAE(X.shape[1], [32, 16]).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.0, capturable=True)   # lr 0: only the mask changes
+    g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    step = CapturedTrainStep(model, opt, g, Xd, warmup=1)
+    a, b = float(step().clone()), float(step().clone())
+    assert a != b

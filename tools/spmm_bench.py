@@ -78,7 +78,8 @@ def main():
         parts = v.split(":")
         name, rpg, nt = parts[:3]
         tv = int(parts[3]) if len(parts) > 3 else 0
-        variants.append((v, 1 if name == "v1" else 2, int(rpg), int(nt), tv))
+        nbw = int(parts[4]) if len(parts) > 4 else 4
+        variants.append((v, 1 if name == "v1" else 2, int(rpg), int(nt), tv, nbw))
     for sname in want:
         ip, ix, n, F, ld = shapes[sname]
         H = torch.rand(n, ld, device=dev)[:, :F]
@@ -89,8 +90,9 @@ def main():
         res = {v[0]: [] for v in variants}
         ref = None
         for rnd in range(args.rounds + 1):
-            for (label, var, rpg, nt, tv) in variants:
+            for (label, var, rpg, nt, tv, nbw) in variants:
                 knob("spmm_variant", var); knob("spmm_rpg", rpg); knob("spmm_nt", nt); knob("spmm_tile_vecs", tv)
+                knob("spmm_nb", nbw)
                 fn = lambda: ops.spmm_raw(ip, ix, H, n, out=out, plan=plans.get(sname))
                 fn(); torch.cuda.synchronize()
                 if rnd == 0:
