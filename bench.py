@@ -104,7 +104,7 @@ class CitationWorkload:
         self.model = G.GAE(self.F_in, self.hidden).to(dev)
         self.use_graph = args.hipgraph and args.loss == "fused"
         self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-2,        # train_transductive.py:43
-                                    capturable=self.use_graph)
+                                    fused=True, capturable=self.use_graph)   # one multi-tensor launch
         self.g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
         self.Xd = torch.from_numpy(X).to(dev)
         self.g.csr(); self.g.csc(); self.g.spmm_plan(False); self.g.spmm_plan(True)   # structure is static
@@ -169,7 +169,7 @@ class ZincWorkload:
         self.B = B
         torch.manual_seed(0)
         self.model = G.GAE(39, [32, 16]).to(dev)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3)        # train_inductive.py:25
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)   # train_inductive.py:25
         self.rng = np.random.default_rng(0)
         self.perm = self.rng.permutation(n_graphs)
         self.cursor = 0
@@ -216,7 +216,7 @@ class RmatShardedWorkload:
         self.dZ = torch.randn(p.n_local, hidden[-1], device=dev, generator=gen) / n
         torch.manual_seed(0)
         self.model = G.GAE(F, hidden).to(dev)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-2)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-2, fused=True)
         self.params = list(self.model.parameters())
         self.n, self.E = n, E
         self.edges_per_step = 3 * E

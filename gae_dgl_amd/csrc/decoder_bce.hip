@@ -23,6 +23,7 @@
 // MFMA-bound (fp32 matrix rate), not HBM-bound: 4 KS (S) + 4 KS (PV) MFMAs per
 // 256 logits with KS = ceil(d / 16).
 // Reductions are two-stage and ordered: bit-stable run to run.
+#include <string.h>
 #include <type_traits>
 
 #include "common.h"
@@ -33,8 +34,9 @@ using gae::kWave;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TJ = 64;   // columns staged per iteration
-constexpr int RI = 2;    // 16-row subtiles per wave  -> 32 rows / wave, 128 rows / block
-constexpr int ROWS_PER_BLOCK = 4 * RI * 16;
+// RI = 16-row subtiles per wave (rows / block = 64 RI); tuning knobs "bce_ri", "bce_minw"
+int g_bce_ri = 2;
+int g_bce_minw = 0;
 
 __device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
 {
@@ -67,12 +69,13 @@ __global__ __launch_bounds__(256) void bce_prepare_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------
-template <int KS, bool WITH_GRAD>
-__global__ __launch_bounds__(256) void bce_dense_kernel(
+template <int KS, bool WITH_GRAD, int RI, int MINW>
+__global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     const float *__restrict__ Zt /*[n][16 KS]*/, int64_t n, int64_t row_begin, int64_t n_local,
     int64_t cols_per_split, float *__restrict__ O_partial /*[splits][n_local][KS*16]*/,
     double *__restrict__ loss_partial /*[gridDim.x * gridDim.y]*/)
 {
+    constexpr int ROWS_PER_BLOCK = 4 * RI * 16;
     constexpr int DP = KS * 16;          // padded feature width
     constexpr int LDA = DP + 4;          // LDS row stride (floats): 16-byte aligned, breaks the power of two
     constexpr int V4 = TJ * DP / 4 / 256;  // float4 per thread and staged tile (1, 2, 4)
@@ -227,8 +230,9 @@ __global__ __launch_bounds__(256) void bce_dense_kernel(
 // ---------------------------------------------------------------------------
 template <int VEC, int LPR, bool WITH_GRAD>
 __global__ __launch_bounds__(256) void bce_edges_kernel(
-    const float *__restrict__ Z, const float *__restrict__ mask, int64_t ldz, int64_t row_begin, int64_t n_local,
-    int d, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ Zt /*[n][DP] = Z (.) mask, zero padded*/, const float *__restrict__ mask, int64_t ldz,
+    int64_t row_begin, int64_t n_local, int d, const int32_t *__restrict__ indptr,
+    const int32_t *__restrict__ indices,
     const int32_t *__restrict__ t_indptr, const int32_t *__restrict__ t_indices, float pw, float inv_n2,
     const float *__restrict__ O_partial, int n_splits, int DP, float *__restrict__ dZ, int64_t lddz,
     double *__restrict__ loss_partial)
@@ -243,47 +247,61 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
     const int f0 = lig * VEC;
     const bool rowv = i < n;
 
+    static_assert(VEC == 4, "edge kernel reads the padded Zt rows as float4");
+    const bool fv = f0 < DP;     // lanes beyond the padded width idle (LPR is a power of two >= DP / 4)
     float zi[VEC], acc[VEC];
+    {
+        const f32x4 t = (rowv && fv) ? *reinterpret_cast<const f32x4 *>(Zt + gi * DP + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) {
-        acc[q] = 0.f;
-        float v = 0.f;
-        if (rowv && f0 + q < d) {
-            v = Z[gi * ldz + f0 + q];
-            if (mask) v *= mask[gi * ldz + f0 + q];
-        }
-        zi[q] = v;
+        for (int q = 0; q < VEC; ++q) { acc[q] = 0.f; zi[q] = t[q]; }
     }
     double lsum = 0.0;
-    auto edge = [&](int32_t j, bool with_loss) {
-        float zj[VEC];
-        float dot = 0.f;
+    // In-edges (CSR: loss + G_s Zt) then out-edges (CSR of A^T: G_s^T Zt) of node i, 4 edges per batch:
+    // the 4 neighbour ids come from one coalesced load, the 4 neighbour rows are all in flight before
+    // the first dot product (one memory round trip per batch instead of one per edge).
+    auto sweep = [&](const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, bool with_loss) {
+        int32_t pos = rowv ? ptr[i] : 0;
+        const int32_t end = rowv ? ptr[i + 1] : 0;
+        const int glane0 = (lane / LPR) * LPR;
+        while (pos < end) {
+            const int32_t e = pos + (LPR >= 4 ? (lig & 3) : 0);
+            const int32_t mine = e < end ? idx[e] : 0;
+            float zj[4][VEC], dot[4];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-            float v = 0.f;
-            if (f0 + q < d) {
-                v = Z[int64_t(j) * ldz + f0 + q];
-                if (mask) v *= mask[int64_t(j) * ldz + f0 + q];
+            for (int u = 0; u < 4; ++u) {
+                const int32_t j = LPR >= 4 ? __shfl(mine, glane0 + u, 64) : (pos + u < end ? idx[pos + u] : 0);
+                const bool ev = pos + u < end;
+                dot[u] = 0.f;
+                const f32x4 t = (ev && fv) ? *reinterpret_cast<const f32x4 *>(Zt + int64_t(j) * DP + f0)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    zj[u][q] = t[q];
+                    dot[u] = fmaf(zi[q], t[q], dot[u]);
+                }
             }
-            zj[q] = v;
-            dot = fmaf(zi[q], v, dot);
+#pragma unroll
+            for (int off = LPR / 2; off > 0; off >>= 1)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dot[u] += __shfl_xor(dot[u], off, 64);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (pos + u < end) {
+                    const float x = dot[u];
+                    float spn, sgn;               // softplus(-x), sigmoid(-x)
+                    softplus_sigmoid(-x, spn, sgn);
+                    const float sg = 1.0f - sgn;  // sigmoid(x)
+                    if (with_loss && lig == 0) lsum += double(-x + (pw - 1.0f) * spn);
+                    const float c = (pw - 1.0f) * sg - pw;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) acc[q] = fmaf(c, zj[u][q], acc[q]);
+                }
+            }
+            pos += 4;
         }
-#pragma unroll
-        for (int off = LPR / 2; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
-        const float x = dot;
-        float spn, sgn;               // softplus(-x), sigmoid(-x)
-        softplus_sigmoid(-x, spn, sgn);
-        const float sg = 1.0f - sgn;  // sigmoid(x)
-        if (with_loss && lig == 0) lsum += double(-x + (pw - 1.0f) * spn);
-        const float c = (pw - 1.0f) * sg - pw;
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) acc[q] = fmaf(c, zj[q], acc[q]);
     };
-    if (rowv) {
-        for (int32_t e = indptr[i]; e < indptr[i + 1]; ++e) edge(indices[e], true);
-        if (WITH_GRAD)
-            for (int32_t e = t_indptr[i]; e < t_indptr[i + 1]; ++e) edge(t_indices[e], false);
-    }
+    sweep(indptr, indices, true);
+    if (WITH_GRAD) sweep(t_indptr, t_indices, false);
     if (WITH_GRAD && rowv) {
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
@@ -322,7 +340,7 @@ __global__ __launch_bounds__(256) void bce_finalize_kernel(const double *__restr
 
 struct BcePlan {
     int64_t row_blocks, n_splits, cols_per_split, edge_blocks;
-    int KS, DP, LPR, VEC;
+    int KS, DP, LPR, VEC, RI;
     int64_t o_bytes, zt_bytes, loss_count, total_bytes;
 };
 
@@ -330,6 +348,9 @@ inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
 bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
 {
+    const int ri = (g_bce_ri == 1 || g_bce_ri == 4) ? g_bce_ri : 2;
+    const int64_t ROWS_PER_BLOCK = 64 * ri;
+    p.RI = ri;
     if (d > 64) return false;
     p.KS = int((d + 15) / 16);
     if (p.KS == 3) p.KS = 4;
@@ -347,7 +368,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     p.cols_per_split = tiles_per_split * TJ;
     p.n_splits = (col_tiles + tiles_per_split - 1) / tiles_per_split;
     p.VEC = vec_ok ? 4 : 1;
-    const int nvec = int((d + p.VEC - 1) / p.VEC);
+    const int nvec = p.DP / 4;   // the edge kernel reads the padded Zt rows
     int lpr = 1;
     while (lpr < nvec) lpr <<= 1;
     p.LPR = lpr;
@@ -365,22 +386,31 @@ int launch_dense(const BcePlan &p, const float *Zt, int64_t n, int64_t row_begin
                  double *lp, hipStream_t s)
 {
     const dim3 grid(unsigned(p.row_blocks), unsigned(p.n_splits));
-    switch (p.KS) {
-    case 1: hipLaunchKernelGGL((bce_dense_kernel<1, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, row_begin, n_local, p.cols_per_split, O, lp); break;
-    case 2: hipLaunchKernelGGL((bce_dense_kernel<2, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, row_begin, n_local, p.cols_per_split, O, lp); break;
-    default: hipLaunchKernelGGL((bce_dense_kernel<4, WITH_GRAD>), grid, dim3(256), 0, s, Zt, n, row_begin, n_local, p.cols_per_split, O, lp); break;
+#define GAE_BD(KS, RI, MW) hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW>), grid, dim3(256), 0, s, Zt, n, row_begin, n_local, p.cols_per_split, O, lp)
+    if (p.KS == 1) {
+        if (p.RI == 1) { if (g_bce_minw >= 8) GAE_BD(1, 1, 8); else GAE_BD(1, 1, 1); }
+        else if (p.RI == 4) GAE_BD(1, 4, 1);
+        else if (g_bce_minw >= 8) GAE_BD(1, 2, 8);
+        else if (g_bce_minw >= 6) GAE_BD(1, 2, 6);
+        else if (g_bce_minw >= 5) GAE_BD(1, 2, 5);
+        else GAE_BD(1, 2, 1);
+    } else if (p.KS == 2) {
+        if (p.RI == 1) GAE_BD(2, 1, 1); else GAE_BD(2, 2, 1);
+    } else {
+        if (p.RI == 1) GAE_BD(4, 1, 1); else GAE_BD(4, 2, 1);
     }
+#undef GAE_BD
     GAE_CHECK_LAUNCH("bce_dense_kernel");
     return GAE_OK;
 }
 
 template <int VEC, bool WITH_GRAD>
-int launch_edges(const BcePlan &p, const float *Z, const float *mask, int64_t ldz, int64_t row_begin, int64_t n, int d,
+int launch_edges(const BcePlan &p, const float *Zt, const float *mask, int64_t ldz, int64_t row_begin, int64_t n, int d,
                  const int32_t *ip, const int32_t *ix, const int32_t *tp, const int32_t *tx, float pw, float inv_n2,
                  const float *O, float *dZ, int64_t lddz, double *lp, hipStream_t s)
 {
 #define GAE_EDGE(LPR)                                                                                              \
-    hipLaunchKernelGGL((bce_edges_kernel<VEC, LPR, WITH_GRAD>), dim3(unsigned(p.edge_blocks)), dim3(256), 0, s, Z,  \
+    hipLaunchKernelGGL((bce_edges_kernel<VEC, LPR, WITH_GRAD>), dim3(unsigned(p.edge_blocks)), dim3(256), 0, s, Zt, \
                        mask, ldz, row_begin, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, dZ, lddz, lp)
     switch (p.LPR) {
     case 1: GAE_EDGE(1); break;
@@ -397,6 +427,15 @@ int launch_edges(const BcePlan &p, const float *Z, const float *mask, int64_t ld
 }
 
 } // namespace
+
+namespace gae {
+int *bce_knob(const char *name)
+{
+    if (strcmp(name, "bce_ri") == 0) return &g_bce_ri;
+    if (strcmp(name, "bce_minw") == 0) return &g_bce_minw;
+    return nullptr;
+}
+} // namespace gae
 
 extern "C" int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t n_local, int64_t d)
 {
@@ -445,9 +484,9 @@ extern "C" int gae_decoder_bce_rows(const float *Z, const float *mask, int64_t l
                 : launch_dense<false>(p, Zt, n, row_begin, n_local, O, lp, s);
     if (rc) return rc;
     double *lpe = lp + p.row_blocks * p.n_splits;
-    rc = dZ ? launch_edges<4, true>(p, Z, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr, t_indices,
+    rc = dZ ? launch_edges<4, true>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr, t_indices,
                                     pos_weight, float(inv_n2), O, dZ, lddz, lpe, s)
-            : launch_edges<4, false>(p, Z, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr,
+            : launch_edges<4, false>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr,
                                      t_indices, pos_weight, float(inv_n2), O, dZ, lddz, lpe, s);
     if (rc) return rc;
     hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(256), 0, s, lp, p.loss_count, inv_n2, loss_out);

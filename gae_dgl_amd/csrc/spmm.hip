@@ -438,14 +438,21 @@ __global__ __launch_bounds__(256) void plan_count_kernel(const int32_t *__restri
                                                          int threshold, int seg, unsigned long long *counts)
 {
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    unsigned long long nh = 0, ns = 0;
+    unsigned long long nh = 0, ns = 0, mx = 0;
     for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
         const int d = indptr[r + 1] - indptr[r];
         if (d > threshold) { nh += 1; ns += (d + seg - 1) / seg; }
+        mx = max(mx, (unsigned long long)d);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { nh += __shfl_down(nh, off, 64); ns += __shfl_down(ns, off, 64); }
-    if ((threadIdx.x & 63) == 0 && nh) { atomicAdd(&counts[0], nh); atomicAdd(&counts[1], ns); }
+    for (int off = 32; off > 0; off >>= 1) {
+        nh += __shfl_down(nh, off, 64); ns += __shfl_down(ns, off, 64);
+        mx = max(mx, (unsigned long long)__shfl_down(mx, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (nh) { atomicAdd(&counts[0], nh); atomicAdd(&counts[1], ns); }
+        atomicMax(&counts[2], mx);
+    }
 }
 
 __global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t *__restrict__ indptr, int64_t n_rows,
@@ -644,7 +651,7 @@ extern "C" int gae_spmm_plan_count(const int32_t *indptr, int64_t n_rows, int32_
                 "gae_spmm_plan_count: threshold >= 1 and segment_edges a positive multiple of 64 required");
     GAE_REQUIRE(indptr && counts_dev, GAE_E_NULL, "gae_spmm_plan_count: NULL pointer");
     hipStream_t s = gae::as_stream(stream);
-    GAE_HIP(hipMemsetAsync(counts_dev, 0, 2 * sizeof(uint64_t), s));
+    GAE_HIP(hipMemsetAsync(counts_dev, 0, 3 * sizeof(uint64_t), s));
     if (n_rows == 0) return GAE_OK;
     int64_t g = (n_rows + 255) / 256;
     if (g > 4096) g = 4096;
@@ -722,7 +729,7 @@ extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64
     return run_spmm<unsigned short, 1>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, false, plan, workspace, s);
 }
 
-namespace gae { int *dense_knob(const char *name); }
+namespace gae { int *dense_knob(const char *name); int *bce_knob(const char *name); }
 
 extern "C" int gae_tuning_set(const char *name, int64_t value)
 {
@@ -736,6 +743,10 @@ extern "C" int gae_tuning_set(const char *name, int64_t value)
             return GAE_OK;
         }
     if (int *k = gae::dense_knob(name)) {
+        *k = int(value);
+        return GAE_OK;
+    }
+    if (int *k = gae::bce_knob(name)) {
         *k = int(value);
         return GAE_OK;
     }

@@ -143,6 +143,7 @@ profiler = None  # set to an EventProfiler to time launches
 # ------------------------------------------------------------------ raw kernels
 SKEW_THRESHOLD = 8       # rows with more in-edges than this go through the segment kernels
 SKEW_SEGMENT = 256       # edges per segment (multiple of 64)
+SKEW_MIN_MAXDEG = 64     # graphs whose longest row is shorter need no plan (3 extra launches would not pay)
 
 
 class SpmmPlan:
@@ -157,17 +158,20 @@ class SpmmPlan:
 
 def spmm_plan(indptr, threshold=None, segment=None):
     """Build the skew plan of a CSR, or None when no row exceeds the threshold
-    (one host read-back of two counters; done once per graph)."""
+    (one host read-back of three counters; done once per graph).  With the
+    default threshold a plan is only built for graphs whose longest row has
+    more than SKEW_MIN_MAXDEG edges."""
+    auto = threshold is None
     threshold = SKEW_THRESHOLD if threshold is None else threshold
     segment = SKEW_SEGMENT if segment is None else segment
     _gpu(indptr, "indptr")
     dev = indptr.device
     n = indptr.numel() - 1
     with torch.cuda.device(dev):
-        counts = torch.zeros(2, dtype=torch.int64, device=dev)
+        counts = torch.zeros(3, dtype=torch.int64, device=dev)
         _lib.call("gae_spmm_plan_count", _ptr(indptr), n, threshold, segment, _ptr(counts), _stream())
-        n_heavy, n_seg = (int(v) for v in counts.tolist())
-        if n_heavy == 0:
+        n_heavy, n_seg, max_deg = (int(v) for v in counts.tolist())
+        if n_heavy == 0 or (auto and max_deg <= SKEW_MIN_MAXDEG):
             return None
         hr = torch.empty(n_heavy, dtype=torch.int32, device=dev)
         hb = torch.empty(n_heavy, dtype=torch.int32, device=dev)

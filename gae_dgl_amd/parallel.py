@@ -122,7 +122,9 @@ class ShardedGraph:
     def plan(self, which="fwd"):
         if which not in self._plan:
             from . import ops
-            self._plan[which] = ops.spmm_plan(self.csr(which)[0])
+            # explicit threshold: whether a row is segmented must depend on that row only, so that every
+            # sharding of a graph (and the 1-rank case) produces bit-identical sums
+            self._plan[which] = ops.spmm_plan(self.csr(which)[0], threshold=ops.SKEW_THRESHOLD)
         return self._plan[which]
 
     def n_edges(self, which="fwd"):

@@ -57,7 +57,7 @@ def collate(samples):
 class Trainer:
     def __init__(self, model, args, fused=True):
         self.model = model
-        self.optim = torch.optim.Adam(self.model.parameters(), lr=args.lr)
+        self.optim = torch.optim.Adam(self.model.parameters(), lr=args.lr, fused=True)
         self.fused = fused
         print('Total Parameters:', sum([p.nelement() for p in self.model.parameters()]))
 

@@ -53,7 +53,7 @@ def main(argv=None):
 
     model = GAE(in_feats, args.hidden_dims, norm=args.norm).to(device)
     model.train()
-    optim = torch.optim.Adam(model.parameters(), lr=args.lr)
+    optim = torch.optim.Adam(model.parameters(), lr=args.lr, fused=True)
 
     g = DGLGraph(data.graph).to(device)
     # normalization (train_transductive.py:55-58) -- parameter independent, so once, not per epoch

@@ -137,7 +137,7 @@ typedef struct gae_spmm_plan {
     const int32_t *seg_heavy;       /* [n_segments] heavy-row slot of the segment (device) */
 } gae_spmm_plan;
 
-/* counts_dev[0] = number of heavy rows, counts_dev[1] = number of segments (uint64, device) */
+/* counts_dev[0] = number of heavy rows, [1] = number of segments, [2] = maximum row degree (3 x uint64, device) */
 int gae_spmm_plan_count(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
                         uint64_t *counts_dev, void *stream);
 /* cursors_dev: 2 x uint64 scratch (zeroed by the call); output arrays sized from the counts */

@@ -29,9 +29,9 @@ def test_virtual_ranks_spmm_fwd_bwd_bit_exact(world, mode):
     n, src, dst, X = graph()
     ip, ix = ops.csr_from_coo(dst, src, n, n)
     tp, tx = ops.csr_from_coo(src, dst, n, n)
-    ref = ops.spmm_raw(ip, ix, X, n, plan=ops.spmm_plan(ip))
+    ref = ops.spmm_raw(ip, ix, X, n, plan=ops.spmm_plan(ip, threshold=ops.SKEW_THRESHOLD))
     dM = torch.randn(n, X.shape[1], device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
-    refb = ops.spmm_raw(tp, tx, dM, n, plan=ops.spmm_plan(tp))
+    refb = ops.spmm_raw(tp, tx, dM, n, plan=ops.spmm_plan(tp, threshold=ops.SKEW_THRESHOLD))
     grp = LocalGroup(world)
     outs, grads = [], []
     for r in range(world):

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""A/B of the fused decoder+BCE kernel variants (interleaved rounds, median/min)."""
+import argparse, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gae_dgl_amd as G
+from gae_dgl_amd import _lib, ops, workloads as W
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--graph", default="pubmed")
+ap.add_argument("--d", type=int, default=16)
+ap.add_argument("--variants", default="ri=2;ri=1;ri=4;ri=2,minw=5;ri=2,minw=6;ri=2,minw=8;ri=1,minw=8")
+ap.add_argument("--rounds", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+n, src, dst, _ = W.citation_graph(a.graph)
+g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+g.csr(); g.csc()
+Z = torch.randn(n, a.d, device=dev) * 0.5
+mask = ops.dropout_mask((n, a.d), 0.1, 1, device=dev)
+pw = (n * n - g.number_of_edges()) / g.number_of_edges()
+res = {}
+ref = None
+for rnd in range(a.rounds + 1):
+    for v in a.variants.split(";"):
+        kv = dict(x.split("=") for x in v.split(","))
+        _lib.call("gae_tuning_set", b"bce_ri", int(kv.get("ri", 2)))
+        _lib.call("gae_tuning_set", b"bce_minw", int(kv.get("minw", 0)))
+        fn = lambda: ops.decoder_bce_raw(Z, mask, g.csr(), g.csc(), pw, True)
+        loss, dz = fn(); torch.cuda.synchronize()
+        if rnd == 0:
+            if ref is None: ref = (loss.clone(), dz.clone())
+            else:
+                assert abs(float(loss) - float(ref[0])) < 1e-6 * abs(float(ref[0])), v
+                assert float((dz - ref[1]).abs().max()) < 1e-5 * float(ref[1].abs().max()), v
+            continue
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): fn()
+        e1.record(); torch.cuda.synchronize()
+        res.setdefault(v, []).append(e0.elapsed_time(e1) * 1e-3 / 10)
+for v, ts in res.items():
+    print(f"{v:16s} median {np.median(ts)*1e6:8.1f} us  min {np.min(ts)*1e6:8.1f} us   {n*n/np.median(ts)/1e12:.3f} T logits/s")
