@@ -210,11 +210,11 @@ int dispatch_gemm(const float *A, int64_t lda, const float *Amask, int64_t ldam,
 // barrier in the K loop; the 4 partial accumulators meet in LDS once, in fixed
 // order.  n / 32 blocks keep all CUs busy where 128-row tiles would not.
 // ---------------------------------------------------------------------------
-template <int NT, bool BT, int PRO_A>
+template <int NT, bool BT, int PRO_A, bool AVEC, bool BVEC>
 __global__ __launch_bounds__(256) void gemm_stream_kernel(
     const float *__restrict__ A, int64_t lda, const float *__restrict__ Amask, int64_t ldam,
     const float *__restrict__ B, int64_t ldb, const float *__restrict__ bias, int act, float *__restrict__ out,
-    int64_t ldo, int64_t n, int K, int J, int avec, int bvec)
+    int64_t ldo, int64_t n, int K, int J)
 {
     __shared__ float red[4 * NT * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -233,56 +233,80 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(
 
     const float *ap = A + row * lda;
     const float *mp = PRO_A != PRO_NONE ? Amask + row * ldam : nullptr;
-#pragma unroll 2
-    for (int kb = kb0; kb < kb1; ++kb) {
+    // Branch-free loads (indices clamped into range, zeroing by selects in compute()): see atb_partial_kernel.
+    struct Stage { float a[4], m[4]; float b[NT][4]; };
+    const int64_t rowc = rv ? row : n - 1;
+    const float *apc = A + rowc * lda;
+    const float *mpc = PRO_A != PRO_NONE ? Amask + rowc * ldam : nullptr;
+    constexpr bool a4 = AVEC, b4 = BVEC;                // compile-time: a runtime choice between two load styles makes
+                                                        // hipcc branch around the loads and drain vmcnt at the joins
+    const int K4 = (K + 3) & ~3;                        // avec: lda % 4 == 0 and lda >= K, so [K, K4) is row padding
+    auto load = [&](Stage &st, int kb) {
         const int k = kb * 8 + 4 * h;
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-        if (rv) {
-            if (avec && k + 4 <= K) {
-                const float4 t4 = *reinterpret_cast<const float4 *>(ap + k);
-                a[0] = t4.x; a[1] = t4.y; a[2] = t4.z; a[3] = t4.w;
-                if (PRO_A != PRO_NONE) {
-                    const float4 m4 = *reinterpret_cast<const float4 *>(mp + k);
-                    const float m[4] = {m4.x, m4.y, m4.z, m4.w};
+        const int kc = k <= K4 - 4 ? k : K4 - 4;        // in-bounds start of a 4-wide vector load (== k when any
+                                                        // of its elements is < K, so positions stay aligned)
+        if (a4) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(apc + kc);
+            st.a[0] = t4.x; st.a[1] = t4.y; st.a[2] = t4.z; st.a[3] = t4.w;
+            if (PRO_A != PRO_NONE) {
+                const float4 m4 = *reinterpret_cast<const float4 *>(mpc + kc);
+                st.m[0] = m4.x; st.m[1] = m4.y; st.m[2] = m4.z; st.m[3] = m4.w;
+            }
+        } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        a[q] = PRO_A == PRO_RELU_MASK ? (m[q] > 0.f ? a[q] : 0.f) : a[q] * m[q];
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (k + q < K) {
-                        float v = ap[k + q];
-                        if (PRO_A == PRO_RELU_MASK) v = mp[k + q] > 0.f ? v : 0.f;
-                        if (PRO_A == PRO_MUL_MASK) v *= mp[k + q];
-                        a[q] = v;
-                    }
+            for (int q = 0; q < 4; ++q) {
+                const int kq = k + q < K ? k + q : K - 1;
+                st.a[q] = apc[kq];
+                if (PRO_A != PRO_NONE) st.m[q] = mpc[kq];
             }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int j = t * 32 + i;
-            float b[4] = {0.f, 0.f, 0.f, 0.f};
-            if (j < J) {
-                if (BT) {
-                    const float *bp = B + int64_t(j) * ldb + k;
-                    if (bvec && k + 4 <= K) {
-                        const float4 t4 = *reinterpret_cast<const float4 *>(bp);
-                        b[0] = t4.x; b[1] = t4.y; b[2] = t4.z; b[3] = t4.w;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (k + q < K) b[q] = bp[q];
-                    }
+            const int jc = j < J ? j : J - 1;
+            if (BT) {
+                const float *bp = B + int64_t(jc) * ldb;
+                if (b4) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(bp + kc);
+                    st.b[t][0] = t4.x; st.b[t][1] = t4.y; st.b[t][2] = t4.z; st.b[t][3] = t4.w;
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (k + q < K) b[q] = B[int64_t(k + q) * ldb + j];
+                    for (int q = 0; q < 4; ++q) st.b[t][q] = bp[k + q < K ? k + q : K - 1];
                 }
-            }
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc[t], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) st.b[t][q] = B[int64_t(k + q < K ? k + q : K - 1) * ldb + jc];
+            }
         }
+    };
+    auto compute = [&](const Stage &st, int kb) {
+        const int k = kb * 8 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bool jv = t * 32 + i < J;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool kv = kb < kb1 && k + q < K;
+                float av = (rv && kv) ? st.a[q] : 0.f;
+                if (PRO_A == PRO_RELU_MASK) av = st.m[q] > 0.f ? av : 0.f;
+                if (PRO_A == PRO_MUL_MASK) av *= st.m[q];
+                const float bv = (jv && kv) ? st.b[t][q] : 0.f;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    };
+    // two k-blocks in flight ahead of the MFMAs (register double buffering, no LDS, no barrier)
+    if (kb0 < kb1) {
+        Stage s0, s1, s2;
+        int kb = kb0;
+#define GAE_PIN() __builtin_amdgcn_sched_barrier(0)
+        load(s0, kb); load(s1, kb + 1); GAE_PIN();
+        while (true) {
+            load(s2, kb + 2); GAE_PIN(); compute(s0, kb); GAE_PIN(); if (++kb >= kb1) break;
+            load(s0, kb + 2); GAE_PIN(); compute(s1, kb); GAE_PIN(); if (++kb >= kb1) break;
+            load(s1, kb + 2); GAE_PIN(); compute(s2, kb); GAE_PIN(); if (++kb >= kb1) break;
+        }
+#undef GAE_PIN
     }
     // ---- fixed-order cross-wave reduction: red[wave][t][r][lane]
 #pragma unroll
@@ -315,11 +339,18 @@ template <int NT, bool BT, int PRO_A>
 int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t ldam, const float *B, int64_t ldb,
                        const float *bias, int act, float *out, int64_t ldo, int64_t n, int K, int64_t J, hipStream_t s)
 {
-    bool avec = (lda % 4 == 0) && gae::aligned16(A);
+    bool avec = (lda % 4 == 0) && gae::aligned16(A) && K >= 1;
     if (PRO_A != PRO_NONE) avec = avec && (ldam % 4 == 0) && gae::aligned16(Amask);
-    const bool bvec = BT && (ldb % 4 == 0) && gae::aligned16(B);
-    hipLaunchKernelGGL((gemm_stream_kernel<NT, BT, PRO_A>), dim3(unsigned((n + 31) / 32)), dim3(256), 0, s, A, lda,
-                       Amask, ldam, B, ldb, bias, act, out, ldo, n, K, int(J), avec ? 1 : 0, bvec ? 1 : 0);
+    const bool bvec = BT && (ldb % 4 == 0) && gae::aligned16(B) && K >= 4 && (K % 4 == 0);
+    const dim3 grid(unsigned((n + 31) / 32));
+#define GAE_GS(AV, BV)                                                                                              \
+    hipLaunchKernelGGL((gemm_stream_kernel<NT, BT, PRO_A, AV, BV>), grid, dim3(256), 0, s, A, lda, Amask, ldam, B, ldb, \
+                       bias, act, out, ldo, n, K, int(J))
+    if (avec && bvec) GAE_GS(true, true);
+    else if (avec) GAE_GS(true, false);
+    else if (bvec) GAE_GS(false, true);
+    else GAE_GS(false, false);
+#undef GAE_GS
     GAE_CHECK_LAUNCH("gemm_stream_kernel");
     return GAE_OK;
 }
@@ -331,17 +362,18 @@ int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t 
 // slot and one 32 x (IT*32) output tile and writes a partial; a second kernel
 // sums the partials in slot order (deterministic, no float atomics).
 // ---------------------------------------------------------------------------
-template <int IT, int PRO_P>
+template <int IT, int PRO_P, bool QVEC>
 __global__ __launch_bounds__(256) void atb_partial_kernel(
     const float *__restrict__ P, int64_t ldp, const float *__restrict__ Pmask, int64_t ldpm,
     const float *__restrict__ Q, int64_t ldq, int64_t n, int O, int I, int64_t rows_per_slot,
     float *__restrict__ partial, float *__restrict__ colsum_partial)
 {
+    static_assert(IT == 4, "lane j owns the 4 adjacent columns 4j..4j+3 of a 128-column group: one float4 per row");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t slot = int64_t(blockIdx.x) * 4 + wave;
-    const int o = blockIdx.z * 32 + (lane & 31);
-    const int i0 = blockIdx.y * (IT * 32);
-    const int h = lane >> 5;
+    const int j = lane & 31, h = lane >> 5;
+    const int o = blockIdx.z * 32 + j;
+    const int cb = blockIdx.y * 128 + 4 * j;   // tile t of this lane is column cb + t
     const int64_t r_begin = slot * rows_per_slot;
     int64_t r_end = r_begin + rows_per_slot;
     if (r_end > n) r_end = n;
@@ -353,43 +385,76 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float csum = 0.f;
 
-    // 4 k-steps (8 rows) per iteration: all loads of the iteration are issued before its first MFMA
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += 8) {
-        float a[4], b[4][IT];
+    // Loads are BRANCH-FREE (row / column indices are clamped into range, out-of-range values are zeroed by
+    // selects in compute()): hipcc otherwise branches around every guarded load and drains vmcnt(0) at each
+    // join, which serialises the whole pipeline (cdna guide, "load everything, select afterwards").
+    struct Stage { float a[4], m[4]; float b[4][IT]; };
+    const int64_t r_last = r_end - 1;                       // r_begin < r_end whenever anything is loaded
+    const int oc = o < O ? o : O - 1;
+    constexpr bool lane_cols_ok = QVEC;                     // I % 4 == 0: a lane's 4 columns are all valid or all invalid
+    const int cbc = lane_cols_ok ? (cb + 4 <= I ? cb : I - 4) : 0;
+    auto load = [&](Stage &st, int64_t r0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int64_t r = r0 + 2 * u + h;
-            const bool rv = r < r_end;
-            float av = 0.f;
-            if (rv && o < O) {
-                av = P[r * ldp + o];
-                if (PRO_P == PRO_RELU_MASK) av = Pmask[r * ldpm + o] > 0.f ? av : 0.f;
-                if (PRO_P == PRO_MUL_MASK) av *= Pmask[r * ldpm + o];
+            int64_t r = r0 + 2 * u + h;
+            r = r < r_last ? r : r_last;
+            st.a[u] = P[r * ldp + oc];
+            if (PRO_P != PRO_NONE) st.m[u] = Pmask[r * ldpm + oc];
+            if (lane_cols_ok) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(Q + r * ldq + cbc);
+                st.b[u][0] = q4.x; st.b[u][1] = q4.y; st.b[u][2] = q4.z; st.b[u][3] = q4.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < IT; ++t) {
+                    const int c = cb + t < I ? cb + t : (I > 0 ? I - 1 : 0);
+                    st.b[u][t] = I > 0 ? Q[r * ldq + c] : 0.f;
+                }
             }
-            a[u] = av;
+        }
+    };
+    auto compute = [&](const Stage &st, int64_t r0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool rv = r0 + 2 * u + h < r_end;
+            float av = (rv && o < O) ? st.a[u] : 0.f;
+            if (PRO_P == PRO_RELU_MASK) av = st.m[u] > 0.f ? av : 0.f;
+            if (PRO_P == PRO_MUL_MASK) av *= st.m[u];
+            csum += av;
 #pragma unroll
             for (int t = 0; t < IT; ++t) {
-                const int i = i0 + t * 32 + (lane & 31);
-                b[u][t] = (rv && i < I) ? Q[r * ldq + i] : 0.f;
+                const float bv = (rv && cb + t < I) ? st.b[u][t] : 0.f;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            csum += a[u];
-#pragma unroll
-            for (int t = 0; t < IT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
+    };
+    // 8 rows per stage, register double buffering: the next stage's loads are in flight during the MFMAs
+    if (r_begin < r_end) {
+        Stage s0, s1, s2;
+        int64_t r0 = r_begin;
+        // sched_barrier pins the issue order: without it the machine scheduler sinks every load next to its
+        // consumer and the prefetch distance collapses to zero
+#define GAE_PIN() __builtin_amdgcn_sched_barrier(0)
+        load(s0, r0); load(s1, r0 + 8); GAE_PIN();
+        while (true) {
+            load(s2, r0 + 16); GAE_PIN(); compute(s0, r0); GAE_PIN(); r0 += 8; if (r0 >= r_end) break;
+            load(s0, r0 + 16); GAE_PIN(); compute(s1, r0); GAE_PIN(); r0 += 8; if (r0 >= r_end) break;
+            load(s1, r0 + 16); GAE_PIN(); compute(s2, r0); GAE_PIN(); r0 += 8; if (r0 >= r_end) break;
         }
+#undef GAE_PIN
     }
-    // partial[slot][O][I]
+    // partial[slot][O][I]; lane j holds columns cb..cb+3 of output row oo in acc[0..3][r]
     float *pp = partial + slot * int64_t(O) * I;
 #pragma unroll
-    for (int t = 0; t < IT; ++t) {
-        const int i = i0 + t * 32 + (lane & 31);
-        if (i >= I) continue;
+    for (int r = 0; r < 16; ++r) {
+        const int oo = blockIdx.z * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (oo >= O) continue;
+        float *dst = pp + int64_t(oo) * I + cb;
+        if (QVEC && cb + 4 <= I) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int oo = blockIdx.z * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (oo < O) pp[int64_t(oo) * I + i] = acc[t][r];
+            for (int t = 0; t < IT; ++t)
+                if (cb + t < I) dst[t] = acc[t][r];
         }
     }
     if (colsum_partial && blockIdx.y == 0) {
@@ -481,8 +546,13 @@ int launch_atb(const float *P, int64_t ldp, const float *Pmask, int64_t ldpm, co
     constexpr int IT = 4;
     const unsigned gy = I > 0 ? unsigned((I + IT * 32 - 1) / (IT * 32)) : 1u;  // I == 0: column sums only
     const dim3 grid(unsigned(pl.blocks), gy, unsigned((O + 31) / 32));
-    hipLaunchKernelGGL((atb_partial_kernel<IT, PRO_P>), grid, dim3(256), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n, O, I,
-                       pl.rows_per_slot, partial, colsum_partial);
+    const bool qvec = (ldq % 4 == 0) && gae::aligned16(Q) && (I % 4 == 0) && I >= 4 && gae::aligned16(partial);
+    if (qvec)
+        hipLaunchKernelGGL((atb_partial_kernel<IT, PRO_P, true>), grid, dim3(256), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n,
+                           O, I, pl.rows_per_slot, partial, colsum_partial);
+    else
+        hipLaunchKernelGGL((atb_partial_kernel<IT, PRO_P, false>), grid, dim3(256), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n,
+                           O, I, pl.rows_per_slot, partial, colsum_partial);
     GAE_CHECK_LAUNCH("atb_partial_kernel");
     return GAE_OK;
 }
