@@ -14,6 +14,9 @@ OBJDIR = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(LIBDIR, "libgae_hip.so")
 SOURCES = ["api.hip", "csr_build.hip", "spmm.hip", "dense.hip", "decoder_bce.hip"]
 ARCH = "gfx950"
+# per-file extra flags.  decoder_bce: let MFMA accumulators live in VGPRs (gfx950 has a unified file) so the
+# VALU epilogue of every tile does not pay one v_accvgpr_read per logit.
+EXTRA_FLAGS = {"decoder_bce.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc():
@@ -32,6 +35,7 @@ def build_library(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "gae_hip.h")]
     headers += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.abspath(__file__))
     objs, rebuilt = [], False
     procs = []
     for src in SOURCES:
@@ -42,7 +46,7 @@ def build_library(force=False, verbose=False):
         objs.append(obj)
         if force or _newer(obj, [sp] + headers):
             cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
-                   "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", sp, "-o", obj]
+                   "-I", os.path.join(ROOT, "include"), "-I", CSRC] + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd)))

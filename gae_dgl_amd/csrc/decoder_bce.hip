@@ -9,22 +9,30 @@
 //
 // Math.  x_ij = zt_i . zt_j,  y_ij = #edges j->i  (CSR rows = destination):
 //   N^2 loss = sum_ij [(1 - y) x + (1 + (pw - 1) y) softplus(-x)]
-//            = sum_ij softplus(x_ij)                       <- dense, label-free
-//            + sum_{edges (i,j)} [-x_ij + (pw - 1) softplus(-x_ij)]   <- sparse
+//            = sum_ij softplus(x_ij)                                   <- dense, label-free
+//            + sum_{edges (i,j)} [-x_ij + (pw - 1) softplus(-x_ij)]    <- sparse
 //   dL/dx_ij = [sigmoid(x_ij) + y_ij ((pw - 1) sigmoid(x_ij) - pw)] / N^2
-//   dZt = (G + G^T) Zt   ->  dense part 2 sigmoid(X) Zt / N^2 (X symmetric)
-//                            sparse part over in-edges (CSR) and out-edges (CSR of A^T).
+//   dZt = (G + G^T) Zt  ->  dense part 2 sigmoid(X) Zt / N^2 (X symmetric), sparse part over
+//                           in-edges (CSR) and out-edges (CSR of A^T).
 //
-// Dense kernel: flash-style.  Wave owns RI 16-row subtiles, streams column tiles
-// through LDS, S^T = Zj Zi^T on v_mfma_f32_16x16x4_f32 (exact fp32), softplus /
-// sigmoid on the VALU, O += sigmoid(S) Zj on the same MFMA shape: the S^T
-// accumulator registers are directly the A fragments of the second product
-// (lane = row i, reg r <-> j = 4 (lane >> 4) + r), so P never leaves registers.
-// MFMA-bound (fp32 matrix rate), not HBM-bound: 4 KS (S) + 4 KS (PV) MFMAs per
-// 256 logits with KS = ceil(d / 16).
-// Reductions are two-stage and ordered: bit-stable run to run.
+// Dense part, trimmed for the VALU (which co-limits with the fp32 matrix rate):
+//   with e = exp(-|x|), t = 1 + e, r = 1/t:
+//     softplus(x) = (x + |x|)/2 + ln2 * log2(t)      sum_ij x_ij = (sum_i zt_i).(sum_j zt_j)  analytic
+//     sigmoid(x)  = 1/2 + copysign(r - 1/2, x)       sum_j (1/2) zt_j                          analytic
+//   so the kernel accumulates only sum|x|, sum log2(t) and O' = sum_j copysign(r - 1/2, x_ij) zt_j:
+//   9 VALU ops (3 transcendental) per logit.  Zero-padded columns contribute exactly log2(2) = 1 to
+//   sum log2(t) and 0 to everything else: corrected analytically, no masking in the loop.
+//
+// Dense kernel: flash-style.  A wave owns RI 16-row subtiles and streams 64-column tiles of Zt through
+// double-buffered LDS.  S^T = Zj Zi^T on the matrix cores, either
+//   * bf16 x 3 (default): Zt = hi + lo (two bf16), S = hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x16_bf16
+//     (fp32 accumulate; the dropped lo.lo term is 2^-16 relative), which runs on the matrix pipe proper and
+//     leaves the fp32 FMA lanes to the VALU work; or
+//   * exact fp32 v_mfma_f32_16x16x4_f32 (knob bce_s_bf16 = 0), which shares the fp32 lanes with the VALU.
+// O' += P Zj on v_mfma_f32_16x16x4_f32: the S^T accumulator registers are directly the A fragments (lane =
+// row i, reg r <-> j = 4 (lane >> 4) + r), so P never leaves registers.
+// Reductions are two-stage, ordered, fp64 for the loss: bit-stable run to run.
 #include <string.h>
-#include <type_traits>
 
 #include "common.h"
 
@@ -32,11 +40,18 @@ namespace {
 
 using gae::kWave;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TJ = 64;   // columns staged per iteration
-// RI = 16-row subtiles per wave (rows / block = 64 RI); tuning knobs "bce_ri", "bce_minw"
+constexpr int PREP_ROWS = 64;    // rows per block of the prepare kernel
+// tuning knobs (gae_tuning_set): "bce_ri" 16-row subtiles per wave (rows / block = 64 RI), "bce_minw" min
+// waves per SIMD hint, "bce_s_bf16" 1 = bf16x3 S product, 0 = exact fp32 S product
 int g_bce_ri = 2;
 int g_bce_minw = 0;
+int g_bce_s_bf16 = 1;
+int g_bce_pv_bf16 = 1;   // "bce_pv_bf16": 1 = bf16x3 for O' += P V as well (P split on the fly), 0 = exact fp32
 
 __device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
 {
@@ -49,38 +64,112 @@ __device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
     sg = (x >= 0.f ? 1.0f : e) * r;
 }
 
-// Zt[n][DP] = Z (.) mask, zero padded to DP = 16 KS columns: the dense kernel then reads
-// clean 16-byte aligned rows without mask loads or feature bounds checks.
+// ---------------------------------------------------------------------------
+// prepare: Zt[n][DP] = Z (.) mask zero padded to DP = 16 KS columns (clean 16-byte rows, no mask loads or
+// feature bounds checks downstream), its bf16 hi / lo split, and per-block fp64 column sums of Zt over all
+// rows and over the row window (for the analytic terms).
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bce_prepare_kernel(const float *__restrict__ Z, const float *__restrict__ mask,
-                                                          int64_t ldz, int64_t n, int d, int DP,
-                                                          float *__restrict__ Zt)
+                                                          int64_t ldz, int64_t n, int d, int DP, int64_t row_begin,
+                                                          int64_t row_end, float *__restrict__ Zt,
+                                                          unsigned short *__restrict__ Zhi,
+                                                          unsigned short *__restrict__ Zlo,
+                                                          double *__restrict__ colsum_partial /*[grid][2][DP]*/)
 {
-    const int64_t total = n * DP, stride = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int64_t i = e / DP;
-        const int k = int(e - i * DP);
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x;
+    const int k = tid % DP, rl = tid / DP, rpp = 256 / DP;   // rows per pass
+    const int64_t r0 = int64_t(blockIdx.x) * PREP_ROWS;
+    double s_all = 0.0, s_win = 0.0;
+    for (int rr = rl; rr < PREP_ROWS; rr += rpp) {
+        const int64_t i = r0 + rr;
+        if (i >= n) break;
         float v = 0.f;
         if (k < d) {
             v = Z[i * ldz + k];
             if (mask) v *= mask[i * ldz + k];
         }
-        Zt[e] = v;
+        Zt[i * DP + k] = v;
+        const unsigned short hi = gae::f32_to_bf16(v);
+        Zhi[i * DP + k] = hi;
+        Zlo[i * DP + k] = gae::f32_to_bf16(v - gae::bf16_to_f32(hi));
+        s_all += double(v);
+        if (i >= row_begin && i < row_end) s_win += double(v);
+    }
+    red[0][tid] = s_all; red[1][tid] = s_win;
+    __syncthreads();
+    if (tid < DP) {
+        double a = 0.0, w = 0.0;
+        for (int q = 0; q < rpp; ++q) { a += red[0][q * DP + tid]; w += red[1][q * DP + tid]; }
+        colsum_partial[(int64_t(blockIdx.x) * 2 + 0) * DP + tid] = a;
+        colsum_partial[(int64_t(blockIdx.x) * 2 + 1) * DP + tid] = w;
+    }
+}
+
+// one block: ordered sum of the per-block column sums -> S_all / S_win (double) and S_all as float.
+// 256 threads = DP columns x (256 / DP) interleaved block partitions, combined in LDS in fixed order.
+__global__ __launch_bounds__(256) void bce_colsum_kernel(const double *__restrict__ colsum_partial, int64_t n_blocks,
+                                                         int DP, double *__restrict__ S /*[2][DP]*/,
+                                                         float *__restrict__ S_all_f /*[DP]*/)
+{
+    __shared__ double red[2][256];
+    const int k = threadIdx.x % DP, q = threadIdx.x / DP, nq = 256 / DP;
+    double a = 0.0, w = 0.0;
+    for (int64_t b = q; b < n_blocks; b += nq) {
+        a += colsum_partial[(b * 2 + 0) * DP + k];
+        w += colsum_partial[(b * 2 + 1) * DP + k];
+    }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = w;
+    __syncthreads();
+    if (threadIdx.x < DP) {
+        a = 0.0; w = 0.0;
+        for (int j = 0; j < nq; ++j) { a += red[0][j * DP + k]; w += red[1][j * DP + k]; }
+        S[k] = a; S[DP + k] = w;
+        S_all_f[k] = float(a);
     }
 }
 
 // ---------------------------------------------------------------------------
-template <int KS, bool WITH_GRAD, int RI, int MINW>
+// dense part.  loss_partial[blk] = {sum |x|, sum log2(1 + exp(-|x|))} over the block's (row, column) window.
+// ---------------------------------------------------------------------------
+// split 4 fp32 values into bf16 hi and bf16 lo = bf16(v - hi): v_cvt_pk_bf16_f32 x4, 5 VALU ops per pair
+__device__ __forceinline__ void split_bf16x4(const f32x4 &v, s16x4 &hi, s16x4 &lo)
+{
+    unsigned h[2], l[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2 a = {v[2 * q], v[2 * q + 1]};
+        const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
+        const f32x2 back = {__uint_as_float(hu << 16), __uint_as_float(hu & 0xffff0000u)};
+        h[q] = hu;
+        l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(a - back, bf16x2));
+    }
+    struct U { unsigned a, b; } uh{h[0], h[1]}, ul{l[0], l[1]};
+    hi = __builtin_bit_cast(s16x4, uh);
+    lo = __builtin_bit_cast(s16x4, ul);
+}
+
+template <int KS, bool WITH_GRAD, int RI, int MINW, bool SBF16, bool PBF16>
 __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
-    const float *__restrict__ Zt /*[n][16 KS]*/, int64_t n, int64_t row_begin, int64_t n_local,
-    int64_t cols_per_split, float *__restrict__ O_partial /*[splits][n_local][KS*16]*/,
-    double *__restrict__ loss_partial /*[gridDim.x * gridDim.y]*/)
+    const float *__restrict__ Zt /*[n][16 KS]*/, const unsigned short *__restrict__ Zhi,
+    const unsigned short *__restrict__ Zlo, int64_t n, int64_t row_begin, int64_t n_local, int64_t cols_per_split,
+    float *__restrict__ O_partial /*[splits][n_local][KS*16]*/, double *__restrict__ loss_partial /*[blocks][2]*/)
 {
     constexpr int ROWS_PER_BLOCK = 4 * RI * 16;
     constexpr int DP = KS * 16;          // padded feature width
-    constexpr int LDA = DP + 4;          // LDS row stride (floats): 16-byte aligned, breaks the power of two
+    constexpr int LDA = DP + 4;          // fp32 LDS row stride (floats): 16-byte aligned, breaks the power of two
+    constexpr int LDH = DP + 4;          // bf16 LDS row stride (elements): 8-byte aligned rows
     constexpr int V4 = TJ * DP / 4 / 256;  // float4 per thread and staged tile (1, 2, 4)
-    __shared__ __attribute__((aligned(16))) float Zs[2][TJ * LDA];   // double-buffered column tile [j][k]
-    __shared__ double red[4];
+    constexpr int LDT = TJ + 4;          // transposed bf16 tile row stride (elements), 8-byte aligned rows
+    constexpr bool NEED_F32 = !SBF16 || (WITH_GRAD && !PBF16);
+    constexpr bool NEED_BF = SBF16 || (WITH_GRAD && PBF16);
+    constexpr bool NEED_T = WITH_GRAD && PBF16;
+    __shared__ __attribute__((aligned(16))) float Zs[2][NEED_F32 ? TJ * LDA : 4];            // fp32 column tile [j][k]
+    __shared__ __attribute__((aligned(16))) unsigned short Hs[2][SBF16 ? TJ * LDH : 4];      // bf16 hi [j][k]
+    __shared__ __attribute__((aligned(16))) unsigned short Ls[2][SBF16 ? TJ * LDH : 4];      // bf16 lo [j][k]
+    __shared__ __attribute__((aligned(16))) unsigned short HT[2][NEED_T ? DP * LDT : 4];     // bf16 hi [k][j]
+    __shared__ __attribute__((aligned(16))) unsigned short LT[2][NEED_T ? DP * LDT : 4];     // bf16 lo [k][j]
+    __shared__ double red[4][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -90,83 +179,145 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     int64_t col_end = col_begin + cols_per_split;
     if (col_end > n) col_end = n;
 
-    // B fragments of S^T = Zj Zi^T: lane (i = l15, g) holds Zt[i][16 c + 4 g + r]
+    // B fragments of S^T = Zj Zi^T: lane (i = l15, g) holds Zt[i][16 c + 4 g + r], r = 0..3 (fp32 or hi / lo bf16)
     f32x4 bfrag[RI][KS];
+    s16x4 bhi[RI][KS], blo[RI][KS];
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri) {
         const int64_t i = row_base + ri * 16 + l15;
+        const int64_t gi = row_begin + (i < n_local ? i : 0);
 #pragma unroll
-        for (int c = 0; c < KS; ++c)
-            bfrag[ri][c] = i < n_local ? *reinterpret_cast<const f32x4 *>(Zt + (row_begin + i) * DP + 16 * c + 4 * g)
-                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < KS; ++c) {
+            if (SBF16) {
+                bhi[ri][c] = *reinterpret_cast<const s16x4 *>(Zhi + gi * DP + 16 * c + 4 * g);
+                blo[ri][c] = *reinterpret_cast<const s16x4 *>(Zlo + gi * DP + 16 * c + 4 * g);
+                if (i >= n_local) { bhi[ri][c] = s16x4{0, 0, 0, 0}; blo[ri][c] = s16x4{0, 0, 0, 0}; }
+            } else {
+                bfrag[ri][c] = *reinterpret_cast<const f32x4 *>(Zt + gi * DP + 16 * c + 4 * g);
+                if (i >= n_local) bfrag[ri][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
     }
     f32x4 oacc[RI][KS];
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri)
 #pragma unroll
         for (int c = 0; c < KS; ++c) oacc[ri][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    double lsum[RI];
+    double sumA[RI], sumL[RI];
 #pragma unroll
-    for (int ri = 0; ri < RI; ++ri) lsum[ri] = 0.0;
+    for (int ri = 0; ri < RI; ++ri) { sumA[ri] = 0.0; sumL[ri] = 0.0; }
 
-    // staging: thread -> float4 #(tid + 256 q) of the tile; tile rows are contiguous in Zt
-    auto load_tile = [&](int64_t j0, f32x4 (&reg)[V4]) {
+    // staging: thread -> 16-byte piece #(tid + 256 q) of the fp32 tile and 8-byte piece of each bf16 tile;
+    // tile rows are contiguous in Zt / Zhi / Zlo.  Rows >= col_end are staged as zeros (branch-free: the
+    // row index is clamped and the value selected).
+    struct Stage { f32x4 f[V4]; s16x4 h[V4], l[V4]; };
+    auto load_tile = [&](int64_t j0, Stage &st) {
 #pragma unroll
         for (int q = 0; q < V4; ++q) {
-            const int idx = tid + 256 * q;            // float4 index inside the tile
-            const int jj = idx / (DP / 4);
-            reg[q] = (j0 + jj < col_end) ? *reinterpret_cast<const f32x4 *>(Zt + (j0 + jj) * DP + (idx % (DP / 4)) * 4)
-                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int idx = tid + 256 * q;            // 4-element piece index inside the tile
+            const int jj = idx / (DP / 4), kk = (idx % (DP / 4)) * 4;
+            const bool jv = j0 + jj < col_end;
+            const int64_t j = jv ? j0 + jj : col_begin;
+            if (NEED_F32) {
+                st.f[q] = *reinterpret_cast<const f32x4 *>(Zt + j * DP + kk);
+                if (!jv) st.f[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (NEED_BF) {
+                st.h[q] = *reinterpret_cast<const s16x4 *>(Zhi + j * DP + kk);
+                st.l[q] = *reinterpret_cast<const s16x4 *>(Zlo + j * DP + kk);
+                if (!jv) { st.h[q] = s16x4{0, 0, 0, 0}; st.l[q] = s16x4{0, 0, 0, 0}; }
+            }
         }
     };
-    auto store_tile = [&](int buf, const f32x4 (&reg)[V4]) {
+    auto store_tile = [&](int buf, const Stage &st) {
 #pragma unroll
         for (int q = 0; q < V4; ++q) {
             const int idx = tid + 256 * q;
-            *reinterpret_cast<f32x4 *>(&Zs[buf][(idx / (DP / 4)) * LDA + (idx % (DP / 4)) * 4]) = reg[q];
+            const int jj = idx / (DP / 4), kk = (idx % (DP / 4)) * 4;
+            if (NEED_F32) *reinterpret_cast<f32x4 *>(&Zs[buf][jj * LDA + kk]) = st.f[q];
+            if (SBF16) {
+                *reinterpret_cast<s16x4 *>(&Hs[buf][jj * LDH + kk]) = st.h[q];
+                *reinterpret_cast<s16x4 *>(&Ls[buf][jj * LDH + kk]) = st.l[q];
+            }
+            if (NEED_T) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    HT[buf][(kk + e) * LDT + jj] = (unsigned short)st.h[q][e];
+                    LT[buf][(kk + e) * LDT + jj] = (unsigned short)st.l[q][e];
+                }
+            }
         }
     };
 
-    auto compute_tile = [&](const float *zs, int64_t j0, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    auto compute_tile = [&](int buf) {
+        const float *zs = Zs[buf];
+        float tA[RI], tL[RI];        // fp32 partial sums of this 64-column tile (16 logits per lane and subtile)
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri) { tA[ri] = 0.f; tL[ri] = 0.f; }
 #pragma unroll
         for (int jt = 0; jt < TJ / 16; ++jt) {
-            // A fragments: lane (j = l15, g) -> zs[jt*16 + j][16 c + 4 g .. +3]
-            f32x4 afrag[KS];
-#pragma unroll
-            for (int c = 0; c < KS; ++c)
-                afrag[c] = *reinterpret_cast<const f32x4 *>(&zs[(jt * 16 + l15) * LDA + 16 * c + 4 * g]);
             f32x4 sacc[RI];
 #pragma unroll
             for (int ri = 0; ri < RI; ++ri) sacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (SBF16) {
+                // A fragments: lane (j = l15, g) -> 4 bf16 at [jt*16 + j][16 c + 4 g ..]
 #pragma unroll
-            for (int c = 0; c < KS; ++c)
+                for (int c = 0; c < KS; ++c) {
+                    const s16x4 ah = *reinterpret_cast<const s16x4 *>(&Hs[buf][(jt * 16 + l15) * LDH + 16 * c + 4 * g]);
+                    const s16x4 al = *reinterpret_cast<const s16x4 *>(&Ls[buf][(jt * 16 + l15) * LDH + 16 * c + 4 * g]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int ri = 0; ri < RI; ++ri) {
+                        sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bhi[ri][c], sacc[ri], 0, 0, 0);
+                        sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, blo[ri][c], sacc[ri], 0, 0, 0);
+                        sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bhi[ri][c], sacc[ri], 0, 0, 0);
+                    }
+                }
+            } else {
 #pragma unroll
-                    for (int ri = 0; ri < RI; ++ri)
-                        sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[c][r], bfrag[ri][c][r], sacc[ri], 0, 0, 0);
+                for (int c = 0; c < KS; ++c) {
+                    const f32x4 af = *reinterpret_cast<const f32x4 *>(&zs[(jt * 16 + l15) * LDA + 16 * c + 4 * g]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int ri = 0; ri < RI; ++ri)
+                            sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], bfrag[ri][c][r], sacc[ri], 0, 0, 0);
+                }
+            }
             // sacc[ri][r] = x(i = l15 of subtile ri, j = jt*16 + 4 g + r)
             f32x4 p[RI];
 #pragma unroll
             for (int ri = 0; ri < RI; ++ri) {
-                float tsum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float sp, sg;
-                    softplus_sigmoid(sacc[ri][r], sp, sg);
-                    if (!FULL) {
-                        const bool jv = j0 + jt * 16 + 4 * g + r < col_end;
-                        sp = jv ? sp : 0.f;
-                        sg = jv ? sg : 0.f;
-                    }
-                    tsum += sp;
-                    p[ri][r] = sg;
+                    const float x = sacc[ri][r];
+                    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(x));
+                    const float t = 1.0f + e;
+                    tL[ri] += __builtin_amdgcn_logf(t);      // log2(1 + exp(-|x|))
+                    tA[ri] += fabsf(x);
+                    const float s = __builtin_amdgcn_rcpf(t) - 0.5f;   // in [0, 1/2]
+                    p[ri][r] = copysignf(s, x);              // sigmoid(x) - 1/2
                 }
-                lsum[ri] += double(tsum);
             }
-            if (WITH_GRAD) {
-                // B fragments of O += P V: lane (nn = l15, g) -> V[jt*16 + 4 g + r][16 c + nn]
+            if (WITH_GRAD && PBF16) {
+                // P = hi + lo (bf16) on the fly; B fragments: lane (nn = l15, g) -> 4 bf16 V[jt*16 + 4 g ..][16 c + nn]
+                // read from the transposed tiles; O' += lo.hi + hi.lo + hi.hi on the bf16 matrix pipe
+                s16x4 ph[RI], pl[RI];
+#pragma unroll
+                for (int ri = 0; ri < RI; ++ri) split_bf16x4(p[ri], ph[ri], pl[ri]);
+#pragma unroll
+                for (int c = 0; c < KS; ++c) {
+                    const s16x4 vh = *reinterpret_cast<const s16x4 *>(&HT[buf][(16 * c + l15) * LDT + jt * 16 + 4 * g]);
+                    const s16x4 vl = *reinterpret_cast<const s16x4 *>(&LT[buf][(16 * c + l15) * LDT + jt * 16 + 4 * g]);
+#pragma unroll
+                    for (int ri = 0; ri < RI; ++ri) {
+                        oacc[ri][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pl[ri], vh, oacc[ri][c], 0, 0, 0);
+                        oacc[ri][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ph[ri], vl, oacc[ri][c], 0, 0, 0);
+                        oacc[ri][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ph[ri], vh, oacc[ri][c], 0, 0, 0);
+                    }
+                }
+            }
+            if (WITH_GRAD && !PBF16) {
+                // B fragments of O' += P V: lane (nn = l15, g) -> V[jt*16 + 4 g + r][16 c + nn]
 #pragma unroll
                 for (int c = 0; c < KS; ++c) {
                     float v[4];
@@ -180,9 +331,11 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
                 }
             }
         }
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri) { sumA[ri] += double(tA[ri]); sumL[ri] += double(tL[ri]); }
     };
 
-    f32x4 stage[V4];
+    Stage stage;
     if (col_begin < col_end) {
         load_tile(col_begin, stage);
         store_tile(0, stage);
@@ -192,12 +345,11 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     for (int64_t j0 = col_begin; j0 < col_end; j0 += TJ, buf ^= 1) {
         const bool more = j0 + TJ < col_end;
         if (more) load_tile(j0 + TJ, stage);        // in flight while this tile is consumed
-        if (j0 + TJ <= col_end) compute_tile(Zs[buf], j0, std::true_type{});
-        else compute_tile(Zs[buf], j0, std::false_type{});
+        compute_tile(buf);
         if (more) store_tile(buf ^ 1, stage);
         __syncthreads();
     }
-    // ---- O partial: oacc[ri][c][r] = O(i = 4 g + r, nn = l15) of subtile ri, feature 16 c + nn
+    // ---- O' partial: oacc[ri][c][r] = O'(i = 4 g + r, nn = l15) of subtile ri, feature 16 c + nn
     if (WITH_GRAD) {
         float *op = O_partial + int64_t(blockIdx.y) * n_local * DP;
 #pragma unroll
@@ -211,44 +363,50 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
                 }
             }
     }
-    // ---- loss partial: drop rows >= n, wave reduce (fixed tree) -> block
-    double ls = 0.0;
+    // ---- loss partials: drop rows >= n_local, wave reduce (fixed tree) -> block
+    double la = 0.0, ll = 0.0;
 #pragma unroll
-    for (int ri = 0; ri < RI; ++ri) ls += (row_base + ri * 16 + l15) < n_local ? lsum[ri] : 0.0;
+    for (int ri = 0; ri < RI; ++ri) {
+        const bool rv = (row_base + ri * 16 + l15) < n_local;
+        la += rv ? sumA[ri] : 0.0;
+        ll += rv ? sumL[ri] : 0.0;
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ls += __shfl_down(ls, off, 64);
-    if (lane == 0) red[wave] = ls;
+    for (int off = 32; off > 0; off >>= 1) { la += __shfl_down(la, off, 64); ll += __shfl_down(ll, off, 64); }
+    if (lane == 0) { red[wave][0] = la; red[wave][1] = ll; }
     __syncthreads();
-    if (tid == 0) loss_partial[int64_t(blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) {
+        const int64_t b = int64_t(blockIdx.y) * gridDim.x + blockIdx.x;
+        loss_partial[2 * b + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        loss_partial[2 * b + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
 }
 
 // ---------------------------------------------------------------------------
-// Sparse part + assembly.  A group of LPR lanes owns node i (VEC features per
-// lane): in-edges from the CSR give the loss terms and G_s Zt, out-edges from
-// the CSR of A^T give G_s^T Zt; then
-//   dZ[i] = mask[i] * ( 2 sum_splits O[s][i] + sparse ) / N^2.
+// Sparse part + assembly.  A group of LPR lanes owns node i (4 features per lane): in-edges from the CSR
+// give the loss terms and G_s Zt, out-edges from the CSR of A^T give G_s^T Zt; then
+//   dZ[i] = mask[i] * ( 2 (sum_splits O'[s][i] + S_all / 2) + sparse ) / N^2.
 // ---------------------------------------------------------------------------
 template <int VEC, int LPR, bool WITH_GRAD>
 __global__ __launch_bounds__(256) void bce_edges_kernel(
     const float *__restrict__ Zt /*[n][DP] = Z (.) mask, zero padded*/, const float *__restrict__ mask, int64_t ldz,
     int64_t row_begin, int64_t n_local, int d, const int32_t *__restrict__ indptr,
-    const int32_t *__restrict__ indices,
-    const int32_t *__restrict__ t_indptr, const int32_t *__restrict__ t_indices, float pw, float inv_n2,
-    const float *__restrict__ O_partial, int n_splits, int DP, float *__restrict__ dZ, int64_t lddz,
-    double *__restrict__ loss_partial)
+    const int32_t *__restrict__ indices, const int32_t *__restrict__ t_indptr, const int32_t *__restrict__ t_indices,
+    float pw, float inv_n2, const float *__restrict__ O_partial, int n_splits, int DP,
+    const float *__restrict__ S_all_f, float *__restrict__ dZ, int64_t lddz, double *__restrict__ loss_partial)
 {
+    static_assert(VEC == 4, "edge kernel reads the padded Zt rows as float4");
     __shared__ double red[4];
     constexpr int RPB = 256 / LPR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lig = tid % LPR;
     const int64_t i = int64_t(blockIdx.x) * RPB + tid / LPR;   // local row
-    const int64_t gi = row_begin + i;                          // its row in Z / mask
+    const int64_t gi = row_begin + i;                          // its row in Zt / mask
     const int64_t n = n_local;
     const int f0 = lig * VEC;
     const bool rowv = i < n;
-
-    static_assert(VEC == 4, "edge kernel reads the padded Zt rows as float4");
     const bool fv = f0 < DP;     // lanes beyond the padded width idle (LPR is a power of two >= DP / 4)
+
     float zi[VEC], acc[VEC];
     {
         const f32x4 t = (rowv && fv) ? *reinterpret_cast<const f32x4 *>(Zt + gi * DP + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -307,7 +465,7 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
         for (int q = 0; q < VEC; ++q) {
             const int f = f0 + q;
             if (f < d) {
-                float o = 0.f;
+                float o = 0.5f * S_all_f[f];
                 for (int s = 0; s < n_splits; ++s) o += O_partial[(int64_t(s) * n + i) * DP + f];
                 float v = (2.0f * o + acc[q]) * inv_n2;
                 if (mask) v *= mask[gi * ldz + f];
@@ -322,26 +480,41 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
     if (tid == 0) loss_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// single block: ordered sum of all partials -> mean
-__global__ __launch_bounds__(256) void bce_finalize_kernel(const double *__restrict__ partial, int64_t count,
-                                                           double inv_n2, float *__restrict__ loss_out)
+// single block: ordered sums of all partials -> mean
+//   N^2 loss = 1/2 S_win.S_all + 1/2 sum|x| + ln2 (sum log2(t) - pad_cols * n_local) + edges
+__global__ __launch_bounds__(256) void bce_finalize_kernel(const double *__restrict__ dense_partial,
+                                                           int64_t n_dense, const double *__restrict__ edge_partial,
+                                                           int64_t n_edge, const double *__restrict__ S, int DP,
+                                                           double pad_terms, double inv_n2,
+                                                           float *__restrict__ loss_out)
 {
-    __shared__ double red[256];
-    double s = 0.0;
-    for (int64_t k = threadIdx.x; k < count; k += 256) s += partial[k];
-    red[threadIdx.x] = s;
+    __shared__ double red[3][256];
+    double a = 0.0, l = 0.0, e = 0.0;
+    for (int64_t k = threadIdx.x; k < n_dense; k += 256) { a += dense_partial[2 * k]; l += dense_partial[2 * k + 1]; }
+    for (int64_t k = threadIdx.x; k < n_edge; k += 256) e += edge_partial[k];
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = l; red[2][threadIdx.x] = e;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
-        if (int(threadIdx.x) < off) red[threadIdx.x] += red[threadIdx.x + off];
+        if (int(threadIdx.x) < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+            red[2][threadIdx.x] += red[2][threadIdx.x + off];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *loss_out = float(red[0] * inv_n2);
+    if (threadIdx.x == 0) {
+        double sx = 0.0;
+        for (int k = 0; k < DP; ++k) sx += S[k] * S[DP + k];          // sum_{i in window} sum_j x_ij
+        const double dense = 0.5 * sx + 0.5 * red[0][0] + 0.69314718055994531 * (red[1][0] - pad_terms);
+        *loss_out = float((dense + red[2][0]) * inv_n2);
+    }
 }
 
 struct BcePlan {
-    int64_t row_blocks, n_splits, cols_per_split, edge_blocks;
+    int64_t row_blocks, n_splits, cols_per_split, edge_blocks, prep_blocks;
     int KS, DP, LPR, VEC, RI;
-    int64_t o_bytes, zt_bytes, loss_count, total_bytes;
+    int64_t o_bytes, zt_bytes, zh_bytes, cs_bytes, s_bytes, n_dense, total_bytes;
+    double pad_terms;
 };
 
 inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
@@ -367,37 +540,53 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     const int64_t tiles_per_split = (col_tiles + want - 1) / want;
     p.cols_per_split = tiles_per_split * TJ;
     p.n_splits = (col_tiles + tiles_per_split - 1) / tiles_per_split;
-    p.VEC = vec_ok ? 4 : 1;
+    p.pad_terms = double(col_tiles * TJ - n) * double(n_local);   // zero columns: log2(1 + e^0) = 1 each
+    (void)vec_ok;
+    p.VEC = 4;
     const int nvec = p.DP / 4;   // the edge kernel reads the padded Zt rows
     int lpr = 1;
     while (lpr < nvec) lpr <<= 1;
     p.LPR = lpr;
     p.edge_blocks = (n_local + (256 / lpr) - 1) / (256 / lpr);
     if (p.edge_blocks < 1) p.edge_blocks = 1;
+    p.prep_blocks = (n + PREP_ROWS - 1) / PREP_ROWS;
     p.o_bytes = align256(p.n_splits * n_local * p.DP * 4);
     p.zt_bytes = align256(n * p.DP * 4);
-    p.loss_count = p.row_blocks * p.n_splits + p.edge_blocks;
-    p.total_bytes = p.o_bytes + p.zt_bytes + align256(p.loss_count * 8);
+    p.zh_bytes = align256(n * p.DP * 2);
+    p.cs_bytes = align256(p.prep_blocks * 2 * p.DP * 8);
+    p.s_bytes = align256(2 * p.DP * 8 + p.DP * 4);
+    p.n_dense = p.row_blocks * p.n_splits;
+    p.total_bytes = p.o_bytes + p.zt_bytes + 2 * p.zh_bytes + p.cs_bytes + p.s_bytes +
+                    align256((2 * p.n_dense + p.edge_blocks) * 8);
     return true;
 }
 
 template <bool WITH_GRAD>
-int launch_dense(const BcePlan &p, const float *Zt, int64_t n, int64_t row_begin, int64_t n_local, float *O,
-                 double *lp, hipStream_t s)
+int launch_dense(const BcePlan &p, const float *Zt, const unsigned short *Zhi, const unsigned short *Zlo, int64_t n,
+                 int64_t row_begin, int64_t n_local, float *O, double *lp, hipStream_t s)
 {
     const dim3 grid(unsigned(p.row_blocks), unsigned(p.n_splits));
-#define GAE_BD(KS, RI, MW) hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW>), grid, dim3(256), 0, s, Zt, n, row_begin, n_local, p.cols_per_split, O, lp)
+#define GAE_BD(KS, RI, MW, SB)                                                                                     \
+    do {                                                                                                           \
+        if (SB && g_bce_pv_bf16)                                                                                   \
+            hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW, SB, SB>), grid, dim3(256), 0, s, Zt, Zhi,  \
+                               Zlo, n, row_begin, n_local, p.cols_per_split, O, lp);                               \
+        else                                                                                                       \
+            hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW, SB, false>), grid, dim3(256), 0, s, Zt,    \
+                               Zhi, Zlo, n, row_begin, n_local, p.cols_per_split, O, lp);                          \
+    } while (0)
+    const bool sb = g_bce_s_bf16 != 0;
     if (p.KS == 1) {
-        if (p.RI == 1) { if (g_bce_minw >= 8) GAE_BD(1, 1, 8); else GAE_BD(1, 1, 1); }
-        else if (p.RI == 4) GAE_BD(1, 4, 1);
-        else if (g_bce_minw >= 8) GAE_BD(1, 2, 8);
-        else if (g_bce_minw >= 6) GAE_BD(1, 2, 6);
-        else if (g_bce_minw >= 5) GAE_BD(1, 2, 5);
-        else GAE_BD(1, 2, 1);
+        if (p.RI == 1) { if (sb) GAE_BD(1, 1, 1, true); else GAE_BD(1, 1, 1, false); }
+        else if (p.RI == 4) { if (sb) GAE_BD(1, 4, 1, true); else GAE_BD(1, 4, 1, false); }
+        else if (g_bce_minw >= 6) { if (sb) GAE_BD(1, 2, 6, true); else GAE_BD(1, 2, 6, false); }
+        else { if (sb) GAE_BD(1, 2, 1, true); else GAE_BD(1, 2, 1, false); }
     } else if (p.KS == 2) {
-        if (p.RI == 1) GAE_BD(2, 1, 1); else GAE_BD(2, 2, 1);
+        if (p.RI == 1) { if (sb) GAE_BD(2, 1, 1, true); else GAE_BD(2, 1, 1, false); }
+        else { if (sb) GAE_BD(2, 2, 1, true); else GAE_BD(2, 2, 1, false); }
     } else {
-        if (p.RI == 1) GAE_BD(4, 1, 1); else GAE_BD(4, 2, 1);
+        if (p.RI == 1) { if (sb) GAE_BD(4, 1, 1, true); else GAE_BD(4, 1, 1, false); }
+        else { if (sb) GAE_BD(4, 2, 1, true); else GAE_BD(4, 2, 1, false); }
     }
 #undef GAE_BD
     GAE_CHECK_LAUNCH("bce_dense_kernel");
@@ -407,19 +596,18 @@ int launch_dense(const BcePlan &p, const float *Zt, int64_t n, int64_t row_begin
 template <int VEC, bool WITH_GRAD>
 int launch_edges(const BcePlan &p, const float *Zt, const float *mask, int64_t ldz, int64_t row_begin, int64_t n, int d,
                  const int32_t *ip, const int32_t *ix, const int32_t *tp, const int32_t *tx, float pw, float inv_n2,
-                 const float *O, float *dZ, int64_t lddz, double *lp, hipStream_t s)
+                 const float *O, const float *S_all_f, float *dZ, int64_t lddz, double *lp, hipStream_t s)
 {
 #define GAE_EDGE(LPR)                                                                                              \
     hipLaunchKernelGGL((bce_edges_kernel<VEC, LPR, WITH_GRAD>), dim3(unsigned(p.edge_blocks)), dim3(256), 0, s, Zt, \
-                       mask, ldz, row_begin, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, dZ, lddz, lp)
+                       mask, ldz, row_begin, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, S_all_f,  \
+                       dZ, lddz, lp)
     switch (p.LPR) {
     case 1: GAE_EDGE(1); break;
     case 2: GAE_EDGE(2); break;
     case 4: GAE_EDGE(4); break;
     case 8: GAE_EDGE(8); break;
-    case 16: GAE_EDGE(16); break;
-    case 32: GAE_EDGE(32); break;
-    default: GAE_EDGE(64); break;
+    default: GAE_EDGE(16); break;
     }
 #undef GAE_EDGE
     GAE_CHECK_LAUNCH("bce_edges_kernel");
@@ -433,6 +621,8 @@ int *bce_knob(const char *name)
 {
     if (strcmp(name, "bce_ri") == 0) return &g_bce_ri;
     if (strcmp(name, "bce_minw") == 0) return &g_bce_minw;
+    if (strcmp(name, "bce_s_bf16") == 0) return &g_bce_s_bf16;
+    if (strcmp(name, "bce_pv_bf16") == 0) return &g_bce_pv_bf16;
     return nullptr;
 }
 } // namespace gae
@@ -466,30 +656,36 @@ extern "C" int gae_decoder_bce_rows(const float *Z, const float *mask, int64_t l
                 (long long)workspace_bytes, (long long)p.total_bytes);
     GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_decoder_bce: workspace not 16-byte aligned");
     hipStream_t s = gae::as_stream(stream);
-    float *O = static_cast<float *>(workspace);
-    float *Zt = reinterpret_cast<float *>(static_cast<char *>(workspace) + p.o_bytes);
-    double *lp = reinterpret_cast<double *>(static_cast<char *>(workspace) + p.o_bytes + p.zt_bytes);
+    char *w = static_cast<char *>(workspace);
+    float *O = reinterpret_cast<float *>(w); w += p.o_bytes;
+    float *Zt = reinterpret_cast<float *>(w); w += p.zt_bytes;
+    unsigned short *Zhi = reinterpret_cast<unsigned short *>(w); w += p.zh_bytes;
+    unsigned short *Zlo = reinterpret_cast<unsigned short *>(w); w += p.zh_bytes;
+    double *cs = reinterpret_cast<double *>(w); w += p.cs_bytes;
+    double *S = reinterpret_cast<double *>(w);
+    float *S_all_f = reinterpret_cast<float *>(w + 2 * p.DP * 8); w += p.s_bytes;
+    double *lp = reinterpret_cast<double *>(w);
     const double inv_n2 = 1.0 / (double(n) * double(n));
     if (n_local == 0) {
         GAE_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), s));
         return GAE_OK;
     }
-    {
-        int64_t gb = (n * p.DP + 255) / 256;
-        if (gb > 2048) gb = 2048;
-        hipLaunchKernelGGL(bce_prepare_kernel, dim3(unsigned(gb)), dim3(256), 0, s, Z, mask, ldz, n, int(d), p.DP, Zt);
-        GAE_CHECK_LAUNCH("bce_prepare_kernel");
-    }
-    int rc = dZ ? launch_dense<true>(p, Zt, n, row_begin, n_local, O, lp, s)
-                : launch_dense<false>(p, Zt, n, row_begin, n_local, O, lp, s);
+    hipLaunchKernelGGL(bce_prepare_kernel, dim3(unsigned(p.prep_blocks)), dim3(256), 0, s, Z, mask, ldz, n, int(d), p.DP,
+                       row_begin, row_begin + n_local, Zt, Zhi, Zlo, cs);
+    GAE_CHECK_LAUNCH("bce_prepare_kernel");
+    hipLaunchKernelGGL(bce_colsum_kernel, dim3(1), dim3(256), 0, s, cs, p.prep_blocks, p.DP, S, S_all_f);
+    GAE_CHECK_LAUNCH("bce_colsum_kernel");
+    int rc = dZ ? launch_dense<true>(p, Zt, Zhi, Zlo, n, row_begin, n_local, O, lp, s)
+                : launch_dense<false>(p, Zt, Zhi, Zlo, n, row_begin, n_local, O, lp, s);
     if (rc) return rc;
-    double *lpe = lp + p.row_blocks * p.n_splits;
+    double *lpe = lp + 2 * p.n_dense;
     rc = dZ ? launch_edges<4, true>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr, t_indices,
-                                    pos_weight, float(inv_n2), O, dZ, lddz, lpe, s)
+                                    pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, s)
             : launch_edges<4, false>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr,
-                                     t_indices, pos_weight, float(inv_n2), O, dZ, lddz, lpe, s);
+                                     t_indices, pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(256), 0, s, lp, p.loss_count, inv_n2, loss_out);
+    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(256), 0, s, lp, p.n_dense, lpe, p.edge_blocks, S, p.DP,
+                       p.pad_terms, inv_n2, loss_out);
     GAE_CHECK_LAUNCH("bce_finalize_kernel");
     return GAE_OK;
 }
