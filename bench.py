@@ -56,10 +56,12 @@ def parse():
     ap.add_argument("--rmat-scale", type=int, default=24)
     ap.add_argument("--batch-graphs", type=int, default=4096)
     ap.add_argument("--exchange", choices=["allgather", "boundary"], default="allgather")
-    ap.add_argument("--hipgraph", action="store_true",
-                    help="citation workloads: replay the step as one captured HIP graph (per-kernel HIP events are "
-                         "then taken from an eager pass of the same steps just before the capture); default is "
-                         "eager launches so the roofline events sit inside the timed region")
+    ap.add_argument("--no-hipgraph", action="store_true",
+                    help="citation workloads: launch the step eagerly.  Default: the timed steps replay the step as "
+                         "one captured HIP graph (the ~30 launches are host-bound otherwise); HIP events cannot be "
+                         "recorded inside a replay, so the per-kernel event timings of `roofline` come from an eager "
+                         "pass of the SAME steps immediately before the capture (with --no-hipgraph they sit inside "
+                         "the timed region)")
     return ap.parse_args()
 
 
@@ -102,7 +104,7 @@ class CitationWorkload:
         self.F_in, self.hidden = X.shape[1], [32, 16]
         torch.manual_seed(0)
         self.model = G.GAE(self.F_in, self.hidden).to(dev)
-        self.use_graph = args.hipgraph and args.loss == "fused"
+        self.use_graph = (not args.no_hipgraph) and args.loss == "fused"
         self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-2,        # train_transductive.py:43
                                     fused=True, capturable=self.use_graph)   # one multi-tensor launch
         self.g = G.DGLGraph((src, dst), num_nodes=n).to(dev)

@@ -47,8 +47,38 @@ def _dtype_code(t):
     raise GaeHipError(f"unsupported dtype {t.dtype} (fp32 and bf16 storage are supported)")
 
 
+_WS_CACHE = {}
+
+
 def _workspace(nbytes, device):
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    """scratch buffer for one call.  Buffers are cached per (device, stream, size class): every launch that
+    uses one is ordered on that stream, so the next call may reuse it (no allocator round trip per call)."""
+    nbytes = max(int(nbytes), 16)
+    size = 1 << (nbytes - 1).bit_length()
+    key = (device, torch.cuda.current_stream(device).cuda_stream, size)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(size, dtype=torch.uint8, device=device)   # graph-private pool owns captured scratch
+    ws = _WS_CACHE.get(key)
+    if ws is None:
+        ws = _WS_CACHE[key] = torch.empty(size, dtype=torch.uint8, device=device)
+    return ws
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the guard costs microseconds)"""
+    __slots__ = ("guard",)
+
+    def __init__(self, dev):
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.guard = None if idx == torch.cuda.current_device() else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *a):
+        if self.guard is not None:
+            self.guard.__exit__(*a)
 
 
 def device_info(device=0):
@@ -67,7 +97,7 @@ def csr_from_coo(row, col, n_rows, n_cols, validate=True):
     if col.numel() != E:
         raise GaeHipError("csr_from_coo: row/col length mismatch")
     dev = row.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         indptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
         indices = torch.empty(E, dtype=torch.int32, device=dev)
         nbytes = _lib.load().gae_csr_from_coo_workspace_bytes(E, n_rows)
@@ -88,7 +118,7 @@ def degree_norm(indptr, want_deg=True, want_norm=True):
     dev = indptr.device
     deg = torch.empty(n, dtype=torch.int32, device=dev) if want_deg else None
     norm = torch.empty(n, dtype=torch.float32, device=dev) if want_norm else None
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.call("gae_degree_norm", _ptr(indptr), n, _ptr(deg), _ptr(norm), _stream())
     return deg, norm
 
@@ -96,7 +126,7 @@ def degree_norm(indptr, want_deg=True, want_norm=True):
 def csr_to_dense(indptr, indices, n_rows, n_cols):
     _gpu(indptr, "indptr")
     out = torch.empty(n_rows, n_cols, dtype=torch.float32, device=indptr.device)
-    with torch.cuda.device(indptr.device):
+    with _on_device(indptr.device):
         _lib.call("gae_csr_to_dense", _ptr(indptr), _ptr(indices), n_rows, n_cols, _ptr(out), max(n_cols, 1),
                   _stream())
     return out
@@ -109,7 +139,7 @@ def batch_gather(graph_ptr, ds_indptr, ds_indices, ds_feat, graph_ids, node_ptr,
     out_indptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
     out_indices = torch.empty(n_edges, dtype=torch.int32, device=dev)
     out_feat = torch.empty(n_nodes, F, dtype=feat.dtype, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.call("gae_batch_gather", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_indices), _ptr(feat), ldf, F,
                   _dtype_code(feat), _ptr(graph_ids), graph_ids.numel(), _ptr(node_ptr), _ptr(edge_ptr),
                   n_nodes, n_edges, _ptr(out_indptr), _ptr(out_indices), _ptr(out_feat), max(F, 1), _stream())
@@ -167,7 +197,7 @@ def spmm_plan(indptr, threshold=None, segment=None):
     _gpu(indptr, "indptr")
     dev = indptr.device
     n = indptr.numel() - 1
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         counts = torch.zeros(3, dtype=torch.int64, device=dev)
         _lib.call("gae_spmm_plan_count", _ptr(indptr), n, threshold, segment, _ptr(counts), _stream())
         n_heavy, n_seg, max_deg = (int(v) for v in counts.tolist())
@@ -191,7 +221,7 @@ def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=Non
     out2, ldm = _rowmajor(out, "out")
     if out2 is not out:
         raise GaeHipError("spmm: `out` must be row-major with unit inner stride")
-    with torch.cuda.device(H.device):
+    with _on_device(H.device):
         pc, ws, ws_bytes = None, None, 0
         if plan is not None:
             pc = ctypes.byref(plan.c)
@@ -214,7 +244,7 @@ def linear_fwd_raw(M, W, b, act):
     n, f_in = M.shape
     f_out = W.shape[0]
     Y = torch.empty(n, f_out, dtype=torch.float32, device=M.device)
-    with torch.cuda.device(M.device):
+    with _on_device(M.device):
         _lib.call("gae_linear_fwd", _ptr(M), ldm, n, f_in, _ptr(W), _ptr(b), f_out, act, _ptr(Y), max(f_out, 1),
                   _stream())
     return Y
@@ -233,7 +263,7 @@ def linear_bwd_raw(dY, Y, act, M, W, need_dW=True, need_db=True, need_dM=True):
     ldy = 0
     if Y is not None:
         Y, ldy = _rowmajor(Y, "Y")
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws = _workspace(_lib.load().gae_linear_bwd_workspace_bytes(n, f_in, f_out), dev)
         _lib.call("gae_linear_bwd", _ptr(dY), lddy, _ptr(Y), ldy, act, _ptr(M), ldm, _ptr(W), n, f_in, f_out,
                   _ptr(dW), _ptr(db), _ptr(dM), max(f_in, 1), _ptr(ws), ws.numel(), _stream())
@@ -244,7 +274,7 @@ def dropout_mask(shape, p, seed, offset=0, device="cuda", draw_counter=None):
     """inverted-dropout multiplier; ``draw_counter`` (int64 device tensor [1]) selects the
     draw on the device so that captured HIP graphs advance the stream between replays"""
     mask = torch.empty(shape, dtype=torch.float32, device=device)
-    with torch.cuda.device(mask.device):
+    with _on_device(mask.device):
         _lib.call("gae_dropout_mask", _ptr(mask), mask.numel(), float(p), int(seed) & (2 ** 64 - 1),
                   int(offset) & (2 ** 64 - 1), _ptr(draw_counter), _stream())
     return mask
@@ -258,7 +288,7 @@ def decoder_dense_raw(Z, mask=None):
             Z = Z.contiguous(); ldz = max(Z.shape[1], 1)
     n, d = Z.shape
     out = torch.empty(n, n, dtype=torch.float32, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on_device(Z.device):
         _lib.call("gae_decoder_dense", _ptr(Z), _ptr(mask), ldz, n, d, _ptr(out), max(n, 1), _stream())
     return out
 
@@ -270,7 +300,7 @@ def decoder_dense_bwd_raw(G, Z, mask=None):
         mask = mask.contiguous()
     n, d = Z.shape
     dZ = torch.empty(n, d, dtype=torch.float32, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on_device(Z.device):
         ws = _workspace(_lib.load().gae_decoder_dense_bwd_workspace_bytes(n, d), Z.device)
         _lib.call("gae_decoder_dense_bwd", _ptr(G), ldg, _ptr(Z), _ptr(mask), max(d, 1), n, d, _ptr(dZ), max(d, 1),
                   _ptr(ws), ws.numel(), _stream())
@@ -291,7 +321,7 @@ def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, 
     dZ = torch.empty(n_local, d, dtype=torch.float32, device=dev) if want_grad else None
     indptr, indices = csr
     t_indptr, t_indices = csc if csc is not None else (None, None)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         nbytes = _lib.load().gae_decoder_bce_workspace_bytes(n, n_local, d)
         if nbytes < 0:
             _lib.check(int(nbytes), "gae_decoder_bce_workspace_bytes")
