@@ -20,7 +20,7 @@
 //     softplus(x) = (x + |x|)/2 + ln2 * log2(t)      sum_ij x_ij = (sum_i zt_i).(sum_j zt_j)  analytic
 //     sigmoid(x)  = 1/2 + copysign(r - 1/2, x)       sum_j (1/2) zt_j                          analytic
 //   so the kernel accumulates only sum|x|, sum log2(t) and O' = sum_j copysign(r - 1/2, x_ij) zt_j:
-//   9 VALU ops (3 transcendental) per logit.  Zero-padded columns contribute exactly log2(2) = 1 to
+//   ~8 VALU ops (2 transcendental: v_exp, v_rcp; the logs are taken of products of 16 t's) per logit.  Zero-padded columns contribute exactly log2(2) = 1 to
 //   sum log2(t) and 0 to everything else: corrected analytically, no masking in the loop.
 //
 // Dense kernel: flash-style.  A wave owns RI 16-row subtiles and streams 64-column tiles of Zt through
@@ -179,7 +179,11 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     int64_t col_end = col_begin + cols_per_split;
     if (col_end > n) col_end = n;
 
-    // B fragments of S^T = Zj Zi^T: lane (i = l15, g) holds Zt[i][16 c + 4 g + r], r = 0..3 (fp32 or hi / lo bf16)
+    // B fragments of S^T = Zj Zi^T: lane (i = l15, g) holds LOG2E * Zt[i][16 c + 4 g + r], r = 0..3 (fp32, or
+    // split into hi / lo bf16 here, once per wave).  The row operand carries the log2(e) factor, so the
+    // accumulator is y = x log2(e) and exp(-|x|) = exp2(-|y|) needs no multiply per logit (sign and |.|
+    // sums are rescaled at the end).
+    constexpr float LOG2E = 1.44269504088896341f;
     f32x4 bfrag[RI][KS];
     s16x4 bhi[RI][KS], blo[RI][KS];
 #pragma unroll
@@ -188,14 +192,11 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
         const int64_t gi = row_begin + (i < n_local ? i : 0);
 #pragma unroll
         for (int c = 0; c < KS; ++c) {
-            if (SBF16) {
-                bhi[ri][c] = *reinterpret_cast<const s16x4 *>(Zhi + gi * DP + 16 * c + 4 * g);
-                blo[ri][c] = *reinterpret_cast<const s16x4 *>(Zlo + gi * DP + 16 * c + 4 * g);
-                if (i >= n_local) { bhi[ri][c] = s16x4{0, 0, 0, 0}; blo[ri][c] = s16x4{0, 0, 0, 0}; }
-            } else {
-                bfrag[ri][c] = *reinterpret_cast<const f32x4 *>(Zt + gi * DP + 16 * c + 4 * g);
-                if (i >= n_local) bfrag[ri][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            f32x4 b = *reinterpret_cast<const f32x4 *>(Zt + gi * DP + 16 * c + 4 * g);
+            if (i >= n_local) b = f32x4{0.f, 0.f, 0.f, 0.f};
+            b *= LOG2E;
+            bfrag[ri][c] = b;
+            if (SBF16) split_bf16x4(b, bhi[ri][c], blo[ri][c]);
         }
     }
     f32x4 oacc[RI][KS];
@@ -251,9 +252,11 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
 
     auto compute_tile = [&](int buf) {
         const float *zs = Zs[buf];
-        float tA[RI], tL[RI];        // fp32 partial sums of this 64-column tile (16 logits per lane and subtile)
+        // fp32 partials of this 64-column tile (16 logits per lane and subtile): sum |x| and PRODUCT of
+        // t = 1 + exp(-|x|) in [1, 2] (<= 2^16): sum log2(t) = log2(prod t) costs one v_log per 16 logits
+        float tA[RI], tP[RI];
 #pragma unroll
-        for (int ri = 0; ri < RI; ++ri) { tA[ri] = 0.f; tL[ri] = 0.f; }
+        for (int ri = 0; ri < RI; ++ri) { tA[ri] = 0.f; tP[ri] = 1.f; }
 #pragma unroll
         for (int jt = 0; jt < TJ / 16; ++jt) {
             f32x4 sacc[RI];
@@ -289,10 +292,10 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
             for (int ri = 0; ri < RI; ++ri) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float x = sacc[ri][r];
-                    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(x));
+                    const float x = sacc[ri][r];                 // = x_ij * log2(e)
+                    const float e = __builtin_amdgcn_exp2f(-fabsf(x));
                     const float t = 1.0f + e;
-                    tL[ri] += __builtin_amdgcn_logf(t);      // log2(1 + exp(-|x|))
+                    tP[ri] *= t;
                     tA[ri] += fabsf(x);
                     const float s = __builtin_amdgcn_rcpf(t) - 0.5f;   // in [0, 1/2]
                     p[ri][r] = copysignf(s, x);              // sigmoid(x) - 1/2
@@ -332,7 +335,10 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
             }
         }
 #pragma unroll
-        for (int ri = 0; ri < RI; ++ri) { sumA[ri] += double(tA[ri]); sumL[ri] += double(tL[ri]); }
+        for (int ri = 0; ri < RI; ++ri) {
+            sumA[ri] += double(tA[ri]);
+            sumL[ri] += double(__builtin_amdgcn_logf(tP[ri]));
+        }
     };
 
     Stage stage;
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri) {
         const bool rv = (row_base + ri * 16 + l15) < n_local;
-        la += rv ? sumA[ri] : 0.0;
+        la += rv ? sumA[ri] * 0.69314718055994531 : 0.0;    // sum |y| / log2(e) = sum |x|
         ll += rv ? sumL[ri] : 0.0;
     }
 #pragma unroll
