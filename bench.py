@@ -65,6 +65,16 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic_r01.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")) as f:
+            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+    except OSError:
+        return None
+
+
 def time_launches(fn, iters=50, warmup=5):
     """average duration of `fn`'s launches between one HIP event pair on the launch stream"""
     for _ in range(warmup):
@@ -120,6 +130,7 @@ class CitationWorkload:
         self.dominant = ("spmm", n, n, self.F_in, "torch.float32")
         self.dominant_desc = f"spmm F={self.F_in} (layer-1 aggregation A*X, {n} rows, {E} edges)"
         self.alg_bytes = W.spmm_alg_bytes(n, n, E, self.F_in, 4)
+        self.pmc_key = f"{name}-F{self.F_in}"
         self.scaling = "weak"
 
     def capture(self):
@@ -368,7 +379,10 @@ def main():
                               + (" (per-rank share of the edges)" if world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": wl.dominant_desc,
                      "achieved": wl.alg_bytes / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": wl.alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "frac": wl.alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic(getattr(wl, "pmc_key", "")),
+                     "traffic_note": "HBM bytes/launch from separate rocprofv3 --pmc passes of the same kernel and "
+                                     "shape (profiles/pmc_traffic_r01.json), not collected in this run",
                      "alg_bytes_per_launch": wl.alg_bytes, "avg_launch_us": t_dom * 1e6, "launches_timed": len(dom)},
     }
     if "decoder_bce" in {k[0] for k in times}:
