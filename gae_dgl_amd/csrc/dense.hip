@@ -608,6 +608,95 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float *__restrict__ m
     }
 }
 
+
+// standard normal noise: Philox4x32-10 + Box-Muller, 4 values per counter (VGAE reparameterisation)
+__global__ __launch_bounds__(256) void normal_noise_kernel(float *__restrict__ out, int64_t n, uint64_t seed,
+                                                           uint64_t offset, const uint64_t *__restrict__ draw_dev)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const int64_t nquad = (n + 3) / 4;
+    if (draw_dev) offset += *draw_dev * uint64_t(nquad);
+    for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < nquad; q += stride) {
+        const uint64_t ctr = offset + uint64_t(q);
+        uint32_t c[4] = {uint32_t(ctr), uint32_t(ctr >> 32), 0x6e6f726du, 0u};   // stream tag differs from dropout
+        uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = (float(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);     // (0, 1)
+            const float u2 = float(c[2 * h + 1] >> 8) * (1.0f / 16777216.0f);          // [0, 1)
+            const float rad = sqrtf(-2.0f * __logf(u1));
+            float sn, cs;
+            __sincosf(6.28318530717958648f * u2, &sn, &cs);
+            z[2 * h] = rad * cs; z[2 * h + 1] = rad * sn;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (q * 4 + i < n) out[q * 4 + i] = z[i];
+    }
+}
+
+// VGAE head (Kipf & Welling 2016; README.md:58 cites the paper, the reference has no code for it):
+//   z = mu + eps * exp(logstd);   KL = -(0.5 / N) * mean_i sum_j (1 + 2 logstd - mu^2 - exp(2 logstd))
+// forward writes z and per-block fp64 partial sums of the KL bracket; backward adds the KL gradient to
+// the gradient arriving through z.
+__global__ __launch_bounds__(256) void vgae_head_fwd_kernel(const float *__restrict__ mu, const float *__restrict__ ls,
+                                                            const float *__restrict__ eps, int64_t n_elems,
+                                                            float *__restrict__ z, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    double acc = 0.0;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
+        const float m = mu[e], l = ls[e];
+        const float s = __expf(l);
+        z[e] = fmaf(eps[e], s, m);
+        acc += double(1.0f + 2.0f * l - m * m - s * s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void vgae_kl_finalize_kernel(const double *__restrict__ partial, int n_partial,
+                                                               double scale, float *__restrict__ kl_out)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < n_partial; k += 256) s += partial[k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (int(threadIdx.x) < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *kl_out = float(red[0] * scale);
+}
+
+// dmu = dz + gkl * mu / N^2 ;  dls = dz * eps * exp(ls) + gkl * (exp(2 ls) - 1) / N^2
+__global__ __launch_bounds__(256) void vgae_head_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ mu,
+                                                            const float *__restrict__ ls, const float *__restrict__ eps,
+                                                            const float *__restrict__ gkl_dev, float inv_n2,
+                                                            int64_t n_elems, float *__restrict__ dmu,
+                                                            float *__restrict__ dls)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const float gk = (gkl_dev ? *gkl_dev : 1.0f) * inv_n2;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
+        const float m = mu[e], l = ls[e], s = __expf(l);
+        const float g = dz ? dz[e] : 0.f;
+        dmu[e] = fmaf(gk, m, g);
+        dls[e] = fmaf(g * eps[e], s, gk * (s * s - 1.0f));
+    }
+}
+
 } // namespace
 
 namespace gae {
@@ -772,5 +861,58 @@ extern "C" int gae_decoder_dense_bwd(const float *G, int64_t ldg, const float *Z
     hipLaunchKernelGGL(reduce_slots_transposed_kernel, dim3(unsigned(g)), dim3(256), 0, s, partial, pl.n_slots, d, n,
                        dZ, lddz, mask, ldz);
     GAE_CHECK_LAUNCH("reduce_slots_transposed_kernel");
+    return GAE_OK;
+}
+
+extern "C" int gae_normal_noise(float *out, int64_t n_elems, uint64_t seed, uint64_t offset, const uint64_t *draw_dev,
+                                void *stream)
+{
+    GAE_REQUIRE(n_elems >= 0, GAE_E_SIZE, "gae_normal_noise: negative size");
+    if (n_elems == 0) return GAE_OK;
+    GAE_REQUIRE(out, GAE_E_NULL, "gae_normal_noise: out is NULL");
+    int64_t g = ((n_elems + 3) / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(normal_noise_kernel, dim3(unsigned(g)), dim3(256), 0, gae::as_stream(stream), out, n_elems, seed,
+                       offset, draw_dev);
+    GAE_CHECK_LAUNCH("normal_noise_kernel");
+    return GAE_OK;
+}
+
+static int vgae_blocks(int64_t n_elems)
+{
+    int64_t g = (n_elems + 255) / 256;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    return int(g);
+}
+
+extern "C" int64_t gae_vgae_head_workspace_bytes(int64_t n_elems) { return n_elems < 0 ? GAE_E_SIZE : 1024 * 8 + 256; }
+
+extern "C" int gae_vgae_head_fwd(const float *mu, const float *logstd, const float *eps, int64_t n, int64_t d,
+                                 float *z, float *kl_out, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    GAE_REQUIRE(n > 0 && d > 0, GAE_E_SIZE, "gae_vgae_head_fwd: n and d must be positive");
+    GAE_REQUIRE(mu && logstd && eps && z && kl_out && workspace, GAE_E_NULL, "gae_vgae_head_fwd: NULL pointer");
+    GAE_REQUIRE(workspace_bytes >= 1024 * 8, GAE_E_WORKSPACE, "gae_vgae_head_fwd: workspace too small");
+    hipStream_t s = gae::as_stream(stream);
+    const int g = vgae_blocks(n * d);
+    double *partial = static_cast<double *>(workspace);
+    hipLaunchKernelGGL(vgae_head_fwd_kernel, dim3(g), dim3(256), 0, s, mu, logstd, eps, n * d, z, partial);
+    GAE_CHECK_LAUNCH("vgae_head_fwd_kernel");
+    // KL = -(0.5 / N) * (1 / N) * sum_ij (...)
+    hipLaunchKernelGGL(vgae_kl_finalize_kernel, dim3(1), dim3(256), 0, s, partial, g, -0.5 / (double(n) * double(n)),
+                       kl_out);
+    GAE_CHECK_LAUNCH("vgae_kl_finalize_kernel");
+    return GAE_OK;
+}
+
+extern "C" int gae_vgae_head_bwd(const float *dz, const float *mu, const float *logstd, const float *eps,
+                                 const float *gkl_dev, int64_t n, int64_t d, float *dmu, float *dlogstd, void *stream)
+{
+    GAE_REQUIRE(n > 0 && d > 0, GAE_E_SIZE, "gae_vgae_head_bwd: n and d must be positive");
+    GAE_REQUIRE(mu && logstd && eps && dmu && dlogstd, GAE_E_NULL, "gae_vgae_head_bwd: NULL pointer");
+    hipLaunchKernelGGL(vgae_head_bwd_kernel, dim3(vgae_blocks(n * d)), dim3(256), 0, gae::as_stream(stream), dz, mu,
+                       logstd, eps, gkl_dev, float(1.0 / (double(n) * double(n))), n * d, dmu, dlogstd);
+    GAE_CHECK_LAUNCH("vgae_head_bwd_kernel");
     return GAE_OK;
 }

@@ -46,6 +46,8 @@ class NodeApplyModule(nn.Module):
     def forward(self, node):
         code = _act_code(self.activation)
         x = node.data['h']
+        if x.dtype != torch.float32:      # bf16-stored features: aggregation ran in bf16 storage / fp32 accumulate
+            x = x.float()
         if code is None:
             h = self.activation(ops.linear(x, self.linear.weight, self.linear.bias, ACT_IDENTITY))
         else:

@@ -280,6 +280,48 @@ def dropout_mask(shape, p, seed, offset=0, device="cuda", draw_counter=None):
     return mask
 
 
+def normal_noise(shape, seed, offset=0, device="cuda", draw_counter=None):
+    """eps ~ N(0, 1) from the library's Philox + Box-Muller generator (VGAE reparameterisation)"""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    with _on_device(out.device):
+        _lib.call("gae_normal_noise", _ptr(out), out.numel(), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
+                  _ptr(draw_counter), _stream())
+    return out
+
+
+class VGAEHeadFunction(torch.autograd.Function):
+    """z = mu + eps exp(logstd) and the KL term of Kipf & Welling's VGAE, fused (gae_vgae_head_fwd / _bwd)"""
+
+    @staticmethod
+    def forward(ctx, mu, logstd, eps):
+        mu = _gpu(mu, "mu").contiguous(); logstd = logstd.contiguous(); eps = eps.contiguous()
+        n, d = mu.shape
+        z = torch.empty_like(mu)
+        kl = torch.empty(1, dtype=torch.float32, device=mu.device)
+        with _on_device(mu.device):
+            ws = _workspace(_lib.load().gae_vgae_head_workspace_bytes(n * d), mu.device)
+            _lib.call("gae_vgae_head_fwd", _ptr(mu), _ptr(logstd), _ptr(eps), n, d, _ptr(z), _ptr(kl), _ptr(ws),
+                      ws.numel(), _stream())
+        ctx.save_for_backward(mu, logstd, eps)
+        return z, kl.reshape(())
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        mu, logstd, eps = ctx.saved_tensors
+        n, d = mu.shape
+        dmu = torch.empty_like(mu); dls = torch.empty_like(mu)
+        dz = None if dz is None else dz.contiguous()
+        gkl = (torch.zeros(1, device=mu.device) if dkl is None else dkl.reshape(1).float().contiguous())
+        with _on_device(mu.device):
+            _lib.call("gae_vgae_head_bwd", _ptr(dz), _ptr(mu), _ptr(logstd), _ptr(eps), _ptr(gkl), n, d, _ptr(dmu),
+                      _ptr(dls), _stream())
+        return dmu, dls, None
+
+
+def vgae_head(mu, logstd, eps):
+    return VGAEHeadFunction.apply(mu, logstd, eps)
+
+
 def decoder_dense_raw(Z, mask=None):
     Z, ldz = _rowmajor(Z, "Z")
     if mask is not None:

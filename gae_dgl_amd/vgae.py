@@ -1,0 +1,62 @@
+"""Variational graph auto-encoder (BASELINE config 5).  The reference only
+cites the paper (README.md:58, Kipf & Welling 2016); this follows the paper
+with the reference's building blocks: a shared GCN layer (ReLU), two GCN heads
+with identity activation for mu and log(sigma), z = mu + eps * exp(log sigma),
+loss = weighted BCE reconstruction (the fused decoder+BCE kernel, identical to
+GAE's) + KL = -(0.5 / N) * mean_i sum_j (1 + 2 log sigma - mu^2 - sigma^2).
+
+Feature storage may be bf16 (``g.ndata['h']`` in torch.bfloat16): the
+layer-1 aggregation then runs the bf16-storage / fp32-accumulate SpMM."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .gae import GCN, InnerProductDecoder, identity
+
+
+class VGAE(nn.Module):
+    def __init__(self, in_dim, hidden_dims=(32, 16), *, norm=None, seed=None):
+        super().__init__()
+        h0, d = int(hidden_dims[0]), int(hidden_dims[-1])
+        self.shared = GCN(in_dim, h0, F.relu, norm)
+        self.mu_head = GCN(h0, d, identity, norm)
+        self.logstd_head = GCN(h0, d, identity, norm)
+        self.decoder = InnerProductDecoder(activation=identity, dropout=0.0)
+        self.seed = seed
+        self._draws = None
+        self.eps = None          # inject a fixed noise tensor for tests; None = draw from the library RNG
+        self.last = {}
+
+    def encode(self, g):
+        h = self.shared(g, g.ndata['h'])
+        mu = self.mu_head(g, h)
+        logstd = self.logstd_head(g, h)
+        return mu, logstd
+
+    def _noise(self, like):
+        if self.eps is not None:
+            return self.eps
+        if self._draws is None or self._draws.device != like.device:
+            self._draws = torch.zeros(1, dtype=torch.int64, device=like.device)
+        seed = self.seed if self.seed is not None else int(torch.initial_seed())
+        eps = ops.normal_noise(tuple(like.shape), seed, 0, like.device, draw_counter=self._draws)
+        self._draws += 1
+        return eps
+
+    def loss(self, g):
+        """reconstruction BCE (train_inductive.py:44-48 semantics, fused) + KL"""
+        mu, logstd = self.encode(g)
+        eps = self._noise(mu)
+        z, kl = ops.vgae_head(mu, logstd, eps)
+        g.ndata['h'] = z
+        rec = self.decoder.loss(z, g)
+        self.last = {"mu": mu, "logstd": logstd, "eps": eps, "z": z, "kl": kl, "rec": rec}
+        return rec + kl
+
+    def forward(self, g):
+        """sampled Z Z^T logits (dense parity / inference path)"""
+        mu, logstd = self.encode(g)
+        z, _ = ops.vgae_head(mu, logstd, self._noise(mu))
+        g.ndata['h'] = z
+        return self.decoder(z)

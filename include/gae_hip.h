@@ -191,6 +191,21 @@ int gae_decoder_dense_bwd(const float *G, int64_t ldg, const float *Z, const flo
                           int64_t ldz, int64_t n, int64_t d, float *dZ, int64_t lddz,
                           void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- VGAE head (BASELINE config 5; not in the reference: README.md:58 only cites Kipf & Welling 2016) ----
+ * gae_normal_noise : eps ~ N(0,1), Philox4x32-10 + Box-Muller, same (seed, offset, draw_dev) contract as
+ *                    gae_dropout_mask.
+ * gae_vgae_head_fwd: z = mu + eps * exp(logstd);  kl_out = -(0.5/N) * mean_i sum_j (1 + 2 logstd - mu^2 -
+ *                    exp(2 logstd))   (one fp32 on the device); mu/logstd/eps/z contiguous [n, d].
+ * gae_vgae_head_bwd: dmu = dz + gkl * dKL/dmu, dlogstd = dz * eps * exp(logstd) + gkl * dKL/dlogstd, with
+ *                    gkl = *gkl_dev (upstream gradient of the KL scalar; NULL = 1), dz may be NULL (= 0). */
+int gae_normal_noise(float *out, int64_t n_elems, uint64_t seed, uint64_t offset, const uint64_t *draw_dev,
+                     void *stream);
+int64_t gae_vgae_head_workspace_bytes(int64_t n_elems);
+int gae_vgae_head_fwd(const float *mu, const float *logstd, const float *eps, int64_t n, int64_t d,
+                      float *z, float *kl_out, void *workspace, int64_t workspace_bytes, void *stream);
+int gae_vgae_head_bwd(const float *dz, const float *mu, const float *logstd, const float *eps,
+                      const float *gkl_dev, int64_t n, int64_t d, float *dmu, float *dlogstd, void *stream);
+
 /* ---- K7+K8+K9 fused: decoder + weighted BCE-with-logits, never materialising N x N
  * Replaces, for training, gae_dgl/train_inductive.py:44-51:
  *   adj = g.adjacency_matrix().to_dense(); pos_weight = (N^2 - sum(adj)) / sum(adj)

@@ -464,3 +464,59 @@ def test_fused_loss_equals_dense_path_large(dev):
     assert rel_err(Z2.grad, Z1.grad) < 5 * TOL
     l2 = ops.decoder_bce(Z.clone().requires_grad_(True), mask, gr)
     assert torch.equal(l2, loss.detach())  # deterministic reductions
+
+
+# ----------------------------------------------------------------- VGAE (BASELINE config 5)
+def test_normal_noise_moments(dev):
+    from gae_dgl_amd import ops
+    e = ops.normal_noise((400000, 16), seed=3, device=dev)
+    assert abs(float(e.mean())) < 3e-3 and abs(float(e.std()) - 1.0) < 3e-3
+    assert abs(float((e ** 3).mean())) < 1e-2 and abs(float((e ** 4).mean()) - 3.0) < 3e-2
+    assert torch.equal(e, ops.normal_noise((400000, 16), seed=3, device=dev))
+    assert not torch.equal(e, ops.normal_noise((400000, 16), seed=4, device=dev))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_vgae_matches_oracle(dtype, tol, dev):
+    """Citeseer-shaped VGAE step (mu / logstd heads, sampled decoder, BCE + KL) vs the CPU restatement"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import workloads as W
+    from gae_dgl_amd.vgae import VGAE
+    n, src, dst, X = W.citation_graph("citeseer", seed=0)
+    n_small = 600                                          # oracle needs the dense N x N label
+    keep = (src < n_small) & (dst < n_small)
+    src, dst, X = src[keep], dst[keep], X[:n_small]
+    torch.manual_seed(0)
+    model = VGAE(X.shape[1], [32, 16], seed=11).to(dev)
+    g = G.DGLGraph((src, dst), num_nodes=n_small).to(dev)
+    Xd = torch.from_numpy(X).to(dev).to(dtype)
+    g.ndata['h'] = Xd
+    loss = model.loss(g)
+    loss.backward()
+    last = {k: v.detach().cpu() for k, v in model.last.items()}
+    # oracle on the SAME (bf16-rounded) inputs and the same eps
+    Xo = Xd.float().cpu()
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    ip, ix = O().csr_from_coo(src, dst, n_small)
+    mu, ls, z = O().vgae_forward(ip, ix, Xo, P["shared.apply_mod.linear.weight"], P["shared.apply_mod.linear.bias"],
+                                 P["mu_head.apply_mod.linear.weight"], P["mu_head.apply_mod.linear.bias"],
+                                 P["logstd_head.apply_mod.linear.weight"], P["logstd_head.apply_mod.linear.bias"],
+                                 last["eps"])
+    adj = O().dense_adjacency(src, dst, n_small)
+    rec = O().bce_with_logits_mean(z @ z.t(), adj, O().pos_weight_of(adj))
+    kl = O().vgae_kl(mu, ls)
+    (rec + kl).backward()
+    assert rel_err(last["mu"], mu) < tol and rel_err(last["logstd"], ls) < tol and rel_err(last["z"], z) < tol
+    assert rel_err(last["kl"], kl) < max(tol, 1e-5) and rel_err(last["rec"], rec) < max(tol, 1e-5)
+    assert rel_err(loss, rec + kl) < max(tol, 1e-5)
+    for k, p in model.named_parameters():
+        assert rel_err(p.grad, P[k].grad) < 10 * tol, k
+    # a few Adam steps reduce the loss
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    first = None
+    for _ in range(20):
+        g.ndata['h'] = Xd
+        l = model.loss(g)
+        opt.zero_grad(); l.backward(); opt.step()
+        first = float(l.detach()) if first is None else first
+    assert float(l.detach()) < first
