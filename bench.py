@@ -55,7 +55,12 @@ def parse():
                          "N x N logits/labels with torch BCE")
     ap.add_argument("--rmat-scale", type=int, default=24)
     ap.add_argument("--batch-graphs", type=int, default=4096)
-    ap.add_argument("--exchange", choices=["allgather", "boundary"], default="allgather")
+    ap.add_argument("--exchange", choices=["allgather", "boundary"], default="boundary",
+                    help="rmat: rows exchanged before each SpMM -- boundary = all-to-all-v of the remote rows a rank's "
+                         "block references (RMAT s24 / 8 ranks: 7-31 %% of the all-gather volume), allgather = all rows")
+    ap.add_argument("--balance", choices=["rows", "nnz"], default="nnz",
+                    help="rmat: row blocks of equal row count or of equal edge count (RMAT puts 44 %% of the edges "
+                         "into the first of 8 equal row blocks)")
     ap.add_argument("--no-hipgraph", action="store_true",
                     help="citation workloads: launch the step eagerly.  Default: the timed steps replay the step as "
                          "one captured HIP graph (the ~30 launches are host-bound otherwise); HIP events cannot be "
@@ -216,7 +221,8 @@ class RmatShardedWorkload:
         n = 1 << scale
         src, dst = W.rmat_edges(scale, 16, seed=0, device=dev)               # same list on every rank (seeded)
         E = int(src.numel())
-        self.sg = ShardedGraph(n, src, dst, rank=rank, world=world, group=group, mode=args.exchange, device=dev)
+        self.sg = ShardedGraph(n, src, dst, rank=rank, world=world, group=group, mode=args.exchange, device=dev,
+                               balance=args.balance)
         del src, dst
         for w in ("fwd", "bwd"):
             self.sg.csr(w); self.sg.plan(w)
@@ -237,6 +243,7 @@ class RmatShardedWorkload:
         e_local = int(ix.numel())
         self.meta = {"workload": f"rmat-s{scale}-ef16-row-sharded-encoder", "n_nodes": n, "n_edges": E, "in_dim": F,
                      "hidden_dims": hidden, "parallelism": f"row-shard x{world}", "exchange": args.exchange,
+                     "balance": args.balance,
                      "exchange_bytes_per_spmm_per_rank": self.sg.exchange_bytes(F),
                      "decoder": "excluded (O(N^2) = 2.8e14 logits at N = 2^24); synthetic dZ",
                      "local_rows": p.n_local, "local_edges_fwd": e_local}
@@ -399,11 +406,18 @@ def main():
         del wl
         torch.cuda.empty_cache()
         line["extra"] = {"spmm_kernel_only": extras(dev)}
-    print(json.dumps(line))
     if dist.is_initialized():
         if world > 1:
             dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio; flush it first so the JSON line is the LAST line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

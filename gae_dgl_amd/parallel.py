@@ -31,6 +31,18 @@ def block_bounds(n, world):
     return np.minimum(np.arange(world + 1, dtype=np.int64) * b, n)
 
 
+def nnz_balanced_bounds(n, src, dst, world):
+    """contiguous row blocks with (almost) equal in+out edge counts: power-law graphs put most edges on
+    few rows, so equal ROW blocks would leave one rank with half of the work (RMAT s24, 8 ranks: 44 %)."""
+    src = torch.as_tensor(src).to(torch.int64).reshape(-1); dst = torch.as_tensor(dst).to(torch.int64).reshape(-1)
+    w = torch.bincount(dst, minlength=n) + torch.bincount(src, minlength=n) + 1      # +1: rows cost something too
+    c = torch.cumsum(w, 0)
+    targets = (torch.arange(1, world, device=c.device, dtype=torch.float64) * (float(c[-1]) / world)).to(c.dtype)
+    cuts = torch.searchsorted(c, targets).clamp(max=n).cpu().numpy().astype(np.int64)
+    b = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    return np.maximum.accumulate(b)
+
+
 class LocalGroup:
     """Single-process stand-in for a process group: `world` virtual ranks whose
     blocks live in one process (validates the sharded kernels and the
@@ -50,13 +62,17 @@ class RowPartition:
     """Host-side plan of one rank's share of a graph (pure index bookkeeping,
     torch ops on whatever device the edge list lives on)."""
 
-    def __init__(self, n, src, dst, rank, world, mode="allgather"):
-        assert mode in ("allgather", "boundary")
+    def __init__(self, n, src, dst, rank, world, mode="allgather", balance="rows"):
+        assert mode in ("allgather", "boundary") and balance in ("rows", "nnz")
         self.n, self.rank, self.world, self.mode = int(n), int(rank), int(world), mode
-        self.bounds = block_bounds(self.n, self.world)
+        self.bounds = block_bounds(self.n, self.world) if balance == "rows" else \
+            nnz_balanced_bounds(self.n, src, dst, self.world)
         self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
         self.n_local = self.r1 - self.r0
-        self.block = int(self.bounds[1] - self.bounds[0]) if world > 0 else self.n
+        sizes = np.diff(self.bounds)
+        # equal blocks (the last may be short) allow one all_gather_into_tensor on a padded buffer
+        self.block = int(sizes[0]) if world > 0 else self.n
+        self.uniform = bool(np.all(sizes[:-1] == self.block) and sizes[-1] <= self.block)
         src = torch.as_tensor(src).to(torch.int64).reshape(-1)
         dst = torch.as_tensor(dst).to(torch.int64).reshape(-1)
         fwd = (dst >= self.r0) & (dst < self.r1)        # in-edges of my rows  -> A_p   (rows dst, cols src)
@@ -87,13 +103,15 @@ class RowPartition:
 
     @property
     def padded_n(self):
-        return self.block * self.world
+        """rows of the assembled matrix an exchange returns in all-gather mode"""
+        return self.block * self.world if self.uniform else self.n
 
 
 class ShardedGraph:
     """One rank's row block with its device CSRs and the exchange plan."""
 
-    def __init__(self, n, src, dst, rank=None, world=None, group=None, mode="allgather", device=None):
+    def __init__(self, n, src, dst, rank=None, world=None, group=None, mode="allgather", device=None,
+                 balance="rows"):
         if isinstance(group, LocalGroup):
             assert rank is not None
             world = group.world
@@ -101,7 +119,7 @@ class ShardedGraph:
             rank = dist.get_rank(group) if rank is None else rank
             world = dist.get_world_size(group) if world is None else world
         self.group = group
-        self.part = RowPartition(n, src, dst, rank, world, mode)
+        self.part = RowPartition(n, src, dst, rank, world, mode, balance)
         self.device = torch.device(device) if device is not None else torch.as_tensor(src).device
         self._csr = {}
         self._plan = {}
@@ -137,7 +155,8 @@ class ShardedGraph:
         p = self.part
         for k in ("fwd", "bwd"):
             need = p.need[k]
-            owner = torch.div(need, p.block, rounding_mode="floor")
+            ends = torch.as_tensor(p.bounds[1:], device=need.device)
+            owner = torch.searchsorted(ends, need, right=True)
             counts = torch.bincount(owner, minlength=p.world).to(torch.int64)
             if isinstance(self.group, LocalGroup):
                 self._a2a[k] = dict(need=need, recv_counts=counts.tolist())
@@ -161,16 +180,12 @@ class ShardedGraph:
             assert full is not None and torch.equal(full[p.r0:p.r1], h_local), "publish() the assembled matrix first"
             if p.mode == "allgather":
                 pad = p.padded_n - full.shape[0]
-                return full if pad == 0 else torch.cat([full, full.new_zeros(pad, F)])
+                return full if pad <= 0 else torch.cat([full, full.new_zeros(pad, F)])
             rem = full.index_select(0, self._a2a[which]["need"].to(full.device))
             nb = p.n_before[which]
             return torch.cat([rem[:nb], h_local, rem[nb:]])
         if p.mode == "allgather":
-            pad = p.block - p.n_local
-            mine = h_local if pad == 0 else torch.cat([h_local, h_local.new_zeros(pad, F)])
-            full = h_local.new_empty(p.padded_n, F)
-            dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group)
-            return full
+            return self.allgather_rows(h_local)
         a = self._a2a[which]
         send = h_local.index_select(0, a["send_idx"].to(h_local.device))
         recv = h_local.new_empty(sum(a["recv_counts"]), F)
@@ -185,11 +200,21 @@ class ShardedGraph:
         if isinstance(self.group, LocalGroup):
             full = self.group.full
             pad = p.padded_n - full.shape[0]
-            return full if pad == 0 else torch.cat([full, full.new_zeros(pad, full.shape[1])])
-        pad = p.block - p.n_local
-        mine = t_local if pad == 0 else torch.cat([t_local, t_local.new_zeros(pad, t_local.shape[1])])
-        full = t_local.new_empty(p.padded_n, t_local.shape[1])
-        dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group)
+            return full if pad <= 0 else torch.cat([full, full.new_zeros(pad, full.shape[1])])
+        if p.uniform:
+            pad = p.block - p.n_local
+            mine = t_local if pad == 0 else torch.cat([t_local, t_local.new_zeros(pad, t_local.shape[1])])
+            full = t_local.new_empty(p.padded_n, t_local.shape[1])
+            dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group)
+            return full
+        # nnz-balanced (uneven) blocks: one broadcast per owner straight into its slice of the result
+        full = t_local.new_empty(p.n, t_local.shape[1])
+        full[p.r0:p.r1] = t_local
+        works = [dist.broadcast(full[int(p.bounds[q]):int(p.bounds[q + 1])], src=dist.get_global_rank(self.group, q)
+                                if self.group is not None else q, group=self.group, async_op=True)
+                 for q in range(p.world) if p.bounds[q + 1] > p.bounds[q]]
+        for w in works:
+            w.wait()
         return full
 
     def allreduce_sum(self, t):
@@ -201,7 +226,7 @@ class ShardedGraph:
         """bytes this rank RECEIVES per exchange"""
         p = self.part
         if p.mode == "allgather":
-            return (p.world - 1) * p.block * F * elem
+            return (p.n - p.n_local) * F * elem
         return int(p.need[which].numel()) * F * elem
 
     # ------------------------------------------------------------------ compute

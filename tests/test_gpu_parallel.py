@@ -23,7 +23,8 @@ def graph(seed=0, n=1500, e=20000, F=32):
 
 @pytest.mark.parametrize("world", [1, 3, 4])
 @pytest.mark.parametrize("mode", ["allgather", "boundary"])
-def test_virtual_ranks_spmm_fwd_bwd_bit_exact(world, mode):
+@pytest.mark.parametrize("balance", ["rows", "nnz"])
+def test_virtual_ranks_spmm_fwd_bwd_bit_exact(world, mode, balance):
     from gae_dgl_amd import ops
     from gae_dgl_amd.parallel import LocalGroup, ShardedGraph
     n, src, dst, X = graph()
@@ -35,7 +36,7 @@ def test_virtual_ranks_spmm_fwd_bwd_bit_exact(world, mode):
     grp = LocalGroup(world)
     outs, grads = [], []
     for r in range(world):
-        sg = ShardedGraph(n, src, dst, rank=r, group=grp, mode=mode, device=DEV)
+        sg = ShardedGraph(n, src, dst, rank=r, group=grp, mode=mode, device=DEV, balance=balance)
         p = sg.part
         h = X[p.r0:p.r1].clone().requires_grad_(True)
         grp.publish(X)
@@ -44,7 +45,7 @@ def test_virtual_ranks_spmm_fwd_bwd_bit_exact(world, mode):
         m.backward(dM[p.r0:p.r1])
         outs.append(m.detach()); grads.append(h.grad)
         if mode == "boundary" and world > 1:
-            assert sg.exchange_bytes(32) < (world - 1) * p.block * 32 * 4      # less than an all-gather
+            assert sg.exchange_bytes(32) < (n - p.n_local) * 32 * 4             # less than an all-gather
     assert torch.equal(torch.cat(outs), ref)
     assert torch.equal(torch.cat(grads), refb)
 

@@ -28,14 +28,14 @@ def make_graph(seed=0, n=101, e=700, F=7):
     return n, src.astype(np.int64), dst.astype(np.int64), X
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, q, balance="rows"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from gae_dgl_amd.parallel import ShardedGraph, allreduce_grads
         from oracle import gae_oracle as O
         n, src, dst, X = make_graph()
-        sg = ShardedGraph(n, torch.from_numpy(src), torch.from_numpy(dst), mode=mode, device="cpu")
+        sg = ShardedGraph(n, torch.from_numpy(src), torch.from_numpy(dst), mode=mode, device="cpu", balance=balance)
         p = sg.part
         # ---- forward: rows [r0, r1) of A X
         ip, ix = O.csr_from_coo(src, dst, n)
@@ -54,7 +54,9 @@ def _worker(rank, world, port, mode, q):
         assert torch.equal(O.spmm_csr(bip, bix, fullb), refb[p.r0:p.r1]), "backward rows differ"
         # ---- exchange volume bookkeeping
         if mode == "allgather":
-            assert full.shape[0] == p.padded_n and sg.exchange_bytes(7) == (world - 1) * p.block * 7 * 4
+            assert full.shape[0] == p.padded_n and sg.exchange_bytes(7) == (n - p.n_local) * 7 * 4
+            if balance == "nnz":
+                assert full.shape[0] == n
         else:
             assert full.shape[0] == p.n_local + p.need["fwd"].numel() < n
         # ---- replicated weights: dW = sum over row blocks (all-reduce)
@@ -81,13 +83,14 @@ def _worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["allgather", "boundary"])
-def test_row_sharded_exchange_world2(mode):
+@pytest.mark.parametrize("mode,balance", [("allgather", "rows"), ("boundary", "rows"), ("allgather", "nnz"),
+                                          ("boundary", "nnz")])
+def test_row_sharded_exchange_world2(mode, balance):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29610 + (0 if mode == "allgather" else 1) + (os.getpid() % 200) * 2
-    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    port = 29610 + ["allgather", "boundary"].index(mode) + 2 * ["rows", "nnz"].index(balance) + (os.getpid() % 200) * 4
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q, balance)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -99,8 +102,17 @@ def test_row_sharded_exchange_world2(mode):
 def test_partition_plan_covers_graph_exactly():
     """virtual ranks (no process group): the blocks tile the rows, every edge lands in exactly one
     forward block and one backward block, boundary remapping is consistent"""
-    from gae_dgl_amd.parallel import RowPartition, block_bounds
+    from gae_dgl_amd.parallel import RowPartition, block_bounds, nnz_balanced_bounds
     n, src, dst, _ = make_graph(seed=4, n=1000, e=9000)
+    for world in (2, 5):     # nnz-balanced blocks: contiguous, cover [0, n), edge counts within 2x of the mean
+        b = nnz_balanced_bounds(n, src, dst, world)
+        assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0)
+        w = np.bincount(dst, minlength=n) + np.bincount(src, minlength=n)
+        per = np.array([w[b[r]:b[r + 1]].sum() for r in range(world)])
+        assert per.max() <= 2.0 * per.mean() + w.max()
+        for r in range(world):
+            p = RowPartition(n, src, dst, r, world, "boundary", "nnz")
+            assert (p.r0, p.r1) == (b[r], b[r + 1])
     for world in (1, 2, 3, 8):
         b = block_bounds(n, world)
         assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0)
