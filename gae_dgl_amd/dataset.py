@@ -69,7 +69,7 @@ class DeviceGraphDataset(Dataset):
         self.edges_host = ip[gp[1:]] - ip[gp[:-1]]                       # edges per graph (in-edges)
         tp = self.t_indptr.cpu().numpy().astype(np.int64)
         self.t_edges_host = tp[gp[1:]] - tp[gp[:-1]]
-        self.feat = torch.as_tensor(feat).to(dev).contiguous()
+        self.feat = ops.pad_rows(torch.as_tensor(feat).to(dev))          # F = 39 stored with ld = 40
         maxdeg = max(int((self.indptr[1:] - self.indptr[:-1]).max()) if N else 0,
                      int((self.t_indptr[1:] - self.t_indptr[:-1]).max()) if N else 0)
         self.no_heavy_rows = maxdeg <= ops.SKEW_THRESHOLD

@@ -28,6 +28,18 @@ def _gpu(t, name):
     return t
 
 
+def pad_rows(t, multiple=None):
+    """view of ``t`` [N, F] inside a buffer whose rows are padded to 16 bytes (zero pad): gives every kernel the
+    aligned vector path for odd feature widths (F = 39, 1433, 3703)"""
+    q = multiple or (4 if t.dtype == torch.float32 else 8)
+    n, f = t.shape
+    if f % q == 0 and t.stride(1) == 1 and t.stride(0) % q == 0:
+        return t
+    buf = torch.zeros(n, (f + q - 1) // q * q, dtype=t.dtype, device=t.device)
+    buf[:, :f] = t
+    return buf[:, :f]
+
+
 def _rowmajor(t, name):
     """(tensor, ld) with unit inner stride; copies only when needed."""
     _gpu(t, name)
@@ -138,11 +150,13 @@ def batch_gather(graph_ptr, ds_indptr, ds_indices, ds_feat, graph_ids, node_ptr,
     dev = feat.device
     out_indptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
     out_indices = torch.empty(n_edges, dtype=torch.int32, device=dev)
-    out_feat = torch.empty(n_nodes, F, dtype=feat.dtype, device=dev)
+    q = 4 if feat.dtype == torch.float32 else 8
+    ldo = max((F + q - 1) // q * q, 1)                      # batch features keep 16-byte rows
+    out_feat = torch.empty(n_nodes, ldo, dtype=feat.dtype, device=dev)[:, :F]
     with _on_device(dev):
         _lib.call("gae_batch_gather", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_indices), _ptr(feat), ldf, F,
                   _dtype_code(feat), _ptr(graph_ids), graph_ids.numel(), _ptr(node_ptr), _ptr(edge_ptr),
-                  n_nodes, n_edges, _ptr(out_indptr), _ptr(out_indices), _ptr(out_feat), max(F, 1), _stream())
+                  n_nodes, n_edges, _ptr(out_indptr), _ptr(out_indices), _ptr(out_feat), ldo, _stream())
     return out_indptr, out_indices, out_feat
 
 
@@ -217,7 +231,9 @@ def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=Non
     _gpu(indptr, "indptr")
     n_cols, F = H.shape
     if out is None:
-        out = torch.empty(n_rows, F, dtype=H.dtype, device=H.device)
+        # rows padded to 16 bytes: keeps the 16-byte vector path for any F (the pad columns are never read as data)
+        q = 4 if H.dtype == torch.float32 else 8
+        out = torch.empty(n_rows, (F + q - 1) // q * q, dtype=H.dtype, device=H.device)[:, :F]
     out2, ldm = _rowmajor(out, "out")
     if out2 is not out:
         raise GaeHipError("spmm: `out` must be row-major with unit inner stride")

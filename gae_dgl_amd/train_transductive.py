@@ -48,7 +48,8 @@ def main(argv=None):
         os.makedirs(args.save_dir)
 
     data = load_data(args)
-    features = torch.FloatTensor(data.features).to(device)
+    from gae_dgl_amd import ops
+    features = ops.pad_rows(torch.FloatTensor(data.features).to(device))   # 16-byte rows for odd widths
     in_feats = features.shape[1]
 
     model = GAE(in_feats, args.hidden_dims, norm=args.norm).to(device)
