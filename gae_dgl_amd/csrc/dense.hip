@@ -22,6 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
 int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
+int g_atb_rows = 256;   // tuning knob: rows per block (= per partial) of the dW kernel; 4 waves x 64 rows
 
 // ---------------------------------------------------------------------------
 // out[n, J] = epi( proA(A)[n, K] * proB(B) )      B given as [J, K] (BT) or [K, J]
@@ -368,14 +369,19 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(
     const float *__restrict__ Q, int64_t ldq, int64_t n, int O, int I, int64_t rows_per_slot,
     float *__restrict__ partial, float *__restrict__ colsum_partial)
 {
-    static_assert(IT == 4, "lane j owns the 4 adjacent columns 4j..4j+3 of a 128-column group: one float4 per row");
+    // IT == 4: lane j owns the 4 adjacent columns 4j..4j+3 of a 128-column group (one float4 per row, tile t =
+    //          column 4j + t);  IT == 1: lane j owns column j of a 32-column group (narrow outputs).
+    static_assert(IT == 4 || IT == 1, "IT is 1 or 4");
+    static_assert(!QVEC || IT == 4, "the float4 path needs IT == 4");
+    __shared__ float red[3][IT * 16 * 64 + 64];     // waves 1..3 park their accumulators (+ column sums) here
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t slot = int64_t(blockIdx.x) * 4 + wave;
+    const int64_t slot = blockIdx.x;                 // one partial per BLOCK: its 4 waves split the slot's rows
     const int j = lane & 31, h = lane >> 5;
     const int o = blockIdx.z * 32 + j;
-    const int cb = blockIdx.y * 128 + 4 * j;   // tile t of this lane is column cb + t
-    const int64_t r_begin = slot * rows_per_slot;
-    int64_t r_end = r_begin + rows_per_slot;
+    const int cb = blockIdx.y * (IT * 32) + (IT == 4 ? 4 * j : j);   // tile t of this lane is column cb + t
+    const int64_t rows_per_wave = rows_per_slot / 4;                  // multiple of 8
+    const int64_t r_begin = slot * rows_per_slot + wave * rows_per_wave;
+    int64_t r_end = r_begin + rows_per_wave;
     if (r_end > n) r_end = n;
 
     f32x16 acc[IT];
@@ -391,8 +397,7 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(
     struct Stage { float a[4], m[4]; float b[4][IT]; };
     const int64_t r_last = r_end - 1;                       // r_begin < r_end whenever anything is loaded
     const int oc = o < O ? o : O - 1;
-    constexpr bool lane_cols_ok = QVEC;                     // I % 4 == 0: a lane's 4 columns are all valid or all invalid
-    const int cbc = lane_cols_ok ? (cb + 4 <= I ? cb : I - 4) : 0;
+    const int cbc = QVEC ? (cb + 4 <= I ? cb : I - 4) : 0;  // QVEC: I % 4 == 0, a lane's 4 columns are all in or all out
     auto load = [&](Stage &st, int64_t r0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(
             r = r < r_last ? r : r_last;
             st.a[u] = P[r * ldp + oc];
             if (PRO_P != PRO_NONE) st.m[u] = Pmask[r * ldpm + oc];
-            if (lane_cols_ok) {
+            if (QVEC) {
                 const float4 q4 = *reinterpret_cast<const float4 *>(Q + r * ldq + cbc);
                 st.b[u][0] = q4.x; st.b[u][1] = q4.y; st.b[u][2] = q4.z; st.b[u][3] = q4.w;
             } else {
@@ -427,7 +432,6 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(
             }
         }
     };
-    // 8 rows per stage, register double buffering: the next stage's loads are in flight during the MFMAs
     if (r_begin < r_end) {
         Stage s0, s1, s2;
         int64_t r0 = r_begin;
@@ -442,7 +446,27 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(
         }
 #undef GAE_PIN
     }
-    // partial[slot][O][I]; lane j holds columns cb..cb+3 of output row oo in acc[0..3][r]
+    // ---- block reduction in fixed wave order (0 + 1 + 2 + 3): waves 1..3 park, wave 0 adds and stores
+    csum += __shfl_down(csum, 32, 64);
+    if (wave > 0) {
+        float *rp = red[wave - 1];
+#pragma unroll
+        for (int t = 0; t < IT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rp[(t * 16 + r) * 64 + lane] = acc[t][r];
+        rp[IT * 16 * 64 + lane] = csum;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+        for (int t = 0; t < IT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += red[w][(t * 16 + r) * 64 + lane];
+        csum += red[w][IT * 16 * 64 + lane];
+    }
+    // partial[slot][O][I]; lane j holds columns cb..cb+IT-1 of output row oo in acc[0..IT-1][r]
     float *pp = partial + slot * int64_t(O) * I;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -450,17 +474,15 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(
         if (oo >= O) continue;
         float *dst = pp + int64_t(oo) * I + cb;
         if (QVEC && cb + 4 <= I) {
-            *reinterpret_cast<float4 *>(dst) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            *reinterpret_cast<float4 *>(dst) = make_float4(acc[0][r], acc[IT > 1 ? 1 : 0][r], acc[IT > 2 ? 2 : 0][r],
+                                                           acc[IT > 3 ? 3 : 0][r]);
         } else {
 #pragma unroll
             for (int t = 0; t < IT; ++t)
                 if (cb + t < I) dst[t] = acc[t][r];
         }
     }
-    if (colsum_partial && blockIdx.y == 0) {
-        csum += __shfl_down(csum, 32, 64);
-        if (h == 0 && o < O) colsum_partial[slot * O + o] = csum;
-    }
+    if (colsum_partial && blockIdx.y == 0 && h == 0 && o < O) colsum_partial[slot * O + o] = csum;
 }
 
 // out[e] = sum_slot partial[slot][e]  (+ optional accumulate into out, optional mask multiply).
@@ -520,21 +542,21 @@ struct AtbPlan {
     int64_t n_slots, rows_per_slot, blocks;
 };
 
-// shared by the workspace query and the launcher
+// shared by the workspace query and the launcher: one slot (= one partial) per block of 4 waves
 AtbPlan atb_plan(int64_t n, int64_t O, int64_t I)
 {
     AtbPlan p;
-    int64_t want = (n + 127) / 128;                  // ~128 rows per wave
+    int64_t want = (n + g_atb_rows - 1) / g_atb_rows;  // ~128 rows per block, 32 per wave
     int64_t cap = (int64_t(32) << 20) / (O * I > 0 ? O * I : 1);  // <= 128 MiB of partials
-    if (cap > 2048) cap = 2048;
-    if (cap < 4) cap = 4;
+    if (cap > 4096) cap = 4096;
+    if (cap < 1) cap = 1;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
-    p.blocks = (want + 3) / 4;
-    p.n_slots = p.blocks * 4;
+    p.blocks = want;
+    p.n_slots = want;
     int64_t rps = (n + p.n_slots - 1) / p.n_slots;
-    rps = (rps + 7) / 8 * 8;
-    if (rps < 8) rps = 8;
+    rps = (rps + 31) / 32 * 32;                      // 4 waves x a multiple of 8 rows
+    if (rps < 32) rps = 32;
     p.rows_per_slot = rps;
     return p;
 }
@@ -543,16 +565,18 @@ template <int PRO_P>
 int launch_atb(const float *P, int64_t ldp, const float *Pmask, int64_t ldpm, const float *Q, int64_t ldq,
                int64_t n, int O, int I, float *partial, float *colsum_partial, const AtbPlan &pl, hipStream_t s)
 {
-    constexpr int IT = 4;
-    const unsigned gy = I > 0 ? unsigned((I + IT * 32 - 1) / (IT * 32)) : 1u;  // I == 0: column sums only
+    const bool narrow = I <= 32;                     // one 32-column tile: no 4-tile float4 mapping needed
+    const int cols_per_block = narrow ? 32 : 128;
+    const unsigned gy = I > 0 ? unsigned((I + cols_per_block - 1) / cols_per_block) : 1u;  // I == 0: column sums only
     const dim3 grid(unsigned(pl.blocks), gy, unsigned((O + 31) / 32));
-    const bool qvec = (ldq % 4 == 0) && gae::aligned16(Q) && (I % 4 == 0) && I >= 4 && gae::aligned16(partial);
-    if (qvec)
-        hipLaunchKernelGGL((atb_partial_kernel<IT, PRO_P, true>), grid, dim3(256), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n,
-                           O, I, pl.rows_per_slot, partial, colsum_partial);
-    else
-        hipLaunchKernelGGL((atb_partial_kernel<IT, PRO_P, false>), grid, dim3(256), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n,
-                           O, I, pl.rows_per_slot, partial, colsum_partial);
+    const bool qvec = !narrow && (ldq % 4 == 0) && gae::aligned16(Q) && (I % 4 == 0) && I >= 4 && gae::aligned16(partial);
+#define GAE_ATB(IT, QV)                                                                                             \
+    hipLaunchKernelGGL((atb_partial_kernel<IT, PRO_P, QV>), grid, dim3(256), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n, O, \
+                       I, pl.rows_per_slot, partial, colsum_partial)
+    if (narrow) GAE_ATB(1, false);
+    else if (qvec) GAE_ATB(4, true);
+    else GAE_ATB(4, false);
+#undef GAE_ATB
     GAE_CHECK_LAUNCH("atb_partial_kernel");
     return GAE_OK;
 }
@@ -703,6 +727,7 @@ namespace gae {
 int *dense_knob(const char *name)
 {
     if (strcmp(name, "gemm_stream") == 0) return &g_gemm_stream;
+    if (strcmp(name, "atb_rows") == 0) return &g_atb_rows;
     return nullptr;
 }
 } // namespace gae
