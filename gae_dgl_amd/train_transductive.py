@@ -33,6 +33,9 @@ def build_parser():
     parser.add_argument('--norm', choices=['none', 'both'], default='none')
     parser.add_argument('--seed', type=int, default=None)
     parser.add_argument('--log_every', type=int, default=50)
+    parser.add_argument('--eval', action='store_true',
+                        help="hold out 5 %% / 10 %% of the edges (the reference's '# TODO: train test split', :35) and "
+                             "report link-prediction ROC-AUC / AP on them after training")
     return parser
 
 
@@ -56,7 +59,16 @@ def main(argv=None):
     model.train()
     optim = torch.optim.Adam(model.parameters(), lr=args.lr, fused=True)
 
-    g = DGLGraph(data.graph).to(device)
+    split = None
+    if args.eval:
+        from gae_dgl_amd import metrics
+        src, dst = (data.graph.src, data.graph.dst) if hasattr(data.graph, "src") else \
+            tuple(map(list, zip(*data.graph.edges())))
+        train, val, test = metrics.split_edges(src, dst, data.graph.number_of_nodes(), seed=args.seed or 0)
+        split = (val, test)
+        g = DGLGraph(train, num_nodes=data.graph.number_of_nodes()).to(device)
+    else:
+        g = DGLGraph(data.graph).to(device)
     # normalization (train_transductive.py:55-58) -- parameter independent, so once, not per epoch
     g.ndata['norm'] = g.norm().unsqueeze(1)
 
@@ -72,6 +84,14 @@ def main(argv=None):
         if epoch % args.log_every == 0 or epoch == args.n_epochs - 1:
             print('Epoch: {:02d} | Loss: {:.5f}'.format(epoch, float(loss.detach())))
     torch.save(model.state_dict(), os.path.join(args.save_dir, 'transductive_{}.pkl'.format(args.dataset)))
+    if split is not None:
+        g.ndata['h'] = features
+        with torch.no_grad():
+            Z = model.encode(g)
+        for name, sp in zip(("val", "test"), split):
+            m = metrics.evaluate(Z, sp)
+            print('{} ROC-AUC: {:.4f} | AP: {:.4f}'.format(name, m["auc"], m["ap"]))
+        main.last_eval = metrics.evaluate(Z, split[1])
     return [float(l) for l in losses]
 
 
