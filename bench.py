@@ -94,13 +94,16 @@ def time_launches(fn, iters=50, warmup=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def spmm_probe(indptr, indices, n, F, ld=None, plan=None, label="", iters=50):
-    """kernel-only SpMM throughput for one shape"""
+def spmm_probe(indptr, indices, n, F, ld=None, plan=None, label="", iters=50, blockdiag=None):
+    """kernel-only SpMM throughput for one shape (row-padded operands as every op of the package produces)"""
     from gae_dgl_amd import ops, workloads as W
     ld = ld or F
     H = torch.rand(n, ld, device=indptr.device)[:, :F]
     out = torch.empty(n, ld, device=indptr.device)[:, :F]
-    t = time_launches(lambda: ops.spmm_raw(indptr, indices, H, n, out=out, plan=plan), iters=iters)
+    # 30 warm-up launches: the probes start on a GPU that idled during the host-side graph generation, and
+    # the first launches after an idle period run at ramping clocks
+    t = time_launches(lambda: ops.spmm_raw(indptr, indices, H, n, out=out, plan=plan, blockdiag=blockdiag,
+                                           out_padded=True), iters=iters, warmup=30)
     nnz = int(indices.numel())
     b = W.spmm_alg_bytes(n, n, nnz, F, 4)
     return {"shape": label, "n": n, "nnz": nnz, "F": F, "ld": ld, "dtype": "float32", "us_per_launch": t * 1e6,
@@ -144,7 +147,7 @@ class CitationWorkload:
         ip, ix = self.g.csr()
         out = ops.pad_rows(torch.empty(self.Xd.shape, device=self.dev))
         plan = self.g.spmm_plan(False)
-        return lambda: ops.spmm_raw(ip, ix, self.Xd, self.n, out=out, plan=plan)
+        return lambda: ops.spmm_raw(ip, ix, self.Xd, self.n, out=out, plan=plan, out_padded=True)
 
     def capture(self):
         from gae_dgl_amd.capture import CapturedTrainStep
@@ -215,8 +218,9 @@ class ZincWorkload:
         bg = self.ds.batch(self.perm[:self.B])
         ip, ix = bg.csr()
         H = bg.ndata['h']
-        out = torch.empty_like(H)
-        return lambda: ops.spmm_raw(ip, ix, H, bg.number_of_nodes(), out=out)
+        out = ops.pad_rows(torch.empty(H.shape, device=self.dev))
+        return lambda: ops.spmm_raw(ip, ix, H, bg.number_of_nodes(), out=out, out_padded=True,
+                                    blockdiag=bg.block_diag)
 
     def step(self):
         ids = self.perm[self.cursor:self.cursor + self.B]
@@ -300,8 +304,10 @@ def extras(dev):
     ipb, ixb = ip[:nb + 1].clone(), ix[:eb].clone()
     out.append(spmm_probe(ipb, ixb, nb, 39, ld=40, label="zinc-batch4096 layer1"))
     out.append(spmm_probe(ipb, ixb, nb, 32, label="zinc-batch4096 layer2"))
-    out.append(spmm_probe(ip, ix, N, 39, ld=40, label="zinc-250k whole set, one launch, layer1", iters=20))
-    out.append(spmm_probe(ip, ix, N, 32, label="zinc-250k whole set, one launch, layer2", iters=20))
+    bd = ops.BlockDiag(gptr, dev)     # whole molecules per thread block: LDS-staged block-diagonal kernel
+    out.append(spmm_probe(ip, ix, N, 39, ld=40, label="zinc-250k whole set, one launch, layer1", iters=20,
+                          blockdiag=bd))
+    out.append(spmm_probe(ip, ix, N, 32, label="zinc-250k whole set, one launch, layer2", iters=20, blockdiag=bd))
     del s, d, ip, ix
     torch.cuda.empty_cache()
     src, dst = W.rmat_edges(24, 16, device=dev)

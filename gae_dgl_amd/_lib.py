@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgae_hip.so")
 
 F32, BF16 = 0, 1
+SPMM_STORE_PAD = 1
 ACT_IDENTITY, ACT_RELU = 0, 1
 
 _i32, _i64, _u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
@@ -42,7 +43,10 @@ SIGNATURES = {
     "gae_spmm_plan_fill": (_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
     "gae_spmm_workspace_bytes": (_i64, [ctypes.POINTER(SpmmPlan), _i64]),
     "gae_spmm_csr": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _int, _p, _p,
-                            ctypes.POINTER(SpmmPlan), _p, _i64, _p]),
+                            ctypes.POINTER(SpmmPlan), _p, _i64, _int, _p]),
+    "gae_spmm_blockdiag_lds_bytes": (_i64, [_i64, _i64, _i64]),
+    "gae_spmm_csr_blockdiag": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _int,
+                                      _p]),
     "gae_linear_fwd": (_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p]),
     "gae_linear_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gae_linear_bwd": (_int, [_p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _i64, _i64,

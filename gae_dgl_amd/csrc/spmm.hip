@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
     const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t n_rows,
     const T *__restrict__ H, int64_t ldh, T *__restrict__ M, int64_t ldm, int F,
     const float *__restrict__ row_scale, const float *__restrict__ col_scale, unsigned n_row_blocks,
-    unsigned n_ftiles, int xcd_tiled, int skip_deg)
+    unsigned n_ftiles, int xcd_tiled, int skip_deg, int store_pad)
 {
     constexpr int GPB = 256 / LPR;            // groups per block
     constexpr int RPB = GPB * RPG;            // rows per block
@@ -302,7 +302,9 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
                 for (int i = 0; i < VEC; ++i) acc[r][c][i] *= rs;
             }
             const int f = f0 + c * TILE;
-            if (VEC == 1 || f + VEC <= F) {
+            // store_pad: M's rows are padded to a whole vector and the caller allows the pad columns to be
+            // overwritten -> the tail vector is written whole (full 16-byte stores, no partially written sectors)
+            if (VEC == 1 || f + VEC <= F || store_pad) {
                 if (NT_STORE) VecIO<T, VEC>::store_nt(mp + c * TILE, acc[r][c]);
                 else VecIO<T, VEC>::store(mp + c * TILE, acc[r][c]);
             } else {
@@ -324,8 +326,9 @@ int g_spmm_nb = 4;        // neighbour rows in flight per owned row for wide row
 template <typename T, int VEC, int LPR, int CH, int RPG>
 int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
                      int64_t ldm, int F, const float *rs, const float *cs, bool nt, bool tiled, int skip_deg,
-                     hipStream_t s)
+                     int flags, hipStream_t s)
 {
+    const int store_pad = ((flags & GAE_SPMM_STORE_PAD) && (F + VEC - 1) / VEC * VEC <= ldm) ? 1 : 0;
     constexpr int RPB = (256 / LPR) * RPG;
     const int nvec = (F + VEC - 1) / VEC;
     const unsigned nrb = unsigned((n_rows + RPB - 1) / RPB), nft = unsigned((nvec + LPR * CH - 1) / (LPR * CH));
@@ -333,7 +336,7 @@ int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_ro
     const int xt = tiled ? 1 : 0;
 #define GAE_L2(SC, NT, NBW)                                                                                         \
     hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, NT, NBW>), grid, dim3(256), 0, s, indptr,   \
-                       indices, n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, skip_deg)
+                       indices, n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, skip_deg, store_pad)
     if (LPR >= 16 && CH <= 2 && g_spmm_nb == 8) {   // wide rows: 8 neighbour rows in flight per owned row
         if (rs || cs) { if (nt) GAE_L2(true, true, 8); else GAE_L2(true, false, 8); }
         else { if (nt) GAE_L2(false, true, 8); else GAE_L2(false, false, 8); }
@@ -349,7 +352,7 @@ int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_ro
 template <typename T, int VEC>
 int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
                        int64_t ldm, int F, const float *rs, const float *cs, int rpg, bool nt, int64_t n_cols,
-                       int skip_deg, hipStream_t s)
+                       int skip_deg, int flags, hipStream_t s)
 {
     const int nvec = (F + VEC - 1) / VEC;
     bool tiled = false;
@@ -357,9 +360,9 @@ int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_
     do {                                                                                                          \
         if (rpg >= 2 && CH == 1)                                                                                  \
             return launch_rowgroup2<T, VEC, LPR, CH, 2>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt,   \
-                                                        tiled, skip_deg, s);                                      \
+                                                        tiled, skip_deg, flags, s);                               \
         return launch_rowgroup2<T, VEC, LPR, CH, 1>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt, tiled, \
-                                                    skip_deg, s);                                                 \
+                                                    skip_deg, flags, s);                                          \
     } while (0)
     // Wide rows whose per-tile slice of H fits one XCD's L2: feature-tiled XCD mapping.
     {
@@ -423,6 +426,98 @@ int dispatch_rowgroup(const int32_t *indptr, const int32_t *indices, int64_t n_r
     if (nvec <= 128) GAE_RG(64, 2);
     GAE_RG(64, 4);
 #undef GAE_RG
+}
+
+// ---------------------------------------------------------------------------
+// Block-diagonal graphs (batched molecules, dgl.batch of train_inductive.py:34): every thread block owns a run of
+// consecutive rows that is CLOSED under adjacency (whole member graphs), so all neighbour rows of its rows live in
+// the same contiguous slice of H.  The slice is streamed into LDS with perfectly coalesced 16-byte loads (every
+// HBM byte is read exactly once, whatever the row width: F = 39 / ld = 40 rows straddle 128-B lines and are
+// expensive to gather from L1/L2), the block's index slice is staged next to it, and the gathers run at LDS
+// speed.  Memory round trips per block: one for (H slice, indptr), one for the indices -- instead of three
+// dependent trips per row.  Sums stay in CSR order: bit-identical to the row-group kernel.
+// ---------------------------------------------------------------------------
+template <int LPR, bool SCALED, int TI>
+__global__ __launch_bounds__(256) void spmm_blockdiag_kernel(
+    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const int32_t *__restrict__ block_ptr,
+    const int32_t *__restrict__ block_eptr, const float *__restrict__ H, int64_t ldh, float *__restrict__ M,
+    int64_t ldm, int F, const float *__restrict__ row_scale, const float *__restrict__ col_scale, int max_rows,
+    int max_edges, int store_pad)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *tile = lds;                                              // [max_rows][ldh]
+    int32_t *iptr = reinterpret_cast<int32_t *>(lds + int64_t(max_rows) * ldh);   // [max_rows + 1]
+    int32_t *idx = iptr + ((max_rows + 1 + 3) & ~3);               // [max_edges]
+    constexpr int GPB = 256 / LPR;
+    const int tid = threadIdx.x, lig = tid % LPR, grp = tid / LPR;
+    // block descriptor (row run and its edge run: block_eptr[b] = indptr[block_ptr[b]], precomputed so that the
+    // index slice does not have to wait for the row pointers) -- wave-uniform scalar loads
+    const int r0 = block_ptr[blockIdx.x], r1 = block_ptr[blockIdx.x + 1];
+    const int32_t e0 = block_eptr[blockIdx.x], e1 = block_eptr[blockIdx.x + 1];
+    const int nr = r1 - r0;
+    const int ne = min(e1 - e0, max_edges);
+    // ---- one bulk round trip: H slice (contiguous nr * ldh floats), row pointers, neighbour ids (as LOCAL row
+    //      offsets).  Every load is issued (branch-free, clamped index) into registers BEFORE the first LDS
+    //      write: a plain `for (i = tid; i < n; i += 256) lds[i] = g[i]` is compiled to load / vmcnt(0) /
+    //      ds_write per iteration, i.e. one serialised HBM round trip per 4 KiB.
+    {
+        constexpr int EI = 4, PI = 2;                 // idx pieces (max_edges <= 1024), iptr pieces (rows <= 511)
+        const float4 *src = reinterpret_cast<const float4 *>(H + int64_t(r0) * ldh);
+        const int n4 = int(int64_t(nr) * ldh / 4);
+        float4 t4[TI];
+        int32_t pv[PI], iv[EI];
+#pragma unroll
+        for (int q = 0; q < TI; ++q) t4[q] = src[min(tid + 256 * q, n4 - 1)];
+#pragma unroll
+        for (int q = 0; q < PI; ++q) pv[q] = indptr[r0 + min(tid + 256 * q, nr)];
+#pragma unroll
+        for (int q = 0; q < EI; ++q) iv[q] = indices[e0 + min(tid + 256 * q, max(e1 - e0 - 1, 0))];
+        float4 *dst = reinterpret_cast<float4 *>(tile);
+#pragma unroll
+        for (int q = 0; q < TI; ++q)
+            if (tid + 256 * q < n4) dst[tid + 256 * q] = t4[q];
+#pragma unroll
+        for (int q = 0; q < PI; ++q)
+            if (tid + 256 * q <= nr) iptr[tid + 256 * q] = pv[q];
+#pragma unroll
+        for (int q = 0; q < EI; ++q)
+            if (tid + 256 * q < ne) idx[tid + 256 * q] = iv[q] - r0;
+    }
+    __syncthreads();
+    // ---- phase C: gather from LDS; group `grp` owns rows grp, grp + GPB, ...
+    const int f0 = lig * 4;
+    const bool lv = f0 < F;
+    for (int r = grp; r < nr; r += GPB) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int32_t s = iptr[r] - e0, e = iptr[r + 1] - e0;
+        for (int32_t k = s; k < e; ++k) {
+            const int j = k < ne ? idx[k] : indices[e0 + k] - r0;      // overflow edges: straight from global
+            if (lv) {
+                const float4 v = *reinterpret_cast<const float4 *>(tile + int64_t(j) * ldh + f0);
+                const float c = SCALED ? col_scale[r0 + j] : 1.f;
+                acc[0] = SCALED ? fmaf(c, v.x, acc[0]) : acc[0] + v.x;
+                acc[1] = SCALED ? fmaf(c, v.y, acc[1]) : acc[1] + v.y;
+                acc[2] = SCALED ? fmaf(c, v.z, acc[2]) : acc[2] + v.z;
+                acc[3] = SCALED ? fmaf(c, v.w, acc[3]) : acc[3] + v.w;
+            }
+        }
+        if (lv) {
+            if (SCALED) {
+                const float rs = row_scale[r0 + r];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] *= rs;
+            }
+            float *mp = M + int64_t(r0 + r) * ldm + f0;
+            if (f0 + 4 <= F || store_pad) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(f4{acc[0], acc[1], acc[2], acc[3]}, reinterpret_cast<f4 *>(mp));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (f0 + q < F) mp[q] = acc[q];
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -616,7 +711,7 @@ inline int plan_ldp(int64_t F) { return int((F + 3) / 4 * 4); }
 template <typename T, int VEC>
 int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols, const T *h, int64_t ldh,
              T *m, int64_t ldm, int f, const float *rs, const float *cs, bool vec, const gae_spmm_plan *plan,
-             void *workspace, hipStream_t s)
+             void *workspace, int flags, hipStream_t s)
 {
     const bool heavy = plan && plan->n_heavy > 0;
     const int skip = heavy ? plan->threshold : 0x7fffffff;
@@ -624,7 +719,7 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
     int rc;
     if (g_spmm_variant == 2 && f > min_f)
         rc = dispatch_rowgroup2<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, g_spmm_rpg,
-                                        g_spmm_nt != 0 && sizeof(T) == 4, n_cols, skip, s);
+                                        g_spmm_nt != 0 && sizeof(T) == 4, n_cols, skip, flags, s);
     else {
         GAE_REQUIRE(!heavy, GAE_E_RANGE, "gae_spmm_csr: a skew plan needs F > %d for this layout", min_f);
         rc = dispatch_rowgroup<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, s);
@@ -691,7 +786,7 @@ extern "C" int64_t gae_spmm_workspace_bytes(const gae_spmm_plan *plan, int64_t F
 extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                             const void *H, int64_t ldh, void *M, int64_t ldm, int64_t F, int dtype,
                             const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
-                            void *workspace, int64_t workspace_bytes, void *stream)
+                            void *workspace, int64_t workspace_bytes, int flags, void *stream)
 {
     GAE_REQUIRE(n_rows >= 0 && n_cols >= 0 && F >= 0, GAE_E_SIZE, "gae_spmm_csr: negative size");
     GAE_REQUIRE(F < (int64_t(1) << 24), GAE_E_SIZE, "gae_spmm_csr: F too large");
@@ -719,14 +814,80 @@ extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64
         const float *h = static_cast<const float *>(H);
         float *m = static_cast<float *>(M);
         const bool vec = (ldh % 4 == 0) && (ldm % 4 == 0) && gae::aligned16(H) && gae::aligned16(M);
-        if (vec) return run_spmm<float, 4>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, true, plan, workspace, s);
-        return run_spmm<float, 1>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, false, plan, workspace, s);
+        if (vec) return run_spmm<float, 4>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, true, plan, workspace, flags, s);
+        return run_spmm<float, 1>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, false, plan, workspace, flags, s);
     }
     const unsigned short *h = static_cast<const unsigned short *>(H);
     unsigned short *m = static_cast<unsigned short *>(M);
     const bool vec = (ldh % 8 == 0) && (ldm % 8 == 0) && gae::aligned16(H) && gae::aligned16(M);
-    if (vec) return run_spmm<unsigned short, 8>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, true, plan, workspace, s);
-    return run_spmm<unsigned short, 1>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, false, plan, workspace, s);
+    if (vec) return run_spmm<unsigned short, 8>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, true, plan, workspace, flags, s);
+    return run_spmm<unsigned short, 1>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, false, plan, workspace, flags, s);
+}
+
+extern "C" int64_t gae_spmm_blockdiag_lds_bytes(int64_t max_block_rows, int64_t max_block_edges, int64_t ldh)
+{
+    if (max_block_rows < 0 || max_block_edges < 0 || ldh < 0) return GAE_E_SIZE;
+    return max_block_rows * ldh * 4 + ((max_block_rows + 1 + 3) & ~int64_t(3)) * 4 + max_block_edges * 4;
+}
+
+extern "C" int gae_spmm_csr_blockdiag(const int32_t *indptr, const int32_t *indices, const int32_t *block_ptr,
+                                      const int32_t *block_eptr, int64_t n_blocks, int64_t max_block_rows,
+                                      int64_t max_block_edges,
+                                      int64_t n_rows, const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
+                                      const float *row_scale, const float *col_scale, int flags, void *stream)
+{
+    GAE_REQUIRE(n_blocks >= 0 && max_block_rows >= 0 && max_block_edges >= 0 && n_rows >= 0 && F >= 0, GAE_E_SIZE,
+                "gae_spmm_csr_blockdiag: negative size");
+    GAE_REQUIRE(F <= 256, GAE_E_RANGE, "gae_spmm_csr_blockdiag: F = %lld > 256 (use gae_spmm_csr)", (long long)F);
+    GAE_REQUIRE(ldh >= F && ldm >= F, GAE_E_SIZE, "gae_spmm_csr_blockdiag: leading dimension smaller than F");
+    GAE_REQUIRE((row_scale == nullptr) == (col_scale == nullptr), GAE_E_NULL,
+                "gae_spmm_csr_blockdiag: row_scale and col_scale must both be given or both be NULL");
+    if (n_blocks == 0 || n_rows == 0 || F == 0) return GAE_OK;
+    GAE_REQUIRE(indptr && block_ptr && block_eptr && H && M, GAE_E_NULL, "gae_spmm_csr_blockdiag: NULL pointer");
+    GAE_REQUIRE(ldh % 4 == 0 && ldm % 4 == 0 && gae::aligned16(H) && gae::aligned16(M), GAE_E_ALIGN,
+                "gae_spmm_csr_blockdiag: H / M rows must be 16-byte aligned (pad the leading dimension)");
+    const int64_t lds = gae_spmm_blockdiag_lds_bytes(max_block_rows, max_block_edges, ldh);
+    GAE_REQUIRE(lds <= 160 * 1024, GAE_E_RANGE, "gae_spmm_csr_blockdiag: block slice needs %lld B of LDS (> 160 KiB)",
+                (long long)lds);
+    hipStream_t s = gae::as_stream(stream);
+    const int nvec = int((F + 3) / 4);
+    const bool scaled = row_scale != nullptr;
+    const int store_pad = ((flags & GAE_SPMM_STORE_PAD) && (F + 3) / 4 * 4 <= ldm) ? 1 : 0;
+    // TI = 16-byte pieces of the H slice per thread (compile-time so that all loads are issued up front)
+    const int64_t n4max = max_block_rows * ldh / 4;
+    const int ti = n4max <= 2 * 256 ? 2 : n4max <= 4 * 256 ? 4 : n4max <= 8 * 256 ? 8 : n4max <= 16 * 256 ? 16 : 0;
+    GAE_REQUIRE(ti != 0 && max_block_rows <= 511 && max_block_edges <= 1024, GAE_E_RANGE,
+                "gae_spmm_csr_blockdiag: a block may hold at most 511 rows / 64 KiB of H / 1024 staged edges");
+#define GAE_BDL(LPR, SC, TI)                                                                                          \
+    do {                                                                                                               \
+        GAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_blockdiag_kernel<LPR, SC, TI>),               \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));                            \
+        hipLaunchKernelGGL((spmm_blockdiag_kernel<LPR, SC, TI>), dim3(unsigned(n_blocks)), dim3(256), size_t(lds), s,  \
+                           indptr, indices, block_ptr, block_eptr, H, ldh, M, ldm, int(F), row_scale, col_scale,       \
+                           int(max_block_rows), int(max_block_edges), store_pad);                                      \
+    } while (0)
+#define GAE_BDT(LPR, SC)                                                                                              \
+    do {                                                                                                               \
+        if (ti == 2) GAE_BDL(LPR, SC, 2);                                                                              \
+        else if (ti == 4) GAE_BDL(LPR, SC, 4);                                                                         \
+        else if (ti == 8) GAE_BDL(LPR, SC, 8);                                                                         \
+        else GAE_BDL(LPR, SC, 16);                                                                                     \
+    } while (0)
+#define GAE_BDG(LPR)                                                                                                  \
+    do {                                                                                                               \
+        if (scaled) GAE_BDT(LPR, true);                                                                                \
+        else GAE_BDT(LPR, false);                                                                                      \
+    } while (0)
+    if (nvec <= 4) GAE_BDG(4);
+    else if (nvec <= 8) GAE_BDG(8);
+    else if (nvec <= 16) GAE_BDG(16);
+    else if (nvec <= 32) GAE_BDG(32);
+    else GAE_BDG(64);
+#undef GAE_BDG
+#undef GAE_BDT
+#undef GAE_BDL
+    GAE_CHECK_LAUNCH("spmm_blockdiag_kernel");
+    return GAE_OK;
 }
 
 namespace gae { int *dense_knob(const char *name); int *bce_knob(const char *name); }

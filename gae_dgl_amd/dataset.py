@@ -97,7 +97,7 @@ class DeviceGraphDataset(Dataset):
         edge_ptr = np.zeros(B + 1, dtype=np.int64); np.cumsum(self.edges_host[gids], out=edge_ptr[1:])
         t_edge_ptr = np.zeros(B + 1, dtype=np.int64); np.cumsum(self.t_edges_host[gids], out=t_edge_ptr[1:])
         dev = self.device
-        plan = torch.from_numpy(np.concatenate([gids, node_ptr, edge_ptr, t_edge_ptr])).to(dev, non_blocking=True)
+        plan = torch.from_numpy(np.concatenate([gids, node_ptr, edge_ptr, t_edge_ptr])).to(dev)
         d_gids, d_np = plan[:B], plan[B:2 * B + 1]
         d_ep, d_tep = plan[2 * B + 1:3 * B + 2], plan[3 * B + 2:]
         nb, eb = int(node_ptr[-1]), int(edge_ptr[-1])
@@ -112,6 +112,7 @@ class DeviceGraphDataset(Dataset):
         g.ndata['h'] = feat
         g.batch_num_nodes = self.sizes_host[gids].tolist()
         g.no_heavy_rows = self.no_heavy_rows
+        g.block_diag = ops.BlockDiag(node_ptr, dev)     # whole molecules per thread block: LDS-staged SpMM
         return g
 
     # -------------------------------------------------------------- flat on-disk format

@@ -46,6 +46,7 @@ class Graph:
         self.norm_mode = "none"      # "none" = reference behaviour, "both" = D^-1/2 A D^-1/2
         self.batch_num_nodes = None  # node counts per member graph when built by batch()
         self.no_heavy_rows = False   # set by builders that know max degree <= ops.SKEW_THRESHOLD (skips the plan)
+        self.block_diag = None       # ops.BlockDiag of a batched graph: enables the LDS-staged block-diagonal SpMM
         self._cache = {}
         if graph_data is not None:
             self._init_from(graph_data, num_nodes)
@@ -252,4 +253,7 @@ def batch(graphs):
             bg.ndata[k] = torch.cat([g.ndata[k] for g in graphs], dim=0)
     bg.batch_num_nodes = counts.tolist()
     bg.norm_mode = graphs[0].norm_mode
+    if dev.type == "cuda":
+        from . import ops
+        bg.block_diag = ops.BlockDiag(offs, dev)      # member graphs are closed under adjacency
     return bg

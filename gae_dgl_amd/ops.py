@@ -225,8 +225,59 @@ def spmm_plan(indptr, threshold=None, segment=None):
     return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh)
 
 
-def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=None, plan=None):
-    """M = diag(row_scale) A diag(col_scale) H  (K1/K2)."""
+BLOCKDIAG_GRAPHS = 4          # member graphs per thread block of the block-diagonal kernel
+BLOCKDIAG_MIN_BLOCKS = 8192   # fewer blocks (a 4096-molecule batch has 1024) run faster on the row-group kernel
+BLOCKDIAG_MAX_EDGES = 1024    # index slice staged in LDS per block (more edges are read from global memory)
+
+
+class BlockDiag:
+    """row runs closed under adjacency (whole member graphs) for gae_spmm_csr_blockdiag.  The number of member
+    graphs per thread block follows the row width (about three rows per lane group: F = 39 -> 2 molecules,
+    F = 32 -> 4, F <= 16 -> 8); the cuts are built on first use and cached."""
+
+    def __init__(self, node_ptr_host, device, graphs_per_block=None):
+        import numpy as np
+        self.node_ptr = np.asarray(node_ptr_host, dtype=np.int64)
+        self.device = device
+        self.fixed = graphs_per_block
+        self.min_blocks = BLOCKDIAG_MIN_BLOCKS
+        self.max_edges = BLOCKDIAG_MAX_EDGES
+        self._cuts = {}
+        self._eptr = {}
+
+    def cuts(self, F):
+        """(block_ptr int32 device tensor, n_blocks, max_rows) for feature width F"""
+        import numpy as np
+        g = self.fixed or (2 if F > 32 else 4 if F > 16 else BLOCKDIAG_GRAPHS * 2)
+        if g not in self._cuts:
+            c = self.node_ptr[::g]
+            if c[-1] != self.node_ptr[-1]:
+                c = np.append(c, self.node_ptr[-1])
+            nb = len(c) - 1
+            self._cuts[g] = (torch.from_numpy(c.astype(np.int32)).to(self.device), nb,
+                             int(np.diff(c).max()) if nb else 0)
+        return self._cuts[g]
+
+    def eptr(self, indptr, block_ptr):
+        """edge offset of every block for this CSR (forward and transposed structures differ)"""
+        key = (indptr.data_ptr(), block_ptr.data_ptr())
+        if key not in self._eptr:
+            self._eptr[key] = indptr.index_select(0, block_ptr.to(torch.int64)).contiguous()
+        return self._eptr[key]
+
+    def usable(self, H, F, ldh, ldm):
+        if H.dtype != torch.float32 or F > 256 or ldh % 4 or ldm % 4 or len(self.node_ptr) < 2:
+            return False
+        _, nb, max_rows = self.cuts(F)
+        if nb < self.min_blocks or max_rows > 511 or max_rows * ldh > 16 * 256 * 4 or self.max_edges > 1024:
+            return False
+        return _lib.load().gae_spmm_blockdiag_lds_bytes(max_rows, self.max_edges, ldh) <= 160 * 1024
+
+
+def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=None, plan=None, blockdiag=None,
+             out_padded=False):
+    """M = diag(row_scale) A diag(col_scale) H  (K1/K2).  ``out_padded``: the caller's ``out`` is a view of a
+    row-padded buffer whose pad columns may be overwritten (always true for the buffer allocated here)."""
     H, ldh = _rowmajor(H, "H")
     _gpu(indptr, "indptr")
     n_cols, F = H.shape
@@ -234,9 +285,26 @@ def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=Non
         # rows padded to 16 bytes: keeps the 16-byte vector path for any F (the pad columns are never read as data)
         q = 4 if H.dtype == torch.float32 else 8
         out = torch.empty(n_rows, (F + q - 1) // q * q, dtype=H.dtype, device=H.device)[:, :F]
+        out_padded = True
+    flags = _lib.SPMM_STORE_PAD if out_padded else 0
     out2, ldm = _rowmajor(out, "out")
     if out2 is not out:
         raise GaeHipError("spmm: `out` must be row-major with unit inner stride")
+    if blockdiag is not None and n_rows == n_cols and H.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 \
+            and blockdiag.usable(H, F, ldh, ldm):
+        with _on_device(H.device):
+            block_ptr, n_blocks, max_rows = blockdiag.cuts(F)
+            eptr = blockdiag.eptr(indptr, block_ptr)
+
+            def launch_bd():
+                _lib.call("gae_spmm_csr_blockdiag", _ptr(indptr), _ptr(indices), _ptr(block_ptr), _ptr(eptr), n_blocks,
+                          max_rows, blockdiag.max_edges, n_rows, _ptr(H), ldh, _ptr(out), ldm, F, _ptr(row_scale),
+                          _ptr(col_scale), flags, _stream())
+            if profiler is not None:
+                profiler.wrap(("spmm", n_rows, n_cols, F, str(H.dtype)), launch_bd)
+            else:
+                launch_bd()
+        return out
     with _on_device(H.device):
         pc, ws, ws_bytes = None, None, 0
         if plan is not None:
@@ -246,7 +314,7 @@ def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=Non
 
         def launch():
             _lib.call("gae_spmm_csr", _ptr(indptr), _ptr(indices), n_rows, n_cols, _ptr(H), ldh, _ptr(out), ldm, F,
-                      _dtype_code(H), _ptr(row_scale), _ptr(col_scale), pc, _ptr(ws), ws_bytes, _stream())
+                      _dtype_code(H), _ptr(row_scale), _ptr(col_scale), pc, _ptr(ws), ws_bytes, flags, _stream())
         if profiler is not None:
             profiler.wrap(("spmm", n_rows, n_cols, F, str(H.dtype)), launch)
         else:
@@ -405,14 +473,16 @@ class SpMMFunction(torch.autograd.Function):
         indptr, indices = graph.csr()
         norm = graph.norm() if use_norm else None
         ctx.graph, ctx.use_norm = graph, use_norm
-        return spmm_raw(indptr, indices, H, graph.number_of_nodes(), norm, norm, plan=graph.spmm_plan(False))
+        return spmm_raw(indptr, indices, H, graph.number_of_nodes(), norm, norm, plan=graph.spmm_plan(False),
+                        blockdiag=graph.block_diag)
 
     @staticmethod
     def backward(ctx, dM):
         g = ctx.graph
         t_indptr, t_indices = g.csc()
         norm = g.norm() if ctx.use_norm else None
-        return spmm_raw(t_indptr, t_indices, dM, g.number_of_nodes(), norm, norm, plan=g.spmm_plan(True)), None, None
+        return spmm_raw(t_indptr, t_indices, dM, g.number_of_nodes(), norm, norm, plan=g.spmm_plan(True),
+                        blockdiag=g.block_diag), None, None
 
 
 class LinearFunction(torch.autograd.Function):

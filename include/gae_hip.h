@@ -147,10 +147,29 @@ int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t threshold,
 /* bytes of workspace gae_spmm_csr needs with this plan (0 without one) */
 int64_t gae_spmm_workspace_bytes(const gae_spmm_plan *plan_host, int64_t F);
 
+/* flags */
+#define GAE_SPMM_STORE_PAD 1 /* M's rows are padded to whole 16-byte vectors (ldm >= roundup(F)) and the caller
+                              * allows the pad columns [F, roundup(F)) to be overwritten: the tail vector of every
+                              * row is stored whole (F = 39: 575 -> 443 us on the ZINC set; partially written
+                              * 32-byte sectors are expensive) */
 int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                  const void *H, int64_t ldh, void *M, int64_t ldm, int64_t F, int dtype,
                  const float *row_scale, const float *col_scale,
-                 const gae_spmm_plan *plan_host, void *workspace, int64_t workspace_bytes, void *stream);
+                 const gae_spmm_plan *plan_host, void *workspace, int64_t workspace_bytes, int flags, void *stream);
+
+/* Block-diagonal form of the same product (the batched molecule graphs of gae_dgl/train_inductive.py:31-35):
+ * block_ptr[n_blocks + 1] (int32, device) cuts the rows into runs that are CLOSED under adjacency (whole member
+ * graphs; every column id of a run's rows lies inside the run).  One thread block streams its slice of H into
+ * LDS with coalesced 16-byte loads and gathers from there.  fp32, n_cols == n_rows, 16-byte aligned rows
+ * (ld % 4 == 0).  max_block_rows bounds a run's row count, max_block_edges the index slice staged in LDS (edges
+ * beyond it are read from global memory): gae_spmm_blockdiag_lds_bytes(...) <= 160 KiB.  Same CSR-order sums as
+ * gae_spmm_csr (bit-identical results). */
+int64_t gae_spmm_blockdiag_lds_bytes(int64_t max_block_rows, int64_t max_block_edges, int64_t ldh);
+int gae_spmm_csr_blockdiag(const int32_t *indptr, const int32_t *indices, const int32_t *block_ptr,
+                           const int32_t *block_eptr /* [n_blocks + 1] = indptr[block_ptr[.]] */,
+                           int64_t n_blocks, int64_t max_block_rows, int64_t max_block_edges, int64_t n_rows,
+                           const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
+                           const float *row_scale, const float *col_scale, int flags, void *stream);
 
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16

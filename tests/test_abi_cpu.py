@@ -41,9 +41,9 @@ def test_argument_errors_do_not_need_a_gpu():
     from gae_dgl_amd import _lib
     lib = _lib.load()
     # negative sizes / NULL pointers are rejected before any launch
-    rc = lib.gae_spmm_csr(None, None, -1, 0, None, 0, None, 0, 0, 0, None, None, None, None, 0, None)
+    rc = lib.gae_spmm_csr(None, None, -1, 0, None, 0, None, 0, 0, 0, None, None, None, None, 0, 0, None)
     assert rc == -2 and b"negative" in lib.gae_last_error()
-    rc = lib.gae_spmm_csr(None, None, 4, 4, None, 8, None, 8, 8, 7, None, None, None, None, 0, None)
+    rc = lib.gae_spmm_csr(None, None, 4, 4, None, 8, None, 8, 8, 7, None, None, None, None, 0, 0, None)
     assert rc == -4
     assert lib.gae_spmm_workspace_bytes(None, 32) == 0
     assert lib.gae_spmm_plan_count(None, 8, 0, 512, None, None) == -6

@@ -141,6 +141,31 @@ def test_spmm_skew_plan(F, dtype, thr, seg, dev):
     assert ops.spmm_plan(dip, threshold=10 ** 6) is None      # nothing heavy -> no plan
 
 
+@pytest.mark.parametrize("F,ld", [(32, 32), (39, 40), (16, 16), (8, 8), (130, 132)])
+@pytest.mark.parametrize("gpb", [1, 4, 16])
+def test_spmm_blockdiag_bit_identical(F, ld, gpb, dev):
+    """LDS-staged block-diagonal kernel == row-group kernel, bit for bit (same CSR-order sums)"""
+    from gae_dgl_amd import ops, workloads as W
+    gp, src, dst, _ = W.zinc_like(500, seed=F + gpb)
+    n = int(gp[-1])
+    ip, ix = ops.csr_from_coo(t(dst, dev), t(src, dev), n, n)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    H = torch.randn(n, ld, device=dev, generator=gen)[:, :F]
+    norm = ops.degree_norm(ip)[1]
+    bd = ops.BlockDiag(gp, dev, graphs_per_block=gpb)
+    bd.min_blocks = 0                                        # force the LDS-staged kernel at this small size
+    for sc in (None, norm):
+        ref = ops.spmm_raw(ip, ix, H, n, sc, sc)
+        out = ops.spmm_raw(ip, ix, H, n, sc, sc, blockdiag=bd)
+        assert torch.equal(out, ref)
+    assert ops.BlockDiag(gp, dev).cuts(F)[1] > 0           # width-dependent cuts
+    # index slice smaller than a block's edge count: overflow edges come from global memory
+    bd.max_edges = 16
+    assert torch.equal(ops.spmm_raw(ip, ix, H, n, blockdiag=bd), ops.spmm_raw(ip, ix, H, n))
+    # oracle
+    assert rel_err(ops.spmm_raw(ip, ix, H, n, blockdiag=bd), O().spmm_csr(ip.cpu().numpy(), ix.cpu().numpy(), H.cpu())) < TOL
+
+
 def test_spmm_padded_ld_and_views(dev):
     from gae_dgl_amd import ops
     rng = np.random.default_rng(1)
@@ -154,7 +179,9 @@ def test_spmm_padded_ld_and_views(dev):
     outp = torch.full((n, 40), 7.0, device=dev)
     ops.spmm_raw(t(ip, dev), t(ix, dev), Hp[:, :F], n, out=outp[:, :F])   # vector path, ld = 40
     assert rel_err(outp[:, :F], ref) < TOL
-    assert float((outp[:, F:] - 7.0).abs().max()) == 0.0                  # padding untouched
+    assert float((outp[:, F:] - 7.0).abs().max()) == 0.0                  # padding untouched (no STORE_PAD flag)
+    ops.spmm_raw(t(ip, dev), t(ix, dev), Hp[:, :F], n, out=outp[:, :F], out_padded=True)   # caller allows the pad
+    assert rel_err(outp[:, :F], ref) < TOL
     out = ops.spmm_raw(t(ip, dev), t(ix, dev), t(H, dev), n)              # scalar path, ld = 39
     assert rel_err(out, ref) < TOL
 

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--rmat-scale", type=int, default=22)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--no-plan", action="store_true")
+    ap.add_argument("--blockdiag", type=int, default=0, help="member graphs per block (0 = off) for the zinc shapes")
     ap.add_argument("--thr", type=int, default=64)
     ap.add_argument("--seg", type=int, default=512)
     ap.add_argument("--variants", default="v1:1:0,v2:1:0,v2:2:0,v2:1:1,v2:2:1")
@@ -68,6 +69,12 @@ def main():
         ip, ix = ops.csr_from_coo(dst, src, n, n)
         del src, dst
         shapes["rmat32"] = (ip, ix, n, 32, 32)
+    bdiag = {}
+    if any(s.startswith("zinc") for s in want) and args.blockdiag:
+        bdiag["zinc39"] = bdiag["zinc32"] = ops.BlockDiag(gp, dev, graphs_per_block=args.blockdiag)
+        bdiag["zincb39"] = bdiag["zincb32"] = ops.BlockDiag(gp[:4097], dev, graphs_per_block=args.blockdiag)
+        for b in bdiag.values():
+            b.min_blocks = 0
     plans = {}
     if "rmat32" in shapes and not args.no_plan:
         plans["rmat32"] = ops.spmm_plan(shapes["rmat32"][0], args.thr, args.seg)
@@ -93,13 +100,15 @@ def main():
             for (label, var, rpg, nt, tv, nbw) in variants:
                 knob("spmm_variant", var); knob("spmm_rpg", rpg); knob("spmm_nt", nt); knob("spmm_tile_vecs", tv)
                 knob("spmm_nb", nbw)
-                fn = lambda: ops.spmm_raw(ip, ix, H, n, out=out, plan=plans.get(sname))
+                fn = lambda: ops.spmm_raw(ip, ix, H, n, out=out, plan=plans.get(sname),
+                                          out_padded="sp" in label.split(":")[-1],
+                                          blockdiag=bdiag.get(sname) if "bd" in label.split(":")[-1] else None)
                 fn(); torch.cuda.synchronize()
                 if rnd == 0:
                     if ref is None:
                         ref = out.clone()
                     elif plans.get(sname) is None:
-                        assert torch.equal(out, ref), f"variant {label} differs on {sname}"
+                        assert torch.equal(out[:, :F], ref[:, :F]), f"variant {label} differs on {sname}"
                     continue
                 res[label].append(time_once(fn, iters))
         print(f"== {sname}: n={n} nnz={nnz} F={F} ld={ld} alg={alg/1e6:.1f} MB iters={iters}")
