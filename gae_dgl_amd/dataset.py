@@ -72,7 +72,7 @@ class DeviceGraphDataset(Dataset):
         self.feat = ops.pad_rows(torch.as_tensor(feat).to(dev))          # F = 39 stored with ld = 40
         maxdeg = max(int((self.indptr[1:] - self.indptr[:-1]).max()) if N else 0,
                      int((self.t_indptr[1:] - self.t_indptr[:-1]).max()) if N else 0)
-        self.no_heavy_rows = maxdeg <= ops.SKEW_THRESHOLD
+        self.no_heavy_rows = maxdeg <= ops.SKEW_MIN_MAXDEG      # same rule as ops.spmm_plan(auto): no plan, no sync
         self.ids = np.arange(len(gp) - 1, dtype=np.int64) if ids is None else np.asarray(ids, dtype=np.int64)
 
     # -------------------------------------------------------------- Dataset protocol
