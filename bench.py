@@ -81,7 +81,9 @@ def pmc_traffic(key):
 
 
 def time_launches(fn, iters=50, warmup=5):
-    """average duration of `fn`'s launches between one HIP event pair on the launch stream"""
+    """average duration of `fn`'s launches between one HIP event pair on the launch stream.  Short launches
+    (< 60 us) are replayed from a HIP graph holding `iters` copies: issued one by one from Python they are
+    bounded by the ~10 us host cost of a ctypes launch, not by the GPU."""
     for _ in range(warmup):
         fn()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -91,7 +93,25 @@ def time_launches(fn, iters=50, warmup=5):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters
+    t = e0.elapsed_time(e1) * 1e-3 / iters
+    if t < 60e-6:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(iters):
+                    fn()
+            g.replay()
+            torch.cuda.synchronize()
+            best = t
+            for _ in range(3):
+                e0.record(); g.replay(); e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) * 1e-3 / iters)
+            t = best
+        except Exception as ex:   # capture not possible (e.g. a collective inside): keep the eager figure
+            print(f"[bench] graph-replay timing unavailable: {ex}", file=sys.stderr)
+            torch.cuda.synchronize()
+    return t
 
 
 def spmm_probe(indptr, indices, n, F, ld=None, plan=None, label="", iters=50, blockdiag=None):
@@ -126,8 +146,8 @@ class CitationWorkload:
         self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-2,        # train_transductive.py:43
                                     fused=True, capturable=self.use_graph)   # one multi-tensor launch
         self.g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
-        self.Xd = ops.pad_rows(torch.from_numpy(X).to(dev))                  # rows padded to 16 B (F = 1433, 3703)
-        self.g.csr(); self.g.csc(); self.g.spmm_plan(False); self.g.spmm_plan(True)   # structure is static
+        self.Xd = ops.pad_rows(torch.from_numpy(X).to(dev))                  # rows padded to whole 128-B lines
+        self.g.csr(); self.g.csc(); self.g.spmm_plan(False); self.g.spmm_plan(True); self.g.scattered()   # static
         E = self.g.number_of_edges()
         self.edges_per_step = E * (2 * len(self.hidden) - 1)                   # L fwd + (L-1) bwd SpMM launches
         self.meta = {"workload": f"{name}-transductive-gae", "n_nodes": n, "n_edges": E, "in_dim": self.F_in,
@@ -147,7 +167,8 @@ class CitationWorkload:
         ip, ix = self.g.csr()
         out = ops.pad_rows(torch.empty(self.Xd.shape, device=self.dev))
         plan = self.g.spmm_plan(False)
-        return lambda: ops.spmm_raw(ip, ix, self.Xd, self.n, out=out, plan=plan, out_padded=True)
+        sc = self.Xd.shape[1] > ops.TILE_MIN_F and self.g.scattered()
+        return lambda: ops.spmm_raw(ip, ix, self.Xd, self.n, out=out, plan=plan, out_padded=True, scattered=sc)
 
     def capture(self):
         from gae_dgl_amd.capture import CapturedTrainStep

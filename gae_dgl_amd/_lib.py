@@ -10,6 +10,8 @@ LIB_PATH = os.path.join(HERE, "lib", "libgae_hip.so")
 
 F32, BF16 = 0, 1
 SPMM_STORE_PAD = 1
+SPMM_TILE = 2
+SPMM_ELL_WIDTH = 16
 ACT_IDENTITY, ACT_RELU = 0, 1
 
 _i32, _i64, _u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
@@ -24,7 +26,8 @@ class DeviceInfo(ctypes.Structure):
 
 class SpmmPlan(ctypes.Structure):
     _fields_ = [("threshold", _i32), ("segment_edges", _i32), ("n_heavy", _i64), ("n_segments", _i64),
-                ("heavy_rows", _p), ("heavy_seg_base", _p), ("seg_heavy", _p)]
+                ("heavy_rows", _p), ("heavy_seg_base", _p), ("seg_heavy", _p), ("ell", _p), ("ell_width", _i32),
+                ("reserved", _i32)]
 
 
 # name -> (restype, argtypes); mirrors include/gae_hip.h one to one
@@ -41,6 +44,7 @@ SIGNATURES = {
                                 _p, _p, _p, _i64, _p]),
     "gae_spmm_plan_count": (_int, [_p, _i64, _i32, _i32, _p, _p]),
     "gae_spmm_plan_fill": (_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
+    "gae_spmm_ell_build": (_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "gae_spmm_workspace_bytes": (_i64, [ctypes.POINTER(SpmmPlan), _i64]),
     "gae_spmm_csr": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _int, _p, _p,
                             ctypes.POINTER(SpmmPlan), _p, _i64, _int, _p]),

@@ -18,7 +18,7 @@ class CapturedTrainStep:
             if "capturable" in group and not group["capturable"]:
                 raise ValueError("build the optimizer with capturable=True to capture its step")
         # structure is static: build it outside the capture (CSR build sorts and reads back a status word)
-        graph.csr(); graph.csc(); graph.spmm_plan(False); graph.spmm_plan(True)
+        graph.csr(); graph.csc(); graph.spmm_plan(False); graph.spmm_plan(True); graph.scattered()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -184,17 +184,77 @@ __global__ __launch_bounds__(256) void spmm_rowgroup_kernel(
 //     are wave-uniform (SGPR) values.
 // Summation order is unchanged (CSR order), so results are bit-identical to v1.
 // ---------------------------------------------------------------------------
-template <typename T, int VEC, int LPR, int CH, int RPG, bool SCALED, bool NT_STORE, int NBW = 4>
+// One batch of the gather: NB neighbour rows per owned row, all issued before the first is consumed (predicated,
+// no serial tail), then added in slot order.
+template <typename T, int VEC, int LPR, int CH, int RPG, int NB, bool SCALED>
+__device__ __forceinline__ void gather_batch(const T *__restrict__ H, int64_t ldh, int f0, const bool (&live)[CH],
+                                             const int32_t (&j)[RPG][NB], const bool (&ev)[RPG][NB],
+                                             const float *__restrict__ col_scale, float (&acc)[RPG][CH][VEC])
+{
+    constexpr int TILE = LPR * VEC;
+    float v[RPG][NB][CH][VEC];
+    float cs[RPG][NB];
+#pragma unroll
+    for (int r = 0; r < RPG; ++r)
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (SCALED) cs[r][u] = ev[r][u] ? col_scale[j[r][u]] : 0.f;
+            const T *hp = H + int64_t(j[r][u]) * ldh + f0;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (ev[r][u] && live[c]) {
+                    VecIO<T, VEC>::load(hp + c * TILE, v[r][u][c]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v[r][u][c][i] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < RPG; ++r)
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+            if (ev[r][u]) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        acc[r][c][i] = SCALED ? fmaf(cs[r][u], v[r][u][c][i], acc[r][c][i]) : acc[r][c][i] + v[r][u][c][i];
+            }
+}
+
+// Markers of the packed neighbour table (gae_spmm_ell_build)
+constexpr int32_t kEllEmpty = -1;      // no neighbour in this slot
+constexpr int32_t kEllOverflow = -2;   // last slot: the row has more neighbours, continue from the CSR arrays
+constexpr int32_t kEllSkip = -3;       // slot 0: heavy row of the skew plan, produced by the segment kernels
+
+// ---------------------------------------------------------------------------
+// v2 "rowgroup2": same ownership (LPR lanes own RPG rows), but
+//   * neighbour ids are fetched by ONE coalesced load per group and batch (lane
+//     u of the group loads indices[pos + u]) and broadcast with ds_bpermute /
+//     readlane instead of every lane re-loading them;
+//   * the neighbour rows of a batch (up to NB per owned row, RPG rows) are all
+//     issued before the first is consumed, with predication instead of a
+//     serial tail loop: one HBM round trip per batch instead of one per edge;
+//   * for LPR == 64 the row, its edge range and the neighbour base addresses
+//     are wave-uniform (SGPR) values;
+//   * ELLW > 0: the first ELLW neighbours of every row come from the packed table
+//     ell[row][ELLW] -- ONE load replaces the dependent indptr -> indices chain
+//     (launches of a few 10 MB are bounded by that chain, not by bytes: Pubmed
+//     F = 500 21 -> 15 us); longer rows continue from the CSR arrays.
+// Summation order is unchanged (CSR order), so results are bit-identical to v1.
+// ---------------------------------------------------------------------------
+template <typename T, int VEC, int LPR, int CH, int RPG, bool SCALED, bool NT_STORE, int ELLW = 0>
 __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
     const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t n_rows,
     const T *__restrict__ H, int64_t ldh, T *__restrict__ M, int64_t ldm, int F,
     const float *__restrict__ row_scale, const float *__restrict__ col_scale, unsigned n_row_blocks,
-    unsigned n_ftiles, int xcd_tiled, int skip_deg, int store_pad)
+    unsigned n_ftiles, int xcd_tiled, int tile_w, int skip_deg, int store_pad, const int32_t *__restrict__ ell)
 {
     constexpr int GPB = 256 / LPR;            // groups per block
     constexpr int RPB = GPB * RPG;            // rows per block
     constexpr int TILE = LPR * VEC;
-    constexpr int NB = LPR >= NBW ? NBW : (LPR >= 4 ? 4 : LPR);    // neighbours per batch and row
+    constexpr int NB = LPR >= 4 ? 4 : LPR;    // neighbours per batch and row
     unsigned blk, ftile;
     if (xcd_tiled) {
         // Feature-tiled XCD mapping: XCD x (= blockIdx % 8) owns feature tiles x, x+8, ... and sweeps all
@@ -213,11 +273,11 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
     int grp = threadIdx.x / LPR;
     if (LPR == 64) grp = __builtin_amdgcn_readfirstlane(grp);
     const int glane0 = (threadIdx.x & 63) - lig;  // first lane of this group inside the wave
-    const int f0 = ftile * (CH * TILE) + lig * VEC;
+    const int f0 = ftile * tile_w + lig * VEC;    // tile_w = features per tile (= CH * TILE unless XCD-tiled)
 
     bool live[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) live[c] = (f0 + c * TILE) < F;
+    for (int c = 0; c < CH; ++c) live[c] = (lig * VEC + c * TILE) < tile_w && (f0 + c * TILE) < F;
 
     int64_t row[RPG];
     int32_t pos[RPG], end[RPG];
@@ -225,17 +285,70 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
 #pragma unroll
     for (int r = 0; r < RPG; ++r) {
         row[r] = int64_t(blk) * RPB + r * GPB + grp;
-        const bool rv = row[r] < n_rows;
-        pos[r] = rv ? indptr[row[r]] : 0;
-        end[r] = rv ? indptr[row[r] + 1] : 0;
-        if (end[r] - pos[r] > skip_deg) {  // heavy row: produced by the segment kernels (plan)
-            row[r] = n_rows;
-            end[r] = pos[r];
-        }
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[r][c][i] = 0.f;
+    }
+
+    if (ELLW > 0) {
+        // ---- packed-table phase: slot k of a row sits in lane k % LPR, register k / LPR of its group
+        constexpr int KI = ELLW > LPR ? ELLW / LPR : 1;
+        int32_t slot[RPG][KI];
+#pragma unroll
+        for (int r = 0; r < RPG; ++r)
+#pragma unroll
+            for (int q = 0; q < KI; ++q) {
+                const int k = q * LPR + lig;
+                slot[r][q] = (row[r] < n_rows && k < ELLW) ? ell[row[r] * ELLW + k] : kEllEmpty;
+            }
+#pragma unroll
+        for (int b = 0; b < ELLW / NB; ++b) {
+            int32_t j[RPG][NB];
+            bool ev[RPG][NB];
+            bool any = false;
+#pragma unroll
+            for (int r = 0; r < RPG; ++r)
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int k = b * NB + u;
+                    if (LPR == 64) j[r][u] = __builtin_amdgcn_readlane(slot[r][k / LPR], k % LPR);
+                    else j[r][u] = __shfl(slot[r][k / LPR], glane0 + k % LPR, 64);
+                    ev[r][u] = j[r][u] >= 0;
+                    if (u == 0) any = any || ev[r][u];
+                }
+            // slots fill from the left: an empty first slot of the batch for every row of the wave ends the phase
+            if (b > 0 && __builtin_amdgcn_ballot_w64(any) == 0) break;
+            gather_batch<T, VEC, LPR, CH, RPG, NB, SCALED>(H, ldh, f0, live, j, ev, col_scale, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) {
+            int32_t first, last;
+            if (LPR == 64) {
+                first = __builtin_amdgcn_readlane(slot[r][0], 0);
+                last = __builtin_amdgcn_readlane(slot[r][(ELLW - 1) / LPR], (ELLW - 1) % LPR);
+            } else {
+                first = __shfl(slot[r][0], glane0, 64);
+                last = __shfl(slot[r][(ELLW - 1) / LPR], glane0 + (ELLW - 1) % LPR, 64);
+            }
+            pos[r] = end[r] = 0;
+            if (first == kEllSkip) row[r] = n_rows;        // heavy row: produced by the segment kernels (plan)
+            if (last == kEllOverflow) {                    // rare: the rest of the row from the CSR arrays
+                pos[r] = indptr[row[r]] + (ELLW - 1);
+                end[r] = indptr[row[r] + 1];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) {
+            const bool rv = row[r] < n_rows;
+            pos[r] = rv ? indptr[row[r]] : 0;
+            end[r] = rv ? indptr[row[r] + 1] : 0;
+            if (end[r] - pos[r] > skip_deg) {  // heavy row: produced by the segment kernels (plan)
+                row[r] = n_rows;
+                end[r] = pos[r];
+            }
+        }
     }
 
     for (;;) {
@@ -250,44 +363,19 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
             const int32_t e = pos[r] + (LPR >= 4 ? (lig & (NB - 1)) : lig);
             myidx[r] = e < end[r] ? indices[e] : 0;
         }
-        float v[RPG][NB][CH][VEC];
-        float cs[RPG][NB];
+        int32_t j[RPG][NB];
+        bool ev[RPG][NB];
 #pragma unroll
         for (int r = 0; r < RPG; ++r)
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                int32_t j;
-                if (LPR == 64) j = __builtin_amdgcn_readlane(myidx[r], u);
-                else j = __shfl(myidx[r], glane0 + u, 64);
-                const bool ev = pos[r] + u < end[r];
-                if (SCALED) cs[r][u] = ev ? col_scale[j] : 0.f;
-                const T *hp = H + int64_t(j) * ldh + f0;
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    if (ev && live[c]) {
-                        VecIO<T, VEC>::load(hp + c * TILE, v[r][u][c]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) v[r][u][c][i] = 0.f;
-                    }
-                }
+                if (LPR == 64) j[r][u] = __builtin_amdgcn_readlane(myidx[r], u);
+                else j[r][u] = __shfl(myidx[r], glane0 + u, 64);
+                ev[r][u] = pos[r] + u < end[r];
             }
+        gather_batch<T, VEC, LPR, CH, RPG, NB, SCALED>(H, ldh, f0, live, j, ev, col_scale, acc);
 #pragma unroll
-        for (int r = 0; r < RPG; ++r) {
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const bool ev = pos[r] + u < end[r];
-                if (ev) {
-#pragma unroll
-                    for (int c = 0; c < CH; ++c)
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i)
-                            acc[r][c][i] = SCALED ? fmaf(cs[r][u], v[r][u][c][i], acc[r][c][i])
-                                                  : acc[r][c][i] + v[r][u][c][i];
-                }
-            }
-            pos[r] = min(pos[r] + NB, end[r]);
-        }
+        for (int r = 0; r < RPG; ++r) pos[r] = min(pos[r] + NB, end[r]);
     }
 #pragma unroll
     for (int r = 0; r < RPG; ++r) {
@@ -316,69 +404,110 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
     }
 }
 
+// packed neighbour table: slot k of row r at ell[r * W + k]
+__global__ __launch_bounds__(256) void ell_build_kernel(const int32_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices, int64_t n_rows, int W,
+                                                        int skip_deg, int32_t *__restrict__ ell)
+{
+    const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= n_rows * W) return;
+    const int64_t row = idx / W;
+    const int k = int(idx - row * W);
+    const int32_t p = indptr[row], deg = indptr[row + 1] - p;
+    int32_t v;
+    if (deg > skip_deg) v = k == 0 ? kEllSkip : kEllEmpty;
+    else if (deg > W && k == W - 1) v = kEllOverflow;
+    else v = k < deg ? indices[p + k] : kEllEmpty;
+    ell[idx] = v;
+}
+
 // tuning knobs (gae_tuning_set): read-mostly process-wide integers
 int g_spmm_variant = 2;   // 1 = v1 rowgroup, 2 = v2 rowgroup2
-int g_spmm_rpg = 2;       // rows per group (v2)
+int g_spmm_rpg = 0;       // rows per lane group (v2): 0 = auto (2 for launches of >= 32768 waves, else 1), 1, 2
 int g_spmm_nt = 1;        // non-temporal stores of M (v2)
-int g_spmm_tile_vecs = -1; // 16-byte vectors per XCD feature tile (0 auto, -1 off: measured gain <= 8 % on random graphs, loss on local ones)
-int g_spmm_nb = 4;        // neighbour rows in flight per owned row for wide rows (4 | 8)
+int g_spmm_tile_vecs = 0; // 16-byte vectors per XCD feature tile: 0 = auto when GAE_SPMM_TILE is set, -1 = never, > 0 = forced
+int g_spmm_ell = 1;       // use the plan's packed neighbour table when it has one
+
+constexpr int kEllWidth = 16;
 
 template <typename T, int VEC, int LPR, int CH, int RPG>
 int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
-                     int64_t ldm, int F, const float *rs, const float *cs, bool nt, bool tiled, int skip_deg,
-                     int flags, hipStream_t s)
+                     int64_t ldm, int F, const float *rs, const float *cs, bool nt, int tile_vecs, int skip_deg,
+                     int flags, const int32_t *ell, hipStream_t s)
 {
     const int store_pad = ((flags & GAE_SPMM_STORE_PAD) && (F + VEC - 1) / VEC * VEC <= ldm) ? 1 : 0;
     constexpr int RPB = (256 / LPR) * RPG;
     const int nvec = (F + VEC - 1) / VEC;
-    const unsigned nrb = unsigned((n_rows + RPB - 1) / RPB), nft = unsigned((nvec + LPR * CH - 1) / (LPR * CH));
+    const bool tiled = tile_vecs > 0;
+    const int tw = tiled ? tile_vecs : LPR * CH;   // 16-byte vectors per feature tile
+    const unsigned nrb = unsigned((n_rows + RPB - 1) / RPB), nft = unsigned((nvec + tw - 1) / tw);
     const dim3 grid = tiled ? dim3(gae::kNumXcd * ((nft + gae::kNumXcd - 1) / gae::kNumXcd) * nrb) : dim3(nrb, nft);
     const int xt = tiled ? 1 : 0;
-#define GAE_L2(SC, NT, NBW)                                                                                         \
-    hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, NT, NBW>), grid, dim3(256), 0, s, indptr,   \
-                       indices, n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, skip_deg, store_pad)
-    if (LPR >= 16 && CH <= 2 && g_spmm_nb == 8) {   // wide rows: 8 neighbour rows in flight per owned row
-        if (rs || cs) { if (nt) GAE_L2(true, true, 8); else GAE_L2(true, false, 8); }
-        else { if (nt) GAE_L2(false, true, 8); else GAE_L2(false, false, 8); }
+#define GAE_L2(SC, NT, EW)                                                                                          \
+    hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, NT, EW>), grid, dim3(256), 0, s, indptr,    \
+                       indices, n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, tw * VEC, skip_deg, store_pad, ell)
+    constexpr int EW = VEC > 1 ? kEllWidth : 0;
+    if (VEC > 1 && ell) {
+        if (rs || cs) { if (nt) GAE_L2(true, true, EW); else GAE_L2(true, false, EW); }
+        else { if (nt) GAE_L2(false, true, EW); else GAE_L2(false, false, EW); }
     } else {
-        if (rs || cs) { if (nt) GAE_L2(true, true, 4); else GAE_L2(true, false, 4); }
-        else { if (nt) GAE_L2(false, true, 4); else GAE_L2(false, false, 4); }
+        if (rs || cs) { if (nt) GAE_L2(true, true, 0); else GAE_L2(true, false, 0); }
+        else { if (nt) GAE_L2(false, true, 0); else GAE_L2(false, false, 0); }
     }
 #undef GAE_L2
     GAE_CHECK_LAUNCH("spmm_rowgroup2_kernel");
     return GAE_OK;
 }
 
+// XCD feature tiling (GAE_SPMM_TILE): tile width in 16-byte vectors, 0 = do not tile.  8k tiles of whole 128-byte
+// lines so that every XCD sweeps the same number of tiles; the widest tile whose slice of H stays L2-resident.
+inline int auto_tile_vecs(int nvec, int64_t n_cols)
+{
+    const int64_t budget = int64_t(21) << 18;   // 5.25 MiB: a 4 MiB L2 keeps most of a slice slightly above its size
+    for (int k = 1; k <= 16; ++k) {
+        int tv = (nvec + 8 * k - 1) / (8 * k);
+        tv = (tv + 7) / 8 * 8;
+        if (tv < 8) return 0;
+        if (tv <= 256 && n_cols * tv * 16 <= budget) return tv;
+    }
+    return 0;
+}
+
 template <typename T, int VEC>
 int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
                        int64_t ldm, int F, const float *rs, const float *cs, int rpg, bool nt, int64_t n_cols,
-                       int skip_deg, int flags, hipStream_t s)
+                       int skip_deg, int flags, const int32_t *ell, hipStream_t s)
 {
     const int nvec = (F + VEC - 1) / VEC;
-    bool tiled = false;
+    int tile_vecs = 0;
 #define GAE_RG2(LPR, CH)                                                                                          \
     do {                                                                                                          \
-        if (rpg >= 2 && CH == 1)                                                                                  \
+        /* two rows per lane group halve the wave count: pays once the launch is many occupancy rounds long   \
+         * (ZINC set 362 -> 288 us), costs parallelism on short ones (Pubmed F = 32: 4.0 -> 5.2 us) */           \
+        const int rpg_ = rpg > 0 ? rpg : (n_rows * LPR / 64 >= 32768 ? 2 : 1);                                    \
+        if (rpg_ >= 2 && CH == 1)                                                                                 \
             return launch_rowgroup2<T, VEC, LPR, CH, 2>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt,   \
-                                                        tiled, skip_deg, flags, s);                               \
-        return launch_rowgroup2<T, VEC, LPR, CH, 1>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt, tiled, \
-                                                    skip_deg, flags, s);                                          \
+                                                        tile_vecs, skip_deg, flags, ell, s);                      \
+        return launch_rowgroup2<T, VEC, LPR, CH, 1>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt,       \
+                                                    tile_vecs, skip_deg, flags, ell, s);                          \
     } while (0)
-    // Wide rows whose per-tile slice of H fits one XCD's L2: feature-tiled XCD mapping.
-    {
-        int tv = g_spmm_tile_vecs;  // vectors (16 B) per feature tile; 0 = auto, < 0 = off
-        if (tv == 0 && nvec > 16) {
-            const int64_t budget = int64_t(5) << 19;  // 2.5 MiB of a 4 MiB L2
-            for (int cand : {32, 16, 8, 4})
-                if (n_cols * cand * 16 <= budget && (nvec + cand - 1) / cand >= 8) { tv = cand; break; }
-        }
+    // Wide rows, poor gather locality (the caller's GAE_SPMM_TILE), rows made of whole 128-byte lines: XCD x owns
+    // feature tiles x, x + 8, ... so that the tile's slice of H is gathered out of that XCD's own L2.
+    if (VEC > 1 && nvec > 16 && g_spmm_tile_vecs >= 0) {
+        const bool lines = (ldh * sizeof(T)) % 128 == 0 && (ldm * sizeof(T)) % 128 == 0 &&
+                           reinterpret_cast<uintptr_t>(H) % 128 == 0 && reinterpret_cast<uintptr_t>(M) % 128 == 0;
+        int tv = g_spmm_tile_vecs > 0 ? g_spmm_tile_vecs
+                                      : ((flags & GAE_SPMM_TILE) && lines ? auto_tile_vecs(nvec, n_cols) : 0);
         if (tv > 0 && (nvec + tv - 1) / tv >= 2) {
-            tiled = true;
+            tile_vecs = tv;
             if (tv <= 4) GAE_RG2(4, 1);
             if (tv <= 8) GAE_RG2(8, 1);
             if (tv <= 16) GAE_RG2(16, 1);
             if (tv <= 32) GAE_RG2(32, 1);
-            GAE_RG2(64, 1);
+            if (tv <= 64) GAE_RG2(64, 1);
+            if (tv <= 128) GAE_RG2(64, 2);
+            if (tv <= 256) GAE_RG2(64, 4);
+            tile_vecs = 0;
         }
     }
     if (nvec <= 4) GAE_RG2(4, 1);
@@ -719,7 +848,8 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
     int rc;
     if (g_spmm_variant == 2 && f > min_f)
         rc = dispatch_rowgroup2<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, g_spmm_rpg,
-                                        g_spmm_nt != 0 && sizeof(T) == 4, n_cols, skip, flags, s);
+                                        g_spmm_nt != 0 && sizeof(T) == 4, n_cols, skip, flags,
+                                        (plan && g_spmm_ell && plan->ell_width == kEllWidth) ? plan->ell : nullptr, s);
     else {
         GAE_REQUIRE(!heavy, GAE_E_RANGE, "gae_spmm_csr: a skew plan needs F > %d for this layout", min_f);
         rc = dispatch_rowgroup<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, s);
@@ -776,6 +906,22 @@ extern "C" int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t
     return GAE_OK;
 }
 
+extern "C" int gae_spmm_ell_build(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t width,
+                                  int32_t skip_degree, int32_t *ell, void *stream)
+{
+    GAE_REQUIRE(n_rows >= 0, GAE_E_SIZE, "gae_spmm_ell_build: negative n_rows");
+    GAE_REQUIRE(width == GAE_SPMM_ELL_WIDTH, GAE_E_RANGE, "gae_spmm_ell_build: width must be %d", GAE_SPMM_ELL_WIDTH);
+    GAE_REQUIRE(skip_degree >= 1, GAE_E_RANGE, "gae_spmm_ell_build: skip_degree >= 1 required");
+    if (n_rows == 0) return GAE_OK;
+    GAE_REQUIRE(indptr && ell, GAE_E_NULL, "gae_spmm_ell_build: NULL pointer");
+    GAE_REQUIRE(n_rows * width < (int64_t(1) << 39), GAE_E_SIZE, "gae_spmm_ell_build: table too large");
+    hipStream_t s = gae::as_stream(stream);
+    hipLaunchKernelGGL(ell_build_kernel, dim3(unsigned((n_rows * width + 255) / 256)), dim3(256), 0, s, indptr, indices,
+                       n_rows, int(width), int(skip_degree), ell);
+    GAE_CHECK_LAUNCH("ell_build_kernel");
+    return GAE_OK;
+}
+
 extern "C" int64_t gae_spmm_workspace_bytes(const gae_spmm_plan *plan, int64_t F)
 {
     if (F < 0) return GAE_E_SIZE;
@@ -808,6 +954,9 @@ extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64
                     (long long)workspace_bytes, (long long)need);
         GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_spmm_csr: workspace not 16-byte aligned");
     }
+    if (plan && plan->ell)
+        GAE_REQUIRE(plan->ell_width == GAE_SPMM_ELL_WIDTH, GAE_E_RANGE, "gae_spmm_csr: plan->ell_width must be %d",
+                    GAE_SPMM_ELL_WIDTH);
     hipStream_t s = gae::as_stream(stream);
     const int f = int(F);
     if (dtype == GAE_F32) {
@@ -897,7 +1046,7 @@ extern "C" int gae_tuning_set(const char *name, int64_t value)
     GAE_REQUIRE(name != nullptr, GAE_E_NULL, "gae_tuning_set: name is NULL");
     const struct { const char *k; int *v; } knobs[] = {
         {"spmm_variant", &g_spmm_variant}, {"spmm_rpg", &g_spmm_rpg}, {"spmm_nt", &g_spmm_nt},
-        {"spmm_tile_vecs", &g_spmm_tile_vecs}, {"spmm_nb", &g_spmm_nb}};
+        {"spmm_tile_vecs", &g_spmm_tile_vecs}, {"spmm_ell", &g_spmm_ell}};
     for (const auto &kv : knobs)
         if (strcmp(kv.k, name) == 0) {
             *kv.v = int(value);

@@ -165,13 +165,22 @@ class Graph:
         return self._cache["csc"]
 
     def spmm_plan(self, transposed=False):
-        """degree-skew plan of the CSR (or of the CSR of A^T); None when no row is heavy"""
+        """plan of the CSR (or of the CSR of A^T): skew plan and / or packed neighbour table (ops.spmm_plan);
+        None when the graph needs neither"""
         key = "plan_t" if transposed else "plan"
         if key not in self._cache:
             from . import ops
-            indptr = (self.csc() if transposed else self.csr())[0]
-            self._cache[key] = None if self.no_heavy_rows else ops.spmm_plan(indptr)
+            indptr, indices = self.csc() if transposed else self.csr()
+            self._cache[key] = None if self.no_heavy_rows else ops.spmm_plan(indptr, indices=indices)
         return self._cache[key]
+
+    def scattered(self):
+        """True when the graph's gathers have poor locality (ops.gather_scattered); block-diagonal batches never"""
+        if "scattered" not in self._cache:
+            from . import ops
+            self._cache["scattered"] = (not self.no_heavy_rows and self.block_diag is None
+                                        and ops.gather_scattered(*self.csr()))
+        return self._cache["scattered"]
 
     def set_csr(self, indptr, indices, t_indptr=None, t_indices=None):
         """adopt an already-built device CSR (used by the device dataset batcher)"""

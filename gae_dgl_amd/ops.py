@@ -28,12 +28,21 @@ def _gpu(t, name):
     return t
 
 
+def row_quantum(f, dtype):
+    """leading-dimension multiple (elements) of an [N, f] operand: rows of 512 bytes and more are made of whole
+    128-byte lines (XCD feature tiles of gae_spmm_csr then never share a line), narrower rows of whole 16-byte
+    vectors"""
+    size = 4 if dtype == torch.float32 else 2
+    return (128 if f * size >= 512 else 16) // size
+
+
 def pad_rows(t, multiple=None):
-    """view of ``t`` [N, F] inside a buffer whose rows are padded to 16 bytes (zero pad): gives every kernel the
-    aligned vector path for odd feature widths (F = 39, 1433, 3703)"""
-    q = multiple or (4 if t.dtype == torch.float32 else 8)
+    """view of ``t`` [N, F] inside a buffer whose rows are padded (zero pad) to 16 bytes, or to 128 bytes for rows
+    of 512 bytes and more: gives every kernel the aligned vector path for odd feature widths (F = 39 -> ld 40,
+    500 -> 512, 1433 -> 1440, 3703 -> 3712)"""
     n, f = t.shape
-    if f % q == 0 and t.stride(1) == 1 and t.stride(0) % q == 0:
+    q = multiple or row_quantum(f, t.dtype)
+    if t.stride(1) == 1 and t.stride(0) % q == 0 and t.stride(0) >= f and t.data_ptr() % (q * t.element_size()) == 0:
         return t
     buf = torch.zeros(n, (f + q - 1) // q * q, dtype=t.dtype, device=t.device)
     buf[:, :f] = t
@@ -190,39 +199,73 @@ SKEW_SEGMENT = 256       # edges per segment (multiple of 64)
 SKEW_MIN_MAXDEG = 64     # graphs whose longest row is shorter need no plan (3 extra launches would not pay)
 
 
+TILE_MIN_F = 64          # XCD feature tiles are only considered for rows wider than one lane group (16 vectors)
+SCATTER_WINDOW = 1024    # a gather is "near" when |column id - row id| <= this many rows ...
+SCATTER_NEAR_FRAC = 0.5  # ... and a graph is scattered when fewer than this fraction of its gathers are near
+ELL_MAX_ROWS = 1 << 18   # packed neighbour table only for graphs whose launches are latency-bound, not byte-bound
+
+
 class SpmmPlan:
-    """degree-skew plan of one CSR (see gae_spmm_plan in include/gae_hip.h)"""
+    """per-CSR acceleration data of gae_spmm_csr (gae_spmm_plan in include/gae_hip.h): the degree-skew plan
+    (heavy rows cut into segments) and / or the packed neighbour table"""
 
-    def __init__(self, threshold, segment, n_heavy, n_segments, heavy_rows, heavy_seg_base, seg_heavy):
-        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy)  # keep the device arrays alive
-        self.n_heavy, self.n_segments = n_heavy, n_segments
-        self.c = _lib.SpmmPlan(threshold, segment, n_heavy, n_segments, heavy_rows.data_ptr(),
-                               heavy_seg_base.data_ptr(), seg_heavy.data_ptr())
+    def __init__(self, threshold, segment, n_heavy, n_segments, heavy_rows, heavy_seg_base, seg_heavy, ell=None):
+        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy, ell)  # keep the device arrays alive
+        self.n_heavy, self.n_segments, self.ell = n_heavy, n_segments, ell
+        ptr = lambda t: None if t is None else t.data_ptr()
+        self.c = _lib.SpmmPlan(threshold, segment, n_heavy, n_segments, ptr(heavy_rows), ptr(heavy_seg_base),
+                               ptr(seg_heavy), ptr(ell), _lib.SPMM_ELL_WIDTH if ell is not None else 0, 0)
 
 
-def spmm_plan(indptr, threshold=None, segment=None):
-    """Build the skew plan of a CSR, or None when no row exceeds the threshold
-    (one host read-back of three counters; done once per graph).  With the
-    default threshold a plan is only built for graphs whose longest row has
-    more than SKEW_MIN_MAXDEG edges."""
+def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None):
+    """Build the plan of a CSR, or None when it needs none (one host read-back of three counters; done once per
+    graph).  Skew part: with the default threshold only for graphs whose longest row has more than
+    SKEW_MIN_MAXDEG edges.  Packed neighbour table: when ``indices`` is given and the graph has at most
+    ELL_MAX_ROWS rows (``ell`` = True / False overrides)."""
     auto = threshold is None
     threshold = SKEW_THRESHOLD if threshold is None else threshold
     segment = SKEW_SEGMENT if segment is None else segment
     _gpu(indptr, "indptr")
     dev = indptr.device
     n = indptr.numel() - 1
+    want_ell = (indices is not None and 0 < n <= ELL_MAX_ROWS) if ell is None else bool(ell)
+    if want_ell and indices is None:
+        raise GaeHipError("spmm_plan: the packed neighbour table needs `indices`")
     with _on_device(dev):
         counts = torch.zeros(3, dtype=torch.int64, device=dev)
         _lib.call("gae_spmm_plan_count", _ptr(indptr), n, threshold, segment, _ptr(counts), _stream())
         n_heavy, n_seg, max_deg = (int(v) for v in counts.tolist())
-        if n_heavy == 0 or (auto and max_deg <= SKEW_MIN_MAXDEG):
+        heavy = n_heavy > 0 and not (auto and max_deg <= SKEW_MIN_MAXDEG)
+        if not heavy and not want_ell:
             return None
-        hr = torch.empty(n_heavy, dtype=torch.int32, device=dev)
-        hb = torch.empty(n_heavy, dtype=torch.int32, device=dev)
-        sh = torch.empty(n_seg, dtype=torch.int32, device=dev)
-        _lib.call("gae_spmm_plan_fill", _ptr(indptr), n, threshold, segment, _ptr(counts), _ptr(hr), _ptr(hb),
-                  _ptr(sh), _stream())
-    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh)
+        hr = hb = sh = table = None
+        if heavy:
+            hr = torch.empty(n_heavy, dtype=torch.int32, device=dev)
+            hb = torch.empty(n_heavy, dtype=torch.int32, device=dev)
+            sh = torch.empty(n_seg, dtype=torch.int32, device=dev)
+            _lib.call("gae_spmm_plan_fill", _ptr(indptr), n, threshold, segment, _ptr(counts), _ptr(hr), _ptr(hb),
+                      _ptr(sh), _stream())
+        else:
+            n_heavy = n_seg = 0
+        if want_ell:
+            table = torch.empty(n * _lib.SPMM_ELL_WIDTH, dtype=torch.int32, device=dev)
+            _lib.call("gae_spmm_ell_build", _ptr(indptr), _ptr(indices), n, _lib.SPMM_ELL_WIDTH,
+                      threshold if heavy else 2 ** 31 - 1, _ptr(table), _stream())
+    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh, table)
+
+
+def gather_scattered(indptr, indices):
+    """True when most column ids lie far from their row id: the neighbour rows of concurrently processed rows then
+    share nothing in L1 / L2 and wide launches do better with XCD feature tiles (GAE_SPMM_TILE).  One host
+    read-back; computed once per graph."""
+    n = indptr.numel() - 1
+    e = indices.numel()
+    if n == 0 or e == 0:
+        return False
+    deg = (indptr[1:] - indptr[:-1]).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(n, device=indptr.device), deg, output_size=e)
+    near = ((indices.to(torch.int64) - rows).abs() <= SCATTER_WINDOW).sum()
+    return bool(int(near) < SCATTER_NEAR_FRAC * e)
 
 
 BLOCKDIAG_GRAPHS = 4          # member graphs per thread block of the block-diagonal kernel
@@ -275,18 +318,19 @@ class BlockDiag:
 
 
 def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=None, plan=None, blockdiag=None,
-             out_padded=False):
+             out_padded=False, scattered=False):
     """M = diag(row_scale) A diag(col_scale) H  (K1/K2).  ``out_padded``: the caller's ``out`` is a view of a
-    row-padded buffer whose pad columns may be overwritten (always true for the buffer allocated here)."""
+    row-padded buffer whose pad columns may be overwritten (always true for the buffer allocated here).
+    ``scattered``: the graph's column ids lie far from the row ids (GAE_SPMM_TILE)."""
     H, ldh = _rowmajor(H, "H")
     _gpu(indptr, "indptr")
     n_cols, F = H.shape
     if out is None:
-        # rows padded to 16 bytes: keeps the 16-byte vector path for any F (the pad columns are never read as data)
-        q = 4 if H.dtype == torch.float32 else 8
+        # rows padded to 16 / 128 bytes: keeps the vector path for any F (the pad columns are never read as data)
+        q = row_quantum(F, H.dtype)
         out = torch.empty(n_rows, (F + q - 1) // q * q, dtype=H.dtype, device=H.device)[:, :F]
         out_padded = True
-    flags = _lib.SPMM_STORE_PAD if out_padded else 0
+    flags = (_lib.SPMM_STORE_PAD if out_padded else 0) | (_lib.SPMM_TILE if scattered else 0)
     out2, ldm = _rowmajor(out, "out")
     if out2 is not out:
         raise GaeHipError("spmm: `out` must be row-major with unit inner stride")
@@ -474,7 +518,7 @@ class SpMMFunction(torch.autograd.Function):
         norm = graph.norm() if use_norm else None
         ctx.graph, ctx.use_norm = graph, use_norm
         return spmm_raw(indptr, indices, H, graph.number_of_nodes(), norm, norm, plan=graph.spmm_plan(False),
-                        blockdiag=graph.block_diag)
+                        blockdiag=graph.block_diag, scattered=H.shape[1] > TILE_MIN_F and graph.scattered())
 
     @staticmethod
     def backward(ctx, dM):
@@ -482,7 +526,7 @@ class SpMMFunction(torch.autograd.Function):
         t_indptr, t_indices = g.csc()
         norm = g.norm() if ctx.use_norm else None
         return spmm_raw(t_indptr, t_indices, dM, g.number_of_nodes(), norm, norm, plan=g.spmm_plan(True),
-                        blockdiag=g.block_diag), None, None
+                        blockdiag=g.block_diag, scattered=dM.shape[1] > TILE_MIN_F and g.scattered()), None, None
 
 
 class LinearFunction(torch.autograd.Function):

@@ -135,6 +135,9 @@ typedef struct gae_spmm_plan {
     const int32_t *heavy_rows;      /* [n_heavy]    row ids                       (device) */
     const int32_t *heavy_seg_base;  /* [n_heavy]    first segment of the row      (device) */
     const int32_t *seg_heavy;       /* [n_segments] heavy-row slot of the segment (device) */
+    const int32_t *ell;             /* [n_rows * ell_width] packed neighbour table (device) or NULL */
+    int32_t ell_width;              /* GAE_SPMM_ELL_WIDTH when `ell` is given, else 0 */
+    int32_t reserved;
 } gae_spmm_plan;
 
 /* counts_dev[0] = number of heavy rows, [1] = number of segments, [2] = maximum row degree (3 x uint64, device) */
@@ -144,6 +147,16 @@ int gae_spmm_plan_count(const int32_t *indptr, int64_t n_rows, int32_t threshold
 int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
                        uint64_t *cursors_dev, int32_t *heavy_rows, int32_t *heavy_seg_base,
                        int32_t *seg_heavy, void *stream);
+/* Packed neighbour table (optional, for launches of a few 10 MB): slot k of row r at ell[r * width + k] holds the
+ * row's k-th column id in CSR order; -1 = empty; a row with more than `width` ids keeps width - 1 of them and the
+ * marker -2 in its last slot (the kernel continues from indptr / indices); rows with more than `skip_degree` ids
+ * (the plan's threshold when it has heavy rows, else INT32_MAX) hold the marker -3 in slot 0.  With the table ONE
+ * load replaces the dependent indptr -> indices chain in front of the gather; short launches are bounded by that
+ * chain, not by bytes (Pubmed F = 500: 21 -> 15 us).  Same summation order, bit-identical results.  The table
+ * costs width * 4 bytes per row of extra traffic: leave plan->ell NULL for graphs of millions of rows. */
+#define GAE_SPMM_ELL_WIDTH 16
+int gae_spmm_ell_build(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t width,
+                       int32_t skip_degree, int32_t *ell, void *stream);
 /* bytes of workspace gae_spmm_csr needs with this plan (0 without one) */
 int64_t gae_spmm_workspace_bytes(const gae_spmm_plan *plan_host, int64_t F);
 
@@ -152,6 +165,11 @@ int64_t gae_spmm_workspace_bytes(const gae_spmm_plan *plan_host, int64_t F);
                               * allows the pad columns [F, roundup(F)) to be overwritten: the tail vector of every
                               * row is stored whole (F = 39: 575 -> 443 us on the ZINC set; partially written
                               * 32-byte sectors are expensive) */
+#define GAE_SPMM_TILE 2      /* the graph's gathers have poor locality (column ids far from the row id) and H is wider
+                              * than one lane group: when H / M rows are whole 128-byte lines (ld * elem % 128 == 0,
+                              * 128-byte aligned bases) XCD x sweeps feature tiles x, x + 8, ... so that a tile's
+                              * slice of H is gathered from that XCD's own L2 instead of HBM (Pubmed F = 500: HBM
+                              * traffic 170 -> 45 MB, 31 -> 19 us).  Hurts graphs with local neighbourhoods. */
 int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                  const void *H, int64_t ldh, void *M, int64_t ldm, int64_t F, int dtype,
                  const float *row_scale, const float *col_scale,

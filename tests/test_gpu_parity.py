@@ -141,6 +141,98 @@ def test_spmm_skew_plan(F, dtype, thr, seg, dev):
     assert ops.spmm_plan(dip, threshold=10 ** 6) is None      # nothing heavy -> no plan
 
 
+@pytest.mark.parametrize("F,dtype", [(16, torch.float32), (32, torch.float32), (39, torch.float32),
+                                      (500, torch.float32), (1433, torch.float32), (64, torch.bfloat16)])
+def test_spmm_packed_table_bit_identical(F, dtype, dev):
+    """packed neighbour table (gae_spmm_ell_build): one load instead of the indptr -> indices chain, same CSR-order
+    sums -- rows longer than the table continue from the CSR arrays, heavy rows of a skew plan are skipped"""
+    from gae_dgl_amd import ops, _lib
+    rng = np.random.default_rng(F)
+    n, e = 2500, 12000
+    src, dst = rand_graph(rng, n, e)
+    dst[:40] = 11; dst[40:57] = 12; dst[57:73] = 13; dst[73:88] = 14     # rows of 40+, 17+, 16+, 15+ edges
+    dst[dst == 5] = 6                                                     # an empty row
+    H = rng.standard_normal((n, F)).astype(np.float32)
+    ip, ix = O().csr_from_coo(src, dst, n)
+    norm = O().norm_from_in_degrees(O().in_degrees(dst, n)).numpy()
+    dip, dix = t(ip, dev), t(ix, dev)
+    Hd = ops.pad_rows(t(H, dev).to(dtype))
+    table = ops.spmm_plan(dip, indices=dix)                               # auto: no heavy rows, table only
+    assert table is not None and table.n_heavy == 0 and table.ell is not None
+    W = _lib.SPMM_ELL_WIDTH
+    tab = table.ell.cpu().numpy().reshape(n, W)
+    deg = np.diff(ip)
+    for r in (5, 11, 12, 13, 14, 100):
+        k = min(int(deg[r]), W if deg[r] <= W else W - 1)
+        assert np.array_equal(tab[r, :k], ix[ip[r]:ip[r] + k])
+        assert (tab[r, k:] == (-2 if deg[r] > W else -1)).all() or (deg[r] > W and tab[r, W - 1] == -2)
+    both = ops.spmm_plan(dip, threshold=8, segment=64, indices=dix)       # heavy rows + table
+    assert both.n_heavy == int((deg > 8).sum()) and both.ell is not None
+    assert int(both.ell.view(n, W)[11, 0]) == -3
+    for scaled in (False, True):
+        sc = t(norm, dev) if scaled else None
+        base = ops.spmm_raw(dip, dix, Hd, n, sc, sc)
+        for rpg in (1, 2):
+            _lib.call("gae_tuning_set", b"spmm_rpg", rpg)
+            try:
+                out = ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=table)
+                assert torch.equal(out, base)
+                heavy = ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=ops.spmm_plan(dip, threshold=8, segment=64))
+                assert torch.equal(ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=both), heavy)
+            finally:
+                _lib.call("gae_tuning_set", b"spmm_rpg", 0)
+    if dtype == torch.float32:
+        from oracle import c_oracle
+        assert np.array_equal(ops.spmm_raw(dip, dix, Hd, n, plan=table).cpu().numpy(), c_oracle.spmm_csr(ip, ix, H))
+
+
+@pytest.mark.parametrize("F", [100, 500, 1433, 3703])
+@pytest.mark.parametrize("n", [300, 5000])
+def test_spmm_feature_tiles_bit_identical(F, n, dev):
+    """GAE_SPMM_TILE: XCD-owned feature tiles on rows made of whole 128-byte lines == the plain row-group launch"""
+    from gae_dgl_amd import ops, _lib
+    rng = np.random.default_rng(F + n)
+    src, dst = rand_graph(rng, n, 5 * n, hub=True)
+    H = rng.standard_normal((n, F)).astype(np.float32)
+    ip, ix = O().csr_from_coo(src, dst, n)
+    dip, dix = t(ip, dev), t(ix, dev)
+    Hp = ops.pad_rows(t(H, dev))
+    assert Hp.stride(0) % 32 == 0 if F * 4 >= 512 else Hp.stride(0) % 4 == 0
+    base = ops.spmm_raw(dip, dix, Hp, n)
+    from oracle import c_oracle
+    assert np.array_equal(base.cpu().numpy(), c_oracle.spmm_csr(ip, ix, H))
+    plan = ops.spmm_plan(dip, indices=dix)          # hub row -> skew plan (segment sums: own order) + packed table
+    assert plan.n_heavy > 0 and plan.ell is not None
+    planned = ops.spmm_raw(dip, dix, Hp, n, plan=plan)
+    assert rel_err(planned, base.double().cpu()) < TOL
+    assert torch.equal(ops.spmm_raw(dip, dix, Hp, n, scattered=True), base)
+    assert torch.equal(ops.spmm_raw(dip, dix, Hp, n, scattered=True, plan=plan), planned)
+    norm = t(O().norm_from_in_degrees(O().in_degrees(dst, n)).numpy(), dev)
+    assert torch.equal(ops.spmm_raw(dip, dix, Hp, n, norm, norm, scattered=True),
+                       ops.spmm_raw(dip, dix, Hp, n, norm, norm))
+    for tv in (8, 16, 40, 64, 136):          # forced tile widths, also on rows that are NOT whole lines
+        _lib.call("gae_tuning_set", b"spmm_tile_vecs", tv)
+        try:
+            assert torch.equal(ops.spmm_raw(dip, dix, Hp, n, plan=plan), planned)
+            Hu = t(H, dev)                                           # ld = F: unaligned rows, scalar or vector path
+            assert torch.equal(ops.spmm_raw(dip, dix, Hu, n), base)
+        finally:
+            _lib.call("gae_tuning_set", b"spmm_tile_vecs", 0)
+
+
+def test_gather_scattered_statistic(dev):
+    from gae_dgl_amd import ops, workloads as W
+    rng = np.random.default_rng(0)
+    n = 20000
+    dst = rng.integers(0, n, 5 * n); src = rng.integers(0, n, 5 * n)
+    assert ops.gather_scattered(*ops.csr_from_coo(t(dst, dev), t(src, dev), n, n))
+    near = np.clip(dst + rng.integers(-32, 33, dst.size), 0, n - 1)
+    assert not ops.gather_scattered(*ops.csr_from_coo(t(dst, dev), t(near, dev), n, n))
+    gp, s2, d2, _ = W.zinc_like(2000, seed=1)
+    assert not ops.gather_scattered(*ops.csr_from_coo(t(d2, dev), t(s2, dev), int(gp[-1]), int(gp[-1])))
+    assert not ops.gather_scattered(*ops.csr_from_coo(t(dst[:0], dev), t(src[:0], dev), 10, 10))
+
+
 @pytest.mark.parametrize("F,ld", [(32, 32), (39, 40), (16, 16), (8, 8), (130, 132)])
 @pytest.mark.parametrize("gpb", [1, 4, 16])
 def test_spmm_blockdiag_bit_identical(F, ld, gpb, dev):

@@ -18,10 +18,16 @@ def knob(name, v):
 
 
 def time_once(fn, iters):
+    """per-launch time of `iters` launches replayed from one HIP graph (eager Python launches cost ~10 us of host
+    time each and would hide any kernel shorter than that)"""
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / iters
@@ -46,6 +52,23 @@ def main():
         ip, ix = ops.csr_from_coo(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n)
         shapes["pubmed500"] = (ip, ix, n, 500, 500)
         shapes["pubmed32"] = (ip, ix, n, 32, 32)
+        shapes["pubmed500a"] = (ip, ix, n, 500, 512)   # rows padded to whole 128-byte lines
+        shapes["pubmed500b"] = (ip, ix, n, 500, 544)   # ... and an odd number of lines per row
+        shapes["pubmed500c"] = (ip, ix, n, 500, 576)   # 18 lines
+    if any(s.startswith("preg") for s in want):     # random graph, every row exactly 4 / 8 in-edges
+        n = 19717
+        rng = np.random.default_rng(2)
+        for dg in (4, 8):
+            dstr = np.repeat(np.arange(n, dtype=np.int64), dg)
+            srcr = rng.integers(0, n, dstr.size)
+            ipr, ixr = ops.csr_from_coo(torch.from_numpy(dstr).to(dev), torch.from_numpy(srcr).to(dev), n, n)
+            shapes[f"preg{dg}_500a"] = (ipr, ixr, n, 500, 512)
+    for nm, Fd in (("cora", 1433), ("citeseer", 3703)):
+        if any(s.startswith(nm) for s in want):
+            n, src, dst, _ = W.citation_graph(nm)
+            ip, ix = ops.csr_from_coo(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n)
+            shapes[f"{nm}{Fd}"] = (ip, ix, n, Fd, (Fd + 3) // 4 * 4)
+            shapes[f"{nm}{Fd}a"] = (ip, ix, n, Fd, (Fd + 31) // 32 * 32)
     if any(s.startswith("pband") for s in want) or any(s.startswith("pself") for s in want):
         n, src, dst, _ = W.citation_graph("pubmed")
         rng = np.random.default_rng(1)
@@ -82,27 +105,34 @@ def main():
         print(f"rmat plan: thr={args.thr} seg={args.seg} heavy rows={pl.n_heavy} segments={pl.n_segments}")
     variants = []
     for v in args.variants.split(","):
+        # name:rpg:nt:tile_vecs:opts   opts = letters: e = packed neighbour table, t = GAE_SPMM_TILE, p = store pad,
+        #                              b = block-diagonal kernel
         parts = v.split(":")
         name, rpg, nt = parts[:3]
         tv = int(parts[3]) if len(parts) > 3 else 0
-        nbw = int(parts[4]) if len(parts) > 4 else 4
-        variants.append((v, 1 if name == "v1" else 2, int(rpg), int(nt), tv, nbw))
+        opts = parts[4] if len(parts) > 4 else ""
+        variants.append((v, 1 if name == "v1" else 2, int(rpg), int(nt), tv, opts))
+    ell_plans = {}
     for sname in want:
         ip, ix, n, F, ld = shapes[sname]
         H = torch.rand(n, ld, device=dev)[:, :F]
         out = torch.empty(n, ld, device=dev)[:, :F]
         nnz = int(ix.numel())
         alg = W.spmm_alg_bytes(n, n, nnz, F)
-        iters = max(3, min(200, int(2e-2 / max(alg / 3e12, 1e-6))))
+        iters = max(3, min(100, int(2e-2 / max(alg / 3e12, 1e-6))))
         res = {v[0]: [] for v in variants}
         ref = None
         for rnd in range(args.rounds + 1):
-            for (label, var, rpg, nt, tv, nbw) in variants:
+            for (label, var, rpg, nt, tv, opts) in variants:
                 knob("spmm_variant", var); knob("spmm_rpg", rpg); knob("spmm_nt", nt); knob("spmm_tile_vecs", tv)
-                knob("spmm_nb", nbw)
-                fn = lambda: ops.spmm_raw(ip, ix, H, n, out=out, plan=plans.get(sname),
-                                          out_padded="sp" in label.split(":")[-1],
-                                          blockdiag=bdiag.get(sname) if "bd" in label.split(":")[-1] else None)
+                plan = plans.get(sname)
+                if "e" in opts and plan is None:
+                    if id(ip) not in ell_plans:
+                        ell_plans[id(ip)] = ops.spmm_plan(ip, indices=ix, ell=True)
+                    plan = ell_plans[id(ip)]
+                fn = lambda: ops.spmm_raw(ip, ix, H, n, out=out, plan=plan, out_padded="p" in opts,
+                                          scattered="t" in opts,
+                                          blockdiag=bdiag.get(sname) if "b" in opts else None)
                 fn(); torch.cuda.synchronize()
                 if rnd == 0:
                     if ref is None:

@@ -22,7 +22,8 @@ for kv in filter(None, a.knobs.split(",")):
 if a.shape.startswith("pubmed"):
     n, src, dst, _ = W.citation_graph("pubmed")
     s, d = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
-    F = int(a.shape[6:]); ld = F
+    al = a.shape.endswith("a")
+    F = int(a.shape[6:].rstrip("a")); ld = (F + 31) // 32 * 32 if al else F
 elif a.shape.startswith("zinc"):
     gp, src, dst, _ = W.zinc_like(249455)
     n = int(gp[-1])
