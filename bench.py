@@ -167,7 +167,7 @@ class CitationWorkload:
         ip, ix = self.g.csr()
         out = ops.pad_rows(torch.empty(self.Xd.shape, device=self.dev))
         plan = self.g.spmm_plan(False)
-        sc = self.Xd.shape[1] > ops.TILE_MIN_F and self.g.scattered()
+        sc = self.Xd.shape[1] > ops.TILE_MIN_F and self.g.scattered(self.Xd.shape[1] * 4)
         return lambda: ops.spmm_raw(ip, ix, self.Xd, self.n, out=out, plan=plan, out_padded=True, scattered=sc)
 
     def capture(self):

@@ -107,23 +107,23 @@ __global__ __launch_bounds__(256) void bce_prepare_kernel(const float *__restric
 }
 
 // one block: ordered sum of the per-block column sums -> S_all / S_win (double) and S_all as float.
-// 256 threads = DP columns x (256 / DP) interleaved block partitions, combined in LDS in fixed order.
-__global__ __launch_bounds__(256) void bce_colsum_kernel(const double *__restrict__ colsum_partial, int64_t n_blocks,
-                                                         int DP, double *__restrict__ S /*[2][DP]*/,
-                                                         float *__restrict__ S_all_f /*[DP]*/)
+// 256 threads = DP columns x (256 / DP) interleaved block partitions, combined in LDS (`red`, 2 x 256 doubles)
+// in fixed order.  Runs as one extra block of the dense launch (nothing in that kernel reads its result).
+__device__ __forceinline__ void bce_colsum_block(const double *__restrict__ colsum_partial, int64_t n_blocks, int DP,
+                                                 double *__restrict__ S /*[2][DP]*/,
+                                                 float *__restrict__ S_all_f /*[DP]*/, double *red /*LDS*/)
 {
-    __shared__ double red[2][256];
     const int k = threadIdx.x % DP, q = threadIdx.x / DP, nq = 256 / DP;
     double a = 0.0, w = 0.0;
     for (int64_t b = q; b < n_blocks; b += nq) {
         a += colsum_partial[(b * 2 + 0) * DP + k];
         w += colsum_partial[(b * 2 + 1) * DP + k];
     }
-    red[0][threadIdx.x] = a; red[1][threadIdx.x] = w;
+    red[threadIdx.x] = a; red[256 + threadIdx.x] = w;
     __syncthreads();
     if (threadIdx.x < DP) {
         a = 0.0; w = 0.0;
-        for (int j = 0; j < nq; ++j) { a += red[0][j * DP + k]; w += red[1][j * DP + k]; }
+        for (int j = 0; j < nq; ++j) { a += red[j * DP + k]; w += red[256 + j * DP + k]; }
         S[k] = a; S[DP + k] = w;
         S_all_f[k] = float(a);
     }
@@ -153,7 +153,9 @@ template <int KS, bool WITH_GRAD, int RI, int MINW, bool SBF16, bool PBF16>
 __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     const float *__restrict__ Zt /*[n][16 KS]*/, const unsigned short *__restrict__ Zhi,
     const unsigned short *__restrict__ Zlo, int64_t n, int64_t row_begin, int64_t n_local, int64_t cols_per_split,
-    float *__restrict__ O_partial /*[splits][n_local][KS*16]*/, double *__restrict__ loss_partial /*[blocks][2]*/)
+    float *__restrict__ O_partial /*[splits][n_local][KS*16]*/, double *__restrict__ loss_partial /*[blocks][2]*/,
+    const double *__restrict__ colsum_partial, int64_t n_prep_blocks, double *__restrict__ S,
+    float *__restrict__ S_all_f, unsigned n_row_blocks)
 {
     constexpr int ROWS_PER_BLOCK = 4 * RI * 16;
     constexpr int DP = KS * 16;          // padded feature width
@@ -171,6 +173,14 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     __shared__ __attribute__((aligned(16))) unsigned short LT[2][NEED_T ? DP * LDT : 4];     // bf16 lo [k][j]
     __shared__ double red[4][2];
 
+    if (blockIdx.x >= n_row_blocks) {   // the extra block column: column sums of Zt for the kernels that follow
+        static_assert(sizeof(Hs) >= 4096 || sizeof(Zs) >= 4096, "column-sum scratch aliases a staging tile");
+        if (blockIdx.y == 0)
+            bce_colsum_block(colsum_partial, n_prep_blocks, DP, S, S_all_f,
+                             reinterpret_cast<double *>(sizeof(Hs) >= 4096 ? static_cast<void *>(&Hs[0][0])
+                                                                           : static_cast<void *>(&Zs[0][0])));
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     // rows are LOCAL ids (0 .. n_local) of the window [row_begin, row_begin + n_local) of Zt
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     if (lane == 0) { red[wave][0] = la; red[wave][1] = ll; }
     __syncthreads();
     if (tid == 0) {
-        const int64_t b = int64_t(blockIdx.y) * gridDim.x + blockIdx.x;
+        const int64_t b = int64_t(blockIdx.y) * n_row_blocks + blockIdx.x;
         loss_partial[2 * b + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
         loss_partial[2 * b + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
@@ -413,67 +423,93 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
     const bool rowv = i < n;
     const bool fv = f0 < DP;     // lanes beyond the padded width idle (LPR is a power of two >= DP / 4)
 
-    float zi[VEC], acc[VEC];
+    // Everything that does not depend on the neighbour gathers is requested first (row of Zt, both edge ranges,
+    // the dense kernel's partial O' rows): the kernel is a chain of dependent round trips, not a byte stream.
+    float zi[VEC], acc_in[VEC], acc_out[VEC];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     {
-        const f32x4 t = (rowv && fv) ? *reinterpret_cast<const f32x4 *>(Zt + gi * DP + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 t = (rowv && fv) ? *reinterpret_cast<const f32x4 *>(Zt + gi * DP + f0) : zero4;
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) { acc[q] = 0.f; zi[q] = t[q]; }
+        for (int q = 0; q < VEC; ++q) { acc_in[q] = acc_out[q] = 0.f; zi[q] = t[q]; }
+    }
+    int32_t posA = rowv ? indptr[i] : 0;
+    const int32_t endA = rowv ? indptr[i + 1] : 0;
+    int32_t posB = (WITH_GRAD && rowv) ? t_indptr[i] : 0;
+    const int32_t endB = (WITH_GRAD && rowv) ? t_indptr[i + 1] : 0;
+    f32x4 osum = zero4;
+    if (WITH_GRAD && rowv && fv) {
+        const float *op = O_partial + i * DP + f0;
+        const int64_t sstride = n * DP;
+        int sp = 0;
+        for (; sp + 4 <= n_splits; sp += 4) {        // 4 independent loads per trip, added in split order
+            const f32x4 o0 = *reinterpret_cast<const f32x4 *>(op + (sp + 0) * sstride);
+            const f32x4 o1 = *reinterpret_cast<const f32x4 *>(op + (sp + 1) * sstride);
+            const f32x4 o2 = *reinterpret_cast<const f32x4 *>(op + (sp + 2) * sstride);
+            const f32x4 o3 = *reinterpret_cast<const f32x4 *>(op + (sp + 3) * sstride);
+            osum = (((osum + o0) + o1) + o2) + o3;
+        }
+        for (; sp < n_splits; ++sp) osum += *reinterpret_cast<const f32x4 *>(op + sp * sstride);
     }
     double lsum = 0.0;
-    // In-edges (CSR: loss + G_s Zt) then out-edges (CSR of A^T: G_s^T Zt) of node i, 4 edges per batch:
-    // the 4 neighbour ids come from one coalesced load, the 4 neighbour rows are all in flight before
-    // the first dot product (one memory round trip per batch instead of one per edge).
-    auto sweep = [&](const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx, bool with_loss) {
-        int32_t pos = rowv ? ptr[i] : 0;
-        const int32_t end = rowv ? ptr[i + 1] : 0;
-        const int glane0 = (lane / LPR) * LPR;
-        while (pos < end) {
-            const int32_t e = pos + (LPR >= 4 ? (lig & 3) : 0);
-            const int32_t mine = e < end ? idx[e] : 0;
-            float zj[4][VEC], dot[4];
+    // In-edges (CSR: loss + G_s Zt) and out-edges (CSR of A^T: G_s^T Zt) of node i advance TOGETHER, 4 edges of
+    // each per trip: the ids come from one coalesced load per list, the 8 neighbour rows are all in flight before
+    // the first dot product (one memory round trip per trip for both lists).
+    const int glane0 = (lane / LPR) * LPR;
+    while (posA < endA || posB < endB) {
+        const int32_t eA = posA + (LPR >= 4 ? (lig & 3) : 0), eB = posB + (LPR >= 4 ? (lig & 3) : 0);
+        const int32_t mineA = eA < endA ? indices[eA] : 0;
+        const int32_t mineB = (WITH_GRAD && eB < endB) ? t_indices[eB] : 0;
+        float zj[8][VEC], dot[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int32_t j = LPR >= 4 ? __shfl(mine, glane0 + u, 64) : (pos + u < end ? idx[pos + u] : 0);
-                const bool ev = pos + u < end;
-                dot[u] = 0.f;
-                const f32x4 t = (ev && fv) ? *reinterpret_cast<const f32x4 *>(Zt + int64_t(j) * DP + f0)
-                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 8; ++u) {
+            const bool second = u >= 4;
+            if (second && !WITH_GRAD) { dot[u] = 0.f; continue; }
+            const int32_t pos = second ? posB : posA, end = second ? endB : endA;
+            const int32_t mine = second ? mineB : mineA;
+            const int uu = u & 3;
+            const int32_t j = LPR >= 4 ? __shfl(mine, glane0 + uu, 64)
+                                       : (pos + uu < end ? (second ? t_indices : indices)[pos + uu] : 0);
+            const bool ev = pos + uu < end;
+            dot[u] = 0.f;
+            const f32x4 t = (ev && fv) ? *reinterpret_cast<const f32x4 *>(Zt + int64_t(j) * DP + f0) : zero4;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                zj[u][q] = t[q];
+                dot[u] = fmaf(zi[q], t[q], dot[u]);
+            }
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1)
+#pragma unroll
+            for (int u = 0; u < (WITH_GRAD ? 8 : 4); ++u) dot[u] += __shfl_xor(dot[u], off, 64);
+#pragma unroll
+        for (int u = 0; u < (WITH_GRAD ? 8 : 4); ++u) {
+            const bool second = u >= 4;
+            const int32_t pos = second ? posB : posA, end = second ? endB : endA;
+            if (pos + (u & 3) < end) {
+                const float x = dot[u];
+                float spn, sgn;               // softplus(-x), sigmoid(-x)
+                softplus_sigmoid(-x, spn, sgn);
+                const float sg = 1.0f - sgn;  // sigmoid(x)
+                if (!second && lig == 0) lsum += double(-x + (pw - 1.0f) * spn);
+                const float c = (pw - 1.0f) * sg - pw;
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) {
-                    zj[u][q] = t[q];
-                    dot[u] = fmaf(zi[q], t[q], dot[u]);
+                    if (second) acc_out[q] = fmaf(c, zj[u][q], acc_out[q]);
+                    else acc_in[q] = fmaf(c, zj[u][q], acc_in[q]);
                 }
             }
-#pragma unroll
-            for (int off = LPR / 2; off > 0; off >>= 1)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) dot[u] += __shfl_xor(dot[u], off, 64);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (pos + u < end) {
-                    const float x = dot[u];
-                    float spn, sgn;               // softplus(-x), sigmoid(-x)
-                    softplus_sigmoid(-x, spn, sgn);
-                    const float sg = 1.0f - sgn;  // sigmoid(x)
-                    if (with_loss && lig == 0) lsum += double(-x + (pw - 1.0f) * spn);
-                    const float c = (pw - 1.0f) * sg - pw;
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) acc[q] = fmaf(c, zj[u][q], acc[q]);
-                }
-            }
-            pos += 4;
         }
-    };
-    sweep(indptr, indices, true);
-    if (WITH_GRAD) sweep(t_indptr, t_indices, false);
+        posA = min(posA + 4, endA);
+        posB = min(posB + 4, endB);
+    }
     if (WITH_GRAD && rowv) {
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             const int f = f0 + q;
             if (f < d) {
-                float o = 0.5f * S_all_f[f];
-                for (int s = 0; s < n_splits; ++s) o += O_partial[(int64_t(s) * n + i) * DP + f];
-                float v = (2.0f * o + acc[q]) * inv_n2;
+                const float o = 0.5f * S_all_f[f] + osum[q];
+                float v = (2.0f * o + (acc_in[q] + acc_out[q])) * inv_n2;
                 if (mask) v *= mask[gi * ldz + f];
                 dZ[i * lddz + f] = v;
             }
@@ -569,17 +605,20 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
 
 template <bool WITH_GRAD>
 int launch_dense(const BcePlan &p, const float *Zt, const unsigned short *Zhi, const unsigned short *Zlo, int64_t n,
-                 int64_t row_begin, int64_t n_local, float *O, double *lp, hipStream_t s)
+                 int64_t row_begin, int64_t n_local, float *O, double *lp, const double *cs, double *S, float *S_all_f,
+                 hipStream_t s)
 {
-    const dim3 grid(unsigned(p.row_blocks), unsigned(p.n_splits));
+    const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
 #define GAE_BD(KS, RI, MW, SB)                                                                                     \
     do {                                                                                                           \
         if (SB && g_bce_pv_bf16)                                                                                   \
             hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW, SB, SB>), grid, dim3(256), 0, s, Zt, Zhi,  \
-                               Zlo, n, row_begin, n_local, p.cols_per_split, O, lp);                               \
+                               Zlo, n, row_begin, n_local, p.cols_per_split, O, lp, cs, p.prep_blocks, S, S_all_f, \
+                               unsigned(p.row_blocks));                                                            \
         else                                                                                                       \
             hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW, SB, false>), grid, dim3(256), 0, s, Zt,    \
-                               Zhi, Zlo, n, row_begin, n_local, p.cols_per_split, O, lp);                          \
+                               Zhi, Zlo, n, row_begin, n_local, p.cols_per_split, O, lp, cs, p.prep_blocks, S,     \
+                               S_all_f, unsigned(p.row_blocks));                                                   \
     } while (0)
     const bool sb = g_bce_s_bf16 != 0;
     if (p.KS == 1) {
@@ -679,10 +718,8 @@ extern "C" int gae_decoder_bce_rows(const float *Z, const float *mask, int64_t l
     hipLaunchKernelGGL(bce_prepare_kernel, dim3(unsigned(p.prep_blocks)), dim3(256), 0, s, Z, mask, ldz, n, int(d), p.DP,
                        row_begin, row_begin + n_local, Zt, Zhi, Zlo, cs);
     GAE_CHECK_LAUNCH("bce_prepare_kernel");
-    hipLaunchKernelGGL(bce_colsum_kernel, dim3(1), dim3(256), 0, s, cs, p.prep_blocks, p.DP, S, S_all_f);
-    GAE_CHECK_LAUNCH("bce_colsum_kernel");
-    int rc = dZ ? launch_dense<true>(p, Zt, Zhi, Zlo, n, row_begin, n_local, O, lp, s)
-                : launch_dense<false>(p, Zt, Zhi, Zlo, n, row_begin, n_local, O, lp, s);
+    int rc = dZ ? launch_dense<true>(p, Zt, Zhi, Zlo, n, row_begin, n_local, O, lp, cs, S, S_all_f, s)
+                : launch_dense<false>(p, Zt, Zhi, Zlo, n, row_begin, n_local, O, lp, cs, S, S_all_f, s);
     if (rc) return rc;
     double *lpe = lp + 2 * p.n_dense;
     rc = dZ ? launch_edges<4, true>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr, t_indices,

@@ -22,7 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
 int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
-int g_atb_rows = 256;   // tuning knob: rows per block (= per partial) of the dW kernel; 4 waves x 64 rows
+int g_atb_rows = 256;   // tuning knob: rows per block (= per partial) of the dW kernel; 8 waves x 32 rows
 
 // ---------------------------------------------------------------------------
 // out[n, J] = epi( proA(A)[n, K] * proB(B) )      B given as [J, K] (BT) or [K, J]
@@ -359,27 +359,33 @@ int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t 
 // ---------------------------------------------------------------------------
 // out[O, I] (+)= sum_r proP(P)[r, O]^T Q[r, I]   -- reduction over rows.
 // Both operands are read in their natural row-major layout straight into the
-// MFMA fragments (lane = column, k = row parity): no LDS.  Each wave owns a row
-// slot and one 32 x (IT*32) output tile and writes a partial; a second kernel
-// sums the partials in slot order (deterministic, no float atomics).
+// MFMA fragments (lane = column, k = row parity): no LDS in the row loop.  A block
+// of NW waves owns one row slot and one 32 x (IT*32) output tile: the waves split
+// the slot's rows (NW = 8: twice the loads in flight per partial of the 4-wave
+// form, and a second wave per SIMD whose MFMAs cover the other's memory waits),
+// meet in LDS in a fixed tree order and write ONE partial; a second kernel sums
+// the partials in slot order (deterministic, no float atomics).
 // ---------------------------------------------------------------------------
-template <int IT, int PRO_P, bool QVEC>
-__global__ __launch_bounds__(256) void atb_partial_kernel(
+template <int IT, int PRO_P, bool QVEC, int NW>
+__global__ __launch_bounds__(NW * 64) void atb_partial_kernel(
     const float *__restrict__ P, int64_t ldp, const float *__restrict__ Pmask, int64_t ldpm,
     const float *__restrict__ Q, int64_t ldq, int64_t n, int O, int I, int64_t rows_per_slot,
-    float *__restrict__ partial, float *__restrict__ colsum_partial)
+    float *__restrict__ partial, int64_t slot_stride, int64_t colsum_offset)
 {
     // IT == 4: lane j owns the 4 adjacent columns 4j..4j+3 of a 128-column group (one float4 per row, tile t =
     //          column 4j + t);  IT == 1: lane j owns column j of a 32-column group (narrow outputs).
     static_assert(IT == 4 || IT == 1, "IT is 1 or 4");
     static_assert(!QVEC || IT == 4, "the float4 path needs IT == 4");
-    __shared__ float red[3][IT * 16 * 64 + 64];     // waves 1..3 park their accumulators (+ column sums) here
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t slot = blockIdx.x;                 // one partial per BLOCK: its 4 waves split the slot's rows
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    constexpr int PARK = IT * 16 * 64 + 64;          // accumulators + column sums of one parked wave
+    __shared__ float red[NW / 2][PARK];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t slot = blockIdx.x;                 // one partial per BLOCK: its waves split the slot's rows
     const int j = lane & 31, h = lane >> 5;
     const int o = blockIdx.z * 32 + j;
     const int cb = blockIdx.y * (IT * 32) + (IT == 4 ? 4 * j : j);   // tile t of this lane is column cb + t
-    const int64_t rows_per_wave = rows_per_slot / 4;                  // multiple of 8
+    const int64_t rows_per_wave = rows_per_slot / NW;                 // multiple of 8
     const int64_t r_begin = slot * rows_per_slot + wave * rows_per_wave;
     int64_t r_end = r_begin + rows_per_wave;
     if (r_end > n) r_end = n;
@@ -397,7 +403,8 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(
     struct Stage { float a[4], m[4]; float b[4][IT]; };
     const int64_t r_last = r_end - 1;                       // r_begin < r_end whenever anything is loaded
     const int oc = o < O ? o : O - 1;
-    const int cbc = QVEC ? (cb + 4 <= I ? cb : I - 4) : 0;  // QVEC: I % 4 == 0, a lane's 4 columns are all in or all out
+    const int I4 = (I + 3) & ~3;                            // QVEC: ldq >= I4, columns [I, I4) are row padding
+    const int cbc = QVEC ? (cb + 4 <= I4 ? cb : I4 - 4) : 0;
     auto load = [&](Stage &st, int64_t r0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -446,83 +453,102 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(
         }
 #undef GAE_PIN
     }
-    // ---- block reduction in fixed wave order (0 + 1 + 2 + 3): waves 1..3 park, wave 0 adds and stores
+    // ---- block reduction, fixed tree order: (w) += (w + half) for half = NW/2, NW/4, ... 1
     csum += __shfl_down(csum, 32, 64);
-    if (wave > 0) {
-        float *rp = red[wave - 1];
 #pragma unroll
-        for (int t = 0; t < IT; ++t)
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+            float *rp = red[wave - half];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rp[(t * 16 + r) * 64 + lane] = acc[t][r];
-        rp[IT * 16 * 64 + lane] = csum;
+            for (int t = 0; t < IT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rp[(t * 16 + r) * 64 + lane] = acc[t][r];
+            rp[IT * 16 * 64 + lane] = csum;
+        }
+        __syncthreads();
+        if (wave < half) {
+            const float *rp = red[wave];
+#pragma unroll
+            for (int t = 0; t < IT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += rp[(t * 16 + r) * 64 + lane];
+            csum += rp[IT * 16 * 64 + lane];
+        }
+        if (half > 1) __syncthreads();
     }
-    __syncthreads();
     if (wave != 0) return;
+    // partial[slot][O][I] (+ [O] column sums at colsum_offset); lane j holds columns cb..cb+IT-1 of row oo
+    float *pp = partial + slot * slot_stride;
+    const bool full = blockIdx.z * 32 + 32 <= O && (QVEC ? cb + 4 <= I && (I & 3) == 0 : false);
+    if (full) {      // whole tile inside the output: unconditional 16-byte stores
 #pragma unroll
-    for (int w = 0; w < 3; ++w) {
+        for (int r = 0; r < 16; ++r) {
+            const int oo = blockIdx.z * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            *reinterpret_cast<float4 *>(pp + int64_t(oo) * I + cb) =
+                make_float4(acc[0][r], acc[IT > 1 ? 1 : 0][r], acc[IT > 2 ? 2 : 0][r], acc[IT > 3 ? 3 : 0][r]);
+        }
+    } else {
 #pragma unroll
-        for (int t = 0; t < IT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] += red[w][(t * 16 + r) * 64 + lane];
-        csum += red[w][IT * 16 * 64 + lane];
-    }
-    // partial[slot][O][I]; lane j holds columns cb..cb+IT-1 of output row oo in acc[0..IT-1][r]
-    float *pp = partial + slot * int64_t(O) * I;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int oo = blockIdx.z * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (oo >= O) continue;
-        float *dst = pp + int64_t(oo) * I + cb;
-        if (QVEC && cb + 4 <= I) {
-            *reinterpret_cast<float4 *>(dst) = make_float4(acc[0][r], acc[IT > 1 ? 1 : 0][r], acc[IT > 2 ? 2 : 0][r],
-                                                           acc[IT > 3 ? 3 : 0][r]);
-        } else {
+        for (int r = 0; r < 16; ++r) {
+            const int oo = blockIdx.z * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (oo >= O) continue;
+            float *dst = pp + int64_t(oo) * I + cb;
 #pragma unroll
             for (int t = 0; t < IT; ++t)
                 if (cb + t < I) dst[t] = acc[t][r];
         }
     }
-    if (colsum_partial && blockIdx.y == 0 && h == 0 && o < O) colsum_partial[slot * O + o] = csum;
+    if (colsum_offset >= 0 && blockIdx.y == 0 && h == 0 && o < O) pp[colsum_offset + o] = csum;
 }
 
-// out[e] = sum_slot partial[slot][e]  (+ optional accumulate into out, optional mask multiply).
-// 64 elements per block; the 4 waves take slots q, q+4, q+8, ... and meet in LDS in fixed order.
-__global__ __launch_bounds__(256) void reduce_slots_kernel(const float *__restrict__ partial, int64_t n_slots,
-                                                           int64_t n_elems, float *__restrict__ out,
-                                                           int64_t out_cols, int64_t ldo, int accumulate,
-                                                           const float *__restrict__ mulmask, int64_t ldmask)
+// out[e] = sum_slot partial[slot * slot_stride + e]  (+ optional accumulate into out, optional mask multiply);
+// elements e >= n_first go to out2[e - n_first] (the column sums parked behind a slot's tile).
+// 64 elements per block of 16 waves; wave q takes slots q, q + 16, ... (independent loads, all in flight) and the
+// waves meet in LDS in fixed order.
+__global__ __launch_bounds__(1024) void reduce_slots_kernel(const float *__restrict__ partial, int64_t n_slots,
+                                                            int64_t slot_stride, int64_t n_elems,
+                                                            float *__restrict__ out, int64_t out_cols, int64_t ldo,
+                                                            int accumulate, const float *__restrict__ mulmask,
+                                                            int64_t ldmask, float *__restrict__ out2, int64_t n_first)
 {
-    __shared__ float red[4][64];
+    __shared__ float red[16][64];
     const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
     for (int64_t base = int64_t(blockIdx.x) * 64; base < n_elems; base += int64_t(gridDim.x) * 64) {
         const int64_t e = base + el;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (e < n_elems) {
             int64_t k = q;
-            for (; k + 12 < n_slots; k += 16) {
-                const float v0 = partial[k * n_elems + e], v1 = partial[(k + 4) * n_elems + e];
-                const float v2 = partial[(k + 8) * n_elems + e], v3 = partial[(k + 12) * n_elems + e];
+            for (; k + 48 < n_slots; k += 64) {
+                const float v0 = partial[k * slot_stride + e], v1 = partial[(k + 16) * slot_stride + e];
+                const float v2 = partial[(k + 32) * slot_stride + e], v3 = partial[(k + 48) * slot_stride + e];
                 s0 += v0; s1 += v1; s2 += v2; s3 += v3;
             }
-            for (; k < n_slots; k += 4) s0 += partial[k * n_elems + e];
+            for (; k < n_slots; k += 16) s0 += partial[k * slot_stride + e];
         }
         red[q][el] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (q == 0 && e < n_elems) {
-            float s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
-            const int64_t r = e / out_cols, c = e - r * out_cols;
-            float *op = out + r * ldo + c;
-            if (accumulate) s += *op;
-            if (mulmask) s *= mulmask[r * ldmask + c];
-            *op = s;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) s += red[w][el];
+            if (out2 && e >= n_first) {
+                out2[e - n_first] = s;
+            } else {
+                const int64_t r = e / out_cols, c = e - r * out_cols;
+                float *op = out + r * ldo + c;
+                if (accumulate) s += *op;
+                if (mulmask) s *= mulmask[r * ldmask + c];
+                *op = s;
+            }
         }
         __syncthreads();
     }
 }
 
-// dst[i, k] = (dst[i, k] + sum_slot partial[slot][k][i]) * mask[i, k]   (partial is [slots][d][n])
+// dst[i, k] = (dst[i, k] + sum_slot partial[slot][k][i]) * mask[i, k]   (a slot holds [d][n] at slot_stride floats)
 __global__ __launch_bounds__(256) void reduce_slots_transposed_kernel(const float *__restrict__ partial,
-                                                                      int64_t n_slots, int64_t d, int64_t n,
+                                                                      int64_t n_slots, int64_t slot_stride,
+                                                                      int64_t d, int64_t n,
                                                                       float *__restrict__ dst, int64_t ldd,
                                                                       const float *__restrict__ mask, int64_t ldmask)
 {
@@ -531,7 +557,7 @@ __global__ __launch_bounds__(256) void reduce_slots_transposed_kernel(const floa
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int64_t k = e / n, i = e - k * n;  // consecutive threads -> consecutive i (coalesced partial reads)
         float s = 0.f;
-        for (int64_t q = 0; q < n_slots; ++q) s += partial[q * total + e];
+        for (int64_t q = 0; q < n_slots; ++q) s += partial[q * slot_stride + e];
         float v = dst[i * ldd + k] + s;
         if (mask) v *= mask[i * ldmask + k];
         dst[i * ldd + k] = v;
@@ -539,14 +565,14 @@ __global__ __launch_bounds__(256) void reduce_slots_transposed_kernel(const floa
 }
 
 struct AtbPlan {
-    int64_t n_slots, rows_per_slot, blocks;
+    int64_t n_slots, rows_per_slot, blocks, slot_stride;   // slot_stride: floats per partial (tile + column sums)
 };
 
-// shared by the workspace query and the launcher: one slot (= one partial) per block of 4 waves
+// shared by the workspace query and the launcher: one slot (= one partial) per block of 8 waves
 AtbPlan atb_plan(int64_t n, int64_t O, int64_t I)
 {
     AtbPlan p;
-    int64_t want = (n + g_atb_rows - 1) / g_atb_rows;  // ~128 rows per block, 32 per wave
+    int64_t want = (n + g_atb_rows - 1) / g_atb_rows;  // ~256 rows per block, 32 per wave
     int64_t cap = (int64_t(32) << 20) / (O * I > 0 ? O * I : 1);  // <= 128 MiB of partials
     if (cap > 4096) cap = 4096;
     if (cap < 1) cap = 1;
@@ -555,24 +581,30 @@ AtbPlan atb_plan(int64_t n, int64_t O, int64_t I)
     p.blocks = want;
     p.n_slots = want;
     int64_t rps = (n + p.n_slots - 1) / p.n_slots;
-    rps = (rps + 31) / 32 * 32;                      // 4 waves x a multiple of 8 rows
-    if (rps < 32) rps = 32;
+    rps = (rps + 63) / 64 * 64;                      // 8 waves x a multiple of 8 rows
+    if (rps < 64) rps = 64;
     p.rows_per_slot = rps;
+    p.n_slots = p.blocks = (n + rps - 1) / rps > 0 ? (n + rps - 1) / rps : 1;
+    p.slot_stride = (O * I + O + 3) / 4 * 4;         // [O][I] tile, then [O] column sums; 16-byte aligned slots
     return p;
 }
 
 template <int PRO_P>
 int launch_atb(const float *P, int64_t ldp, const float *Pmask, int64_t ldpm, const float *Q, int64_t ldq,
-               int64_t n, int O, int I, float *partial, float *colsum_partial, const AtbPlan &pl, hipStream_t s)
+               int64_t n, int O, int I, float *partial, bool colsum, const AtbPlan &pl, hipStream_t s)
 {
     const bool narrow = I <= 32;                     // one 32-column tile: no 4-tile float4 mapping needed
     const int cols_per_block = narrow ? 32 : 128;
     const unsigned gy = I > 0 ? unsigned((I + cols_per_block - 1) / cols_per_block) : 1u;  // I == 0: column sums only
     const dim3 grid(unsigned(pl.blocks), gy, unsigned((O + 31) / 32));
-    const bool qvec = !narrow && (ldq % 4 == 0) && gae::aligned16(Q) && (I % 4 == 0) && I >= 4 && gae::aligned16(partial);
+    // float4 loads of Q: 16-byte aligned rows that reach the next multiple of 4 columns (row padding past I is
+    // read but never used)
+    const bool qvec = !narrow && (ldq % 4 == 0) && gae::aligned16(Q) && ldq >= ((I + 3) & ~3) && I >= 4 &&
+                      gae::aligned16(partial);
+    const int64_t cso = colsum ? int64_t(O) * I : -1;
 #define GAE_ATB(IT, QV)                                                                                             \
-    hipLaunchKernelGGL((atb_partial_kernel<IT, PRO_P, QV>), grid, dim3(256), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n, O, \
-                       I, pl.rows_per_slot, partial, colsum_partial)
+    hipLaunchKernelGGL((atb_partial_kernel<IT, PRO_P, QV, 8>), grid, dim3(512), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n, \
+                       O, I, pl.rows_per_slot, partial, pl.slot_stride, cso)
     if (narrow) GAE_ATB(1, false);
     else if (qvec) GAE_ATB(4, true);
     else GAE_ATB(4, false);
@@ -581,14 +613,16 @@ int launch_atb(const float *P, int64_t ldp, const float *Pmask, int64_t ldpm, co
     return GAE_OK;
 }
 
-int launch_reduce(const float *partial, int64_t n_slots, int64_t n_elems, float *out, int64_t out_cols, int64_t ldo,
-                  int accumulate, const float *mulmask, int64_t ldmask, hipStream_t s)
+// out[r, c] = sum_slot partial[slot][r * out_cols + c] for the first n_first elements of a slot, out2[.] for the rest
+int launch_reduce(const float *partial, int64_t n_slots, int64_t slot_stride, int64_t n_elems, float *out,
+                  int64_t out_cols, int64_t ldo, int accumulate, const float *mulmask, int64_t ldmask, float *out2,
+                  int64_t n_first, hipStream_t s)
 {
     int64_t g = (n_elems + 63) / 64;
     if (g > 4096) g = 4096;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(reduce_slots_kernel, dim3(unsigned(g)), dim3(256), 0, s, partial, n_slots, n_elems, out,
-                       out_cols, ldo, accumulate, mulmask, ldmask);
+    hipLaunchKernelGGL(reduce_slots_kernel, dim3(unsigned(g)), dim3(1024), 0, s, partial, n_slots, slot_stride, n_elems,
+                       out, out_cols, ldo, accumulate, mulmask, ldmask, out2, n_first);
     GAE_CHECK_LAUNCH("reduce_slots_kernel");
     return GAE_OK;
 }
@@ -752,7 +786,7 @@ extern "C" int64_t gae_linear_bwd_workspace_bytes(int64_t n, int64_t f_in, int64
 {
     if (n < 0 || f_in < 0 || f_out < 0) return GAE_E_SIZE;
     const AtbPlan pl = atb_plan(n, f_out, f_in);
-    return align256(pl.n_slots * f_out * f_in * 4) + align256(pl.n_slots * f_out * 4) + 256;
+    return align256(pl.n_slots * pl.slot_stride * 4) + 256;
 }
 
 extern "C" int gae_linear_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, int act, const float *M,
@@ -772,33 +806,26 @@ extern "C" int gae_linear_bwd(const float *dY, int64_t lddy, const float *Y, int
     if (dW || db) {
         GAE_REQUIRE(!dW || (ldm >= f_in && (n == 0 || M)), GAE_E_NULL, "gae_linear_bwd: dW needs M");
         const AtbPlan pl = atb_plan(n, f_out, f_in);
-        const int64_t need = align256(pl.n_slots * f_out * f_in * 4) + align256(pl.n_slots * f_out * 4);
+        const int64_t need = align256(pl.n_slots * pl.slot_stride * 4);
         GAE_REQUIRE(workspace && workspace_bytes >= need, GAE_E_WORKSPACE,
                     "gae_linear_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+        GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_linear_bwd: workspace not 16-byte aligned");
         float *partial = static_cast<float *>(workspace);
-        float *cpartial = reinterpret_cast<float *>(static_cast<char *>(workspace) +
-                                                    align256(pl.n_slots * f_out * f_in * 4));
-        // dW = dYm^T M : P = dY [n, f_out] (O = f_out), Q = M [n, f_in] (I = f_in)
+        // dW = dYm^T M : P = dY [n, f_out] (O = f_out), Q = M [n, f_in] (I = f_in); the column sums of dYm (= db)
+        // ride behind each slot's tile and come out of the same reduction launch
         const float *Q = dW ? M : dY;  // db only: any readable Q, I = 0 tiles skipped
+        const int64_t ldq = dW ? ldm : lddy;
         const int I = dW ? int(f_in) : 0;
-        int rc;
-        if (I == 0) {
-            // column sums only: run with a single (masked-out) tile
-            rc = relu ? launch_atb<PRO_RELU_MASK>(dY, lddy, Y, ldy, Q, lddy, n, int(f_out), 0, partial, cpartial, pl, s)
-                      : launch_atb<PRO_NONE>(dY, lddy, nullptr, 0, Q, lddy, n, int(f_out), 0, partial, cpartial, pl, s);
-        } else {
-            rc = relu ? launch_atb<PRO_RELU_MASK>(dY, lddy, Y, ldy, Q, ldm, n, int(f_out), I, partial, db ? cpartial : nullptr, pl, s)
-                      : launch_atb<PRO_NONE>(dY, lddy, nullptr, 0, Q, ldm, n, int(f_out), I, partial, db ? cpartial : nullptr, pl, s);
-        }
+        int rc = relu ? launch_atb<PRO_RELU_MASK>(dY, lddy, Y, ldy, Q, ldq, n, int(f_out), I, partial, db != nullptr, pl, s)
+                      : launch_atb<PRO_NONE>(dY, lddy, nullptr, 0, Q, ldq, n, int(f_out), I, partial, db != nullptr, pl, s);
         if (rc) return rc;
-        if (dW) {
-            rc = launch_reduce(partial, pl.n_slots, f_out * f_in, dW, f_in, f_in, 0, nullptr, 0, s);
-            if (rc) return rc;
-        }
-        if (db) {
-            rc = launch_reduce(cpartial, pl.n_slots, f_out, db, f_out, f_out, 0, nullptr, 0, s);
-            if (rc) return rc;
-        }
+        const int64_t n_tile = f_out * I;
+        if (dW)
+            rc = launch_reduce(partial, pl.n_slots, pl.slot_stride, n_tile + (db ? f_out : 0), dW, f_in, f_in, 0, nullptr,
+                               0, db, n_tile, s);
+        else
+            rc = launch_reduce(partial, pl.n_slots, pl.slot_stride, f_out, db, f_out, f_out, 0, nullptr, 0, nullptr, 0, s);
+        if (rc) return rc;
     }
     if (dM && n > 0) {
         GAE_REQUIRE(lddm >= f_in && W, GAE_E_NULL, "gae_linear_bwd: dM needs W and lddm >= f_in");
@@ -847,7 +874,7 @@ extern "C" int64_t gae_decoder_dense_bwd_workspace_bytes(int64_t n, int64_t d)
 {
     if (n < 0 || d < 0) return GAE_E_SIZE;
     const AtbPlan pl = atb_plan(n, d, n);
-    return align256(pl.n_slots * n * d * 4) + 256;
+    return align256(pl.n_slots * pl.slot_stride * 4) + 256;
 }
 
 extern "C" int gae_decoder_dense_bwd(const float *G, int64_t ldg, const float *Z, const float *mask, int64_t ldz,
@@ -861,7 +888,7 @@ extern "C" int gae_decoder_dense_bwd(const float *G, int64_t ldg, const float *Z
     GAE_REQUIRE(G && Z && dZ, GAE_E_NULL, "gae_decoder_dense_bwd: NULL pointer");
     hipStream_t s = gae::as_stream(stream);
     const AtbPlan pl = atb_plan(n, d, n);
-    const int64_t need = align256(pl.n_slots * n * d * 4);
+    const int64_t need = align256(pl.n_slots * pl.slot_stride * 4);
     GAE_REQUIRE(workspace && workspace_bytes >= need, GAE_E_WORKSPACE,
                 "gae_decoder_dense_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     int rc;
@@ -876,15 +903,15 @@ extern "C" int gae_decoder_dense_bwd(const float *G, int64_t ldg, const float *Z
     // term 2: (G^T Zt)^T [d, n] = Zt^T G   (P = Z with the mask folded in, Q = G), partials per row slot
     float *partial = static_cast<float *>(workspace);
     if (mask)
-        rc = launch_atb<PRO_MUL_MASK>(Z, ldz, mask, ldz, G, ldg, n, int(d), int(n), partial, nullptr, pl, s);
+        rc = launch_atb<PRO_MUL_MASK>(Z, ldz, mask, ldz, G, ldg, n, int(d), int(n), partial, false, pl, s);
     else
-        rc = launch_atb<PRO_NONE>(Z, ldz, nullptr, 0, G, ldg, n, int(d), int(n), partial, nullptr, pl, s);
+        rc = launch_atb<PRO_NONE>(Z, ldz, nullptr, 0, G, ldg, n, int(d), int(n), partial, false, pl, s);
     if (rc) return rc;
     // dZ[i, k] = (dZ[i, k] + sum_slot partial[slot][k][i]) * mask[i, k]
     int64_t g = (n * d + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(reduce_slots_transposed_kernel, dim3(unsigned(g)), dim3(256), 0, s, partial, pl.n_slots, d, n,
-                       dZ, lddz, mask, ldz);
+    hipLaunchKernelGGL(reduce_slots_transposed_kernel, dim3(unsigned(g)), dim3(256), 0, s, partial, pl.n_slots,
+                       pl.slot_stride, d, n, dZ, lddz, mask, ldz);
     GAE_CHECK_LAUNCH("reduce_slots_transposed_kernel");
     return GAE_OK;
 }

@@ -174,13 +174,15 @@ class Graph:
             self._cache[key] = None if self.no_heavy_rows else ops.spmm_plan(indptr, indices=indices)
         return self._cache[key]
 
-    def scattered(self):
-        """True when the graph's gathers have poor locality (ops.gather_scattered); block-diagonal batches never"""
-        if "scattered" not in self._cache:
+    def scattered(self, row_bytes=2048):
+        """True when the gathers of rows of ``row_bytes`` bytes have poor locality (ops.gather_scattered);
+        block-diagonal batches never"""
+        if "gather_distance" not in self._cache:
             from . import ops
-            self._cache["scattered"] = (not self.no_heavy_rows and self.block_diag is None
-                                        and ops.gather_scattered(*self.csr()))
-        return self._cache["scattered"]
+            local = self.no_heavy_rows or self.block_diag is not None
+            self._cache["gather_distance"] = 0 if local else ops.gather_distance(*self.csr())
+        from . import ops
+        return ops.gather_scattered(None, None, row_bytes, distance=self._cache["gather_distance"])
 
     def set_csr(self, indptr, indices, t_indptr=None, t_indices=None):
         """adopt an already-built device CSR (used by the device dataset batcher)"""

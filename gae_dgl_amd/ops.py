@@ -200,8 +200,7 @@ SKEW_MIN_MAXDEG = 64     # graphs whose longest row is shorter need no plan (3 e
 
 
 TILE_MIN_F = 64          # XCD feature tiles are only considered for rows wider than one lane group (16 vectors)
-SCATTER_WINDOW = 1024    # a gather is "near" when |column id - row id| <= this many rows ...
-SCATTER_NEAR_FRAC = 0.5  # ... and a graph is scattered when fewer than this fraction of its gathers are near
+SCATTER_L2_BYTES = 2 << 20   # half of one XCD's 4 MiB L2: the window of H rows a row block can expect to find cached
 ELL_MAX_ROWS = 1 << 18   # packed neighbour table only for graphs whose launches are latency-bound, not byte-bound
 
 
@@ -254,18 +253,24 @@ def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None):
     return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh, table)
 
 
-def gather_scattered(indptr, indices):
-    """True when most column ids lie far from their row id: the neighbour rows of concurrently processed rows then
-    share nothing in L1 / L2 and wide launches do better with XCD feature tiles (GAE_SPMM_TILE).  One host
-    read-back; computed once per graph."""
+def gather_distance(indptr, indices):
+    """median |column id - row id| over the edges (0 for an edge-less graph).  One host read-back; computed once
+    per graph."""
     n = indptr.numel() - 1
     e = indices.numel()
     if n == 0 or e == 0:
-        return False
+        return 0
     deg = (indptr[1:] - indptr[:-1]).to(torch.int64)
     rows = torch.repeat_interleave(torch.arange(n, device=indptr.device), deg, output_size=e)
-    near = ((indices.to(torch.int64) - rows).abs() <= SCATTER_WINDOW).sum()
-    return bool(int(near) < SCATTER_NEAR_FRAC * e)
+    return int((indices.to(torch.int64) - rows).abs().median())
+
+
+def gather_scattered(indptr, indices, row_bytes, distance=None):
+    """True when most neighbour rows lie further from their row than half an XCD's L2 holds (SCATTER_L2_BYTES /
+    row_bytes rows): concurrently processed rows then share nothing in L1 / L2 and wide launches do better with
+    XCD feature tiles (GAE_SPMM_TILE)."""
+    d = gather_distance(indptr, indices) if distance is None else distance
+    return d * row_bytes > SCATTER_L2_BYTES
 
 
 BLOCKDIAG_GRAPHS = 4          # member graphs per thread block of the block-diagonal kernel
@@ -509,6 +514,10 @@ def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, 
 
 
 # ------------------------------------------------------------------ autograd glue
+def _scattered(graph, H):
+    return H.shape[1] > TILE_MIN_F and graph.scattered(H.shape[1] * H.element_size())
+
+
 class SpMMFunction(torch.autograd.Function):
     """update_all(copy_src, sum) with its backward  dH = A^T dM  (gae.py:28)."""
 
@@ -518,7 +527,7 @@ class SpMMFunction(torch.autograd.Function):
         norm = graph.norm() if use_norm else None
         ctx.graph, ctx.use_norm = graph, use_norm
         return spmm_raw(indptr, indices, H, graph.number_of_nodes(), norm, norm, plan=graph.spmm_plan(False),
-                        blockdiag=graph.block_diag, scattered=H.shape[1] > TILE_MIN_F and graph.scattered())
+                        blockdiag=graph.block_diag, scattered=_scattered(graph, H))
 
     @staticmethod
     def backward(ctx, dM):
@@ -526,7 +535,7 @@ class SpMMFunction(torch.autograd.Function):
         t_indptr, t_indices = g.csc()
         norm = g.norm() if ctx.use_norm else None
         return spmm_raw(t_indptr, t_indices, dM, g.number_of_nodes(), norm, norm, plan=g.spmm_plan(True),
-                        blockdiag=g.block_diag, scattered=dM.shape[1] > TILE_MIN_F and g.scattered()), None, None
+                        blockdiag=g.block_diag, scattered=_scattered(g, dM)), None, None
 
 
 class LinearFunction(torch.autograd.Function):

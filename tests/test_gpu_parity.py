@@ -222,15 +222,21 @@ def test_spmm_feature_tiles_bit_identical(F, n, dev):
 
 def test_gather_scattered_statistic(dev):
     from gae_dgl_amd import ops, workloads as W
+    import gae_dgl_amd as G
     rng = np.random.default_rng(0)
     n = 20000
     dst = rng.integers(0, n, 5 * n); src = rng.integers(0, n, 5 * n)
-    assert ops.gather_scattered(*ops.csr_from_coo(t(dst, dev), t(src, dev), n, n))
+    ip, ix = ops.csr_from_coo(t(dst, dev), t(src, dev), n, n)
+    d = ops.gather_distance(ip, ix)
+    assert d == int(np.median(np.abs(src - dst)))
+    assert ops.gather_scattered(ip, ix, 2000) and not ops.gather_scattered(ip, ix, 128)
     near = np.clip(dst + rng.integers(-32, 33, dst.size), 0, n - 1)
-    assert not ops.gather_scattered(*ops.csr_from_coo(t(dst, dev), t(near, dev), n, n))
+    assert not ops.gather_scattered(*ops.csr_from_coo(t(dst, dev), t(near, dev), n, n), 2000)
     gp, s2, d2, _ = W.zinc_like(2000, seed=1)
-    assert not ops.gather_scattered(*ops.csr_from_coo(t(d2, dev), t(s2, dev), int(gp[-1]), int(gp[-1])))
-    assert not ops.gather_scattered(*ops.csr_from_coo(t(dst[:0], dev), t(src[:0], dev), 10, 10))
+    assert not ops.gather_scattered(*ops.csr_from_coo(t(d2, dev), t(s2, dev), int(gp[-1]), int(gp[-1])), 2000)
+    assert ops.gather_distance(*ops.csr_from_coo(t(dst[:0], dev), t(src[:0], dev), 10, 10)) == 0
+    g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    assert g.scattered(2000) and not g.scattered(64)
 
 
 @pytest.mark.parametrize("F,ld", [(32, 32), (39, 40), (16, 16), (8, 8), (130, 132)])
