@@ -64,9 +64,10 @@ SIGNATURES = {
     "gae_decoder_dense_bwd_workspace_bytes": (_i64, [_i64, _i64]),
     "gae_decoder_dense_bwd": (_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),
     "gae_decoder_bce_workspace_bytes": (_i64, [_i64, _i64, _i64]),
-    "gae_decoder_bce_rows": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _f, _p, _p, _i64, _p,
-                                    _i64, _p]),
-    "gae_decoder_bce": (_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _f, _p, _p, _i64, _p, _i64, _p]),
+    "gae_decoder_bce_rows": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _f, _f, _u64, _u64, _p,
+                                    _p, _p, _i64, _p, _i64, _p]),
+    "gae_decoder_bce": (_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _f, _f, _u64, _u64, _p, _p, _p, _i64, _p,
+                               _i64, _p]),
 }
 
 _lib = None

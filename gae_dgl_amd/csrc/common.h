@@ -68,4 +68,34 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f)
     return static_cast<unsigned short>(u >> 16);
 }
 
+// ---------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (dropout masks, VGAE noise): 4 x 32 random bits per (counter, seed)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+    const uint64_t p0 = uint64_t(0xD2511F53u) * c[0];
+    const uint64_t p1 = uint64_t(0xCD9E8D57u) * c[2];
+    const uint32_t n0 = uint32_t(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n2 = uint32_t(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = uint32_t(p1); c[3] = uint32_t(p0); c[0] = n0; c[2] = n2;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint32_t (&c)[4])
+{
+    c[0] = uint32_t(ctr); c[1] = uint32_t(ctr >> 32); c[2] = 0u; c[3] = 0u;
+    uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// inverted-dropout multiplier of one 32-bit draw: 0 with probability p, else scale = 1 / (1 - p)
+__device__ __forceinline__ float dropout_multiplier(uint32_t bits, float p, float scale)
+{
+    const float u = float(bits >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+    return u >= p ? scale : 0.f;
+}
+
 } // namespace gae

@@ -69,25 +69,41 @@ __device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
 // feature bounds checks downstream), its bf16 hi / lo split, and per-block fp64 column sums of Zt over all
 // rows and over the row window (for the analytic terms).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bce_prepare_kernel(const float *__restrict__ Z, const float *__restrict__ mask,
+// drop_p > 0: the inverted-dropout multipliers of this draw are generated here (the Philox stream of
+// gae_dropout_mask: element e = i d + k of the [n, d] mask), applied, and stored to `mask` for the backward pass.
+__global__ __launch_bounds__(256) void bce_prepare_kernel(const float *__restrict__ Z, float *__restrict__ mask,
                                                           int64_t ldz, int64_t n, int d, int DP, int64_t row_begin,
                                                           int64_t row_end, float *__restrict__ Zt,
                                                           unsigned short *__restrict__ Zhi,
                                                           unsigned short *__restrict__ Zlo,
-                                                          double *__restrict__ colsum_partial /*[grid][2][DP]*/)
+                                                          double *__restrict__ colsum_partial /*[grid][2][DP]*/,
+                                                          float drop_p, float drop_scale, uint64_t seed,
+                                                          uint64_t offset, const uint64_t *__restrict__ draw_dev)
 {
     __shared__ double red[2][256];
     const int tid = threadIdx.x;
     const int k = tid % DP, rl = tid / DP, rpp = 256 / DP;   // rows per pass
     const int64_t r0 = int64_t(blockIdx.x) * PREP_ROWS;
     double s_all = 0.0, s_win = 0.0;
+    const bool draw = drop_p > 0.f;
+    if (draw && draw_dev) offset += *draw_dev * uint64_t((n * d + 3) / 4);
     for (int rr = rl; rr < PREP_ROWS; rr += rpp) {
         const int64_t i = r0 + rr;
         if (i >= n) break;
         float v = 0.f;
         if (k < d) {
             v = Z[i * ldz + k];
-            if (mask) v *= mask[i * ldz + k];
+            if (draw) {
+                const int64_t e = i * d + k;
+                uint32_t c[4];
+                gae::philox4x32_10(offset + uint64_t(e >> 2), seed, c);
+                const uint32_t bits = (e & 2) ? ((e & 1) ? c[3] : c[2]) : ((e & 1) ? c[1] : c[0]);
+                const float m = gae::dropout_multiplier(bits, drop_p, drop_scale);
+                mask[i * ldz + k] = m;
+                v *= m;
+            } else if (mask) {
+                v *= mask[i * ldz + k];
+            }
         }
         Zt[i * DP + k] = v;
         const unsigned short hi = gae::f32_to_bf16(v);
@@ -528,7 +544,8 @@ __global__ __launch_bounds__(256) void bce_finalize_kernel(const double *__restr
                                                            int64_t n_dense, const double *__restrict__ edge_partial,
                                                            int64_t n_edge, const double *__restrict__ S, int DP,
                                                            double pad_terms, double inv_n2,
-                                                           float *__restrict__ loss_out)
+                                                           float *__restrict__ loss_out,
+                                                           uint64_t *__restrict__ bump_draw)
 {
     __shared__ double red[3][256];
     double a = 0.0, l = 0.0, e = 0.0;
@@ -549,6 +566,7 @@ __global__ __launch_bounds__(256) void bce_finalize_kernel(const double *__restr
         for (int k = 0; k < DP; ++k) sx += S[k] * S[DP + k];          // sum_{i in window} sum_j x_ij
         const double dense = 0.5 * sx + 0.5 * red[0][0] + 0.69314718055994531 * (red[1][0] - pad_terms);
         *loss_out = float((dense + red[2][0]) * inv_n2);
+        if (bump_draw) *bump_draw += 1;     // every read of the counter (prepare) is stream-ordered before this kernel
     }
 }
 
@@ -680,12 +698,16 @@ extern "C" int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t n_local, i
     return p.total_bytes + 256;
 }
 
-extern "C" int gae_decoder_bce_rows(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
+extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,
                                     int64_t row_begin, int64_t n_local, const int32_t *indptr,
                                     const int32_t *indices, const int32_t *t_indptr, const int32_t *t_indices,
-                                    float pos_weight, float *loss_out, float *dZ, int64_t lddz, void *workspace,
+                                    float pos_weight, float dropout_p, uint64_t seed, uint64_t offset,
+                                    uint64_t *draw_dev, float *loss_out, float *dZ, int64_t lddz, void *workspace,
                                     int64_t workspace_bytes, void *stream)
 {
+    GAE_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GAE_E_RANGE, "gae_decoder_bce: dropout_p = %g outside [0, 1)",
+                double(dropout_p));
+    GAE_REQUIRE(dropout_p == 0.f || mask, GAE_E_NULL, "gae_decoder_bce: dropout_p > 0 needs the mask output buffer");
     GAE_REQUIRE(n > 0 && d > 0, GAE_E_SIZE, "gae_decoder_bce: n and d must be positive");
     GAE_REQUIRE(row_begin >= 0 && n_local >= 0 && row_begin + n_local <= n, GAE_E_SIZE,
                 "gae_decoder_bce: row window outside [0, n)");
@@ -716,7 +738,8 @@ extern "C" int gae_decoder_bce_rows(const float *Z, const float *mask, int64_t l
         return GAE_OK;
     }
     hipLaunchKernelGGL(bce_prepare_kernel, dim3(unsigned(p.prep_blocks)), dim3(256), 0, s, Z, mask, ldz, n, int(d), p.DP,
-                       row_begin, row_begin + n_local, Zt, Zhi, Zlo, cs);
+                       row_begin, row_begin + n_local, Zt, Zhi, Zlo, cs, dropout_p, 1.0f / (1.0f - dropout_p), seed,
+                       offset, draw_dev);
     GAE_CHECK_LAUNCH("bce_prepare_kernel");
     int rc = dZ ? launch_dense<true>(p, Zt, Zhi, Zlo, n, row_begin, n_local, O, lp, cs, S, S_all_f, s)
                 : launch_dense<false>(p, Zt, Zhi, Zlo, n, row_begin, n_local, O, lp, cs, S, S_all_f, s);
@@ -728,16 +751,17 @@ extern "C" int gae_decoder_bce_rows(const float *Z, const float *mask, int64_t l
                                      t_indices, pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, s);
     if (rc) return rc;
     hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(256), 0, s, lp, p.n_dense, lpe, p.edge_blocks, S, p.DP,
-                       p.pad_terms, inv_n2, loss_out);
+                       p.pad_terms, inv_n2, loss_out, dropout_p > 0.f ? draw_dev : nullptr);
     GAE_CHECK_LAUNCH("bce_finalize_kernel");
     return GAE_OK;
 }
 
-extern "C" int gae_decoder_bce(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
+extern "C" int gae_decoder_bce(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,
                                const int32_t *indptr, const int32_t *indices, const int32_t *t_indptr,
-                               const int32_t *t_indices, float pos_weight, float *loss_out, float *dZ, int64_t lddz,
+                               const int32_t *t_indices, float pos_weight, float dropout_p, uint64_t seed,
+                               uint64_t offset, uint64_t *draw_dev, float *loss_out, float *dZ, int64_t lddz,
                                void *workspace, int64_t workspace_bytes, void *stream)
 {
-    return gae_decoder_bce_rows(Z, mask, ldz, n, d, 0, n, indptr, indices, t_indptr, t_indices, pos_weight, loss_out,
-                                dZ, lddz, workspace, workspace_bytes, stream);
+    return gae_decoder_bce_rows(Z, mask, ldz, n, d, 0, n, indptr, indices, t_indptr, t_indices, pos_weight, dropout_p,
+                                seed, offset, draw_dev, loss_out, dZ, lddz, workspace, workspace_bytes, stream);
 }

@@ -630,14 +630,7 @@ int launch_reduce(const float *partial, int64_t n_slots, int64_t slot_stride, in
 // ---------------------------------------------------------------------------
 // Philox4x32-10 counter RNG -> inverted dropout multiplier
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
-{
-    const uint64_t p0 = uint64_t(0xD2511F53u) * c[0];
-    const uint64_t p1 = uint64_t(0xCD9E8D57u) * c[2];
-    const uint32_t n0 = uint32_t(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n2 = uint32_t(p0 >> 32) ^ c[3] ^ k1;
-    c[1] = uint32_t(p1); c[3] = uint32_t(p0); c[0] = n0; c[2] = n2;
-}
+using gae::philox_round;
 
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float *__restrict__ mask, int64_t n, float p, float scale,
                                                            uint64_t seed, uint64_t offset,
@@ -647,21 +640,12 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float *__restrict__ m
     const int64_t nquad = (n + 3) / 4;
     if (draw_dev) offset += *draw_dev * uint64_t(nquad);   // device-side draw counter: graph replays advance the stream
     for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < nquad; q += stride) {
-        const uint64_t ctr = offset + uint64_t(q);
-        uint32_t c[4] = {uint32_t(ctr), uint32_t(ctr >> 32), 0u, 0u};
-        uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            philox_round(c, k0, k1);
-            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-        }
+        uint32_t c[4];
+        gae::philox4x32_10(offset + uint64_t(q), seed, c);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t e = q * 4 + i;
-            if (e < n) {
-                const float u = float(c[i] >> 8) * (1.0f / 16777216.0f);  // [0,1)
-                mask[e] = u >= p ? scale : 0.f;
-            }
+            if (e < n) mask[e] = gae::dropout_multiplier(c[i], p, scale);
         }
     }
 }

@@ -155,7 +155,14 @@ class InnerProductDecoder(nn.Module):
         return adj
 
     def loss(self, z, g):
-        """fused decoder + weighted BCE (identity activation = logits, gae.py:47)"""
-        mask = self._draw_mask(z)
+        """fused decoder + weighted BCE (identity activation = logits, gae.py:47).  The dropout mask of this call
+        is drawn inside the fused launch (same Philox stream as _draw_mask) and kept in ``last_mask``."""
+        if self.mask is not None or not self.dropout:
+            self.last_mask = self.mask
+            return ops.decoder_bce(z, self.mask, g)
+        seed = self.seed if self.seed is not None else int(torch.initial_seed())
+        if self._draws is None or self._draws.device != z.device:
+            self._draws = torch.zeros(1, dtype=torch.int64, device=z.device)
+        mask = torch.empty(tuple(z.shape), dtype=torch.float32, device=z.device)
         self.last_mask = mask
-        return ops.decoder_bce(z, mask, g)
+        return ops.decoder_bce(z, mask, g, dropout=(self.dropout, seed, 0, self._draws))

@@ -482,13 +482,18 @@ def decoder_dense_bwd_raw(G, Z, mask=None):
     return dZ
 
 
-def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, n_local=None):
+def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, n_local=None, dropout=None):
     """fused decoder + weighted BCE (mean): returns (loss[1], dZ or None).
     ``row_begin/n_local`` select a row window (row-sharded form): Z/mask stay the
-    full [n, d] arrays, csr/csc are the window's local row blocks."""
+    full [n, d] arrays, csr/csc are the window's local row blocks.
+    ``dropout`` = (p, seed, offset, draw_counter): the mask of this draw is generated inside the launch, written
+    to ``mask`` (an [n, d] output buffer then) and the device draw counter is advanced by the library."""
     Z = _gpu(Z, "Z").contiguous()
     if mask is not None:
         mask = _gpu(mask, "mask").contiguous()
+    p_drop, seed, offset, draws = dropout if dropout is not None else (0.0, 0, 0, None)
+    if p_drop and (mask is None or mask.shape != Z.shape):
+        raise GaeHipError("decoder_bce: in-kernel dropout needs an [n, d] mask output buffer")
     n, d = Z.shape
     n_local = n if n_local is None else int(n_local)
     dev = Z.device
@@ -504,8 +509,9 @@ def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, 
 
         def launch():
             _lib.call("gae_decoder_bce_rows", _ptr(Z), _ptr(mask), max(d, 1), n, d, int(row_begin), n_local,
-                      _ptr(indptr), _ptr(indices), _ptr(t_indptr), _ptr(t_indices), float(pos_weight), _ptr(loss),
-                      _ptr(dZ), max(d, 1), _ptr(ws), ws.numel(), _stream())
+                      _ptr(indptr), _ptr(indices), _ptr(t_indptr), _ptr(t_indices), float(pos_weight), float(p_drop),
+                      int(seed) & (2 ** 64 - 1), int(offset), _ptr(draws), _ptr(loss), _ptr(dZ), max(d, 1), _ptr(ws),
+                      ws.numel(), _stream())
         if profiler is not None:
             profiler.wrap(("decoder_bce", n, d, want_grad), launch)
         else:
@@ -578,23 +584,25 @@ class DecoderBCEFunction(torch.autograd.Function):
     the same launch sequence as the loss (flash-style) and scaled in backward."""
 
     @staticmethod
-    def forward(ctx, Z, mask, graph):
+    def forward(ctx, Z, mask, graph, dropout=None):
         n = graph.number_of_nodes()
         nnz = graph.number_of_edges()
         pw = (float(n) * float(n) - float(nnz)) / float(nnz)      # train_inductive.py:46
         need = ctx.needs_input_grad[0]
-        loss, dZ = decoder_bce_raw(Z, mask, graph.csr(), graph.csc() if need else None, pw, want_grad=need)
+        loss, dZ = decoder_bce_raw(Z, mask, graph.csr(), graph.csc() if need else None, pw, want_grad=need,
+                                   dropout=dropout)
         ctx.save_for_backward(dZ)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         (dZ,) = ctx.saved_tensors
-        return dZ * g, None, None
+        return dZ * g, None, None, None
 
 
-def decoder_bce(Z, mask, graph):
-    return DecoderBCEFunction.apply(Z, mask, graph)
+def decoder_bce(Z, mask, graph, dropout=None):
+    """``dropout`` = (p, seed, offset, draw_counter): draw the mask inside the fused launch into ``mask``"""
+    return DecoderBCEFunction.apply(Z, mask, graph, dropout)
 
 
 class ShardedDecoderBCEFunction(torch.autograd.Function):

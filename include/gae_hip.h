@@ -252,11 +252,20 @@ int gae_vgae_head_bwd(const float *dz, const float *mu, const float *logstd, con
  *   loss_out : 1 fp32 on the device
  *   dZ       : d loss / d Z  [n, d] (NULL = loss only, e.g. validation); needs the
  *              CSR of A^T (t_indptr, t_indices) for the G^T term
- *   d <= 64.  Ordered two-stage reductions: deterministic. */
+ *   d <= 64.  Ordered two-stage reductions: deterministic.
+ * Dropout (gae_dgl/gae.py:70, always on in the reference):
+ *   dropout_p == 0 : `mask` [n, d] (ld = ldz) is an optional INPUT (NULL = no dropout), e.g. one drawn by
+ *                    gae_dropout_mask.
+ *   dropout_p  > 0 : `mask` is an OUTPUT: this draw's multipliers -- the same Philox stream as
+ *                    gae_dropout_mask(mask, n * d, p, seed, offset, draw_dev) -- are generated inside the call,
+ *                    applied, and stored for the caller; at the end of the call *draw_dev (device counter, may be
+ *                    NULL) is incremented by one, stream-ordered, so a replayed HIP graph draws a fresh mask
+ *                    every time without a separate launch. */
 int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t n_local, int64_t d);
-int gae_decoder_bce(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
+int gae_decoder_bce(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,
                     const int32_t *indptr, const int32_t *indices,
                     const int32_t *t_indptr, const int32_t *t_indices, float pos_weight,
+                    float dropout_p, uint64_t seed, uint64_t offset, uint64_t *draw_dev,
                     float *loss_out, float *dZ, int64_t lddz,
                     void *workspace, int64_t workspace_bytes, void *stream);
 
@@ -266,10 +275,11 @@ int gae_decoder_bce(const float *Z, const float *mask, int64_t ldz, int64_t n, i
  * rank's LOCAL row blocks of A and A^T (n_local + 1 entries, global column ids);
  * loss_out receives this block's share of the mean (sum over ranks = the loss);
  * dZ [n_local, d] is the gradient of the GLOBAL loss w.r.t. the local rows. */
-int gae_decoder_bce_rows(const float *Z, const float *mask, int64_t ldz, int64_t n, int64_t d,
+int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,
                          int64_t row_begin, int64_t n_local,
                          const int32_t *indptr, const int32_t *indices,
                          const int32_t *t_indptr, const int32_t *t_indices, float pos_weight,
+                         float dropout_p, uint64_t seed, uint64_t offset, uint64_t *draw_dev,
                          float *loss_out, float *dZ, int64_t lddz,
                          void *workspace, int64_t workspace_bytes, void *stream);
 

@@ -591,6 +591,36 @@ def test_fused_loss_equals_dense_path_large(dev):
     assert torch.equal(l2, loss.detach())  # deterministic reductions
 
 
+@pytest.mark.parametrize("n,d", [(700, 16), (1300, 7), (257, 48)])
+def test_fused_loss_draws_its_own_mask(n, d, dev):
+    """dropout_p > 0: the mask of the draw is generated inside the fused launch -- same Philox stream as
+    gae_dropout_mask, same loss / gradient bit for bit -- and the device draw counter advances by one per call"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(n)
+    src, dst = rand_graph(rng, n, 6 * n)
+    gr = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    Z = t(rng.standard_normal((n, d)).astype(np.float32) * 0.5, dev)
+    draws = torch.zeros(1, dtype=torch.int64, device=dev)
+    masks = []
+    for k in range(3):
+        ref_mask = ops.dropout_mask((n, d), 0.1, seed=11, device=dev, draw_counter=torch.full_like(draws, k))
+        Z1 = Z.clone().requires_grad_(True); Z2 = Z.clone().requires_grad_(True)
+        ref = ops.decoder_bce(Z1, ref_mask, gr); ref.backward()
+        mask = torch.full((n, d), -7.0, device=dev)
+        loss = ops.decoder_bce(Z2, mask, gr, dropout=(0.1, 11, 0, draws)); loss.backward()
+        assert int(draws) == k + 1
+        assert torch.equal(mask, ref_mask)
+        assert torch.equal(loss.detach(), ref.detach()) and torch.equal(Z2.grad, Z1.grad)
+        masks.append(mask)
+    assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
+    # module level: InnerProductDecoder.loss draws in-kernel, forward() with the separate mask kernel: same stream
+    dec_a, dec_c = G.gae.InnerProductDecoder(seed=5), G.gae.InnerProductDecoder(seed=5)
+    la = dec_a.loss(Z, gr)
+    assert torch.equal(dec_a.last_mask, dec_c._draw_mask(Z)) and int(dec_a._draws) == 1 and int(dec_c._draws) == 1
+    assert float(la) > 0
+
+
 # ----------------------------------------------------------------- VGAE (BASELINE config 5)
 def test_normal_noise_moments(dev):
     from gae_dgl_amd import ops
