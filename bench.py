@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--balance", choices=["rows", "nnz"], default="nnz",
                     help="rmat: row blocks of equal row count or of equal edge count (RMAT puts 44 %% of the edges "
                          "into the first of 8 equal row blocks)")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="torch.optim.Adam(fused=True) instead of the library's one-launch Adam (same update rule)")
     ap.add_argument("--no-hipgraph", action="store_true",
                     help="citation workloads: launch the step eagerly.  Default: the timed steps replay the step as "
                          "one captured HIP graph (the ~30 launches are host-bound otherwise); HIP events cannot be "
@@ -114,6 +116,14 @@ def time_launches(fn, iters=50, warmup=5):
     return t
 
 
+def make_adam(params, lr, args, capturable=False):
+    """train_inductive.py:40 / train_transductive.py:43: Adam with the reference's hyper-parameters"""
+    if args.torch_adam:
+        return torch.optim.Adam(params, lr=lr, fused=True, capturable=capturable), "torch.optim.Adam(fused)"
+    from gae_dgl_amd.optim import Adam
+    return Adam(params, lr=lr), "gae_adam_step (torch.optim.Adam rule, one launch)"
+
+
 def spmm_probe(indptr, indices, n, F, ld=None, plan=None, label="", iters=50, blockdiag=None):
     """kernel-only SpMM throughput for one shape (row-padded operands as every op of the package produces)"""
     from gae_dgl_amd import ops, workloads as W
@@ -143,8 +153,7 @@ class CitationWorkload:
         torch.manual_seed(0)
         self.model = G.GAE(self.F_in, self.hidden).to(dev)
         self.use_graph = (not args.no_hipgraph) and args.loss == "fused"
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-2,        # train_transductive.py:43
-                                    fused=True, capturable=self.use_graph)   # one multi-tensor launch
+        self.opt, opt_name = make_adam(self.model.parameters(), 1e-2, args, self.use_graph)  # train_transductive.py:43
         self.g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
         self.Xd = ops.pad_rows(torch.from_numpy(X).to(dev))                  # rows padded to whole 128-B lines
         self.g.csr(); self.g.csc(); self.g.spmm_plan(False); self.g.spmm_plan(True); self.g.scattered()   # static
@@ -152,7 +161,7 @@ class CitationWorkload:
         self.edges_per_step = E * (2 * len(self.hidden) - 1)                   # L fwd + (L-1) bwd SpMM launches
         self.meta = {"workload": f"{name}-transductive-gae", "n_nodes": n, "n_edges": E, "in_dim": self.F_in,
                      "hidden_dims": self.hidden, "norm": "none", "loss": args.loss + "-bce",
-                     "optimizer": "adam lr=1e-2", "parallelism": "1 GPU",
+                     "optimizer": "adam lr=1e-2: " + opt_name, "parallelism": "1 GPU",
                      "launch": "hipGraph replay of the captured step" if self.use_graph else "eager"}
         self.captured = None
         self.dominant = ("spmm", n, n, self.F_in, "torch.float32")
@@ -185,7 +194,8 @@ class CitationWorkload:
             adj = g.dense_adjacency()                                         # train_transductive.py:59
             pw = (self.n * self.n - adj.sum()) / adj.sum()                    # :60
             loss = torch.nn.functional.binary_cross_entropy_with_logits(model(g), adj, pos_weight=pw)
-        self.opt.zero_grad(); loss.backward(); self.opt.step()
+        from gae_dgl_amd import ops
+        self.opt.zero_grad(); ops.backward(loss); self.opt.step()
         return loss
 
     def cpu_baseline(self, seconds):
@@ -219,7 +229,7 @@ class ZincWorkload:
         self.B = B
         torch.manual_seed(0)
         self.model = G.GAE(39, [32, 16]).to(dev)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True)   # train_inductive.py:25
+        self.opt, opt_name = make_adam(self.model.parameters(), 1e-3, args)   # train_inductive.py:25
         self.rng = np.random.default_rng(0)
         self.perm = self.rng.permutation(n_graphs)
         self.cursor = 0
@@ -227,7 +237,7 @@ class ZincWorkload:
         self.edges_per_step = 3 * eb                                          # nominal (batch 0); varies < 1 % per batch
         self.meta = {"workload": "zinc250k-inductive-gae", "batch_graphs": B, "nodes_per_batch~": nb,
                      "edges_per_batch~": eb, "in_dim": 39, "hidden_dims": [32, 16], "loss": "fused-bce",
-                     "optimizer": "adam lr=1e-3", "dataset_graphs": n_graphs, "parallelism": "1 GPU",
+                     "optimizer": "adam lr=1e-3: " + opt_name, "dataset_graphs": n_graphs, "parallelism": "1 GPU",
                      "batches_per_epoch_at_239455_graphs": int(np.ceil(239455 / B))}
         self.dominant = None
         self.W = W
@@ -248,7 +258,8 @@ class ZincWorkload:
         self.cursor = (self.cursor + self.B) % (len(self.perm) - self.B)
         bg = self.ds.batch(ids)                                               # dgl.batch on the device (K10)
         loss = self.model.reconstruction_loss(bg)
-        self.opt.zero_grad(); loss.backward(); self.opt.step()
+        from gae_dgl_amd import ops
+        self.opt.zero_grad(); ops.backward(loss); self.opt.step()
         return loss
 
 
@@ -276,7 +287,7 @@ class RmatShardedWorkload:
         self.dZ = torch.randn(p.n_local, hidden[-1], device=dev, generator=gen) / n
         torch.manual_seed(0)
         self.model = G.GAE(F, hidden).to(dev)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-2, fused=True)
+        self.opt, opt_name = make_adam(self.model.parameters(), 1e-2, args)
         self.params = list(self.model.parameters())
         self.n, self.E = n, E
         self.edges_per_step = 3 * E

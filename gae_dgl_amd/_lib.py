@@ -30,6 +30,12 @@ class SpmmPlan(ctypes.Structure):
                 ("reserved", _i32)]
 
 
+class AdamTensor(ctypes.Structure):
+    _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("n", _i64)]
+
+
+ADAM_MAX_TENSORS = 16
+
 # name -> (restype, argtypes); mirrors include/gae_hip.h one to one
 SIGNATURES = {
     "gae_version": (_int, []),
@@ -63,6 +69,7 @@ SIGNATURES = {
     "gae_decoder_dense": (_int, [_p, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "gae_decoder_dense_bwd_workspace_bytes": (_i64, [_i64, _i64]),
     "gae_decoder_dense_bwd": (_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),
+    "gae_adam_step": (_int, [ctypes.POINTER(AdamTensor), _i32, _f, _f, _f, _f, _f, _p, _p]),
     "gae_decoder_bce_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gae_decoder_bce_rows": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _f, _f, _u64, _u64, _p,
                                     _p, _p, _i64, _p, _i64, _p]),

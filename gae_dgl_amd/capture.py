@@ -6,8 +6,11 @@ hipGraph (through torch.cuda.CUDAGraph, which records every launch on the
 capture stream -- including the ctypes launches of libgae_hip.so, which use
 PyTorch's current stream) and replayed per epoch: no Python / launch overhead
 between kernels.  The decoder's dropout mask still changes every replay
-because its Philox draw counter lives in device memory (gae_dropout_mask)."""
+because its Philox draw counter lives in device memory (gae_decoder_bce), and so does Adam's step counter
+(gae_dgl_amd.optim.Adam / torch.optim.Adam(capturable=True))."""
 import torch
+
+from . import ops
 
 
 class CapturedTrainStep:
@@ -33,7 +36,7 @@ class CapturedTrainStep:
     def _fwd_bwd_step(self):
         self.g.ndata['h'] = self.x
         loss = self.loss_fn(self.model, self.g)
-        loss.backward()
+        ops.backward(loss)
         self.opt.step()
         return loss.detach()
 

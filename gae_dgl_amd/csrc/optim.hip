@@ -1,0 +1,96 @@
+// K12: Adam (torch.optim.Adam defaults: no amsgrad, no maximize, L2 weight decay) for the few small parameter
+// tensors of the GAE (layers.{i}.apply_mod.linear.{weight,bias}; 1 808 .. 119 056 values), ONE launch per step.
+//
+// Replaces the optimiser step of gae_dgl/train_inductive.py:40,50-52 / train_transductive.py:43,66-68.  PyTorch's
+// own fused Adam needs two multi-tensor launches per step (13 + 4 us on gfx950) for these 16 k values; inside a
+// replayed HIP graph of ~25 launches that is 5 % of a Pubmed step and 10 % of a Cora step.
+//
+// The step counter lives in device memory (state[0]) so that a captured graph advances it on every replay: every
+// block reads it when it starts, the LAST block to finish (ticket in state[1]) increments it and clears the ticket.
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kAdamMaxTensors = GAE_ADAM_MAX_TENSORS;
+constexpr int kAdamChunk = 1024;      // elements per block: 256 threads x float4
+
+struct AdamArgs {
+    gae_adam_tensor t[kAdamMaxTensors];
+    int32_t first_block[kAdamMaxTensors + 1];   // block range of tensor k: [first_block[k], first_block[k + 1])
+    int32_t n_tensors;
+};
+
+__global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, float beta1, float beta2, float eps,
+                                                        float weight_decay, unsigned long long *__restrict__ state)
+{
+    int k = 0;
+    while (k + 1 < a.n_tensors && int(blockIdx.x) >= a.first_block[k + 1]) ++k;
+    const gae_adam_tensor t = a.t[k];
+    const double step = double(state[0] + 1ull);                       // this is step number `step` (1-based)
+    const float bc1 = float(1.0 - pow(double(beta1), step));
+    const float bc2_sqrt = float(sqrt(1.0 - pow(double(beta2), step)));
+    const float step_size = lr / bc1;
+    const int64_t base = int64_t(int(blockIdx.x) - a.first_block[k]) * kAdamChunk + threadIdx.x * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t e = base + q;
+        if (e < t.n) {
+            float g = t.grad[e];
+            const float p = t.param[e];
+            if (weight_decay != 0.f) g = fmaf(weight_decay, p, g);
+            float m = t.exp_avg[e], v = t.exp_avg_sq[e];
+            m = fmaf(g - m, 1.0f - beta1, m);                          // lerp(m, g, 1 - beta1)
+            v = fmaf(beta2, v, (1.0f - beta2) * g * g);
+            const float denom = sqrtf(v) / bc2_sqrt + eps;
+            t.param[e] = p - step_size * (m / denom);
+            t.exp_avg[e] = m;
+            t.exp_avg_sq[e] = v;
+        }
+    }
+    // ---- the last block to finish advances the step counter
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long ticket = atomicAdd(&state[1], 1ull);
+        if (ticket == gridDim.x - 1ull) {
+            state[1] = 0ull;
+            state[0] += 1ull;
+        }
+    }
+}
+
+} // namespace
+
+extern "C" int gae_adam_step(const gae_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, uint64_t *state_dev, void *stream)
+{
+    GAE_REQUIRE(n_tensors >= 0 && n_tensors <= kAdamMaxTensors, GAE_E_RANGE,
+                "gae_adam_step: %d tensors per call (at most %d)", n_tensors, kAdamMaxTensors);
+    GAE_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f &&
+                    weight_decay >= 0.f,
+                GAE_E_RANGE, "gae_adam_step: hyper-parameter out of range");
+    if (n_tensors == 0) return GAE_OK;
+    GAE_REQUIRE(tensors && state_dev, GAE_E_NULL, "gae_adam_step: NULL pointer");
+    AdamArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_tensors = n_tensors;
+    int64_t blocks = 0;
+    for (int k = 0; k < n_tensors; ++k) {
+        const gae_adam_tensor &t = tensors[k];
+        GAE_REQUIRE(t.n >= 0, GAE_E_SIZE, "gae_adam_step: tensor %d has a negative size", k);
+        GAE_REQUIRE(t.n == 0 || (t.param && t.grad && t.exp_avg && t.exp_avg_sq), GAE_E_NULL,
+                    "gae_adam_step: tensor %d has a NULL pointer", k);
+        a.t[k] = t;
+        a.first_block[k] = int32_t(blocks);
+        blocks += (t.n + kAdamChunk - 1) / kAdamChunk;
+        GAE_REQUIRE(blocks < (int64_t(1) << 30), GAE_E_SIZE, "gae_adam_step: too many elements for one launch");
+    }
+    a.first_block[n_tensors] = int32_t(blocks);
+    if (blocks == 0) blocks = 1;        // still advances the step counter (a.t[0].n == 0: no element passes e < n)
+    hipLaunchKernelGGL(adam_step_kernel, dim3(unsigned(blocks)), dim3(256), 0, gae::as_stream(stream), a, lr, beta1,
+                       beta2, eps, weight_decay, reinterpret_cast<unsigned long long *>(state_dev));
+    GAE_CHECK_LAUNCH("adam_step_kernel");
+    return GAE_OK;
+}

@@ -597,7 +597,27 @@ class DecoderBCEFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dZ,) = ctx.saved_tensors
+        if _is_unit(g):
+            return dZ, None, None, None          # upstream gradient is the cached constant 1 (ops.backward)
         return dZ * g, None, None, None
+
+
+_UNIT = {}
+
+
+def _is_unit(g):
+    one = _UNIT.get(g.device)
+    return one is not None and g.dim() == 0 and g.data_ptr() == one.data_ptr()
+
+
+def backward(loss):
+    """``loss.backward()`` with the upstream gradient 1 handed over as a cached device constant: the fused loss
+    recognises it and returns its stored gradient as is (saves the fill and the multiply launch of a plain
+    ``loss.backward()``; 9 us of a 190 us Cora step)."""
+    one = _UNIT.get(loss.device)
+    if one is None:
+        one = _UNIT[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    loss.backward(gradient=one)
 
 
 def decoder_bce(Z, mask, graph, dropout=None):

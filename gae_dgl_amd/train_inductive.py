@@ -19,6 +19,7 @@ from torch.nn.functional import binary_cross_entropy_with_logits as BCELoss
 from torch.utils.data import DataLoader
 
 import gae_dgl_amd as dgl
+from gae_dgl_amd import ops, optim
 from gae_dgl_amd.dataset import DeviceGraphDataset, MolDataset  # noqa: F401
 from gae_dgl_amd.gae import GAE
 
@@ -57,7 +58,7 @@ def collate(samples):
 class Trainer:
     def __init__(self, model, args, fused=True):
         self.model = model
-        self.optim = torch.optim.Adam(self.model.parameters(), lr=args.lr, fused=True)
+        self.optim = optim.Adam(self.model.parameters(), lr=args.lr)    # torch.optim.Adam's rule, one HIP launch
         self.fused = fused
         print('Total Parameters:', sum([p.nelement() for p in self.model.parameters()]))
 
@@ -74,7 +75,7 @@ class Trainer:
         if train:
             loss = self.loss(g)
             self.optim.zero_grad()
-            loss.backward()
+            ops.backward(loss)            # loss.backward() with a cached unit gradient
             self.optim.step()
         else:
             with torch.no_grad():

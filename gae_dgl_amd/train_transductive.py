@@ -52,12 +52,13 @@ def main(argv=None):
 
     data = load_data(args)
     from gae_dgl_amd import ops
-    features = ops.pad_rows(torch.FloatTensor(data.features).to(device))   # 16-byte rows for odd widths
+    from gae_dgl_amd.optim import Adam
+    features = ops.pad_rows(torch.FloatTensor(data.features).to(device))   # rows of whole 16 / 128-byte units
     in_feats = features.shape[1]
 
     model = GAE(in_feats, args.hidden_dims, norm=args.norm).to(device)
     model.train()
-    optim = torch.optim.Adam(model.parameters(), lr=args.lr, fused=True)
+    optim = Adam(model.parameters(), lr=args.lr)      # torch.optim.Adam's rule, one HIP launch
 
     split = None
     if args.eval:
@@ -78,7 +79,7 @@ def main(argv=None):
         g.ndata['h'] = features
         loss = model.reconstruction_loss(g)
         optim.zero_grad()
-        loss.backward()
+        ops.backward(loss)                # loss.backward() with a cached unit gradient
         optim.step()
         losses.append(loss.detach())
         if epoch % args.log_every == 0 or epoch == args.n_epochs - 1:

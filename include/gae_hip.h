@@ -283,6 +283,26 @@ int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, int64_t n, in
                          float *loss_out, float *dZ, int64_t lddz,
                          void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- K12: Adam ----------------------------------------------------------------
+ * torch.optim.Adam(params, lr, betas, eps, weight_decay) of gae_dgl/train_inductive.py:40,50-52 and
+ * train_transductive.py:43,66-68 (no amsgrad, no maximize) for up to GAE_ADAM_MAX_TENSORS contiguous fp32
+ * tensors in ONE launch:
+ *   g += weight_decay p;  m = lerp(m, g, 1 - beta1);  v = beta2 v + (1 - beta2) g^2
+ *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = state_dev[0] + 1
+ * state_dev: 2 x uint64 on the device, zeroed by the caller once: [0] = steps taken so far (advanced by the
+ * call, stream-ordered, so a replayed HIP graph counts its own steps), [1] = scratch ticket.
+ * `tensors` is a HOST array (copied into the kernel arguments). */
+#define GAE_ADAM_MAX_TENSORS 16
+typedef struct gae_adam_tensor {
+    float *param;          /* [n] updated in place            (device) */
+    const float *grad;     /* [n]                              (device) */
+    float *exp_avg;        /* [n] first moment, in place       (device) */
+    float *exp_avg_sq;     /* [n] second moment, in place      (device) */
+    int64_t n;
+} gae_adam_tensor;
+int gae_adam_step(const gae_adam_tensor *tensors_host, int32_t n_tensors, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, uint64_t *state_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

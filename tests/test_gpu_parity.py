@@ -621,6 +621,61 @@ def test_fused_loss_draws_its_own_mask(n, d, dev):
     assert float(la) > 0
 
 
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_adam_matches_torch(wd, dev):
+    """gae_adam_step == torch.optim.Adam (train_inductive.py:40) over a trajectory; 20 tensors -> two launches"""
+    from gae_dgl_amd.optim import Adam
+    gen = torch.Generator(device=dev).manual_seed(0)
+    shapes = [(32, 500), (32,), (16, 32), (16,), (1,), (3, 1025)] + [(7, 5)] * 14
+    pa = [torch.randn(s, device=dev, generator=gen).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = Adam(pa, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    ob = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    for it in range(25):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, device=dev, generator=gen) * (1.0 + it)
+            a.grad = gr.clone(); b.grad = gr.clone()
+        oa.step(); ob.step()
+    assert oa.steps_taken() == 25
+    for a, b in zip(pa, pb):
+        assert rel_err(a, b) < 2e-6
+        assert torch.isfinite(a).all()
+    # a tensor without a gradient is left alone (the step counter is per parameter group, not per tensor)
+    before = pa[2].detach().clone()
+    for a in pa:
+        a.grad = torch.ones_like(a)
+    pa[2].grad = None
+    oa.step()
+    assert torch.equal(pa[2].detach(), before) and not torch.equal(pa[0].detach(), pb[0].detach())
+
+
+def test_adam_in_captured_step(dev):
+    """device-side step counter: a replayed HIP graph keeps counting (bias correction follows the replays)"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import workloads as W, ops
+    from gae_dgl_amd.capture import CapturedTrainStep
+    from gae_dgl_amd.optim import Adam
+    n, src, dst, X = W.citation_graph("cora", seed=0)
+    g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    Xd = ops.pad_rows(torch.from_numpy(X).to(dev))
+    torch.manual_seed(0)
+    ma = G.GAE(X.shape[1], [32, 16]).to(dev); ma.decoder.dropout = 0.0
+    mb = G.GAE(X.shape[1], [32, 16]).to(dev); mb.load_state_dict(ma.state_dict()); mb.decoder.dropout = 0.0
+    oa = Adam(ma.parameters(), lr=1e-2)
+    ob = torch.optim.Adam(mb.parameters(), lr=1e-2)
+    step = CapturedTrainStep(ma, oa, g, Xd, warmup=2)       # 2 eager warm-up steps, then replays
+    la = [float(step()) for _ in range(6)]
+    lb = []
+    for _ in range(2 + 1 + 6):                              # warm-up + the captured (not executed... see below) + replays
+        g.ndata['h'] = Xd
+        l = mb.reconstruction_loss(g)
+        ob.zero_grad(); l.backward(); ob.step()
+        lb.append(float(l.detach()))
+    # capture itself does not execute the step: the replays are steps 3..8 of the trajectory
+    assert oa.steps_taken() == 2 + 6
+    assert np.allclose(la, lb[2:8], rtol=2e-4, atol=0)
+
+
 # ----------------------------------------------------------------- VGAE (BASELINE config 5)
 def test_normal_noise_moments(dev):
     from gae_dgl_amd import ops
