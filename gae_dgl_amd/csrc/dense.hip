@@ -183,17 +183,23 @@ int launch_gemm(const float *A, int64_t lda, const float *Amask, int64_t ldam, c
 
 template <int NT, bool BT, int PRO_A>
 int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t ldam, const float *B, int64_t ldb,
-                       const float *bias, int act, float *out, int64_t ldo, int64_t n, int K, int64_t J, hipStream_t s);
+                       const float *bias, int act, float *out, int64_t ldo, int64_t n, int K, int64_t J, hipStream_t s,
+                       float *split_ws, int64_t split_ws_floats);
 
 template <bool BT, int PRO_A, bool MASK_B>
 int dispatch_gemm(const float *A, int64_t lda, const float *Amask, int64_t ldam, const float *B, int64_t ldb,
                   const float *Bmask, int64_t ldbm, const float *bias, int act, float *out, int64_t ldo, int64_t n,
-                  int K, int64_t J, hipStream_t s)
+                  int K, int64_t J, hipStream_t s, float *split_ws = nullptr, int64_t split_ws_floats = 0)
 {
     if (!MASK_B && J <= 128 && g_gemm_stream) {
-        if (J <= 32) return launch_gemm_stream<1, BT, PRO_A>(A, lda, Amask, ldam, B, ldb, bias, act, out, ldo, n, K, J, s);
-        if (J <= 64) return launch_gemm_stream<2, BT, PRO_A>(A, lda, Amask, ldam, B, ldb, bias, act, out, ldo, n, K, J, s);
-        return launch_gemm_stream<4, BT, PRO_A>(A, lda, Amask, ldam, B, ldb, bias, act, out, ldo, n, K, J, s);
+        if (J <= 32)
+            return launch_gemm_stream<1, BT, PRO_A>(A, lda, Amask, ldam, B, ldb, bias, act, out, ldo, n, K, J, s, split_ws,
+                                                    split_ws_floats);
+        if (J <= 64)
+            return launch_gemm_stream<2, BT, PRO_A>(A, lda, Amask, ldam, B, ldb, bias, act, out, ldo, n, K, J, s, split_ws,
+                                                    split_ws_floats);
+        return launch_gemm_stream<4, BT, PRO_A>(A, lda, Amask, ldam, B, ldb, bias, act, out, ldo, n, K, J, s, split_ws,
+                                                split_ws_floats);
     }
     if (J <= 32)
         return launch_gemm<1, BT, PRO_A, MASK_B>(A, lda, Amask, ldam, B, ldb, Bmask, ldbm, bias, act, out, ldo, n, K, J, s);
@@ -215,7 +221,7 @@ template <int NT, bool BT, int PRO_A, bool AVEC, bool BVEC>
 __global__ __launch_bounds__(256) void gemm_stream_kernel(
     const float *__restrict__ A, int64_t lda, const float *__restrict__ Amask, int64_t ldam,
     const float *__restrict__ B, int64_t ldb, const float *__restrict__ bias, int act, float *__restrict__ out,
-    int64_t ldo, int64_t n, int K, int J)
+    int64_t ldo, int64_t n, int K, int J, int kb_per_split, int64_t split_stride)
 {
     __shared__ float red[4 * NT * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -223,8 +229,13 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(
     const int i = lane & 31, h = lane >> 5;
     const int64_t row = int64_t(blockIdx.x) * 32 + i;
     const bool rv = row < n;
-    const int kblocks = (K + 7) / 8, per = (kblocks + 3) / 4;
-    const int kb0 = wave * per, kb1 = min(kb0 + per, kblocks);
+    // split-K over blockIdx.y (operands with few row tiles and a long K): this block owns k-blocks [kbs0, kbs1)
+    // and writes its partial product to its own slab of `out`
+    const int kblocks = (K + 7) / 8;
+    const int kbs0 = blockIdx.y * kb_per_split, kbs1 = min(kbs0 + kb_per_split, kblocks);
+    const int per = (kbs1 - kbs0 + 3) / 4;
+    const int kb0 = kbs0 + wave * per, kb1 = min(kb0 + per, kbs1);
+    out += blockIdx.y * split_stride;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -336,23 +347,75 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(
     }
 }
 
+// out[e] = act(bias[e % J] + sum_s partial[s][e])  -- the second pass of the split-K forward Linear
+__global__ __launch_bounds__(256) void split_reduce_kernel(const float *__restrict__ partial, int splits,
+                                                           int64_t n_elems, int J, const float *__restrict__ bias,
+                                                           int act, float *__restrict__ out, int64_t ldo)
+{
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= n_elems) return;
+    float v[8];
+    float y = 0.f;
+    int sp = 0;
+    for (; sp + 8 <= splits; sp += 8) {     // 8 independent loads per trip, added in split order
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(sp + u) * n_elems + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) y += v[u];
+    }
+    for (; sp < splits; ++sp) y += partial[sp * n_elems + e];
+    const int64_t r = e / J;
+    const int c = int(e - r * J);
+    if (bias) y += bias[c];
+    if (act == GAE_ACT_RELU) y = y > 0.f ? y : 0.f;
+    out[r * ldo + c] = y;
+}
+
+// split-K factor of the tall-skinny product: 1 unless the operand has too few 32-row tiles to keep every CU
+// pulling on HBM (a CU sustains ~10 GB/s of line misses: Cora's 85 tiles alone reach 0.8 TB/s)
+inline int gemm_stream_splits(int64_t n, int K)
+{
+    const int64_t tiles = (n + 31) / 32;
+    const int kblocks = (K + 7) / 8;
+    if (tiles >= 384 || kblocks < 64) return 1;
+    int64_t sp = (768 + tiles - 1) / tiles;
+    if (sp > kblocks / 16) sp = kblocks / 16;        // at least 16 k-blocks (4 per wave) per split
+    if (sp > 32) sp = 32;
+    return sp < 1 ? 1 : int(sp);
+}
+
 template <int NT, bool BT, int PRO_A>
 int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t ldam, const float *B, int64_t ldb,
-                       const float *bias, int act, float *out, int64_t ldo, int64_t n, int K, int64_t J, hipStream_t s)
+                       const float *bias, int act, float *out, int64_t ldo, int64_t n, int K, int64_t J, hipStream_t s,
+                       float *split_ws, int64_t split_ws_floats)
 {
     bool avec = (lda % 4 == 0) && gae::aligned16(A) && K >= 1;
     if (PRO_A != PRO_NONE) avec = avec && (ldam % 4 == 0) && gae::aligned16(Amask);
     const bool bvec = BT && (ldb % 4 == 0) && gae::aligned16(B) && K >= 4 && (K % 4 == 0);
-    const dim3 grid(unsigned((n + 31) / 32));
+    int splits = split_ws ? gemm_stream_splits(n, K) : 1;
+    if (splits > 1 && split_ws_floats < int64_t(splits) * n * J) splits = 1;
+    const int kblocks = (K + 7) / 8;
+    const int kbps = (kblocks + splits - 1) / splits;
+    const dim3 grid(unsigned((n + 31) / 32), unsigned(splits));
+    float *dst = splits > 1 ? split_ws : out;
+    const int64_t ldd = splits > 1 ? J : ldo;
+    const float *bias1 = splits > 1 ? nullptr : bias;
+    const int act1 = splits > 1 ? GAE_ACT_IDENTITY : act;
 #define GAE_GS(AV, BV)                                                                                              \
     hipLaunchKernelGGL((gemm_stream_kernel<NT, BT, PRO_A, AV, BV>), grid, dim3(256), 0, s, A, lda, Amask, ldam, B, ldb, \
-                       bias, act, out, ldo, n, K, int(J))
+                       bias1, act1, dst, ldd, n, K, int(J), kbps, n * J)
     if (avec && bvec) GAE_GS(true, true);
     else if (avec) GAE_GS(true, false);
     else if (bvec) GAE_GS(false, true);
     else GAE_GS(false, false);
 #undef GAE_GS
     GAE_CHECK_LAUNCH("gemm_stream_kernel");
+    if (splits > 1) {
+        const int64_t ne = n * J;
+        hipLaunchKernelGGL(split_reduce_kernel, dim3(unsigned((ne + 255) / 256)), dim3(256), 0, s, split_ws, splits, ne,
+                           int(J), bias, act, out, ldo);
+        GAE_CHECK_LAUNCH("split_reduce_kernel");
+    }
     return GAE_OK;
 }
 
@@ -751,8 +814,16 @@ int *dense_knob(const char *name)
 } // namespace gae
 
 // ===========================================================================
+extern "C" int64_t gae_linear_fwd_workspace_bytes(int64_t n, int64_t f_in, int64_t f_out)
+{
+    if (n < 0 || f_in < 0 || f_out < 0 || f_in >= (1 << 24)) return GAE_E_SIZE;
+    const int sp = f_out <= 128 ? gemm_stream_splits(n, int(f_in)) : 1;
+    return sp > 1 ? (int64_t(sp) * n * f_out * 4 + 255) / 256 * 256 : 0;
+}
+
 extern "C" int gae_linear_fwd(const float *M, int64_t ldm, int64_t n, int64_t f_in, const float *W, const float *b,
-                              int64_t f_out, int act, float *Y, int64_t ldy, void *stream)
+                              int64_t f_out, int act, float *Y, int64_t ldy, void *workspace,
+                              int64_t workspace_bytes, void *stream)
 {
     GAE_REQUIRE(n >= 0 && f_in >= 0 && f_out >= 0, GAE_E_SIZE, "gae_linear_fwd: negative size");
     GAE_REQUIRE(f_in < (1 << 24) && f_out < (1 << 24), GAE_E_SIZE, "gae_linear_fwd: feature width too large");
@@ -760,8 +831,10 @@ extern "C" int gae_linear_fwd(const float *M, int64_t ldm, int64_t n, int64_t f_
     GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_DTYPE, "gae_linear_fwd: activation %d", act);
     if (n == 0 || f_out == 0) return GAE_OK;
     GAE_REQUIRE(Y && (f_in == 0 || (M && W)), GAE_E_NULL, "gae_linear_fwd: NULL pointer");
+    GAE_REQUIRE(!workspace || gae::aligned16(workspace), GAE_E_ALIGN, "gae_linear_fwd: workspace not 16-byte aligned");
     return dispatch_gemm<true, PRO_NONE, false>(M, ldm, nullptr, 0, W, f_in, nullptr, 0, b, act, Y, ldy, n, int(f_in),
-                                                f_out, gae::as_stream(stream));
+                                                f_out, gae::as_stream(stream), static_cast<float *>(workspace),
+                                                workspace ? workspace_bytes / 4 : 0);
 }
 
 static int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }

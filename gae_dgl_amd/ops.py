@@ -378,8 +378,10 @@ def linear_fwd_raw(M, W, b, act):
     f_out = W.shape[0]
     Y = torch.empty(n, f_out, dtype=torch.float32, device=M.device)
     with _on_device(M.device):
+        nbytes = _lib.load().gae_linear_fwd_workspace_bytes(n, f_in, f_out)
+        ws = _workspace(nbytes, M.device) if nbytes > 0 else None
         _lib.call("gae_linear_fwd", _ptr(M), ldm, n, f_in, _ptr(W), _ptr(b), f_out, act, _ptr(Y), max(f_out, 1),
-                  _stream())
+                  _ptr(ws), ws.numel() if ws is not None else 0, _stream())
     return Y
 
 

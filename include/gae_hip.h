@@ -192,10 +192,14 @@ int gae_spmm_csr_blockdiag(const int32_t *indptr, const int32_t *indices, const 
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16
  * M [n, f_in] (ldm), W [f_out, f_in] row-major contiguous (nn.Linear.weight,
- * gae_dgl/gae.py:10), b [f_out] (may be NULL), Y [n, f_out] (ldy). fp32. */
+ * gae_dgl/gae.py:10), b [f_out] (may be NULL), Y [n, f_out] (ldy). fp32.
+ * workspace (optional, gae_linear_fwd_workspace_bytes; 0 bytes for most shapes): operands with few rows and a
+ * long f_in (Cora 2708 x 1433, Citeseer 3327 x 3703) are split along f_in over more thread blocks, whose partial
+ * products meet in the workspace in fixed order; without it the product runs unsplit. */
+int64_t gae_linear_fwd_workspace_bytes(int64_t n, int64_t f_in, int64_t f_out);
 int gae_linear_fwd(const float *M, int64_t ldm, int64_t n, int64_t f_in,
                    const float *W, const float *b, int64_t f_out, int act,
-                   float *Y, int64_t ldy, void *stream);
+                   float *Y, int64_t ldy, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* autograd of the above.  dYm = dY (.) [Y > 0] when act = RELU.
  *   dW [f_out, f_in] = dYm^T M      (NULL to skip)

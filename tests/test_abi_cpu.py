@@ -47,7 +47,7 @@ def test_argument_errors_do_not_need_a_gpu():
     assert rc == -4
     assert lib.gae_spmm_workspace_bytes(None, 32) == 0
     assert lib.gae_spmm_plan_count(None, 8, 0, 512, None, None) == -6
-    rc = lib.gae_linear_fwd(None, 4, 4, 4, None, None, 4, 9, None, 4, None)
+    rc = lib.gae_linear_fwd(None, 4, 4, 4, None, None, 4, 9, None, 4, None, 0, None)
     assert rc == -4
     rc = lib.gae_dropout_mask(None, 8, ctypes.c_float(1.5), 0, 0, None, None)
     assert rc == -6
