@@ -466,10 +466,10 @@ def main():
         kb = [k for k in times if k[0] == "decoder_bce"]
         tb = float(np.mean([t for k in kb for t in times[k]]))
         n = kb[0][1]; d = kb[0][2]
-        flops = n * n * (2 * d + 2 * d)      # S = Zt Zt^T and O = sigmoid(S) Zt on the fp32 matrix cores
         line["decoder_loss"] = {"kernel": "fused decoder+BCE fwd+bwd (prepare + dense + edges + finalize)",
-                                "avg_us": tb * 1e6, "logits_per_s": n * n / tb, "bound": "mfma(f32)+valu",
-                                "mfma_tflops": flops / tb / 1e12, "mfma_f32_peak_tflops": 157.3}
+                                "avg_us_event_pairs_in_eager_steps": tb * 1e6, "logits_per_s": n * n / tb,
+                                "bound": "valu: 2 transcendentals + ~6 fp32 ops per logit next to bf16x3 MFMA "
+                                         "(S = Zt Zt^T, O = sigmoid(S) Zt); rocprofv3 kernel time in profiles/"}
     if not args.no_cpu_baseline and hasattr(wl, "cpu_baseline"):
         line["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
     if not args.no_extra and world == 1 and workload not in ("rmat",):

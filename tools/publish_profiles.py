@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Copy the measurements of tools/collect_r01.sh (gpurun_out/r01/) into profiles/ and derive
+profiles/pmc_traffic_r01.json + a markdown summary (stdout).  Runs in the build container, no GPU."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "r01")
+DST = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def last_json(path):
+    lines = [l for l in open(path).read().strip().splitlines() if l.startswith("{")]
+    return json.loads(lines[-1])
+
+
+def pmc_means(d):
+    out = {}
+    for f in sorted(glob.glob(os.path.join(d, "p*", "pmc_counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            if "spmm" not in r["Kernel_Name"]:
+                continue
+            k = (r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0], r["Counter_Name"])
+            out.setdefault(k, []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in out.items()}
+
+
+benches = {}
+for name in ("pubmed", "cora", "citeseer", "zinc", "rmat_s24_1gpu"):
+    p = os.path.join(SRC, f"bench_{name}.json")
+    if os.path.exists(p):
+        benches[name] = last_json(p)
+        json.dump(benches[name], open(os.path.join(DST, f"{TAG}_bench_{name}.json"), "w"), indent=1)
+for w in ("pubmed", "cora", "zinc"):
+    st = os.path.join(SRC, f"prof_{w}", "bench_kernel_stats.csv")
+    if os.path.exists(st):
+        shutil.copy(st, os.path.join(DST, f"{TAG}_{w}_step_kernel_stats.csv"))
+        shutil.copy(os.path.join(SRC, f"{w}_step_kernel_stats_top.txt"), os.path.join(DST, f"{TAG}_{w}_step_kernel_stats_top.txt"))
+for f in ("linear_bench.txt", "spmm_bench_pubmed.txt"):
+    if os.path.exists(os.path.join(SRC, f)):
+        shutil.copy(os.path.join(SRC, f), os.path.join(DST, f"{TAG}_{f}"))
+
+sys.path.insert(0, ROOT)
+from gae_dgl_amd import workloads as W  # noqa: E402  (pure numpy helpers)
+traffic = {"_how": "rocprofv3 --pmc, one counter set per pass (tools/pmc.sh: FETCH_SIZE | WRITE_SIZE | TCC_*), MI355X, "
+                   "ROCm 7.2, per-launch means over the launches of tools/spmm_one.py (operands and flags as the "
+                   "package launches them).  FETCH_SIZE is in KiB and doubled as MI355X_MICROARCH.md prescribes for "
+                   "16-B/lane coalesced reads on gfx950 (calibrated on the zinc-250k F=32 launch, whose compulsory "
+                   "read bytes are known); WRITE_SIZE is used as reported (matches the output bytes to 0.1 %)."}
+shapes = {"pubmed500": ("pubmed-F500", "pubmed", 500), "pubmed500_plain": ("pubmed-F500-untiled", "pubmed", 500),
+          "pubmed32": ("pubmed-F32", "pubmed", 32), "citeseer3703": ("citeseer-F3703", "citeseer", 3703),
+          "zinc32": ("zinc250k-F32", "zinc", 32), "zinc39": ("zinc250k-F39-ld40", "zinc", 39)}
+for sh, (key, graph, F) in shapes.items():
+    d = os.path.join(SRC, f"pmc_{sh}")
+    if not os.path.isdir(d):
+        continue
+    m = pmc_means(d)
+    kernels = sorted({k[0] for k in m})
+    main = max(kernels, key=lambda k: m.get((k, "FETCH_SIZE"), 0))
+    fetch, write = m.get((main, "FETCH_SIZE"), 0.0), m.get((main, "WRITE_SIZE"), 0.0)
+    log = open(os.path.join(SRC, f"pmc_{sh}.txt")).read() if os.path.exists(os.path.join(SRC, f"pmc_{sh}.txt")) else ""
+    done = [l for l in open(os.path.join(d, "p1.log")).read().splitlines() if l.startswith("done")]
+    n, nnz = (int(done[0].split()[2]), int(done[0].split()[3])) if done else (0, 0)
+    traffic[key] = {"kernel": main, "launch": done[0] if done else "", "fetch_kib_raw": fetch, "write_kib": write,
+                    "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
+                    "alg_bytes": W.spmm_alg_bytes(n, n, nnz, F, 4) if n else None,
+                    "tcc_hit": m.get((main, "TCC_HIT_sum")), "tcc_miss": m.get((main, "TCC_MISS_sum"))}
+    dd = os.path.join(DST, f"{TAG}_pmc_{sh}")
+    os.makedirs(dd, exist_ok=True)
+    for i, f in enumerate(sorted(glob.glob(os.path.join(d, "p*", "pmc_counter_collection.csv"))), 1):
+        shutil.copy(f, os.path.join(dd, f"pass{i}.csv"))
+json.dump(traffic, open(os.path.join(DST, f"pmc_traffic_{TAG}.json"), "w"), indent=1)
+
+print("| workload | ms/step | edges/s | dominant launch | us | % of 8 TB/s | CPU port ms/step |")
+print("|---|---|---|---|---|---|---|")
+for name, d in benches.items():
+    r = d["roofline"]; c = d.get("cpu_baseline") or {}
+    print(f"| {name} | {d['ms_per_step']:.4f} | {d['value']:.3e} | {r['kernel'][:60]} | {r['avg_launch_us']:.2f} | "
+          f"{100 * r['frac']:.1f} | {c.get('ms_per_step', float('nan')):.1f} |")
+if "pubmed" in benches and "extra" in benches["pubmed"]:
+    print()
+    for e in benches["pubmed"]["extra"]["spmm_kernel_only"]:
+        print(f"| {e['shape']} | F={e['F']} ld={e['ld']} | {e['us_per_launch']:.1f} us | {e['edges_per_s'] / 1e9:.2f} Gedge/s | "
+              f"{100 * e['frac_hbm_peak']:.1f} % |")
+    print(json.dumps(benches["pubmed"].get("decoder_loss")))
+for k, v in traffic.items():
+    if k != "_how":
+        print(k, v["hbm_bytes_per_launch"], v["alg_bytes"], v["kernel"][:70])

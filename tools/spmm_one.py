@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run one SpMM shape a few times (target of rocprofv3 --pmc / --kernel-trace passes)."""
+"""Run one SpMM shape a few times, exactly as the package launches it (target of rocprofv3 --pmc / --kernel-trace)."""
 import argparse
 import os
 import sys
@@ -10,33 +10,37 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gae_dgl_amd import _lib, ops, workloads as W  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--shape", default="pubmed500")
+ap.add_argument("--shape", default="pubmed500", help="pubmedF | coraF | citeseerF | zincF (whole set) | rmatF")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--knobs", default="")
 ap.add_argument("--rmat-scale", type=int, default=22)
+ap.add_argument("--plain", action="store_true", help="no plan, no feature tiles, no block-diagonal kernel")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 for kv in filter(None, a.knobs.split(",")):
     k, v = kv.split("=")
     _lib.call("gae_tuning_set", k.encode(), int(v))
-if a.shape.startswith("pubmed"):
-    n, src, dst, _ = W.citation_graph("pubmed")
+bd = None
+name = a.shape.rstrip("0123456789")
+F = int(a.shape[len(name):])
+if name in ("pubmed", "cora", "citeseer"):
+    n, src, dst, _ = W.citation_graph(name)
     s, d = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
-    al = a.shape.endswith("a")
-    F = int(a.shape[6:].rstrip("a")); ld = (F + 31) // 32 * 32 if al else F
-elif a.shape.startswith("zinc"):
+elif name == "zinc":
     gp, src, dst, _ = W.zinc_like(249455)
     n = int(gp[-1])
     s, d = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
-    F = int(a.shape[4:]); ld = (F + 3) // 4 * 4
+    bd = None if a.plain else ops.BlockDiag(gp, dev)
 else:
     s, d = W.rmat_edges(a.rmat_scale, 16, device=dev)
     n = 1 << a.rmat_scale
-    F = int(a.shape[4:]); ld = F
 ip, ix = ops.csr_from_coo(d, s, n, n)
-H = torch.rand(n, ld, device=dev)[:, :F]
-out = torch.empty(n, ld, device=dev)[:, :F]
+H = ops.pad_rows(torch.rand(n, F, device=dev))
+out = ops.pad_rows(torch.empty(n, F, device=dev))
+plan = None if a.plain else ops.spmm_plan(ip, indices=ix if bd is None else None)
+scattered = (not a.plain) and bd is None and F > ops.TILE_MIN_F and ops.gather_scattered(ip, ix, F * 4)
 for _ in range(a.iters):
-    ops.spmm_raw(ip, ix, H, n, out=out)
+    ops.spmm_raw(ip, ix, H, n, out=out, plan=plan, blockdiag=bd, out_padded=True, scattered=scattered)
 torch.cuda.synchronize()
-print("done", a.shape, n, int(ix.numel()), F)
+print("done", a.shape, n, int(ix.numel()), F, "ld", H.stride(0), "scattered", scattered, "plan", plan is not None,
+      "blockdiag", bd is not None)
