@@ -51,6 +51,7 @@ constexpr int PREP_ROWS = 64;    // rows per block of the prepare kernel
 int g_bce_ri = 2;
 int g_bce_minw = 0;
 int g_bce_s_bf16 = 1;
+int g_bce_sym = 1;       // "bce_sym": 1 = symmetric dense kernel for full-square launches with d <= 16
 int g_bce_pv_bf16 = 1;   // "bce_pv_bf16": 1 = bf16x3 for O' += P V as well (P split on the fly), 0 = exact fp32
 
 __device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
@@ -415,6 +416,301 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Symmetric form of the dense part (full square, d <= 16, bf16x3 products): X = Zt Zt^T is symmetric, so only the
+// tiles on and above the block diagonal are evaluated.  A block owns a panel of 128 rows (4 waves x 2 x 16) and
+// one chunk of the columns at or right of the panel:
+//   * tiles inside the panel's own 128 x 128 square are evaluated as in bce_dense_kernel (weight 1);
+//   * tiles right of it are evaluated ONCE (the 2 transcendentals + ~6 VALU ops per logit are the cost of this
+//     kernel) and serve both halves: their loss terms count twice, O'_I += P Z_J as before, and the mirror
+//     O'_J += P^T Z_I is a second small matrix product whose A operand is P transposed through a wave-private
+//     LDS tile (P sits in registers as lane = row i, regs = columns j; the mirror needs lane = column j).
+//     The 4 waves' mirror tiles meet in LDS (fixed order) and go to a triangular strip buffer
+//     Wmir[panel][f][j] that bce_mirror_reduce_kernel folds into O'_mirror[j][f] in panel order.
+// Mirror traffic: N^2 / 4 bytes written and read once (Pubmed 97 MB against 1.9 x 10^8 logits saved).
+// Zero-padded columns (j >= n) are corrected in the kernel (their log2(1 + e^0) = 1 is subtracted).
+// ---------------------------------------------------------------------------
+constexpr int SYM_PR = 128;   // rows per panel
+
+// the upper 16 bits of four fp32 values (exact when they are bf16 values): one v_perm_b32 per pair
+__device__ __forceinline__ s16x4 upper_halves(const f32x4 &d)
+{
+    struct U { unsigned a, b; } u{__builtin_amdgcn_perm(__float_as_uint(d[1]), __float_as_uint(d[0]), 0x07060302u),
+                                  __builtin_amdgcn_perm(__float_as_uint(d[3]), __float_as_uint(d[2]), 0x07060302u)};
+    return __builtin_bit_cast(s16x4, u);
+}
+
+// float offset of panel I's strip in Wmir: strips are [16][NP - PR (I + 1)] with NP = n rounded up to 64
+__host__ __device__ inline int64_t sym_strip_offset(int64_t I, int64_t NP)
+{
+    return 16 * (I * NP - SYM_PR * (I * (I + 1) / 2));
+}
+
+template <bool WITH_GRAD>
+__global__ __launch_bounds__(256, 3) void bce_dense_sym_kernel(
+    const float *__restrict__ Zt /*[n][16]*/, const unsigned short *__restrict__ Zhi,
+    const unsigned short *__restrict__ Zlo, int64_t n, int64_t cols_per_chunk,
+    float *__restrict__ O_partial /*[chunks][n][16]*/, float *__restrict__ Wmir,
+    double *__restrict__ loss_partial /*[chunks * panels][2]*/, const double *__restrict__ colsum_partial,
+    int64_t n_prep_blocks, double *__restrict__ S, float *__restrict__ S_all_f, unsigned n_panels)
+{
+    constexpr int RI = 2, DP = 16;
+    constexpr int LDH = DP + 4;          // bf16 LDS row stride (elements): 8-byte aligned rows
+    constexpr int V4 = TJ * DP / 4 / 256;  // = 1
+    constexpr int LDT = TJ + 4;          // transposed bf16 tile row stride (elements)
+    constexpr int LDM = TJ + 4;          // mirror tile row stride (floats)
+    __shared__ __attribute__((aligned(16))) unsigned short Hs[2][TJ * LDH];       // bf16 hi [j][k]
+    __shared__ __attribute__((aligned(16))) unsigned short Ls[2][TJ * LDH];       // bf16 lo [j][k]
+    __shared__ __attribute__((aligned(16))) unsigned short HT[2][DP * LDT];       // bf16 hi [k][j]
+    __shared__ __attribute__((aligned(16))) unsigned short LT[2][DP * LDT];       // bf16 lo [k][j]
+    __shared__ __attribute__((aligned(16))) float MR[4][16 * LDM];                // mirror tiles [wave][f][j]
+    __shared__ double red[4][2];
+
+    if (blockIdx.x >= n_panels) {   // the extra block column: column sums of Zt for the kernels that follow
+        if (blockIdx.y == 0)
+            bce_colsum_block(colsum_partial, n_prep_blocks, DP, S, S_all_f, reinterpret_cast<double *>(&MR[0][0]));
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int64_t I = blockIdx.x;
+    const int64_t NP = (n + 63) / 64 * 64;
+    const int64_t col_begin = SYM_PR * I + int64_t(blockIdx.y) * cols_per_chunk;
+    int64_t col_end = col_begin + cols_per_chunk;
+    if (col_end > n) col_end = n;
+    const int64_t lp_index = int64_t(blockIdx.y) * n_panels + blockIdx.x;
+    if (col_begin >= n) {            // chunk beyond this panel's columns
+        if (tid == 0) { loss_partial[2 * lp_index] = 0.0; loss_partial[2 * lp_index + 1] = 0.0; }
+        return;
+    }
+    const int64_t row_base = SYM_PR * I + wave * (RI * 16);
+    const int64_t diag_end = SYM_PR * (I + 1);      // tiles starting below this column lie in the panel's own square
+
+    constexpr float LOG2E = 1.44269504088896341f;
+    s16x4 bhi[RI], blo[RI];      // B fragments of S^T = Zj Zi^T (row operand, log2(e) folded in)
+    s16x4 zTh[RI], zTl[RI];      // B fragments of the mirror product: lane (f = l15, g) -> Zt[i = 4 g + r][f]
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri) {
+        const int64_t i = row_base + ri * 16 + l15;
+        f32x4 b = *reinterpret_cast<const f32x4 *>(Zt + (i < n ? i : 0) * DP + 4 * g);
+        if (i >= n) b = f32x4{0.f, 0.f, 0.f, 0.f};
+        b *= LOG2E;
+        split_bf16x4(b, bhi[ri], blo[ri]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t ir = row_base + ri * 16 + 4 * g + r;
+            const bool v = ir < n;
+            zTh[ri][r] = v ? short(Zhi[(v ? ir : 0) * DP + l15]) : short(0);
+            zTl[ri][r] = v ? short(Zlo[(v ? ir : 0) * DP + l15]) : short(0);
+        }
+    }
+    s16x4 ident;                 // B fragment of the 16 x 16 identity: lane (n = l15, g) -> [k = 4 g + r == n]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ident[r] = (4 * g + r == l15) ? short(0x3F80) : short(0);
+    f32x4 oacc[RI];
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri) oacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
+    double sumA[RI], sumL[RI];
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri) { sumA[ri] = 0.0; sumL[ri] = 0.0; }
+    // zero-padded columns (j >= n) exist only in the last tile of the last chunk: their count per lane, once
+    const int64_t pad_j0 = (col_end == n && (n % TJ) != 0) ? n / TJ * TJ : -1;
+    float pad_lane = 0.f;
+    if (pad_j0 >= 0) {
+#pragma unroll
+        for (int jt = 0; jt < TJ / 16; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pad_lane += (pad_j0 + jt * 16 + 4 * g + r >= n) ? 1.f : 0.f;
+    }
+
+    struct Stage { s16x4 h[V4], l[V4]; };
+    auto load_tile = [&](int64_t j0, Stage &st) {
+#pragma unroll
+        for (int q = 0; q < V4; ++q) {
+            const int idx = tid + 256 * q;
+            const int jj = idx / (DP / 4), kk = (idx % (DP / 4)) * 4;
+            const bool jv = j0 + jj < col_end;
+            const int64_t j = jv ? j0 + jj : col_begin;
+            st.h[q] = *reinterpret_cast<const s16x4 *>(Zhi + j * DP + kk);
+            st.l[q] = *reinterpret_cast<const s16x4 *>(Zlo + j * DP + kk);
+            if (!jv) { st.h[q] = s16x4{0, 0, 0, 0}; st.l[q] = s16x4{0, 0, 0, 0}; }
+        }
+    };
+    auto store_tile = [&](int buf, const Stage &st) {
+#pragma unroll
+        for (int q = 0; q < V4; ++q) {
+            const int idx = tid + 256 * q;
+            const int jj = idx / (DP / 4), kk = (idx % (DP / 4)) * 4;
+            *reinterpret_cast<s16x4 *>(&Hs[buf][jj * LDH + kk]) = st.h[q];
+            *reinterpret_cast<s16x4 *>(&Ls[buf][jj * LDH + kk]) = st.l[q];
+            if (WITH_GRAD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    HT[buf][(kk + e) * LDT + jj] = (unsigned short)st.h[q][e];
+                    LT[buf][(kk + e) * LDT + jj] = (unsigned short)st.l[q][e];
+                }
+            }
+        }
+    };
+    // sum the 4 waves' mirror tiles of the tile that started at column j0 and store it to this panel's strip
+    float *strip = Wmir + sym_strip_offset(I, NP);
+    const int64_t strip_ld = NP - diag_end;
+    auto flush_mirror = [&](int64_t j0) {
+        const int f = tid >> 4, jq = (tid & 15) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&MR[0][f * LDM + jq]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(&MR[w][f * LDM + jq]);
+        *reinterpret_cast<f32x4 *>(strip + f * strip_ld + (j0 - diag_end) + jq) = v;
+    };
+
+    auto compute_tile = [&](int buf, int64_t j0, bool offdiag) {
+        float tA[RI], tP[RI];
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri) { tA[ri] = 0.f; tP[ri] = 1.f; }
+#pragma unroll
+        for (int jt = 0; jt < TJ / 16; ++jt) {
+            f32x4 macc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 sacc[RI];
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri) sacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const s16x4 ah = *reinterpret_cast<const s16x4 *>(&Hs[buf][(jt * 16 + l15) * LDH + 4 * g]);
+            const s16x4 al = *reinterpret_cast<const s16x4 *>(&Ls[buf][(jt * 16 + l15) * LDH + 4 * g]);
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri) {
+                sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bhi[ri], sacc[ri], 0, 0, 0);
+                sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, blo[ri], sacc[ri], 0, 0, 0);
+                sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bhi[ri], sacc[ri], 0, 0, 0);
+            }
+            // sacc[ri][r] = y(i = l15 of subtile ri, j = jt*16 + 4 g + r), y = x log2(e)
+            f32x4 p[RI];
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = sacc[ri][r];
+                    const float e = __builtin_amdgcn_exp2f(-fabsf(x));
+                    const float t = 1.0f + e;
+                    tP[ri] *= t;
+                    tA[ri] += fabsf(x);
+                    const float sg = __builtin_amdgcn_rcpf(t) - 0.5f;   // in [0, 1/2]
+                    p[ri][r] = copysignf(sg, x);                        // sigmoid(x) - 1/2
+                }
+            }
+            if (WITH_GRAD) {
+                s16x4 ph[RI], pl[RI];
+#pragma unroll
+                for (int ri = 0; ri < RI; ++ri) split_bf16x4(p[ri], ph[ri], pl[ri]);
+                const s16x4 vh = *reinterpret_cast<const s16x4 *>(&HT[buf][l15 * LDT + jt * 16 + 4 * g]);
+                const s16x4 vl = *reinterpret_cast<const s16x4 *>(&LT[buf][l15 * LDT + jt * 16 + 4 * g]);
+#pragma unroll
+                for (int ri = 0; ri < RI; ++ri) {
+                    oacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pl[ri], vh, oacc[ri], 0, 0, 0);
+                    oacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ph[ri], vl, oacc[ri], 0, 0, 0);
+                    oacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ph[ri], vh, oacc[ri], 0, 0, 0);
+                }
+                if (offdiag) {
+                    // mirror: (P^T Z_I)[j][f] += sum_i P[i][j] Z[i][f] needs P with lane = column j, registers = rows
+                    // i; this lane holds P[i = l15][j = 4 g + r].  One MFMA against the identity re-lays it out on
+                    // the matrix pipe (which has room): D = P_hi I has the C layout lane = j, regs = i, and its
+                    // fp32 values are exactly the bf16 inputs, so their upper halves are the A fragments wanted.
+#pragma unroll
+                    for (int ri = 0; ri < RI; ++ri) {
+                        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                        const f32x4 dh = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ph[ri], ident, z4, 0, 0, 0);
+                        const f32x4 dl = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pl[ri], ident, z4, 0, 0, 0);
+                        const s16x4 qh = upper_halves(dh), ql = upper_halves(dl);
+                        macc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ql, zTh[ri], macc, 0, 0, 0);
+                        macc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qh, zTl[ri], macc, 0, 0, 0);
+                        macc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qh, zTh[ri], macc, 0, 0, 0);
+                    }
+                    // macc[r] = mirror(j = jt*16 + 4 g + r, f = l15)  ->  MR[wave][f][j]
+                    *reinterpret_cast<f32x4 *>(&MR[wave][l15 * LDM + jt * 16 + 4 * g]) = macc;
+                }
+            }
+        }
+        // zero-padded columns of the last tile (j >= n): each contributed log2(1 + e^0) = 1 per row
+        const float padcnt = j0 == pad_j0 ? pad_lane : 0.f;
+        const double w = offdiag ? 2.0 : 1.0;
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri) {
+            sumA[ri] += w * double(tA[ri]);
+            sumL[ri] += w * double(__builtin_amdgcn_logf(tP[ri]) - padcnt);
+        }
+    };
+
+    Stage stage;
+    load_tile(col_begin, stage);
+    store_tile(0, stage);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t j0 = col_begin; j0 < col_end; j0 += TJ, buf ^= 1) {
+        const bool more = j0 + TJ < col_end;
+        if (more) load_tile(j0 + TJ, stage);        // in flight while this tile is consumed
+        const bool offdiag = j0 >= diag_end;
+        compute_tile(buf, j0, offdiag);
+        if (more) store_tile(buf ^ 1, stage);
+        __syncthreads();
+        if (WITH_GRAD && offdiag) {                 // block-uniform
+            flush_mirror(j0);
+            __syncthreads();                        // MR is rewritten by the next tile
+        }
+    }
+    // ---- O' partial: oacc[ri][r] = O'(i = 4 g + r, f = l15) of subtile ri
+    if (WITH_GRAD) {
+        float *op = O_partial + int64_t(blockIdx.y) * n * DP;
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = row_base + ri * 16 + 4 * g + r;
+                if (i < n) op[i * DP + l15] = oacc[ri][r];
+            }
+    }
+    double la = 0.0, ll = 0.0;
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri) {
+        const bool rv = (row_base + ri * 16 + l15) < n;
+        la += rv ? sumA[ri] * 0.69314718055994531 : 0.0;    // sum |y| / log2(e) = sum |x|
+        ll += rv ? sumL[ri] : 0.0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { la += __shfl_down(la, off, 64); ll += __shfl_down(ll, off, 64); }
+    if (lane == 0) { red[wave][0] = la; red[wave][1] = ll; }
+    __syncthreads();
+    if (tid == 0) {
+        loss_partial[2 * lp_index + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        loss_partial[2 * lp_index + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+// O'_mirror[j][f] = sum over the panels left of j's panel, in panel order, of their strip entries.
+// Block = one 64-column tile; thread (f, 4 columns); up to 8 strips in flight.
+__global__ __launch_bounds__(256) void bce_mirror_reduce_kernel(const float *__restrict__ Wmir, int64_t n,
+                                                               float *__restrict__ Omir /*[n][16]*/)
+{
+    const int64_t NP = (n + 63) / 64 * 64;
+    const int64_t j0 = int64_t(blockIdx.x) * TJ;
+    const int f = threadIdx.x >> 4, jq = (threadIdx.x & 15) * 4;
+    const int64_t n_left = j0 / SYM_PR;       // panels 0 .. n_left - 1 hold a mirror tile for these columns
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto at = [&](int64_t I) {
+        const int64_t de = SYM_PR * (I + 1);
+        return *reinterpret_cast<const f32x4 *>(Wmir + sym_strip_offset(I, NP) + f * (NP - de) + (j0 - de) + jq);
+    };
+    int64_t I = 0;
+    for (; I + 8 <= n_left; I += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = at(I + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; I < n_left; ++I) acc += at(I);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (j0 + jq + e < n) Omir[(j0 + jq + e) * 16 + f] = acc[e];
+}
+
+// ---------------------------------------------------------------------------
 // Sparse part + assembly.  A group of LPR lanes owns node i (4 features per lane): in-edges from the CSR
 // give the loss terms and G_s Zt, out-edges from the CSR of A^T give G_s^T Zt; then
 //   dZ[i] = mask[i] * ( 2 (sum_splits O'[s][i] + S_all / 2) + sparse ) / N^2.
@@ -425,7 +721,8 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
     int64_t row_begin, int64_t n_local, int d, const int32_t *__restrict__ indptr,
     const int32_t *__restrict__ indices, const int32_t *__restrict__ t_indptr, const int32_t *__restrict__ t_indices,
     float pw, float inv_n2, const float *__restrict__ O_partial, int n_splits, int DP,
-    const float *__restrict__ S_all_f, float *__restrict__ dZ, int64_t lddz, double *__restrict__ loss_partial)
+    const float *__restrict__ S_all_f, float *__restrict__ dZ, int64_t lddz, double *__restrict__ loss_partial,
+    const float *__restrict__ O_mirror /*[n][16] or NULL*/, int64_t sym_cols_per_chunk)
 {
     static_assert(VEC == 4, "edge kernel reads the padded Zt rows as float4");
     __shared__ double red[4];
@@ -456,6 +753,11 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
     if (WITH_GRAD && rowv && fv) {
         const float *op = O_partial + i * DP + f0;
         const int64_t sstride = n * DP;
+        if (O_mirror) {     // symmetric dense kernel: row i's panel wrote ceil((n - panel start) / chunk) partials
+            const int64_t rem = n - (i / SYM_PR) * SYM_PR;
+            n_splits = int((rem + sym_cols_per_chunk - 1) / sym_cols_per_chunk);
+            osum = *reinterpret_cast<const f32x4 *>(O_mirror + i * DP + f0);
+        }
         int sp = 0;
         for (; sp + 4 <= n_splits; sp += 4) {        // 4 independent loads per trip, added in split order
             const f32x4 o0 = *reinterpret_cast<const f32x4 *>(op + (sp + 0) * sstride);
@@ -575,6 +877,8 @@ struct BcePlan {
     int KS, DP, LPR, VEC, RI;
     int64_t o_bytes, zt_bytes, zh_bytes, cs_bytes, s_bytes, n_dense, total_bytes;
     double pad_terms;
+    bool sym;                     // symmetric dense kernel (full square, d <= 16, bf16x3 products)
+    int64_t wmir_bytes, omir_bytes;
 };
 
 inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
@@ -610,6 +914,29 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     p.edge_blocks = (n_local + (256 / lpr) - 1) / (256 / lpr);
     if (p.edge_blocks < 1) p.edge_blocks = 1;
     p.prep_blocks = (n + PREP_ROWS - 1) / PREP_ROWS;
+    // Symmetric form: every tile right of the block diagonal is evaluated once for both halves.
+    p.sym = false;
+    p.wmir_bytes = p.omir_bytes = 0;
+    if (g_bce_sym && n_local == n && p.KS == 1 && g_bce_s_bf16 && g_bce_pv_bf16 &&
+        n >= (g_bce_sym > 1 ? 4 * SYM_PR : 8192)) {   // below ~8 k rows the extra launch costs more than it saves
+        const int64_t T = (n + SYM_PR - 1) / SYM_PR, NP = (n + 63) / 64 * 64;
+        int64_t chunks = (4096 + T - 1) / T;           // ~2048 live blocks (half of the (panel, chunk) grid)
+        if (chunks > 64) chunks = 64;
+        if (chunks > col_tiles) chunks = col_tiles;
+        if (chunks < 1) chunks = 1;
+        const int64_t cpc = ((n + chunks - 1) / chunks + TJ - 1) / TJ * TJ;
+        const int64_t last_len = NP - SYM_PR * T;      // strip length of the last panel (<= 0: it has no strip)
+        const int64_t wfloats = sym_strip_offset(T - 1, NP) + 16 * (last_len > 0 ? last_len : 0);
+        if (wfloats * 4 <= (int64_t(8) << 30)) {
+            p.sym = true;
+            p.row_blocks = T;
+            p.cols_per_split = cpc;
+            p.n_splits = (n + cpc - 1) / cpc;
+            p.pad_terms = 0.0;                         // padded columns are corrected inside the kernel
+            p.wmir_bytes = align256(wfloats * 4);
+            p.omir_bytes = align256(n * 16 * 4);
+        }
+    }
     p.o_bytes = align256(p.n_splits * n_local * p.DP * 4);
     p.zt_bytes = align256(n * p.DP * 4);
     p.zh_bytes = align256(n * p.DP * 2);
@@ -617,7 +944,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     p.s_bytes = align256(2 * p.DP * 8 + p.DP * 4);
     p.n_dense = p.row_blocks * p.n_splits;
     p.total_bytes = p.o_bytes + p.zt_bytes + 2 * p.zh_bytes + p.cs_bytes + p.s_bytes +
-                    align256((2 * p.n_dense + p.edge_blocks) * 8);
+                    align256((2 * p.n_dense + p.edge_blocks) * 8) + p.wmir_bytes + p.omir_bytes;
     return true;
 }
 
@@ -659,12 +986,13 @@ int launch_dense(const BcePlan &p, const float *Zt, const unsigned short *Zhi, c
 template <int VEC, bool WITH_GRAD>
 int launch_edges(const BcePlan &p, const float *Zt, const float *mask, int64_t ldz, int64_t row_begin, int64_t n, int d,
                  const int32_t *ip, const int32_t *ix, const int32_t *tp, const int32_t *tx, float pw, float inv_n2,
-                 const float *O, const float *S_all_f, float *dZ, int64_t lddz, double *lp, hipStream_t s)
+                 const float *O, const float *S_all_f, float *dZ, int64_t lddz, double *lp, const float *Omir,
+                 hipStream_t s)
 {
 #define GAE_EDGE(LPR)                                                                                              \
     hipLaunchKernelGGL((bce_edges_kernel<VEC, LPR, WITH_GRAD>), dim3(unsigned(p.edge_blocks)), dim3(256), 0, s, Zt, \
                        mask, ldz, row_begin, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, S_all_f,  \
-                       dZ, lddz, lp)
+                       dZ, lddz, lp, Omir, p.cols_per_split)
     switch (p.LPR) {
     case 1: GAE_EDGE(1); break;
     case 2: GAE_EDGE(2); break;
@@ -686,6 +1014,7 @@ int *bce_knob(const char *name)
     if (strcmp(name, "bce_minw") == 0) return &g_bce_minw;
     if (strcmp(name, "bce_s_bf16") == 0) return &g_bce_s_bf16;
     if (strcmp(name, "bce_pv_bf16") == 0) return &g_bce_pv_bf16;
+    if (strcmp(name, "bce_sym") == 0) return &g_bce_sym;
     return nullptr;
 }
 } // namespace gae
@@ -731,7 +1060,9 @@ extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, in
     double *cs = reinterpret_cast<double *>(w); w += p.cs_bytes;
     double *S = reinterpret_cast<double *>(w);
     float *S_all_f = reinterpret_cast<float *>(w + 2 * p.DP * 8); w += p.s_bytes;
-    double *lp = reinterpret_cast<double *>(w);
+    double *lp = reinterpret_cast<double *>(w); w += align256((2 * p.n_dense + p.edge_blocks) * 8);
+    float *Wmir = reinterpret_cast<float *>(w); w += p.wmir_bytes;
+    float *Omir = reinterpret_cast<float *>(w);
     const double inv_n2 = 1.0 / (double(n) * double(n));
     if (n_local == 0) {
         GAE_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), s));
@@ -741,14 +1072,32 @@ extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, in
                        row_begin, row_begin + n_local, Zt, Zhi, Zlo, cs, dropout_p, 1.0f / (1.0f - dropout_p), seed,
                        offset, draw_dev);
     GAE_CHECK_LAUNCH("bce_prepare_kernel");
-    int rc = dZ ? launch_dense<true>(p, Zt, Zhi, Zlo, n, row_begin, n_local, O, lp, cs, S, S_all_f, s)
+    int rc;
+    if (p.sym) {
+        const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
+        if (dZ)
+            hipLaunchKernelGGL((bce_dense_sym_kernel<true>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O,
+                               Wmir, lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks));
+        else
+            hipLaunchKernelGGL((bce_dense_sym_kernel<false>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split,
+                               O, Wmir, lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks));
+        GAE_CHECK_LAUNCH("bce_dense_sym_kernel");
+        if (dZ) {
+            hipLaunchKernelGGL(bce_mirror_reduce_kernel, dim3(unsigned((n + TJ - 1) / TJ)), dim3(256), 0, s, Wmir, n,
+                               Omir);
+            GAE_CHECK_LAUNCH("bce_mirror_reduce_kernel");
+        }
+        rc = GAE_OK;
+    } else {
+        rc = dZ ? launch_dense<true>(p, Zt, Zhi, Zlo, n, row_begin, n_local, O, lp, cs, S, S_all_f, s)
                 : launch_dense<false>(p, Zt, Zhi, Zlo, n, row_begin, n_local, O, lp, cs, S, S_all_f, s);
+    }
     if (rc) return rc;
     double *lpe = lp + 2 * p.n_dense;
     rc = dZ ? launch_edges<4, true>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr, t_indices,
-                                    pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, s)
+                                    pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, p.sym ? Omir : nullptr, s)
             : launch_edges<4, false>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr,
-                                     t_indices, pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, s);
+                                     t_indices, pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, nullptr, s);
     if (rc) return rc;
     hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(256), 0, s, lp, p.n_dense, lpe, p.edge_blocks, S, p.DP,
                        p.pad_terms, inv_n2, loss_out, dropout_p > 0.f ? draw_dev : nullptr);

@@ -568,6 +568,44 @@ def test_fused_loss_vs_oracle_random(n, d, e, dev):
         assert rel_err(ops.decoder_bce(t(Z, dev), t(mask, dev), gr), ref) < TOL
 
 
+@pytest.mark.parametrize("n,d", [(512, 16), (513, 16), (700, 7), (1000, 3), (1025, 16), (4096, 16), (5000, 12),
+                                 (8193, 16)])
+def test_fused_loss_symmetric_kernel(n, d, dev):
+    """symmetric dense kernel (tiles right of the block diagonal evaluated once, mirror product, strip reduction)
+    == the full-square kernel == the oracle; panels / tiles / chunks with tails in every dimension"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, _lib
+    rng = np.random.default_rng(n + d)
+    src, dst = rand_graph(rng, n, 5 * n, hub=True)
+    Z = (rng.standard_normal((n, d)) * 0.7).astype(np.float32)
+    mask = ((rng.random((n, d)) >= 0.1) / 0.9).astype(np.float32)
+    gr = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    out = {}
+    for sym in (2, 0):                       # 2 = symmetric kernel from 512 rows on (default: from 8192)
+        _lib.call("gae_tuning_set", b"bce_sym", sym)
+        try:
+            Zd = t(Z, dev).requires_grad_(True)
+            loss = ops.decoder_bce(Zd, t(mask, dev), gr)
+            loss.backward()
+            with torch.no_grad():
+                lo = ops.decoder_bce(t(Z, dev), t(mask, dev), gr)          # loss-only mode
+            again = ops.decoder_bce(t(Z, dev).requires_grad_(True), t(mask, dev), gr)
+            out[sym] = (loss.detach(), Zd.grad.clone(), lo, again.detach())
+        finally:
+            _lib.call("gae_tuning_set", b"bce_sym", 1)
+    assert rel_err(out[2][0], out[0][0].double().cpu()) < 2e-6
+    assert rel_err(out[2][1], out[0][1].double().cpu()) < TOL
+    assert rel_err(out[2][2], out[0][0].double().cpu()) < 2e-6
+    assert torch.equal(out[2][0], out[2][3])                               # deterministic
+    if n <= 1100:
+        adj = O().dense_adjacency(src, dst, n, dtype=torch.float64)
+        Zt = torch.tensor(Z, dtype=torch.float64, requires_grad=True)
+        ref = O().bce_with_logits_mean(O().decoder_logits(Zt, torch.tensor(mask, dtype=torch.float64)), adj,
+                                       O().pos_weight_of(adj))
+        ref.backward()
+        assert rel_err(out[2][0], ref) < TOL and rel_err(out[2][1], Zt.grad) < 5 * TOL
+
+
 def test_fused_loss_equals_dense_path_large(dev):
     """Pubmed-sized: fused loss/grad == dense HIP decoder + torch BCE on the same Z"""
     import gae_dgl_amd as G

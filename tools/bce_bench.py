@@ -10,11 +10,16 @@ from gae_dgl_amd import _lib, ops, workloads as W
 ap = argparse.ArgumentParser()
 ap.add_argument("--graph", default="pubmed")
 ap.add_argument("--d", type=int, default=16)
-ap.add_argument("--variants", default="ri=2,sb=1;ri=2,sb=0;ri=1,sb=1;ri=4,sb=1;ri=2,sb=1,minw=6")
+ap.add_argument("--variants", default="sym=1;sym=0;sym=0,sb=0")
+ap.add_argument("--n", type=int, default=0, help="random graph with this many nodes instead of --graph")
 ap.add_argument("--rounds", type=int, default=5)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-n, src, dst, _ = W.citation_graph(a.graph)
+if a.n:
+    rng = np.random.default_rng(0)
+    n = a.n; src = rng.integers(0, n, 5 * n); dst = rng.integers(0, n, 5 * n)
+else:
+    n, src, dst, _ = W.citation_graph(a.graph)
 g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
 g.csr(); g.csc()
 Z = torch.randn(n, a.d, device=dev) * 0.5
@@ -29,6 +34,7 @@ for rnd in range(a.rounds + 1):
         _lib.call("gae_tuning_set", b"bce_minw", int(kv.get("minw", 0)))
         _lib.call("gae_tuning_set", b"bce_s_bf16", int(kv.get("sb", 1)))
         _lib.call("gae_tuning_set", b"bce_pv_bf16", int(kv.get("pb", 1)))
+        _lib.call("gae_tuning_set", b"bce_sym", int(kv.get("sym", 1)))
         fn = lambda: ops.decoder_bce_raw(Z, mask, g.csr(), g.csc(), pw, True)
         loss, dz = fn(); torch.cuda.synchronize()
         if rnd == 0:
