@@ -35,6 +35,7 @@ for rnd in range(a.rounds + 1):
         _lib.call("gae_tuning_set", b"bce_s_bf16", int(kv.get("sb", 1)))
         _lib.call("gae_tuning_set", b"bce_pv_bf16", int(kv.get("pb", 1)))
         _lib.call("gae_tuning_set", b"bce_sym", int(kv.get("sym", 1)))
+        _lib.call("gae_tuning_set", b"bce_sym_grid", int(kv.get("grid", 4096)))
         fn = lambda: ops.decoder_bce_raw(Z, mask, g.csr(), g.csc(), pw, True)
         loss, dz = fn(); torch.cuda.synchronize()
         if rnd == 0:
