@@ -923,7 +923,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
         n >= (g_bce_sym > 1 ? 4 * SYM_PR : 8192)) {   // below ~8 k rows the extra launch costs more than it saves
         const int64_t T = (n + SYM_PR - 1) / SYM_PR, NP = (n + 63) / 64 * 64;
         int64_t chunks = (g_bce_sym_grid + T - 1) / T; // half of the (panel, chunk) grid is live
-        if (chunks > 64) chunks = 64;
+        if (chunks > 28) chunks = 28;                  // every chunk is one more partial O' per row to write and add
         if (chunks > col_tiles) chunks = col_tiles;
         if (chunks < 1) chunks = 1;
         const int64_t cpc = ((n + chunks - 1) / chunks + TJ - 1) / TJ * TJ;
