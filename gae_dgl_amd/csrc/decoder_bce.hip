@@ -431,7 +431,10 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
 // Mirror traffic: N^2 / 4 bytes written and read once (Pubmed 97 MB against 1.9 x 10^8 logits saved).
 // Zero-padded columns (j >= n) are corrected in the kernel (their log2(1 + e^0) = 1 is subtracted).
 // ---------------------------------------------------------------------------
-constexpr int SYM_PR = 128;   // rows per panel
+// rows per panel = 64 RI (4 waves x RI subtiles of 16 rows); "bce_sym_ri" = 0 (auto) | 2 | 4.  Taller panels halve
+// the mirror strips (N^2 / 8 bytes) at the price of registers (2 waves per SIMD): they pay from ~32 k rows on
+// (ZINC batch of 95 k rows: 3.38 -> 3.13 ms; Pubmed, 20 k rows: 206 -> 212 us)
+int g_bce_sym_ri = 0;
 
 // the upper 16 bits of four fp32 values (exact when they are bf16 values): one v_perm_b32 per pair
 __device__ __forceinline__ s16x4 upper_halves(const f32x4 &d)
@@ -442,20 +445,20 @@ __device__ __forceinline__ s16x4 upper_halves(const f32x4 &d)
 }
 
 // float offset of panel I's strip in Wmir: strips are [16][NP - PR (I + 1)] with NP = n rounded up to 64
-__host__ __device__ inline int64_t sym_strip_offset(int64_t I, int64_t NP)
+__host__ __device__ inline int64_t sym_strip_offset(int64_t I, int64_t NP, int64_t PR)
 {
-    return 16 * (I * NP - SYM_PR * (I * (I + 1) / 2));
+    return 16 * (I * NP - PR * (I * (I + 1) / 2));
 }
 
-template <bool WITH_GRAD>
-__global__ __launch_bounds__(256, 3) void bce_dense_sym_kernel(
+template <bool WITH_GRAD, int RI>
+__global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     const float *__restrict__ Zt /*[n][16]*/, const unsigned short *__restrict__ Zhi,
     const unsigned short *__restrict__ Zlo, int64_t n, int64_t cols_per_chunk,
     float *__restrict__ O_partial /*[chunks][n][16]*/, float *__restrict__ Wmir,
     double *__restrict__ loss_partial /*[chunks * panels][2]*/, const double *__restrict__ colsum_partial,
     int64_t n_prep_blocks, double *__restrict__ S, float *__restrict__ S_all_f, unsigned n_panels)
 {
-    constexpr int RI = 2, DP = 16;
+    constexpr int DP = 16, SYM_PR = 64 * RI;
     constexpr int LDH = DP + 4;          // bf16 LDS row stride (elements): 8-byte aligned rows
     constexpr int V4 = TJ * DP / 4 / 256;  // = 1
     constexpr int LDT = TJ + 4;          // transposed bf16 tile row stride (elements)
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(256, 3) void bce_dense_sym_kernel(
         }
     };
     // sum the 4 waves' mirror tiles of the tile that started at column j0 and store it to this panel's strip
-    float *strip = Wmir + sym_strip_offset(I, NP);
+    float *strip = Wmir + sym_strip_offset(I, NP, SYM_PR);
     const int64_t strip_ld = NP - diag_end;
     auto flush_mirror = [&](int64_t j0) {
         const int f = tid >> 4, jq = (tid & 15) * 4;
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(256, 3) void bce_dense_sym_kernel(
 // O'_mirror[j][f] = sum over the panels left of j's panel, in panel order, of their strip entries.
 // Block = one 64-column tile; thread (f, 4 columns); up to 8 strips in flight.
 __global__ __launch_bounds__(256) void bce_mirror_reduce_kernel(const float *__restrict__ Wmir, int64_t n,
-                                                               float *__restrict__ Omir /*[n][16]*/)
+                                                               float *__restrict__ Omir /*[n][16]*/, int SYM_PR)
 {
     const int64_t NP = (n + 63) / 64 * 64;
     const int64_t j0 = int64_t(blockIdx.x) * TJ;
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(256) void bce_mirror_reduce_kernel(const float *__r
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     auto at = [&](int64_t I) {
         const int64_t de = SYM_PR * (I + 1);
-        return *reinterpret_cast<const f32x4 *>(Wmir + sym_strip_offset(I, NP) + f * (NP - de) + (j0 - de) + jq);
+        return *reinterpret_cast<const f32x4 *>(Wmir + sym_strip_offset(I, NP, SYM_PR) + f * (NP - de) + (j0 - de) + jq);
     };
     int64_t I = 0;
     for (; I + 8 <= n_left; I += 8) {
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
     const int32_t *__restrict__ indices, const int32_t *__restrict__ t_indptr, const int32_t *__restrict__ t_indices,
     float pw, float inv_n2, const float *__restrict__ O_partial, int n_splits, int DP,
     const float *__restrict__ S_all_f, float *__restrict__ dZ, int64_t lddz, double *__restrict__ loss_partial,
-    const float *__restrict__ O_mirror /*[n][16] or NULL*/, int64_t sym_cols_per_chunk)
+    const float *__restrict__ O_mirror /*[n][16] or NULL*/, int64_t sym_cols_per_chunk, int SYM_PR)
 {
     static_assert(VEC == 4, "edge kernel reads the padded Zt rows as float4");
     __shared__ double red[4];
@@ -880,6 +883,7 @@ struct BcePlan {
     int64_t o_bytes, zt_bytes, zh_bytes, cs_bytes, s_bytes, n_dense, total_bytes;
     double pad_terms;
     bool sym;                     // symmetric dense kernel (full square, d <= 16, bf16x3 products)
+    int sym_pr;                   // its panel height (rows)
     int64_t wmir_bytes, omir_bytes;
 };
 
@@ -918,9 +922,12 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     p.prep_blocks = (n + PREP_ROWS - 1) / PREP_ROWS;
     // Symmetric form: every tile right of the block diagonal is evaluated once for both halves.
     p.sym = false;
+    p.sym_pr = 128;
     p.wmir_bytes = p.omir_bytes = 0;
     if (g_bce_sym && n_local == n && p.KS == 1 && g_bce_s_bf16 && g_bce_pv_bf16 &&
-        n >= (g_bce_sym > 1 ? 4 * SYM_PR : 8192)) {   // below ~8 k rows the extra launch costs more than it saves
+        n >= (g_bce_sym > 1 ? 512 : 8192)) {           // below ~8 k rows the extra launch costs more than it saves
+        const int64_t SYM_PR = (g_bce_sym_ri == 4 || (g_bce_sym_ri == 0 && n >= 32768)) ? 256 : 128;
+        p.sym_pr = int(SYM_PR);
         const int64_t T = (n + SYM_PR - 1) / SYM_PR, NP = (n + 63) / 64 * 64;
         int64_t chunks = (g_bce_sym_grid + T - 1) / T; // half of the (panel, chunk) grid is live
         if (chunks > 28) chunks = 28;                  // every chunk is one more partial O' per row to write and add
@@ -928,7 +935,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
         if (chunks < 1) chunks = 1;
         const int64_t cpc = ((n + chunks - 1) / chunks + TJ - 1) / TJ * TJ;
         const int64_t last_len = NP - SYM_PR * T;      // strip length of the last panel (<= 0: it has no strip)
-        const int64_t wfloats = sym_strip_offset(T - 1, NP) + 16 * (last_len > 0 ? last_len : 0);
+        const int64_t wfloats = sym_strip_offset(T - 1, NP, SYM_PR) + 16 * (last_len > 0 ? last_len : 0);
         if (wfloats * 4 <= (int64_t(8) << 30)) {
             p.sym = true;
             p.row_blocks = T;
@@ -994,7 +1001,7 @@ int launch_edges(const BcePlan &p, const float *Zt, const float *mask, int64_t l
 #define GAE_EDGE(LPR)                                                                                              \
     hipLaunchKernelGGL((bce_edges_kernel<VEC, LPR, WITH_GRAD>), dim3(unsigned(p.edge_blocks)), dim3(256), 0, s, Zt, \
                        mask, ldz, row_begin, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, S_all_f,  \
-                       dZ, lddz, lp, Omir, p.cols_per_split)
+                       dZ, lddz, lp, Omir, p.cols_per_split, p.sym_pr)
     switch (p.LPR) {
     case 1: GAE_EDGE(1); break;
     case 2: GAE_EDGE(2); break;
@@ -1018,6 +1025,7 @@ int *bce_knob(const char *name)
     if (strcmp(name, "bce_pv_bf16") == 0) return &g_bce_pv_bf16;
     if (strcmp(name, "bce_sym") == 0) return &g_bce_sym;
     if (strcmp(name, "bce_sym_grid") == 0) return &g_bce_sym_grid;
+    if (strcmp(name, "bce_sym_ri") == 0) return &g_bce_sym_ri;
     return nullptr;
 }
 } // namespace gae
@@ -1078,16 +1086,16 @@ extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, in
     int rc;
     if (p.sym) {
         const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
-        if (dZ)
-            hipLaunchKernelGGL((bce_dense_sym_kernel<true>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O,
-                               Wmir, lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks));
-        else
-            hipLaunchKernelGGL((bce_dense_sym_kernel<false>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split,
-                               O, Wmir, lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks));
+#define GAE_SYM(WG, R)                                                                                             \
+    hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
+                       lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks))
+        if (p.sym_pr == 256) { if (dZ) GAE_SYM(true, 4); else GAE_SYM(false, 4); }
+        else { if (dZ) GAE_SYM(true, 2); else GAE_SYM(false, 2); }
+#undef GAE_SYM
         GAE_CHECK_LAUNCH("bce_dense_sym_kernel");
         if (dZ) {
             hipLaunchKernelGGL(bce_mirror_reduce_kernel, dim3(unsigned((n + TJ - 1) / TJ)), dim3(256), 0, s, Wmir, n,
-                               Omir);
+                               Omir, p.sym_pr);
             GAE_CHECK_LAUNCH("bce_mirror_reduce_kernel");
         }
         rc = GAE_OK;

@@ -583,6 +583,7 @@ def test_fused_loss_symmetric_kernel(n, d, dev):
     out = {}
     for sym in (2, 0):                       # 2 = symmetric kernel from 512 rows on (default: from 8192)
         _lib.call("gae_tuning_set", b"bce_sym", sym)
+        _lib.call("gae_tuning_set", b"bce_sym_ri", 4 if n % 2 else 2)      # both panel heights across the cases
         try:
             Zd = t(Z, dev).requires_grad_(True)
             loss = ops.decoder_bce(Zd, t(mask, dev), gr)
@@ -593,6 +594,7 @@ def test_fused_loss_symmetric_kernel(n, d, dev):
             out[sym] = (loss.detach(), Zd.grad.clone(), lo, again.detach())
         finally:
             _lib.call("gae_tuning_set", b"bce_sym", 1)
+            _lib.call("gae_tuning_set", b"bce_sym_ri", 0)
     assert rel_err(out[2][0], out[0][0].double().cpu()) < 2e-6
     assert rel_err(out[2][1], out[0][1].double().cpu()) < TOL
     assert rel_err(out[2][2], out[0][0].double().cpu()) < 2e-6
