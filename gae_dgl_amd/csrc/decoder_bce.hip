@@ -764,33 +764,47 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
             osum = *reinterpret_cast<const f32x4 *>(O_mirror + i * DP + f0);
         }
         int sp = 0;
-        for (; sp + 4 <= n_splits; sp += 4) {        // 4 independent loads per trip, added in split order
-            const f32x4 o0 = *reinterpret_cast<const f32x4 *>(op + (sp + 0) * sstride);
-            const f32x4 o1 = *reinterpret_cast<const f32x4 *>(op + (sp + 1) * sstride);
-            const f32x4 o2 = *reinterpret_cast<const f32x4 *>(op + (sp + 2) * sstride);
-            const f32x4 o3 = *reinterpret_cast<const f32x4 *>(op + (sp + 3) * sstride);
-            osum = (((osum + o0) + o1) + o2) + o3;
+        for (; sp + 8 <= n_splits; sp += 8) {        // 8 independent loads per trip, added in split order
+            f32x4 o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = *reinterpret_cast<const f32x4 *>(op + (sp + u) * sstride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) osum += o[u];
         }
-        for (; sp < n_splits; ++sp) osum += *reinterpret_cast<const f32x4 *>(op + sp * sstride);
+        if (sp < n_splits) {                         // tail: one more trip, clamped loads, selected to zero
+            f32x4 o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int su = sp + u < n_splits ? sp + u : n_splits - 1;
+                o[u] = *reinterpret_cast<const f32x4 *>(op + su * sstride);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) osum += (sp + u < n_splits) ? o[u] : zero4;
+        }
     }
     double lsum = 0.0;
-    // In-edges (CSR: loss + G_s Zt) and out-edges (CSR of A^T: G_s^T Zt) of node i advance TOGETHER, 4 edges of
-    // each per trip: the ids come from one coalesced load per list, the 8 neighbour rows are all in flight before
-    // the first dot product (one memory round trip per trip for both lists).
+    // In-edges (CSR: loss + G_s Zt) and out-edges (CSR of A^T: G_s^T Zt) of node i advance TOGETHER, NE edges of
+    // each per trip: the ids come from two coalesced loads per list, the 2 NE neighbour rows are all in flight
+    // before the first dot product (one memory round trip per trip for both lists; rows of <= 8 edges: one trip).
+    constexpr int NE = LPR >= 4 ? 8 : 4;
     const int glane0 = (lane / LPR) * LPR;
     while (posA < endA || posB < endB) {
-        const int32_t eA = posA + (LPR >= 4 ? (lig & 3) : 0), eB = posB + (LPR >= 4 ? (lig & 3) : 0);
-        const int32_t mineA = eA < endA ? indices[eA] : 0;
-        const int32_t mineB = (WITH_GRAD && eB < endB) ? t_indices[eB] : 0;
-        float zj[8][VEC], dot[8];
+        int32_t mineA[NE / 4], mineB[NE / 4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool second = u >= 4;
+        for (int h = 0; h < NE / 4; ++h) {
+            const int32_t eA = posA + 4 * h + (LPR >= 4 ? (lig & 3) : 0), eB = posB + 4 * h + (LPR >= 4 ? (lig & 3) : 0);
+            mineA[h] = eA < endA ? indices[eA] : 0;
+            mineB[h] = (WITH_GRAD && eB < endB) ? t_indices[eB] : 0;
+        }
+        float zj[2 * NE][VEC], dot[2 * NE];
+#pragma unroll
+        for (int u = 0; u < 2 * NE; ++u) {
+            const bool second = u >= NE;
             if (second && !WITH_GRAD) { dot[u] = 0.f; continue; }
             const int32_t pos = second ? posB : posA, end = second ? endB : endA;
-            const int32_t mine = second ? mineB : mineA;
-            const int uu = u & 3;
-            const int32_t j = LPR >= 4 ? __shfl(mine, glane0 + uu, 64)
+            const int uu = u % NE;
+            const int32_t mine = second ? mineB[uu / 4] : mineA[uu / 4];
+            const int32_t j = LPR >= 4 ? __shfl(mine, glane0 + (uu & 3), 64)
                                        : (pos + uu < end ? (second ? t_indices : indices)[pos + uu] : 0);
             const bool ev = pos + uu < end;
             dot[u] = 0.f;
@@ -804,12 +818,12 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
 #pragma unroll
         for (int off = LPR / 2; off > 0; off >>= 1)
 #pragma unroll
-            for (int u = 0; u < (WITH_GRAD ? 8 : 4); ++u) dot[u] += __shfl_xor(dot[u], off, 64);
+            for (int u = 0; u < (WITH_GRAD ? 2 * NE : NE); ++u) dot[u] += __shfl_xor(dot[u], off, 64);
 #pragma unroll
-        for (int u = 0; u < (WITH_GRAD ? 8 : 4); ++u) {
-            const bool second = u >= 4;
+        for (int u = 0; u < (WITH_GRAD ? 2 * NE : NE); ++u) {
+            const bool second = u >= NE;
             const int32_t pos = second ? posB : posA, end = second ? endB : endA;
-            if (pos + (u & 3) < end) {
+            if (pos + (u % NE) < end) {
                 const float x = dot[u];
                 float spn, sgn;               // softplus(-x), sigmoid(-x)
                 softplus_sigmoid(-x, spn, sgn);
@@ -823,8 +837,8 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
                 }
             }
         }
-        posA = min(posA + 4, endA);
-        posB = min(posB + 4, endB);
+        posA = min(posA + NE, endA);
+        posB = min(posB + NE, endB);
     }
     if (WITH_GRAD && rowv) {
 #pragma unroll
@@ -847,32 +861,39 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
 
 // single block: ordered sums of all partials -> mean
 //   N^2 loss = 1/2 S_win.S_all + 1/2 sum|x| + ln2 (sum log2(t) - pad_cols * n_local) + edges
-__global__ __launch_bounds__(256) void bce_finalize_kernel(const double *__restrict__ dense_partial,
-                                                           int64_t n_dense, const double *__restrict__ edge_partial,
-                                                           int64_t n_edge, const double *__restrict__ S, int DP,
-                                                           double pad_terms, double inv_n2,
-                                                           float *__restrict__ loss_out,
-                                                           uint64_t *__restrict__ bump_draw)
+__global__ __launch_bounds__(1024) void bce_finalize_kernel(const double *__restrict__ dense_partial,
+                                                            int64_t n_dense, const double *__restrict__ edge_partial,
+                                                            int64_t n_edge, const double *__restrict__ S, int DP,
+                                                            double pad_terms, double inv_n2,
+                                                            float *__restrict__ loss_out,
+                                                            uint64_t *__restrict__ bump_draw)
 {
-    __shared__ double red[3][256];
+    // 1024 threads, 4 independent loads per trip: the kernel is a few dependent round trips, nothing else
+    __shared__ double red[3][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double a = 0.0, l = 0.0, e = 0.0;
-    for (int64_t k = threadIdx.x; k < n_dense; k += 256) { a += dense_partial[2 * k]; l += dense_partial[2 * k + 1]; }
-    for (int64_t k = threadIdx.x; k < n_edge; k += 256) e += edge_partial[k];
-    red[0][threadIdx.x] = a; red[1][threadIdx.x] = l; red[2][threadIdx.x] = e;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (int(threadIdx.x) < off) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + off];
-            red[1][threadIdx.x] += red[1][threadIdx.x + off];
-            red[2][threadIdx.x] += red[2][threadIdx.x + off];
-        }
-        __syncthreads();
+    const double2 *dp2 = reinterpret_cast<const double2 *>(dense_partial);   // {sum |x|, sum log2 t} pairs
+    int64_t k = tid;
+    for (; k + 3 * 1024 < n_dense; k += 4 * 1024) {
+        const double2 v0 = dp2[k], v1 = dp2[k + 1024], v2 = dp2[k + 2048], v3 = dp2[k + 3072];
+        a += (v0.x + v1.x) + (v2.x + v3.x);
+        l += (v0.y + v1.y) + (v2.y + v3.y);
     }
-    if (threadIdx.x == 0) {
+    for (; k < n_dense; k += 1024) { const double2 v = dp2[k]; a += v.x; l += v.y; }
+    for (int64_t q = tid; q < n_edge; q += 1024) e += edge_partial[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64); l += __shfl_down(l, off, 64); e += __shfl_down(e, off, 64);
+    }
+    if (lane == 0) { red[0][wave] = a; red[1][wave] = l; red[2][wave] = e; }
+    __syncthreads();
+    if (tid == 0) {
+        a = l = e = 0.0;
+        for (int w = 0; w < 16; ++w) { a += red[0][w]; l += red[1][w]; e += red[2][w]; }
         double sx = 0.0;
-        for (int k = 0; k < DP; ++k) sx += S[k] * S[DP + k];          // sum_{i in window} sum_j x_ij
-        const double dense = 0.5 * sx + 0.5 * red[0][0] + 0.69314718055994531 * (red[1][0] - pad_terms);
-        *loss_out = float((dense + red[2][0]) * inv_n2);
+        for (int q = 0; q < DP; ++q) sx += S[q] * S[DP + q];          // sum_{i in window} sum_j x_ij
+        const double dense = 0.5 * sx + 0.5 * a + 0.69314718055994531 * (l - pad_terms);
+        *loss_out = float((dense + e) * inv_n2);
         if (bump_draw) *bump_draw += 1;     // every read of the counter (prepare) is stream-ordered before this kernel
     }
 }
@@ -905,7 +926,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     if (col_tiles < 1) col_tiles = 1;
     int64_t want = (2048 + p.row_blocks - 1) / p.row_blocks;  // ~8 blocks per CU
     if (want > col_tiles) want = col_tiles;
-    if (want > 64) want = 64;
+    if (want > 32) want = 32;                                 // each split is one more partial O' per row to add
     if (want < 1) want = 1;
     const int64_t tiles_per_split = (col_tiles + want - 1) / want;
     p.cols_per_split = tiles_per_split * TJ;
@@ -1110,7 +1131,7 @@ extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, in
             : launch_edges<4, false>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr,
                                      t_indices, pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, nullptr, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(256), 0, s, lp, p.n_dense, lpe, p.edge_blocks, S, p.DP,
+    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(1024), 0, s, lp, p.n_dense, lpe, p.edge_blocks, S, p.DP,
                        p.pad_terms, inv_n2, loss_out, dropout_p > 0.f ? draw_dev : nullptr);
     GAE_CHECK_LAUNCH("bce_finalize_kernel");
     return GAE_OK;
