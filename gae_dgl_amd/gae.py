@@ -44,19 +44,16 @@ class NodeApplyModule(nn.Module):
         self.activation = activation
 
     def forward(self, node):
-        code = _act_code(self.activation)
-        x = node.data['h']
-        if x.dtype != torch.float32:      # bf16-stored features: aggregation ran in bf16 storage / fp32 accumulate
-            x = x.float()
-        if code is None:
-            h = self.activation(ops.linear(x, self.linear.weight, self.linear.bias, ACT_IDENTITY))
-        else:
-            h = ops.linear(x, self.linear.weight, self.linear.bias, code)
-        return {'h': h}
+        feats = node.data['h']
+        if feats.dtype != torch.float32:  # bf16-stored features: aggregation ran in bf16 storage / fp32 accumulate
+            feats = feats.float()
+        fused = _act_code(self.activation)
+        out = ops.linear(feats, self.linear.weight, self.linear.bias, ACT_IDENTITY if fused is None else fused)
+        return {'h': out if fused is not None else self.activation(out)}
 
 
-gcn_msg = fn.copy_src(src='h', out='m')
-gcn_reduce = fn.sum(msg='m', out='h')  # sum aggregation (gae.py:18-19)
+# the message / reduce pair the reference hands to update_all (gae.py:18-19): copy the source feature, sum it
+gcn_msg, gcn_reduce = fn.copy_src(src='h', out='m'), fn.sum(msg='m', out='h')
 
 
 class GCN(nn.Module):
@@ -64,15 +61,16 @@ class GCN(nn.Module):
 
     def __init__(self, in_feats, out_feats, activation, norm=None):
         super().__init__()
-        self.apply_mod = NodeApplyModule(in_feats, out_feats, activation)
         self.norm = norm
+        self.apply_mod = NodeApplyModule(in_feats, out_feats, activation)
 
     def forward(self, g, feature):
+        # same traffic on g.ndata['h'] as the reference: set (gae.py:27), reduced in place (:28), transformed in
+        # place (:29), removed (:30)
         g.ndata['h'] = feature
         g.update_all(gcn_msg, gcn_reduce, norm=self.norm)
         g.apply_nodes(func=self.apply_mod)
-        h = g.ndata.pop('h')
-        return h
+        return g.ndata.pop('h')
 
 
 class GAE(nn.Module):
@@ -81,32 +79,25 @@ class GAE(nn.Module):
 
     def __init__(self, in_dim, hidden_dims, *, norm=None):
         super().__init__()
-        hidden_dims = list(hidden_dims)
-        if len(hidden_dims) >= 2:
-            layers = [GCN(in_dim, hidden_dims[0], F.relu, norm)]
-            for i in range(1, len(hidden_dims)):
-                if i != len(hidden_dims) - 1:
-                    layers.append(GCN(hidden_dims[i - 1], hidden_dims[i], F.relu, norm))
-                else:
-                    layers.append(GCN(hidden_dims[i - 1], hidden_dims[i], identity, norm))
-        else:
-            layers = [GCN(in_dim, hidden_dims[0], identity, norm)]
-        self.layers = nn.ModuleList(layers)
+        widths = [in_dim] + list(hidden_dims)
+        last = len(widths) - 2
+        self.layers = nn.ModuleList(
+            GCN(widths[k], widths[k + 1], identity if k == last else F.relu, norm) for k in range(last + 1))
         self.decoder = InnerProductDecoder(activation=identity)
 
+    def _embed(self, g, write_back):
+        z = g.ndata['h']
+        for layer in self.layers:
+            z = layer(g, z)
+        if write_back:
+            g.ndata['h'] = z     # forward() leaves the embedding on the graph (gae.py:53); encode() does not
+        return z
+
     def forward(self, g):
-        h = g.ndata['h']
-        for conv in self.layers:
-            h = conv(g, h)
-        g.ndata['h'] = h
-        adj_rec = self.decoder(h)
-        return adj_rec
+        return self.decoder(self._embed(g, write_back=True))
 
     def encode(self, g):
-        h = g.ndata['h']
-        for conv in self.layers:
-            h = conv(g, h)
-        return h
+        return self._embed(g, write_back=False)
 
     def reconstruction_loss(self, g):
         """The training loss of train_inductive.py:44-48 (dense label from g,
@@ -114,11 +105,7 @@ class GAE(nn.Module):
         by the fused HIP kernel: numerically the same quantity as
         ``BCELoss(self.forward(g), adj, pos_weight)`` without the N x N logits /
         label matrices.  Side effect on ``g.ndata['h']`` as in forward()."""
-        h = g.ndata['h']
-        for conv in self.layers:
-            h = conv(g, h)
-        g.ndata['h'] = h
-        return self.decoder.loss(h, g)
+        return self.decoder.loss(self._embed(g, write_back=True), g)
 
 
 class InnerProductDecoder(nn.Module):
@@ -149,10 +136,8 @@ class InnerProductDecoder(nn.Module):
         return mask
 
     def forward(self, z):
-        mask = self._draw_mask(z)
-        self.last_mask = mask
-        adj = self.activation(ops.decoder_dense(z, mask))
-        return adj
+        self.last_mask = self._draw_mask(z)
+        return self.activation(ops.decoder_dense(z, self.last_mask))
 
     def loss(self, z, g):
         """fused decoder + weighted BCE (identity activation = logits, gae.py:47).  The dropout mask of this call

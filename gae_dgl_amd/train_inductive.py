@@ -24,24 +24,33 @@ from gae_dgl_amd.dataset import DeviceGraphDataset, MolDataset  # noqa: F401
 from gae_dgl_amd.gae import GAE
 
 
+# flag, short flag, type, default, help -- the reference's command line (train_inductive.py:18-27), same names,
+# short forms and defaults; "hidden_dims" is a list of widths
+_REFERENCE_FLAGS = (
+    ("n_epochs", "e", int, 10, "passes over the training molecules"),
+    ("data_file", "d", str, "data/graphs.pkl", "dataset (flat .npz of DeviceGraphDataset.save)"),
+    ("save_dir", "s", str, "../result", "where checkpoints ep{NN}.pkl and the loss curve go"),
+    ("in_dim", "i", int, 39, "atom feature width"),
+    ("batch_size", "b", int, 128, "molecules per batch"),
+    ("lr", None, float, 1e-3, "Adam step size"),
+    ("gpu_id", None, int, 0, "which GPU"),
+)
+
+
 def build_parser():
-    parser = argparse.ArgumentParser(description='Pre-train GAE')
-    parser.add_argument('--n_epochs', '-e', type=int, default=10, help='number of epochs')
-    parser.add_argument('--data_file', '-d', type=str, default='data/graphs.pkl', help='data file')
-    parser.add_argument('--save_dir', '-s', type=str, default='../result', help='result directry')
-    parser.add_argument('--in_dim', '-i', type=int, default=39, help='input dimension')
-    parser.add_argument('--hidden_dims', metavar='N', type=int, nargs='+', help='list of hidden dimensions')
-    parser.add_argument('--batch_size', '-b', type=int, default=128, help='batch size')
-    parser.add_argument('--lr', type=float, default=1e-3, help='Adam learning rate')
-    parser.add_argument('--gpu_id', type=int, default=0, help='GPU ID to use')
+    ap = argparse.ArgumentParser(description="Pre-train GAE")
+    for name, short, kind, default, text in _REFERENCE_FLAGS:
+        names = ["--" + name] + (["-" + short] if short else [])
+        ap.add_argument(*names, type=kind, default=default, help=text)
+    ap.add_argument("--hidden_dims", type=int, nargs="+", metavar="N", help="encoder widths, e.g. 32 16")
     # extensions
-    parser.add_argument('--synthetic', type=int, default=0, metavar='G',
-                        help='generate G ZINC-shaped molecules instead of reading --data_file')
-    parser.add_argument('--val_size', type=int, default=10000, help='validation graphs (train_inductive.py:79)')
-    parser.add_argument('--loss', choices=['fused', 'dense'], default='fused')
-    parser.add_argument('--seed', type=int, default=None)
-    parser.add_argument('--no_plot', action='store_true')
-    return parser
+    ap.add_argument("--synthetic", type=int, default=0, metavar="G",
+                    help="generate G ZINC-shaped molecules instead of reading --data_file")
+    ap.add_argument("--val_size", type=int, default=10000, help="validation graphs (train_inductive.py:79)")
+    ap.add_argument("--loss", choices=["fused", "dense"], default="fused")
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--no_plot", action="store_true")
+    return ap
 
 
 args = None
@@ -49,59 +58,57 @@ device = torch.device("cpu")
 
 
 def collate(samples):
-    for g in samples:
-        g.to(torch.device(device))
-    bg = dgl.batch(samples)
-    return bg
+    """DataLoader collate_fn of the reference (train_inductive.py:31-35): member graphs -> one block-diagonal
+    graph on the device (gae_batch_gather for the device-resident dataset)"""
+    target = torch.device(device)
+    return dgl.batch([g.to(target) or g for g in samples])
 
 
 class Trainer:
+    """train_inductive.py:37-57: owns the optimiser; iteration() = one step (or one evaluation), save() = the
+    reference's checkpoint files"""
+
     def __init__(self, model, args, fused=True):
-        self.model = model
-        self.optim = optim.Adam(self.model.parameters(), lr=args.lr)    # torch.optim.Adam's rule, one HIP launch
-        self.fused = fused
-        print('Total Parameters:', sum([p.nelement() for p in self.model.parameters()]))
+        self.model, self.fused = model, fused
+        self.optim = optim.Adam(model.parameters(), lr=args.lr)     # torch.optim.Adam's rule, one HIP launch
+        print("Total Parameters:", sum(p.nelement() for p in model.parameters()))
 
     def loss(self, g):
         if self.fused:
             return self.model.reconstruction_loss(g)
-        adj = g.adjacency_matrix().to_dense().to(device)
-        # alleviate imbalance
-        pos_weight = ((adj.shape[0] * adj.shape[0] - adj.sum()) / adj.sum())
-        adj_logits = self.model.forward(g)
-        return BCELoss(adj_logits, adj, pos_weight=pos_weight)
+        # the reference-shaped path (train_inductive.py:44-48): dense label, pos_weight against the imbalance, N x N logits
+        label = g.adjacency_matrix().to_dense().to(device)
+        n_pairs, n_pos = label.numel(), label.sum()
+        return BCELoss(self.model(g), label, pos_weight=(n_pairs - n_pos) / n_pos)
 
     def iteration(self, g, train=True, as_tensor=False):
-        if train:
+        with torch.set_grad_enabled(train):
             loss = self.loss(g)
+        if train:
             self.optim.zero_grad()
             ops.backward(loss)            # loss.backward() with a cached unit gradient
             self.optim.step()
-        else:
-            with torch.no_grad():
-                loss = self.loss(g)
         return loss.detach() if as_tensor else loss.item()
 
     def save(self, epoch, save_dir):
-        output_path = os.path.join(save_dir, 'ep{:02}.pkl'.format(epoch))
-        torch.save(self.model.state_dict(), output_path)
+        torch.save(self.model.state_dict(), os.path.join(save_dir, f"ep{epoch:02}.pkl"))
 
 
 def plot(train_losses, val_losses, save_dir=None):
     try:
         import matplotlib
         matplotlib.use("Agg")
-        import matplotlib.pyplot as plt
+        from matplotlib import pyplot
     except Exception:  # matplotlib is optional here
         return
-    plt.plot(train_losses, label='train')
-    plt.plot(val_losses, label='val')
-    plt.legend()
-    plt.xlabel('epoch')
-    plt.ylabel('loss')
-    plt.grid()
+    fig, ax = pyplot.subplots()
+    for series, name in ((train_losses, "train"), (val_losses, "val")):
+        ax.plot(series, label=name)
+    ax.set(xlabel="epoch", ylabel="loss")
+    ax.grid(True); ax.legend()
     if save_dir:
-        plt.savefig(os.path.join(save_dir, 'zinc250k.png'))
+        fig.savefig(os.path.join(save_dir, "zinc250k.png"))
+    pyplot.close(fig)
 
 
 def load_dataset(args):
@@ -115,56 +122,51 @@ def load_dataset(args):
                      ".npz format (DeviceGraphDataset.save: graph_ptr, src, dst, feat)")
 
 
+def _run_epoch(trainer, loader, train):
+    """mean loss over the loader's batches; the running sum stays on the device (no host sync per iteration)"""
+    total = torch.zeros((), device=device)
+    for bg in loader:
+        for install in (bg.set_e_initializer, bg.set_n_initializer):      # train_inductive.py:93-94
+            install(dgl.init.zero_initializer)
+        total += trainer.iteration(bg, train=train, as_tensor=True)
+    return float(total) / max(len(loader), 1)
+
+
 def main(argv=None):
     global args, device
     args = build_parser().parse_args(argv)
     if not torch.cuda.is_available():
         raise RuntimeError("gae_dgl_amd runs on AMD GPUs only (no CPU fallback)")
-    device = torch.device("cuda:{}".format(args.gpu_id))
+    device = torch.device(f"cuda:{args.gpu_id}")
     torch.cuda.set_device(device)
     if args.seed is not None:
         torch.manual_seed(args.seed); np.random.seed(args.seed)
-    if not os.path.exists(args.save_dir):
-        os.makedirs(args.save_dir)
+    os.makedirs(args.save_dir, exist_ok=True)
 
-    model = GAE(args.in_dim, args.hidden_dims)
-    model.to(device)
-    print('Loading data')
+    model = GAE(args.in_dim, args.hidden_dims).to(device)
+    print("Loading data")
     graphs = load_dataset(args)
-    print('Loaded {} molecules'.format(len(graphs)))
-    perm = np.random.permutation(len(graphs))            # train_test_split(graphs, test_size=10000), :79
-    n_val = min(args.val_size, max(1, len(graphs) // 10)) if len(graphs) <= args.val_size else args.val_size
-    train_dataset = graphs.subset(graphs.ids[perm[n_val:]])
-    val_dataset = graphs.subset(graphs.ids[perm[:n_val]])
-
-    train_loader = DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True, collate_fn=collate)
-    val_loader = DataLoader(val_dataset, batch_size=args.batch_size, shuffle=False, collate_fn=collate)
-    trainer = Trainer(model, args, fused=(args.loss == 'fused'))
-    train_losses, val_losses = [], []
-    print('Training Start')
+    print(f"Loaded {len(graphs)} molecules")
+    order = np.random.permutation(len(graphs))           # train_test_split(graphs, test_size=10000), :79
+    n_val = args.val_size if len(graphs) > args.val_size else min(args.val_size, max(1, len(graphs) // 10))
+    loaders = {}
+    for split, ids, shuffle in (("train", order[n_val:], True), ("val", order[:n_val], False)):
+        loaders[split] = DataLoader(graphs.subset(graphs.ids[ids]), batch_size=args.batch_size, shuffle=shuffle,
+                                    collate_fn=collate)
+    trainer = Trainer(model, args, fused=(args.loss == "fused"))
+    history = {"train": [], "val": []}
+    print("Training Start")
     for epoch in range(args.n_epochs):
-        train_loss = torch.zeros((), device=device)
         model.train()
-        for bg in train_loader:
-            bg.set_e_initializer(dgl.init.zero_initializer)
-            bg.set_n_initializer(dgl.init.zero_initializer)
-            train_loss += trainer.iteration(bg, as_tensor=True)   # no per-iteration host sync
-        train_loss = float(train_loss) / len(train_loader)
-        train_losses.append(train_loss)
+        history["train"].append(_run_epoch(trainer, loaders["train"], train=True))
         trainer.save(epoch, args.save_dir)
-
-        val_loss = torch.zeros((), device=device)
-        model.eval()
-        for bg in val_loader:
-            bg.set_e_initializer(dgl.init.zero_initializer)
-            bg.set_n_initializer(dgl.init.zero_initializer)
-            val_loss += trainer.iteration(bg, train=False, as_tensor=True)
-        val_loss = float(val_loss) / len(val_loader)
-        val_losses.append(val_loss)
-        print('Epoch: {:02d} | Train Loss: {:.4f} | Validation Loss: {:.4f}'.format(epoch, train_loss, val_loss))
+        model.eval()         # no effect on the decoder's dropout, exactly like the reference (gae.py:70)
+        history["val"].append(_run_epoch(trainer, loaders["val"], train=False))
+        print(f"Epoch: {epoch:02d} | Train Loss: {history['train'][-1]:.4f} | "
+              f"Validation Loss: {history['val'][-1]:.4f}")
     if not args.no_plot:
-        plot(train_losses, val_losses, args.save_dir)
-    return train_losses, val_losses
+        plot(history["train"], history["val"], args.save_dir)
+    return history["train"], history["val"]
 
 
 if __name__ == '__main__':

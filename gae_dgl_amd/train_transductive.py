@@ -20,79 +20,89 @@ from gae_dgl_amd.gae import GAE
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description='Pre-train GAE')
-    register_data_args(parser)
-    parser.add_argument('--n_epochs', '-e', type=int, default=500, help='number of epochs (reference hard-codes 500)')
-    parser.add_argument('--save_dir', '-s', type=str, default='../result', help='result directry')
-    parser.add_argument('--in_dim', '-i', type=int, default=39, help='input dimension (ignored: taken from data)')
-    parser.add_argument('--hidden_dims', metavar='N', type=int, nargs='+', default=[32, 16],
-                        help='list of hidden dimensions')
-    parser.add_argument('--batch_size', '-b', type=int, default=128, help='unused (full graph)')
-    parser.add_argument('--lr', type=float, default=1e-2, help='Adam learning rate')
-    parser.add_argument('--gpu_id', type=int, default=0, help='GPU ID to use')
-    parser.add_argument('--norm', choices=['none', 'both'], default='none')
-    parser.add_argument('--seed', type=int, default=None)
-    parser.add_argument('--log_every', type=int, default=50)
-    parser.add_argument('--eval', action='store_true',
-                        help="hold out 5 %% / 10 %% of the edges (the reference's '# TODO: train test split', :35) and "
-                             "report link-prediction ROC-AUC / AP on them after training")
-    return parser
+    ap = argparse.ArgumentParser(description="Pre-train GAE")
+    register_data_args(ap)                                       # --dataset, as dgl.data.register_data_args
+    # the reference's flags (train_transductive.py:18-27); it ignores most of them and hard-codes [32, 16],
+    # lr 1e-2 and 500 epochs (:41,43,49), which are the defaults here
+    for names, kind, default, text in (
+            (("--n_epochs", "-e"), int, 500, "full-graph epochs"),
+            (("--save_dir", "-s"), str, "../result", "where the checkpoint goes"),
+            (("--in_dim", "-i"), int, 39, "ignored: the width comes from the data"),
+            (("--batch_size", "-b"), int, 128, "unused (full graph)"),
+            (("--lr",), float, 1e-2, "Adam step size"),
+            (("--gpu_id",), int, 0, "which GPU")):
+        ap.add_argument(*names, type=kind, default=default, help=text)
+    ap.add_argument("--hidden_dims", type=int, nargs="+", metavar="N", default=[32, 16], help="encoder widths")
+    # extensions
+    ap.add_argument("--norm", choices=["none", "both"], default="none")
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--log_every", type=int, default=50)
+    ap.add_argument("--no_hipgraph", action="store_true",
+                    help="launch every kernel from Python instead of replaying the captured step")
+    ap.add_argument("--eval", action="store_true",
+                    help="hold out 5 %% / 10 %% of the edges (the reference's '# TODO: train test split', :35) and "
+                         "report link-prediction ROC-AUC / AP on them after training")
+    return ap
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if not torch.cuda.is_available():
         raise RuntimeError("gae_dgl_amd runs on AMD GPUs only (no CPU fallback)")
-    device = torch.device("cuda:{}".format(args.gpu_id))
+    device = torch.device(f"cuda:{args.gpu_id}")
     torch.cuda.set_device(device)
     if args.seed is not None:
         torch.manual_seed(args.seed)
-    if not os.path.exists(args.save_dir):
-        os.makedirs(args.save_dir)
+    os.makedirs(args.save_dir, exist_ok=True)
 
-    data = load_data(args)
-    from gae_dgl_amd import ops
+    from gae_dgl_amd import metrics, ops
+    from gae_dgl_amd.capture import CapturedTrainStep
     from gae_dgl_amd.optim import Adam
-    features = ops.pad_rows(torch.FloatTensor(data.features).to(device))   # rows of whole 16 / 128-byte units
-    in_feats = features.shape[1]
-
-    model = GAE(in_feats, args.hidden_dims, norm=args.norm).to(device)
-    model.train()
-    optim = Adam(model.parameters(), lr=args.lr)      # torch.optim.Adam's rule, one HIP launch
-
-    split = None
+    data = load_data(args)
+    features = ops.pad_rows(torch.as_tensor(data.features, dtype=torch.float32).to(device))   # 16 / 128-byte rows
+    n_nodes = data.graph.number_of_nodes()
+    held_out = None
     if args.eval:
-        from gae_dgl_amd import metrics
         src, dst = (data.graph.src, data.graph.dst) if hasattr(data.graph, "src") else \
             tuple(map(list, zip(*data.graph.edges())))
-        train, val, test = metrics.split_edges(src, dst, data.graph.number_of_nodes(), seed=args.seed or 0)
-        split = (val, test)
-        g = DGLGraph(train, num_nodes=data.graph.number_of_nodes()).to(device)
+        kept, val, test = metrics.split_edges(src, dst, n_nodes, seed=args.seed or 0)
+        held_out = {"val": val, "test": test}
+        g = DGLGraph(kept, num_nodes=n_nodes).to(device)
     else:
         g = DGLGraph(data.graph).to(device)
-    # normalization (train_transductive.py:55-58) -- parameter independent, so once, not per epoch
-    g.ndata['norm'] = g.norm().unsqueeze(1)
+    g.ndata['norm'] = g.norm().unsqueeze(1)    # train_transductive.py:55-58; parameter independent: once, not per epoch
 
-    losses = []
-    print('Training Start')
-    for epoch in range(args.n_epochs):
+    model = GAE(features.shape[1], args.hidden_dims, norm=args.norm).to(device).train()
+    optimiser = Adam(model.parameters(), lr=args.lr)      # torch.optim.Adam's rule, one HIP launch
+
+    def eager_step():
         g.ndata['h'] = features
         loss = model.reconstruction_loss(g)
-        optim.zero_grad()
+        optimiser.zero_grad()
         ops.backward(loss)                # loss.backward() with a cached unit gradient
-        optim.step()
-        losses.append(loss.detach())
-        if epoch % args.log_every == 0 or epoch == args.n_epochs - 1:
-            print('Epoch: {:02d} | Loss: {:.5f}'.format(epoch, float(loss.detach())))
-    torch.save(model.state_dict(), os.path.join(args.save_dir, 'transductive_{}.pkl'.format(args.dataset)))
-    if split is not None:
+        optimiser.step()
+        return loss.detach()
+
+    # The step is a fixed sequence of ~25 launches on static buffers: after the first epoch (which creates the
+    # optimiser state and every cached workspace) it is captured once and replayed as one HIP graph.
+    step = eager_step
+    losses = []
+    print("Training Start")
+    for epoch in range(args.n_epochs):
+        if epoch == 1 and not args.no_hipgraph:
+            step = CapturedTrainStep(model, optimiser, g, features, warmup=0)
+        losses.append(step().clone())
+        if epoch % args.log_every == 0 or epoch + 1 == args.n_epochs:
+            print(f"Epoch: {epoch:02d} | Loss: {float(losses[-1]):.5f}")
+    torch.save(model.state_dict(), os.path.join(args.save_dir, f"transductive_{args.dataset}.pkl"))
+    if held_out is not None:
         g.ndata['h'] = features
         with torch.no_grad():
             Z = model.encode(g)
-        for name, sp in zip(("val", "test"), split):
-            m = metrics.evaluate(Z, sp)
-            print('{} ROC-AUC: {:.4f} | AP: {:.4f}'.format(name, m["auc"], m["ap"]))
-        main.last_eval = metrics.evaluate(Z, split[1])
+        for name, pairs in held_out.items():
+            scores = metrics.evaluate(Z, pairs)
+            print(f"{name} ROC-AUC: {scores['auc']:.4f} | AP: {scores['ap']:.4f}")
+        main.last_eval = metrics.evaluate(Z, held_out["test"])
     return [float(l) for l in losses]
 
 
