@@ -342,6 +342,42 @@ def test_spmm_properties_large(dev):
     assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
 
 
+def test_spmm_baseline_full_sizes(dev):
+    """BASELINE.json sizes through size-independent properties: the ZINC-250k whole-set launch (block-diagonal
+    LDS kernel) and the Pubmed layer-1 launch (XCD feature tiles + packed table) are bit-identical to the plain
+    row-group launch, A 1 = in-degree, and no edge leaves its molecule"""
+    from gae_dgl_amd import ops, workloads as W
+    gptr, src, dst, _ = W.zinc_like(249455, seed=0)
+    n = int(gptr[-1])
+    ip, ix = ops.csr_from_coo(t(dst, dev), t(src, dev), n, n)
+    assert int(ip[-1]) == len(src)
+    deg, _ = ops.degree_norm(ip)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    bd = ops.BlockDiag(gptr, dev)
+    for F in (39, 32):
+        H = ops.pad_rows(torch.randn(n, F, device=dev, generator=gen))
+        plain = ops.spmm_raw(ip, ix, H, n)
+        assert torch.equal(ops.spmm_raw(ip, ix, H, n, blockdiag=bd), plain)
+        ones = ops.pad_rows(torch.ones(n, F, device=dev))
+        assert torch.equal(ops.spmm_raw(ip, ix, ones, n, blockdiag=bd)[:, F - 1], deg.float())
+    # block-diagonal: the molecule of every column id is the molecule of its row
+    mol = torch.repeat_interleave(torch.arange(len(gptr) - 1, device=dev),
+                                  torch.as_tensor(np.diff(gptr), device=dev))
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), deg.long())
+    assert torch.equal(mol[ix.long()], mol[rows])
+    del H, plain, ones, mol, rows
+    n, src, dst, X = W.citation_graph("pubmed", seed=0)
+    ip, ix = ops.csr_from_coo(t(dst, dev), t(src, dev), n, n)
+    Xd = ops.pad_rows(t(X, dev))
+    assert Xd.stride(0) == 512 and ops.gather_scattered(ip, ix, 2000)
+    plan = ops.spmm_plan(ip, indices=ix)
+    plain = ops.spmm_raw(ip, ix, Xd, n)
+    assert torch.equal(ops.spmm_raw(ip, ix, Xd, n, plan=plan, scattered=True), plain)
+    deg, _ = ops.degree_norm(ip)
+    ones = ops.pad_rows(torch.ones(n, 500, device=dev))
+    assert torch.equal(ops.spmm_raw(ip, ix, ones, n, plan=plan, scattered=True)[:, 499], deg.float())
+
+
 # ----------------------------------------------------------------- K3-K5 linear
 @pytest.mark.parametrize("n,fin,fout", [(1, 1, 1), (5, 7, 3), (200, 39, 32), (333, 32, 16), (1000, 500, 32),
                                          (513, 1433, 32), (129, 100, 200), (4099, 16, 256)])
