@@ -22,7 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
 int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
-int g_atb_rows = 256;   // tuning knob: rows per block (= per partial) of the dW kernel; 8 waves x 32 rows
+int g_atb_rows = 0;     // tuning knob: rows per block (= per partial) of the dW kernel; 0 = auto (atb_plan)
 
 // ---------------------------------------------------------------------------
 // out[n, J] = epi( proA(A)[n, K] * proB(B) )      B given as [J, K] (BT) or [K, J]
@@ -631,20 +631,25 @@ struct AtbPlan {
     int64_t n_slots, rows_per_slot, blocks, slot_stride;   // slot_stride: floats per partial (tile + column sums)
 };
 
-// shared by the workspace query and the launcher: one slot (= one partial) per block of 8 waves
+// shared by the workspace query and the launcher: one slot (= one partial) per block of 8 waves.
+// Rows per slot: so that the launch is about 0.8 blocks per CU -- ONE round of 512-thread blocks (measured on
+// every layer shape of the BASELINE configs: a second, partial round costs more than the longer row loop).
 AtbPlan atb_plan(int64_t n, int64_t O, int64_t I)
 {
     AtbPlan p;
-    int64_t want = (n + g_atb_rows - 1) / g_atb_rows;  // ~256 rows per block, 32 per wave
+    const int64_t tiles = ((I <= 32 ? (I + 31) / 32 : (I + 127) / 128) > 0 ? (I <= 32 ? (I + 31) / 32 : (I + 127) / 128) : 1) *
+                          ((O + 31) / 32 > 0 ? (O + 31) / 32 : 1);      // output tiles = blocks per slot
+    int64_t rows = g_atb_rows > 0 ? g_atb_rows : (n * tiles + 207) / 208;
+    rows = (rows + 63) / 64 * 64;                    // 8 waves x a multiple of 8 rows
+    if (rows < 64) rows = 64;
+    int64_t want = (n + rows - 1) / rows;
     int64_t cap = (int64_t(32) << 20) / (O * I > 0 ? O * I : 1);  // <= 128 MiB of partials
     if (cap > 4096) cap = 4096;
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
-    p.blocks = want;
-    p.n_slots = want;
-    int64_t rps = (n + p.n_slots - 1) / p.n_slots;
-    rps = (rps + 63) / 64 * 64;                      // 8 waves x a multiple of 8 rows
+    int64_t rps = (n + want - 1) / want;
+    rps = (rps + 63) / 64 * 64;
     if (rps < 64) rps = 64;
     p.rows_per_slot = rps;
     p.n_slots = p.blocks = (n + rps - 1) / rps > 0 ? (n + rps - 1) / rps : 1;

@@ -25,7 +25,7 @@ def t_(fn, iters=50):
 
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--rows", default="64,128,256,512")
+ap.add_argument("--rows", default="0,128,256,512")
 ap.add_argument("--knobs", default="")
 ap.add_argument("--only", default="")
 a = ap.parse_args()
@@ -48,4 +48,4 @@ for (name, n, fin, fout) in shapes:
         t1 = t_(lambda: ops.linear_bwd_raw(dY, Y, 1, M, W, True, True, False))
         t2 = t_(lambda: ops.linear_bwd_raw(dY, Y, 1, M, W, True, True, True))
         print(f"   atb_rows={rows}: bwd(dW,db) {t1:.1f} us ({mb / t1:.2f} TB/s)   bwd(dW,db,dM) {t2:.1f} us")
-    _lib.call("gae_tuning_set", b"atb_rows", 256)
+    _lib.call("gae_tuning_set", b"atb_rows", 0)
