@@ -22,6 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
 int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
+int g_linear_wlds = 1;  // tuning knob: 0 = never use linear_fwd_wlds_kernel, 1 = where measured faster, 2 = wherever it applies
 int g_atb_rows = 0;     // tuning knob: rows per block (= per partial) of the dW kernel; 0 = auto (atb_plan)
 
 // ---------------------------------------------------------------------------
@@ -347,6 +348,125 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Forward Linear with the weight slice in LDS: out[n, J <= 32] = act(A[n, K] W[J, K]^T + b).
+// In gemm_stream_kernel the W fragments are fetched from global memory in the same "32 rows x 32 bytes" pattern as
+// the A fragments, i.e. HALF of the kernel's line requests go to the (L2-resident) 64 KB weight matrix, and line
+// requests per CU are what bounds it.  Here a block of 8 waves owns 64 rows (2 row tiles x 4 quarters of the
+// block's K range); each quarter's slice of W (32 x <= 128 floats) is loaded ONCE with whole-line loads into LDS
+// and read from there by both row tiles.  Split-K over blockIdx.y as in gemm_stream_kernel.
+// ---------------------------------------------------------------------------
+constexpr int kWq = 128;          // floats of K per wave quarter (16 k-blocks of 8)
+constexpr int kLdw = kWq + 4;     // LDS row stride of a W slice (floats)
+
+template <bool AVEC, bool WVEC>
+__global__ __launch_bounds__(512) void linear_fwd_wlds_kernel(
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ W, int64_t ldw,
+    const float *__restrict__ bias, int act, float *__restrict__ out, int64_t ldo, int64_t n, int K, int J,
+    int kb_per_split, int64_t split_stride)
+{
+    __shared__ __attribute__((aligned(16))) float ws[4][32 * kLdw];     // W slices, one per K quarter; later: red
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quarter = wave & 3, rt = wave >> 2;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t row = int64_t(blockIdx.x) * 64 + rt * 32 + i;
+    const bool rv = row < n;
+    const int kblocks = (K + 7) / 8;
+    const int kbs0 = blockIdx.y * kb_per_split, kbs1 = min(kbs0 + kb_per_split, kblocks);
+    const int per = (kbs1 - kbs0 + 3) / 4;                       // <= 16 (launcher)
+    const int kb0 = kbs0 + quarter * per, kb1 = min(kb0 + per, kbs1);
+    out += blockIdx.y * split_stride;
+    const int K4 = (K + 3) & ~3;
+
+    // ---- stage this quarter's W slice: waves (quarter, 0) and (quarter, 1) load 16 rows each, 2 rows x 512 B per
+    // instruction; columns past K and rows past J are staged as zeros
+    {
+        float *dst = ws[quarter];
+        const int c = (lane & 31) * 4, jl = lane >> 5;
+        const int k = kb0 * 8 + c;
+        const int kc = k <= K4 - 4 ? k : K4 - 4;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int j = rt * 16 + it * 2 + jl;
+            const int jc = j < J ? j : J - 1;
+            float4 v;
+            if (WVEC) {
+                v = *reinterpret_cast<const float4 *>(W + int64_t(jc) * ldw + kc);
+            } else {                                  // odd K: the rows of W are not 16-byte aligned
+                const float *wr = W + int64_t(jc) * ldw;
+                v.x = wr[k + 0 < K ? k + 0 : K - 1]; v.y = wr[k + 1 < K ? k + 1 : K - 1];
+                v.z = wr[k + 2 < K ? k + 2 : K - 1]; v.w = wr[k + 3 < K ? k + 3 : K - 1];
+            }
+            const bool jv = j < J && kb0 < kb1;
+            v.x = (jv && k + 0 < K) ? v.x : 0.f; v.y = (jv && k + 1 < K) ? v.y : 0.f;
+            v.z = (jv && k + 2 < K) ? v.z : 0.f; v.w = (jv && k + 3 < K) ? v.w : 0.f;
+            *reinterpret_cast<float4 *>(dst + j * kLdw + c) = v;
+        }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int64_t rowc = rv ? row : n - 1;
+    const float *apc = A + rowc * lda;
+    struct Stage { float a[4]; };
+    auto load = [&](Stage &st, int kb) {
+        const int k = kb * 8 + 4 * h;
+        if (AVEC) {
+            const int kc = k <= K4 - 4 ? k : K4 - 4;
+            const float4 t4 = *reinterpret_cast<const float4 *>(apc + kc);
+            st.a[0] = t4.x; st.a[1] = t4.y; st.a[2] = t4.z; st.a[3] = t4.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st.a[q] = apc[k + q < K ? k + q : K - 1];
+        }
+    };
+    __syncthreads();                                  // the quarter's slice is complete (two waves wrote it)
+    const float *wq = ws[quarter] + i * kLdw + 4 * h;
+    auto compute = [&](const Stage &st, int kb) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(wq + (kb - kb0) * 8);   // zero beyond K / J
+        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        const int k = kb * 8 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool kv = kb < kb1 && k + q < K;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32((rv && kv) ? st.a[q] : 0.f, kv ? bv[q] : 0.f, acc, 0, 0, 0);
+        }
+    };
+    if (kb0 < kb1) {
+        Stage s0, s1, s2;
+        int kb = kb0;
+#define GAE_PIN() __builtin_amdgcn_sched_barrier(0)
+        load(s0, kb); load(s1, kb + 1); GAE_PIN();
+        while (true) {
+            load(s2, kb + 2); GAE_PIN(); compute(s0, kb); GAE_PIN(); if (++kb >= kb1) break;
+            load(s0, kb + 2); GAE_PIN(); compute(s1, kb); GAE_PIN(); if (++kb >= kb1) break;
+            load(s1, kb + 2); GAE_PIN(); compute(s2, kb); GAE_PIN(); if (++kb >= kb1) break;
+        }
+#undef GAE_PIN
+    }
+    // ---- fixed-order reduction over the 4 quarters of each row tile; red[rt][quarter][r][lane] aliases ws
+    __syncthreads();
+    float *red = &ws[0][0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((rt * 4 + quarter) * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    const float bv = (bias && i < J) ? bias[i] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {                  // wave (rt, quarter) finalises registers 4 quarter ..
+        const int r = quarter * 4 + rr;
+        float y = red[((rt * 4 + 0) * 16 + r) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) y += red[((rt * 4 + w) * 16 + r) * 64 + lane];
+        const int64_t orow = int64_t(blockIdx.x) * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (orow < n && i < J) {
+            y += bv;
+            if (act == GAE_ACT_RELU) y = y > 0.f ? y : 0.f;
+            out[orow * ldo + i] = y;
+        }
+    }
+}
+
 // out[e] = act(bias[e % J] + sum_s partial[s][e])  -- the second pass of the split-K forward Linear
 __global__ __launch_bounds__(256) void split_reduce_kernel(const float *__restrict__ partial, int splits,
                                                            int64_t n_elems, int J, const float *__restrict__ bias,
@@ -396,6 +516,32 @@ int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t 
     if (splits > 1 && split_ws_floats < int64_t(splits) * n * J) splits = 1;
     const int kblocks = (K + 7) / 8;
     const int kbps = (kblocks + splits - 1) / splits;
+    // forward Linear (W given as [J <= 32][K], no mask) with the weight slices in LDS (linear_fwd_wlds_kernel):
+    // measured faster only for very long K under split-K (Citeseer 3327 x 3703: 32.7 -> 24.3 us); slower on
+    // Pubmed (15.2 -> 16.7 us), Cora (15.2 -> 17.6 us) and the narrow ZINC layers, which keep gemm_stream_kernel
+    if (NT == 1 && BT && PRO_A == PRO_NONE && kbps <= 64 && n > 0 &&
+        (g_linear_wlds > 1 ? K >= 32 : (g_linear_wlds == 1 && splits > 1 && K >= 2048))) {
+        float *dst = splits > 1 ? split_ws : out;
+        const dim3 grid(unsigned((n + 63) / 64), unsigned(splits));
+        const bool wvec = (ldb % 4 == 0) && gae::aligned16(B);
+#define GAE_WL(AV, WV)                                                                                             \
+    hipLaunchKernelGGL((linear_fwd_wlds_kernel<AV, WV>), grid, dim3(512), 0, s, A, lda, B, ldb,                    \
+                       splits > 1 ? nullptr : bias, splits > 1 ? int(GAE_ACT_IDENTITY) : act, dst,                 \
+                       splits > 1 ? J : ldo, n, K, int(J), kbps, n * J)
+        if (avec && wvec) GAE_WL(true, true);
+        else if (avec) GAE_WL(true, false);
+        else if (wvec) GAE_WL(false, true);
+        else GAE_WL(false, false);
+#undef GAE_WL
+        GAE_CHECK_LAUNCH("linear_fwd_wlds_kernel");
+        if (splits > 1) {
+            const int64_t ne = n * J;
+            hipLaunchKernelGGL(split_reduce_kernel, dim3(unsigned((ne + 255) / 256)), dim3(256), 0, s, split_ws, splits,
+                               ne, int(J), bias, act, out, ldo);
+            GAE_CHECK_LAUNCH("split_reduce_kernel");
+        }
+        return GAE_OK;
+    }
     const dim3 grid(unsigned((n + 31) / 32), unsigned(splits));
     float *dst = splits > 1 ? split_ws : out;
     const int64_t ldd = splits > 1 ? J : ldo;
@@ -814,6 +960,7 @@ int *dense_knob(const char *name)
 {
     if (strcmp(name, "gemm_stream") == 0) return &g_gemm_stream;
     if (strcmp(name, "atb_rows") == 0) return &g_atb_rows;
+    if (strcmp(name, "linear_wlds") == 0) return &g_linear_wlds;
     return nullptr;
 }
 } // namespace gae

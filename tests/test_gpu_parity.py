@@ -406,6 +406,32 @@ def test_linear_fwd_bwd(n, fin, fout, act, dev):
     assert rel_err(Md.grad, Mt.grad) < 5 * TOL
 
 
+@pytest.mark.parametrize("n,fin,fout,pad", [(1, 32, 1, False), (65, 39, 32, True), (200, 500, 32, True),
+                                             (513, 1433, 32, True), (513, 1433, 17, False), (300, 3703, 32, True),
+                                             (4099, 64, 16, False), (700, 2048, 32, True)])
+def test_linear_fwd_weight_slices_in_lds(n, fin, fout, pad, dev):
+    """linear_fwd_wlds_kernel (weight slices staged in LDS, 64-row blocks, split-K): forced on every shape it
+    accepts, and on its default shape (few rows, f_in >= 2048), against fp64 and against gemm_stream_kernel"""
+    from gae_dgl_amd import ops, _lib
+    rng = np.random.default_rng(n + fin + fout)
+    M = rng.standard_normal((n, fin)).astype(np.float32)
+    W = (rng.standard_normal((fout, fin)) / np.sqrt(fin)).astype(np.float32)
+    b = rng.standard_normal(fout).astype(np.float32)
+    ref = torch.relu(torch.tensor(M, dtype=torch.float64) @ torch.tensor(W, dtype=torch.float64).t()
+                     + torch.tensor(b, dtype=torch.float64))
+    Md = ops.pad_rows(t(M, dev)) if pad else t(M, dev)
+    out = {}
+    for mode in (2, 0, 1):
+        _lib.call("gae_tuning_set", b"linear_wlds", mode)
+        try:
+            out[mode] = ops.linear_fwd_raw(Md, t(W, dev), t(b, dev), 1)
+        finally:
+            _lib.call("gae_tuning_set", b"linear_wlds", 1)
+        assert rel_err(out[mode], ref) < TOL
+    assert rel_err(out[2], out[0].double().cpu()) < TOL
+    assert torch.equal(out[2], ops.linear_fwd_raw(Md, t(W, dev), t(b, dev), 1)) or fin < 2048   # default = forced here
+
+
 def test_linear_odd_ld_and_no_bias(dev):
     from gae_dgl_amd import ops
     M = torch.randn(70, 45, device=dev)[:, :39]  # ld 45: scalar staging path
