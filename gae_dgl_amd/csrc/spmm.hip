@@ -484,7 +484,9 @@ int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_
     do {                                                                                                          \
         /* two rows per lane group halve the wave count: pays once the launch is many occupancy rounds long   \
          * (ZINC set 362 -> 288 us), costs parallelism on short ones (Pubmed F = 32: 4.0 -> 5.2 us) */           \
-        const int rpg_ = rpg > 0 ? rpg : (n_rows * LPR / 64 >= 32768 ? 2 : 1);                                    \
+        const int64_t tw_ = tile_vecs > 0 ? tile_vecs : LPR * CH;      /* vectors per feature tile */           \
+        const int64_t waves_ = n_rows * LPR / 64 * ((nvec + tw_ - 1) / tw_);                                     \
+        const int rpg_ = rpg > 0 ? rpg : (waves_ >= 32768 ? 2 : 1);                                               \
         if (rpg_ >= 2 && CH == 1)                                                                                 \
             return launch_rowgroup2<T, VEC, LPR, CH, 2>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt,   \
                                                         tile_vecs, skip_deg, flags, ell, s);                      \
