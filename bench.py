@@ -240,6 +240,7 @@ class ZincWorkload:
                      "optimizer": "adam lr=1e-3: " + opt_name, "dataset_graphs": n_graphs, "parallelism": "1 GPU",
                      "batches_per_epoch_at_239455_graphs": int(np.ceil(239455 / B))}
         self.dominant = None
+        self.pmc_key = "zinc-batch4096-F39" if B == 4096 else ""
         self.W = W
         self.scaling = "weak"
         self._edges_done = 0

@@ -12,7 +12,7 @@ for w in pubmed cora zinc; do
 done
 export PMC_SETS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
 export PMC_FILTER=spmm
-for sh in pubmed500 pubmed32 citeseer3703 zinc32 zinc39; do
+for sh in pubmed500 pubmed32 cora1433 citeseer3703 zincb39 zinc32 zinc39; do
   tools/pmc.sh r01/pmc_$sh tools/spmm_one.py --shape $sh --iters 5 > $O/pmc_$sh.txt
 done
 tools/pmc.sh r01/pmc_pubmed500_plain tools/spmm_one.py --shape pubmed500 --iters 5 --plain > $O/pmc_pubmed500_plain.txt

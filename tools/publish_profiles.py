@@ -54,6 +54,7 @@ traffic = {"_how": "rocprofv3 --pmc, one counter set per pass (tools/pmc.sh: FET
                    "read bytes are known); WRITE_SIZE is used as reported (matches the output bytes to 0.1 %)."}
 shapes = {"pubmed500": ("pubmed-F500", "pubmed", 500), "pubmed500_plain": ("pubmed-F500-untiled", "pubmed", 500),
           "pubmed32": ("pubmed-F32", "pubmed", 32), "citeseer3703": ("citeseer-F3703", "citeseer", 3703),
+          "cora1433": ("cora-F1433", "cora", 1433), "zincb39": ("zinc-batch4096-F39", "zinc", 39),
           "zinc32": ("zinc250k-F32", "zinc", 32), "zinc39": ("zinc250k-F39-ld40", "zinc", 39)}
 for sh, (key, graph, F) in shapes.items():
     d = os.path.join(SRC, f"pmc_{sh}")

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gae_dgl_amd import _lib, ops, workloads as W  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--shape", default="pubmed500", help="pubmedF | coraF | citeseerF | zincF (whole set) | rmatF")
+ap.add_argument("--shape", default="pubmed500", help="pubmedF | coraF | citeseerF | zincF (whole set) | zincbF (batch) | rmatF")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--knobs", default="")
 ap.add_argument("--rmat-scale", type=int, default=22)
@@ -26,8 +26,12 @@ F = int(a.shape[len(name):])
 if name in ("pubmed", "cora", "citeseer"):
     n, src, dst, _ = W.citation_graph(name)
     s, d = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
-elif name == "zinc":
+elif name in ("zinc", "zincb"):              # whole set / the first 4096 molecules (one training batch)
     gp, src, dst, _ = W.zinc_like(249455)
+    if name == "zincb":
+        gp = gp[:4097]
+        keep = dst < gp[-1]
+        src, dst = src[keep], dst[keep]
     n = int(gp[-1])
     s, d = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
     bd = None if a.plain else ops.BlockDiag(gp, dev)
