@@ -378,6 +378,59 @@ def test_spmm_baseline_full_sizes(dev):
     assert torch.equal(ops.spmm_raw(ip, ix, ones, n, plan=plan, scattered=True)[:, 499], deg.float())
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_spmm_dispatch_fuzz(seed, dev):
+    """random (graph, width, leading dimension, dtype, scales, plan / packed table / feature tiles / rows-per-group /
+    store-pad) combinations: every dispatch branch of gae_spmm_csr gives the CSR-order sums -- bit-identical to the
+    C oracle for un-normalised fp32, bit-identical across the variants otherwise"""
+    from gae_dgl_amd import ops, _lib
+    from oracle import c_oracle
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 7, 64, 333, 1500, 6000]))
+    e = int(rng.integers(0, 8 * n + 1))
+    F = int(rng.choice([1, 2, 5, 8, 16, 31, 32, 33, 39, 64, 65, 100, 129, 256, 500, 777, 1433]))
+    hub = bool(rng.integers(0, 2)) and n > 2
+    src, dst = rand_graph(rng, n, e, hub=hub) if e else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+    dtype = torch.bfloat16 if rng.integers(0, 4) == 0 else torch.float32
+    scaled = bool(rng.integers(0, 3) == 0)
+    ip, ix = O().csr_from_coo(src, dst, n)
+    dip, dix = t(ip, dev), t(ix, dev)
+    H32 = rng.standard_normal((n, F)).astype(np.float32)
+    pad_mode = int(rng.integers(0, 3))                 # 0: contiguous, 1: pad_rows, 2: odd leading dimension
+    Hd = t(H32, dev).to(dtype)
+    if pad_mode == 1:
+        Hd = ops.pad_rows(Hd)
+    elif pad_mode == 2:
+        Hd = torch.cat([Hd, torch.full((n, 3), 7.0, device=dev, dtype=dtype)], dim=1)[:, :F]
+    norm = t(O().norm_from_in_degrees(O().in_degrees(dst, n)).numpy(), dev) if scaled else None
+    base = ops.spmm_raw(dip, dix, Hd, n, norm, norm)
+    if dtype == torch.float32 and not scaled:
+        assert np.array_equal(base.cpu().numpy(), c_oracle.spmm_csr(ip, ix, H32))
+    else:
+        ref = O().spmm_csr(ip, ix, Hd.float().cpu().double(), None if norm is None else norm.cpu().numpy(),
+                           None if norm is None else norm.cpu().numpy())
+        assert rel_err(base.float(), ref) < (TOL if dtype == torch.float32 else 1e-2)
+    table = ops.spmm_plan(dip, indices=dix, ell=True, threshold=10 ** 6) if n else None
+    heavy = ops.spmm_plan(dip, threshold=int(rng.choice([1, 4, 8])), segment=64)
+    for trial in range(4):
+        rpg = int(rng.integers(0, 3)); tv = int(rng.choice([0, 0, 8, 16, 40]))
+        use_table = bool(rng.integers(0, 2)) and table is not None
+        scattered = bool(rng.integers(0, 2))
+        out = torch.full((n, Hd.stride(0) if n > 1 else max(F, 1)), 3.0, device=dev, dtype=dtype)[:, :F] \
+            if rng.integers(0, 2) else None
+        _lib.call("gae_tuning_set", b"spmm_rpg", rpg); _lib.call("gae_tuning_set", b"spmm_tile_vecs", tv)
+        try:
+            got = ops.spmm_raw(dip, dix, Hd, n, norm, norm, out=out, plan=table if use_table else None,
+                               scattered=scattered, out_padded=out is not None and pad_mode == 1)
+        finally:
+            _lib.call("gae_tuning_set", b"spmm_rpg", 0); _lib.call("gae_tuning_set", b"spmm_tile_vecs", 0)
+        assert torch.equal(got, base), (n, e, F, dtype, scaled, pad_mode, rpg, tv, use_table, scattered)
+    if heavy is not None and F > 12:                  # segment sums have their own (fixed) order: tolerance, stable
+        a = ops.spmm_raw(dip, dix, Hd, n, norm, norm, plan=heavy)
+        assert rel_err(a.float(), base.float().double().cpu()) < (TOL if dtype == torch.float32 else 2e-2)
+        assert torch.equal(a, ops.spmm_raw(dip, dix, Hd, n, norm, norm, plan=heavy, scattered=True))
+
+
 # ----------------------------------------------------------------- K3-K5 linear
 @pytest.mark.parametrize("n,fin,fout", [(1, 1, 1), (5, 7, 3), (200, 39, 32), (333, 32, 16), (1000, 500, 32),
                                          (513, 1433, 32), (129, 100, 200), (4099, 16, 256)])
@@ -668,6 +721,40 @@ def test_fused_loss_symmetric_kernel(n, d, dev):
                                        O().pos_weight_of(adj))
         ref.backward()
         assert rel_err(out[2][0], ref) < TOL and rel_err(out[2][1], Zt.grad) < 5 * TOL
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_loss_fuzz(seed, dev):
+    """random sizes / widths / multigraphs / kernel choices of the fused loss against the fp64 oracle"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, _lib
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.choice([2, 9, 63, 64, 65, 127, 129, 511, 640, 1100, 1537]))
+    d = int(rng.choice([1, 2, 7, 15, 16, 17, 32, 33, 48, 64]))
+    e = int(rng.integers(1, 6 * n + 2))
+    src, dst = rand_graph(rng, n, e, hub=bool(rng.integers(0, 2)) and n > 2)
+    if rng.integers(0, 2):
+        src[: min(e, 5)] = dst[: min(e, 5)]                       # self loops
+    Z = (rng.standard_normal((n, d)) * rng.choice([0.1, 0.7, 3.0])).astype(np.float32)
+    mask = ((rng.random((n, d)) >= 0.1) / 0.9).astype(np.float32) if rng.integers(0, 3) else None
+    adj = O().dense_adjacency(src, dst, n, dtype=torch.float64)
+    Zt = torch.tensor(Z, dtype=torch.float64, requires_grad=True)
+    mk = None if mask is None else torch.tensor(mask, dtype=torch.float64)
+    ref = O().bce_with_logits_mean(O().decoder_logits(Zt, mk), adj, O().pos_weight_of(adj))
+    ref.backward()
+    gr = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    sym = int(rng.choice([0, 1, 2])); sri = int(rng.choice([0, 2, 4]))
+    _lib.call("gae_tuning_set", b"bce_sym", sym); _lib.call("gae_tuning_set", b"bce_sym_ri", sri)
+    try:
+        Zd = t(Z, dev).requires_grad_(True)
+        loss = ops.decoder_bce(Zd, None if mask is None else t(mask, dev), gr)
+        loss.backward()
+        with torch.no_grad():
+            loss_only = ops.decoder_bce(t(Z, dev), None if mask is None else t(mask, dev), gr)
+    finally:
+        _lib.call("gae_tuning_set", b"bce_sym", 1); _lib.call("gae_tuning_set", b"bce_sym_ri", 0)
+    assert rel_err(loss, ref) < TOL and rel_err(loss_only, ref) < TOL, (n, d, e, sym, sri)
+    assert rel_err(Zd.grad, Zt.grad) < 5 * TOL, (n, d, e, sym, sri)
 
 
 def test_fused_loss_equals_dense_path_large(dev):
