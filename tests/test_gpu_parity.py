@@ -485,6 +485,47 @@ def test_linear_fwd_weight_slices_in_lds(n, fin, fout, pad, dev):
     assert torch.equal(out[2], ops.linear_fwd_raw(Md, t(W, dev), t(b, dev), 1)) or fin < 2048   # default = forced here
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_linear_fuzz(seed, dev):
+    """random NodeApplyModule shapes (rows, widths, padded / odd leading dimensions, bias, activation, which
+    gradients are wanted) against fp64: stream / tiled / split-K / LDS-slice forward, 8-wave dW kernel, dM"""
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.choice([1, 31, 32, 33, 64, 65, 257, 1000, 5000]))
+    fin = int(rng.choice([1, 3, 31, 32, 33, 39, 64, 100, 500, 1433, 2049]))
+    fout = int(rng.choice([1, 7, 16, 32, 33, 64, 130]))
+    act = int(rng.integers(0, 2)); bias = bool(rng.integers(0, 4))
+    M = rng.standard_normal((n, fin)).astype(np.float32)
+    W = (rng.standard_normal((fout, fin)) / np.sqrt(fin)).astype(np.float32)
+    b = rng.standard_normal(fout).astype(np.float32) if bias else None
+    dY = rng.standard_normal((n, fout)).astype(np.float32)
+    Mt = torch.tensor(M, dtype=torch.float64, requires_grad=True)
+    Wt = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    Yref = Mt @ Wt.t()
+    if bias:
+        bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+        Yref = Yref + bt
+    if act:
+        Yref = torch.relu(Yref)
+    Yref.backward(torch.tensor(dY, dtype=torch.float64))
+    Md = t(M, dev)
+    mode = int(rng.integers(0, 3))
+    if mode == 1:
+        Md = ops.pad_rows(Md)
+    elif mode == 2:
+        Md = torch.cat([Md, torch.full((n, 5), 9.0, device=dev)], dim=1)[:, :fin]
+    Md = Md.requires_grad_(bool(rng.integers(0, 2)) or True)
+    Wd = t(W, dev).requires_grad_(True)
+    bd = t(b, dev).requires_grad_(True) if bias else None
+    Y = ops.linear(Md, Wd, bd, act)
+    assert rel_err(Y, Yref) < TOL, (n, fin, fout, act, bias, mode)
+    Y.backward(t(dY, dev))
+    assert rel_err(Wd.grad, Wt.grad) < 5 * TOL, (n, fin, fout, act, bias, mode)
+    assert rel_err(Md.grad, Mt.grad) < 5 * TOL
+    if bias:
+        assert rel_err(bd.grad, bt.grad) < 5 * TOL
+
+
 def test_linear_odd_ld_and_no_bias(dev):
     from gae_dgl_amd import ops
     M = torch.randn(70, 45, device=dev)[:, :39]  # ld 45: scalar staging path
