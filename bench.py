@@ -63,6 +63,7 @@ def parse():
                          "into the first of 8 equal row blocks)")
     ap.add_argument("--torch-adam", action="store_true",
                     help="torch.optim.Adam(fused=True) instead of the library's one-launch Adam (same update rule)")
+    ap.add_argument("--knobs", default="", help="comma-separated gae_tuning_set name=value pairs (experiments)")
     ap.add_argument("--no-hipgraph", action="store_true",
                     help="citation workloads: launch the step eagerly.  Default: the timed steps replay the step as "
                          "one captured HIP graph (the ~30 launches are host-bound otherwise); HIP events cannot be "
@@ -369,6 +370,11 @@ def main():
     if world > 1 or workload == "rmat":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.knobs:
+        from gae_dgl_amd import _lib
+        for kv in args.knobs.split(","):
+            k, v = kv.split("=")
+            _lib.call("gae_tuning_set", k.encode(), int(v))
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
