@@ -14,6 +14,12 @@ from . import ops
 
 
 class CapturedTrainStep:
+    """Construct it BEFORE running eager steps on the default stream, or after dropping every reference to their
+    losses / outputs: a live autograd graph of an earlier step keeps the parameters' AccumulateGrad nodes bound to
+    the default stream, and replaying them inside the capture breaks it (PyTorch warns "AccumulateGrad node's
+    stream does not match", then hipStreamEndCapture fails).  The warm-up steps of this class run on a side
+    stream for that reason."""
+
     def __init__(self, model, optimizer, graph, features, loss_fn=None, warmup=3):
         self.model, self.opt, self.g, self.x = model, optimizer, graph, features
         self.loss_fn = loss_fn or (lambda m, g: m.reconstruction_loss(g))
