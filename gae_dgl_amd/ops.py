@@ -305,10 +305,13 @@ class BlockDiag:
         self._cuts = {}
         self._eptr = {}
 
+    def _graphs_per_block(self, F):
+        return self.fixed or (2 if F > 32 else 4 if F > 16 else BLOCKDIAG_GRAPHS * 2)
+
     def cuts(self, F):
         """(block_ptr int32 device tensor, n_blocks, max_rows) for feature width F"""
         import numpy as np
-        g = self.fixed or (2 if F > 32 else 4 if F > 16 else BLOCKDIAG_GRAPHS * 2)
+        g = self._graphs_per_block(F)
         if g not in self._cuts:
             c = self.node_ptr[::g]
             if c[-1] != self.node_ptr[-1]:
@@ -327,6 +330,9 @@ class BlockDiag:
 
     def usable(self, H, F, ldh, ldm):
         if H.dtype != torch.float32 or F > 256 or ldh % 4 or ldm % 4 or len(self.node_ptr) < 2:
+            return False
+        g = self._graphs_per_block(F)
+        if (len(self.node_ptr) - 2) // g + 1 < self.min_blocks:    # too few blocks: decided without building the cuts
             return False
         _, nb, max_rows = self.cuts(F)
         if nb < self.min_blocks or max_rows > 511 or max_rows * ldh > 16 * 256 * 4 or self.max_edges > 1024:
