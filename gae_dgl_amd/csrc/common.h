@@ -69,6 +69,33 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f)
 }
 
 // ---------------------------------------------------------------------------
+// bf16 x 3 products on the matrix cores: v = hi + lo with hi = bf16(v), lo = bf16(v - hi); hi.hi + hi.lo + lo.hi in
+// fp32 accumulators drops only the lo.lo term (2^-16 relative).  fp32 MFMA shares the fp32 FMA lanes with the
+// VALU on gfx950 (tools/probes/mfma_valu_overlap.hip), bf16 MFMA runs on the matrix pipe proper.
+// ---------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+
+// split 4 fp32 values into bf16 hi and bf16 lo = bf16(v - hi): v_cvt_pk_bf16_f32 x 4, ~5 VALU ops per pair
+__device__ __forceinline__ void split_bf16x4(const v4f &v, v4s &hi, v4s &lo)
+{
+    unsigned h[2], l[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const v2f a = {v[2 * q], v[2 * q + 1]};
+        const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(a, v2bf));
+        const v2f back = {__uint_as_float(hu << 16), __uint_as_float(hu & 0xffff0000u)};
+        h[q] = hu;
+        l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(a - back, v2bf));
+    }
+    struct U { unsigned a, b; } uh{h[0], h[1]}, ul{l[0], l[1]};
+    hi = __builtin_bit_cast(v4s, uh);
+    lo = __builtin_bit_cast(v4s, ul);
+}
+
+// ---------------------------------------------------------------------------
 // Philox4x32-10 counter RNG (dropout masks, VGAE noise): 4 x 32 random bits per (counter, seed)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1)

@@ -23,6 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
 int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
 int g_linear_wlds = 1;  // tuning knob: 0 = never use linear_fwd_wlds_kernel, 1 = where measured faster, 2 = wherever it applies
+int g_atb_bf16 = 1;     // tuning knob: 1 = bf16 x 3 matrix-core products in the dW kernel where the layout allows
 int g_atb_rows = 0;     // tuning knob: rows per block (= per partial) of the dW kernel; 0 = auto (atb_plan)
 
 // ---------------------------------------------------------------------------
@@ -710,6 +711,171 @@ __global__ __launch_bounds__(NW * 64) void atb_partial_kernel(
     if (colsum_offset >= 0 && blockIdx.y == 0 && h == 0 && o < O) pp[colsum_offset + o] = csum;
 }
 
+// ---------------------------------------------------------------------------
+// The same reduction with bf16 x 3 products (gae::split_bf16x4) on v_mfma_f32_16x16x16_bf16, for O <= 32 and
+// 16-byte aligned rows of Q: on gfx950 the fp32 MFMA of atb_partial_kernel occupies the fp32 FMA lanes for
+// ~7 us of the Pubmed layer-1 launch and does not overlap the wave's own loads; the bf16 matrix pipe does the
+// same products in a fifth of the time, the operand split costs ~2.5 VALU ops per element.  The dropped lo.lo
+// term is 2^-16 relative (same scheme as the fused loss).
+// A block of 8 waves owns one row slot and 64 columns: lane (l15, g) of a wave loads, per step of 16 rows, the
+// float4 Q[row 4g + r][c0 + 4 l15 ..] for r = 0..3 -- column 4 l15 + t belongs to output tile t -- and
+// P[row][16 mt + l15]; accumulators acc[mt][t][r] = out[16 mt + 4 g + r][c0 + 4 l15 + t].
+// ---------------------------------------------------------------------------
+template <int PRO_P>
+__global__ __launch_bounds__(512) void atb_bf16_kernel(
+    const float *__restrict__ P, int64_t ldp, const float *__restrict__ Pmask, int64_t ldpm,
+    const float *__restrict__ Q, int64_t ldq, int64_t n, int O, int I, int64_t rows_per_slot,
+    float *__restrict__ partial, int64_t slot_stride, int64_t colsum_offset)
+{
+    constexpr int NW = 8;
+    constexpr int PARK = 34 * 64;                    // 32 accumulator + 2 column-sum floats per lane
+    __shared__ float red[NW / 2][PARK];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int64_t slot = blockIdx.x;
+    const int c0 = blockIdx.y * 64, col = c0 + 4 * l15;
+    const int64_t rows_per_wave = rows_per_slot / NW;                 // multiple of 16
+    const int64_t r_begin = slot * rows_per_slot + wave * rows_per_wave;
+    int64_t r_end = r_begin + rows_per_wave;
+    if (r_end > n) r_end = n;
+
+    gae::v4f acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mt][t] = gae::v4f{0.f, 0.f, 0.f, 0.f};
+    float csum[2] = {0.f, 0.f};
+
+    struct Stage { float a[2][4], m[2][4]; float4 b[4]; };
+    const int64_t r_last = r_end - 1;
+    const int I4 = (I + 3) & ~3;
+    const int colc = col + 4 <= I4 ? col : I4 - 4;
+    int oc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) oc[mt] = 16 * mt + l15 < O ? 16 * mt + l15 : O - 1;
+    auto load = [&](Stage &st, int64_t r0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int64_t row = r0 + 4 * g + r;
+            row = row < r_last ? row : r_last;
+            st.b[r] = *reinterpret_cast<const float4 *>(Q + row * ldq + colc);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                st.a[mt][r] = P[row * ldp + oc[mt]];
+                if (PRO_P != PRO_NONE) st.m[mt][r] = Pmask[row * ldpm + oc[mt]];
+            }
+        }
+    };
+    auto compute = [&](const Stage &st, int64_t r0) {
+        bool rv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = r0 + 4 * g + r < r_end;
+        gae::v4s ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            gae::v4f av;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = (rv[r] && 16 * mt + l15 < O) ? st.a[mt][r] : 0.f;
+                if (PRO_P == PRO_RELU_MASK) v = st.m[mt][r] > 0.f ? v : 0.f;
+                if (PRO_P == PRO_MUL_MASK) v *= st.m[mt][r];
+                av[r] = v;
+                csum[mt] += v;
+            }
+            gae::split_bf16x4(av, ah[mt], al[mt]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float b0 = t == 0 ? st.b[0].x : t == 1 ? st.b[0].y : t == 2 ? st.b[0].z : st.b[0].w;
+            const float b1 = t == 0 ? st.b[1].x : t == 1 ? st.b[1].y : t == 2 ? st.b[1].z : st.b[1].w;
+            const float b2 = t == 0 ? st.b[2].x : t == 1 ? st.b[2].y : t == 2 ? st.b[2].z : st.b[2].w;
+            const float b3 = t == 0 ? st.b[3].x : t == 1 ? st.b[3].y : t == 2 ? st.b[3].z : st.b[3].w;
+            const bool cv = col + t < I;
+            const gae::v4f bv = {(rv[0] && cv) ? b0 : 0.f, (rv[1] && cv) ? b1 : 0.f, (rv[2] && cv) ? b2 : 0.f,
+                                 (rv[3] && cv) ? b3 : 0.f};
+            gae::split_bf16x4(bv, bh[t], bl[t]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[mt], bh[t], acc[mt][t], 0, 0, 0);
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], bl[t], acc[mt][t], 0, 0, 0);
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], bh[t], acc[mt][t], 0, 0, 0);
+            }
+    };
+    if (r_begin < r_end) {
+        Stage s0, s1, s2;
+        int64_t r0 = r_begin;
+#define GAE_PIN() __builtin_amdgcn_sched_barrier(0)
+        load(s0, r0); load(s1, r0 + 16); GAE_PIN();
+        while (true) {
+            load(s2, r0 + 32); GAE_PIN(); compute(s0, r0); GAE_PIN(); r0 += 16; if (r0 >= r_end) break;
+            load(s0, r0 + 32); GAE_PIN(); compute(s1, r0); GAE_PIN(); r0 += 16; if (r0 >= r_end) break;
+            load(s1, r0 + 32); GAE_PIN(); compute(s2, r0); GAE_PIN(); r0 += 16; if (r0 >= r_end) break;
+        }
+#undef GAE_PIN
+    }
+    // column sums of P: this lane summed rows 4 g + r of column 16 mt + l15 -> add the 4 row groups
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        csum[mt] += __shfl_xor(csum[mt], 16, 64);
+        csum[mt] += __shfl_xor(csum[mt], 32, 64);
+    }
+    // ---- block reduction, fixed tree order: (w) += (w + half) for half = 4, 2, 1
+#pragma unroll
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+            float *rp = red[wave - half];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rp[((mt * 4 + t) * 4 + r) * 64 + lane] = acc[mt][t][r];
+                rp[(32 + mt) * 64 + lane] = csum[mt];
+            }
+        }
+        __syncthreads();
+        if (wave < half) {
+            const float *rp = red[wave];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mt][t][r] += rp[((mt * 4 + t) * 4 + r) * 64 + lane];
+                csum[mt] += rp[(32 + mt) * 64 + lane];
+            }
+        }
+        if (half > 1) __syncthreads();
+    }
+    if (wave != 0) return;
+    float *pp = partial + slot * slot_stride;
+    const bool vec_store = (I & 3) == 0 && col + 4 <= I;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oo = 16 * mt + 4 * g + r;
+            if (oo >= O) continue;
+            float *dst = pp + int64_t(oo) * I + col;
+            if (vec_store) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (col + t < I) dst[t] = acc[mt][t][r];
+            }
+        }
+    if (colsum_offset >= 0 && blockIdx.y == 0 && g == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            if (16 * mt + l15 < O) pp[colsum_offset + 16 * mt + l15] = csum[mt];
+    }
+}
+
 // out[e] = sum_slot partial[slot * slot_stride + e]  (+ optional accumulate into out, optional mask multiply);
 // elements e >= n_first go to out2[e - n_first] (the column sums parked behind a slot's tile).
 // 64 elements per block of 16 waves; wave q takes slots q, q + 16, ... (independent loads, all in flight) and the
@@ -783,11 +949,12 @@ struct AtbPlan {
 AtbPlan atb_plan(int64_t n, int64_t O, int64_t I)
 {
     AtbPlan p;
-    const int64_t tiles = ((I <= 32 ? (I + 31) / 32 : (I + 127) / 128) > 0 ? (I <= 32 ? (I + 31) / 32 : (I + 127) / 128) : 1) *
-                          ((O + 31) / 32 > 0 ? (O + 31) / 32 : 1);      // output tiles = blocks per slot
+    const bool bf16 = g_atb_bf16 && O <= 32 && I > 32;                  // atb_bf16_kernel: 64 columns per block
+    const int64_t cgroups = I <= 32 ? (I + 31) / 32 : bf16 ? (I + 63) / 64 : (I + 127) / 128;
+    const int64_t tiles = (cgroups > 0 ? cgroups : 1) * ((O + 31) / 32 > 0 ? (O + 31) / 32 : 1);   // blocks per slot
     int64_t rows = g_atb_rows > 0 ? g_atb_rows : (n * tiles + 207) / 208;
-    rows = (rows + 63) / 64 * 64;                    // 8 waves x a multiple of 8 rows
-    if (rows < 64) rows = 64;
+    rows = (rows + 127) / 128 * 128;                 // 8 waves x a multiple of 16 rows (8 for the fp32 kernel)
+    if (rows < 128) rows = 128;
     int64_t want = (n + rows - 1) / rows;
     int64_t cap = (int64_t(32) << 20) / (O * I > 0 ? O * I : 1);  // <= 128 MiB of partials
     if (cap > 4096) cap = 4096;
@@ -795,8 +962,8 @@ AtbPlan atb_plan(int64_t n, int64_t O, int64_t I)
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     int64_t rps = (n + want - 1) / want;
-    rps = (rps + 63) / 64 * 64;
-    if (rps < 64) rps = 64;
+    rps = (rps + 127) / 128 * 128;
+    if (rps < 128) rps = 128;
     p.rows_per_slot = rps;
     p.n_slots = p.blocks = (n + rps - 1) / rps > 0 ? (n + rps - 1) / rps : 1;
     p.slot_stride = (O * I + O + 3) / 4 * 4;         // [O][I] tile, then [O] column sums; 16-byte aligned slots
@@ -808,6 +975,15 @@ int launch_atb(const float *P, int64_t ldp, const float *Pmask, int64_t ldpm, co
                int64_t n, int O, int I, float *partial, bool colsum, const AtbPlan &pl, hipStream_t s)
 {
     const bool narrow = I <= 32;                     // one 32-column tile: no 4-tile float4 mapping needed
+    // bf16 x 3 matrix-core products when the layout allows float4 loads of Q (atb_bf16_kernel)
+    if (g_atb_bf16 && !narrow && O <= 32 && (ldq % 4 == 0) && gae::aligned16(Q) && ldq >= ((I + 3) & ~3) && I >= 4 &&
+        gae::aligned16(partial) && pl.rows_per_slot % 128 == 0) {
+        const dim3 grid(unsigned(pl.blocks), unsigned((I + 63) / 64), 1);
+        hipLaunchKernelGGL((atb_bf16_kernel<PRO_P>), grid, dim3(512), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n, O, I,
+                           pl.rows_per_slot, partial, pl.slot_stride, colsum ? int64_t(O) * I : int64_t(-1));
+        GAE_CHECK_LAUNCH("atb_bf16_kernel");
+        return GAE_OK;
+    }
     const int cols_per_block = narrow ? 32 : 128;
     const unsigned gy = I > 0 ? unsigned((I + cols_per_block - 1) / cols_per_block) : 1u;  // I == 0: column sums only
     const dim3 grid(unsigned(pl.blocks), gy, unsigned((O + 31) / 32));
@@ -960,6 +1136,7 @@ int *dense_knob(const char *name)
 {
     if (strcmp(name, "gemm_stream") == 0) return &g_gemm_stream;
     if (strcmp(name, "atb_rows") == 0) return &g_atb_rows;
+    if (strcmp(name, "atb_bf16") == 0) return &g_atb_bf16;
     if (strcmp(name, "linear_wlds") == 0) return &g_linear_wlds;
     return nullptr;
 }
