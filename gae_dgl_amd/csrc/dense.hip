@@ -23,6 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
 int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
 int g_linear_wlds = 1;  // tuning knob: 0 = never use linear_fwd_wlds_kernel, 1 = where measured faster, 2 = wherever it applies
+int g_linear_bf16 = 1;  // tuning knob: 1 = bf16 x 3 forward Linear where measured faster (J <= 32, aligned rows of A and W), 2 = wherever it applies, 0 = never
 int g_atb_bf16 = 1;     // tuning knob: 1 = bf16 x 3 matrix-core products in the dW kernel where the layout allows
 int g_atb_rows = 0;     // tuning knob: rows per block (= per partial) of the dW kernel; 0 = auto (atb_plan)
 
@@ -468,6 +469,123 @@ __global__ __launch_bounds__(512) void linear_fwd_wlds_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Forward Linear with bf16 x 3 products: out[n, J <= 32] = act(A[n, K] W[J, K]^T + b), 16-byte aligned rows of A.
+// v_mfma_f32_16x16x16_bf16 wants lane (row = l15, k = 4 g + r): ONE float4 A[row][k0 + 4 g ..] per lane and 16-k
+// step, i.e. an instruction reads 64 contiguous bytes of 16 rows -- half as many requests per 128-byte line as the
+// 32-byte pieces of gemm_stream_kernel's fp32 fragments (4.3 L1->L2 requests per line there) -- and the matrix
+// pipe does the products in a fifth of the fp32 MFMA time.  A block owns 32 rows (2 row tiles); its 4 waves split
+// the block's K range (split-K over blockIdx.y as in gemm_stream_kernel) and meet in LDS in fixed order.
+// ---------------------------------------------------------------------------
+template <bool WVEC>
+__global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ W, int64_t ldw,
+    const float *__restrict__ bias, int act, float *__restrict__ out, int64_t ldo, int64_t n, int K, int J,
+    int ks_per_split, int64_t split_stride)
+{
+    __shared__ float red[4][16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int64_t row0 = int64_t(blockIdx.x) * 32;
+    const int ksteps = (K + 15) / 16;
+    const int kss0 = blockIdx.y * ks_per_split, kss1 = min(kss0 + ks_per_split, ksteps);
+    const int per = (kss1 - kss0 + 3) / 4;
+    const int ks0 = kss0 + wave * per, ks1 = min(ks0 + per, kss1);
+    out += blockIdx.y * split_stride;
+    const int K4 = (K + 3) & ~3;
+
+    gae::v4f acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = gae::v4f{0.f, 0.f, 0.f, 0.f};
+    const float *ap[2], *wp[2];
+    bool rv[2], jv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int64_t r = row0 + 16 * q + l15;
+        rv[q] = r < n;
+        ap[q] = A + (rv[q] ? r : n - 1) * lda;
+        const int j = 16 * q + l15;
+        jv[q] = j < J;
+        wp[q] = W + int64_t(jv[q] ? j : J - 1) * ldw;
+    }
+    struct Stage { float4 a[2], w[2]; };
+    auto load = [&](Stage &st, int ks) {
+        const int k = ks * 16 + 4 * g;
+        const int kc = k <= K4 - 4 ? k : K4 - 4;          // in-bounds start of the vector loads (rows padded to K4)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            st.a[q] = *reinterpret_cast<const float4 *>(ap[q] + kc);
+            if (WVEC) {
+                st.w[q] = *reinterpret_cast<const float4 *>(wp[q] + kc);
+            } else {                                      // odd K: rows of W are not 16-byte aligned
+                st.w[q].x = wp[q][k + 0 < K ? k + 0 : K - 1]; st.w[q].y = wp[q][k + 1 < K ? k + 1 : K - 1];
+                st.w[q].z = wp[q][k + 2 < K ? k + 2 : K - 1]; st.w[q].w = wp[q][k + 3 < K ? k + 3 : K - 1];
+            }
+        }
+    };
+    auto compute = [&](const Stage &st, int ks) {
+        const int k = ks * 16 + 4 * g;
+        const bool live = ks < ks1;
+        const bool kv0 = live && k + 0 < K, kv1 = live && k + 1 < K, kv2 = live && k + 2 < K, kv3 = live && k + 3 < K;
+        gae::v4s ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const gae::v4f av = {(rv[q] && kv0) ? st.a[q].x : 0.f, (rv[q] && kv1) ? st.a[q].y : 0.f,
+                                 (rv[q] && kv2) ? st.a[q].z : 0.f, (rv[q] && kv3) ? st.a[q].w : 0.f};
+            const gae::v4f wv = {(jv[q] && kv0) ? st.w[q].x : 0.f, (jv[q] && kv1) ? st.w[q].y : 0.f,
+                                 (jv[q] && kv2) ? st.w[q].z : 0.f, (jv[q] && kv3) ? st.w[q].w : 0.f};
+            gae::split_bf16x4(av, ah[q], al[q]);
+            gae::split_bf16x4(wv, wh[q], wl[q]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[mt], wh[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], wl[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], wh[nt], acc[mt][nt], 0, 0, 0);
+            }
+    };
+    if (ks0 < ks1) {
+        Stage s0, s1, s2;
+        int ks = ks0;
+#define GAE_PIN() __builtin_amdgcn_sched_barrier(0)
+        load(s0, ks); load(s1, ks + 1); GAE_PIN();
+        while (true) {
+            load(s2, ks + 2); GAE_PIN(); compute(s0, ks); GAE_PIN(); if (++ks >= ks1) break;
+            load(s0, ks + 2); GAE_PIN(); compute(s1, ks); GAE_PIN(); if (++ks >= ks1) break;
+            load(s1, ks + 2); GAE_PIN(); compute(s2, ks); GAE_PIN(); if (++ks >= ks1) break;
+        }
+#undef GAE_PIN
+    }
+    // ---- fixed-order cross-wave reduction: red[wave][(mt, nt, r)][lane]; wave w finalises (mt, nt) = (w >> 1, w & 1)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][((mt * 2 + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+    __syncthreads();
+    const int mt = wave >> 1, nt = wave & 1;
+    const int j = 16 * nt + l15;                    // acc[mt][nt][r] = out[row0 + 16 mt + 4 g + r][16 nt + l15]
+    const float bv = (bias && j < J) ? bias[j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float y = red[0][((mt * 2 + nt) * 4 + r) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) y += red[w][((mt * 2 + nt) * 4 + r) * 64 + lane];
+        const int64_t orow = row0 + 16 * mt + 4 * g + r;
+        if (orow < n && j < J) {
+            y += bv;
+            if (act == GAE_ACT_RELU) y = y > 0.f ? y : 0.f;
+            out[orow * ldo + j] = y;
+        }
+    }
+}
+
 // out[e] = act(bias[e % J] + sum_s partial[s][e])  -- the second pass of the split-K forward Linear
 __global__ __launch_bounds__(256) void split_reduce_kernel(const float *__restrict__ partial, int splits,
                                                            int64_t n_elems, int J, const float *__restrict__ bias,
@@ -517,6 +635,32 @@ int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t 
     if (splits > 1 && split_ws_floats < int64_t(splits) * n * J) splits = 1;
     const int kblocks = (K + 7) / 8;
     const int kbps = (kblocks + splits - 1) / splits;
+    // forward Linear with bf16 x 3 products and 64-byte row pieces (linear_fwd_bf16_kernel)
+    // (only with 16-byte aligned rows of W, i.e. K % 4 == 0: the scalar W path measured slower than
+    // gemm_stream_kernel -- Cora K = 1433: 15.2 -> 18.1 us, ZINC K = 39: 10.3 -> 14.0 us; knob 2 forces it)
+    const bool wvec_ok = (ldb % 4 == 0) && gae::aligned16(B) && ldb >= ((K + 3) & ~3);
+    if (NT == 1 && BT && PRO_A == PRO_NONE && (g_linear_bf16 > 1 || (g_linear_bf16 == 1 && wvec_ok)) && avec &&
+        lda >= ((K + 3) & ~3) && K >= 16 && n > 0) {
+        const bool wvec = wvec_ok;
+        const int ksteps = (K + 15) / 16;
+        const int kspp = (ksteps + splits - 1) / splits;
+        float *dst = splits > 1 ? split_ws : out;
+        const dim3 grid(unsigned((n + 31) / 32), unsigned(splits));
+#define GAE_LB(WV)                                                                                                 \
+    hipLaunchKernelGGL((linear_fwd_bf16_kernel<WV>), grid, dim3(256), 0, s, A, lda, B, ldb,                        \
+                       splits > 1 ? nullptr : bias, splits > 1 ? int(GAE_ACT_IDENTITY) : act, dst,                 \
+                       splits > 1 ? J : ldo, n, K, int(J), kspp, n * J)
+        if (wvec) GAE_LB(true); else GAE_LB(false);
+#undef GAE_LB
+        GAE_CHECK_LAUNCH("linear_fwd_bf16_kernel");
+        if (splits > 1) {
+            const int64_t ne = n * J;
+            hipLaunchKernelGGL(split_reduce_kernel, dim3(unsigned((ne + 255) / 256)), dim3(256), 0, s, split_ws, splits,
+                               ne, int(J), bias, act, out, ldo);
+            GAE_CHECK_LAUNCH("split_reduce_kernel");
+        }
+        return GAE_OK;
+    }
     // forward Linear (W given as [J <= 32][K], no mask) with the weight slices in LDS (linear_fwd_wlds_kernel):
     // measured faster only for very long K under split-K (Citeseer 3327 x 3703: 32.7 -> 24.3 us); slower on
     // Pubmed (15.2 -> 16.7 us), Cora (15.2 -> 17.6 us) and the narrow ZINC layers, which keep gemm_stream_kernel
@@ -1137,6 +1281,7 @@ int *dense_knob(const char *name)
     if (strcmp(name, "gemm_stream") == 0) return &g_gemm_stream;
     if (strcmp(name, "atb_rows") == 0) return &g_atb_rows;
     if (strcmp(name, "atb_bf16") == 0) return &g_atb_bf16;
+    if (strcmp(name, "linear_bf16") == 0) return &g_linear_bf16;
     if (strcmp(name, "linear_wlds") == 0) return &g_linear_wlds;
     return nullptr;
 }

@@ -474,15 +474,26 @@ def test_linear_fwd_weight_slices_in_lds(n, fin, fout, pad, dev):
                      + torch.tensor(b, dtype=torch.float64))
     Md = ops.pad_rows(t(M, dev)) if pad else t(M, dev)
     out = {}
-    for mode in (2, 0, 1):
-        _lib.call("gae_tuning_set", b"linear_wlds", mode)
-        try:
-            out[mode] = ops.linear_fwd_raw(Md, t(W, dev), t(b, dev), 1)
-        finally:
-            _lib.call("gae_tuning_set", b"linear_wlds", 1)
-        assert rel_err(out[mode], ref) < TOL
-    assert rel_err(out[2], out[0].double().cpu()) < TOL
-    assert torch.equal(out[2], ops.linear_fwd_raw(Md, t(W, dev), t(b, dev), 1)) or fin < 2048   # default = forced here
+    _lib.call("gae_tuning_set", b"linear_bf16", 0)          # this test is about the fp32-MFMA kernels
+    try:
+        for mode in (2, 0, 1):
+            _lib.call("gae_tuning_set", b"linear_wlds", mode)
+            try:
+                out[mode] = ops.linear_fwd_raw(Md, t(W, dev), t(b, dev), 1)
+            finally:
+                _lib.call("gae_tuning_set", b"linear_wlds", 1)
+            assert rel_err(out[mode], ref) < TOL
+        assert rel_err(out[2], out[0].double().cpu()) < TOL
+        assert torch.equal(out[2], ops.linear_fwd_raw(Md, t(W, dev), t(b, dev), 1)) or fin < 2048   # default = forced
+    finally:
+        _lib.call("gae_tuning_set", b"linear_bf16", 1)
+    # bf16 x 3 kernel (64-byte row pieces, split-K), forced on every shape it accepts incl. unaligned rows of W
+    _lib.call("gae_tuning_set", b"linear_bf16", 2)
+    try:
+        forced = ops.linear_fwd_raw(Md, t(W, dev), t(b, dev), 1)
+    finally:
+        _lib.call("gae_tuning_set", b"linear_bf16", 1)
+    assert rel_err(forced, ref) < TOL
 
 
 @pytest.mark.parametrize("seed", range(16))
