@@ -520,9 +520,17 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(
             st.a[q] = *reinterpret_cast<const float4 *>(ap[q] + kc);
             if (WVEC) {
                 st.w[q] = *reinterpret_cast<const float4 *>(wp[q] + kc);
-            } else {                                      // odd K: rows of W are not 16-byte aligned
-                st.w[q].x = wp[q][k + 0 < K ? k + 0 : K - 1]; st.w[q].y = wp[q][k + 1 < K ? k + 1 : K - 1];
-                st.w[q].z = wp[q][k + 2 < K ? k + 2 : K - 1]; st.w[q].w = wp[q][k + 3 < K ? k + 3 : K - 1];
+            } else {
+                // odd K: rows of W are only 4-byte aligned.  gfx950 loads an unaligned dwordx4; the last group of a
+                // row starts at K - 4 instead (never past the end of W) and is shifted into place by selects
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                const int ku = k <= K - 4 ? k : K - 4;
+                const f4u l = *reinterpret_cast<const f4u *>(wp[q] + ku);
+                const int sh = k - ku;                    // 0 except in the tail group (then 1..3; >= 4: all masked)
+                st.w[q].x = sh == 0 ? l[0] : sh == 1 ? l[1] : sh == 2 ? l[2] : l[3];
+                st.w[q].y = sh == 0 ? l[1] : sh == 1 ? l[2] : l[3];
+                st.w[q].z = sh == 0 ? l[2] : l[3];
+                st.w[q].w = l[3];
             }
         }
     };
@@ -636,11 +644,10 @@ int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t 
     const int kblocks = (K + 7) / 8;
     const int kbps = (kblocks + splits - 1) / splits;
     // forward Linear with bf16 x 3 products and 64-byte row pieces (linear_fwd_bf16_kernel)
-    // (only with 16-byte aligned rows of W, i.e. K % 4 == 0: the scalar W path measured slower than
-    // gemm_stream_kernel -- Cora K = 1433: 15.2 -> 18.1 us, ZINC K = 39: 10.3 -> 14.0 us; knob 2 forces it)
+    // (short unaligned rows of W keep gemm_stream_kernel: ZINC K = 39 measured 10.3 -> 13.2 us; knob 2 forces it)
     const bool wvec_ok = (ldb % 4 == 0) && gae::aligned16(B) && ldb >= ((K + 3) & ~3);
-    if (NT == 1 && BT && PRO_A == PRO_NONE && (g_linear_bf16 > 1 || (g_linear_bf16 == 1 && wvec_ok)) && avec &&
-        lda >= ((K + 3) & ~3) && K >= 16 && n > 0) {
+    if (NT == 1 && BT && PRO_A == PRO_NONE && (g_linear_bf16 > 1 || (g_linear_bf16 == 1 && (wvec_ok || K >= 128))) &&
+        avec && lda >= ((K + 3) & ~3) && K >= 16 && n > 0) {
         const bool wvec = wvec_ok;
         const int ksteps = (K + 15) / 16;
         const int kspp = (ksteps + splits - 1) / splits;
