@@ -486,13 +486,13 @@ def test_linear_fwd_weight_slices_in_lds(n, fin, fout, pad, dev):
         assert rel_err(out[2], out[0].double().cpu()) < TOL
         assert torch.equal(out[2], ops.linear_fwd_raw(Md, t(W, dev), t(b, dev), 1)) or fin < 2048   # default = forced
     finally:
-        _lib.call("gae_tuning_set", b"linear_bf16", 1)
-    # bf16 x 3 kernel (64-byte row pieces, split-K), forced on every shape it accepts incl. unaligned rows of W
+        _lib.call("gae_tuning_set", b"linear_bf16", 0)
+    # bf16 x 3 kernel (64-byte row pieces, split-K; opt-in), forced on every shape it accepts incl. unaligned rows of W
     _lib.call("gae_tuning_set", b"linear_bf16", 2)
     try:
         forced = ops.linear_fwd_raw(Md, t(W, dev), t(b, dev), 1)
     finally:
-        _lib.call("gae_tuning_set", b"linear_bf16", 1)
+        _lib.call("gae_tuning_set", b"linear_bf16", 0)
     assert rel_err(forced, ref) < TOL
 
 
