@@ -107,3 +107,30 @@ def test_graph_host_logic_and_batch():
     with pytest.raises(ValueError):
         gs[0].add_edges([0], [10 ** 6])
     bg.set_n_initializer(G.init.zero_initializer); bg.set_e_initializer(G.init.zero_initializer)
+
+
+def test_row_layout_helpers_are_host_logic():
+    """pad_rows / row_quantum decide the HBM layout (16-byte vectors, whole 128-byte lines from 512 B per row on)"""
+    from gae_dgl_amd import ops
+    assert ops.row_quantum(39, torch.float32) == 4 and ops.row_quantum(127, torch.float32) == 4
+    assert ops.row_quantum(128, torch.float32) == 32 and ops.row_quantum(3703, torch.float32) == 32
+    assert ops.row_quantum(255, torch.bfloat16) == 8 and ops.row_quantum(256, torch.bfloat16) == 64
+    for f, ld in ((39, 40), (500, 512), (1433, 1440), (3703, 3712), (32, 32)):
+        x = torch.arange(3 * f, dtype=torch.float32).reshape(3, f)
+        y = ops.pad_rows(x)
+        assert y.shape == (3, f) and y.stride() == (ld, 1) and torch.equal(y, x)
+        assert ops.pad_rows(y) is y                                  # already laid out: no copy
+        assert y.storage_offset() == 0 and float(y._base[:, f:].abs().sum()) == 0.0 if ld != f else True
+
+
+def test_atb_and_loss_plans_are_consistent_without_a_gpu():
+    """workspace queries are pure host functions of the shapes (and grow monotonically enough to be cached)"""
+    from gae_dgl_amd import _lib
+    lib = _lib.load()
+    assert lib.gae_linear_fwd_workspace_bytes(19717, 500, 32) == 0          # enough row tiles: no split-K
+    assert lib.gae_linear_fwd_workspace_bytes(2708, 1433, 32) > 0            # Cora: split along f_in
+    assert lib.gae_linear_bwd_workspace_bytes(19717, 500, 32) >= 32 * 500 * 4
+    small, big = lib.gae_decoder_bce_workspace_bytes(2708, 2708, 16), lib.gae_decoder_bce_workspace_bytes(19717, 19717, 16)
+    assert 0 < small < big
+    assert lib.gae_decoder_bce_workspace_bytes(19717, 19717, 16) > 19717 * 19717 // 4   # symmetric path: strip buffer
+    assert lib.gae_decoder_bce_workspace_bytes(100, 200, 16) < 0            # n_local > n is an argument error
