@@ -19,6 +19,16 @@
 
 #include "common.h"
 
+namespace gae {
+// spmm_ell.hip: the packed-neighbour-table kernels (lean instruction stream; see that file)
+bool spmm_ell_usable(int64_t n_cols, int64_t ldh, int elem, int ell_width, int tile_vecs);
+int spmm_ell_launch(const int32_t *indptr, const int32_t *indices, const int32_t *ell, int ell_width, int64_t n_rows,
+                    int64_t n_cols, const void *H, int64_t ldh, void *M, int64_t ldm, int F, int dtype,
+                    const float *rs, const float *cs, int tile_vecs, int xcd_tiled, int store_pad, int store_mode,
+                    hipStream_t s);
+int *spmm_ell_knob(const char *name);
+}
+
 namespace {
 
 using gae::kWave;
@@ -42,12 +52,21 @@ struct VecIO<float, 4> {
         typedef float f4 __attribute__((ext_vector_type(4)));
         __builtin_nontemporal_store(f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4 *>(p));
     }
+    // write-through store that does NOT keep the line in the XCD's L2 (MI355X_MICROARCH.md, "stores of each
+    // flavour"): the output stream of an XCD-tiled launch must not compete with the L2-resident slice of H
+    static __device__ __forceinline__ void store_sc1(float *p, const float (&v)[4])
+    {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 x = {v[0], v[1], v[2], v[3]};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+    }
 };
 template <>
 struct VecIO<float, 1> {
     static __device__ __forceinline__ void load(const float *p, float (&v)[1]) { v[0] = *p; }
     static __device__ __forceinline__ void store(float *p, const float (&v)[1]) { *p = v[0]; }
     static __device__ __forceinline__ void store_nt(float *p, const float (&v)[1]) { __builtin_nontemporal_store(v[0], p); }
+    static __device__ __forceinline__ void store_sc1(float *p, const float (&v)[1]) { __builtin_nontemporal_store(v[0], p); }
 };
 template <>
 struct VecIO<unsigned short, 8> {
@@ -70,6 +89,7 @@ struct VecIO<unsigned short, 8> {
         *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
     static __device__ __forceinline__ void store_nt(unsigned short *p, const float (&v)[8]) { store(p, v); }
+    static __device__ __forceinline__ void store_sc1(unsigned short *p, const float (&v)[8]) { store(p, v); }
 };
 template <>
 struct VecIO<unsigned short, 1> {
@@ -82,6 +102,7 @@ struct VecIO<unsigned short, 1> {
         *p = gae::f32_to_bf16(v[0]);
     }
     static __device__ __forceinline__ void store_nt(unsigned short *p, const float (&v)[1]) { store(p, v); }
+    static __device__ __forceinline__ void store_sc1(unsigned short *p, const float (&v)[1]) { store(p, v); }
 };
 
 __device__ __forceinline__ void store_scalar(float *p, float v) { *p = v; }
@@ -244,12 +265,13 @@ constexpr int32_t kEllSkip = -3;       // slot 0: heavy row of the skew plan, pr
 //     F = 500 21 -> 15 us); longer rows continue from the CSR arrays.
 // Summation order is unchanged (CSR order), so results are bit-identical to v1.
 // ---------------------------------------------------------------------------
-template <typename T, int VEC, int LPR, int CH, int RPG, bool SCALED, bool NT_STORE, int ELLW = 0>
+template <typename T, int VEC, int LPR, int CH, int RPG, bool SCALED, int ELLW = 0>
 __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
     const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t n_rows,
     const T *__restrict__ H, int64_t ldh, T *__restrict__ M, int64_t ldm, int F,
     const float *__restrict__ row_scale, const float *__restrict__ col_scale, unsigned n_row_blocks,
-    unsigned n_ftiles, int xcd_tiled, int tile_w, int skip_deg, int store_pad, const int32_t *__restrict__ ell)
+    unsigned n_ftiles, int xcd_tiled, int tile_w, int skip_deg, int store_pad, int store_mode,
+    const int32_t *__restrict__ ell)
 {
     constexpr int GPB = 256 / LPR;            // groups per block
     constexpr int RPB = GPB * RPG;            // rows per block
@@ -393,7 +415,9 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
             // store_pad: M's rows are padded to a whole vector and the caller allows the pad columns to be
             // overwritten -> the tail vector is written whole (full 16-byte stores, no partially written sectors)
             if (VEC == 1 || f + VEC <= F || store_pad) {
-                if (NT_STORE) VecIO<T, VEC>::store_nt(mp + c * TILE, acc[r][c]);
+                // store_mode is a kernel argument (wave-uniform): 0 = plain, 1 = non-temporal, 2 = write-through sc1
+                if (store_mode == 2) VecIO<T, VEC>::store_sc1(mp + c * TILE, acc[r][c]);
+                else if (store_mode == 1) VecIO<T, VEC>::store_nt(mp + c * TILE, acc[r][c]);
                 else VecIO<T, VEC>::store(mp + c * TILE, acc[r][c]);
             } else {
 #pragma unroll
@@ -424,15 +448,16 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const int32_t *__restric
 // tuning knobs (gae_tuning_set): read-mostly process-wide integers
 int g_spmm_variant = 2;   // 1 = v1 rowgroup, 2 = v2 rowgroup2
 int g_spmm_rpg = 0;       // rows per lane group (v2): 0 = auto (2 for launches of >= 32768 waves, else 1), 1, 2
-int g_spmm_nt = 1;        // non-temporal stores of M (v2)
+int g_spmm_nt = 1;        // store policy of M (v2): -1 = auto, 0 plain, 1 non-temporal, 2 write-through sc1
 int g_spmm_tile_vecs = 0; // 16-byte vectors per XCD feature tile: 0 = auto when GAE_SPMM_TILE is set, -1 = never, > 0 = forced
-int g_spmm_ell = 1;       // use the plan's packed neighbour table when it has one
+int g_spmm_ell = 1;       // the plan's packed neighbour table: 0 = ignore it, 1 = spmm_ell.hip kernels (row-group
+                          // kernel when they cannot run the launch), 2 = row-group kernel only
 
 constexpr int kEllWidth = 16;
 
 template <typename T, int VEC, int LPR, int CH, int RPG>
 int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
-                     int64_t ldm, int F, const float *rs, const float *cs, bool nt, int tile_vecs, int skip_deg,
+                     int64_t ldm, int F, const float *rs, const float *cs, int st, int tile_vecs, int skip_deg,
                      int flags, const int32_t *ell, hipStream_t s)
 {
     const int store_pad = ((flags & GAE_SPMM_STORE_PAD) && (F + VEC - 1) / VEC * VEC <= ldm) ? 1 : 0;
@@ -443,16 +468,17 @@ int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_ro
     const unsigned nrb = unsigned((n_rows + RPB - 1) / RPB), nft = unsigned((nvec + tw - 1) / tw);
     const dim3 grid = tiled ? dim3(gae::kNumXcd * ((nft + gae::kNumXcd - 1) / gae::kNumXcd) * nrb) : dim3(nrb, nft);
     const int xt = tiled ? 1 : 0;
-#define GAE_L2(SC, NT, EW)                                                                                          \
-    hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, NT, EW>), grid, dim3(256), 0, s, indptr,    \
-                       indices, n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, tw * VEC, skip_deg, store_pad, ell)
+#define GAE_L2(SC, EW)                                                                                              \
+    hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, EW>), grid, dim3(256), 0, s, indptr, indices,  \
+                       n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, tw * VEC, skip_deg, store_pad, store_mode, ell)
     constexpr int EW = VEC > 1 ? kEllWidth : 0;
+    // store policy: 0 plain, 1 non-temporal, 2 write-through sc1; auto (-1) = sc1 under XCD feature tiles (the
+    // output stream must not evict the tile's L2-resident slice of H), non-temporal otherwise
+    const int store_mode = sizeof(T) != 4 ? 0 : st >= 0 ? st : (tiled ? 2 : 1);
     if (VEC > 1 && ell) {
-        if (rs || cs) { if (nt) GAE_L2(true, true, EW); else GAE_L2(true, false, EW); }
-        else { if (nt) GAE_L2(false, true, EW); else GAE_L2(false, false, EW); }
+        if (rs || cs) GAE_L2(true, EW); else GAE_L2(false, EW);
     } else {
-        if (rs || cs) { if (nt) GAE_L2(true, true, 0); else GAE_L2(true, false, 0); }
-        else { if (nt) GAE_L2(false, true, 0); else GAE_L2(false, false, 0); }
+        if (rs || cs) GAE_L2(true, 0); else GAE_L2(false, 0);
     }
 #undef GAE_L2
     GAE_CHECK_LAUNCH("spmm_rowgroup2_kernel");
@@ -475,11 +501,31 @@ inline int auto_tile_vecs(int nvec, int64_t n_cols)
 
 template <typename T, int VEC>
 int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
-                       int64_t ldm, int F, const float *rs, const float *cs, int rpg, bool nt, int64_t n_cols,
-                       int skip_deg, int flags, const int32_t *ell, hipStream_t s)
+                       int64_t ldm, int F, const float *rs, const float *cs, int rpg, int st, int64_t n_cols,
+                       int skip_deg, int flags, const int32_t *ell, int ell_width, hipStream_t s)
 {
     const int nvec = (F + VEC - 1) / VEC;
     int tile_vecs = 0;
+    // XCD feature tiles (GAE_SPMM_TILE): wide rows, poor gather locality, rows made of whole 128-byte lines
+    if (VEC > 1 && nvec > 16 && g_spmm_tile_vecs >= 0) {
+        const bool lines = (ldh * sizeof(T)) % 128 == 0 && (ldm * sizeof(T)) % 128 == 0 &&
+                           reinterpret_cast<uintptr_t>(H) % 128 == 0 && reinterpret_cast<uintptr_t>(M) % 128 == 0;
+        const int tv = g_spmm_tile_vecs > 0 ? g_spmm_tile_vecs
+                                            : ((flags & GAE_SPMM_TILE) && lines ? auto_tile_vecs(nvec, n_cols) : 0);
+        if (tv > 0 && (nvec + tv - 1) / tv >= 2) tile_vecs = tv;
+    }
+    // packed-table kernels (spmm_ell.hip) whenever the plan carries a table they can use
+    if (VEC > 1 && ell && g_spmm_ell == 1) {
+        const int tv = tile_vecs > 0 ? tile_vecs : (nvec < 64 ? nvec : 64);
+        if (tv <= 64 && gae::spmm_ell_usable(n_cols, ldh, int(sizeof(T)), ell_width, tv)) {
+            const int store_pad = ((flags & GAE_SPMM_STORE_PAD) && int64_t(nvec) * VEC <= ldm) ? 1 : 0;
+            const int store_mode = sizeof(T) != 4 ? 0 : st >= 0 ? st : 1;
+            return gae::spmm_ell_launch(indptr, indices, ell, ell_width, n_rows, n_cols, H, ldh, M, ldm, F,
+                                        sizeof(T) == 4 ? GAE_F32 : GAE_BF16, rs, cs, tv, tile_vecs > 0 ? 1 : 0,
+                                        store_pad, store_mode, s);
+        }
+    }
+    if (ell_width != kEllWidth) ell = nullptr;     // the row-group kernel reads 16-wide tables only
 #define GAE_RG2(LPR, CH)                                                                                          \
     do {                                                                                                          \
         /* two rows per lane group halve the wave count: pays once the launch is many occupancy rounds long   \
@@ -488,29 +534,21 @@ int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_
         const int64_t waves_ = n_rows * LPR / 64 * ((nvec + tw_ - 1) / tw_);                                     \
         const int rpg_ = rpg > 0 ? rpg : (waves_ >= 32768 ? 2 : 1);                                               \
         if (rpg_ >= 2 && CH == 1)                                                                                 \
-            return launch_rowgroup2<T, VEC, LPR, CH, 2>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt,   \
+            return launch_rowgroup2<T, VEC, LPR, CH, 2>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, st,   \
                                                         tile_vecs, skip_deg, flags, ell, s);                      \
-        return launch_rowgroup2<T, VEC, LPR, CH, 1>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, nt,       \
+        return launch_rowgroup2<T, VEC, LPR, CH, 1>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, st,       \
                                                     tile_vecs, skip_deg, flags, ell, s);                          \
     } while (0)
-    // Wide rows, poor gather locality (the caller's GAE_SPMM_TILE), rows made of whole 128-byte lines: XCD x owns
-    // feature tiles x, x + 8, ... so that the tile's slice of H is gathered out of that XCD's own L2.
-    if (VEC > 1 && nvec > 16 && g_spmm_tile_vecs >= 0) {
-        const bool lines = (ldh * sizeof(T)) % 128 == 0 && (ldm * sizeof(T)) % 128 == 0 &&
-                           reinterpret_cast<uintptr_t>(H) % 128 == 0 && reinterpret_cast<uintptr_t>(M) % 128 == 0;
-        int tv = g_spmm_tile_vecs > 0 ? g_spmm_tile_vecs
-                                      : ((flags & GAE_SPMM_TILE) && lines ? auto_tile_vecs(nvec, n_cols) : 0);
-        if (tv > 0 && (nvec + tv - 1) / tv >= 2) {
-            tile_vecs = tv;
-            if (tv <= 4) GAE_RG2(4, 1);
-            if (tv <= 8) GAE_RG2(8, 1);
-            if (tv <= 16) GAE_RG2(16, 1);
-            if (tv <= 32) GAE_RG2(32, 1);
-            if (tv <= 64) GAE_RG2(64, 1);
-            if (tv <= 128) GAE_RG2(64, 2);
-            if (tv <= 256) GAE_RG2(64, 4);
-            tile_vecs = 0;
-        }
+    if (tile_vecs > 0) {
+        const int tv = tile_vecs;
+        if (tv <= 4) GAE_RG2(4, 1);
+        if (tv <= 8) GAE_RG2(8, 1);
+        if (tv <= 16) GAE_RG2(16, 1);
+        if (tv <= 32) GAE_RG2(32, 1);
+        if (tv <= 64) GAE_RG2(64, 1);
+        if (tv <= 128) GAE_RG2(64, 2);
+        if (tv <= 256) GAE_RG2(64, 4);
+        tile_vecs = 0;
     }
     if (nvec <= 4) GAE_RG2(4, 1);
     if (nvec <= 8) GAE_RG2(8, 1);
@@ -850,8 +888,8 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
     int rc;
     if (g_spmm_variant == 2 && f > min_f)
         rc = dispatch_rowgroup2<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, g_spmm_rpg,
-                                        g_spmm_nt != 0 && sizeof(T) == 4, n_cols, skip, flags,
-                                        (plan && g_spmm_ell && plan->ell_width == kEllWidth) ? plan->ell : nullptr, s);
+                                        g_spmm_nt, n_cols, skip, flags,
+                                        (plan && g_spmm_ell) ? plan->ell : nullptr, plan ? plan->ell_width : 0, s);
     else {
         GAE_REQUIRE(!heavy, GAE_E_RANGE, "gae_spmm_csr: a skew plan needs F > %d for this layout", min_f);
         rc = dispatch_rowgroup<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, s);
@@ -912,7 +950,8 @@ extern "C" int gae_spmm_ell_build(const int32_t *indptr, const int32_t *indices,
                                   int32_t skip_degree, int32_t *ell, void *stream)
 {
     GAE_REQUIRE(n_rows >= 0, GAE_E_SIZE, "gae_spmm_ell_build: negative n_rows");
-    GAE_REQUIRE(width == GAE_SPMM_ELL_WIDTH, GAE_E_RANGE, "gae_spmm_ell_build: width must be %d", GAE_SPMM_ELL_WIDTH);
+    GAE_REQUIRE(width == 4 || width == 8 || width == GAE_SPMM_ELL_WIDTH, GAE_E_RANGE,
+                "gae_spmm_ell_build: width must be 4, 8 or %d", GAE_SPMM_ELL_WIDTH);
     GAE_REQUIRE(skip_degree >= 1, GAE_E_RANGE, "gae_spmm_ell_build: skip_degree >= 1 required");
     if (n_rows == 0) return GAE_OK;
     GAE_REQUIRE(indptr && ell, GAE_E_NULL, "gae_spmm_ell_build: NULL pointer");
@@ -957,8 +996,8 @@ extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64
         GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_spmm_csr: workspace not 16-byte aligned");
     }
     if (plan && plan->ell)
-        GAE_REQUIRE(plan->ell_width == GAE_SPMM_ELL_WIDTH, GAE_E_RANGE, "gae_spmm_csr: plan->ell_width must be %d",
-                    GAE_SPMM_ELL_WIDTH);
+        GAE_REQUIRE(plan->ell_width == 4 || plan->ell_width == 8 || plan->ell_width == GAE_SPMM_ELL_WIDTH, GAE_E_RANGE,
+                    "gae_spmm_csr: plan->ell_width must be 4, 8 or %d", GAE_SPMM_ELL_WIDTH);
     hipStream_t s = gae::as_stream(stream);
     const int f = int(F);
     if (dtype == GAE_F32) {
@@ -1054,6 +1093,10 @@ extern "C" int gae_tuning_set(const char *name, int64_t value)
             *kv.v = int(value);
             return GAE_OK;
         }
+    if (int *k = gae::spmm_ell_knob(name)) {
+        *k = int(value);
+        return GAE_OK;
+    }
     if (int *k = gae::dense_knob(name)) {
         *k = int(value);
         return GAE_OK;

@@ -1,0 +1,422 @@
+// K1/K2, third kernel family: "ell" -- the packed-neighbour-table form of the sparse aggregation
+//     M = diag(rs) A diag(cs) H        (gae_dgl/gae.py:18-19,28: update_all(copy_src, sum); backward on A^T)
+// written for the smallest possible instruction stream per gathered byte.
+//
+// Why: rocprofv3 (profiles/r02_spmm_diag.md) showed the row-group kernel of spmm.hip INSTRUCTION-ISSUE bound on
+// the launches that matter (Pubmed F = 500: SIMDs 80 % busy, average L1->L2 read latency only 415 cycles, TLB
+// clean, HBM/fabric at 60 %): per neighbour row it spent a ds_bpermute, a 64-bit address computation, exec-mask
+// juggling for the predicated load, a zero fill for the empty slots and four scalar adds.  Here a neighbour costs
+//     v_mov_dpp row_newbcast (1-2)  +  v_add_u32  +  buffer_load_dwordx4  +  2 v_pk_add_f32
+//   * the lane that holds slot k of the table turns the column id into the BYTE OFFSET of that row of H once;
+//     empty slots (-1 and the markers) become an offset behind the buffer: the raw-buffer bounds check makes the
+//     load return zeros without touching memory -- no predication, no branches, no zero fill, and adding +0.0f
+//     leaves every sum bit-identical to the CSR-order sum of spmm.hip / oracle/spmm_ref.c;
+//   * slot k reaches the lanes of its group with one DPP row_newbcast (two bank-masked ones for 8-lane groups);
+//   * all NB (4 or 8) neighbour rows of the RPG rows a lane group owns are requested before the first is used;
+//     waves leave the slot loop together as soon as no row of the wave has a neighbour left (scalar branch).
+// Ownership, XCD-aware block mapping, feature tiles and store policies are those of spmm_rowgroup2_kernel.
+#include <string.h>
+
+#include <utility>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int32_t kEllOverflow = -2;   // last slot: the row continues in the CSR arrays
+constexpr int32_t kEllSkip = -3;       // slot 0: heavy row of the skew plan (segment kernels produce it)
+
+template <int CTRL, int BANK>
+__device__ __forceinline__ unsigned dpp_mov(unsigned old, unsigned v)
+{
+    return unsigned(__builtin_amdgcn_update_dpp(int(old), int(v), CTRL, 0xF, BANK, false));
+}
+
+// value of lane (group base + K) of the caller's 16-lane row, for groups of LP16 lanes inside the row
+template <int LP16, int K>
+__device__ __forceinline__ unsigned bcast_slot(unsigned v)
+{
+    constexpr int ROW_NEWBCAST = 0x150;
+    if constexpr (LP16 == 16) {
+        return dpp_mov<ROW_NEWBCAST + K, 0xF>(v, v);
+    } else if constexpr (LP16 == 8) {
+        const unsigned t = dpp_mov<ROW_NEWBCAST + K, 0x3>(v, v);          // banks 0,1 = lanes 0..7
+        return dpp_mov<ROW_NEWBCAST + 8 + K, 0xC>(t, v);                  // banks 2,3 = lanes 8..15
+    } else {
+        static_assert(LP16 == 4, "groups of 4, 8 or 16 lanes per DPP row");
+        unsigned t = dpp_mov<ROW_NEWBCAST + K, 0x1>(v, v);
+        t = dpp_mov<ROW_NEWBCAST + 4 + K, 0x2>(t, v);
+        t = dpp_mov<ROW_NEWBCAST + 8 + K, 0x4>(t, v);
+        return dpp_mov<ROW_NEWBCAST + 12 + K, 0x8>(t, v);
+    }
+}
+
+// lanes of a wave that hold slot K (in their register K / LP16)
+template <int LP16, int K>
+constexpr unsigned long long holder_mask()
+{
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if ((l & (LP16 - 1)) == (K % LP16)) m |= 1ull << l;
+    return m;
+}
+
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+    static constexpr int NV = 4;
+    static __device__ __forceinline__ void add(float (&acc)[4], const u32x4 raw)
+    {
+        const f32x4 v = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += v[i];
+    }
+    static __device__ __forceinline__ void fma(float (&acc)[4], const u32x4 raw, float c)
+    {
+        const f32x4 v = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(c, v[i], acc[i]);
+    }
+    static __device__ __forceinline__ u32x4 pack(const float (&acc)[4])
+    {
+        return __builtin_bit_cast(u32x4, (f32x4){acc[0], acc[1], acc[2], acc[3]});
+    }
+};
+template <>
+struct Vec16<unsigned short> {   // bf16 storage, fp32 accumulation
+    static constexpr int NV = 8;
+    static __device__ __forceinline__ void add(float (&acc)[8], const u32x4 raw)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[2 * i] += __uint_as_float(raw[i] << 16);
+            acc[2 * i + 1] += __uint_as_float(raw[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void fma(float (&acc)[8], const u32x4 raw, float c)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[2 * i] = fmaf(c, __uint_as_float(raw[i] << 16), acc[2 * i]);
+            acc[2 * i + 1] = fmaf(c, __uint_as_float(raw[i] & 0xffff0000u), acc[2 * i + 1]);
+        }
+    }
+    static __device__ __forceinline__ u32x4 pack(const float (&acc)[8])
+    {
+        u32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = unsigned(gae::f32_to_bf16(acc[2 * i])) | (unsigned(gae::f32_to_bf16(acc[2 * i + 1])) << 16);
+        return w;
+    }
+};
+
+}  // namespace
+namespace gae {
+int g_spmm_ell_rpg = 0;      // rows per lane group of the ell kernels: 0 = auto (1)
+}
+namespace {
+
+struct EllArgs {
+    const int32_t *indptr, *indices, *ell;
+    const void *H;
+    void *M;
+    const float *row_scale, *col_scale;
+    int64_t n_rows, ldm;          // ldm in elements
+    unsigned ldh_bytes, h_bytes;  // row pitch and total size of H in bytes (h_bytes = n_cols * ldh_bytes < 2^32 - 2^16)
+    unsigned n_cols, F, nvec;     // nvec = ceil(F / NV)
+    unsigned n_row_blocks, n_ftiles, tile_vecs;   // tile_vecs <= LPR: 16-byte vectors per feature tile
+    int xcd_tiled, store_pad, store_mode;
+};
+
+template <typename T>
+__device__ __forceinline__ void store16(T *p, const u32x4 w, int mode)
+{
+    if (mode == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+    } else if (mode == 1) {
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(p));
+    } else {
+        *reinterpret_cast<u32x4 *>(p) = w;
+    }
+}
+__device__ __forceinline__ void store_elem(float *p, float v) { *p = v; }
+__device__ __forceinline__ void store_elem(unsigned short *p, float v) { *p = gae::f32_to_bf16(v); }
+
+// byte offsets of slots B0 + U... for the lanes of a group (compile-time slot numbers: the DPP control word is an
+// immediate)
+template <int LP16, int B0, int NREG, int... U>
+__device__ __forceinline__ void slot_offsets(const unsigned (&off)[NREG], unsigned add, unsigned (&out)[sizeof...(U)],
+                                             std::integer_sequence<int, U...>)
+{
+    ((out[U] = bcast_slot<LP16, (B0 + U) % LP16>(off[(B0 + U) / LP16]) + add), ...);
+}
+
+// Slots [B0, B0 + N) of the RPG rows, straight-line: every load is issued before the first add.  Rows of the wave
+// with fewer neighbours get zeros from the bounds check.
+template <typename T, int LP16, int RPG, int NREG, int B0, int N, bool SCALED>
+__device__ __forceinline__ void ell_slots(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_buffer_rsrc_t rs_c,
+                                          const unsigned (&off)[RPG][NREG], const unsigned (&coff)[RPG][NREG],
+                                          unsigned lane_off, bool live, float (&acc)[RPG][Vec16<T>::NV])
+{
+    unsigned vo[RPG][N], co[RPG][N];
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        slot_offsets<LP16, B0>(off[r], lane_off, vo[r], std::make_integer_sequence<int, N>{});
+        if (SCALED) slot_offsets<LP16, B0>(coff[r], 0u, co[r], std::make_integer_sequence<int, N>{});
+    }
+    if (live) {       // lanes beyond the row's last vector take no part in the memory traffic
+        u32x4 raw[RPG][N];
+        float cs[RPG][N];
+#pragma unroll
+        for (int r = 0; r < RPG; ++r)
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                raw[r][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_h, vo[r][u], 0, 0);
+                if (SCALED) cs[r][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, co[r][u], 0, 0));
+            }
+#pragma unroll
+        for (int r = 0; r < RPG; ++r)
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                if (SCALED) Vec16<T>::fma(acc[r], raw[r][u], cs[r][u]);
+                else Vec16<T>::add(acc[r], raw[r][u]);
+            }
+    }
+}
+
+// One batch: slots [B0, B0 + NB).  Only as many slots as the longest row of the WAVE fills are touched (scalar
+// count from the ballots, one straight-line body per count): a bounds-checked load that returns zeros still costs
+// its address-unit cycles (no-edge launch of the Pubmed shape: 14.2 us with 8 such loads per row, 9 us without).
+template <typename T, int LP16, int RPG, int NREG, int B0, int NB, bool SCALED, int... U>
+__device__ __forceinline__ void ell_batch(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_buffer_rsrc_t rs_c,
+                                          const unsigned (&off)[RPG][NREG], const unsigned (&coff)[RPG][NREG],
+                                          const unsigned long long (&valid)[RPG][NREG], unsigned lane_off, bool live,
+                                          float (&acc)[RPG][Vec16<T>::NV], std::integer_sequence<int, U...>)
+{
+    int cnt = 0;       // slots of this batch that hold a neighbour in some row of the wave (they fill from the left)
+    (([&] {
+         bool any = false;
+#pragma unroll
+         for (int r = 0; r < RPG; ++r) any = any || (valid[r][(B0 + U) / LP16] & holder_mask<LP16, B0 + U>()) != 0;
+         cnt += any ? 1 : 0;
+     }()),
+     ...);
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
+    switch (cnt) {
+#define GAE_ELL_CASE(N)                                                                                      \
+    case N:                                                                                                  \
+        if constexpr (N <= NB)                                                                               \
+            ell_slots<T, LP16, RPG, NREG, B0, (N <= NB ? N : 1), SCALED>(rs_h, rs_c, off, coff, lane_off, live, acc); \
+        break;
+        GAE_ELL_CASE(1) GAE_ELL_CASE(2) GAE_ELL_CASE(3) GAE_ELL_CASE(4)
+        GAE_ELL_CASE(5) GAE_ELL_CASE(6) GAE_ELL_CASE(7) GAE_ELL_CASE(8)
+#undef GAE_ELL_CASE
+    default: break;
+    }
+}
+
+// One wave = 64 / LPR lane groups x RPG rows of one feature tile.  (A persistent variant -- waves looping over
+// their items with the next item's table rows prefetched -- was measured and is 10 % SLOWER on every shape: the
+// stores of item i sit in front of the gathers of item i + 1 in the wave's in-order memory queue.)
+template <typename T, int LPR, int RPG, int W, int NB, bool SCALED>
+__global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
+{
+    constexpr int NV = Vec16<T>::NV;
+    constexpr int LP16 = LPR < 16 ? LPR : 16;      // lanes of one group inside a 16-lane DPP row
+    constexpr int NREG = (W + LP16 - 1) / LP16;    // table registers per lane and row
+    constexpr int GPB = 256 / LPR, RPB = GPB * RPG;
+    static_assert(W % NB == 0 && NB % 4 == 0, "slots are consumed in whole batches");
+    unsigned blk, ftile;
+    if (a.xcd_tiled) {
+        // XCD x (= blockIdx % 8) owns feature tiles x, x + 8, ... and sweeps all row blocks of a tile before the
+        // next: the tile's slice of H stays in that XCD's private L2 while it is gathered
+        const unsigned xcd = blockIdx.x % gae::kNumXcd, k = blockIdx.x / gae::kNumXcd;
+        const unsigned tl = k / a.n_row_blocks;
+        blk = k - tl * a.n_row_blocks;
+        ftile = xcd + gae::kNumXcd * tl;
+        if (ftile >= a.n_ftiles) return;
+    } else {
+        blk = gae::xcd_remap(blockIdx.x, gridDim.x);
+        ftile = blockIdx.y;
+    }
+    const int lane = threadIdx.x & 63;
+    const int lig = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const unsigned fvec = ftile * a.tile_vecs + lig;   // this lane's 16-byte vector of the row
+    const bool live = unsigned(lig) < a.tile_vecs && fvec < a.nvec;
+    const unsigned lane_off = fvec * 16u;
+
+    __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.H), 0, int(a.h_bytes), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(SCALED ? a.col_scale : nullptr), 0, SCALED ? int(a.n_cols * 4u) : 0, 0x00020000);
+
+    int64_t row[RPG];
+    unsigned off[RPG][NREG], coff[RPG][NREG];
+    unsigned long long valid[RPG][NREG], skipm[RPG], ovfm[RPG];
+    float acc[RPG][NV];
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        row[r] = int64_t(blk) * RPB + r * GPB + grp;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[r][i] = 0.f;
+        // ---- the table row: slot q * LP16 + (lane % LP16) sits in register q (every 16-lane row of a wide group
+        //      holds its own copy: the re-read is served by the same L1 line)
+        int32_t first = -1, last = -1;
+#pragma unroll
+        for (int q = 0; q < NREG; ++q) {
+            const int s = q * LP16 + (lane & (LP16 - 1));
+            int32_t j = -1;
+            if (row[r] < a.n_rows && s < W) j = a.ell[row[r] * W + s];
+            off[r][q] = min(unsigned(j), a.n_cols) * a.ldh_bytes;       // empty / marker -> behind the buffer
+            if (SCALED) coff[r][q] = min(unsigned(j), a.n_cols) * 4u;
+            valid[r][q] = __builtin_amdgcn_ballot_w64(j >= 0);
+            if (s == 0) first = j;
+            if (s == W - 1) last = j;
+        }
+        skipm[r] = __builtin_amdgcn_ballot_w64(first == kEllSkip);
+        ovfm[r] = __builtin_amdgcn_ballot_w64(last == kEllOverflow);
+    }
+
+    // ---- slot batches; `more` is a scalar: no row of this wave has a neighbour in slot B0
+#define GAE_ELL_BATCH(B0)                                                                                          \
+    if constexpr ((B0) < W) {                                                                                      \
+        bool more = (B0) == 0;                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < RPG; ++r)                                                            \
+            more = more || (valid[r][(B0) / LP16] & holder_mask<LP16, (B0)>()) != 0;                               \
+        if (!more) goto slots_done;                                                                                \
+        ell_batch<T, LP16, RPG, NREG, (B0), NB, SCALED>(rs_h, rs_c, off, coff, valid, lane_off, live, acc,         \
+                                                        std::make_integer_sequence<int, NB>{});                    \
+    }
+    GAE_ELL_BATCH(0)
+    GAE_ELL_BATCH(NB)
+    GAE_ELL_BATCH(2 * NB)
+    GAE_ELL_BATCH(3 * NB)
+#undef GAE_ELL_BATCH
+slots_done:
+    // ---- rare: rows longer than the table continue from the CSR arrays (same order: slots 0 .. W-2 came first)
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        const int holder0 = lane & ~(LPR - 1);                            // lane holding slot 0 of this group
+        const int holderL = holder0 + ((W - 1) % LP16);                   // ... and slot W - 1 (first DPP row of the group)
+        if ((skipm[r] >> holder0) & 1ull) row[r] = a.n_rows;              // heavy row: not produced here
+        if (ovfm[r] != 0) {                                               // scalar test first: almost never taken
+            if (((ovfm[r] >> holderL) & 1ull) && row[r] < a.n_rows && live) {
+                const int32_t e1 = a.indptr[row[r] + 1];
+                for (int32_t e = a.indptr[row[r]] + (W - 1); e < e1; ++e) {
+                    const unsigned j = unsigned(a.indices[e]);
+                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_h, j * a.ldh_bytes + lane_off, 0, 0);
+                    if (SCALED) Vec16<T>::fma(acc[r], raw, a.col_scale[j]);
+                    else Vec16<T>::add(acc[r], raw);
+                }
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        if (row[r] >= a.n_rows) continue;
+        if (SCALED) {
+            const float rs = a.row_scale[row[r]];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) acc[r][i] *= rs;
+        }
+        T *mp = static_cast<T *>(a.M) + row[r] * a.ldm + int64_t(fvec) * NV;
+        if ((fvec + 1) * NV <= a.F || a.store_pad) {
+            store16(mp, Vec16<T>::pack(acc[r]), a.store_mode);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (fvec * NV + i < a.F) store_elem(mp + i, acc[r][i]);
+        }
+    }
+}
+
+template <typename T, int LPR, int RPG, int W, int NB>
+int launch_ell(const EllArgs &a, bool scaled, hipStream_t s)
+{
+    constexpr int RPB = (256 / LPR) * RPG;
+    EllArgs b = a;
+    b.n_row_blocks = unsigned((a.n_rows + RPB - 1) / RPB);
+    b.n_ftiles = (a.nvec + a.tile_vecs - 1) / a.tile_vecs;
+    const dim3 grid = a.xcd_tiled
+                          ? dim3(gae::kNumXcd * ((b.n_ftiles + gae::kNumXcd - 1) / gae::kNumXcd) * b.n_row_blocks)
+                          : dim3(b.n_row_blocks, b.n_ftiles);
+    if (scaled) hipLaunchKernelGGL((spmm_ell_kernel<T, LPR, RPG, W, NB, true>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((spmm_ell_kernel<T, LPR, RPG, W, NB, false>), grid, dim3(256), 0, s, b);
+    GAE_CHECK_LAUNCH("spmm_ell_kernel");
+    return GAE_OK;
+}
+
+template <typename T, int LPR, int RPG>
+int launch_ell_w(const EllArgs &a, int W, bool scaled, hipStream_t s)
+{
+    if (W == 4) return launch_ell<T, LPR, RPG, 4, 4>(a, scaled, s);
+    if (W == 8) return launch_ell<T, LPR, RPG, 8, 8>(a, scaled, s);
+    return launch_ell<T, LPR, RPG, 16, 8>(a, scaled, s);
+}
+
+template <typename T>
+int launch_ell_t(const EllArgs &a, int lpr, int rpg, int W, bool scaled, hipStream_t s)
+{
+#define GAE_ELL_L(LPR)                                                                   \
+    if (lpr == LPR) {                                                                    \
+        if (rpg >= 2 && sizeof(T) == 4) return launch_ell_w<T, LPR, 2>(a, W, scaled, s); \
+        return launch_ell_w<T, LPR, 1>(a, W, scaled, s);                                 \
+    }
+    GAE_ELL_L(8)
+    GAE_ELL_L(16)
+    GAE_ELL_L(32)
+    GAE_ELL_L(64)
+#undef GAE_ELL_L
+    gae::set_error("spmm_ell: unsupported lane-group width %d", lpr);
+    return GAE_E_RANGE;
+}
+
+} // namespace
+
+namespace gae {
+
+int *spmm_ell_knob(const char *name)
+{
+    if (strcmp(name, "spmm_ell_rpg") == 0) return &g_spmm_ell_rpg;
+    return nullptr;
+}
+
+// Can the ell family run this launch?  (16-byte vector layout is the caller's precondition.)
+bool spmm_ell_usable(int64_t n_cols, int64_t ldh, int elem, int ell_width, int tile_vecs)
+{
+    const int64_t h_bytes = n_cols * ldh * elem;
+    return (ell_width == 4 || ell_width == 8 || ell_width == 16) && tile_vecs > 4 && tile_vecs <= 64 &&
+           h_bytes + (int64_t(1) << 16) < (int64_t(1) << 32) && n_cols > 0;
+}
+
+// tile_vecs: 16-byte vectors of one feature tile (1 .. 64; the lane group is the next power of two, at least 8);
+// xcd_tiled as GAE_SPMM_TILE decided
+int spmm_ell_launch(const int32_t *indptr, const int32_t *indices, const int32_t *ell, int ell_width, int64_t n_rows,
+                    int64_t n_cols, const void *H, int64_t ldh, void *M, int64_t ldm, int F, int dtype,
+                    const float *rs, const float *cs, int tile_vecs, int xcd_tiled, int store_pad, int store_mode,
+                    hipStream_t s)
+{
+    int lanes_per_row = 8;
+    while (lanes_per_row < tile_vecs) lanes_per_row *= 2;
+    const int elem = dtype == GAE_F32 ? 4 : 2, nv = 16 / elem;
+    EllArgs a{};
+    a.indptr = indptr; a.indices = indices; a.ell = ell;
+    a.H = H; a.M = M; a.row_scale = rs; a.col_scale = cs;
+    a.n_rows = n_rows; a.ldm = ldm;
+    a.ldh_bytes = unsigned(ldh * elem);
+    a.h_bytes = unsigned(n_cols * ldh * elem);
+    a.n_cols = unsigned(n_cols); a.F = unsigned(F); a.nvec = unsigned((F + nv - 1) / nv);
+    a.tile_vecs = unsigned(tile_vecs);
+    a.xcd_tiled = xcd_tiled; a.store_pad = store_pad; a.store_mode = store_mode;
+    const int rpg = g_spmm_ell_rpg > 0 ? g_spmm_ell_rpg : 1;
+    const bool scaled = rs != nullptr;
+    if (dtype == GAE_F32) return launch_ell_t<float>(a, lanes_per_row, rpg, ell_width, scaled, s);
+    return launch_ell_t<unsigned short>(a, lanes_per_row, 1, ell_width, scaled, s);
+}
+
+} // namespace gae

@@ -220,19 +220,28 @@ class SpmmPlan:
     """per-CSR acceleration data of gae_spmm_csr (gae_spmm_plan in include/gae_hip.h): the degree-skew plan
     (heavy rows cut into segments) and / or the packed neighbour table"""
 
-    def __init__(self, threshold, segment, n_heavy, n_segments, heavy_rows, heavy_seg_base, seg_heavy, ell=None):
+    def __init__(self, threshold, segment, n_heavy, n_segments, heavy_rows, heavy_seg_base, seg_heavy, ell=None,
+                 ell_width=None):
         self.tensors = (heavy_rows, heavy_seg_base, seg_heavy, ell)  # keep the device arrays alive
         self.n_heavy, self.n_segments, self.ell = n_heavy, n_segments, ell
+        self.ell_width = (ell_width or _lib.SPMM_ELL_WIDTH) if ell is not None else 0
         ptr = lambda t: None if t is None else t.data_ptr()
         self.c = _lib.SpmmPlan(threshold, segment, n_heavy, n_segments, ptr(heavy_rows), ptr(heavy_seg_base),
-                               ptr(seg_heavy), ptr(ell), _lib.SPMM_ELL_WIDTH if ell is not None else 0, 0)
+                               ptr(seg_heavy), ptr(ell), self.ell_width, 0)
 
 
-def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None):
+def ell_width_for(max_deg):
+    """narrowest packed-table width (4, 8 or 16 slots) that holds every row of a graph whose longest (light) row
+    has ``max_deg`` edges; rows longer than 16 continue from the CSR arrays"""
+    return 4 if max_deg <= 4 else 8 if max_deg <= 8 else _lib.SPMM_ELL_WIDTH
+
+
+def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_width=None):
     """Build the plan of a CSR, or None when it needs none (one host read-back of three counters; done once per
     graph).  Skew part: with the default threshold only for graphs whose longest row has more than
     SKEW_MIN_MAXDEG edges.  Packed neighbour table: when ``indices`` is given and the graph has at most
-    ELL_MAX_ROWS rows (``ell`` = True / False overrides)."""
+    ELL_MAX_ROWS rows (``ell`` = True / False overrides); ``ell_width`` 4 / 8 / 16 slots per row, default: the
+    narrowest that holds the longest light row."""
     auto = threshold is None
     threshold = SKEW_THRESHOLD if threshold is None else threshold
     segment = SKEW_SEGMENT if segment is None else segment
@@ -259,10 +268,12 @@ def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None):
         else:
             n_heavy = n_seg = 0
         if want_ell:
-            table = torch.empty(n * _lib.SPMM_ELL_WIDTH, dtype=torch.int32, device=dev)
-            _lib.call("gae_spmm_ell_build", _ptr(indptr), _ptr(indices), n, _lib.SPMM_ELL_WIDTH,
+            if ell_width is None:
+                ell_width = ell_width_for(min(max_deg, threshold) if heavy else max_deg)
+            table = torch.empty(n * ell_width, dtype=torch.int32, device=dev)
+            _lib.call("gae_spmm_ell_build", _ptr(indptr), _ptr(indices), n, ell_width,
                       threshold if heavy else 2 ** 31 - 1, _ptr(table), _stream())
-    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh, table)
+    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh, table, ell_width)
 
 
 def gather_distance(indptr, indices):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GAE_VERSION 100 /* 0.1.0 */
+#define GAE_VERSION 101 /* 0.1.1 */
 
 enum {
     GAE_OK = 0,
@@ -136,7 +136,7 @@ typedef struct gae_spmm_plan {
     const int32_t *heavy_seg_base;  /* [n_heavy]    first segment of the row      (device) */
     const int32_t *seg_heavy;       /* [n_segments] heavy-row slot of the segment (device) */
     const int32_t *ell;             /* [n_rows * ell_width] packed neighbour table (device) or NULL */
-    int32_t ell_width;              /* GAE_SPMM_ELL_WIDTH when `ell` is given, else 0 */
+    int32_t ell_width;              /* 4, 8 or GAE_SPMM_ELL_WIDTH when `ell` is given, else 0 */
     int32_t reserved;
 } gae_spmm_plan;
 
@@ -155,6 +155,7 @@ int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t threshold,
  * chain, not by bytes (Pubmed F = 500: 21 -> 15 us).  Same summation order, bit-identical results.  The table
  * costs width * 4 bytes per row of extra traffic: leave plan->ell NULL for graphs of millions of rows. */
 #define GAE_SPMM_ELL_WIDTH 16
+/* width: 4, 8 or 16 slots per row */
 int gae_spmm_ell_build(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t width,
                        int32_t skip_degree, int32_t *ell, void *stream);
 /* bytes of workspace gae_spmm_csr needs with this plan (0 without one) */

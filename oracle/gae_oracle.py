@@ -218,6 +218,37 @@ def bce_with_logits_mean(logits, adj, pos_weight):
     return loss.mean()
 
 
+def bce_row_window(Zt, r0, r1, indptr, indices, t_indptr, t_indices, pos_weight):
+    """Rows ``[r0, r1)`` of the loss of train_inductive.py:44-48 for graphs whose
+    dense N x N label does not fit (ZINC batch of 4096 molecules: 9e9 logits).
+    ``Zt`` is the dropped embedding (gae.py:70), ``(indptr, indices)`` the CSR
+    of the label (rows = destination: ``y_ij`` = #edges j->i, duplicates add,
+    train_inductive.py:44), ``(t_indptr, t_indices)`` the CSR of its transpose
+    (``y_ji``).  Returns ``(sum_{i in window, j} l_ij / N^2, dLoss/dZt[r0:r1])``
+    in fp64 with ``l = (1-y) x + (1+(pw-1) y) softplus(-x)`` and
+    ``dZt_i = sum_j (G_ij + G_ji) Zt_j``, ``G = dl/dx / N^2`` (x is symmetric,
+    the label need not be)."""
+    Zt = torch.as_tensor(Zt).double()
+    n = Zt.shape[0]
+    pw = float(pos_weight)
+    x = Zt[r0:r1] @ Zt.t()
+
+    def label(ip, ix):
+        y = torch.zeros(r1 - r0, n, dtype=torch.float64)
+        ip = np.asarray(ip, dtype=np.int64)
+        cols = torch.as_tensor(np.asarray(ix[ip[r0]:ip[r1]], dtype=np.int64))
+        rows = torch.repeat_interleave(torch.arange(r1 - r0), torch.as_tensor(np.diff(ip[r0:r1 + 1])))
+        y.index_put_((rows, cols), torch.ones(len(cols), dtype=torch.float64), accumulate=True)
+        return y
+
+    y_row, y_col = label(indptr, indices), label(t_indptr, t_indices)
+    sp = torch.nn.functional.softplus(-x)
+    loss = ((1 - y_row) * x + (1 + (pw - 1) * y_row) * sp).sum() / (float(n) * n)
+    sig_neg = torch.sigmoid(-x)
+    g = ((1 - y_row) - (1 + (pw - 1) * y_row) * sig_neg) + ((1 - y_col) - (1 + (pw - 1) * y_col) * sig_neg)
+    return loss, (g @ Zt) / (float(n) * n)
+
+
 def gae_loss_and_grads(src, dst, n, X, weights, biases, mask=None, norm=None):
     """One reference training step up to the gradients
     (train_inductive.py:44-51): dense label, pos_weight, GAE.forward with an

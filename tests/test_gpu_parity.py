@@ -160,6 +160,7 @@ def test_spmm_packed_table_bit_identical(F, dtype, dev):
     table = ops.spmm_plan(dip, indices=dix)                               # auto: no heavy rows, table only
     assert table is not None and table.n_heavy == 0 and table.ell is not None
     W = _lib.SPMM_ELL_WIDTH
+    assert table.ell_width == W                                           # longest row > 8 edges: 16 slots
     tab = table.ell.cpu().numpy().reshape(n, W)
     deg = np.diff(ip)
     for r in (5, 11, 12, 13, 14, 100):
@@ -168,7 +169,9 @@ def test_spmm_packed_table_bit_identical(F, dtype, dev):
         assert (tab[r, k:] == (-2 if deg[r] > W else -1)).all() or (deg[r] > W and tab[r, W - 1] == -2)
     both = ops.spmm_plan(dip, threshold=8, segment=64, indices=dix)       # heavy rows + table
     assert both.n_heavy == int((deg > 8).sum()) and both.ell is not None
-    assert int(both.ell.view(n, W)[11, 0]) == -3
+    assert both.ell_width == 8                                            # light rows have at most 8 edges
+    assert int(both.ell.view(n, 8)[11, 0]) == -3
+    narrow = ops.spmm_plan(dip, indices=dix, ell_width=4)                 # most rows overflow into the CSR arrays
     for scaled in (False, True):
         sc = t(norm, dev) if scaled else None
         base = ops.spmm_raw(dip, dix, Hd, n, sc, sc)
@@ -177,6 +180,12 @@ def test_spmm_packed_table_bit_identical(F, dtype, dev):
             try:
                 out = ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=table)
                 assert torch.equal(out, base)
+                assert torch.equal(ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=narrow), base)
+                for ell_kernels in (2, 1):        # 2 = row-group kernel reads the table, 1 = spmm_ell.hip kernels
+                    _lib.call("gae_tuning_set", b"spmm_ell", ell_kernels)
+                    _lib.call("gae_tuning_set", b"spmm_ell_rpg", rpg)
+                    assert torch.equal(ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=table), base)
+                _lib.call("gae_tuning_set", b"spmm_ell_rpg", 0)
                 heavy = ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=ops.spmm_plan(dip, threshold=8, segment=64))
                 assert torch.equal(ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=both), heavy)
             finally:
@@ -378,7 +387,7 @@ def test_spmm_baseline_full_sizes(dev):
     assert torch.equal(ops.spmm_raw(ip, ix, ones, n, plan=plan, scattered=True)[:, 499], deg.float())
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(40))
 def test_spmm_dispatch_fuzz(seed, dev):
     """random (graph, width, leading dimension, dtype, scales, plan / packed table / feature tiles / rows-per-group /
     store-pad) combinations: every dispatch branch of gae_spmm_csr gives the CSR-order sums -- bit-identical to the
@@ -410,7 +419,8 @@ def test_spmm_dispatch_fuzz(seed, dev):
         ref = O().spmm_csr(ip, ix, Hd.float().cpu().double(), None if norm is None else norm.cpu().numpy(),
                            None if norm is None else norm.cpu().numpy())
         assert rel_err(base.float(), ref) < (TOL if dtype == torch.float32 else 1e-2)
-    table = ops.spmm_plan(dip, indices=dix, ell=True, threshold=10 ** 6) if n else None
+    table = ops.spmm_plan(dip, indices=dix, ell=True, threshold=10 ** 6,
+                          ell_width=[None, 4, 8, 16][int(rng.integers(0, 4))]) if n else None
     heavy = ops.spmm_plan(dip, threshold=int(rng.choice([1, 4, 8])), segment=64)
     for trial in range(4):
         rpg = int(rng.integers(0, 3)); tv = int(rng.choice([0, 0, 8, 16, 40]))
@@ -419,11 +429,13 @@ def test_spmm_dispatch_fuzz(seed, dev):
         out = torch.full((n, Hd.stride(0) if n > 1 else max(F, 1)), 3.0, device=dev, dtype=dtype)[:, :F] \
             if rng.integers(0, 2) else None
         _lib.call("gae_tuning_set", b"spmm_rpg", rpg); _lib.call("gae_tuning_set", b"spmm_tile_vecs", tv)
+        _lib.call("gae_tuning_set", b"spmm_ell_rpg", rpg); _lib.call("gae_tuning_set", b"spmm_ell", int(rng.integers(1, 3)))
         try:
             got = ops.spmm_raw(dip, dix, Hd, n, norm, norm, out=out, plan=table if use_table else None,
                                scattered=scattered, out_padded=out is not None and pad_mode == 1)
         finally:
             _lib.call("gae_tuning_set", b"spmm_rpg", 0); _lib.call("gae_tuning_set", b"spmm_tile_vecs", 0)
+            _lib.call("gae_tuning_set", b"spmm_ell_rpg", 0); _lib.call("gae_tuning_set", b"spmm_ell", 1)
         assert torch.equal(got, base), (n, e, F, dtype, scaled, pad_mode, rpg, tv, use_table, scattered)
     if heavy is not None and F > 12:                  # segment sums have their own (fixed) order: tolerance, stable
         a = ops.spmm_raw(dip, dix, Hd, n, norm, norm, plan=heavy)

@@ -11,7 +11,7 @@ fi
 IFS=';' read -ra SETS <<< "$PMC_SETS"
 for CNT in "${SETS[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $CNT --output-format csv -d $OUT/p$i -o pmc -- python $R/"$1" "${@:2}" > $OUT/p$i.log 2>&1
+  timeout -k 5 ${PMC_TIMEOUT:-180} rocprofv3 --pmc $CNT --output-format csv -d $OUT/p$i -o pmc -- python $R/"$1" "${@:2}" > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections

@@ -43,7 +43,11 @@ def main():
     ap.add_argument("--seg", type=int, default=512)
     ap.add_argument("--variants", default="v1:1:0,v2:1:0,v2:2:0,v2:1:1,v2:2:1")
     ap.add_argument("--shapes", default="pubmed500,pubmed32,zincb39,zincb32,zinc39,zinc32,rmat32")
+    ap.add_argument("--knobs", default="", help="comma-separated gae_tuning_set name=value pairs applied to every variant")
     args = ap.parse_args()
+    for kv in filter(None, args.knobs.split(",")):
+        k, v = kv.split("=")
+        knob(k, int(v))
     dev = torch.device("cuda:0")
     shapes = {}
     want = args.shapes.split(",")
@@ -55,6 +59,17 @@ def main():
         shapes["pubmed500a"] = (ip, ix, n, 500, 512)   # rows padded to whole 128-byte lines
         shapes["pubmed500b"] = (ip, ix, n, 500, 544)   # ... and an odd number of lines per row
         shapes["pubmed500c"] = (ip, ix, n, 500, 576)   # 18 lines
+    if any(s.startswith("pdiag") for s in want):   # diagnostics: Pubmed rows / degrees with controlled gather targets
+        n, src, dst, _ = W.citation_graph("pubmed")
+        rng = np.random.default_rng(3)
+        d = torch.from_numpy(dst).to(dev)
+        for nm, srcx in (("pdiag_col2k", rng.integers(0, 2000, dst.size)),          # H slice fits every L2
+                         ("pdiag_self", dst.copy()),                                 # every neighbour = the row itself
+                         ("pdiag_near", np.clip(dst + rng.integers(-8, 9, dst.size), 0, n - 1))):
+            ipx, ixx = ops.csr_from_coo(d, torch.from_numpy(srcx).to(dev), n, n)
+            shapes[nm] = (ipx, ixx, n, 500, 512)
+        ipz = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        shapes["pdiag_zero"] = (ipz, torch.zeros(0, dtype=torch.int32, device=dev), n, 500, 512)   # no edges: stores only
     if any(s.startswith("preg") for s in want):     # random graph, every row exactly 4 / 8 in-edges
         n = 19717
         rng = np.random.default_rng(2)
@@ -105,8 +120,9 @@ def main():
         print(f"rmat plan: thr={args.thr} seg={args.seg} heavy rows={pl.n_heavy} segments={pl.n_segments}")
     variants = []
     for v in args.variants.split(","):
-        # name:rpg:nt:tile_vecs:opts   opts = letters: e = packed neighbour table, t = GAE_SPMM_TILE, p = store pad,
-        #                              b = block-diagonal kernel
+        # name:rpg:nt:tile_vecs:opts   opts = letters: e = packed neighbour table + spmm_ell.hip kernels (w4 / w8 =
+        #                              table width, default 16), E = table + row-group kernel, t = GAE_SPMM_TILE,
+        #                              p = store pad, b = block-diagonal kernel
         parts = v.split(":")
         name, rpg, nt = parts[:3]
         tv = int(parts[3]) if len(parts) > 3 else 0
@@ -125,11 +141,13 @@ def main():
         for rnd in range(args.rounds + 1):
             for (label, var, rpg, nt, tv, opts) in variants:
                 knob("spmm_variant", var); knob("spmm_rpg", rpg); knob("spmm_nt", nt); knob("spmm_tile_vecs", tv)
+                knob("spmm_ell", 2 if "E" in opts else 1); knob("spmm_ell_rpg", rpg)
                 plan = plans.get(sname)
-                if "e" in opts and plan is None:
-                    if id(ip) not in ell_plans:
-                        ell_plans[id(ip)] = ops.spmm_plan(ip, indices=ix, ell=True)
-                    plan = ell_plans[id(ip)]
+                if ("e" in opts or "E" in opts) and plan is None:
+                    w = 4 if "w4" in opts else 8 if "w8" in opts else 16
+                    if (id(ip), w) not in ell_plans:
+                        ell_plans[(id(ip), w)] = ops.spmm_plan(ip, indices=ix, ell=True, ell_width=w)
+                    plan = ell_plans[(id(ip), w)]
                 fn = lambda: ops.spmm_raw(ip, ix, H, n, out=out, plan=plan, out_padded="p" in opts,
                                           scattered="t" in opts,
                                           blockdiag=bdiag.get(sname) if "b" in opts else None)
