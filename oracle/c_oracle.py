@@ -48,6 +48,19 @@ def spmm_csr(indptr, indices, H, row_scale=None, col_scale=None):
     return M
 
 
+def spmm_csr_acc64(indptr, indices, H):
+    """un-normalised aggregate with a double accumulator (fp32 H, fp64 result)"""
+    H = np.ascontiguousarray(H, dtype=np.float32)
+    indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    n, F = len(indptr) - 1, H.shape[1]
+    M = np.empty((n, F), dtype=np.float64)
+    lib().oracle_spmm_csr_f32_acc64(ctypes.c_int64(n), _p(indptr, ctypes.c_int32), _p(indices, ctypes.c_int32),
+                                    _p(H, ctypes.c_float), ctypes.c_int64(F), _p(M, ctypes.c_double),
+                                    ctypes.c_int64(F), ctypes.c_int64(F))
+    return M
+
+
 def linear(M, W, b, relu):
     M = np.ascontiguousarray(M, dtype=np.float32); W = np.ascontiguousarray(W, dtype=np.float32)
     b = np.ascontiguousarray(b, dtype=np.float32)

@@ -46,6 +46,22 @@ void oracle_spmm_csr_f32(int64_t n_rows, const int32_t *indptr, const int32_t *i
     }
 }
 
+/* Same traversal with a double accumulator and double output: the reference for rows so long (RMAT hubs: 10^5
+ * in-edges) that the order of an fp32 sum matters more than the 1e-5 tolerance. */
+void oracle_spmm_csr_f32_acc64(int64_t n_rows, const int32_t *indptr, const int32_t *indices,
+                               const float *H, int64_t ldh, double *M, int64_t ldm, int64_t F)
+{
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t v = 0; v < n_rows; ++v) {
+        double *out = M + v * ldm;
+        for (int64_t f = 0; f < F; ++f) out[f] = 0.0;
+        for (int32_t e = indptr[v]; e < indptr[v + 1]; ++e) {
+            const float *h = H + (int64_t)indices[e] * ldh;
+            for (int64_t f = 0; f < F; ++f) out[f] += (double)h[f];
+        }
+    }
+}
+
 /* Y = act(M W^T + b), W [F_out, F_in] row-major (nn.Linear, gae.py:10,14-15) */
 void oracle_linear_f32(int64_t n, const float *M, int64_t F_in, const float *W, const float *b,
                        int64_t F_out, int relu, float *Y)
