@@ -48,6 +48,9 @@ SIGNATURES = {
     "gae_csr_to_dense": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
     "gae_batch_gather": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _p, _i64, _i64,
                                 _p, _p, _p, _i64, _p]),
+    "gae_bce_logits_workspace_bytes": (_i64, []),
+    "gae_bce_logits": (_int, [_p, _i64, _p, _i64, _i64, _i64, _f, _p, _p, _i64, _p, _i64, _p]),
+    "gae_segment_readout": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),
     "gae_spmm_plan_count": (_int, [_p, _i64, _i32, _i32, _p, _p]),
     "gae_spmm_plan_fill": (_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
     "gae_spmm_ell_build": (_int, [_p, _p, _i64, _i32, _i32, _p, _p]),

@@ -34,10 +34,18 @@ class CapturedTrainStep:
             for _ in range(warmup):
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
+        self._capture()
+
+    def _hyper(self):
+        """optimiser hyper-parameters that a launch takes by value (frozen into the captured graph)"""
+        return tuple((g["lr"], tuple(g.get("betas", ())), g.get("eps"), g.get("weight_decay")) for g in self.opt.param_groups)
+
+    def _capture(self):
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.loss = self._fwd_bwd_step()
+        self._captured_hyper = self._hyper()
 
     def _fwd_bwd_step(self):
         self.g.ndata['h'] = self.x
@@ -51,6 +59,9 @@ class CapturedTrainStep:
         return self._fwd_bwd_step()
 
     def __call__(self):
-        """one training step; returns the (static) loss tensor of this replay"""
+        """one training step; returns the (static) loss tensor of this replay.  A changed learning rate (scheduler,
+        manual edit of param_groups) is picked up by capturing the step again."""
+        if self._hyper() != self._captured_hyper:
+            self._capture()
         self.graph.replay()
         return self.loss

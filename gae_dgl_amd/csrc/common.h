@@ -107,9 +107,11 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
     c[1] = uint32_t(p1); c[3] = uint32_t(p0); c[0] = n0; c[2] = n2;
 }
 
-__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint32_t (&c)[4])
+// `draw` selects one of 2^64 disjoint streams of the same seed through the high counter words: consecutive draws
+// over tensors of different sizes (inductive batches) can never reuse a 128-bit block
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t draw, uint64_t seed, uint32_t (&c)[4])
 {
-    c[0] = uint32_t(ctr); c[1] = uint32_t(ctr >> 32); c[2] = 0u; c[3] = 0u;
+    c[0] = uint32_t(ctr); c[1] = uint32_t(ctr >> 32); c[2] = uint32_t(draw); c[3] = uint32_t(draw >> 32);
     uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {

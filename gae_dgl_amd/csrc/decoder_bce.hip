@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void bce_prepare_kernel(const float *__restric
     const int64_t r0 = int64_t(blockIdx.x) * PREP_ROWS;
     double s_all = 0.0, s_win = 0.0;
     const bool draw = drop_p > 0.f;
-    if (draw && draw_dev) offset += *draw_dev * uint64_t((n * d + 3) / 4);
+    const uint64_t draw_idx = (draw && draw_dev) ? *draw_dev : 0;   // a stream of its own per draw (as gae_dropout_mask)
     for (int rr = rl; rr < PREP_ROWS; rr += rpp) {
         const int64_t i = r0 + rr;
         if (i >= n) break;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void bce_prepare_kernel(const float *__restric
             if (draw) {
                 const int64_t e = i * d + k;
                 uint32_t c[4];
-                gae::philox4x32_10(offset + uint64_t(e >> 2), seed, c);
+                gae::philox4x32_10(offset + uint64_t(e >> 2), draw_idx, seed, c);
                 const uint32_t bits = (e & 2) ? ((e & 1) ? c[3] : c[2]) : ((e & 1) ? c[1] : c[0]);
                 const float m = gae::dropout_multiplier(bits, drop_p, drop_scale);
                 mask[i * ldz + k] = m;

@@ -1181,10 +1181,13 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float *__restrict__ m
 {
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     const int64_t nquad = (n + 3) / 4;
-    if (draw_dev) offset += *draw_dev * uint64_t(nquad);   // device-side draw counter: graph replays advance the stream
+    // device-side draw counter: graph replays advance the stream.  The draw index goes into the HIGH counter words
+    // (a stream of its own per draw), not into the element counter: draws over tensors of different sizes
+    // (inductive batches) would otherwise overlap.
+    const uint64_t draw = draw_dev ? *draw_dev : 0;
     for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < nquad; q += stride) {
         uint32_t c[4];
-        gae::philox4x32_10(offset + uint64_t(q), seed, c);
+        gae::philox4x32_10(offset + uint64_t(q), draw, seed, c);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t e = q * 4 + i;
@@ -1200,10 +1203,10 @@ __global__ __launch_bounds__(256) void normal_noise_kernel(float *__restrict__ o
 {
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     const int64_t nquad = (n + 3) / 4;
-    if (draw_dev) offset += *draw_dev * uint64_t(nquad);
+    const uint64_t draw = draw_dev ? *draw_dev : 0;     // one stream per draw (word 3), tag in word 2
     for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < nquad; q += stride) {
         const uint64_t ctr = offset + uint64_t(q);
-        uint32_t c[4] = {uint32_t(ctr), uint32_t(ctr >> 32), 0x6e6f726du, 0u};   // stream tag differs from dropout
+        uint32_t c[4] = {uint32_t(ctr), uint32_t(ctr >> 32), 0x6e6f726du ^ uint32_t(draw >> 32), uint32_t(draw)};   // stream tag differs from dropout
         uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
 #pragma unroll
         for (int r = 0; r < 10; ++r) {

@@ -184,6 +184,16 @@ class Graph:
         from . import ops
         return ops.gather_scattered(None, None, row_bytes, distance=self._cache["gather_distance"])
 
+    def graph_ptr(self):
+        """int64 [G + 1] node offsets of the member graphs (a graph that was not built by batch() is its own only
+        member) on the graph's device"""
+        if "graph_ptr" not in self._cache:
+            counts = self.batch_num_nodes if self.batch_num_nodes is not None else [self._n]
+            gp = np.zeros(len(counts) + 1, dtype=np.int64)
+            np.cumsum(np.asarray(counts, dtype=np.int64), out=gp[1:])
+            self._cache["graph_ptr"] = torch.from_numpy(gp).to(self._device)
+        return self._cache["graph_ptr"]
+
     def set_csr(self, indptr, indices, t_indptr=None, t_indices=None):
         """adopt an already-built device CSR (used by the device dataset batcher)"""
         self._cache["csr"] = (indptr, indices)
@@ -236,6 +246,16 @@ class Graph:
 
 
 DGLGraph = Graph
+
+
+def readout_nodes(g, feat='h'):
+    """[mean | sum | max] of ``g.ndata[feat]`` over the nodes of every member graph of a batched graph -> [G, 3 d]:
+    the molecule feature of the reference's ESOL experiment (README.md:54; DGL: mean_nodes / sum_nodes / max_nodes).
+    ``feat`` may also be the [N, d] tensor itself (e.g. ``model.encode(g)``)."""
+    from . import ops
+    z = g.ndata[feat] if isinstance(feat, str) else feat
+    g._follow(z)
+    return ops.segment_readout(z, g.graph_ptr())
 
 
 def batch(graphs):

@@ -72,6 +72,13 @@ def _rowmajor(t, name):
     return t, max(ld, t.shape[1], 1)
 
 
+def _f32(t, name):
+    """the dense kernels read raw fp32 memory: any other dtype would be reinterpreted, not converted"""
+    if t is not None and t.dtype != torch.float32:
+        raise GaeHipError(f"{name}: fp32 tensor expected, got {t.dtype} (cast explicitly; the kernels do not convert)")
+    return t
+
+
 def _dtype_code(t):
     if t.dtype == torch.float32:
         return F32
@@ -179,6 +186,22 @@ def batch_gather(graph_ptr, ds_indptr, ds_indices, ds_feat, graph_ids, node_ptr,
                   _dtype_code(feat), _ptr(graph_ids), graph_ids.numel(), _ptr(node_ptr), _ptr(edge_ptr),
                   n_nodes, n_edges, _ptr(out_indptr), _ptr(out_indices), _ptr(out_feat), ldo, _stream())
     return out_indptr, out_indices, out_feat
+
+
+def segment_readout(Z, graph_ptr):
+    """[mean | sum | max] of the rows of Z [N, d] per member graph (README.md:54 of the reference: the 48-d molecule
+    feature); ``graph_ptr`` int64 [G + 1] node offsets on the device.  Returns [G, 3 d] fp32.  Inference-side op:
+    no autograd."""
+    Z, ldz = _rowmajor(_gpu(Z, "Z").detach(), "Z")
+    if Z.dtype != torch.float32:
+        raise GaeHipError(f"segment_readout: fp32 embeddings expected, got {Z.dtype}")
+    gp = _gpu(graph_ptr, "graph_ptr").to(torch.int64).contiguous()
+    n, d = Z.shape
+    G_ = gp.numel() - 1
+    out = torch.empty(max(G_, 0), 3 * d, dtype=torch.float32, device=Z.device)
+    with _on_device(Z.device):
+        _lib.call("gae_segment_readout", _ptr(Z), ldz, n, d, _ptr(gp), G_, _ptr(out), max(3 * d, 1), _stream())
+    return out
 
 
 # ------------------------------------------------------------------ profiling hook
@@ -401,8 +424,9 @@ def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=Non
 
 
 def linear_fwd_raw(M, W, b, act):
-    M, ldm = _rowmajor(M, "M")
-    W = _gpu(W, "W").contiguous()
+    M, ldm = _rowmajor(_f32(M, "linear: M"), "M")
+    W = _f32(_gpu(W, "W"), "linear: W").contiguous()
+    _f32(b, "linear: b")
     n, f_in = M.shape
     f_out = W.shape[0]
     Y = torch.empty(n, f_out, dtype=torch.float32, device=M.device)
@@ -415,9 +439,10 @@ def linear_fwd_raw(M, W, b, act):
 
 
 def linear_bwd_raw(dY, Y, act, M, W, need_dW=True, need_db=True, need_dM=True):
-    dY, lddy = _rowmajor(dY, "dY")
-    M, ldm = _rowmajor(M, "M")
-    W = W.contiguous()
+    dY, lddy = _rowmajor(_f32(dY, "linear backward: dY"), "dY")
+    M, ldm = _rowmajor(_f32(M, "linear backward: M"), "M")
+    W = _f32(W, "linear backward: W").contiguous()
+    _f32(Y, "linear backward: Y")
     n, f_in = M.shape
     f_out = W.shape[0]
     dev = M.device
@@ -487,7 +512,8 @@ def vgae_head(mu, logstd, eps):
 
 
 def decoder_dense_raw(Z, mask=None):
-    Z, ldz = _rowmajor(Z, "Z")
+    Z, ldz = _rowmajor(_f32(Z, "decoder: Z"), "Z")
+    _f32(mask, "decoder: mask")
     if mask is not None:
         mask = _gpu(mask, "mask").contiguous()
         if Z.stride(0) != mask.stride(0) and Z.shape[0] > 1:
@@ -500,8 +526,9 @@ def decoder_dense_raw(Z, mask=None):
 
 
 def decoder_dense_bwd_raw(G, Z, mask=None):
-    G, ldg = _rowmajor(G, "G")
-    Z = _gpu(Z, "Z").contiguous()
+    G, ldg = _rowmajor(_f32(G, "decoder backward: G"), "G")
+    Z = _f32(_gpu(Z, "Z"), "decoder backward: Z").contiguous()
+    _f32(mask, "decoder backward: mask")
     if mask is not None:
         mask = mask.contiguous()
     n, d = Z.shape
@@ -519,9 +546,9 @@ def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, 
     full [n, d] arrays, csr/csc are the window's local row blocks.
     ``dropout`` = (p, seed, offset, draw_counter): the mask of this draw is generated inside the launch, written
     to ``mask`` (an [n, d] output buffer then) and the device draw counter is advanced by the library."""
-    Z = _gpu(Z, "Z").contiguous()
+    Z = _f32(_gpu(Z, "Z"), "decoder_bce: Z").contiguous()
     if mask is not None:
-        mask = _gpu(mask, "mask").contiguous()
+        mask = _f32(_gpu(mask, "mask"), "decoder_bce: mask").contiguous()
     p_drop, seed, offset, draws = dropout if dropout is not None else (0.0, 0, 0, None)
     if p_drop and (mask is None or mask.shape != Z.shape):
         raise GaeHipError("decoder_bce: in-kernel dropout needs an [n, d] mask output buffer")
@@ -633,6 +660,46 @@ class DecoderBCEFunction(torch.autograd.Function):
         return dZ * g, None, None, None
 
 
+def bce_logits_raw(logits, labels, pos_weight, want_grad=True):
+    """F.binary_cross_entropy_with_logits(logits, labels, pos_weight) (mean) on materialised [n, m] fp32 matrices:
+    returns (loss[1], dLoss/dLogits or None).  The gradient is written over ``logits``."""
+    X, ldx = _rowmajor(_f32(logits, "bce_logits: logits"), "logits")
+    Y, ldy = _rowmajor(_f32(labels, "bce_logits: labels"), "labels")
+    if X.shape != Y.shape:
+        raise GaeHipError("bce_logits: logits / labels shape mismatch")
+    n, m = X.shape
+    loss = torch.empty(1, dtype=torch.float32, device=X.device)
+    with _on_device(X.device):
+        ws = _workspace(_lib.load().gae_bce_logits_workspace_bytes(), X.device)
+        _lib.call("gae_bce_logits", _ptr(X), ldx, _ptr(Y), ldy, n, m, float(pos_weight), _ptr(loss),
+                  _ptr(X) if want_grad else None, ldx, _ptr(ws), ws.numel(), _stream())
+    return loss, (X if want_grad else None)
+
+
+class DecoderDenseBCEFunction(torch.autograd.Function):
+    """train_inductive.py:44-48 in the reference's own shape -- dense label, N x N logits, weighted BCE (mean) -- as a
+    chain of HIP kernels (gae_decoder_dense, gae_csr_to_dense, gae_bce_logits, gae_decoder_dense_bwd).  Used for
+    embedding widths above FUSED_MAX_D, which the never-materialised kernel does not take; O(N^2) memory."""
+
+    @staticmethod
+    def forward(ctx, Z, mask, graph):
+        n, nnz = graph.number_of_nodes(), graph.number_of_edges()
+        pw = (float(n) * float(n) - float(nnz)) / float(nnz)      # train_inductive.py:46
+        need = ctx.needs_input_grad[0]
+        logits = decoder_dense_raw(Z, mask)
+        loss, G = bce_logits_raw(logits, graph.dense_adjacency(), pw, want_grad=need)
+        ctx.save_for_backward(G, Z, mask)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        G, Z, mask = ctx.saved_tensors
+        dZ = decoder_dense_bwd_raw(G, Z, mask)
+        return (dZ if _is_unit(g) else dZ * g), None, None
+
+
+FUSED_MAX_D = 64     # widest embedding of the fused decoder + BCE kernels (gae_decoder_bce)
+
 _UNIT = {}
 
 
@@ -652,7 +719,15 @@ def backward(loss):
 
 
 def decoder_bce(Z, mask, graph, dropout=None):
-    """``dropout`` = (p, seed, offset, draw_counter): draw the mask inside the fused launch into ``mask``"""
+    """``dropout`` = (p, seed, offset, draw_counter): draw the mask inside the fused launch into ``mask``.
+    Embeddings wider than FUSED_MAX_D take the dense HIP chain (same value, O(N^2) memory)."""
+    if Z.shape[1] > FUSED_MAX_D:
+        if dropout is not None and dropout[0]:
+            p_drop, seed, offset, draws = dropout
+            mask.copy_(dropout_mask(tuple(Z.shape), p_drop, seed, offset, Z.device, draw_counter=draws))
+            if draws is not None:
+                draws += 1
+        return DecoderDenseBCEFunction.apply(Z, mask, graph)
     return DecoderBCEFunction.apply(Z, mask, graph, dropout)
 
 

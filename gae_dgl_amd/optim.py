@@ -3,8 +3,12 @@
 Same update rule, defaults and constructor as ``torch.optim.Adam(params, lr, betas, eps, weight_decay)`` -- the
 optimiser of the reference's Trainer (train_inductive.py:40,50-52; train_transductive.py:43,66-68) -- without
 amsgrad / maximize.  One step counter per parameter group (torch keeps one per tensor; the two agree whenever
-every parameter receives a gradient on every step, as in the reference's loops).  The counter lives on the device, so the step can be captured in a HIP graph
-(``capture.CapturedTrainStep``) like ``torch.optim.Adam(capturable=True)``.  PyTorch's fused Adam takes two
+every parameter receives a gradient on every step, as in the reference's loops).  The counter lives on the device,
+so the step can be captured in a HIP graph (``capture.CapturedTrainStep``) like ``torch.optim.Adam(capturable=True)``;
+lr / betas / eps / weight_decay are launch arguments and therefore frozen into a captured graph --
+``CapturedTrainStep`` re-captures when it sees them change (an LR scheduler keeps working).
+``state_dict()`` / ``load_state_dict()`` use torch.optim.Adam's layout (per-parameter ``step``, ``exp_avg``,
+``exp_avg_sq``), so checkpoints move between the two optimisers.  PyTorch's fused Adam takes two
 multi-tensor launches (about 17 us on an MI355X) for the 16 k parameters of a GAE; this one takes one short launch."""
 import ctypes
 
@@ -20,6 +24,7 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("Adam: hyper-parameter out of range")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
                                       capturable=True))
+        self._counters = {}      # (group index, chunk) -> device int64[2]: steps taken, ticket
 
     def _moments(self, p):
         st = self.state[p]
@@ -30,8 +35,33 @@ class Adam(torch.optim.Optimizer):
 
     def steps_taken(self, group=0, chunk=0):
         """number of steps the device-side counter of a parameter group has seen (host read-back)"""
-        counters = self.param_groups[group].get("_hip_steps", {})
-        return int(counters[chunk][0]) if chunk in counters else 0
+        c = self._counters.get((group, chunk))
+        return int(c[0]) if c is not None else 0
+
+    def hyper_params(self):
+        """the values a captured launch has frozen in"""
+        return tuple((g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]) for g in self.param_groups)
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for gi, group in enumerate(sd["param_groups"]):
+            step = torch.tensor(float(self.steps_taken(gi)))
+            for idx in group["params"]:
+                if idx in sd["state"]:
+                    sd["state"][idx]["step"] = step.clone()      # torch.optim.Adam keeps one per tensor
+        return sd
+
+    def load_state_dict(self, state_dict):
+        steps = []
+        for group in state_dict["param_groups"]:
+            seen = [float(state_dict["state"][i]["step"]) for i in group["params"]
+                    if i in state_dict["state"] and "step" in state_dict["state"][i]]
+            steps.append(int(max(seen)) if seen else 0)
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            st.pop("step", None)
+        self._counters = {}
+        self._resume_steps = steps
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -39,9 +69,8 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
-            counters = group.setdefault("_hip_steps", {})      # one device counter pair per chunk of 16 tensors
             for c0 in range(0, len(ps), _lib.ADAM_MAX_TENSORS):
                 chunk = ps[c0:c0 + _lib.ADAM_MAX_TENSORS]
                 dev = chunk[0].device
@@ -57,9 +86,13 @@ class Adam(torch.optim.Optimizer):
                     m, v = self._moments(p)
                     keep.append(g)
                     arr[k] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
-                key = c0 // _lib.ADAM_MAX_TENSORS
-                if key not in counters:
-                    counters[key] = torch.zeros(2, dtype=torch.int64, device=dev)
+                key = (gi, c0 // _lib.ADAM_MAX_TENSORS)        # one device counter pair per chunk of 16 tensors
+                if key not in self._counters:
+                    self._counters[key] = torch.zeros(2, dtype=torch.int64, device=dev)
+                    resume = getattr(self, "_resume_steps", None)
+                    if resume is not None and gi < len(resume):
+                        self._counters[key][0] = resume[gi]
+                counters = self._counters
                 with _on_device(dev):
                     _lib.call("gae_adam_step", arr, len(chunk), float(group["lr"]), float(group["betas"][0]),
                               float(group["betas"][1]), float(group["eps"]), float(group["weight_decay"]),

@@ -219,9 +219,11 @@ int gae_linear_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, i
  * activation GAE passes (gae_dgl/gae.py:47).
  * gae_dropout_mask: inverted-dropout multiplier (0 or 1/(1-p)), Philox4x32-10
  * counter RNG keyed by (seed, offset + element index): reproducible for bwd.
- * draw_dev (device uint64, may be NULL): number of masks drawn so far; the
- * counter base becomes offset + *draw_dev * ceil(n_elems / 4), so a captured
- * HIP graph draws a fresh mask on every replay once the caller bumps it.
+ * draw_dev (device uint64, may be NULL): number of masks drawn so far.  The
+ * Philox counter of element block q is (offset + q) in its low 64 bits and
+ * *draw_dev in its high 64 bits: every draw is a stream of its own, whatever the
+ * sizes of earlier draws, and a captured HIP graph draws a fresh mask on every
+ * replay once the caller bumps the counter.
  * gae_decoder_dense: out = Zt Zt^T with Zt = Z (.) mask (mask may be NULL). */
 int gae_dropout_mask(float *mask, int64_t n_elems, float p, uint64_t seed, uint64_t offset,
                      const uint64_t *draw_dev, void *stream);
@@ -287,6 +289,25 @@ int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, int64_t n, in
                          float dropout_p, uint64_t seed, uint64_t offset, uint64_t *draw_dev,
                          float *loss_out, float *dZ, int64_t lddz,
                          void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Reference-shaped loss on MATERIALISED logits: F.binary_cross_entropy_with_logits(adj_logits, adj,
+ * pos_weight=pos_weight) with the default mean reduction (gae_dgl/train_inductive.py:48) and dLoss/dLogits.  Used
+ * for embedding widths the fused kernel does not take (d > 64; gae_dgl/optuna_gae.py:29-34 samples hidden dims up
+ * to 256) together with gae_decoder_dense / gae_csr_to_dense / gae_decoder_dense_bwd.  logits / labels / grad:
+ * [n_rows, n_cols] fp32 with their leading dimensions; grad may be NULL (loss only) and may alias logits.
+ * workspace: gae_bce_logits_workspace_bytes() bytes.  Ordered fp64 reduction: deterministic. */
+int64_t gae_bce_logits_workspace_bytes(void);
+int gae_bce_logits(const float *logits, int64_t ldx, const float *labels, int64_t ldy, int64_t n_rows, int64_t n_cols,
+                   float pos_weight, float *loss_out, float *grad, int64_t ldg, void *workspace,
+                   int64_t workspace_bytes, void *stream);
+
+/* ---- graph-level readout ------------------------------------------------------
+ * out[g] = [ mean | sum | max ] over the nodes graph_ptr[g] .. graph_ptr[g+1] of Z [n_nodes, d] (ldz): the 3 d
+ * molecule feature the reference describes for its ESOL experiment (README.md:54; with DGL: mean_nodes /
+ * sum_nodes / max_nodes over the batched graph of gae_dgl/train_inductive.py:34).  graph_ptr: int64 [n_graphs + 1]
+ * node offsets (device), out [n_graphs, 3 d] (ldo), fp32.  Deterministic; an empty graph gives zeros. */
+int gae_segment_readout(const float *Z, int64_t ldz, int64_t n_nodes, int64_t d, const int64_t *graph_ptr,
+                        int64_t n_graphs, float *out, int64_t ldo, void *stream);
 
 /* ---- K12: Adam ----------------------------------------------------------------
  * torch.optim.Adam(params, lr, betas, eps, weight_decay) of gae_dgl/train_inductive.py:40,50-52 and

@@ -249,6 +249,21 @@ def bce_row_window(Zt, r0, r1, indptr, indices, t_indptr, t_indices, pos_weight)
     return loss, (g @ Zt) / (float(n) * n)
 
 
+def segment_readout(Z, graph_ptr):
+    """README.md:54: "concatenation of mean, sum, and max aggregation of the hidden vector H in R^{N x 16}" per
+    molecule -> [G, 3 d].  (The reference ships no code for it; with DGL it is mean_nodes / sum_nodes / max_nodes
+    on the batched graph.)  An empty graph gives zeros."""
+    Z = np.asarray(Z, dtype=np.float64)
+    gp = np.asarray(graph_ptr, dtype=np.int64)
+    d = Z.shape[1]
+    out = np.zeros((len(gp) - 1, 3 * d))
+    for g in range(len(gp) - 1):
+        seg = Z[gp[g]:gp[g + 1]]
+        if len(seg):
+            out[g, :d], out[g, d:2 * d], out[g, 2 * d:] = seg.mean(0), seg.sum(0), seg.max(0)
+    return out
+
+
 def gae_loss_and_grads(src, dst, n, X, weights, biases, mask=None, norm=None):
     """One reference training step up to the gradients
     (train_inductive.py:44-51): dense label, pos_weight, GAE.forward with an

@@ -1027,3 +1027,190 @@ def test_vgae_matches_oracle(dtype, tol, dev):
         opt.zero_grad(); l.backward(); opt.step()
         first = float(l.detach()) if first is None else first
     assert float(l.detach()) < first
+
+
+# ----------------------------------------------------------------- graph-level readout (README.md:54)
+def test_readout_golden_molecules(dev):
+    """mean | sum | max per molecule of the golden 8-molecule batch == the oracle, through readout_nodes(batch)"""
+    import gae_dgl_amd as G
+    parts = load_golden("mol8_parts"); whole = load_golden("mol8")
+    graphs = []
+    for i in range(int(parts["n_graphs"])):
+        g = G.DGLGraph((parts[f"g{i}/src"], parts[f"g{i}/dst"]), num_nodes=int(parts[f"g{i}/n"])).to(dev)
+        g.ndata['h'] = t(parts[f"g{i}/X"], dev)
+        graphs.append(g)
+    bg = G.batch(graphs)
+    gp = bg.graph_ptr().cpu().numpy()
+    assert gp[-1] == int(whole["n"]) and len(gp) == len(graphs) + 1
+    Z = t(whole["Z"], dev)
+    out = G.readout_nodes(bg, Z)
+    assert out.shape == (len(graphs), 3 * Z.shape[1])
+    assert rel_err(out, O().segment_readout(whole["Z"], gp)) < TOL
+    model = build_model(whole, dev)
+    bg.ndata['h'] = t(whole["X"], dev)
+    with torch.no_grad():
+        model(bg)                                   # GAE.forward leaves Z in ndata['h'] (gae.py:53)
+    assert rel_err(G.readout_nodes(bg), O().segment_readout(whole["Z"], gp)) < TOL
+
+
+@pytest.mark.parametrize("d", [1, 3, 16, 48, 64, 100])
+def test_readout_ragged(d, dev):
+    """ragged segments incl. empty graphs, single-node graphs and one long graph; deterministic"""
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(d)
+    sizes = np.concatenate([[0, 1, 1, 0, 700], rng.integers(0, 40, 300), [0]])
+    gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    Z = rng.standard_normal((int(gp[-1]), d)).astype(np.float32)
+    Zd = ops.pad_rows(t(Z, dev))
+    out = ops.segment_readout(Zd, t(gp, dev))
+    ref = O().segment_readout(Z, gp)
+    assert rel_err(out, ref) < TOL
+    assert float(out[0].abs().max()) == 0.0 and float(out[-1].abs().max()) == 0.0      # empty graphs
+    assert torch.equal(out[:, 2 * d:][1], Zd[0])                                        # max of a single node
+    assert torch.equal(out, ops.segment_readout(Zd, t(gp, dev)))
+
+
+# ----------------------------------------------------------------- ADVICE r01 items
+@pytest.mark.parametrize("n,d", [(300, 128), (257, 65), (130, 256)])
+def test_loss_wide_embedding_dense_chain(n, d, dev):
+    """embedding widths above the fused kernel's 64 columns (optuna_gae.py:29-34 samples hidden dims up to 256) take
+    the dense HIP chain (gae_decoder_dense -> gae_csr_to_dense -> gae_bce_logits -> gae_decoder_dense_bwd): loss and
+    gradient vs the fp64 oracle, in-kernel dropout draws included, and a full model step with hidden dims 256 128"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(n + d)
+    src, dst = rand_graph(rng, n, 5 * n, hub=True)
+    Z = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+    mask = ((rng.random((n, d)) >= 0.1) / 0.9).astype(np.float32)
+    adj = O().dense_adjacency(src, dst, n, dtype=torch.float64)
+    Zt = torch.tensor(Z, dtype=torch.float64, requires_grad=True)
+    ref = O().bce_with_logits_mean(O().decoder_logits(Zt, torch.tensor(mask, dtype=torch.float64)), adj,
+                                   O().pos_weight_of(adj))
+    ref.backward()
+    gr = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    Zd = t(Z, dev).requires_grad_(True)
+    loss = ops.decoder_bce(Zd, t(mask, dev), gr)
+    assert rel_err(loss, ref) < TOL
+    (2.0 * loss).backward()
+    assert rel_err(Zd.grad, 2.0 * Zt.grad) < 5 * TOL
+    with torch.no_grad():
+        assert rel_err(ops.decoder_bce(t(Z, dev), t(mask, dev), gr), ref) < TOL
+    # in-kernel dropout contract: the mask of this draw lands in the buffer, the device counter advances
+    draws = torch.zeros(1, dtype=torch.int64, device=dev)
+    mbuf = torch.empty(n, d, device=dev)
+    l2 = ops.decoder_bce(t(Z, dev).requires_grad_(True), mbuf, gr, dropout=(0.1, 7, 0, draws))
+    assert int(draws) == 1 and torch.equal(mbuf, ops.dropout_mask((n, d), 0.1, 7, device=dev))
+    assert torch.equal(l2.detach(), ops.decoder_bce(t(Z, dev), mbuf, gr).detach())
+    if d == 128:
+        torch.manual_seed(1)
+        model = G.GAE(39, [256, 128]).to(dev)          # the ADVICE example: --hidden_dims 256 128
+        gr.ndata['h'] = t((rng.random((n, 39)) < 0.2).astype(np.float32), dev)
+        lm = model.reconstruction_loss(gr)
+        ops.backward(lm)
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+
+
+def test_bce_logits_kernel(dev):
+    """gae_bce_logits == F.binary_cross_entropy_with_logits (train_inductive.py:48) with pos_weight, mean reduction,
+    and its gradient; ragged leading dimensions; deterministic"""
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(3)
+    n, m = 301, 517
+    x = rng.standard_normal((n, m)).astype(np.float32) * 4
+    y = ((rng.random((n, m)) < 0.02) * rng.integers(1, 3, (n, m))).astype(np.float32)   # labels 0 / 1 / 2 (duplicate edges)
+    pw = 37.5
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = O().bce_with_logits_mean(xt, torch.tensor(y, dtype=torch.float64), pw)
+    ref.backward()
+    xd = torch.zeros(n, m + 3, device=dev)[:, :m]; xd.copy_(t(x, dev))
+    loss, g = ops.bce_logits_raw(xd, t(y, dev), pw)
+    assert rel_err(loss.reshape(()), ref) < TOL and rel_err(g, xt.grad) < TOL
+    loss2, g2 = ops.bce_logits_raw(t(x, dev), t(y, dev), pw, want_grad=False)
+    assert g2 is None and torch.equal(loss2, loss)
+
+
+def test_dense_kernels_reject_other_dtypes(dev):
+    """fp32 kernels fed with fp64 / bf16 tensors raise instead of reinterpreting the memory"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops
+    from gae_dgl_amd._lib import GaeHipError
+    x = torch.randn(50, 8, device=dev); w = torch.randn(4, 8, device=dev); b = torch.randn(4, device=dev)
+    for bad in (lambda: ops.linear_fwd_raw(x.double(), w, b, 0), lambda: ops.linear_fwd_raw(x, w.bfloat16(), b, 0),
+                lambda: ops.linear_fwd_raw(x, w, b.double(), 0), lambda: ops.decoder_dense_raw(x.double()),
+                lambda: ops.linear_bwd_raw(torch.randn(50, 4, device=dev).double(), None, 0, x, w)):
+        with pytest.raises(GaeHipError):
+            bad()
+    g = G.DGLGraph((np.array([0, 1]), np.array([1, 0])), num_nodes=50).to(dev)
+    with pytest.raises(GaeHipError):
+        ops.decoder_bce(x.double(), None, g)
+    model = G.GAE(8, [4, 2]).to(dev).double()
+    g.ndata['h'] = x
+    with pytest.raises(GaeHipError):
+        model.encode(g)
+
+
+def test_dropout_draws_are_disjoint_streams(dev):
+    """the draw index selects a Philox stream of its own (high counter words): draw 1 over n elements is NOT the
+    continuation of draw 0 over a longer tensor (it was, when the draw index scaled the element counter)"""
+    from gae_dgl_amd import ops
+    n = 4096
+    one = torch.ones(1, dtype=torch.int64, device=dev)
+    m0_long = ops.dropout_mask((2 * n,), 0.5, seed=9, device=dev)
+    m1 = ops.dropout_mask((n,), 0.5, seed=9, device=dev, draw_counter=one)
+    assert not torch.equal(m1, m0_long[n:]) and not torch.equal(m1, m0_long[:n])
+    assert torch.equal(ops.dropout_mask((n,), 0.5, seed=9, device=dev), m0_long[:n])     # draw 0: prefix property
+    assert torch.equal(m1, ops.dropout_mask((n,), 0.5, seed=9, device=dev, draw_counter=one))
+    assert abs(float((m1 > 0).float().mean()) - 0.5) < 0.05
+
+
+def test_adam_state_dict_and_captured_lr_change(dev):
+    """optimizer.state_dict() has torch.optim.Adam's layout (checkpoints move between the two optimisers, steps
+    included); a learning-rate change after the capture reaches the replayed step"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd.optim import Adam
+    from gae_dgl_amd.capture import CapturedTrainStep
+    torch.manual_seed(0)
+    ps = [torch.randn(7, 5, device=dev, requires_grad=True), torch.randn(5, device=dev, requires_grad=True)]
+    qs = [p.detach().clone().requires_grad_(True) for p in ps]
+    a, b = Adam(ps, lr=1e-2), torch.optim.Adam(qs, lr=1e-2)
+    for k in range(3):
+        for p, q in zip(ps, qs):
+            gk = torch.randn_like(p); p.grad = gk.clone(); q.grad = gk.clone()
+        a.step(); b.step()
+    sd = a.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 3.0
+    assert "_hip_steps" not in sd["param_groups"][0]
+    rs = [p.detach().clone().requires_grad_(True) for p in ps]
+    import copy        # load_state_dict keeps same-device tensors by reference: copy, or the optimisers share moments
+    c = torch.optim.Adam(rs, lr=1e-2); c.load_state_dict(copy.deepcopy(sd))   # ours -> torch
+    us = [p.detach().clone().requires_grad_(True) for p in ps]
+    d = Adam(us, lr=1e-2); d.load_state_dict(copy.deepcopy(b.state_dict()))   # torch -> ours
+    for p, q, r, u in zip(ps, qs, rs, us):
+        gk = torch.randn_like(p)
+        for x in (p, q, r, u):
+            x.grad = gk.clone()
+    for o in (a, b, c, d):
+        o.step()
+    assert d.steps_taken() == 4
+    for p, q, r, u in zip(ps, qs, rs, us):
+        assert rel_err(p, q) < 2e-6 and rel_err(r, q) < 2e-6 and rel_err(u, q) < 2e-6
+    # captured step: lr is a launch argument -> the capture is redone when it changes
+    rng = np.random.default_rng(0)
+    n = 600
+    src, dst = rand_graph(rng, n, 3000)
+    g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    X = t(rng.standard_normal((n, 20)).astype(np.float32), dev)
+    torch.manual_seed(2)
+    model = G.GAE(20, [8, 4]).to(dev); model.decoder.dropout = 0.0
+    opt = Adam(model.parameters(), lr=1e-2)
+    step = CapturedTrainStep(model, opt, g, X)
+    step(); torch.cuda.synchronize()
+    w0 = model.layers[0].apply_mod.linear.weight.detach().clone()
+    for grp in opt.param_groups:
+        grp["lr"] = 0.0
+    step(); torch.cuda.synchronize()
+    assert torch.equal(model.layers[0].apply_mod.linear.weight.detach(), w0)       # lr = 0 took effect
+    for grp in opt.param_groups:
+        grp["lr"] = 1e-2
+    step(); torch.cuda.synchronize()
+    assert not torch.equal(model.layers[0].apply_mod.linear.weight.detach(), w0)

@@ -183,3 +183,20 @@ def test_bce_row_window_matches_dense_oracle():
         total += float(share)
         close(g, Zt.grad[r0:r1], 1e-10)
     assert abs(total - float(loss)) < 1e-12
+
+
+def test_segment_readout_on_golden_molecules():
+    """README.md:54 readout (mean | sum | max per molecule) on the 8-molecule golden batch: the oracle's loop equals
+    an independent torch restatement per member graph"""
+    parts = load_golden("mol8_parts")
+    whole = load_golden("mol8")
+    sizes = [int(parts[f"g{i}/n"]) for i in range(int(parts["n_graphs"]))]
+    gp = np.concatenate([[0], np.cumsum(sizes)])
+    Z = whole["Z"]
+    got = O.segment_readout(Z, gp)
+    assert got.shape == (len(sizes), 3 * Z.shape[1])
+    for g, zs in enumerate(torch.split(torch.tensor(Z, dtype=torch.float64), sizes)):
+        ref = torch.cat([zs.mean(0), zs.sum(0), zs.max(0).values]).numpy()
+        np.testing.assert_allclose(got[g], ref, rtol=1e-12, atol=1e-12)
+    empty = O.segment_readout(Z, np.array([0, 0, len(Z)]))
+    assert (empty[0] == 0).all() and np.allclose(empty[1, :Z.shape[1]], Z.mean(0))
