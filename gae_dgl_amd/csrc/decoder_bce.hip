@@ -48,13 +48,13 @@ constexpr int TJ = 64;   // columns staged per iteration
 constexpr int PREP_ROWS = 64;    // rows per block of the prepare kernel
 // tuning knobs (gae_tuning_set): "bce_ri" 16-row subtiles per wave (rows / block = 64 RI), "bce_minw" min
 // waves per SIMD hint, "bce_s_bf16" 1 = bf16x3 S product, 0 = exact fp32 S product
-int g_bce_ri = 2;
-int g_bce_minw = 0;
-int g_bce_s_bf16 = 1;
-int g_bce_sym_grid = 16384;  // "bce_sym_grid": target size of the (panel, chunk) grid of the symmetric kernel
+thread_local int g_bce_ri = 2;
+thread_local int g_bce_minw = 0;
+thread_local int g_bce_s_bf16 = 1;
+thread_local int g_bce_sym_grid = 16384;  // "bce_sym_grid": target size of the (panel, chunk) grid of the symmetric kernel
                              // (many short blocks even out the triangular work: ZINC batch 3.64 -> 3.35 ms)
-int g_bce_sym = 1;       // "bce_sym": 1 = symmetric dense kernel for full-square launches with d <= 16
-int g_bce_pv_bf16 = 1;   // "bce_pv_bf16": 1 = bf16x3 for O' += P V as well (P split on the fly), 0 = exact fp32
+thread_local int g_bce_sym = 1;       // "bce_sym": 1 = symmetric dense kernel for full-square launches with d <= 16
+thread_local int g_bce_pv_bf16 = 1;   // "bce_pv_bf16": 1 = bf16x3 for O' += P V as well (P split on the fly), 0 = exact fp32
 
 __device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
 {
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
 // rows per panel = 64 RI (4 waves x RI subtiles of 16 rows); "bce_sym_ri" = 0 (auto) | 2 | 4.  Taller panels halve
 // the mirror strips (N^2 / 8 bytes) at the price of registers (2 waves per SIMD): they pay from ~32 k rows on
 // (ZINC batch of 95 k rows: 3.38 -> 3.13 ms; Pubmed, 20 k rows: 206 -> 212 us)
-int g_bce_sym_ri = 0;
+thread_local int g_bce_sym_ri = 0;
 
 // the upper 16 bits of four fp32 values (exact when they are bf16 values): one v_perm_b32 per pair
 __device__ __forceinline__ s16x4 upper_halves(const f32x4 &d)

@@ -21,13 +21,13 @@ using gae::kWave;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
-int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
-int g_linear_wlds = 1;  // tuning knob: 0 = never use linear_fwd_wlds_kernel, 1 = where measured faster, 2 = wherever it applies
-int g_linear_bf16 = 0;  // tuning knob: 0 = exact fp32 forward Linear (default: embeddings within 2e-7 of fp64 instead of
+thread_local int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
+thread_local int g_linear_wlds = 1;  // tuning knob: 0 = never use linear_fwd_wlds_kernel, 1 = where measured faster, 2 = wherever it applies
+thread_local int g_linear_bf16 = 0;  // tuning knob: 0 = exact fp32 forward Linear (default: embeddings within 2e-7 of fp64 instead of
                         // 7e-6, tools/encode_error.py), 1 = bf16 x 3 forward where measured faster (Pubmed L1 15.4 -> 13.0 us),
                         // 2 = wherever it applies
-int g_atb_bf16 = 1;     // tuning knob: 1 = bf16 x 3 matrix-core products in the dW kernel where the layout allows
-int g_atb_rows = 0;     // tuning knob: rows per block (= per partial) of the dW kernel; 0 = auto (atb_plan)
+thread_local int g_atb_bf16 = 1;     // tuning knob: 1 = bf16 x 3 matrix-core products in the dW kernel where the layout allows
+thread_local int g_atb_rows = 0;     // tuning knob: rows per block (= per partial) of the dW kernel; 0 = auto (atb_plan)
 
 // ---------------------------------------------------------------------------
 // out[n, J] = epi( proA(A)[n, K] * proB(B) )      B given as [J, K] (BT) or [K, J]

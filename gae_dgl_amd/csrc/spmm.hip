@@ -446,11 +446,11 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const int32_t *__restric
 }
 
 // tuning knobs (gae_tuning_set): read-mostly process-wide integers
-int g_spmm_variant = 2;   // 1 = v1 rowgroup, 2 = v2 rowgroup2
-int g_spmm_rpg = 0;       // rows per lane group (v2): 0 = auto (2 for launches of >= 32768 waves, else 1), 1, 2
-int g_spmm_nt = 1;        // store policy of M (v2): -1 = auto, 0 plain, 1 non-temporal, 2 write-through sc1
-int g_spmm_tile_vecs = 0; // 16-byte vectors per XCD feature tile: 0 = auto when GAE_SPMM_TILE is set, -1 = never, > 0 = forced
-int g_spmm_ell = 1;       // the plan's packed neighbour table: 0 = ignore it, 1 = spmm_ell.hip kernels (row-group
+thread_local int g_spmm_variant = 2;   // 1 = v1 rowgroup, 2 = v2 rowgroup2
+thread_local int g_spmm_rpg = 0;       // rows per lane group (v2): 0 = auto (2 for launches of >= 32768 waves, else 1), 1, 2
+thread_local int g_spmm_nt = 1;        // store policy of M (v2): -1 = auto, 0 plain, 1 non-temporal, 2 write-through sc1
+thread_local int g_spmm_tile_vecs = 0; // 16-byte vectors per XCD feature tile: 0 = auto when GAE_SPMM_TILE is set, -1 = never, > 0 = forced
+thread_local int g_spmm_ell = 1;       // the plan's packed neighbour table: 0 = ignore it, 1 = spmm_ell.hip kernels (row-group
                           // kernel when they cannot run the launch), 2 = row-group kernel only
 
 constexpr int kEllWidth = 16;
@@ -624,6 +624,7 @@ __global__ __launch_bounds__(256) void spmm_blockdiag_kernel(
     const int r0 = block_ptr[blockIdx.x], r1 = block_ptr[blockIdx.x + 1];
     const int32_t e0 = block_eptr[blockIdx.x], e1 = block_eptr[blockIdx.x + 1];
     const int nr = r1 - r0;
+    if (nr <= 0) return;          // empty run (block-uniform): nothing to stage, nothing to write
     const int ne = min(e1 - e0, max_edges);
     // ---- one bulk round trip: H slice (contiguous nr * ldh floats), row pointers, neighbour ids (as LOCAL row
     //      offsets).  Every load is issued (branch-free, clamped index) into registers BEFORE the first LDS
@@ -1050,8 +1051,16 @@ extern "C" int gae_spmm_csr_blockdiag(const int32_t *indptr, const int32_t *indi
                 "gae_spmm_csr_blockdiag: a block may hold at most 511 rows / 64 KiB of H / 1024 staged edges");
 #define GAE_BDL(LPR, SC, TI)                                                                                          \
     do {                                                                                                               \
-        GAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_blockdiag_kernel<LPR, SC, TI>),               \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));                            \
+        /* the attribute is per kernel and device: set it once per (instantiation, device), and again only when a   \
+         * launch asks for more LDS than any before (host microseconds on a launch-bound path otherwise) */          \
+        static int configured[16] = {0};                                                                               \
+        int dev_ = 0;                                                                                                  \
+        GAE_HIP(hipGetDevice(&dev_));                                                                                  \
+        if (dev_ < 0 || dev_ >= 16 || configured[dev_] < int(lds)) {                                                   \
+            GAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_blockdiag_kernel<LPR, SC, TI>),           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));                        \
+            if (dev_ >= 0 && dev_ < 16) configured[dev_] = int(lds);                                                   \
+        }                                                                                                              \
         hipLaunchKernelGGL((spmm_blockdiag_kernel<LPR, SC, TI>), dim3(unsigned(n_blocks)), dim3(256), size_t(lds), s,  \
                            indptr, indices, block_ptr, block_eptr, H, ldh, M, ldm, int(F), row_scale, col_scale,       \
                            int(max_block_rows), int(max_block_edges), store_pad);                                      \

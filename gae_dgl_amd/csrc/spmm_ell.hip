@@ -117,7 +117,7 @@ struct Vec16<unsigned short> {   // bf16 storage, fp32 accumulation
 
 }  // namespace
 namespace gae {
-int g_spmm_ell_rpg = 0;      // rows per lane group of the ell kernels: 0 = auto (1)
+thread_local int g_spmm_ell_rpg = 0;      // rows per lane group of the ell kernels: 0 = auto (1)
 }
 namespace {
 

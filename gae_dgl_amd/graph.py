@@ -20,6 +20,15 @@ from . import function as fn
 from ._lib import GaeHipError
 
 
+# update_all on a graph WITHOUT ANY edge.  DGL 0.4 -- the API era of the reference: set_n_initializer /
+# zero_initializer (train_inductive.py:93-94) exist only there -- short-cuts such a call in its scheduler
+# (schedule_update_all: "all the nodes are zero degree; downgrade to apply nodes") and leaves the reduce output field
+# untouched: gae.py:27-29 then feeds the layer INPUT to the Linear.  "dgl04" reproduces that (drop-in with the
+# reference's DGL); "zeros" gives the mathematical aggregate A H = 0 (what DGL >= 0.5 and the raw SpMM kernel give).
+# Graphs with at least one edge are unaffected: their zero-in-degree rows aggregate to 0 either way.
+ZERO_EDGE_UPDATE_ALL = "dgl04"
+
+
 class NodeBatch:
     """what DGL hands to an apply_nodes UDF: ``nodes.data`` is the ndata frame"""
 
@@ -239,6 +248,9 @@ class Graph:
         mode = self.norm_mode if norm is None else norm
         if mode not in ("none", "both"):
             raise ValueError(f"norm must be 'none' or 'both', got {mode!r}")
+        if self.number_of_edges() == 0 and ZERO_EDGE_UPDATE_ALL == "dgl04":
+            self.ndata.setdefault(reduce_func.out, h)     # DGL 0.4 leaves the frame as it is (see the note above)
+            return
         self.ndata[reduce_func.out] = ops.spmm(self, h, use_norm=(mode == "both"))
 
     def apply_nodes(self, func):

@@ -59,8 +59,14 @@ typedef struct gae_device_info {
 int gae_version(void);
 const char *gae_last_error(void);
 int gae_device_info_get(int device, gae_device_info *out_host);
-/* performance-tuning knobs (process-wide integers; results never depend on them):
- * "spmm_variant" (1|2), "spmm_rpg" (rows per lane group), "spmm_nt" (non-temporal stores) */
+/* Tuning / test knobs: integers local to the CALLING THREAD (thread_local; the launches of a thread see what that
+ * thread set, other threads keep the defaults -- no process-wide mutable state).  Most select among kernels that give
+ * bit-identical results ("spmm_variant", "spmm_rpg", "spmm_nt", "spmm_tile_vecs", "spmm_ell", "spmm_ell_rpg",
+ * "gemm_stream", "linear_wlds", "atb_rows", "bce_ri", "bce_minw", "bce_sym", "bce_sym_ri", "bce_sym_grid"); four
+ * select the ARITHMETIC of matrix-core products and change rounding within the documented tolerances:
+ * "bce_s_bf16" / "bce_pv_bf16" / "atb_bf16" (1 = bf16 x 3 split products, default; 0 = exact fp32 MFMA) and
+ * "linear_bf16" (default 0 = exact fp32 forward Linear).  A skew plan (gae_spmm_plan with heavy rows) also changes
+ * the summation order of the heavy rows. */
 int gae_tuning_set(const char *name, int64_t value);
 
 /* ---- graph structure -------------------------------------------------------

@@ -1214,3 +1214,85 @@ def test_adam_state_dict_and_captured_lr_change(dev):
         grp["lr"] = 1e-2
     step(); torch.cuda.synchronize()
     assert not torch.equal(model.layers[0].apply_mod.linear.weight.detach(), w0)
+
+
+# ----------------------------------------------------------------- semantics decisions / opt-in layer options
+def test_update_all_on_edgeless_graph(dev):
+    """DGL 0.4 (the reference's API era) short-cuts update_all on a graph without any edge and leaves 'h' = the
+    layer input (default here: drop-in); "zeros" is the mathematical aggregate, which is also what the raw SpMM
+    kernel returns.  Graphs with edges: zero-in-degree rows aggregate to 0 in both modes."""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import graph as gmod
+    n = 9
+    X = torch.randn(n, 5, device=dev)
+    torch.manual_seed(0)
+    layer = G.GCN(5, 3, torch.relu).to(dev)
+    W, b = layer.apply_mod.linear.weight, layer.apply_mod.linear.bias
+    empty = G.DGLGraph((np.zeros(0, np.int64), np.zeros(0, np.int64)), num_nodes=n).to(dev)
+    assert gmod.ZERO_EDGE_UPDATE_ALL == "dgl04"
+    with torch.no_grad():
+        out = layer(empty, X)
+        assert rel_err(out, torch.relu(X @ W.t() + b)) < TOL and 'h' not in empty.ndata
+        gmod.ZERO_EDGE_UPDATE_ALL = "zeros"
+        try:
+            assert rel_err(layer(empty, X), torch.relu(b).expand(n, 3)) < TOL
+        finally:
+            gmod.ZERO_EDGE_UPDATE_ALL = "dgl04"
+        one = G.DGLGraph((np.array([0]), np.array([1])), num_nodes=n).to(dev)        # a single edge 0 -> 1
+        ref = torch.zeros(n, 5, device=dev); ref[1] = X[0]
+        assert rel_err(layer(one, X), torch.relu(ref @ W.t() + b)) < TOL
+
+
+@pytest.mark.parametrize("name", ["sym200", "deep3"])
+def test_transform_first_option(name, dev):
+    """opt-in A (H W^T) order of the narrowing layers: embeddings, loss and parameter gradients within the fp32
+    tolerance of the reference-order goldens; state-dict keys unchanged"""
+    import gae_dgl_amd as G
+    g = load_golden(name)
+    model = G.GAE(g["X"].shape[1], [int(v) for v in g["hidden"]], transform_first=True)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")}
+    assert sorted(model.state_dict()) == sorted(sd)                 # the option adds no checkpoint keys
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    assert any(l.transform_first for l in model.layers)          # only layers that narrow the features reorder
+    model.decoder.dropout = 0.0
+    gr = fresh_graph(g, dev)
+    loss = model.reconstruction_loss(gr)
+    assert rel_err(gr.ndata['h'], g["Z"]) < TOL and rel_err(loss, g["loss_p0"]) < TOL
+    loss.backward()
+    for k, p in model.named_parameters():
+        assert rel_err(p.grad, g[f"grad_p0/{k}"]) < 5 * TOL, k
+
+
+def test_cache_first_aggregate_option(dev):
+    """opt-in reuse of A X across steps (the transductive loop aggregates the same features every epoch): identical
+    results, the layer-1 SpMM runs once, an in-place change of X invalidates the cache"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(4)
+    n = 500
+    src, dst = rand_graph(rng, n, 2500)
+    X = t(rng.standard_normal((n, 70)).astype(np.float32), dev)
+    torch.manual_seed(3)
+    plain = G.GAE(70, [16, 8]).to(dev)
+    torch.manual_seed(3)
+    cached = G.GAE(70, [16, 8], cache_first_aggregate=True).to(dev)
+    g1 = G.DGLGraph((src, dst), num_nodes=n).to(dev); g2 = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    for m in (plain, cached):
+        m.decoder.dropout = 0.0
+    prof = ops.EventProfiler(); ops.profiler = prof
+    try:
+        for step in range(3):
+            g1.ndata['h'] = X; g2.ndata['h'] = X
+            la, lb = plain.reconstruction_loss(g1), cached.reconstruction_loss(g2)
+            assert torch.equal(la.detach(), lb.detach())
+            la.backward(); lb.backward()
+        wide = [k for k in prof.records if k[0] == "spmm" and k[3] == 70]
+        assert sum(len(prof.records[k]) for k in wide) == 3 + 1                 # plain: every step, cached: once
+        for pa, pb in zip(plain.parameters(), cached.parameters()):
+            assert torch.equal(pa.grad, pb.grad)
+        X.mul_(2.0)                                                             # version bump -> recompute
+        g1.ndata['h'] = X; g2.ndata['h'] = X
+        assert torch.equal(plain.reconstruction_loss(g1).detach(), cached.reconstruction_loss(g2).detach())
+    finally:
+        ops.profiler = None
