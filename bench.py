@@ -233,6 +233,7 @@ class ZincWorkload:
         self.opt, opt_name = make_adam(self.model.parameters(), 1e-3, args)   # train_inductive.py:25
         self.rng = np.random.default_rng(0)
         self.perm = self.rng.permutation(n_graphs)
+        self.d_perm = torch.from_numpy(self.perm).to(dev)      # the epoch order lives on the device (ds.epoch())
         self.cursor = 0
         nb = int(self.ds.sizes_host[:B].sum()); eb = int(self.ds.edges_host[:B].sum())
         self.edges_per_step = 3 * eb                                          # nominal (batch 0); varies < 1 % per batch
@@ -257,8 +258,9 @@ class ZincWorkload:
 
     def step(self):
         ids = self.perm[self.cursor:self.cursor + self.B]
+        self._lo = self.cursor
         self.cursor = (self.cursor + self.B) % (len(self.perm) - self.B)
-        bg = self.ds.batch(ids)                                               # dgl.batch on the device (K10)
+        bg = self.ds._assemble(self.d_perm[self._lo:self._lo + self.B], ids)   # dgl.batch on the device (K10), no H2D
         loss = self.model.reconstruction_loss(bg)
         from gae_dgl_amd import ops
         self.opt.zero_grad(); ops.backward(loss); self.opt.step()

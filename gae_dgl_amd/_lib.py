@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgae_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, U8 = 0, 1, 2
 SPMM_STORE_PAD = 1
 SPMM_TILE = 2
 SPMM_ELL_WIDTH = 16
@@ -46,8 +46,9 @@ SIGNATURES = {
     "gae_csr_from_coo": (_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _i64, _p, _p]),
     "gae_degree_norm": (_int, [_p, _i64, _p, _p, _p]),
     "gae_csr_to_dense": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
+    "gae_batch_plan": (_int, [_p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "gae_batch_gather": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _p, _i64, _i64,
-                                _p, _p, _p, _i64, _p]),
+                                _p, _p, _p, _i64, _p, _i32, _p]),
     "gae_bce_logits_workspace_bytes": (_i64, []),
     "gae_bce_logits": (_int, [_p, _i64, _p, _i64, _i64, _i64, _f, _p, _p, _i64, _p, _i64, _p]),
     "gae_segment_readout": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),

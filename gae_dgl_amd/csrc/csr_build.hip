@@ -97,15 +97,86 @@ __global__ __launch_bounds__(256) void csr_to_dense_kernel(const int32_t *__rest
             atomicAdd(&out[r * ld + indices[e]], 1.0f);
 }
 
-// One wave per selected graph: rebase its indptr slice, its column ids and copy
-// its feature rows into the batch (block-diagonal) arrays.
-template <typename T>
+// Exclusive prefix sums of the selected graphs' node / edge counts ON THE DEVICE (the batch plan of dgl.batch,
+// train_inductive.py:34: "node ids offset by the prefix sum of node counts").  One block; the scan runs in chunks of
+// 1024 graphs with a carried total.  t_indptr may be NULL (symmetric dataset: the transposed structure is the same).
+__global__ __launch_bounds__(1024) void batch_plan_kernel(const int64_t *__restrict__ graph_ptr,
+                                                          const int32_t *__restrict__ indptr,
+                                                          const int32_t *__restrict__ t_indptr,
+                                                          const int64_t *__restrict__ graph_ids, int64_t n_graphs,
+                                                          int64_t *__restrict__ node_ptr, int64_t *__restrict__ edge_ptr,
+                                                          int64_t *__restrict__ t_edge_ptr)
+{
+    __shared__ long long wsum[3][16];
+    __shared__ long long carry[3];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 3) carry[tid] = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_graphs; base += 1024) {
+        const int64_t b = base + tid;
+        long long v[3] = {0, 0, 0};
+        if (b < n_graphs) {
+            const int64_t g = graph_ids[b];
+            const int64_t n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
+            v[0] = n1 - n0;
+            v[1] = (long long)indptr[n1] - indptr[n0];
+            v[2] = t_indptr ? (long long)t_indptr[n1] - t_indptr[n0] : v[1];
+        }
+        long long inc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            long long x = v[q];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const long long y = __shfl_up(x, off, 64);
+                if (lane >= off) x += y;
+            }
+            inc[q] = x;
+            if (lane == 63) wsum[q][wv] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            long long pre = carry[q];
+            for (int w2 = 0; w2 < wv; ++w2) pre += wsum[q][w2];
+            inc[q] += pre;                                   // inclusive sum up to this graph
+        }
+        if (b < n_graphs) {
+            node_ptr[b] = inc[0] - v[0];
+            edge_ptr[b] = inc[1] - v[1];
+            if (t_edge_ptr) t_edge_ptr[b] = inc[2] - v[2];
+            if (b == n_graphs - 1) {
+                node_ptr[n_graphs] = inc[0];
+                edge_ptr[n_graphs] = inc[1];
+                if (t_edge_ptr) t_edge_ptr[n_graphs] = inc[2];
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) carry[q] = inc[q];
+        }
+        __syncthreads();
+    }
+}
+
+template <typename TI, typename TO>
+__device__ __forceinline__ TO feat_convert(TI v);
+template <> __device__ __forceinline__ float feat_convert<float, float>(float v) { return v; }
+template <> __device__ __forceinline__ unsigned short feat_convert<unsigned short, unsigned short>(unsigned short v) { return v; }
+template <> __device__ __forceinline__ float feat_convert<unsigned char, float>(unsigned char v) { return float(v); }
+
+// One wave per selected graph: rebase its indptr slice, its column ids and copy (uint8 -> fp32: expand) its feature
+// rows into the batch (block-diagonal) arrays; optionally write the packed neighbour table of the batch CSR
+// (gae_spmm_ell_build's format) in the same pass -- the batch's SpMM launches then start with one table load.
+template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void batch_gather_kernel(
     const int64_t *__restrict__ graph_ptr, const int32_t *__restrict__ ds_indptr,
-    const int32_t *__restrict__ ds_indices, const T *__restrict__ ds_feat, int64_t ld_feat, int64_t F,
+    const int32_t *__restrict__ ds_indices, const TI *__restrict__ ds_feat, int64_t ld_feat, int64_t F,
     const int64_t *__restrict__ graph_ids, int64_t n_graphs, const int64_t *__restrict__ out_node_ptr,
     const int64_t *__restrict__ out_edge_ptr, int32_t *__restrict__ out_indptr,
-    int32_t *__restrict__ out_indices, T *__restrict__ out_feat, int64_t ld_out)
+    int32_t *__restrict__ out_indices, TO *__restrict__ out_feat, int64_t ld_out, int32_t *__restrict__ out_ell,
+    int ell_width)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t b = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
@@ -121,10 +192,24 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
     const int64_t shift = on - n0;
     for (int32_t e = e0 + lane; e < e1; e += kWave)
         out_indices[oe + (e - e0)] = int32_t(ds_indices[e] + shift);
-    const int64_t total = nn * F;
-    for (int64_t i = lane; i < total; i += kWave) {
-        const int64_t r = i / F, c = i - r * F;
-        out_feat[(on + r) * ld_out + c] = ds_feat[(n0 + r) * ld_feat + c];
+    if (out_ell) {
+        const int W = ell_width;
+        for (int64_t idx = lane; idx < nn * W; idx += kWave) {
+            const int64_t i = idx / W;
+            const int k = int(idx - i * W);
+            const int32_t p = ds_indptr[n0 + i], deg = ds_indptr[n0 + i + 1] - p;
+            int32_t v;
+            if (deg > W && k == W - 1) v = -2;                    // row continues in the CSR arrays
+            else v = k < deg ? int32_t(ds_indices[p + k] + shift) : -1;
+            out_ell[(on + i) * W + k] = v;
+        }
+    }
+    if (out_feat) {                        // whole output rows: the pad columns [F, ld_out) are written as zeros
+        const int64_t total = nn * ld_out;
+        for (int64_t i = lane; i < total; i += kWave) {
+            const int64_t r = i / ld_out, c = i - r * ld_out;
+            out_feat[(on + r) * ld_out + c] = c < F ? feat_convert<TI, TO>(ds_feat[(n0 + r) * ld_feat + c]) : TO(0);
+        }
     }
 }
 
@@ -224,18 +309,41 @@ extern "C" int gae_csr_to_dense(const int32_t *indptr, const int32_t *indices, i
     return GAE_OK;
 }
 
+extern "C" int gae_batch_plan(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
+                              const int64_t *graph_ids, int64_t n_graphs, int64_t *out_node_ptr,
+                              int64_t *out_edge_ptr, int64_t *out_t_edge_ptr, void *stream)
+{
+    GAE_REQUIRE(n_graphs >= 0, GAE_E_SIZE, "gae_batch_plan: negative n_graphs");
+    GAE_REQUIRE(out_node_ptr && out_edge_ptr, GAE_E_NULL, "gae_batch_plan: NULL output");
+    hipStream_t s = gae::as_stream(stream);
+    if (n_graphs == 0) {
+        GAE_HIP(hipMemsetAsync(out_node_ptr, 0, sizeof(int64_t), s));
+        GAE_HIP(hipMemsetAsync(out_edge_ptr, 0, sizeof(int64_t), s));
+        if (out_t_edge_ptr) GAE_HIP(hipMemsetAsync(out_t_edge_ptr, 0, sizeof(int64_t), s));
+        return GAE_OK;
+    }
+    GAE_REQUIRE(graph_ptr && ds_indptr && graph_ids, GAE_E_NULL, "gae_batch_plan: NULL pointer");
+    hipLaunchKernelGGL(batch_plan_kernel, dim3(1), dim3(1024), 0, s, graph_ptr, ds_indptr, ds_t_indptr, graph_ids,
+                       n_graphs, out_node_ptr, out_edge_ptr, out_t_edge_ptr);
+    GAE_CHECK_LAUNCH("batch_plan_kernel");
+    return GAE_OK;
+}
+
 extern "C" int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_indices,
                                 const void *ds_feat, int64_t ld_feat, int64_t F, int dtype,
                                 const int64_t *graph_ids, int64_t n_graphs, const int64_t *out_node_ptr,
                                 const int64_t *out_edge_ptr, int64_t n_batch_nodes, int64_t n_batch_edges,
                                 int32_t *out_indptr, int32_t *out_indices, void *out_feat, int64_t ld_out,
-                                void *stream)
+                                int32_t *out_ell, int32_t ell_width, void *stream)
 {
     GAE_REQUIRE(n_graphs >= 0 && F >= 0 && n_batch_nodes >= 0 && n_batch_edges >= 0, GAE_E_SIZE,
                 "gae_batch_gather: negative size");
     GAE_REQUIRE(ld_feat >= F && ld_out >= F, GAE_E_SIZE, "gae_batch_gather: leading dimension < F");
-    GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16, GAE_E_DTYPE, "gae_batch_gather: dtype %d", dtype);
+    GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16 || dtype == GAE_U8, GAE_E_DTYPE, "gae_batch_gather: dtype %d",
+                dtype);
     GAE_REQUIRE(out_indptr != nullptr, GAE_E_NULL, "gae_batch_gather: out_indptr is NULL");
+    GAE_REQUIRE(!out_ell || ell_width == 4 || ell_width == 8 || ell_width == GAE_SPMM_ELL_WIDTH, GAE_E_RANGE,
+                "gae_batch_gather: ell_width must be 4, 8 or %d", GAE_SPMM_ELL_WIDTH);
     hipStream_t s = gae::as_stream(stream);
     if (n_graphs == 0) {
         GAE_HIP(hipMemsetAsync(out_indptr, 0, sizeof(int32_t), s));
@@ -245,19 +353,18 @@ extern "C" int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indp
                 "gae_batch_gather: NULL pointer");
     GAE_REQUIRE(n_batch_edges == 0 || (ds_indices && out_indices), GAE_E_NULL,
                 "gae_batch_gather: NULL index pointer");
-    GAE_REQUIRE(F == 0 || n_batch_nodes == 0 || (ds_feat && out_feat), GAE_E_NULL,
+    GAE_REQUIRE(F == 0 || n_batch_nodes == 0 || !out_feat || ds_feat, GAE_E_NULL,
                 "gae_batch_gather: NULL feature pointer");
     const int64_t blocks = (n_graphs * kWave + 255) / 256;
-    if (dtype == GAE_F32)
-        hipLaunchKernelGGL(batch_gather_kernel<float>, dim3(unsigned(blocks)), dim3(256), 0, s, graph_ptr,
-                           ds_indptr, ds_indices, static_cast<const float *>(ds_feat), ld_feat, F, graph_ids,
-                           n_graphs, out_node_ptr, out_edge_ptr, out_indptr, out_indices,
-                           static_cast<float *>(out_feat), ld_out);
-    else
-        hipLaunchKernelGGL(batch_gather_kernel<unsigned short>, dim3(unsigned(blocks)), dim3(256), 0, s,
-                           graph_ptr, ds_indptr, ds_indices, static_cast<const unsigned short *>(ds_feat),
-                           ld_feat, F, graph_ids, n_graphs, out_node_ptr, out_edge_ptr, out_indptr, out_indices,
-                           static_cast<unsigned short *>(out_feat), ld_out);
+#define GAE_BG(TI, TO)                                                                                              \
+    hipLaunchKernelGGL((batch_gather_kernel<TI, TO>), dim3(unsigned(blocks)), dim3(256), 0, s, graph_ptr, ds_indptr,  \
+                       ds_indices, static_cast<const TI *>(ds_feat), ld_feat, F, graph_ids, n_graphs, out_node_ptr,  \
+                       out_edge_ptr, out_indptr, out_indices, static_cast<TO *>(out_feat), ld_out, out_ell,          \
+                       int(ell_width))
+    if (dtype == GAE_F32) GAE_BG(float, float);
+    else if (dtype == GAE_BF16) GAE_BG(unsigned short, unsigned short);
+    else GAE_BG(unsigned char, float);
+#undef GAE_BG
     GAE_CHECK_LAUNCH("batch_gather_kernel");
     return GAE_OK;
 }

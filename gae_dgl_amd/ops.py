@@ -172,20 +172,46 @@ def csr_to_dense(indptr, indices, n_rows, n_cols):
     return out
 
 
-def batch_gather(graph_ptr, ds_indptr, ds_indices, ds_feat, graph_ids, node_ptr, edge_ptr, n_nodes, n_edges):
-    feat, ldf = _rowmajor(ds_feat, "ds_feat")
-    F = feat.shape[1]
-    dev = feat.device
+def batch_plan(graph_ptr, ds_indptr, ds_t_indptr, graph_ids):
+    """exclusive prefix sums of the selected graphs' node / edge / transposed-edge counts, computed on the device
+    (gae_batch_plan): (node_ptr, edge_ptr, t_edge_ptr or None), int64 [B + 1] each.  ``ds_t_indptr`` None = the
+    dataset is symmetric."""
+    gids = _gpu(graph_ids, "graph_ids")
+    B = gids.numel()
+    dev = gids.device
+    buf = torch.empty(3 if ds_t_indptr is not None else 2, B + 1, dtype=torch.int64, device=dev)
+    with _on_device(dev):
+        _lib.call("gae_batch_plan", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_t_indptr), _ptr(gids), B, _ptr(buf[0]),
+                  _ptr(buf[1]), _ptr(buf[2]) if ds_t_indptr is not None else None, _stream())
+    return buf[0], buf[1], (buf[2] if ds_t_indptr is not None else None)
+
+
+def batch_gather(graph_ptr, ds_indptr, ds_indices, ds_feat, graph_ids, node_ptr, edge_ptr, n_nodes, n_edges,
+                 ell_width=0, n_feat=None):
+    """dgl.batch of the graphs ``graph_ids`` of a device-resident dataset (gae_batch_gather): returns
+    (indptr, indices, feat or None, packed table or None).  ``ds_feat`` None = structure only; uint8 features come
+    back as fp32; ``n_feat`` = number of feature columns when ``ds_feat`` carries pad columns."""
+    dev = ds_indptr.device
     out_indptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
     out_indices = torch.empty(n_edges, dtype=torch.int32, device=dev)
-    q = 4 if feat.dtype == torch.float32 else 8
-    ldo = max((F + q - 1) // q * q, 1)                      # batch features keep 16-byte rows
-    out_feat = torch.empty(n_nodes, ldo, dtype=feat.dtype, device=dev)[:, :F]
+    table = torch.empty(n_nodes * ell_width, dtype=torch.int32, device=dev) if ell_width else None
+    feat = out_feat = None
+    ldf = F = ldo = 0
+    code = F32
+    if ds_feat is not None:
+        feat, ldf = _rowmajor(ds_feat, "ds_feat")
+        F = feat.shape[1] if n_feat is None else int(n_feat)
+        code = _lib.U8 if feat.dtype == torch.uint8 else _dtype_code(feat)
+        odt = torch.float32 if feat.dtype == torch.uint8 else feat.dtype
+        q = 4 if odt == torch.float32 else 8
+        ldo = max((F + q - 1) // q * q, 1)                      # batch features keep 16-byte rows
+        out_feat = torch.empty(n_nodes, ldo, dtype=odt, device=dev)       # pad columns are zeroed by the kernel
     with _on_device(dev):
-        _lib.call("gae_batch_gather", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_indices), _ptr(feat), ldf, F,
-                  _dtype_code(feat), _ptr(graph_ids), graph_ids.numel(), _ptr(node_ptr), _ptr(edge_ptr),
-                  n_nodes, n_edges, _ptr(out_indptr), _ptr(out_indices), _ptr(out_feat), ldo, _stream())
-    return out_indptr, out_indices, out_feat
+        _lib.call("gae_batch_gather", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_indices), _ptr(feat), max(ldf, F), F,
+                  code, _ptr(graph_ids), graph_ids.numel(), _ptr(node_ptr), _ptr(edge_ptr),
+                  n_nodes, n_edges, _ptr(out_indptr), _ptr(out_indices), _ptr(out_feat), max(ldo, F), _ptr(table),
+                  int(ell_width), _stream())
+    return out_indptr, out_indices, (out_feat[:, :F] if out_feat is not None else None), table
 
 
 def segment_readout(Z, graph_ptr):
@@ -257,6 +283,11 @@ def ell_width_for(max_deg):
     """narrowest packed-table width (4, 8 or 16 slots) that holds every row of a graph whose longest (light) row
     has ``max_deg`` edges; rows longer than 16 continue from the CSR arrays"""
     return 4 if max_deg <= 4 else 8 if max_deg <= 8 else _lib.SPMM_ELL_WIDTH
+
+
+def table_plan(table, ell_width):
+    """plan that only carries an already-built packed neighbour table (no heavy rows)"""
+    return SpmmPlan(SKEW_THRESHOLD, SKEW_SEGMENT, 0, 0, None, None, None, table, ell_width)
 
 
 def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_width=None):

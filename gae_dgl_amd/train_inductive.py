@@ -50,6 +50,9 @@ def build_parser():
     ap.add_argument("--loss", choices=["fused", "dense"], default="fused")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no_plot", action="store_true")
+    ap.add_argument("--dataloader", action="store_true",
+                    help="batch through torch's DataLoader + collate exactly like the reference (one small pinned "
+                         "copy of the graph ids per batch) instead of the device-resident epoch iterator")
     return ap
 
 
@@ -151,8 +154,11 @@ def main(argv=None):
     n_val = args.val_size if len(graphs) > args.val_size else min(args.val_size, max(1, len(graphs) // 10))
     loaders = {}
     for split, ids, shuffle in (("train", order[n_val:], True), ("val", order[:n_val], False)):
-        loaders[split] = DataLoader(graphs.subset(graphs.ids[ids]), batch_size=args.batch_size, shuffle=shuffle,
-                                    collate_fn=collate)
+        part = graphs.subset(graphs.ids[ids])
+        if args.dataloader:      # train_inductive.py:84-85 verbatim
+            loaders[split] = DataLoader(part, batch_size=args.batch_size, shuffle=shuffle, collate_fn=collate)
+        else:                    # same batches, assembled from an epoch order that already lives on the device
+            loaders[split] = part.loader(args.batch_size, shuffle=shuffle, seed=args.seed)
     trainer = Trainer(model, args, fused=(args.loss == "fused"))
     history = {"train": [], "val": []}
     print("Training Start")

@@ -41,7 +41,8 @@ enum {
     GAE_E_RANGE = -6      /* value out of the supported range */
 };
 
-enum { GAE_F32 = 0, GAE_BF16 = 1 };     /* storage dtype; accumulation is always fp32 */
+enum { GAE_F32 = 0, GAE_BF16 = 1,       /* storage dtype; accumulation is always fp32 */
+       GAE_U8 = 2 };                    /* 0/1 molecule features of a resident dataset (gae_batch_gather input only) */
 enum { GAE_ACT_IDENTITY = 0, GAE_ACT_RELU = 1 };
 
 typedef struct gae_device_info {
@@ -100,22 +101,30 @@ int gae_csr_to_dense(const int32_t *indptr, const int32_t *indices, int64_t n_ro
                      int64_t n_cols, float *out, int64_t ld, void *stream);
 
 /* dgl.batch(samples) (gae_dgl/train_inductive.py:31-35) on a device-resident
- * dataset CSR: builds the block-diagonal CSR + feature matrix of the graphs
- * graph_ids[0..n_graphs) (in that order).
- *   dataset: graph_ptr[n_total_graphs+1] (int64 node offsets), ds_indptr/ds_indices
- *            (CSR over all dataset nodes, column ids GLOBAL dataset node ids),
- *            ds_feat [n_total_nodes, F] (ld_feat)
- *   plan   : out_node_ptr[n_graphs+1] / out_edge_ptr[n_graphs+1] (int64): exclusive
- *            prefix sums of the selected graphs' node / edge counts (the caller
- *            computes them from its host copy of the per-graph sizes)
- *   outputs: out_indptr[N_b+1], out_indices[E_b], out_feat [N_b, F] (ld_out). */
+ * dataset: the whole molecule set lives in HBM as ONE block-diagonal CSR (+ the CSR of A^T unless the set is
+ * symmetric) and one feature matrix; a batch is assembled by two launches and no host <-> device copy.
+ *   dataset: graph_ptr[n_total_graphs+1] (int64 node offsets), ds_indptr/ds_indices (CSR over all dataset nodes,
+ *            column ids GLOBAL dataset node ids), ds_feat [n_total_nodes, F] (ld_feat) fp32 / bf16 / uint8
+ *            (GAE_U8: the 0/1 atom one-hots of gae_dgl/prepare_data.py:31-36 stored in a byte each)
+ *   graph_ids[n_graphs] (int64, device): the selected graphs, in batch order
+ * gae_batch_plan  : out_node_ptr / out_edge_ptr / out_t_edge_ptr [n_graphs+1] (int64, device) = exclusive prefix
+ *                   sums of the selected graphs' node / edge / transposed-edge counts ("node ids offset by the
+ *                   prefix sum of node counts"); ds_t_indptr and out_t_edge_ptr may be NULL.
+ * gae_batch_gather: out_indptr[N_b+1], out_indices[E_b] (ids rebased into the batch), out_feat [N_b, F] (ld_out;
+ *                   same dtype as ds_feat, fp32 for GAE_U8; may be NULL: structure only), and -- optional, out_ell
+ *                   != NULL -- the packed neighbour table of the batch CSR (gae_spmm_ell_build's format,
+ *                   ell_width 4 / 8 / 16) written in the same pass.  N_b / E_b: the totals out_node_ptr[n_graphs] /
+ *                   out_edge_ptr[n_graphs], which the caller also knows from its host copy of the per-graph sizes. */
+int gae_batch_plan(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
+                   const int64_t *graph_ids, int64_t n_graphs, int64_t *out_node_ptr, int64_t *out_edge_ptr,
+                   int64_t *out_t_edge_ptr, void *stream);
 int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_indices,
                      const void *ds_feat, int64_t ld_feat, int64_t F, int dtype,
                      const int64_t *graph_ids, int64_t n_graphs,
                      const int64_t *out_node_ptr, const int64_t *out_edge_ptr,
                      int64_t n_batch_nodes, int64_t n_batch_edges,
                      int32_t *out_indptr, int32_t *out_indices,
-                     void *out_feat, int64_t ld_out, void *stream);
+                     void *out_feat, int64_t ld_out, int32_t *out_ell, int32_t ell_width, void *stream);
 
 /* ---- K1/K2: sparse aggregation ---------------------------------------------
  * M = diag(row_scale) * A * diag(col_scale) * H,  A given as CSR.

@@ -164,6 +164,10 @@ def run_case(ref, name, n, src, dst, X, hidden, seed):
                hidden=np.asarray(hidden, np.int64))
     for k, v in sd0.items():
         out["sd/" + k] = v.numpy()
+    if name == "mol8":
+        # a checkpoint FILE exactly as the reference writes it (train_inductive.py:55-57:
+        # torch.save(self.model.state_dict(), save_dir/ep{epoch:02}.pkl)) -- the tensors of "sd/*" above
+        torch.save(model.state_dict(), os.path.join(OUT, "mol8_ep00.pkl"))
     # encode (gae.py:57-61) -- also records the ndata side effect (A9)
     g = fresh()
     Z = model.encode(g)

@@ -36,12 +36,119 @@ def test_device_dataset_batch_matches_host_batch():
     assert torch.equal(bg2.csr()[1], bg.csr()[1]) and torch.equal(bg2.ndata['h'], bg.ndata['h'])
 
 
+@pytest.mark.parametrize("storage", ["auto", "float32"])
+@pytest.mark.parametrize("directed", [False, True])
+def test_device_dataset_pipeline(storage, directed):
+    """uint8 feature storage (expanded to fp32 by the gather), device-side batch plan, packed neighbour table written
+    by the gather, epoch iterator without per-batch copies, symmetric (shared) and directed (separate A^T) datasets:
+    every batch equals the oracle's dgl.batch restatement bit for bit"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, workloads as W
+    from gae_dgl_amd.dataset import DeviceGraphDataset
+    from oracle import gae_oracle as O
+    dev = torch.device("cuda:0")
+    gp, src, dst, X = W.zinc_like(400, seed=5)
+    if directed:                                    # drop one direction of a third of the bonds
+        keep = np.ones(len(src), bool); keep[1::6] = False
+        src, dst = src[keep], dst[keep]
+    ds = DeviceGraphDataset(gp, src, dst, X, device=dev, feat_storage=storage)
+    assert ds.feat.dtype == (torch.uint8 if storage == "auto" else torch.float32)
+    assert ds.symmetric == (not directed) and ds.ell_width in (4, 8)     # ring closures give a few atoms 5+ bonds
+    W_ = ds.ell_width
+    if not directed:
+        assert ds.t_indptr.data_ptr() == ds.indptr.data_ptr()          # one structure serves both directions
+
+    def check(bg, ids):
+        parts = []
+        for gi in ids:
+            lo, hi = gp[gi], gp[gi + 1]
+            m = (dst >= lo) & (dst < hi)
+            parts.append((int(hi - lo), src[m] - lo, dst[m] - lo, X[lo:hi]))
+        N, s, d, Xb, gptr = O.batch_graphs(parts)
+        ip, ix = O.csr_from_coo(s, d, N); tp, tx = O.csc_from_coo(s, d, N)
+        assert bg.number_of_nodes() == N and bg.number_of_edges() == len(s)
+        assert np.array_equal(bg.csr()[0].cpu().numpy(), ip) and np.array_equal(bg.csr()[1].cpu().numpy(), ix)
+        assert np.array_equal(bg.csc()[0].cpu().numpy(), tp) and np.array_equal(bg.csc()[1].cpu().numpy(), tx)
+        h = bg.ndata['h']
+        assert h.dtype == torch.float32 and h.stride(0) == 40 and np.array_equal(h.cpu().numpy(), Xb.numpy())
+        assert float(h.as_strided((N,), (40,), h.storage_offset() + 39).abs().max()) == 0.0   # pad column zeroed
+        assert np.array_equal(bg.graph_ptr().cpu().numpy(), np.asarray(gptr))
+        for tr, (p, x) in ((False, bg.csr()), (True, bg.csc())):
+            plan = bg.spmm_plan(tr)
+            built = ops.spmm_plan(p, indices=x, ell=True, ell_width=W_)
+            assert plan.ell_width == W_ and torch.equal(plan.ell, built.ell)
+        Z = torch.randn(N, 16, device=dev)
+        assert torch.equal(ops.spmm(bg, Z), ops.spmm_raw(*bg.csr(), Z, N))        # table kernels == CSR-order sums
+
+    ids = [7, 3, 250, 3, 0, 399]                    # order matters, repeats allowed
+    check(ds.batch(ids), ids)
+    rng = np.random.default_rng(0)
+    sub = ds.subset(np.arange(10, 390))
+    seen = []
+    for bg, lo in zip(sub.epoch(128, shuffle=True, rng=np.random.default_rng(11)), range(0, 380, 128)):
+        order = sub.ids.copy(); np.random.default_rng(11).shuffle(order)
+        check(bg, order[lo:lo + 128]); seen.extend(order[lo:lo + 128])
+    assert sorted(seen) == list(range(10, 390)) and len(sub.loader(128)) == 3
+    from gae_dgl_amd._lib import GaeHipError
+    with pytest.raises(GaeHipError):               # an edge between two molecules
+        DeviceGraphDataset(gp, np.append(src, 0), np.append(dst, gp[1]), X, device=dev)
+
+
+def test_dataset_file_round_trip_and_contract(tmp_path):
+    from gae_dgl_amd import workloads as W
+    from gae_dgl_amd.dataset import DeviceGraphDataset
+    from gae_dgl_amd._lib import GaeHipError
+    gp, src, dst, X = W.zinc_like(64, seed=9)
+    good = tmp_path / "good.npz"
+    DeviceGraphDataset.save(good, gp, src, dst, X)
+    ds = DeviceGraphDataset.load(good, device="cuda:0")
+    ref = DeviceGraphDataset(gp, src, dst, X, device="cuda:0")
+    assert len(ds) == 64 and torch.equal(ds.indices, ref.indices) and torch.equal(ds.feat, ref.feat)
+    b1, b2 = ds.batch([3, 1, 60]), ref.batch([3, 1, 60])
+    assert torch.equal(b1.csr()[1], b2.csr()[1]) and torch.equal(b1.ndata['h'], b2.ndata['h'])
+    bad = X.copy(); bad[0, :23] = 0
+    DeviceGraphDataset.save(tmp_path / "bad.npz", gp, src, dst, bad)
+    with pytest.raises(GaeHipError, match="featuriser contract"):
+        DeviceGraphDataset.load(tmp_path / "bad.npz", device="cuda:0")
+    assert len(DeviceGraphDataset.load(tmp_path / "bad.npz", device="cuda:0", validate=False)) == 64
+    np.savez(tmp_path / "short.npz", graph_ptr=gp, src=src)
+    with pytest.raises(GaeHipError, match="missing"):
+        DeviceGraphDataset.load(tmp_path / "short.npz", device="cuda:0")
+
+
+def test_reference_checkpoint_file_loads(tmp_path):
+    """ep{NN}.pkl as the reference writes it (train_inductive.py:55-57; fixture written by the reference's own GAE in
+    make_golden.py): loads into this GAE and reproduces the golden embedding; Trainer.save writes the same format"""
+    import argparse, os
+    import gae_dgl_amd as G
+    from conftest import GOLDEN, load_golden
+    from gae_dgl_amd import train_inductive as TI
+    from oracle import gae_oracle  # noqa: F401
+    dev = torch.device("cuda:0")
+    g = load_golden("mol8")
+    model = G.GAE(39, [32, 16])
+    model.load_state_dict(torch.load(os.path.join(GOLDEN, "mol8_ep00.pkl")))
+    model = model.to(dev)
+    gr = G.DGLGraph((g["src"], g["dst"]), num_nodes=int(g["n"])).to(dev)
+    gr.ndata['h'] = torch.as_tensor(g["X"]).to(dev)
+    Z = model.encode(gr)
+    assert float((Z.cpu().double() - torch.as_tensor(g["Z"]).double()).abs().max()) < 1e-5
+    TI.Trainer(model, argparse.Namespace(lr=1e-3)).save(0, str(tmp_path))
+    ours = torch.load(tmp_path / "ep00.pkl"); theirs = torch.load(os.path.join(GOLDEN, "mol8_ep00.pkl"))
+    assert list(ours) == list(theirs)
+    for k in ours:
+        assert ours[k].dtype == theirs[k].dtype and torch.equal(ours[k].cpu(), theirs[k])
+
+
 def test_train_inductive_runs_and_learns(tmp_path):
     from gae_dgl_amd import train_inductive as TI
     tr, va = TI.main(["--hidden_dims", "32", "16", "--synthetic", "3000", "-b", "256", "-e", "3", "--lr", "1e-2",
                       "--val_size", "300", "--seed", "0", "-s", str(tmp_path), "--no_plot"])
     assert len(tr) == 3 and all(np.isfinite(tr)) and all(np.isfinite(va))
     assert tr[-1] < tr[0]                                   # loss goes down (README loss-curve sanity band)
+    tr2, _ = TI.main(["--hidden_dims", "32", "16", "--synthetic", "3000", "-b", "256", "-e", "1", "--lr", "1e-2",
+                      "--val_size", "300", "--seed", "0", "-s", str(tmp_path), "--no_plot", "--dataloader"])
+    assert np.isfinite(tr2).all()                           # the reference's DataLoader + collate route still works
     sd = torch.load(tmp_path / "ep02.pkl")
     assert list(sd.keys()) == ["layers.0.apply_mod.linear.weight", "layers.0.apply_mod.linear.bias",
                                "layers.1.apply_mod.linear.weight", "layers.1.apply_mod.linear.bias"]
