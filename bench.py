@@ -39,6 +39,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# VALU roofline of the fused decoder + BCE kernels (the step's dominant launch): fp32 lane-operations per second of the
+# vector ALUs, 256 CUs x 4 SIMD-32 x 2.4 GHz (spec; tools/probes/valu_rate.hip sustains 5.55e13 = 71 % of it with
+# v_fma_f32), a transcendental (v_exp / v_log / v_rcp) costs 4 plain operations (quarter rate; measured 3.6-3.9).
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
+TRANSCENDENTAL_COST = 4.0
+# per evaluated logit (counted in the ISA of the kernels): full-square kernel 5.6 plain + 2
+# transcendental; symmetric kernel 8.2 plain + 2 transcendental per evaluated logit, N^2 / 2 logits evaluated
+LOSS_OPS = {"symmetric": (8.2, 2.0, 0.5), "full": (5.6, 2.0, 1.0)}
 
 
 def parse():
@@ -75,12 +83,16 @@ def parse():
 
 def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/pmc_traffic_r01.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")) as f:
-            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
-    except OSError:
-        return None
+    (profiles/pmc_traffic_r02.json, else _r01: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)."""
+    for name in ("pmc_traffic_r02.json", "pmc_traffic_r01.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                v = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+            if v is not None:
+                return v
+        except OSError:
+            pass
+    return None
 
 
 def time_launches(fn, iters=50, warmup=5):
@@ -115,6 +127,65 @@ def time_launches(fn, iters=50, warmup=5):
             print(f"[bench] graph-replay timing unavailable: {ex}", file=sys.stderr)
             torch.cuda.synchronize()
     return t
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_spmm_baseline(src, dst, n, widths, seconds):
+    """the SpMM metric on the host cores -- oracle/spmm_ref.c (OpenMP row-parallel CSR traversal, the
+    algorithm of DGL's CPU backend) and torch.sparse.mm on CSR, forward (A H) and backward (A^T dM) separately,
+    all cores and one thread, median of >= 10 runs after 3 warm-ups (bounded by `seconds` per entry)."""
+    from oracle import c_oracle, gae_oracle as O
+    ip, ix = O.csr_from_coo(src, dst, n)
+    tp, tx = O.csc_from_coo(src, dst, n)
+    E = len(ix)
+    rng = np.random.default_rng(0)
+    out = {"cpu_model": cpu_model_name(), "host_cpu_count": os.cpu_count(), "edges": E, "entries": []}
+    all_threads = torch.get_num_threads()
+
+    def median_time(fn, budget):
+        for _ in range(3):
+            fn()
+        ts = []
+        t_end = time.perf_counter() + budget
+        while len(ts) < 10 or (time.perf_counter() < t_end and len(ts) < 50):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+            if len(ts) >= 10 and time.perf_counter() >= t_end:
+                break
+        return float(np.median(ts)), len(ts)
+
+    def sparse(ptr, idx):
+        return torch.sparse_csr_tensor(torch.as_tensor(ptr.astype(np.int64)), torch.as_tensor(idx.astype(np.int64)),
+                                       torch.ones(len(idx)), size=(n, n))
+
+    A, At = sparse(ip, ix), sparse(tp, tx)
+    for F in widths:
+        H = rng.random((n, F), dtype=np.float32)
+        Ht = torch.from_numpy(H)
+        Mo = np.zeros((n, F), dtype=np.float32)        # preallocated and touched: no page faults in the timed calls
+        for direction, (p_, x_, S) in (("fwd A*H", (ip, ix, A)), ("bwd A^T*dM", (tp, tx, At))):
+            for threads in (all_threads, 1):
+                os.environ["OMP_NUM_THREADS"] = str(threads)
+                torch.set_num_threads(threads)
+                c_oracle.set_num_threads(threads)
+                tc, kc = median_time(lambda: c_oracle.spmm_csr(p_, x_, H, out=Mo), seconds)
+                tt, kt = median_time(lambda: torch.sparse.mm(S, Ht), seconds)
+                out["entries"].append({"F": F, "direction": direction, "threads": threads,
+                                       "openmp_c_edges_per_s": E / tc, "openmp_c_ms": tc * 1e3, "openmp_c_runs": kc,
+                                       "torch_sparse_mm_edges_per_s": E / tt, "torch_sparse_mm_ms": tt * 1e3,
+                                       "torch_sparse_mm_runs": kt})
+    torch.set_num_threads(all_threads)
+    c_oracle.set_num_threads(all_threads)
+    return out
 
 
 def make_adam(params, lr, args, capturable=False):
@@ -163,7 +234,13 @@ class CitationWorkload:
         self.meta = {"workload": f"{name}-transductive-gae", "n_nodes": n, "n_edges": E, "in_dim": self.F_in,
                      "hidden_dims": self.hidden, "norm": "none", "loss": args.loss + "-bce",
                      "optimizer": "adam lr=1e-2: " + opt_name, "parallelism": "1 GPU",
-                     "launch": "hipGraph replay of the captured step" if self.use_graph else "eager"}
+                     "launch": "hipGraph replay of the captured step" if self.use_graph else "eager",
+                     "forward_products": "fp32 MFMA (exact fp32 embeddings)",
+                     "loss_products": "bf16x3 split products, fp32 accumulate (knobs bce_s_bf16=1, bce_pv_bf16=1)",
+                     "dW_products": "bf16x3 split products, fp32 accumulate (knob atb_bf16=1)",
+                     "residency": f"operands of the dominant launch ({2 * n * self.F_in * 4 / 1e6:.0f} MB) stay in the "
+                                  "256 MB Infinity Cache across the timed replays: its '% of 8 TB/s' is measured "
+                                  "against the on-die fabric, not DRAM"}
         self.captured = None
         self.dominant = ("spmm", n, n, self.F_in, "torch.float32")
         self.dominant_desc = f"spmm F={self.F_in} (layer-1 aggregation A*X, {n} rows, {E} edges)"
@@ -183,6 +260,19 @@ class CitationWorkload:
     def capture(self):
         from gae_dgl_amd.capture import CapturedTrainStep
         self.captured = CapturedTrainStep(self.model, self.opt, self.g, self.Xd)
+
+    def loss_launch(self):
+        """the step's dominant launch sequence -- the fused decoder + BCE (loss and dZ: prepare, dense, edges,
+        finalize) -- on an embedding of the trained model"""
+        from gae_dgl_amd import ops
+        self.g.ndata['h'] = self.Xd
+        with torch.no_grad():
+            Z = self.model.encode(self.g).clone()
+        mask = ops.dropout_mask(tuple(Z.shape), 0.1, seed=1, device=self.dev)
+        csr, csc = self.g.csr(), self.g.csc()
+        E = self.g.number_of_edges()
+        pw = (float(self.n) ** 2 - E) / E
+        return lambda: ops.decoder_bce_raw(Z, mask, csr, csc, pw, want_grad=True)
 
     def step(self):
         if self.captured is not None:
@@ -254,7 +344,7 @@ class ZincWorkload:
         H = bg.ndata['h']
         out = ops.pad_rows(torch.empty(H.shape, device=self.dev))
         return lambda: ops.spmm_raw(ip, ix, H, bg.number_of_nodes(), out=out, out_padded=True,
-                                    blockdiag=bg.block_diag)
+                                    blockdiag=bg.block_diag, plan=bg.spmm_plan(False))
 
     def step(self):
         ids = self.perm[self.cursor:self.cursor + self.B]
@@ -338,8 +428,10 @@ def extras(dev):
     ip, ix = ops.csr_from_coo(d, s, N, N)
     nb = int(gptr[4096]); eb = int(ip[nb])
     ipb, ixb = ip[:nb + 1].clone(), ix[:eb].clone()
-    out.append(spmm_probe(ipb, ixb, nb, 39, ld=40, label="zinc-batch4096 layer1"))
-    out.append(spmm_probe(ipb, ixb, nb, 32, label="zinc-batch4096 layer2"))
+    # as the product launches it: the packed neighbour table of the batch comes out of the batch gather
+    pb = ops.spmm_plan(ipb, indices=ixb, ell=True, ell_width=ops.ell_width_for(int((ipb[1:] - ipb[:-1]).max())))
+    out.append(spmm_probe(ipb, ixb, nb, 39, ld=40, plan=pb, label="zinc-batch4096 layer1"))
+    out.append(spmm_probe(ipb, ixb, nb, 32, plan=pb, label="zinc-batch4096 layer2"))
     bd = ops.BlockDiag(gptr, dev)     # whole molecules per thread block: LDS-staged block-diagonal kernel
     out.append(spmm_probe(ip, ix, N, 39, ld=40, label="zinc-250k whole set, one launch, layer1", iters=20,
                           blockdiag=bd))
@@ -467,7 +559,7 @@ def main():
                      "frac": wl.alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(getattr(wl, "pmc_key", "")),
                      "traffic_note": "HBM bytes/launch from separate rocprofv3 --pmc passes of the same kernel and "
-                                     "shape (profiles/pmc_traffic_r01.json), not collected in this run",
+                                     "shape (profiles/pmc_traffic_r0N.json), not collected in this run",
                      "alg_bytes_per_launch": wl.alg_bytes, "avg_launch_us": t_dom * 1e6,
                      "avg_launch_us_event_pairs_inside_steps": t_dom_instep * 1e6, "launches_timed_inside_steps": len(dom)},
     }
@@ -483,6 +575,44 @@ def main():
                                               "source": "profiles/r01_bench_rmat_s24_1gpu.json"}
         except Exception:
             pass
+    if world == 1 and hasattr(wl, "loss_launch"):
+        # ---- the step's DOMINANT launch: fused decoder + weighted BCE (loss + dZ), VALU / transcendental bound
+        t_loss = time_launches(wl.loss_launch(), iters=20, warmup=5)
+        n = wl.n
+        kind = "symmetric" if n >= 8192 else "full"          # gae_decoder_bce's own rule (bce_sym, d <= 16)
+        plain, trans, frac_eval = LOSS_OPS[kind]
+        units = (plain + TRANSCENDENTAL_COST * trans) * frac_eval * float(n) * n
+        line["roofline_step_dominant"] = {
+            "bound": "valu", "kernel": f"fused decoder + BCE, loss and dZ ({kind} dense kernel + edge / prepare / finalize "
+                                       f"launches), N = {n}, d = 16",
+            "achieved": units / t_loss / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-ops/s",
+            "frac": units / t_loss / VALU_PEAK_LANE_OPS, "avg_launch_us": t_loss * 1e6,
+            "logits_per_s": float(n) * n / t_loss,
+            "model": f"{plain} plain + {trans} transcendental (x{TRANSCENDENTAL_COST:g}) fp32 lane-ops per evaluated "
+                     f"logit, {frac_eval:g} N^2 logits evaluated; matrix-core work (bf16x3 S = Zt Zt^T, O += P Zt) "
+                     "runs on the MFMA pipe next to it",
+            "mfma_flops_per_s": (3 * 2 * 2 * 16 * frac_eval * (2 if kind == "symmetric" else 1)) * float(n) * n / t_loss,
+            "share_of_step": t_loss / (elapsed / args.steps)}
+        # ---- the same step with exact-fp32 products everywhere (no bf16 x 3 split)
+        if graphed:
+            from gae_dgl_amd import _lib
+            knobs = (b"bce_s_bf16", b"bce_pv_bf16", b"atb_bf16")
+            for k in knobs:
+                _lib.call("gae_tuning_set", k, 0)
+            try:
+                wl.captured = None
+                wl.capture()
+                for _ in range(3):
+                    wl.step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    wl.step()
+                torch.cuda.synchronize()
+                line["ms_per_step_exact_fp32"] = (time.perf_counter() - t1) / args.steps * 1e3
+            finally:
+                for k in knobs:
+                    _lib.call("gae_tuning_set", k, 1)
     if "decoder_bce" in {k[0] for k in times}:
         kb = [k for k in times if k[0] == "decoder_bce"]
         tb = float(np.mean([t for k in kb for t in times[k]]))
@@ -493,6 +623,9 @@ def main():
                                          "(S = Zt Zt^T, O = sigmoid(S) Zt); rocprofv3 kernel time in profiles/"}
     if not args.no_cpu_baseline and hasattr(wl, "cpu_baseline"):
         line["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
+        line["cpu_baseline"]["cpu_model"] = cpu_model_name()
+        # the SpMM metric alone on the host cores: forward and backward, all cores and one thread
+        line["cpu_baseline"]["spmm"] = cpu_spmm_baseline(wl.src, wl.dst, wl.n, [wl.F_in, 32], 0.3)
     if not args.no_extra and world == 1 and workload not in ("rmat",):
         del wl
         torch.cuda.empty_cache()

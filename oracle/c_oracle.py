@@ -33,12 +33,13 @@ def _p(a, t):
     return a.ctypes.data_as(ctypes.POINTER(t)) if a is not None else None
 
 
-def spmm_csr(indptr, indices, H, row_scale=None, col_scale=None):
+def spmm_csr(indptr, indices, H, row_scale=None, col_scale=None, out=None):
+    """``out``: preallocated [n, F] fp32 result (timed loops: keeps the page faults of a fresh array out)"""
     H = np.ascontiguousarray(H, dtype=np.float32)
     indptr = np.ascontiguousarray(indptr, dtype=np.int32)
     indices = np.ascontiguousarray(indices, dtype=np.int32)
     n, F = len(indptr) - 1, H.shape[1]
-    M = np.empty((n, F), dtype=np.float32)
+    M = np.empty((n, F), dtype=np.float32) if out is None else out
     rs = None if row_scale is None else np.ascontiguousarray(row_scale, dtype=np.float32).ravel()
     cs = None if col_scale is None else np.ascontiguousarray(col_scale, dtype=np.float32).ravel()
     lib().oracle_spmm_csr_f32(ctypes.c_int64(n), _p(indptr, ctypes.c_int32), _p(indices, ctypes.c_int32),
@@ -69,6 +70,10 @@ def linear(M, W, b, relu):
                             _p(W, ctypes.c_float), _p(b, ctypes.c_float), ctypes.c_int64(W.shape[0]),
                             ctypes.c_int(int(relu)), _p(Y, ctypes.c_float))
     return Y
+
+
+def set_num_threads(n):
+    lib().oracle_set_num_threads(ctypes.c_int(int(n)))
 
 
 def num_threads():

@@ -77,6 +77,15 @@ void oracle_linear_f32(int64_t n, const float *M, int64_t F_in, const float *W, 
     }
 }
 
+void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP
