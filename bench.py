@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--balance", choices=["rows", "nnz"], default="nnz",
                     help="rmat: row blocks of equal row count or of equal edge count (RMAT puts 44 %% of the edges "
                          "into the first of 8 equal row blocks)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="rmat: exchange, then one SpMM over the assembled rows (bit-identical to one GPU) instead of "
+                         "the default own-column SpMM under the exchange + accumulated remote-column SpMM")
     ap.add_argument("--torch-adam", action="store_true",
                     help="torch.optim.Adam(fused=True) instead of the library's one-launch Adam (same update rule)")
     ap.add_argument("--knobs", default="", help="comma-separated gae_tuning_set name=value pairs (experiments)")
@@ -367,14 +370,21 @@ class RmatShardedWorkload:
         n = 1 << scale
         src, dst = W.rmat_edges(scale, 16, seed=0, device=dev)               # same list on every rank (seeded)
         E = int(src.numel())
+        self.overlap = not args.no_overlap
         self.sg = ShardedGraph(n, src, dst, rank=rank, world=world, group=group, mode=args.exchange, device=dev,
-                               balance=args.balance)
+                               balance=args.balance, overlap=self.overlap)
         del src, dst
-        for w in ("fwd", "bwd"):
-            self.sg.csr(w); self.sg.plan(w)
-        self.sg.part.fwd_rows = self.sg.part.fwd_cols = self.sg.part.bwd_rows = self.sg.part.bwd_cols = None
-        torch.cuda.empty_cache()
         p = self.sg.part
+        e_local = int(p.fwd_rows.numel())
+        for w in ("fwd", "bwd"):
+            for part in (("own", "remote") if self.overlap else (None,)):
+                self.sg.csr(w, part); self.sg.plan(w, part)
+        # the edge lists of the plan are not needed once the device CSRs exist (2 x 2^28 int64 per direction)
+        p.fwd_rows = p.fwd_cols = p.bwd_rows = p.bwd_cols = None
+        p.cols_global = {}
+        for k in p.split:
+            p.split[k] = dict(n_remote_cols=p.split[k]["n_remote_cols"])
+        torch.cuda.empty_cache()
         F, hidden = 32, [32, 16]
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         self.X = torch.rand(p.n_local, F, device=dev, generator=gen)
@@ -385,27 +395,52 @@ class RmatShardedWorkload:
         self.params = list(self.model.parameters())
         self.n, self.E = n, E
         self.edges_per_step = 3 * E
-        ip, ix = self.sg.csr("fwd")
-        e_local = int(ix.numel())
         self.meta = {"workload": f"rmat-s{scale}-ef16-row-sharded-encoder", "n_nodes": n, "n_edges": E, "in_dim": F,
                      "hidden_dims": hidden, "parallelism": f"row-shard x{world}", "exchange": args.exchange,
                      "balance": args.balance,
+                     "overlap": "own-column SpMM under the exchange, then M += remote-column SpMM" if self.overlap
+                                else "exchange, then one SpMM (bit-identical to one GPU)",
                      "exchange_bytes_per_spmm_per_rank": self.sg.exchange_bytes(F),
                      "decoder": "excluded (O(N^2) = 2.8e14 logits at N = 2^24); synthetic dZ",
                      "local_rows": p.n_local, "local_edges_fwd": e_local}
-        self.dominant = ("spmm", p.n_local, p.n_cols["fwd"], F, "torch.float32")
-        self.dominant_desc = f"spmm F=32 on this rank's row block ({p.n_local} rows, {e_local} edges, skew plan)"
-        # compulsory bytes of the local launch: local indptr/indices + the referenced H + the local output
+        self.dominant = None
+        self.dominant_desc = (f"spmm F=32 on this rank's row block ({p.n_local} rows, {e_local} edges, skew plan"
+                              + ("; own-column + remote-column launches" if self.overlap else "") + ")")
+        # compulsory bytes of the local product: local indptr/indices + the referenced H + the local output
         self.alg_bytes = 4 * (p.n_local + 1) + 4 * e_local + 4 * F * min(n, p.n_cols["fwd"]) + 4 * F * p.n_local
         self.scaling = "strong"
 
     def dominant_launch(self):
+        """this rank's forward product on already-exchanged rows (no collective inside the timed launches)"""
         from gae_dgl_amd import ops
-        full = self.sg.exchange(self.X, "fwd")          # collective: every rank calls it
-        ip, ix = self.sg.csr("fwd")
-        out = torch.empty(self.sg.part.n_local, self.X.shape[1], device=self.dev)
-        plan = self.sg.plan("fwd")
-        return lambda: ops.spmm_raw(ip, ix, full, self.sg.part.n_local, out=out, plan=plan)
+        sg, n_local = self.sg, self.sg.part.n_local
+        out = torch.empty(n_local, self.X.shape[1], device=self.dev)
+        if not self.overlap:
+            full = sg.exchange(self.X, "fwd")          # collective: every rank calls it
+            ip, ix = sg.csr("fwd")
+            plan = sg.plan("fwd")
+            return lambda: ops.spmm_raw(ip, ix, full, n_local, out=out, plan=plan)
+        recv, wait = sg.exchange_start(self.X, "fwd")
+        wait()
+        oip, oix = sg.csr("fwd", "own"); rip, rix = sg.csr("fwd", "remote")
+        po, pr = sg.plan("fwd", "own"), sg.plan("fwd", "remote")
+
+        def launch():
+            ops.spmm_raw(oip, oix, self.X, n_local, out=out, plan=po)
+            if rix.numel():
+                ops.spmm_raw(rip, rix, recv, n_local, out=out, plan=pr, accumulate=True)
+        return launch
+
+    def comm_profile(self, steps=5):
+        """HIP-event times of the exchange and SpMM parts over a few extra steps (outside the timed region)"""
+        self.sg.timers = {}
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        t = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) * 1e-3 for k, v in self.sg.timers.items()}
+        calls = {k: len(v) // steps for k, v in self.sg.timers.items()}
+        self.sg.timers = None
+        return t, calls
 
     def step(self):
         from gae_dgl_amd.parallel import allreduce_grads, sharded_encode
@@ -520,6 +555,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
     dom_fn = wl.dominant_launch() if hasattr(wl, "dominant_launch") else None   # may contain a collective
+    comm = wl.comm_profile() if hasattr(wl, "comm_profile") else None              # collective: every rank
     if rank != 0:
         if dist.is_initialized():
             dist.barrier()
@@ -527,7 +563,9 @@ def main():
         return
     times = prof.summary()
     spmm_keys = [k for k in times if k[0] == "spmm"]
-    if wl.dominant is None and spmm_keys:   # zinc: batch shapes vary slightly; take the F=39 launches
+    if wl.dominant is None and workload == "rmat":
+        dom = []
+    elif wl.dominant is None and spmm_keys:   # zinc: batch shapes vary slightly; take the F=39 launches
         dom = [t for k in spmm_keys if k[3] == 39 for t in times[k]]
         k39 = [k for k in spmm_keys if k[3] == 39]
         nb = int(np.mean([k[1] for k in k39])); eb = wl.edges_per_step // 3
@@ -563,6 +601,21 @@ def main():
                      "alg_bytes_per_launch": wl.alg_bytes, "avg_launch_us": t_dom * 1e6,
                      "avg_launch_us_event_pairs_inside_steps": t_dom_instep * 1e6, "launches_timed_inside_steps": len(dom)},
     }
+    if comm is not None:
+        t, calls = comm
+        ex = t.get("exchange", 0.0) * calls.get("exchange", 0) + \
+            t.get("exchange_start", 0.0) * calls.get("exchange_start", 0) + \
+            t.get("exchange_wait", 0.0) * calls.get("exchange_wait", 0)
+        sp = sum(t.get(k, 0.0) * calls.get(k, 0) for k in ("spmm", "spmm_own", "spmm_remote"))
+        line["comm"] = {
+            "exchange_s_per_step": ex, "spmm_s_per_step": sp, "step_s": elapsed / args.steps,
+            "edges_per_s_spmm_only_no_comm": wl.edges_per_step / max(world, 1) / sp * world if sp else None,
+            "edges_per_s_spmm_plus_exchange": wl.edges_per_step / (sp + ex) if sp + ex else None,
+            "avg_us": {k: v * 1e6 for k, v in t.items()}, "calls_per_step": calls,
+            "exchange_bytes_received_per_spmm": wl.sg.exchange_bytes(32),
+            "note": "rank-0 HIP-event times over 5 extra steps outside the timed region; exchange_wait is what the "
+                    "own-column SpMM did not hide; SpMM-only edges/s assumes every rank takes as long as rank 0 "
+                    "(nnz-balanced blocks)"}
     if world > 1 and workload == "rmat":
         # the N = 1 default of this script is the Pubmed step (BASELINE configs[1]); the same row-sharded RMAT
         # workload on ONE GPU was measured with `--gpus 1 --workload rmat` and filed under profiles/

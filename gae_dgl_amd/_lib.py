@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libgae_hip.so")
 F32, BF16, U8 = 0, 1, 2
 SPMM_STORE_PAD = 1
 SPMM_TILE = 2
+SPMM_ACCUMULATE = 4
 SPMM_ELL_WIDTH = 16
 ACT_IDENTITY, ACT_RELU = 0, 1
 

@@ -105,6 +105,19 @@ struct VecIO<unsigned short, 1> {
     static __device__ __forceinline__ void store_sc1(unsigned short *p, const float (&v)[1]) { store(p, v); }
 };
 
+// GAE_SPMM_ACCUMULATE: v += the values already stored at p (first `valid` elements of the vector)
+template <typename T, int VEC>
+__device__ __forceinline__ void add_old(const T *p, float (&v)[VEC], int valid)
+{
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+        if (i < valid) {
+            float t[1];
+            VecIO<T, 1>::load(p + i, t);
+            v[i] += t[0];
+        }
+}
+
 __device__ __forceinline__ void store_scalar(float *p, float v) { *p = v; }
 __device__ __forceinline__ void store_scalar(unsigned short *p, float v) { *p = gae::f32_to_bf16(v); }
 
@@ -112,7 +125,7 @@ template <typename T, int VEC, int LPR, int CH, bool SCALED>
 __global__ __launch_bounds__(256) void spmm_rowgroup_kernel(
     const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t n_rows,
     const T *__restrict__ H, int64_t ldh, T *__restrict__ M, int64_t ldm, int F,
-    const float *__restrict__ row_scale, const float *__restrict__ col_scale)
+    const float *__restrict__ row_scale, const float *__restrict__ col_scale, int accumulate)
 {
     constexpr int RPB = 256 / LPR;      // rows per block
     constexpr int TILE = LPR * VEC;     // features per chunk
@@ -182,6 +195,7 @@ __global__ __launch_bounds__(256) void spmm_rowgroup_kernel(
             for (int i = 0; i < VEC; ++i) acc[c][i] *= rs;
         }
         const int f = f0 + c * TILE;
+        if (accumulate) add_old<T, VEC>(mp + c * TILE, acc[c], F - f);      // GAE_SPMM_ACCUMULATE: M += result
         if (VEC == 1 || f + VEC <= F) {
             VecIO<T, VEC>::store(mp + c * TILE, acc[c]);
         } else {
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
     const T *__restrict__ H, int64_t ldh, T *__restrict__ M, int64_t ldm, int F,
     const float *__restrict__ row_scale, const float *__restrict__ col_scale, unsigned n_row_blocks,
     unsigned n_ftiles, int xcd_tiled, int tile_w, int skip_deg, int store_pad, int store_mode,
-    const int32_t *__restrict__ ell)
+    const int32_t *__restrict__ ell, int accumulate)
 {
     constexpr int GPB = 256 / LPR;            // groups per block
     constexpr int RPB = GPB * RPG;            // rows per block
@@ -412,6 +426,7 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
                 for (int i = 0; i < VEC; ++i) acc[r][c][i] *= rs;
             }
             const int f = f0 + c * TILE;
+            if (accumulate) add_old<T, VEC>(mp + c * TILE, acc[r][c], F - f);   // GAE_SPMM_ACCUMULATE: M += result
             // store_pad: M's rows are padded to a whole vector and the caller allows the pad columns to be
             // overwritten -> the tail vector is written whole (full 16-byte stores, no partially written sectors)
             if (VEC == 1 || f + VEC <= F || store_pad) {
@@ -470,7 +485,8 @@ int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_ro
     const int xt = tiled ? 1 : 0;
 #define GAE_L2(SC, EW)                                                                                              \
     hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, EW>), grid, dim3(256), 0, s, indptr, indices,  \
-                       n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, tw * VEC, skip_deg, store_pad, store_mode, ell)
+                       n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, tw * VEC, skip_deg, store_pad, store_mode, ell,        \
+                       (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0)
     constexpr int EW = VEC > 1 ? kEllWidth : 0;
     // store policy: 0 plain, 1 non-temporal, 2 write-through sc1; auto (-1) = sc1 under XCD feature tiles (the
     // output stream must not evict the tile's L2-resident slice of H), non-temporal otherwise
@@ -515,7 +531,7 @@ int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_
         if (tv > 0 && (nvec + tv - 1) / tv >= 2) tile_vecs = tv;
     }
     // packed-table kernels (spmm_ell.hip) whenever the plan carries a table they can use
-    if (VEC > 1 && ell && g_spmm_ell == 1) {
+    if (VEC > 1 && ell && g_spmm_ell == 1 && !(flags & GAE_SPMM_ACCUMULATE)) {
         const int tv = tile_vecs > 0 ? tile_vecs : (nvec < 64 ? nvec : 64);
         if (tv <= 64 && gae::spmm_ell_usable(n_cols, ldh, int(sizeof(T)), ell_width, tv)) {
             const int store_pad = ((flags & GAE_SPMM_STORE_PAD) && int64_t(nvec) * VEC <= ldm) ? 1 : 0;
@@ -563,7 +579,7 @@ int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_
 
 template <typename T, int VEC, int LPR, int CH>
 int launch_rowgroup(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
-                    int64_t ldm, int F, const float *rs, const float *cs, hipStream_t s)
+                    int64_t ldm, int F, const float *rs, const float *cs, int acc, hipStream_t s)
 {
     constexpr int RPB = 256 / LPR;
     const int nvec = (F + VEC - 1) / VEC;
@@ -571,20 +587,20 @@ int launch_rowgroup(const int32_t *indptr, const int32_t *indices, int64_t n_row
     const unsigned gy = unsigned((nvec + LPR * CH - 1) / (LPR * CH));
     if (rs || cs)
         hipLaunchKernelGGL((spmm_rowgroup_kernel<T, VEC, LPR, CH, true>), dim3(gx, gy), dim3(256), 0, s, indptr,
-                           indices, n_rows, H, ldh, M, ldm, F, rs, cs);
+                           indices, n_rows, H, ldh, M, ldm, F, rs, cs, acc);
     else
         hipLaunchKernelGGL((spmm_rowgroup_kernel<T, VEC, LPR, CH, false>), dim3(gx, gy), dim3(256), 0, s, indptr,
-                           indices, n_rows, H, ldh, M, ldm, F, rs, cs);
+                           indices, n_rows, H, ldh, M, ldm, F, rs, cs, acc);
     GAE_CHECK_LAUNCH("spmm_rowgroup_kernel");
     return GAE_OK;
 }
 
 template <typename T, int VEC>
 int dispatch_rowgroup(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
-                      int64_t ldm, int F, const float *rs, const float *cs, hipStream_t s)
+                      int64_t ldm, int F, const float *rs, const float *cs, int acc, hipStream_t s)
 {
     const int nvec = (F + VEC - 1) / VEC;
-#define GAE_RG(LPR, CH) return launch_rowgroup<T, VEC, LPR, CH>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, s)
+#define GAE_RG(LPR, CH) return launch_rowgroup<T, VEC, LPR, CH>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, acc, s)
     if (nvec <= 1) GAE_RG(1, 1);
     if (nvec <= 2) GAE_RG(2, 1);
     if (nvec <= 4) GAE_RG(4, 1);
@@ -826,7 +842,7 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t *__rest
                                                            const int32_t *__restrict__ heavy_seg_base,
                                                            int64_t n_heavy, int seg, const float *__restrict__ partial,
                                                            int ldp, int F, const float *__restrict__ row_scale,
-                                                           T *__restrict__ M, int64_t ldm)
+                                                           T *__restrict__ M, int64_t ldm, int accumulate)
 {
     const int lane = threadIdx.x & 63;
     const int64_t h = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -838,7 +854,13 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t *__rest
     for (int f = lane; f < F; f += 64) {
         float s = 0.f;
         for (int k = 0; k < ns; ++k) s += pp[int64_t(k) * ldp + f];
-        store_scalar(M + row * ldm + f, s * rs);
+        s *= rs;
+        if (accumulate) {
+            float t[1];
+            VecIO<T, 1>::load(M + row * ldm + f, t);
+            s += t[0];
+        }
+        store_scalar(M + row * ldm + f, s);
     }
 }
 
@@ -893,7 +915,8 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
                                         (plan && g_spmm_ell) ? plan->ell : nullptr, plan ? plan->ell_width : 0, s);
     else {
         GAE_REQUIRE(!heavy, GAE_E_RANGE, "gae_spmm_csr: a skew plan needs F > %d for this layout", min_f);
-        rc = dispatch_rowgroup<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, s);
+        rc = dispatch_rowgroup<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs,
+                                       (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0, s);
     }
     if (rc || !heavy) return rc;
     float *partial = static_cast<float *>(workspace);
@@ -902,7 +925,7 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
     if (rc) return rc;
     hipLaunchKernelGGL((spmm_combine_kernel<T>), dim3(unsigned((plan->n_heavy + 3) / 4)), dim3(256), 0, s, indptr,
                        plan->heavy_rows, plan->heavy_seg_base, plan->n_heavy, plan->segment_edges, partial, ldp, f, rs,
-                       m, ldm);
+                       m, ldm, (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0);
     GAE_CHECK_LAUNCH("spmm_combine_kernel");
     return GAE_OK;
 }

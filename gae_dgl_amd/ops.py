@@ -406,10 +406,11 @@ class BlockDiag:
 
 
 def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=None, plan=None, blockdiag=None,
-             out_padded=False, scattered=False):
+             out_padded=False, scattered=False, accumulate=False):
     """M = diag(row_scale) A diag(col_scale) H  (K1/K2).  ``out_padded``: the caller's ``out`` is a view of a
     row-padded buffer whose pad columns may be overwritten (always true for the buffer allocated here).
-    ``scattered``: the graph's column ids lie far from the row ids (GAE_SPMM_TILE)."""
+    ``scattered``: the graph's column ids lie far from the row ids (GAE_SPMM_TILE).
+    ``accumulate``: ``out += ...`` (GAE_SPMM_ACCUMULATE; needs ``out``)."""
     H, ldh = _rowmajor(H, "H")
     _gpu(indptr, "indptr")
     n_cols, F = H.shape
@@ -418,7 +419,12 @@ def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=Non
         q = row_quantum(F, H.dtype)
         out = torch.empty(n_rows, (F + q - 1) // q * q, dtype=H.dtype, device=H.device)[:, :F]
         out_padded = True
-    flags = (_lib.SPMM_STORE_PAD if out_padded else 0) | (_lib.SPMM_TILE if scattered else 0)
+    if accumulate and out is None:
+        raise GaeHipError("spmm: accumulate=True adds to `out`")
+    flags = (_lib.SPMM_STORE_PAD if out_padded else 0) | (_lib.SPMM_TILE if scattered else 0) | \
+        (_lib.SPMM_ACCUMULATE if accumulate else 0)
+    if accumulate:
+        blockdiag = None
     out2, ldm = _rowmajor(out, "out")
     if out2 is not out:
         raise GaeHipError("spmm: `out` must be row-major with unit inner stride")
@@ -775,9 +781,8 @@ class ShardedDecoderBCEFunction(torch.autograd.Function):
         n = p.n
         pw = (float(n) * float(n) - float(n_edges_global)) / float(n_edges_global)
         need = ctx.needs_input_grad[0]
-        if p.mode != "allgather":
-            raise GaeHipError("sharded_decoder_bce needs global column ids (exchange mode 'allgather')")
-        loss, dzt = decoder_bce_raw(full[:n], None, sg.csr("fwd"), sg.csr("bwd") if need else None, pw,
+        # labels are looked up by GLOBAL column id, whatever the exchange mode of the SpMM
+        loss, dzt = decoder_bce_raw(full[:n], None, sg.csr_global("fwd"), sg.csr_global("bwd") if need else None, pw,
                                     want_grad=need, row_begin=p.r0, n_local=p.n_local)
         sg.allreduce_sum(loss)
         ctx.save_for_backward(dzt, mask_local)

@@ -19,7 +19,14 @@ modes:
     row order, so column order inside every CSR row is unchanged.
 Linear weights are replicated; their gradients are all-reduced (sum).  The
 fused decoder+BCE loss is evaluated per row block against the all-gathered Z
-(N x 16: small) and summed with a scalar all-reduce."""
+(N x 16: small) and summed with a scalar all-reduce.
+
+``overlap=True`` splits a rank's structure by COLUMN owner: A_p = [A_own | A_remote].  The exchange is started
+asynchronously, ``A_own * H_p`` runs on the rank's own rows while it is in flight, then ``M_p += A_remote * recv``
+(GAE_SPMM_ACCUMULATE) reads the received rows where the collective put them -- no assembled [below | own | above]
+copy exists.  Every partial is a CSR-order sum and the two are added in a fixed order, so the result is
+deterministic; it differs from the single-GPU sum by fp32 rounding (a different association), where the default
+``overlap=False`` is bit-identical to it."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -62,8 +69,9 @@ class RowPartition:
     """Host-side plan of one rank's share of a graph (pure index bookkeeping,
     torch ops on whatever device the edge list lives on)."""
 
-    def __init__(self, n, src, dst, rank, world, mode="allgather", balance="rows"):
+    def __init__(self, n, src, dst, rank, world, mode="allgather", balance="rows", overlap=False):
         assert mode in ("allgather", "boundary") and balance in ("rows", "nnz")
+        self.overlap = bool(overlap)
         self.n, self.rank, self.world, self.mode = int(n), int(rank), int(world), mode
         self.bounds = block_bounds(self.n, self.world) if balance == "rows" else \
             nnz_balanced_bounds(self.n, src, dst, self.world)
@@ -79,8 +87,11 @@ class RowPartition:
         bwd = (src >= self.r0) & (src < self.r1)        # out-edges of my rows -> A^T_p (rows src, cols dst)
         self.fwd_rows, self.fwd_cols = dst[fwd] - self.r0, src[fwd]
         self.bwd_rows, self.bwd_cols = src[bwd] - self.r0, dst[bwd]
+        # GLOBAL column ids of the local rows (the fused loss labels pairs by global id, whatever the exchange mode)
+        self.cols_global = {"fwd": self.fwd_cols, "bwd": self.bwd_cols}
         self.n_cols = {"fwd": self.padded_n, "bwd": self.padded_n}
         self.need = {}
+        self.split = {}            # overlap: k -> dict(own=(rows, cols), remote=(rows, cols), n_remote_cols)
         if mode == "boundary":
             for k, cols in (("fwd", self.fwd_cols), ("bwd", self.bwd_cols)):
                 remote = cols[(cols < self.r0) | (cols >= self.r1)]
@@ -100,6 +111,16 @@ class RowPartition:
                 else:
                     self.bwd_cols = newc
                 self.n_cols[k] = self.n_local + int(need.numel())
+        if self.overlap:
+            for k, rows in (("fwd", self.fwd_rows), ("bwd", self.bwd_rows)):
+                cols = self.cols_global[k]
+                own = (cols >= self.r0) & (cols < self.r1)
+                if mode == "boundary":       # remote ids -> position in the receive buffer (ascending global id)
+                    rcols, n_rc = torch.searchsorted(self.need[k], cols[~own]), int(self.need[k].numel())
+                else:                        # the gathered matrix is indexed by global id
+                    rcols, n_rc = cols[~own], self.padded_n
+                self.split[k] = dict(own=(rows[own], cols[own] - self.r0), remote=(rows[~own], rcols),
+                                     n_remote_cols=n_rc)
 
     @property
     def padded_n(self):
@@ -111,7 +132,7 @@ class ShardedGraph:
     """One rank's row block with its device CSRs and the exchange plan."""
 
     def __init__(self, n, src, dst, rank=None, world=None, group=None, mode="allgather", device=None,
-                 balance="rows"):
+                 balance="rows", overlap=False):
         if isinstance(group, LocalGroup):
             assert rank is not None
             world = group.world
@@ -119,7 +140,8 @@ class ShardedGraph:
             rank = dist.get_rank(group) if rank is None else rank
             world = dist.get_world_size(group) if world is None else world
         self.group = group
-        self.part = RowPartition(n, src, dst, rank, world, mode, balance)
+        self.part = RowPartition(n, src, dst, rank, world, mode, balance, overlap)
+        self.timers = None         # set to {} to collect HIP-event pairs of the exchange / SpMM parts (bench.py)
         self.device = torch.device(device) if device is not None else torch.as_tensor(src).device
         self._csr = {}
         self._plan = {}
@@ -128,22 +150,52 @@ class ShardedGraph:
             self._setup_boundary()
 
     # ------------------------------------------------------------------ structure (HIP)
-    def csr(self, which="fwd"):
-        if which not in self._csr:
+    def csr(self, which="fwd", part=None):
+        """device CSR of this rank's rows: the whole structure (``part`` None; column ids as the exchange buffer
+        orders them), or -- overlap -- its "own" / "remote" column part"""
+        key = which if part is None else (which, part)
+        if key not in self._csr:
             from . import ops
             p = self.part
-            rows, cols = (p.fwd_rows, p.fwd_cols) if which == "fwd" else (p.bwd_rows, p.bwd_cols)
-            self._csr[which] = ops.csr_from_coo(rows.to(self.device), cols.to(self.device), p.n_local,
-                                                p.n_cols[which])
-        return self._csr[which]
+            if part is None:
+                rows, cols = (p.fwd_rows, p.fwd_cols) if which == "fwd" else (p.bwd_rows, p.bwd_cols)
+                n_cols = p.n_cols[which]
+            else:
+                rows, cols = p.split[which][part]
+                n_cols = p.n_local if part == "own" else p.split[which]["n_remote_cols"]
+            self._csr[key] = ops.csr_from_coo(rows.to(self.device), cols.to(self.device), p.n_local, max(n_cols, 1))
+        return self._csr[key]
 
-    def plan(self, which="fwd"):
-        if which not in self._plan:
+    def csr_global(self, which="fwd"):
+        """CSR of this rank's rows with GLOBAL column ids (what the fused loss reads; in all-gather mode this is
+        csr(which) itself)"""
+        if self.part.mode == "allgather" and which in self._csr:
+            return self._csr[which]
+        key = (which, "global")
+        if key not in self._csr:
+            from . import ops
+            p = self.part
+            rows = p.fwd_rows if which == "fwd" else p.bwd_rows
+            self._csr[key] = ops.csr_from_coo(rows.to(self.device), p.cols_global[which].to(self.device), p.n_local,
+                                              p.n)
+        return self._csr[key]
+
+    def plan(self, which="fwd", part=None):
+        key = which if part is None else (which, part)
+        if key not in self._plan:
             from . import ops
             # explicit threshold: whether a row is segmented must depend on that row only, so that every
             # sharding of a graph (and the 1-rank case) produces bit-identical sums
-            self._plan[which] = ops.spmm_plan(self.csr(which)[0], threshold=ops.SKEW_THRESHOLD)
-        return self._plan[which]
+            self._plan[key] = ops.spmm_plan(self.csr(which, part)[0], threshold=ops.SKEW_THRESHOLD)
+        return self._plan[key]
+
+    def _timed(self, name, fn):
+        if self.timers is None:
+            return fn()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); out = fn(); e1.record()
+        self.timers.setdefault(name, []).append((e0, e1))
+        return out
 
     def n_edges(self, which="fwd"):
         p = self.part
@@ -194,6 +246,47 @@ class ShardedGraph:
         nb = p.n_before[which]          # rows owned by lower ranks arrive first (ascending global id)
         return torch.cat([recv[:nb], h_local, recv[nb:]])
 
+    def exchange_start(self, h_local, which="fwd"):
+        """overlap: start the exchange of the REMOTE rows and return (buffer the remote CSR indexes, wait()).  The
+        collective runs on RCCL's stream; wait() orders the caller's stream behind it."""
+        p = self.part
+        F = h_local.shape[1]
+        if isinstance(self.group, LocalGroup):
+            full = self.group.full
+            assert full is not None and torch.equal(full[p.r0:p.r1], h_local), "publish() the assembled matrix first"
+            if p.mode == "allgather":
+                pad = p.padded_n - full.shape[0]
+                return (full if pad <= 0 else torch.cat([full, full.new_zeros(pad, F)])), (lambda: None)
+            return full.index_select(0, self._a2a[which]["need"].to(full.device)), (lambda: None)
+        if p.mode == "allgather":
+            full, works = self._allgather_async(h_local)
+            return full, (lambda: [w.wait() for w in works])
+        a = self._a2a[which]
+        send = h_local.index_select(0, a["send_idx"].to(h_local.device))
+        recv = h_local.new_empty(sum(a["recv_counts"]), F)
+        work = dist.all_to_all_single(recv, send, output_split_sizes=a["recv_counts"],
+                                      input_split_sizes=a["send_counts"], group=self.group, async_op=True)
+        return recv, work.wait
+
+    def _allgather_async(self, t_local):
+        """(full [padded_n or n, F], list of Work): equal blocks -> one all_gather_into_tensor; uneven (nnz-balanced)
+        blocks -> ONE grouped all_gather into views of the result (RCCL: a ncclGroup of broadcasts); the gloo
+        backend of the CPU tests has no uneven all_gather: one broadcast per owner there"""
+        p = self.part
+        if p.uniform:
+            pad = p.block - p.n_local
+            mine = t_local if pad == 0 else torch.cat([t_local, t_local.new_zeros(pad, t_local.shape[1])])
+            full = t_local.new_empty(p.padded_n, t_local.shape[1])
+            return full, [dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group, async_op=True)]
+        full = t_local.new_empty(p.n, t_local.shape[1])
+        views = [full[int(p.bounds[q]):int(p.bounds[q + 1])] for q in range(p.world)]
+        if dist.get_backend(self.group) == "nccl":
+            return full, [dist.all_gather(views, t_local.contiguous(), group=self.group, async_op=True)]
+        full[p.r0:p.r1] = t_local
+        return full, [dist.broadcast(views[q], src=dist.get_global_rank(self.group, q) if self.group is not None else q,
+                                     group=self.group, async_op=True)
+                      for q in range(p.world) if p.bounds[q + 1] > p.bounds[q]]
+
     def allgather_rows(self, t_local):
         """[padded_n, F] matrix of every rank's row block (all-gather; rows >= n are zero padding)"""
         p = self.part
@@ -201,18 +294,7 @@ class ShardedGraph:
             full = self.group.full
             pad = p.padded_n - full.shape[0]
             return full if pad <= 0 else torch.cat([full, full.new_zeros(pad, full.shape[1])])
-        if p.uniform:
-            pad = p.block - p.n_local
-            mine = t_local if pad == 0 else torch.cat([t_local, t_local.new_zeros(pad, t_local.shape[1])])
-            full = t_local.new_empty(p.padded_n, t_local.shape[1])
-            dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group)
-            return full
-        # nnz-balanced (uneven) blocks: one broadcast per owner straight into its slice of the result
-        full = t_local.new_empty(p.n, t_local.shape[1])
-        full[p.r0:p.r1] = t_local
-        works = [dist.broadcast(full[int(p.bounds[q]):int(p.bounds[q + 1])], src=dist.get_global_rank(self.group, q)
-                                if self.group is not None else q, group=self.group, async_op=True)
-                 for q in range(p.world) if p.bounds[q + 1] > p.bounds[q]]
+        full, works = self._allgather_async(t_local)
         for w in works:
             w.wait()
         return full
@@ -238,20 +320,32 @@ class ShardedSpMMFunction(torch.autograd.Function):
     """M_p = A_p exchange(H_p);  dH_p = A^T_p exchange(dM_p)"""
 
     @staticmethod
-    def forward(ctx, h_local, sg):
+    def _product(sg, t_local, which):
         from . import ops
+        n_local = sg.part.n_local
+        if not sg.part.overlap:
+            full = sg._timed("exchange", lambda: sg.exchange(t_local, which))
+            ip, ix = sg.csr(which)
+            return sg._timed("spmm", lambda: ops.spmm_raw(ip, ix, full, n_local, plan=sg.plan(which)))
+        # own columns while the remote rows travel, then M += A_remote * received
+        recv, wait = sg._timed("exchange_start", lambda: sg.exchange_start(t_local, which))
+        oip, oix = sg.csr(which, "own")
+        out = sg._timed("spmm_own", lambda: ops.spmm_raw(oip, oix, t_local, n_local, plan=sg.plan(which, "own")))
+        sg._timed("exchange_wait", wait)
+        rip, rix = sg.csr(which, "remote")
+        if rix.numel():
+            sg._timed("spmm_remote", lambda: ops.spmm_raw(rip, rix, recv, n_local, out=out, accumulate=True,
+                                                           plan=sg.plan(which, "remote")))
+        return out
+
+    @staticmethod
+    def forward(ctx, h_local, sg):
         ctx.sg = sg
-        full = sg.exchange(h_local, "fwd")
-        ip, ix = sg.csr("fwd")
-        return ops.spmm_raw(ip, ix, full, sg.part.n_local, plan=sg.plan("fwd"))
+        return ShardedSpMMFunction._product(sg, h_local.contiguous(), "fwd")
 
     @staticmethod
     def backward(ctx, dm_local):
-        from . import ops
-        sg = ctx.sg
-        full = sg.exchange(dm_local.contiguous(), "bwd")
-        ip, ix = sg.csr("bwd")
-        return ops.spmm_raw(ip, ix, full, sg.part.n_local, plan=sg.plan("bwd")), None
+        return ShardedSpMMFunction._product(ctx.sg, dm_local.contiguous(), "bwd"), None
 
 
 def sharded_encode(model, sg, x_local):

@@ -186,6 +186,9 @@ int64_t gae_spmm_workspace_bytes(const gae_spmm_plan *plan_host, int64_t F);
                               * 128-byte aligned bases) XCD x sweeps feature tiles x, x + 8, ... so that a tile's
                               * slice of H is gathered from that XCD's own L2 instead of HBM (Pubmed F = 500: HBM
                               * traffic 170 -> 45 MB, 31 -> 19 us).  Hurts graphs with local neighbourhoods. */
+#define GAE_SPMM_ACCUMULATE 4 /* M += diag(rs) A diag(cs) H instead of M = ...: lets a row-sharded product add the
+                              * contribution of the REMOTE columns (after the exchange has landed) to the product
+                              * of the rank's OWN columns, which ran while the exchange was in flight */
 int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                  const void *H, int64_t ldh, void *M, int64_t ldm, int64_t F, int dtype,
                  const float *row_scale, const float *col_scale,

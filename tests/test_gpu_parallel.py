@@ -50,6 +50,67 @@ def test_virtual_ranks_spmm_fwd_bwd_bit_exact(world, mode, balance):
     assert torch.equal(torch.cat(grads), refb)
 
 
+@pytest.mark.parametrize("world", [1, 3, 4])
+@pytest.mark.parametrize("mode", ["allgather", "boundary"])
+def test_virtual_ranks_overlap_form(world, mode):
+    """overlap=True: own-column product while the exchange is in flight, then M += remote-column product
+    (GAE_SPMM_ACCUMULATE).  Deterministic; equal to the single-GPU rows up to fp32 re-association (1e-5 tolerance)"""
+    from gae_dgl_amd import ops
+    from gae_dgl_amd.parallel import LocalGroup, ShardedGraph
+    n, src, dst, X = graph()
+    ip, ix = ops.csr_from_coo(dst, src, n, n)
+    tp, tx = ops.csr_from_coo(src, dst, n, n)
+    ref = ops.spmm_raw(ip, ix, X, n)
+    dM = torch.randn(n, X.shape[1], device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    refb = ops.spmm_raw(tp, tx, dM, n)
+    grp = LocalGroup(world)
+    for trial in range(2):
+        outs, grads = [], []
+        for r in range(world):
+            sg = ShardedGraph(n, src, dst, rank=r, group=grp, mode=mode, device=DEV, balance="nnz", overlap=True)
+            p = sg.part
+            h = X[p.r0:p.r1].clone().requires_grad_(True)
+            grp.publish(X)
+            m = sg.spmm(h)
+            grp.publish(dM)
+            m.backward(dM[p.r0:p.r1])
+            outs.append(m.detach()); grads.append(h.grad)
+        out, grad = torch.cat(outs), torch.cat(grads)
+        assert float((out - ref).abs().max() / ref.abs().max()) < 1e-5        # hub rows: thousands of terms re-associated
+        assert float((grad - refb).abs().max() / refb.abs().max()) < 1e-5
+        if trial:
+            assert torch.equal(out, first[0]) and torch.equal(grad, first[1])       # deterministic
+        first = (out, grad)
+
+
+def test_spmm_accumulate_flag():
+    """GAE_SPMM_ACCUMULATE: out += A H for every kernel family that takes it (row-group, v1, segment plan), scaled
+    and unscaled, fp32 and bf16 storage"""
+    from gae_dgl_amd import ops, _lib
+    n, src, dst, X = graph(seed=7, n=900, e=9000, F=40)
+    ip, ix = ops.csr_from_coo(dst, src, n, n)
+    deg, norm = ops.degree_norm(ip)
+    plan = ops.spmm_plan(ip, threshold=8, segment=64)
+    for dtype in (torch.float32, torch.bfloat16):
+        H = X.to(dtype)
+        base = torch.randn(n, 40, device=DEV).to(dtype)
+        for sc in (None, norm):
+            for pl in (None, plan):
+                for variant in (2, 1):
+                    if pl is not None and variant == 1:
+                        continue
+                    _lib.call("gae_tuning_set", b"spmm_variant", variant)
+                    try:
+                        prod = ops.spmm_raw(ip, ix, H, n, sc, sc, plan=pl)
+                        out = base.clone()
+                        ops.spmm_raw(ip, ix, H, n, sc, sc, plan=pl, out=out, accumulate=True)
+                    finally:
+                        _lib.call("gae_tuning_set", b"spmm_variant", 2)
+                    want = (base.float() + prod.float())
+                    tol = 1e-6 if dtype == torch.float32 else 2e-2
+                    assert float((out.float() - want).abs().max() / want.abs().max()) < tol
+
+
 @pytest.mark.parametrize("world", [1, 3])
 def test_virtual_ranks_fused_loss(world):
     import gae_dgl_amd as G
@@ -67,7 +128,8 @@ def test_virtual_ranks_fused_loss(world):
     grp.publish(Z * mask)
     total, grads = 0.0, []
     for r in range(world):
-        sg = ShardedGraph(n, src, dst, rank=r, group=grp, mode="allgather", device=DEV)
+        # the loss labels pairs by global id: it works in both exchange modes of the SpMM
+        sg = ShardedGraph(n, src, dst, rank=r, group=grp, mode=("allgather", "boundary")[r % 2], device=DEV)
         p = sg.part
         z = Z[p.r0:p.r1].clone().requires_grad_(True)
         part = ops.sharded_decoder_bce(z, mask[p.r0:p.r1], sg, n_edges_global=int(src.numel()))
@@ -114,3 +176,62 @@ def test_one_rank_rccl_group_end_to_end():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _rccl_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        import gae_dgl_amd as G
+        from gae_dgl_amd import ops
+        from gae_dgl_amd.parallel import ShardedGraph, allreduce_grads, sharded_encode
+        dev = f"cuda:{rank}"
+        n, src, dst, X = graph(seed=4, n=3000, e=40000, F=39)
+        src, dst, X = src.to(dev), dst.to(dev), X.to(dev)
+        torch.manual_seed(0)
+        model = G.GAE(39, [32, 16]).to(dev)
+        g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+        g.ndata['h'] = X
+        ref = model.encode(g)
+        dZ = torch.randn(n, 16, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+        ref.backward(dZ)
+        gref = [p.grad.clone() for p in model.parameters()]
+        for mode in ("allgather", "boundary"):
+            for overlap in (False, True):
+                for balance in ("rows", "nnz"):
+                    sg = ShardedGraph(n, src, dst, mode=mode, device=dev, balance=balance, overlap=overlap)
+                    p = sg.part
+                    model.zero_grad()
+                    z = sharded_encode(model, sg, X[p.r0:p.r1])
+                    err = float((z - ref[p.r0:p.r1]).abs().max() / ref.abs().max())
+                    assert err < 1e-5 and (overlap or torch.equal(z, ref[p.r0:p.r1].detach())), (mode, overlap, err)
+                    z.backward(dZ[p.r0:p.r1])
+                    allreduce_grads(list(model.parameters()))
+                    for a, prm in zip(gref, model.parameters()):
+                        assert float((a - prm.grad).abs().max()) <= 5e-5 * float(a.abs().max()), (mode, overlap)
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI, world size 2)")
+def test_two_rank_rccl_sharded_encoder():
+    """real RCCL, one process per GPU: both exchange modes, both block rules, with and without overlap reproduce the
+    single-GPU encoder (bit for bit without overlap) and its parameter gradients after the gradient all-reduce"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), res

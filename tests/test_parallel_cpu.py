@@ -52,6 +52,23 @@ def _worker(rank, world, port, mode, q, balance="rows"):
         fullb = sg.exchange(torch.from_numpy(dM[p.r0:p.r1]), "bwd")
         bip, bix = O.csr_from_coo(p.bwd_cols.numpy(), p.bwd_rows.numpy(), p.n_local, p.n_cols["bwd"])
         assert torch.equal(O.spmm_csr(bip, bix, fullb), refb[p.r0:p.r1]), "backward rows differ"
+        # ---- overlap form: A_p = [A_own | A_remote]; own columns read the local block, remote columns read the
+        #      received rows where the collective put them; own + remote partials = the rows of the global product
+        sgo = ShardedGraph(n, torch.from_numpy(src), torch.from_numpy(dst), mode=mode, device="cpu", balance=balance,
+                           overlap=True)
+        po = sgo.part
+        for which, loc, ref_rows in (("fwd", h_local, ref[p.r0:p.r1]),
+                                     ("bwd", torch.from_numpy(dM[p.r0:p.r1]), refb[p.r0:p.r1])):
+            recv, wait = sgo.exchange_start(loc, which)
+            orow, ocol = po.split[which]["own"]; rrow, rcol = po.split[which]["remote"]
+            assert int(ocol.max()) < po.n_local and (rcol.numel() == 0 or int(rcol.max()) < recv.shape[0])
+            oip, oix = O.csr_from_coo(ocol.numpy(), orow.numpy(), po.n_local, po.n_local)
+            part_own = O.spmm_csr(oip, oix, loc)
+            wait()
+            rip, rix = O.csr_from_coo(rcol.numpy(), rrow.numpy(), po.n_local, max(recv.shape[0], 1))
+            total = part_own + (O.spmm_csr(rip, rix, recv) if rcol.numel() else 0)
+            assert torch.allclose(total, ref_rows, rtol=1e-5, atol=1e-5), "overlap partials differ"
+            assert orow.numel() + rrow.numel() == (po.fwd_rows if which == "fwd" else po.bwd_rows).numel()
         # ---- exchange volume bookkeeping
         if mode == "allgather":
             assert full.shape[0] == p.padded_n and sg.exchange_bytes(7) == (n - p.n_local) * 7 * 4
