@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Copy the measurements of tools/collect_r01.sh (gpurun_out/r01/) into profiles/ and derive
-profiles/pmc_traffic_r01.json + a markdown summary (stdout).  Runs in the build container, no GPU."""
+"""Copy the measurements of tools/collect.sh <tag> (gpurun_out/<tag>/) into profiles/ and derive
+profiles/pmc_traffic_<tag>.json + a markdown summary (stdout).  Runs in the build container, no GPU.
+usage: python tools/publish_profiles.py r02"""
 import csv
 import glob
 import json
@@ -9,9 +10,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r01")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
 def last_json(path):
@@ -31,7 +32,7 @@ def pmc_means(d):
 
 
 benches = {}
-for name in ("pubmed", "cora", "citeseer", "zinc", "rmat_s24_1gpu"):
+for name in ("pubmed", "cora", "citeseer", "zinc", "zinc128", "rmat_s24_1gpu"):
     p = os.path.join(SRC, f"bench_{name}.json")
     if os.path.exists(p):
         benches[name] = last_json(p)
@@ -41,7 +42,8 @@ for w in ("pubmed", "cora", "zinc"):
     if os.path.exists(st):
         shutil.copy(st, os.path.join(DST, f"{TAG}_{w}_step_kernel_stats.csv"))
         shutil.copy(os.path.join(SRC, f"{w}_step_kernel_stats_top.txt"), os.path.join(DST, f"{TAG}_{w}_step_kernel_stats_top.txt"))
-for f in ("linear_bench.txt", "spmm_bench_pubmed.txt"):
+for f in ("linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt",
+          "probe_gather_l2.txt", "probe_gather_l2b.txt", "probe_valu_rate.txt"):
     if os.path.exists(os.path.join(SRC, f)):
         shutil.copy(os.path.join(SRC, f), os.path.join(DST, f"{TAG}_{f}"))
 
@@ -88,7 +90,7 @@ if "pubmed" in benches and "extra" in benches["pubmed"]:
     for e in benches["pubmed"]["extra"]["spmm_kernel_only"]:
         print(f"| {e['shape']} | F={e['F']} ld={e['ld']} | {e['us_per_launch']:.1f} us | {e['edges_per_s'] / 1e9:.2f} Gedge/s | "
               f"{100 * e['frac_hbm_peak']:.1f} % |")
-    print(json.dumps(benches["pubmed"].get("decoder_loss")))
+    print(json.dumps(benches["pubmed"].get("roofline_step_dominant")))
 for k, v in traffic.items():
     if k != "_how":
         print(k, v["hbm_bytes_per_launch"], v["alg_bytes"], v["kernel"][:70])

@@ -41,7 +41,12 @@ else:
 ip, ix = ops.csr_from_coo(d, s, n, n)
 H = ops.pad_rows(torch.rand(n, F, device=dev))
 out = ops.pad_rows(torch.empty(n, F, device=dev))
-plan = None if a.plain else ops.spmm_plan(ip, indices=ix if bd is None else None)
+if a.plain:
+    plan = None
+elif name == "zincb":      # a training batch carries the packed table its gather wrote (dataset.DeviceGraphDataset)
+    plan = ops.spmm_plan(ip, indices=ix, ell=True, ell_width=ops.ell_width_for(int((ip[1:] - ip[:-1]).max())))
+else:
+    plan = ops.spmm_plan(ip, indices=ix if bd is None else None)
 scattered = (not a.plain) and bd is None and F > ops.TILE_MIN_F and ops.gather_scattered(ip, ix, F * 4)
 for _ in range(a.iters):
     ops.spmm_raw(ip, ix, H, n, out=out, plan=plan, blockdiag=bd, out_padded=True, scattered=scattered)
