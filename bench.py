@@ -464,7 +464,7 @@ def extras(dev):
     nb = int(gptr[4096]); eb = int(ip[nb])
     ipb, ixb = ip[:nb + 1].clone(), ix[:eb].clone()
     # as the product launches it: the packed neighbour table of the batch comes out of the batch gather
-    pb = ops.spmm_plan(ipb, indices=ixb, ell=True, ell_width=ops.ell_width_for(int((ipb[1:] - ipb[:-1]).max())))
+    pb = ops.spmm_plan(ipb, indices=ixb, ell=True, ell_width=ops.ell_width_for_degrees(ipb[1:] - ipb[:-1]))
     out.append(spmm_probe(ipb, ixb, nb, 39, ld=40, plan=pb, label="zinc-batch4096 layer1"))
     out.append(spmm_probe(ipb, ixb, nb, 32, plan=pb, label="zinc-batch4096 layer2"))
     bd = ops.BlockDiag(gptr, dev)     # whole molecules per thread block: LDS-staged block-diagonal kernel

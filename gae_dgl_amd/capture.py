@@ -65,3 +65,227 @@ class CapturedTrainStep:
             self._capture()
         self.graph.replay()
         return self.loss
+
+
+class CapturedInductiveStep:
+    """The mini-batch training step of train_inductive.py:88-99 -- collate (dgl.batch), forward, loss, backward, Adam
+    -- as ONE captured HIP graph, replayed per batch.
+
+    Batches of molecules all differ in size; a captured graph must launch the same shapes every time.  The step
+    therefore runs on a FIXED-CAPACITY batch: ``batch_size`` graphs are gathered from the device-resident dataset
+    into static buffers of ``cap_nodes`` rows / ``cap_edges`` edges (gae_batch_gather pads the rows behind the batch
+    with isolated zero-feature nodes and leaves the true sizes in device memory), the encoder runs on all
+    ``cap_nodes`` rows (padding rows have no edges: they never reach a real row), and the loss reads the true
+    N and E on the device (gae_decoder_bce_padded: pos_weight, the mean, zero gradient for padding rows).  The graph
+    ids come from an epoch order uploaded once and a device-side cursor (gae_batch_select).  Nothing crosses the
+    host <-> device boundary per batch and the host issues one graph launch per step.
+
+    The capacities are the largest full batch of the epoch orders seen so far (+ ``margin``); an epoch whose largest
+    batch does not fit is captured again with larger buffers.  The ragged last batch of an epoch (fewer graphs)
+    runs through the ordinary eager path.
+
+        runner = CapturedInductiveStep(model, optimizer, dataset, batch_size=128)
+        for epoch in range(n_epochs):
+            for loss in runner.epoch(rng.permutation(dataset.ids)):   # device scalars; .item() only when needed
+                ...
+    """
+
+    def __init__(self, model, optimizer, dataset, batch_size, warmup=2, margin=1.02):
+        if not dataset.ell_width or not dataset.no_heavy_rows:
+            raise ops.GaeHipError("CapturedInductiveStep needs a dataset of low-degree graphs (packed neighbour "
+                                  "table); skewed graphs take the eager path")
+        self.model, self.opt, self.ds = model, optimizer, dataset
+        self.B = int(batch_size)
+        if self.B < 1 or self.B > len(dataset):
+            raise ValueError("batch_size must be in [1, len(dataset)]")
+        self.warmup, self.margin = warmup, margin
+        for group in optimizer.param_groups:
+            if "capturable" in group and not group["capturable"]:
+                raise ValueError("build the optimizer with capturable=True to capture its step")
+        if any(getattr(m, "cache_aggregate", False) for m in model.modules()):
+            raise ValueError("cache_first_aggregate keys its cache on tensor identity; the static batch buffers of a "
+                             "captured step change content, not identity")
+        dev = dataset.device
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.d_order = torch.zeros(len(dataset), dtype=torch.int64, device=dev)
+        self.cap_nodes = self.cap_edges = 0
+        self.graph = None
+        self.captures = 0
+        self._order = None
+
+    # ---------------------------------------------------------------- static buffers
+    def _allocate(self, cap_nodes, cap_edges):
+        from .graph import Graph
+        ds, dev, B, W = self.ds, self.ds.device, self.B, self.ds.ell_width
+        self.cap_nodes, self.cap_edges = cap_nodes, cap_edges
+        self.gids = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.ptrs = torch.zeros(2 if ds.symmetric else 3, B + 1, dtype=torch.int64, device=dev)
+        self.counts = torch.zeros(2, dtype=torch.int64, device=dev)
+        F, ldo, odt = ops.batch_feature_ld(ds.feat, ds.n_feat)
+        ip = torch.zeros(cap_nodes + 1, dtype=torch.int32, device=dev)
+        ix = torch.zeros(cap_edges, dtype=torch.int32, device=dev)
+        feat = torch.zeros(cap_nodes, ldo, dtype=odt, device=dev)
+        table = torch.full((cap_nodes * W,), -1, dtype=torch.int32, device=dev)
+        self.fwd = (ip, ix, feat, table)
+        if ds.symmetric:
+            self.bwd = None
+            tp, tx, t_table = ip, ix, table
+        else:
+            tp = torch.zeros_like(ip); tx = torch.zeros_like(ix); t_table = torch.full_like(table, -1)
+            self.bwd = (tp, tx, None, t_table)
+        g = Graph(device=dev)
+        g._n = cap_nodes
+        g._src = g._dst = None
+        g.set_csr(ip, ix, tp, tx)
+        g.ndata['h'] = feat[:, :F]
+        g.no_heavy_rows = True
+        g.block_diag = None                     # its cuts are host-side and batch-specific: the table kernels run here
+        g._cache["plan"] = ops.table_plan(table, W)
+        g._cache["plan_t"] = ops.table_plan(t_table, W)
+        g._cache["graph_ptr"] = self.ptrs[0]
+        g.batch_counts = self.counts
+        self.g, self.x = g, feat[:, :F]
+
+    def _step_body(self):
+        """select -> plan -> gather -> forward -> loss -> backward -> Adam, all on static buffers"""
+        ds, g = self.ds, self.g
+        ops.batch_select(self.d_order, self.cursor, self.B, self.gids)
+        node_ptr, edge_ptr, t_edge_ptr = ops.batch_plan(ds.graph_ptr, ds.indptr, None if ds.symmetric else ds.t_indptr,
+                                                        self.gids, out=self.ptrs)
+        ops.batch_gather(ds.graph_ptr, ds.indptr, ds.indices, ds.feat, self.gids, node_ptr, edge_ptr, self.cap_nodes,
+                         self.cap_edges, ell_width=ds.ell_width, n_feat=ds.n_feat, out=self.fwd, pad_to_capacity=True,
+                         counts=self.counts)
+        if self.bwd is not None:
+            ops.batch_gather(ds.graph_ptr, ds.t_indptr, ds.t_indices, None, self.gids, node_ptr, t_edge_ptr,
+                             self.cap_nodes, self.cap_edges, ell_width=ds.ell_width, out=self.bwd,
+                             pad_to_capacity=True)
+        for key in ("deg", "norm"):             # degree norms (norm="both" models) follow the batch: recompute
+            g._cache.pop(key, None)
+        g.ndata.clear()
+        g.ndata['h'] = self.x
+        loss = self.model.reconstruction_loss(g)
+        ops.backward(loss)
+        self.opt.step()
+        return loss.detach()
+
+    # ---------------------------------------------------------------- capture
+    def _state(self):
+        """tensors a warm-up step changes: parameters, optimiser state, device-side counters"""
+        ts = [p.data for p in self.model.parameters()]
+        for st in self.opt.state.values():
+            ts += [v for v in st.values() if isinstance(v, torch.Tensor)]
+        ts += list(getattr(self.opt, "_counters", {}).values())
+        ts += [m._draws for m in self.model.modules() if getattr(m, "_draws", None) is not None]
+        return ts
+
+    def _capture(self, cap_nodes, cap_edges):
+        self.graph = None
+        self._allocate(cap_nodes, cap_edges)
+        # the warm-up steps (allocator, lazy optimiser state, autograd streams) must not train the model: run one to
+        # create every lazily-built tensor, snapshot, run the rest, restore
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            had_state = len(self.opt.state) > 0 or len(getattr(self.opt, "_counters", {})) > 0
+            before = [t.clone() for t in self._state()] if had_state else None
+            params0 = [p.detach().clone() for p in self.model.parameters()]
+            draws0 = {id(m): (None if getattr(m, "_draws", None) is None else m._draws.clone())
+                      for m in self.model.modules() if hasattr(m, "_draws")}
+            for _ in range(max(self.warmup, 1)):
+                self.opt.zero_grad(set_to_none=True)
+                self._step_body()
+            if had_state:
+                for t, b in zip(self._state(), before):
+                    t.copy_(b)
+            else:                                   # first use: optimiser state was created by the warm-up -> zero it
+                for st in self.opt.state.values():
+                    for v in st.values():
+                        if isinstance(v, torch.Tensor):
+                            v.zero_()
+                for c in getattr(self.opt, "_counters", {}).values():
+                    c.zero_()
+                for p, p0 in zip(self.model.parameters(), params0):
+                    p.data.copy_(p0)
+                for m in self.model.modules():
+                    if getattr(m, "_draws", None) is not None:
+                        d0 = draws0.get(id(m))
+                        m._draws.zero_() if d0 is None else m._draws.copy_(d0)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = self._step_body()
+        self._captured_hyper = self._hyper()
+        self.captures += 1
+
+    def _hyper(self):
+        return tuple((g["lr"], tuple(g.get("betas", ())), g.get("eps"), g.get("weight_decay"))
+                     for g in self.opt.param_groups)
+
+    # ---------------------------------------------------------------- epoch interface
+    def begin_epoch(self, order):
+        """upload the epoch's order of graph ids (``DataLoader(shuffle=True)``'s permutation) and reset the cursor;
+        returns the number of full batches"""
+        import numpy as np
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        if len(order) > self.d_order.numel():
+            raise ValueError("epoch order longer than the dataset")
+        n_full = len(order) // self.B
+        self._order = order
+        if n_full:
+            starts = np.arange(0, n_full * self.B, self.B)
+            head = order[:n_full * self.B]
+            need_n = int(np.add.reduceat(self.ds.sizes_host[head], starts).max())
+            need_e = int(max(np.add.reduceat(self.ds.edges_host[head], starts).max(),
+                             np.add.reduceat(self.ds.t_edges_host[head], starts).max()))
+            if self.graph is None or need_n > self.cap_nodes or need_e > self.cap_edges:
+                # round the capacities up (whole row blocks of the kernels, headroom for later epochs)
+                cap_n = max(-(-int(need_n * self.margin) // 64) * 64, self.cap_nodes)
+                cap_e = max(-(-int(need_e * self.margin) // 256) * 256, self.cap_edges, 1)
+                self.d_order[:len(order)].copy_(torch.from_numpy(order))   # the warm-up steps read it
+                self.cursor.zero_()
+                self._capture(cap_n, cap_e)
+        self.d_order[:len(order)].copy_(torch.from_numpy(order))
+        self.cursor.zero_()
+        self._done = 0
+        return n_full
+
+    def step(self):
+        """next full batch of the epoch: one graph launch; returns the static loss tensor of this replay"""
+        if self._hyper() != self._captured_hyper:
+            self._recapture()
+        self.graph.replay()
+        self._done += 1
+        return self.loss
+
+    def _recapture(self):
+        cur = self.cursor.clone()
+        self._capture(self.cap_nodes, self.cap_edges)
+        self.cursor.copy_(cur)
+
+    def tail_step(self):
+        """the ragged last batch (len(order) % batch_size graphs), eagerly; None when the epoch has no tail"""
+        order, lo = self._order, (len(self._order) // self.B) * self.B
+        if lo == len(order):
+            return None
+        bg = self.ds._assemble(self.d_order[lo:len(order)], order[lo:])
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.model.reconstruction_loss(bg)
+        ops.backward(loss)
+        self.opt.step()
+        return loss.detach()
+
+    def epoch(self, order):
+        """iterate over the losses of one epoch (device scalars; the full-batch ones alias one static tensor: read or
+        clone before the next step)"""
+        n_full = self.begin_epoch(order)
+        for _ in range(n_full):
+            yield self.step()
+        tail = self.tail_step()
+        if tail is not None:
+            yield tail
+
+    def batch_sizes(self):
+        """true (nodes, edges) of the batch the last replay trained on (host read-back; debugging / tests)"""
+        n, e = self.counts.tolist()
+        return int(n), int(e)

@@ -100,6 +100,21 @@ __global__ __launch_bounds__(256) void csr_to_dense_kernel(const int32_t *__rest
 // Exclusive prefix sums of the selected graphs' node / edge counts ON THE DEVICE (the batch plan of dgl.batch,
 // train_inductive.py:34: "node ids offset by the prefix sum of node counts").  One block; the scan runs in chunks of
 // 1024 graphs with a carried total.  t_indptr may be NULL (symmetric dataset: the transposed structure is the same).
+// graph ids of the next batch of an epoch order that already lives on the device: out_ids[b] = order[cursor * B + b];
+// the cursor (device int64) advances by one batch, so a replayed HIP graph walks the epoch
+__global__ __launch_bounds__(256) void batch_select_kernel(const int64_t *__restrict__ order, int64_t n_order,
+                                                           int64_t *__restrict__ cursor, int64_t B,
+                                                           int64_t *__restrict__ out_ids)
+{
+    const int64_t c = *cursor;
+    for (int64_t b = threadIdx.x; b < B; b += 256) {
+        const int64_t k = c * B + b;
+        out_ids[b] = order[k < n_order ? k : n_order - 1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *cursor = c + 1;
+}
+
 __global__ __launch_bounds__(1024) void batch_plan_kernel(const int64_t *__restrict__ graph_ptr,
                                                           const int32_t *__restrict__ indptr,
                                                           const int32_t *__restrict__ t_indptr,
@@ -176,11 +191,28 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
     const int64_t *__restrict__ graph_ids, int64_t n_graphs, const int64_t *__restrict__ out_node_ptr,
     const int64_t *__restrict__ out_edge_ptr, int32_t *__restrict__ out_indptr,
     int32_t *__restrict__ out_indices, TO *__restrict__ out_feat, int64_t ld_out, int32_t *__restrict__ out_ell,
-    int ell_width)
+    int ell_width, int64_t cap_nodes, int64_t *__restrict__ out_counts)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t b = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
-    if (b >= n_graphs) return;
+    if (b >= n_graphs) {
+        // ---- fixed-capacity batch (cap_nodes > 0): the waves behind the last graph turn the rows [N_b, cap_nodes)
+        //      into isolated zero-feature nodes -- empty CSR rows, zero features, an empty table row -- so that a
+        //      captured HIP graph can run every batch on the same shapes; the true sizes go to out_counts
+        if (cap_nodes <= 0) return;
+        const int64_t nb = out_node_ptr[n_graphs], eb = out_edge_ptr[n_graphs];
+        const int64_t n_pad_waves = (int64_t(gridDim.x) * blockDim.x) / kWave - n_graphs;
+        const int64_t w = b - n_graphs;
+        if (w == 0 && lane == 0 && out_counts) { out_counts[0] = nb; out_counts[1] = eb; }
+        for (int64_t i = nb + w; i < cap_nodes; i += n_pad_waves) {
+            if (lane == 0) out_indptr[i + 1] = int32_t(eb);
+            if (out_ell)
+                for (int k = lane; k < ell_width; k += kWave) out_ell[i * ell_width + k] = -1;
+            if (out_feat)
+                for (int64_t c = lane; c < ld_out; c += kWave) out_feat[i * ld_out + c] = TO(0);
+        }
+        return;
+    }
     const int64_t g = graph_ids[b];
     const int64_t n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
     const int64_t on = out_node_ptr[b], oe = out_edge_ptr[b];
@@ -309,6 +341,17 @@ extern "C" int gae_csr_to_dense(const int32_t *indptr, const int32_t *indices, i
     return GAE_OK;
 }
 
+extern "C" int gae_batch_select(const int64_t *order, int64_t n_order, int64_t *cursor_dev, int64_t batch_graphs,
+                                int64_t *out_ids, void *stream)
+{
+    GAE_REQUIRE(n_order > 0 && batch_graphs > 0, GAE_E_SIZE, "gae_batch_select: sizes must be positive");
+    GAE_REQUIRE(order && cursor_dev && out_ids, GAE_E_NULL, "gae_batch_select: NULL pointer");
+    hipLaunchKernelGGL(batch_select_kernel, dim3(1), dim3(256), 0, gae::as_stream(stream), order, n_order, cursor_dev,
+                       batch_graphs, out_ids);
+    GAE_CHECK_LAUNCH("batch_select_kernel");
+    return GAE_OK;
+}
+
 extern "C" int gae_batch_plan(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
                               const int64_t *graph_ids, int64_t n_graphs, int64_t *out_node_ptr,
                               int64_t *out_edge_ptr, int64_t *out_t_edge_ptr, void *stream)
@@ -334,8 +377,11 @@ extern "C" int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indp
                                 const int64_t *graph_ids, int64_t n_graphs, const int64_t *out_node_ptr,
                                 const int64_t *out_edge_ptr, int64_t n_batch_nodes, int64_t n_batch_edges,
                                 int32_t *out_indptr, int32_t *out_indices, void *out_feat, int64_t ld_out,
-                                int32_t *out_ell, int32_t ell_width, void *stream)
+                                int32_t *out_ell, int32_t ell_width, int64_t cap_nodes, int64_t *out_counts,
+                                void *stream)
 {
+    GAE_REQUIRE(cap_nodes == 0 || cap_nodes >= n_batch_nodes, GAE_E_SIZE,
+                "gae_batch_gather: cap_nodes smaller than the batch");
     GAE_REQUIRE(n_graphs >= 0 && F >= 0 && n_batch_nodes >= 0 && n_batch_edges >= 0, GAE_E_SIZE,
                 "gae_batch_gather: negative size");
     GAE_REQUIRE(ld_feat >= F && ld_out >= F, GAE_E_SIZE, "gae_batch_gather: leading dimension < F");
@@ -355,12 +401,13 @@ extern "C" int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indp
                 "gae_batch_gather: NULL index pointer");
     GAE_REQUIRE(F == 0 || n_batch_nodes == 0 || !out_feat || ds_feat, GAE_E_NULL,
                 "gae_batch_gather: NULL feature pointer");
-    const int64_t blocks = (n_graphs * kWave + 255) / 256;
+    // one wave per graph (+ 256 waves that write the padding of a fixed-capacity batch)
+    const int64_t blocks = ((n_graphs + (cap_nodes > 0 ? 256 : 0)) * kWave + 255) / 256;
 #define GAE_BG(TI, TO)                                                                                              \
     hipLaunchKernelGGL((batch_gather_kernel<TI, TO>), dim3(unsigned(blocks)), dim3(256), 0, s, graph_ptr, ds_indptr,  \
                        ds_indices, static_cast<const TI *>(ds_feat), ld_feat, F, graph_ids, n_graphs, out_node_ptr,  \
                        out_edge_ptr, out_indptr, out_indices, static_cast<TO *>(out_feat), ld_out, out_ell,          \
-                       int(ell_width))
+                       int(ell_width), cap_nodes, out_counts)
     if (dtype == GAE_F32) GAE_BG(float, float);
     else if (dtype == GAE_BF16) GAE_BG(unsigned short, unsigned short);
     else GAE_BG(unsigned char, float);

@@ -81,10 +81,22 @@ __global__ __launch_bounds__(256) void bce_prepare_kernel(const float *__restric
                                                           unsigned short *__restrict__ Zlo,
                                                           double *__restrict__ colsum_partial /*[grid][2][DP]*/,
                                                           float drop_p, float drop_scale, uint64_t seed,
-                                                          uint64_t offset, const uint64_t *__restrict__ draw_dev)
+                                                          uint64_t offset, const uint64_t *__restrict__ draw_dev,
+                                                          const int64_t *__restrict__ counts /*{nodes, edges} or NULL*/,
+                                                          double *__restrict__ scal /*[3] or NULL*/, double all_pairs)
 {
     __shared__ double red[2][256];
     const int tid = threadIdx.x;
+    // fixed-capacity batch (gae_decoder_bce_padded): rows >= counts[0] are padding -- their Zt rows are zero (logit 0
+    // with everything, no gradient to anybody) and pos_weight / 1 / N^2 / the count of zero-logit pairs come from the
+    // device-side counts
+    const int64_t n_valid = counts ? counts[0] : n;
+    if (counts && blockIdx.x == 0 && tid == 0) {
+        const double nv = double(counts[0]), ev = double(counts[1]);
+        scal[0] = ev > 0 ? (nv * nv - ev) / ev : 0.0;      // pos_weight (train_inductive.py:46)
+        scal[1] = nv > 0 ? 1.0 / (nv * nv) : 0.0;          // mean over the N^2 real pairs
+        scal[2] = all_pairs - nv * nv;                     // evaluated pairs with a zero operand: log2(1 + e^0) = 1 each
+    }
     const int k = tid % DP, rl = tid / DP, rpp = 256 / DP;   // rows per pass
     const int64_t r0 = int64_t(blockIdx.x) * PREP_ROWS;
     double s_all = 0.0, s_win = 0.0;
@@ -94,7 +106,9 @@ __global__ __launch_bounds__(256) void bce_prepare_kernel(const float *__restric
         const int64_t i = r0 + rr;
         if (i >= n) break;
         float v = 0.f;
-        if (k < d) {
+        if (k < d && i >= n_valid) {
+            if (draw) mask[i * ldz + k] = 0.f;
+        } else if (k < d) {
             v = Z[i * ldz + k];
             if (draw) {
                 const int64_t e = i * d + k;
@@ -727,9 +741,12 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
     const int32_t *__restrict__ indices, const int32_t *__restrict__ t_indptr, const int32_t *__restrict__ t_indices,
     float pw, float inv_n2, const float *__restrict__ O_partial, int n_splits, int DP,
     const float *__restrict__ S_all_f, float *__restrict__ dZ, int64_t lddz, double *__restrict__ loss_partial,
-    const float *__restrict__ O_mirror /*[n][16] or NULL*/, int64_t sym_cols_per_chunk, int SYM_PR)
+    const float *__restrict__ O_mirror /*[n][16] or NULL*/, int64_t sym_cols_per_chunk, int SYM_PR,
+    const int64_t *__restrict__ counts, const double *__restrict__ scal)
 {
     static_assert(VEC == 4, "edge kernel reads the padded Zt rows as float4");
+    if (scal) { pw = float(scal[0]); inv_n2 = float(scal[1]); }      // fixed-capacity batch: true sizes on the device
+    const int64_t n_valid = counts ? counts[0] : n_local;
     __shared__ double red[4];
     constexpr int RPB = 256 / LPR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -848,6 +865,7 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
                 const float o = 0.5f * S_all_f[f] + osum[q];
                 float v = (2.0f * o + (acc_in[q] + acc_out[q])) * inv_n2;
                 if (mask) v *= mask[gi * ldz + f];
+                if (i >= n_valid) v = 0.f;                     // padding rows receive no gradient
                 dZ[i * lddz + f] = v;
             }
         }
@@ -866,8 +884,10 @@ __global__ __launch_bounds__(1024) void bce_finalize_kernel(const double *__rest
                                                             int64_t n_edge, const double *__restrict__ S, int DP,
                                                             double pad_terms, double inv_n2,
                                                             float *__restrict__ loss_out,
-                                                            uint64_t *__restrict__ bump_draw)
+                                                            uint64_t *__restrict__ bump_draw,
+                                                            const double *__restrict__ scal)
 {
+    if (scal) { inv_n2 = scal[1]; pad_terms = scal[2]; }
     // 1024 threads, 4 independent loads per trip: the kernel is a few dependent round trips, nothing else
     __shared__ double red[3][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -910,7 +930,7 @@ struct BcePlan {
 
 inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
-bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
+bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p, bool allow_sym = true)
 {
     const int ri = (g_bce_ri == 1 || g_bce_ri == 4) ? g_bce_ri : 2;
     const int64_t ROWS_PER_BLOCK = 64 * ri;
@@ -945,7 +965,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     p.sym = false;
     p.sym_pr = 128;
     p.wmir_bytes = p.omir_bytes = 0;
-    if (g_bce_sym && n_local == n && p.KS == 1 && g_bce_s_bf16 && g_bce_pv_bf16 &&
+    if (allow_sym && g_bce_sym && n_local == n && p.KS == 1 && g_bce_s_bf16 && g_bce_pv_bf16 &&
         n >= (g_bce_sym > 1 ? 512 : 8192)) {           // below ~8 k rows the extra launch costs more than it saves
         const int64_t SYM_PR = (g_bce_sym_ri == 4 || (g_bce_sym_ri == 0 && n >= 32768)) ? 256 : 128;
         p.sym_pr = int(SYM_PR);
@@ -971,7 +991,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     p.zt_bytes = align256(n * p.DP * 4);
     p.zh_bytes = align256(n * p.DP * 2);
     p.cs_bytes = align256(p.prep_blocks * 2 * p.DP * 8);
-    p.s_bytes = align256(2 * p.DP * 8 + p.DP * 4);
+    p.s_bytes = align256(2 * p.DP * 8 + p.DP * 4 + 4 * 8);       // column sums (double x 2, float) + 3 scalars
     p.n_dense = p.row_blocks * p.n_splits;
     p.total_bytes = p.o_bytes + p.zt_bytes + 2 * p.zh_bytes + p.cs_bytes + p.s_bytes +
                     align256((2 * p.n_dense + p.edge_blocks) * 8) + p.wmir_bytes + p.omir_bytes;
@@ -1017,12 +1037,12 @@ template <int VEC, bool WITH_GRAD>
 int launch_edges(const BcePlan &p, const float *Zt, const float *mask, int64_t ldz, int64_t row_begin, int64_t n, int d,
                  const int32_t *ip, const int32_t *ix, const int32_t *tp, const int32_t *tx, float pw, float inv_n2,
                  const float *O, const float *S_all_f, float *dZ, int64_t lddz, double *lp, const float *Omir,
-                 hipStream_t s)
+                 const int64_t *counts, const double *scal, hipStream_t s)
 {
 #define GAE_EDGE(LPR)                                                                                              \
     hipLaunchKernelGGL((bce_edges_kernel<VEC, LPR, WITH_GRAD>), dim3(unsigned(p.edge_blocks)), dim3(256), 0, s, Zt, \
                        mask, ldz, row_begin, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, S_all_f,  \
-                       dZ, lddz, lp, Omir, p.cols_per_split, p.sym_pr)
+                       dZ, lddz, lp, Omir, p.cols_per_split, p.sym_pr, counts, scal)
     switch (p.LPR) {
     case 1: GAE_EDGE(1); break;
     case 2: GAE_EDGE(2); break;
@@ -1059,12 +1079,13 @@ extern "C" int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t n_local, i
     return p.total_bytes + 256;
 }
 
-extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,
-                                    int64_t row_begin, int64_t n_local, const int32_t *indptr,
-                                    const int32_t *indices, const int32_t *t_indptr, const int32_t *t_indices,
-                                    float pos_weight, float dropout_p, uint64_t seed, uint64_t offset,
-                                    uint64_t *draw_dev, float *loss_out, float *dZ, int64_t lddz, void *workspace,
-                                    int64_t workspace_bytes, void *stream)
+namespace {
+int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,
+                     int64_t row_begin, int64_t n_local, const int32_t *indptr,
+                     const int32_t *indices, const int32_t *t_indptr, const int32_t *t_indices,
+                     float pos_weight, float dropout_p, uint64_t seed, uint64_t offset,
+                     uint64_t *draw_dev, float *loss_out, float *dZ, int64_t lddz, void *workspace,
+                     int64_t workspace_bytes, const int64_t *counts, void *stream)
 {
     GAE_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GAE_E_RANGE, "gae_decoder_bce: dropout_p = %g outside [0, 1)",
                 double(dropout_p));
@@ -1079,7 +1100,7 @@ extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, in
     GAE_REQUIRE(Z && loss_out && workspace && (n_local == 0 || indptr), GAE_E_NULL, "gae_decoder_bce: NULL pointer");
     GAE_REQUIRE(!dZ || n_local == 0 || t_indptr, GAE_E_NULL, "gae_decoder_bce: the gradient needs the CSR of A^T");
     BcePlan p;
-    bce_plan(n, n_local, d, true, p);
+    bce_plan(n, n_local, d, true, p, counts == nullptr);
     GAE_REQUIRE(workspace_bytes >= p.total_bytes, GAE_E_WORKSPACE, "gae_decoder_bce: workspace %lld < %lld bytes",
                 (long long)workspace_bytes, (long long)p.total_bytes);
     GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_decoder_bce: workspace not 16-byte aligned");
@@ -1091,7 +1112,9 @@ extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, in
     unsigned short *Zlo = reinterpret_cast<unsigned short *>(w); w += p.zh_bytes;
     double *cs = reinterpret_cast<double *>(w); w += p.cs_bytes;
     double *S = reinterpret_cast<double *>(w);
-    float *S_all_f = reinterpret_cast<float *>(w + 2 * p.DP * 8); w += p.s_bytes;
+    float *S_all_f = reinterpret_cast<float *>(w + 2 * p.DP * 8);
+    double *scal = counts ? reinterpret_cast<double *>(w + 2 * p.DP * 8 + ((p.DP * 4 + 7) & ~7)) : nullptr;
+    w += p.s_bytes;
     double *lp = reinterpret_cast<double *>(w); w += align256((2 * p.n_dense + p.edge_blocks) * 8);
     float *Wmir = reinterpret_cast<float *>(w); w += p.wmir_bytes;
     float *Omir = reinterpret_cast<float *>(w);
@@ -1102,7 +1125,8 @@ extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, in
     }
     hipLaunchKernelGGL(bce_prepare_kernel, dim3(unsigned(p.prep_blocks)), dim3(256), 0, s, Z, mask, ldz, n, int(d), p.DP,
                        row_begin, row_begin + n_local, Zt, Zhi, Zlo, cs, dropout_p, 1.0f / (1.0f - dropout_p), seed,
-                       offset, draw_dev);
+                       offset, draw_dev, counts, scal,
+                       double(n_local) * double((n + TJ - 1) / TJ * TJ));   // pairs the dense kernel evaluates
     GAE_CHECK_LAUNCH("bce_prepare_kernel");
     int rc;
     if (p.sym) {
@@ -1127,14 +1151,40 @@ extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, in
     if (rc) return rc;
     double *lpe = lp + 2 * p.n_dense;
     rc = dZ ? launch_edges<4, true>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr, t_indices,
-                                    pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, p.sym ? Omir : nullptr, s)
+                                    pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, p.sym ? Omir : nullptr,
+                                    counts, scal, s)
             : launch_edges<4, false>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr,
-                                     t_indices, pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, nullptr, s);
+                                     t_indices, pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, nullptr, counts,
+                                     scal, s);
     if (rc) return rc;
     hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(1024), 0, s, lp, p.n_dense, lpe, p.edge_blocks, S, p.DP,
-                       p.pad_terms, inv_n2, loss_out, dropout_p > 0.f ? draw_dev : nullptr);
+                       p.pad_terms, inv_n2, loss_out, dropout_p > 0.f ? draw_dev : nullptr, scal);
     GAE_CHECK_LAUNCH("bce_finalize_kernel");
     return GAE_OK;
+}
+} // namespace
+
+extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,
+                                    int64_t row_begin, int64_t n_local, const int32_t *indptr,
+                                    const int32_t *indices, const int32_t *t_indptr, const int32_t *t_indices,
+                                    float pos_weight, float dropout_p, uint64_t seed, uint64_t offset,
+                                    uint64_t *draw_dev, float *loss_out, float *dZ, int64_t lddz, void *workspace,
+                                    int64_t workspace_bytes, void *stream)
+{
+    return decoder_bce_impl(Z, mask, ldz, n, d, row_begin, n_local, indptr, indices, t_indptr, t_indices, pos_weight,
+                            dropout_p, seed, offset, draw_dev, loss_out, dZ, lddz, workspace, workspace_bytes, nullptr,
+                            stream);
+}
+
+extern "C" int gae_decoder_bce_padded(const float *Z, float *mask, int64_t ldz, int64_t n_cap, int64_t d,
+                                      const int32_t *indptr, const int32_t *indices, const int32_t *t_indptr,
+                                      const int32_t *t_indices, const int64_t *counts_dev, float dropout_p,
+                                      uint64_t seed, uint64_t offset, uint64_t *draw_dev, float *loss_out, float *dZ,
+                                      int64_t lddz, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    GAE_REQUIRE(counts_dev != nullptr, GAE_E_NULL, "gae_decoder_bce_padded: counts_dev is NULL");
+    return decoder_bce_impl(Z, mask, ldz, n_cap, d, 0, n_cap, indptr, indices, t_indptr, t_indices, 0.f, dropout_p,
+                            seed, offset, draw_dev, loss_out, dZ, lddz, workspace, workspace_bytes, counts_dev, stream);
 }
 
 extern "C" int gae_decoder_bce(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,

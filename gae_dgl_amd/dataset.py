@@ -169,9 +169,12 @@ class DeviceGraphDataset(Dataset):
         tdeg = deg if self.symmetric else (self.t_indptr[1:] - self.t_indptr[:-1])
         maxdeg = max(int(deg.max()) if N else 0, int(tdeg.max()) if N else 0)
         self.no_heavy_rows = maxdeg <= ops.SKEW_MIN_MAXDEG      # same rule as ops.spmm_plan(auto): no plan, no sync
-        # packed neighbour table of every batch, written by the gather itself (bonded atoms have at most a handful
-        # of neighbours: 4 slots for ZINC); 0 = none (rows longer than 16 would mostly overflow)
-        self.ell_width = ops.ell_width_for(maxdeg) if 0 < maxdeg <= 16 else 0
+        # packed neighbour table of every batch, written by the gather itself: the narrowest width that holds all
+        # but 1 % of the atoms (bonded atoms have at most a handful of neighbours; the few longer rows continue from
+        # the CSR arrays); 0 = none (a set with hub nodes)
+        self.ell_width = ops.ell_width_for_degrees(torch.maximum(deg, tdeg)) if 0 < maxdeg <= 64 else 0
+        self.max_nodes = int(self.sizes_host.max()) if len(self.sizes_host) else 0
+        self.max_edges = int(max(self.edges_host.max(), self.t_edges_host.max())) if len(self.sizes_host) else 0
         self.ids = np.arange(len(gp) - 1, dtype=np.int64) if ids is None else np.asarray(ids, dtype=np.int64)
         self._pinned = None
 

@@ -48,15 +48,30 @@ def row_quantum(f, dtype):
     return (128 if f * size >= 512 else 16) // size
 
 
+def padded_ld(f, dtype):
+    """leading dimension (elements) this package allocates for an [N, f] operand: 16-byte rows below 512 bytes; from
+    there on whole 128-byte lines and an ODD number of them (F = 500 fp32: 17 lines = 544 floats, not 16): with a
+    power-of-two row pitch the column slice an XCD gathers under feature tiling maps to a fraction of the L1 tag
+    banks / L2 channels (Pubmed layer-1 SpMM 19.1 -> 18.1 us; the pad line is never read or written)"""
+    size = 4 if dtype == torch.float32 else 2
+    q = row_quantum(f, dtype)
+    ld = (f + q - 1) // q * q
+    if f * size >= 512 and (ld * size // 128) % 2 == 0:
+        ld += 128 // size
+    return ld
+
+
 def pad_rows(t, multiple=None):
-    """view of ``t`` [N, F] inside a buffer whose rows are padded (zero pad) to 16 bytes, or to 128 bytes for rows
-    of 512 bytes and more: gives every kernel the aligned vector path for odd feature widths (F = 39 -> ld 40,
-    500 -> 512, 1433 -> 1440, 3703 -> 3712)"""
+    """view of ``t`` [N, F] inside a buffer whose rows are padded (zero pad) to 16 bytes, or to whole 128-byte lines
+    (an odd number of them, see padded_ld) for rows of 512 bytes and more: gives every kernel the aligned vector
+    path for odd feature widths (F = 39 -> ld 40, 500 -> 544, 1433 -> 1440, 3703 -> 3744).  A tensor that already has
+    16-byte / whole-line rows is returned as it is."""
     n, f = t.shape
     q = multiple or row_quantum(f, t.dtype)
     if t.stride(1) == 1 and t.stride(0) % q == 0 and t.stride(0) >= f and t.data_ptr() % (q * t.element_size()) == 0:
         return t
-    buf = torch.zeros(n, (f + q - 1) // q * q, dtype=t.dtype, device=t.device)
+    ld = (f + q - 1) // q * q if multiple else padded_ld(f, t.dtype)
+    buf = torch.zeros(n, ld, dtype=t.dtype, device=t.device)
     buf[:, :f] = t
     return buf[:, :f]
 
@@ -172,45 +187,79 @@ def csr_to_dense(indptr, indices, n_rows, n_cols):
     return out
 
 
-def batch_plan(graph_ptr, ds_indptr, ds_t_indptr, graph_ids):
+def batch_plan(graph_ptr, ds_indptr, ds_t_indptr, graph_ids, out=None):
     """exclusive prefix sums of the selected graphs' node / edge / transposed-edge counts, computed on the device
     (gae_batch_plan): (node_ptr, edge_ptr, t_edge_ptr or None), int64 [B + 1] each.  ``ds_t_indptr`` None = the
-    dataset is symmetric."""
+    dataset is symmetric.  ``out``: an int64 [3 or 2, B + 1] buffer to write into."""
     gids = _gpu(graph_ids, "graph_ids")
     B = gids.numel()
     dev = gids.device
-    buf = torch.empty(3 if ds_t_indptr is not None else 2, B + 1, dtype=torch.int64, device=dev)
+    rows = 3 if ds_t_indptr is not None else 2
+    buf = torch.empty(rows, B + 1, dtype=torch.int64, device=dev) if out is None else out
+    if buf.shape != (rows, B + 1) or buf.dtype != torch.int64 or not buf.is_contiguous():
+        raise GaeHipError("batch_plan: `out` must be a contiguous int64 [rows, B + 1] buffer")
     with _on_device(dev):
         _lib.call("gae_batch_plan", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_t_indptr), _ptr(gids), B, _ptr(buf[0]),
                   _ptr(buf[1]), _ptr(buf[2]) if ds_t_indptr is not None else None, _stream())
     return buf[0], buf[1], (buf[2] if ds_t_indptr is not None else None)
 
 
+def batch_select(order, cursor, batch_graphs, out_ids):
+    """out_ids[b] = order[cursor * batch_graphs + b]; cursor += 1 -- all on the device (gae_batch_select), so a
+    replayed HIP graph walks an epoch order that was uploaded once.  ``cursor`` int64[1], ``out_ids`` int64[B]."""
+    order = _gpu(order, "order")
+    with _on_device(order.device):
+        _lib.call("gae_batch_select", _ptr(order), order.numel(), _ptr(cursor), int(batch_graphs), _ptr(out_ids),
+                  _stream())
+    return out_ids
+
+
+def batch_feature_ld(ds_feat, n_feat=None):
+    """(F, leading dimension, dtype) of the feature matrix gae_batch_gather writes for ``ds_feat``"""
+    F = ds_feat.shape[1] if n_feat is None else int(n_feat)
+    odt = torch.float32 if ds_feat.dtype == torch.uint8 else ds_feat.dtype
+    q = 4 if odt == torch.float32 else 8
+    return F, max((F + q - 1) // q * q, 1), odt                  # batch features keep 16-byte rows
+
+
 def batch_gather(graph_ptr, ds_indptr, ds_indices, ds_feat, graph_ids, node_ptr, edge_ptr, n_nodes, n_edges,
-                 ell_width=0, n_feat=None):
+                 ell_width=0, n_feat=None, out=None, pad_to_capacity=False, counts=None):
     """dgl.batch of the graphs ``graph_ids`` of a device-resident dataset (gae_batch_gather): returns
     (indptr, indices, feat or None, packed table or None).  ``ds_feat`` None = structure only; uint8 features come
-    back as fp32; ``n_feat`` = number of feature columns when ``ds_feat`` carries pad columns."""
+    back as fp32; ``n_feat`` = number of feature columns when ``ds_feat`` carries pad columns.
+    ``out`` = (indptr, indices, feat, table) buffers to write into (static buffers of a captured step);
+    ``pad_to_capacity``: n_nodes / n_edges are CAPACITIES, the rows behind the batch become isolated zero-feature
+    nodes and the true {nodes, edges} go to ``counts`` (int64[2], device)."""
     dev = ds_indptr.device
-    out_indptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
-    out_indices = torch.empty(n_edges, dtype=torch.int32, device=dev)
-    table = torch.empty(n_nodes * ell_width, dtype=torch.int32, device=dev) if ell_width else None
-    feat = out_feat = None
+    if out is not None:
+        out_indptr, out_indices, out_feat, table = out
+    else:
+        out_indptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+        out_indices = torch.empty(n_edges, dtype=torch.int32, device=dev)
+        table = torch.empty(n_nodes * ell_width, dtype=torch.int32, device=dev) if ell_width else None
+        out_feat = None
+    feat = None
     ldf = F = ldo = 0
     code = F32
     if ds_feat is not None:
         feat, ldf = _rowmajor(ds_feat, "ds_feat")
-        F = feat.shape[1] if n_feat is None else int(n_feat)
+        F, ldo, odt = batch_feature_ld(feat, n_feat)
         code = _lib.U8 if feat.dtype == torch.uint8 else _dtype_code(feat)
-        odt = torch.float32 if feat.dtype == torch.uint8 else feat.dtype
-        q = 4 if odt == torch.float32 else 8
-        ldo = max((F + q - 1) // q * q, 1)                      # batch features keep 16-byte rows
-        out_feat = torch.empty(n_nodes, ldo, dtype=odt, device=dev)       # pad columns are zeroed by the kernel
+        if out_feat is None:
+            out_feat = torch.empty(n_nodes, ldo, dtype=odt, device=dev)   # pad columns are zeroed by the kernel
+        elif out_feat.shape != (n_nodes, ldo) or out_feat.dtype != odt or not out_feat.is_contiguous():
+            raise GaeHipError("batch_gather: `out` feature buffer has the wrong shape / dtype")
+    else:
+        out_feat = None
+    if out_indptr.numel() != n_nodes + 1 or out_indices.numel() < n_edges or (
+            ell_width and (table is None or table.numel() != n_nodes * ell_width)):
+        raise GaeHipError("batch_gather: `out` structure buffers have the wrong size")
     with _on_device(dev):
         _lib.call("gae_batch_gather", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_indices), _ptr(feat), max(ldf, F), F,
                   code, _ptr(graph_ids), graph_ids.numel(), _ptr(node_ptr), _ptr(edge_ptr),
-                  n_nodes, n_edges, _ptr(out_indptr), _ptr(out_indices), _ptr(out_feat), max(ldo, F), _ptr(table),
-                  int(ell_width), _stream())
+                  n_nodes, n_edges, _ptr(out_indptr), _ptr(out_indices), _ptr(out_feat), max(ldo, F),
+                  _ptr(table) if ell_width else None, int(ell_width), n_nodes if pad_to_capacity else 0,
+                  _ptr(counts), _stream())
     return out_indptr, out_indices, (out_feat[:, :F] if out_feat is not None else None), table
 
 
@@ -285,6 +334,22 @@ def ell_width_for(max_deg):
     return 4 if max_deg <= 4 else 8 if max_deg <= 8 else _lib.SPMM_ELL_WIDTH
 
 
+ELL_OVERFLOW_SHARE = 0.01     # rows that may continue from the CSR arrays (they take a slower path in the kernel)
+
+
+def ell_width_for_degrees(deg, cap=None):
+    """narrowest table width that holds all but ELL_OVERFLOW_SHARE of the rows (``deg``: device tensor of row
+    lengths; rows above ``cap`` are heavy rows of a skew plan and do not count): a molecule set whose atoms have at
+    most 4 bonds except for a handful gets 4 slots = 16 bytes per row instead of 64.  One host read-back."""
+    if deg.numel() == 0:
+        return 4
+    d = deg if cap is None else deg[deg <= cap]
+    if d.numel() == 0:
+        return 4
+    over = torch.stack([(d > 4).float().mean(), (d > 8).float().mean()]).tolist()
+    return 4 if over[0] <= ELL_OVERFLOW_SHARE else 8 if over[1] <= ELL_OVERFLOW_SHARE else _lib.SPMM_ELL_WIDTH
+
+
 def table_plan(table, ell_width):
     """plan that only carries an already-built packed neighbour table (no heavy rows)"""
     return SpmmPlan(SKEW_THRESHOLD, SKEW_SEGMENT, 0, 0, None, None, None, table, ell_width)
@@ -323,7 +388,7 @@ def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_
             n_heavy = n_seg = 0
         if want_ell:
             if ell_width is None:
-                ell_width = ell_width_for(min(max_deg, threshold) if heavy else max_deg)
+                ell_width = ell_width_for_degrees(indptr[1:] - indptr[:-1], threshold if heavy else None)
             table = torch.empty(n * ell_width, dtype=torch.int32, device=dev)
             _lib.call("gae_spmm_ell_build", _ptr(indptr), _ptr(indices), n, ell_width,
                       threshold if heavy else 2 ** 31 - 1, _ptr(table), _stream())
@@ -416,8 +481,7 @@ def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=Non
     n_cols, F = H.shape
     if out is None:
         # rows padded to 16 / 128 bytes: keeps the vector path for any F (the pad columns are never read as data)
-        q = row_quantum(F, H.dtype)
-        out = torch.empty(n_rows, (F + q - 1) // q * q, dtype=H.dtype, device=H.device)[:, :F]
+        out = torch.empty(n_rows, padded_ld(F, H.dtype), dtype=H.dtype, device=H.device)[:, :F]
         out_padded = True
     if accumulate and out is None:
         raise GaeHipError("spmm: accumulate=True adds to `out`")
@@ -577,8 +641,11 @@ def decoder_dense_bwd_raw(G, Z, mask=None):
     return dZ
 
 
-def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, n_local=None, dropout=None):
+def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, n_local=None, dropout=None,
+                    counts=None):
     """fused decoder + weighted BCE (mean): returns (loss[1], dZ or None).
+    ``counts`` (int64[2] on the device: true {nodes, edges}) = Z / csr are a fixed-capacity batch
+    (gae_decoder_bce_padded): pos_weight and the mean come from the counts, ``pos_weight`` is ignored.
     ``row_begin/n_local`` select a row window (row-sharded form): Z/mask stay the
     full [n, d] arrays, csr/csc are the window's local row blocks.
     ``dropout`` = (p, seed, offset, draw_counter): the mask of this draw is generated inside the launch, written
@@ -603,6 +670,14 @@ def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, 
         ws = _workspace(nbytes, dev)
 
         def launch():
+            if counts is not None:
+                if row_begin or n_local != n:
+                    raise GaeHipError("decoder_bce: a fixed-capacity batch has no row window")
+                _lib.call("gae_decoder_bce_padded", _ptr(Z), _ptr(mask), max(d, 1), n, d, _ptr(indptr),
+                          _ptr(indices), _ptr(t_indptr), _ptr(t_indices), _ptr(counts), float(p_drop),
+                          int(seed) & (2 ** 64 - 1), int(offset), _ptr(draws), _ptr(loss), _ptr(dZ), max(d, 1),
+                          _ptr(ws), ws.numel(), _stream())
+                return
             _lib.call("gae_decoder_bce_rows", _ptr(Z), _ptr(mask), max(d, 1), n, d, int(row_begin), n_local,
                       _ptr(indptr), _ptr(indices), _ptr(t_indptr), _ptr(t_indices), float(pos_weight), float(p_drop),
                       int(seed) & (2 ** 64 - 1), int(offset), _ptr(draws), _ptr(loss), _ptr(dZ), max(d, 1), _ptr(ws),
@@ -682,10 +757,11 @@ class DecoderBCEFunction(torch.autograd.Function):
     def forward(ctx, Z, mask, graph, dropout=None):
         n = graph.number_of_nodes()
         nnz = graph.number_of_edges()
-        pw = (float(n) * float(n) - float(nnz)) / float(nnz)      # train_inductive.py:46
+        counts = getattr(graph, "batch_counts", None)             # fixed-capacity batch: true sizes on the device
+        pw = 0.0 if counts is not None else (float(n) * float(n) - float(nnz)) / float(nnz)  # train_inductive.py:46
         need = ctx.needs_input_grad[0]
         loss, dZ = decoder_bce_raw(Z, mask, graph.csr(), graph.csc() if need else None, pw, want_grad=need,
-                                   dropout=dropout)
+                                   dropout=dropout, counts=counts)
         ctx.save_for_backward(dZ)
         return loss.reshape(())
 
@@ -759,6 +835,8 @@ def decoder_bce(Z, mask, graph, dropout=None):
     """``dropout`` = (p, seed, offset, draw_counter): draw the mask inside the fused launch into ``mask``.
     Embeddings wider than FUSED_MAX_D take the dense HIP chain (same value, O(N^2) memory)."""
     if Z.shape[1] > FUSED_MAX_D:
+        if getattr(graph, "batch_counts", None) is not None:
+            raise GaeHipError(f"fixed-capacity batches need an embedding width <= {FUSED_MAX_D}")
         if dropout is not None and dropout[0]:
             p_drop, seed, offset, draws = dropout
             mask.copy_(dropout_mask(tuple(Z.shape), p_drop, seed, offset, Z.device, draw_counter=draws))

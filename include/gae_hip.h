@@ -114,7 +114,17 @@ int gae_csr_to_dense(const int32_t *indptr, const int32_t *indices, int64_t n_ro
  *                   same dtype as ds_feat, fp32 for GAE_U8; may be NULL: structure only), and -- optional, out_ell
  *                   != NULL -- the packed neighbour table of the batch CSR (gae_spmm_ell_build's format,
  *                   ell_width 4 / 8 / 16) written in the same pass.  N_b / E_b: the totals out_node_ptr[n_graphs] /
- *                   out_edge_ptr[n_graphs], which the caller also knows from its host copy of the per-graph sizes. */
+ *                   out_edge_ptr[n_graphs], which the caller also knows from its host copy of the per-graph sizes.
+ *
+ * Fixed-capacity batches (HIP-graph capture of the inductive step: every replay must launch the same shapes):
+ * gae_batch_gather with cap_nodes > 0 pads the batch to cap_nodes rows -- the rows behind the last member graph
+ * become isolated nodes (empty CSR rows, zero features, empty table rows) -- and writes the true sizes {nodes,
+ * edges} to out_counts (int64[2], device), which gae_decoder_bce_padded reads.  In that mode n_batch_nodes /
+ * n_batch_edges are upper bounds (the capacity of the output arrays), not the exact totals.
+ * gae_batch_select: out_ids[b] = order[*cursor_dev * batch_graphs + b], then *cursor_dev += 1 (device-side cursor:
+ * a replayed graph walks an epoch order that was uploaded once). */
+int gae_batch_select(const int64_t *order, int64_t n_order, int64_t *cursor_dev, int64_t batch_graphs,
+                     int64_t *out_ids, void *stream);
 int gae_batch_plan(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
                    const int64_t *graph_ids, int64_t n_graphs, int64_t *out_node_ptr, int64_t *out_edge_ptr,
                    int64_t *out_t_edge_ptr, void *stream);
@@ -124,7 +134,8 @@ int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indptr, const i
                      const int64_t *out_node_ptr, const int64_t *out_edge_ptr,
                      int64_t n_batch_nodes, int64_t n_batch_edges,
                      int32_t *out_indptr, int32_t *out_indices,
-                     void *out_feat, int64_t ld_out, int32_t *out_ell, int32_t ell_width, void *stream);
+                     void *out_feat, int64_t ld_out, int32_t *out_ell, int32_t ell_width,
+                     int64_t cap_nodes, int64_t *out_counts, void *stream);
 
 /* ---- K1/K2: sparse aggregation ---------------------------------------------
  * M = diag(row_scale) * A * diag(col_scale) * H,  A given as CSR.
@@ -307,6 +318,19 @@ int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, int64_t n, in
                          float dropout_p, uint64_t seed, uint64_t offset, uint64_t *draw_dev,
                          float *loss_out, float *dZ, int64_t lddz,
                          void *workspace, int64_t workspace_bytes, void *stream);
+
+/* The same loss on a FIXED-CAPACITY batch (gae_batch_gather with cap_nodes > 0): Z / mask / dZ have n_cap rows, the
+ * CSRs n_cap rows; counts_dev (int64[2], device) holds the true {nodes, edges} of this batch.  Rows >= counts[0]
+ * are padding: they take no part in the loss (pos_weight and the mean use the true N and E, read on the device)
+ * and receive a zero gradient.  Lets the inductive training step of gae_dgl/train_inductive.py:92-95 run as ONE
+ * captured HIP graph although every batch has a different size.  Workspace: gae_decoder_bce_workspace_bytes(n_cap,
+ * n_cap, d). */
+int gae_decoder_bce_padded(const float *Z, float *mask, int64_t ldz, int64_t n_cap, int64_t d,
+                           const int32_t *indptr, const int32_t *indices,
+                           const int32_t *t_indptr, const int32_t *t_indices, const int64_t *counts_dev,
+                           float dropout_p, uint64_t seed, uint64_t offset, uint64_t *draw_dev,
+                           float *loss_out, float *dZ, int64_t lddz,
+                           void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Reference-shaped loss on MATERIALISED logits: F.binary_cross_entropy_with_logits(adj_logits, adj,
  * pos_weight=pos_weight) with the default mean reduction (gae_dgl/train_inductive.py:48) and dLoss/dLogits.  Used

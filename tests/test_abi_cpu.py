@@ -115,7 +115,11 @@ def test_row_layout_helpers_are_host_logic():
     assert ops.row_quantum(39, torch.float32) == 4 and ops.row_quantum(127, torch.float32) == 4
     assert ops.row_quantum(128, torch.float32) == 32 and ops.row_quantum(3703, torch.float32) == 32
     assert ops.row_quantum(255, torch.bfloat16) == 8 and ops.row_quantum(256, torch.bfloat16) == 64
-    for f, ld in ((39, 40), (500, 512), (1433, 1440), (3703, 3712), (32, 32)):
+    assert ops.padded_ld(500, torch.float32) == 544 and ops.padded_ld(1433, torch.float32) == 1440    # odd line counts
+    assert ops.padded_ld(39, torch.float32) == 40 and ops.padded_ld(256, torch.bfloat16) == 320
+    already = torch.zeros(3, 512)[:, :500]
+    assert ops.pad_rows(already) is already or already.data_ptr() % 128      # whole-line rows are taken as they are
+    for f, ld in ((39, 40), (500, 544), (1433, 1440), (3703, 3744), (32, 32)):
         x = torch.arange(3 * f, dtype=torch.float32).reshape(3, f)
         y = ops.pad_rows(x)
         assert y.shape == (3, f) and y.stride() == (ld, 1) and torch.equal(y, x)

@@ -44,7 +44,7 @@ out = ops.pad_rows(torch.empty(n, F, device=dev))
 if a.plain:
     plan = None
 elif name == "zincb":      # a training batch carries the packed table its gather wrote (dataset.DeviceGraphDataset)
-    plan = ops.spmm_plan(ip, indices=ix, ell=True, ell_width=ops.ell_width_for(int((ip[1:] - ip[:-1]).max())))
+    plan = ops.spmm_plan(ip, indices=ix, ell=True, ell_width=ops.ell_width_for_degrees(ip[1:] - ip[:-1]))
 else:
     plan = ops.spmm_plan(ip, indices=ix if bd is None else None)
 scattered = (not a.plain) and bd is None and F > ops.TILE_MIN_F and ops.gather_scattered(ip, ix, F * 4)
