@@ -323,7 +323,9 @@ class ZincWorkload:
         self.B = B
         torch.manual_seed(0)
         self.model = G.GAE(39, [32, 16]).to(dev)
-        self.opt, opt_name = make_adam(self.model.parameters(), 1e-3, args)   # train_inductive.py:25
+        self.use_graph = (not args.no_hipgraph) and args.loss == "fused"
+        self.opt, opt_name = make_adam(self.model.parameters(), 1e-3, args, self.use_graph)   # train_inductive.py:25
+        self.runner = None
         self.rng = np.random.default_rng(0)
         self.perm = self.rng.permutation(n_graphs)
         self.d_perm = torch.from_numpy(self.perm).to(dev)      # the epoch order lives on the device (ds.epoch())
@@ -333,6 +335,8 @@ class ZincWorkload:
         self.meta = {"workload": "zinc250k-inductive-gae", "batch_graphs": B, "nodes_per_batch~": nb,
                      "edges_per_batch~": eb, "in_dim": 39, "hidden_dims": [32, 16], "loss": "fused-bce",
                      "optimizer": "adam lr=1e-3: " + opt_name, "dataset_graphs": n_graphs, "parallelism": "1 GPU",
+                     "launch": "hipGraph replay per batch (collate + step on a fixed-capacity batch, "
+                               "capture.CapturedInductiveStep)" if self.use_graph else "eager",
                      "batches_per_epoch_at_239455_graphs": int(np.ceil(239455 / B))}
         self.dominant = None
         self.pmc_key = "zinc-batch4096-F39" if B == 4096 else ""
@@ -349,7 +353,19 @@ class ZincWorkload:
         return lambda: ops.spmm_raw(ip, ix, H, bg.number_of_nodes(), out=out, out_padded=True,
                                     blockdiag=bg.block_diag, plan=bg.spmm_plan(False))
 
+    def capture(self):
+        from gae_dgl_amd.capture import CapturedInductiveStep
+        self.runner = CapturedInductiveStep(self.model, self.opt, self.ds, self.B)
+        self._left = 0
+        self.meta["capacity"] = None
+
     def step(self):
+        if self.runner is not None:
+            if self._left == 0:                     # next epoch: upload the order again, reset the device cursor
+                self._left = self.runner.begin_epoch(self.perm)
+                self.meta["capacity"] = {"nodes": self.runner.cap_nodes, "edges": self.runner.cap_edges}
+            self._left -= 1
+            return self.runner.step()
         ids = self.perm[self.cursor:self.cursor + self.B]
         self._lo = self.cursor
         self.cursor = (self.cursor + self.B) % (len(self.perm) - self.B)

@@ -43,6 +43,7 @@ SIGNATURES = {
     "gae_last_error": (ctypes.c_char_p, []),
     "gae_device_info_get": (_int, [_int, ctypes.POINTER(DeviceInfo)]),
     "gae_tuning_set": (_int, [ctypes.c_char_p, _i64]),
+    "gae_tuning_get": (_int, [ctypes.c_char_p, _p]),
     "gae_csr_from_coo_workspace_bytes": (_i64, [_i64, _i64]),
     "gae_csr_from_coo": (_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _i64, _p, _p]),
     "gae_degree_norm": (_int, [_p, _i64, _p, _p, _p]),

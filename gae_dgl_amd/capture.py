@@ -8,6 +8,8 @@ PyTorch's current stream) and replayed per epoch: no Python / launch overhead
 between kernels.  The decoder's dropout mask still changes every replay
 because its Philox draw counter lives in device memory (gae_decoder_bce), and so does Adam's step counter
 (gae_dgl_amd.optim.Adam / torch.optim.Adam(capturable=True))."""
+import gc
+
 import torch
 
 from . import ops
@@ -22,12 +24,14 @@ class CapturedTrainStep:
 
     def __init__(self, model, optimizer, graph, features, loss_fn=None, warmup=3):
         self.model, self.opt, self.g, self.x = model, optimizer, graph, features
+        self._params = [p for group in optimizer.param_groups for p in group["params"]]
         self.loss_fn = loss_fn or (lambda m, g: m.reconstruction_loss(g))
         for group in optimizer.param_groups:           # Adam must keep its step counter on the device
             if "capturable" in group and not group["capturable"]:
                 raise ValueError("build the optimizer with capturable=True to capture its step")
         # structure is static: build it outside the capture (CSR build sorts and reads back a status word)
         graph.csr(); graph.csc(); graph.spmm_plan(False); graph.spmm_plan(True); graph.scattered()
+        gc.collect()       # autograd graphs of earlier eager steps that only a collection frees (see the class note)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -50,7 +54,7 @@ class CapturedTrainStep:
     def _fwd_bwd_step(self):
         self.g.ndata['h'] = self.x
         loss = self.loss_fn(self.model, self.g)
-        ops.backward(loss)
+        ops.backward(loss, self._params)          # autograd.grad: no AccumulateGrad nodes (stream-bound) in the capture
         self.opt.step()
         return loss.detach()
 
@@ -90,11 +94,12 @@ class CapturedInductiveStep:
                 ...
     """
 
-    def __init__(self, model, optimizer, dataset, batch_size, warmup=2, margin=1.02):
+    def __init__(self, model, optimizer, dataset, batch_size, warmup=2, margin=1.005):
         if not dataset.ell_width or not dataset.no_heavy_rows:
             raise ops.GaeHipError("CapturedInductiveStep needs a dataset of low-degree graphs (packed neighbour "
                                   "table); skewed graphs take the eager path")
         self.model, self.opt, self.ds = model, optimizer, dataset
+        self._params = [p for group in optimizer.param_groups for p in group["params"]]
         self.B = int(batch_size)
         if self.B < 1 or self.B > len(dataset):
             raise ValueError("batch_size must be in [1, len(dataset)]")
@@ -164,7 +169,7 @@ class CapturedInductiveStep:
         g.ndata.clear()
         g.ndata['h'] = self.x
         loss = self.model.reconstruction_loss(g)
-        ops.backward(loss)
+        ops.backward(loss, self._params)          # autograd.grad: no AccumulateGrad nodes (stream-bound) in the capture
         self.opt.step()
         return loss.detach()
 
@@ -183,6 +188,8 @@ class CapturedInductiveStep:
         self._allocate(cap_nodes, cap_edges)
         # the warm-up steps (allocator, lazy optimiser state, autograd streams) must not train the model: run one to
         # create every lazily-built tensor, snapshot, run the rest, restore
+        gc.collect()       # autograd graphs of earlier eager steps that only a collection frees keep AccumulateGrad
+        #                    nodes bound to the default stream, which would invalidate the capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -215,6 +222,7 @@ class CapturedInductiveStep:
         self.opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.loss = self._step_body()
+        self.g.ndata.clear()            # drops the captured iteration's autograd graph (kept alive by the embedding)
         self._captured_hyper = self._hyper()
         self.captures += 1
 

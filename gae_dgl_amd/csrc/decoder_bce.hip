@@ -930,7 +930,7 @@ struct BcePlan {
 
 inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
-bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p, bool allow_sym = true)
+bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
 {
     const int ri = (g_bce_ri == 1 || g_bce_ri == 4) ? g_bce_ri : 2;
     const int64_t ROWS_PER_BLOCK = 64 * ri;
@@ -965,7 +965,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p, bo
     p.sym = false;
     p.sym_pr = 128;
     p.wmir_bytes = p.omir_bytes = 0;
-    if (allow_sym && g_bce_sym && n_local == n && p.KS == 1 && g_bce_s_bf16 && g_bce_pv_bf16 &&
+    if (g_bce_sym && n_local == n && p.KS == 1 && g_bce_s_bf16 && g_bce_pv_bf16 &&
         n >= (g_bce_sym > 1 ? 512 : 8192)) {           // below ~8 k rows the extra launch costs more than it saves
         const int64_t SYM_PR = (g_bce_sym_ri == 4 || (g_bce_sym_ri == 0 && n >= 32768)) ? 256 : 128;
         p.sym_pr = int(SYM_PR);
@@ -1100,7 +1100,7 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
     GAE_REQUIRE(Z && loss_out && workspace && (n_local == 0 || indptr), GAE_E_NULL, "gae_decoder_bce: NULL pointer");
     GAE_REQUIRE(!dZ || n_local == 0 || t_indptr, GAE_E_NULL, "gae_decoder_bce: the gradient needs the CSR of A^T");
     BcePlan p;
-    bce_plan(n, n_local, d, true, p, counts == nullptr);
+    bce_plan(n, n_local, d, true, p);
     GAE_REQUIRE(workspace_bytes >= p.total_bytes, GAE_E_WORKSPACE, "gae_decoder_bce: workspace %lld < %lld bytes",
                 (long long)workspace_bytes, (long long)p.total_bytes);
     GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_decoder_bce: workspace not 16-byte aligned");
@@ -1126,7 +1126,9 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
     hipLaunchKernelGGL(bce_prepare_kernel, dim3(unsigned(p.prep_blocks)), dim3(256), 0, s, Z, mask, ldz, n, int(d), p.DP,
                        row_begin, row_begin + n_local, Zt, Zhi, Zlo, cs, dropout_p, 1.0f / (1.0f - dropout_p), seed,
                        offset, draw_dev, counts, scal,
-                       double(n_local) * double((n + TJ - 1) / TJ * TJ));   // pairs the dense kernel evaluates
+                       // pairs the dense kernel leaves in its log2 sum: the symmetric kernel corrects its own pad
+                       // columns (the n x n square remains), the full kernel counts whole column tiles
+                       p.sym ? double(n) * double(n) : double(n_local) * double((n + TJ - 1) / TJ * TJ));
     GAE_CHECK_LAUNCH("bce_prepare_kernel");
     int rc;
     if (p.sym) {

@@ -1114,29 +1114,34 @@ extern "C" int gae_spmm_csr_blockdiag(const int32_t *indptr, const int32_t *indi
 
 namespace gae { int *dense_knob(const char *name); int *bce_knob(const char *name); }
 
-extern "C" int gae_tuning_set(const char *name, int64_t value)
+namespace {
+int *find_knob(const char *name)
 {
-    GAE_REQUIRE(name != nullptr, GAE_E_NULL, "gae_tuning_set: name is NULL");
     const struct { const char *k; int *v; } knobs[] = {
         {"spmm_variant", &g_spmm_variant}, {"spmm_rpg", &g_spmm_rpg}, {"spmm_nt", &g_spmm_nt},
         {"spmm_tile_vecs", &g_spmm_tile_vecs}, {"spmm_ell", &g_spmm_ell}};
     for (const auto &kv : knobs)
-        if (strcmp(kv.k, name) == 0) {
-            *kv.v = int(value);
-            return GAE_OK;
-        }
-    if (int *k = gae::spmm_ell_knob(name)) {
-        *k = int(value);
-        return GAE_OK;
-    }
-    if (int *k = gae::dense_knob(name)) {
-        *k = int(value);
-        return GAE_OK;
-    }
-    if (int *k = gae::bce_knob(name)) {
-        *k = int(value);
-        return GAE_OK;
-    }
-    gae::set_error("gae_tuning_set: unknown knob '%s'", name);
-    return GAE_E_RANGE;
+        if (strcmp(kv.k, name) == 0) return kv.v;
+    if (int *k = gae::spmm_ell_knob(name)) return k;
+    if (int *k = gae::dense_knob(name)) return k;
+    return gae::bce_knob(name);
+}
+} // namespace
+
+extern "C" int gae_tuning_set(const char *name, int64_t value)
+{
+    GAE_REQUIRE(name != nullptr, GAE_E_NULL, "gae_tuning_set: name is NULL");
+    int *k = find_knob(name);
+    GAE_REQUIRE(k != nullptr, GAE_E_RANGE, "gae_tuning_set: unknown knob '%s'", name);
+    *k = int(value);
+    return GAE_OK;
+}
+
+extern "C" int gae_tuning_get(const char *name, int64_t *value_out)
+{
+    GAE_REQUIRE(name != nullptr && value_out != nullptr, GAE_E_NULL, "gae_tuning_get: NULL argument");
+    const int *k = find_knob(name);
+    GAE_REQUIRE(k != nullptr, GAE_E_RANGE, "gae_tuning_get: unknown knob '%s'", name);
+    *value_out = *k;
+    return GAE_OK;
 }

@@ -306,5 +306,12 @@ class DeviceLoader:
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
+    def next_order(self):
+        """the graph ids of the next epoch, in batch order (consumes the same random numbers as __iter__)"""
+        order = self.dataset.ids.copy()
+        if self.shuffle:
+            self.rng.shuffle(order)
+        return order
+
     def __iter__(self):
         return self.dataset.epoch(self.batch_size, shuffle=self.shuffle, rng=self.rng)

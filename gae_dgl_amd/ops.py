@@ -695,23 +695,28 @@ def _scattered(graph, H):
 
 
 class SpMMFunction(torch.autograd.Function):
-    """update_all(copy_src, sum) with its backward  dH = A^T dM  (gae.py:28)."""
+    """update_all(copy_src, sum) with its backward  dH = A^T dM  (gae.py:28).
+    The backward's operands (CSR of A^T, plan, norm) are taken from the graph in forward(): the autograd node must
+    not hold the graph itself -- the graph holds the output (``g.ndata['h']``), whose grad_fn would hold the graph
+    again, a cycle only the garbage collector can free (batches of an eager epoch would pile up in HBM until it
+    runs, and their AccumulateGrad nodes would stay bound to the stream of a long-finished iteration)."""
 
     @staticmethod
     def forward(ctx, H, graph, use_norm):
         indptr, indices = graph.csr()
         norm = graph.norm() if use_norm else None
-        ctx.graph, ctx.use_norm = graph, use_norm
-        return spmm_raw(indptr, indices, H, graph.number_of_nodes(), norm, norm, plan=graph.spmm_plan(False),
-                        blockdiag=graph.block_diag, scattered=_scattered(graph, H))
+        n = graph.number_of_nodes()
+        sc = _scattered(graph, H)
+        if ctx.needs_input_grad[0]:
+            ctx.bwd = (graph.csc(), n, norm, graph.spmm_plan(True), graph.block_diag, sc)
+        return spmm_raw(indptr, indices, H, n, norm, norm, plan=graph.spmm_plan(False),
+                        blockdiag=graph.block_diag, scattered=sc)
 
     @staticmethod
     def backward(ctx, dM):
-        g = ctx.graph
-        t_indptr, t_indices = g.csc()
-        norm = g.norm() if ctx.use_norm else None
-        return spmm_raw(t_indptr, t_indices, dM, g.number_of_nodes(), norm, norm, plan=g.spmm_plan(True),
-                        blockdiag=g.block_diag, scattered=_scattered(g, dM)), None, None
+        (t_indptr, t_indices), n, norm, plan_t, blockdiag, sc = ctx.bwd
+        return spmm_raw(t_indptr, t_indices, dM, n, norm, norm, plan=plan_t, blockdiag=blockdiag,
+                        scattered=sc), None, None
 
 
 class LinearFunction(torch.autograd.Function):
@@ -821,14 +826,22 @@ def _is_unit(g):
     return one is not None and g.dim() == 0 and g.data_ptr() == one.data_ptr()
 
 
-def backward(loss):
+def backward(loss, params=None):
     """``loss.backward()`` with the upstream gradient 1 handed over as a cached device constant: the fused loss
     recognises it and returns its stored gradient as is (saves the fill and the multiply launch of a plain
-    ``loss.backward()``; 9 us of a 190 us Cora step)."""
+    ``loss.backward()``; 9 us of a 190 us Cora step).
+    ``params``: write the gradients of exactly these tensors through ``torch.autograd.grad`` (p.grad is REPLACED, not
+    accumulated).  No AccumulateGrad node takes part then -- those remember the stream of the iteration that
+    created them, which breaks a HIP-graph capture that follows eager steps on another stream."""
     one = _UNIT.get(loss.device)
     if one is None:
         one = _UNIT[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
-    loss.backward(gradient=one)
+    if params is None:
+        loss.backward(gradient=one)
+        return
+    params = [p for p in params if p.requires_grad]
+    for p, g in zip(params, torch.autograd.grad(loss, params, grad_outputs=one, allow_unused=True)):
+        p.grad = g
 
 
 def decoder_bce(Z, mask, graph, dropout=None):

@@ -50,6 +50,11 @@ def build_parser():
     ap.add_argument("--loss", choices=["fused", "dense"], default="fused")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no_plot", action="store_true")
+    ap.add_argument("--capture", choices=["auto", "on", "off"], default="auto",
+                    help="run the training batches as ONE captured HIP graph each (collate + forward + loss + "
+                         "backward + Adam on a fixed-capacity batch, capture.CapturedInductiveStep): 7x faster steps "
+                         "at batch 128, where the eager step is host-bound.  auto = on with the fused loss and the "
+                         "device-resident iterator")
     ap.add_argument("--dataloader", action="store_true",
                     help="batch through torch's DataLoader + collate exactly like the reference (one small pinned "
                          "copy of the graph ids per batch) instead of the device-resident epoch iterator")
@@ -125,9 +130,15 @@ def load_dataset(args):
                      ".npz format (DeviceGraphDataset.save: graph_ptr, src, dst, feat)")
 
 
-def _run_epoch(trainer, loader, train):
+def _run_epoch(trainer, loader, train, captured=None):
     """mean loss over the loader's batches; the running sum stays on the device (no host sync per iteration)"""
     total = torch.zeros((), device=device)
+    if captured is not None:                     # the same batches (same shuffle), one graph launch each
+        n = 0
+        for loss in captured.epoch(loader.next_order()):
+            total += loss
+            n += 1
+        return float(total) / max(n, 1)
     for bg in loader:
         for install in (bg.set_e_initializer, bg.set_n_initializer):      # train_inductive.py:93-94
             install(dgl.init.zero_initializer)
@@ -160,11 +171,21 @@ def main(argv=None):
         else:                    # same batches, assembled from an epoch order that already lives on the device
             loaders[split] = part.loader(args.batch_size, shuffle=shuffle, seed=args.seed)
     trainer = Trainer(model, args, fused=(args.loss == "fused"))
+    captured = None
+    can_capture = (args.loss == "fused" and not args.dataloader and len(loaders["train"].dataset) >= args.batch_size
+                   and loaders["train"].dataset.ell_width and loaders["train"].dataset.no_heavy_rows
+                   and args.hidden_dims[-1] <= ops.FUSED_MAX_D)
+    if args.capture == "on" and not can_capture:
+        raise ValueError("--capture on needs the fused loss, the device-resident iterator, a low-degree dataset with "
+                         "at least one full batch and an embedding width <= %d" % ops.FUSED_MAX_D)
+    if args.capture != "off" and can_capture:
+        from gae_dgl_amd.capture import CapturedInductiveStep
+        captured = CapturedInductiveStep(model, trainer.optim, loaders["train"].dataset, args.batch_size)
     history = {"train": [], "val": []}
     print("Training Start")
     for epoch in range(args.n_epochs):
         model.train()
-        history["train"].append(_run_epoch(trainer, loaders["train"], train=True))
+        history["train"].append(_run_epoch(trainer, loaders["train"], train=True, captured=captured))
         trainer.save(epoch, args.save_dir)
         model.eval()         # no effect on the decoder's dropout, exactly like the reference (gae.py:70)
         history["val"].append(_run_epoch(trainer, loaders["val"], train=False))

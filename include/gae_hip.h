@@ -69,6 +69,7 @@ int gae_device_info_get(int device, gae_device_info *out_host);
  * "linear_bf16" (default 0 = exact fp32 forward Linear).  A skew plan (gae_spmm_plan with heavy rows) also changes
  * the summation order of the heavy rows. */
 int gae_tuning_set(const char *name, int64_t value);
+int gae_tuning_get(const char *name, int64_t *value_out);   /* the calling thread's current value */
 
 /* ---- graph structure -------------------------------------------------------
  * Replaces the DGL graph index built by DGLGraph.add_edges / dgl.batch

@@ -33,3 +33,20 @@ def golden(request):
     g = load_golden(request.param)
     g["name"] = request.param
     return g
+
+
+@pytest.fixture
+def tuning():
+    """set library knobs (gae_tuning_set) for one test; the previous values come back afterwards"""
+    from gae_dgl_amd import _lib
+    saved = []
+
+    def set_knob(name, value):
+        import ctypes
+        old = ctypes.c_int64(0)
+        _lib.call("gae_tuning_get", name.encode(), ctypes.byref(old))
+        saved.append((name, old.value))
+        _lib.call("gae_tuning_set", name.encode(), int(value))
+    yield set_knob
+    for name, value in reversed(saved):
+        _lib.call("gae_tuning_set", name.encode(), value)

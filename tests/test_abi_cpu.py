@@ -139,3 +139,25 @@ def test_atb_and_loss_plans_are_consistent_without_a_gpu():
     assert 0 < small < big
     assert lib.gae_decoder_bce_workspace_bytes(19717, 19717, 16) > 19717 * 19717 // 4   # symmetric path: strip buffer
     assert lib.gae_decoder_bce_workspace_bytes(100, 200, 16) < 0            # n_local > n is an argument error
+
+
+def test_tuning_knobs_round_trip_and_are_thread_local():
+    """gae_tuning_set / gae_tuning_get: host-side integers of the calling thread; another thread sees the defaults"""
+    import ctypes
+    import threading
+    from gae_dgl_amd import _lib
+    lib = _lib.load()
+
+    def get(name):
+        v = ctypes.c_int64(-1)
+        assert lib.gae_tuning_get(name, ctypes.byref(v)) == 0
+        return v.value
+    default = get(b"spmm_tile_vecs")
+    assert lib.gae_tuning_set(b"spmm_tile_vecs", 8) == 0 and get(b"spmm_tile_vecs") == 8
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(get(b"spmm_tile_vecs")))
+    t.start(); t.join()
+    assert seen == [default]
+    assert lib.gae_tuning_set(b"spmm_tile_vecs", default) == 0
+    assert lib.gae_tuning_get(b"no_such_knob", ctypes.byref(ctypes.c_int64())) != 0
+    assert lib.gae_tuning_set(b"no_such_knob", 1) != 0 and b"unknown knob" in lib.gae_last_error()

@@ -20,12 +20,14 @@ def _dataset(n=300, seed=11, directed=False):
     return DeviceGraphDataset(gp, src, dst, X, device=DEV), (gp, src, dst, X)
 
 
+@pytest.mark.parametrize("sym", [1, 2])
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
-def test_padded_loss_matches_unpadded(dropout):
+def test_padded_loss_matches_unpadded(dropout, sym, tuning):
     """gae_decoder_bce_padded on a capacity-padded batch == gae_decoder_bce on the batch itself (loss 1e-6 relative,
     gradient 1e-5 of its scale; padding rows get an exactly zero gradient) and == the fp64 oracle"""
     from gae_dgl_amd import ops
     from oracle import gae_oracle as O
+    tuning("bce_sym", sym)            # 2: the symmetric dense kernel already from 512 rows on (default: 8192)
     ds, _ = _dataset()
     ids = np.arange(40, 104)
     bg = ds.batch(ids)

@@ -149,6 +149,16 @@ def test_train_inductive_runs_and_learns(tmp_path):
     tr2, _ = TI.main(["--hidden_dims", "32", "16", "--synthetic", "3000", "-b", "256", "-e", "1", "--lr", "1e-2",
                       "--val_size", "300", "--seed", "0", "-s", str(tmp_path), "--no_plot", "--dataloader"])
     assert np.isfinite(tr2).all()                           # the reference's DataLoader + collate route still works
+    # the default run trains through the captured step (one HIP graph per batch); the eager iterator gives the same
+    # curve: same batches, same dropout stream, reductions split over slightly different row counts
+    tr3, va3 = TI.main(["--hidden_dims", "32", "16", "--synthetic", "3000", "-b", "256", "-e", "3", "--lr", "1e-2",
+                        "--val_size", "300", "--seed", "0", "-s", str(tmp_path / "eager"), "--no_plot",
+                        "--capture", "off"])
+    np.testing.assert_allclose(tr, tr3, rtol=2e-4)
+    np.testing.assert_allclose(va, va3, rtol=2e-4)
+    with pytest.raises(ValueError):
+        TI.main(["--hidden_dims", "32", "16", "--synthetic", "300", "-b", "256", "-e", "1", "--val_size", "100",
+                 "-s", str(tmp_path), "--no_plot", "--capture", "on", "--dataloader"])
     sd = torch.load(tmp_path / "ep02.pkl")
     assert list(sd.keys()) == ["layers.0.apply_mod.linear.weight", "layers.0.apply_mod.linear.bias",
                                "layers.1.apply_mod.linear.weight", "layers.1.apply_mod.linear.bias"]
