@@ -6,7 +6,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgae_hip.so")
+# GAE_HIP_LIB: load another build of the same library (kernel experiments, tools/r02/bce_whatif.sh); never a fallback
+LIB_PATH = os.environ.get("GAE_HIP_LIB") or os.path.join(HERE, "lib", "libgae_hip.so")
 
 F32, BF16, U8 = 0, 1, 2
 SPMM_STORE_PAD = 1

@@ -165,6 +165,27 @@ __device__ __forceinline__ void bce_colsum_block(const double *__restrict__ cols
 // ---------------------------------------------------------------------------
 // dense part.  loss_partial[blk] = {sum |x|, sum log2(1 + exp(-|x|))} over the block's (row, column) window.
 // ---------------------------------------------------------------------------
+// K = 32 fragments: two K = 16 fragments side by side (lane group g holds k = 4 g + r of either half)
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ s16x8 cat(const s16x4 &a, const s16x4 &b)
+{
+    return s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__device__ __forceinline__ void put_half(s16x8 &v, int h, const s16x4 &x)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * h + e] = x[e];
+}
+__device__ __forceinline__ s16x4 get_half(const s16x8 &v, int h)
+{
+    return s16x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+}
+__device__ __forceinline__ f32x4 mfma32(const s16x8 &a, const s16x8 &b, const f32x4 &c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // split 4 fp32 values into bf16 hi and bf16 lo = bf16(v - hi): v_cvt_pk_bf16_f32 x4, 5 VALU ops per pair
 __device__ __forceinline__ void split_bf16x4(const f32x4 &v, s16x4 &hi, s16x4 &lo)
 {
@@ -227,8 +248,11 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     // accumulator is y = x log2(e) and exp(-|x|) = exp2(-|y|) needs no multiply per logit (sign and |.|
     // sums are rescaled at the end).
     constexpr float LOG2E = 1.44269504088896341f;
+    // bf16 x 3 on K = 32 MFMAs (see bce_dense_sym_kernel): K2 fragments per row subtile, each two K = 16 fragments
+    // side by side -- chunk pairs [c | c + 1] for d > 16, the same chunk twice for d <= 16.
+    constexpr int K2 = KS == 1 ? 1 : KS / 2;
     f32x4 bfrag[RI][KS];
-    s16x4 bhi[RI][KS], blo[RI][KS];
+    s16x8 bhh[RI][K2], bll[RI][K2];
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri) {
         const int64_t i = row_base + ri * 16 + l15;
@@ -239,7 +263,17 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
             if (i >= n_local) b = f32x4{0.f, 0.f, 0.f, 0.f};
             b *= LOG2E;
             bfrag[ri][c] = b;
-            if (SBF16) split_bf16x4(b, bhi[ri][c], blo[ri][c]);
+            if (SBF16) {
+                s16x4 bh, bl;
+                split_bf16x4(b, bh, bl);
+                if (KS == 1) {
+                    bhh[ri][0] = cat(bh, bh);
+                    bll[ri][0] = cat(bl, bl);
+                } else {
+                    put_half(bhh[ri][c / 2], c & 1, bh);
+                    put_half(bll[ri][c / 2], c & 1, bl);
+                }
+            }
         }
     }
     f32x4 oacc[RI][KS];
@@ -301,79 +335,105 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri) { tA[ri] = 0.f; tP[ri] = 1.f; }
 #pragma unroll
-        for (int jt = 0; jt < TJ / 16; ++jt) {
-            f32x4 sacc[RI];
+        for (int jp = 0; jp < TJ / 32; ++jp) {           // pairs of 16-column subtiles (K = 32 for O' += P V)
+            s16x8 ph[RI], pl[RI];                        // bf16 P of the pair: [subtile 2 jp | subtile 2 jp + 1]
 #pragma unroll
-            for (int ri = 0; ri < RI; ++ri) sacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (SBF16) {
-                // A fragments: lane (j = l15, g) -> 4 bf16 at [jt*16 + j][16 c + 4 g ..]
+            for (int h = 0; h < 2; ++h) {
+                const int jt = 2 * jp + h;
+                f32x4 sacc[RI];
 #pragma unroll
-                for (int c = 0; c < KS; ++c) {
-                    const s16x4 ah = *reinterpret_cast<const s16x4 *>(&Hs[buf][(jt * 16 + l15) * LDH + 16 * c + 4 * g]);
-                    const s16x4 al = *reinterpret_cast<const s16x4 *>(&Ls[buf][(jt * 16 + l15) * LDH + 16 * c + 4 * g]);
+                for (int ri = 0; ri < RI; ++ri) sacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (SBF16) {
+                    // A fragments: lane (j = l15, g) -> 4 bf16 at [jt*16 + j][16 c + 4 g ..]
+                    auto frag = [&](const unsigned short *base, int c) {
+                        return *reinterpret_cast<const s16x4 *>(&base[(jt * 16 + l15) * LDH + 16 * c + 4 * g]);
+                    };
+                    if (KS == 1) {        // S = [ah | al] x [bhi | bhi] + [ah | al] x [blo | blo]
+                        const s16x8 ahl = cat(frag(Hs[buf], 0), frag(Ls[buf], 0));
 #pragma unroll
-                    for (int ri = 0; ri < RI; ++ri) {
-                        sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bhi[ri][c], sacc[ri], 0, 0, 0);
-                        sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, blo[ri][c], sacc[ri], 0, 0, 0);
-                        sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bhi[ri][c], sacc[ri], 0, 0, 0);
+                        for (int ri = 0; ri < RI; ++ri) {
+                            sacc[ri] = mfma32(ahl, bll[ri][0], sacc[ri]);
+                            sacc[ri] = mfma32(ahl, bhh[ri][0], sacc[ri]);
+                        }
+                    } else {              // chunk pairs: lo.hi + hi.lo + hi.hi, 3 MFMAs per 32 features
+#pragma unroll
+                        for (int c2 = 0; c2 < K2; ++c2) {
+                            const s16x8 ah = cat(frag(Hs[buf], 2 * c2), frag(Hs[buf], 2 * c2 + 1));
+                            const s16x8 al = cat(frag(Ls[buf], 2 * c2), frag(Ls[buf], 2 * c2 + 1));
+#pragma unroll
+                            for (int ri = 0; ri < RI; ++ri) {
+                                sacc[ri] = mfma32(al, bhh[ri][c2], sacc[ri]);
+                                sacc[ri] = mfma32(ah, bll[ri][c2], sacc[ri]);
+                                sacc[ri] = mfma32(ah, bhh[ri][c2], sacc[ri]);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < KS; ++c) {
+                        const f32x4 af = *reinterpret_cast<const f32x4 *>(&zs[(jt * 16 + l15) * LDA + 16 * c + 4 * g]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int ri = 0; ri < RI; ++ri)
+                                sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], bfrag[ri][c][r], sacc[ri], 0, 0, 0);
                     }
                 }
-            } else {
+                // sacc[ri][r] = x(i = l15 of subtile ri, j = jt*16 + 4 g + r)
+                f32x4 p[RI];
 #pragma unroll
-                for (int c = 0; c < KS; ++c) {
-                    const f32x4 af = *reinterpret_cast<const f32x4 *>(&zs[(jt * 16 + l15) * LDA + 16 * c + 4 * g]);
+                for (int ri = 0; ri < RI; ++ri) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int ri = 0; ri < RI; ++ri)
-                            sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], bfrag[ri][c][r], sacc[ri], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = sacc[ri][r];                 // = x_ij * log2(e)
+                        const float e = __builtin_amdgcn_exp2f(-fabsf(x));
+                        const float t = 1.0f + e;
+                        tP[ri] *= t;
+                        tA[ri] += fabsf(x);
+                        const float sg = __builtin_amdgcn_rcpf(t) - 0.5f;   // in [0, 1/2]
+                        p[ri][r] = copysignf(sg, x);             // sigmoid(x) - 1/2
+                    }
                 }
-            }
-            // sacc[ri][r] = x(i = l15 of subtile ri, j = jt*16 + 4 g + r)
-            f32x4 p[RI];
+                if (WITH_GRAD && PBF16) {     // P = hi + lo (bf16) on the fly
 #pragma unroll
-            for (int ri = 0; ri < RI; ++ri) {
+                    for (int ri = 0; ri < RI; ++ri) {
+                        s16x4 h4, l4;
+                        split_bf16x4(p[ri], h4, l4);
+                        put_half(ph[ri], h, h4);
+                        put_half(pl[ri], h, l4);
+                    }
+                }
+                if (WITH_GRAD && !PBF16) {
+                    // B fragments of O' += P V: lane (nn = l15, g) -> V[jt*16 + 4 g + r][16 c + nn]
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float x = sacc[ri][r];                 // = x_ij * log2(e)
-                    const float e = __builtin_amdgcn_exp2f(-fabsf(x));
-                    const float t = 1.0f + e;
-                    tP[ri] *= t;
-                    tA[ri] += fabsf(x);
-                    const float s = __builtin_amdgcn_rcpf(t) - 0.5f;   // in [0, 1/2]
-                    p[ri][r] = copysignf(s, x);              // sigmoid(x) - 1/2
+                    for (int c = 0; c < KS; ++c) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = zs[(jt * 16 + 4 * g + r) * LDA + 16 * c + l15];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int ri = 0; ri < RI; ++ri)
+                                oacc[ri][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[ri][r], v[r], oacc[ri][c], 0, 0, 0);
+                    }
                 }
             }
             if (WITH_GRAD && PBF16) {
-                // P = hi + lo (bf16) on the fly; B fragments: lane (nn = l15, g) -> 4 bf16 V[jt*16 + 4 g ..][16 c + nn]
-                // read from the transposed tiles; O' += lo.hi + hi.lo + hi.hi on the bf16 matrix pipe
-                s16x4 ph[RI], pl[RI];
-#pragma unroll
-                for (int ri = 0; ri < RI; ++ri) split_bf16x4(p[ri], ph[ri], pl[ri]);
+                // B fragments: lane (nn = l15, g) -> bf16 V[j][16 c + nn] for the 4 + 4 columns j this lane group
+                // holds of the two subtiles, read from the transposed tiles; O' += lo.hi + hi.lo + hi.hi, K = 32
 #pragma unroll
                 for (int c = 0; c < KS; ++c) {
-                    const s16x4 vh = *reinterpret_cast<const s16x4 *>(&HT[buf][(16 * c + l15) * LDT + jt * 16 + 4 * g]);
-                    const s16x4 vl = *reinterpret_cast<const s16x4 *>(&LT[buf][(16 * c + l15) * LDT + jt * 16 + 4 * g]);
+                    const int at = (16 * c + l15) * LDT + jp * 32 + 4 * g;
+                    const s16x8 vh = cat(*reinterpret_cast<const s16x4 *>(&HT[buf][at]),
+                                         *reinterpret_cast<const s16x4 *>(&HT[buf][at + 16]));
+                    const s16x8 vl = cat(*reinterpret_cast<const s16x4 *>(&LT[buf][at]),
+                                         *reinterpret_cast<const s16x4 *>(&LT[buf][at + 16]));
 #pragma unroll
                     for (int ri = 0; ri < RI; ++ri) {
-                        oacc[ri][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pl[ri], vh, oacc[ri][c], 0, 0, 0);
-                        oacc[ri][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ph[ri], vl, oacc[ri][c], 0, 0, 0);
-                        oacc[ri][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ph[ri], vh, oacc[ri][c], 0, 0, 0);
+                        oacc[ri][c] = mfma32(pl[ri], vh, oacc[ri][c]);
+                        oacc[ri][c] = mfma32(ph[ri], vl, oacc[ri][c]);
+                        oacc[ri][c] = mfma32(ph[ri], vh, oacc[ri][c]);
                     }
-                }
-            }
-            if (WITH_GRAD && !PBF16) {
-                // B fragments of O' += P V: lane (nn = l15, g) -> V[jt*16 + 4 g + r][16 c + nn]
-#pragma unroll
-                for (int c = 0; c < KS; ++c) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = zs[(jt * 16 + 4 * g + r) * LDA + 16 * c + l15];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int ri = 0; ri < RI; ++ri)
-                            oacc[ri][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[ri][r], v[r], oacc[ri][c], 0, 0, 0);
                 }
             }
         }
@@ -445,9 +505,10 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
 // Mirror traffic: N^2 / 4 bytes written and read once (Pubmed 97 MB against 1.9 x 10^8 logits saved).
 // Zero-padded columns (j >= n) are corrected in the kernel (their log2(1 + e^0) = 1 is subtracted).
 // ---------------------------------------------------------------------------
-// rows per panel = 64 RI (4 waves x RI subtiles of 16 rows); "bce_sym_ri" = 0 (auto) | 2 | 4.  Taller panels halve
-// the mirror strips (N^2 / 8 bytes) at the price of registers (2 waves per SIMD): they pay from ~32 k rows on
-// (ZINC batch of 95 k rows: 3.38 -> 3.13 ms; Pubmed, 20 k rows: 206 -> 212 us)
+// rows per panel = 64 RI (4 waves x RI subtiles of 16 rows); "bce_sym_ri" = 0 (auto = 2) | 2 | 4.  Taller panels halve
+// the mirror strips (N^2 / 8 bytes) at the price of registers.  With the K = 16 MFMAs of round 1 they paid from
+// ~32 k rows on (ZINC batch of 95 k rows: 3.38 -> 3.13 ms); the K = 32 form keeps pairs of fragments live and the
+// 256-row variant spills 43 VGPRs (ZINC batch: 128-row panels 3.00 ms, 256-row panels 3.48 ms): opt-in only.
 thread_local int g_bce_sym_ri = 0;
 
 // the upper 16 bits of four fp32 values (exact when they are bf16 values): one v_perm_b32 per pair
@@ -505,22 +566,31 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     const int64_t diag_end = SYM_PR * (I + 1);      // tiles starting below this column lie in the panel's own square
 
     constexpr float LOG2E = 1.44269504088896341f;
-    s16x4 bhi[RI], blo[RI];      // B fragments of S^T = Zj Zi^T (row operand, log2(e) folded in)
-    s16x4 zTh[RI], zTl[RI];      // B fragments of the mirror product: lane (f = l15, g) -> Zt[i = 4 g + r][f]
+    static_assert(RI % 2 == 0, "row subtiles are paired into K = 32 mirror products");
+    s16x8 bhh[RI];               // B fragments of S^T = Zj Zi^T (row operand, log2(e) folded in): [hi | hi]
+    s16x8 bll[RI];               // ... and [lo | lo]: S = (ah + al)(bhi + blo), all four partial products
+    s16x8 zTh[RI / 2], zTl[RI / 2];   // B fragments of the mirror product, row subtiles (2 rp, 2 rp + 1) concatenated:
+                                      // lane (f = l15, g) -> Zt[i = 4 g + r][f]
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri) {
         const int64_t i = row_base + ri * 16 + l15;
         f32x4 b = *reinterpret_cast<const f32x4 *>(Zt + (i < n ? i : 0) * DP + 4 * g);
         if (i >= n) b = f32x4{0.f, 0.f, 0.f, 0.f};
         b *= LOG2E;
-        split_bf16x4(b, bhi[ri], blo[ri]);
+        s16x4 bhi, blo;
+        split_bf16x4(b, bhi, blo);
+        bhh[ri] = cat(bhi, bhi);
+        bll[ri] = cat(blo, blo);
+        s16x4 th, tl;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t ir = row_base + ri * 16 + 4 * g + r;
             const bool v = ir < n;
-            zTh[ri][r] = v ? short(Zhi[(v ? ir : 0) * DP + l15]) : short(0);
-            zTl[ri][r] = v ? short(Zlo[(v ? ir : 0) * DP + l15]) : short(0);
+            th[r] = v ? short(Zhi[(v ? ir : 0) * DP + l15]) : short(0);
+            tl[r] = v ? short(Zlo[(v ? ir : 0) * DP + l15]) : short(0);
         }
+        put_half(zTh[ri / 2], ri & 1, th);
+        put_half(zTl[ri / 2], ri & 1, tl);
     }
     s16x4 ident;                 // B fragment of the 16 x 16 identity: lane (n = l15, g) -> [k = 4 g + r == n]
 #pragma unroll
@@ -581,68 +651,96 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
         *reinterpret_cast<f32x4 *>(strip + f * strip_ld + (j0 - diag_end) + jq) = v;
     };
 
+    // ---- one 64-column tile.  gfx950 runs v_mfma_f32_16x16x32_bf16 in the same 4 passes as the 16x16x16 form
+    //      (tools/probes/inst_cost.hip: 7.5 ns per SIMD either way), and on this chip a SIMD's MFMA and VALU time
+    //      ADD (mfma + 4 v_fma: 11.2 - 12.8 ns against 7.4 + 5.7): every MFMA saved is time saved.  A K = 32 MFMA on
+    //      concatenated fragments [a1 | a2] x [b1 | b2] is a1 b1 + a2 b2 (lane group g holds k = 4 g + r of both
+    //      halves), so
+    //        S     = [ah | al] x [bhi | bhi]  +  [ah | al] x [blo | blo]   2 instead of 3 MFMAs per 16 x 16 logits
+    //        O'   += [p(jt) | p(jt+1)] x [v(jt) | v(jt+1)]  (x 3)      3 per TWO column subtiles
+    //        mirror = [q(ri) | q(ri+1)] x [z(ri) | z(ri+1)]  (x 3)     3 per TWO row subtiles
+    //      -- 56 instead of 88 MFMAs per tile and wave (RI = 2).
     auto compute_tile = [&](int buf, int64_t j0, bool offdiag) {
         float tA[RI], tP[RI];
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri) { tA[ri] = 0.f; tP[ri] = 1.f; }
 #pragma unroll
-        for (int jt = 0; jt < TJ / 16; ++jt) {
-            f32x4 macc = {0.f, 0.f, 0.f, 0.f};
-            f32x4 sacc[RI];
+        for (int jp = 0; jp < TJ / 32; ++jp) {           // pairs of 16-column subtiles
+            s16x8 ph[RI], pl[RI];                        // P of the pair: [subtile 2 jp | subtile 2 jp + 1]
 #pragma unroll
-            for (int ri = 0; ri < RI; ++ri) sacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const s16x4 ah = *reinterpret_cast<const s16x4 *>(&Hs[buf][(jt * 16 + l15) * LDH + 4 * g]);
-            const s16x4 al = *reinterpret_cast<const s16x4 *>(&Ls[buf][(jt * 16 + l15) * LDH + 4 * g]);
+            for (int h = 0; h < 2; ++h) {
+                const int jt = 2 * jp + h;
+                const s16x4 ah = *reinterpret_cast<const s16x4 *>(&Hs[buf][(jt * 16 + l15) * LDH + 4 * g]);
+                const s16x4 al = *reinterpret_cast<const s16x4 *>(&Ls[buf][(jt * 16 + l15) * LDH + 4 * g]);
+                const s16x8 ahl = cat(ah, al);
+                f32x4 sacc[RI];
 #pragma unroll
-            for (int ri = 0; ri < RI; ++ri) {
-                sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bhi[ri], sacc[ri], 0, 0, 0);
-                sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, blo[ri], sacc[ri], 0, 0, 0);
-                sacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bhi[ri], sacc[ri], 0, 0, 0);
-            }
-            // sacc[ri][r] = y(i = l15 of subtile ri, j = jt*16 + 4 g + r), y = x log2(e)
-            f32x4 p[RI];
+                for (int ri = 0; ri < RI; ++ri) {
+                    sacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    sacc[ri] = mfma32(ahl, bll[ri], sacc[ri]);
+                    sacc[ri] = mfma32(ahl, bhh[ri], sacc[ri]);
+                }
+                // sacc[ri][r] = y(i = l15 of subtile ri, j = jt*16 + 4 g + r), y = x log2(e)
 #pragma unroll
-            for (int ri = 0; ri < RI; ++ri) {
+                for (int ri = 0; ri < RI; ++ri) {
+                    f32x4 p;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float x = sacc[ri][r];
-                    const float e = __builtin_amdgcn_exp2f(-fabsf(x));
-                    const float t = 1.0f + e;
-                    tP[ri] *= t;
-                    tA[ri] += fabsf(x);
-                    const float sg = __builtin_amdgcn_rcpf(t) - 0.5f;   // in [0, 1/2]
-                    p[ri][r] = copysignf(sg, x);                        // sigmoid(x) - 1/2
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = sacc[ri][r];
+                        const float e = __builtin_amdgcn_exp2f(-fabsf(x));
+                        const float t = 1.0f + e;
+                        tP[ri] *= t;
+                        tA[ri] += fabsf(x);
+                        const float sg = __builtin_amdgcn_rcpf(t) - 0.5f;   // in [0, 1/2]
+                        p[r] = copysignf(sg, x);                            // sigmoid(x) - 1/2
+                    }
+                    if (WITH_GRAD) {
+                        s16x4 h4, l4;
+                        split_bf16x4(p, h4, l4);
+                        put_half(ph[ri], h, h4);
+                        put_half(pl[ri], h, l4);
+                    }
                 }
             }
             if (WITH_GRAD) {
-                s16x4 ph[RI], pl[RI];
-#pragma unroll
-                for (int ri = 0; ri < RI; ++ri) split_bf16x4(p[ri], ph[ri], pl[ri]);
-                const s16x4 vh = *reinterpret_cast<const s16x4 *>(&HT[buf][l15 * LDT + jt * 16 + 4 * g]);
-                const s16x4 vl = *reinterpret_cast<const s16x4 *>(&LT[buf][l15 * LDT + jt * 16 + 4 * g]);
+                const int jc = jp * 32 + 4 * g;
+                const s16x8 vh = cat(*reinterpret_cast<const s16x4 *>(&HT[buf][l15 * LDT + jc]),
+                                     *reinterpret_cast<const s16x4 *>(&HT[buf][l15 * LDT + jc + 16]));
+                const s16x8 vl = cat(*reinterpret_cast<const s16x4 *>(&LT[buf][l15 * LDT + jc]),
+                                     *reinterpret_cast<const s16x4 *>(&LT[buf][l15 * LDT + jc + 16]));
 #pragma unroll
                 for (int ri = 0; ri < RI; ++ri) {
-                    oacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pl[ri], vh, oacc[ri], 0, 0, 0);
-                    oacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ph[ri], vl, oacc[ri], 0, 0, 0);
-                    oacc[ri] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ph[ri], vh, oacc[ri], 0, 0, 0);
+                    oacc[ri] = mfma32(pl[ri], vh, oacc[ri]);
+                    oacc[ri] = mfma32(ph[ri], vl, oacc[ri]);
+                    oacc[ri] = mfma32(ph[ri], vh, oacc[ri]);
                 }
                 if (offdiag) {
                     // mirror: (P^T Z_I)[j][f] += sum_i P[i][j] Z[i][f] needs P with lane = column j, registers = rows
                     // i; this lane holds P[i = l15][j = 4 g + r].  One MFMA against the identity re-lays it out on
-                    // the matrix pipe (which has room): D = P_hi I has the C layout lane = j, regs = i, and its
-                    // fp32 values are exactly the bf16 inputs, so their upper halves are the A fragments wanted.
+                    // the matrix pipe: D = P_hi I has the C layout lane = j, regs = i, and its fp32 values are
+                    // exactly the bf16 inputs, so their upper halves are the A fragments wanted.
 #pragma unroll
-                    for (int ri = 0; ri < RI; ++ri) {
-                        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                        const f32x4 dh = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ph[ri], ident, z4, 0, 0, 0);
-                        const f32x4 dl = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pl[ri], ident, z4, 0, 0, 0);
-                        const s16x4 qh = upper_halves(dh), ql = upper_halves(dl);
-                        macc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ql, zTh[ri], macc, 0, 0, 0);
-                        macc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qh, zTl[ri], macc, 0, 0, 0);
-                        macc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qh, zTh[ri], macc, 0, 0, 0);
+                    for (int h = 0; h < 2; ++h) {
+                        f32x4 macc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int rp = 0; rp < RI / 2; ++rp) {       // pairs of row subtiles: K = 32 rows
+                            s16x8 qh, ql;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int ri = 2 * rp + e;
+                                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                                const f32x4 dh = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(get_half(ph[ri], h), ident, z4, 0, 0, 0);
+                                const f32x4 dl = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(get_half(pl[ri], h), ident, z4, 0, 0, 0);
+                                put_half(qh, e, upper_halves(dh));
+                                put_half(ql, e, upper_halves(dl));
+                            }
+                            macc = mfma32(ql, zTh[rp], macc);
+                            macc = mfma32(qh, zTl[rp], macc);
+                            macc = mfma32(qh, zTh[rp], macc);
+                        }
+                        // macc[r] = mirror(j = jt*16 + 4 g + r, f = l15)  ->  MR[wave][f][j]
+                        *reinterpret_cast<f32x4 *>(&MR[wave][l15 * LDM + (2 * jp + h) * 16 + 4 * g]) = macc;
                     }
-                    // macc[r] = mirror(j = jt*16 + 4 g + r, f = l15)  ->  MR[wave][f][j]
-                    *reinterpret_cast<f32x4 *>(&MR[wave][l15 * LDM + jt * 16 + 4 * g]) = macc;
                 }
             }
         }
@@ -967,7 +1065,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     p.wmir_bytes = p.omir_bytes = 0;
     if (g_bce_sym && n_local == n && p.KS == 1 && g_bce_s_bf16 && g_bce_pv_bf16 &&
         n >= (g_bce_sym > 1 ? 512 : 8192)) {           // below ~8 k rows the extra launch costs more than it saves
-        const int64_t SYM_PR = (g_bce_sym_ri == 4 || (g_bce_sym_ri == 0 && n >= 32768)) ? 256 : 128;
+        const int64_t SYM_PR = g_bce_sym_ri == 4 ? 256 : 128;   // 256-row panels spill since the K = 32 rewrite: opt-in only
         p.sym_pr = int(SYM_PR);
         const int64_t T = (n + SYM_PR - 1) / SYM_PR, NP = (n + 63) / 64 * 64;
         int64_t chunks = (g_bce_sym_grid + T - 1) / T; // half of the (panel, chunk) grid is live
