@@ -42,11 +42,25 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # VALU roofline of the fused decoder + BCE kernels (the step's dominant launch): fp32 lane-operations per second of the
 # vector ALUs, 256 CUs x 4 SIMD-32 x 2.4 GHz (spec; tools/probes/valu_rate.hip sustains 5.55e13 = 71 % of it with
 # v_fma_f32), a transcendental (v_exp / v_log / v_rcp) costs 4 plain operations (quarter rate; measured 3.6-3.9).
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
-TRANSCENDENTAL_COST = 4.0
-# per evaluated logit (counted in the ISA of the kernels): full-square kernel 5.6 plain + 2
-# transcendental; symmetric kernel 8.2 plain + 2 transcendental per evaluated logit, N^2 / 2 logits evaluated
-LOSS_OPS = {"symmetric": (8.2, 2.0, 0.5), "full": (5.6, 2.0, 1.0)}
+# ---- issue model of the fused decoder + BCE kernels (tools/probes/inst_cost.hip, profiles/r02_probe_inst_cost.txt).
+# On gfx950 a SIMD's MFMA time and VALU time ADD (mfma + 4 v_fma: 11.2 ns against 7.4 + 5.7), so the bound of these
+# kernels is the sum of their instructions' issue costs.  Costs in units of one v_fma_f32 (1.42 ns per wave64
+# instruction and SIMD at 4 waves / SIMD): transcendental 2.5, v_pk_*_f32 1.8, v_cvt_pk_bf16_f32 / v_bfi_b32 1.7,
+# v_perm_b32 1.4, v_lshlrev_b32 1.6, v_mfma_f32_16x16x{16,32}_bf16 5.2.
+SLOT_NS = 1.42
+ISSUE_PEAK_LANE_SLOTS = 256 * 4 * 64 / (SLOT_NS * 1e-9)      # lane-slots per second of the whole chip
+SLOT_COST = {"plain": 1.0, "trans": 2.5, "pk": 1.8, "cvt_pk": 1.7, "bfi": 1.7, "perm": 1.4, "lshl": 1.6, "mfma": 5.2}
+# instructions per wave and 64-column tile of a 32-row wave slice (= 32 logits per lane), counted in the ISA of the
+# kernels' main loops (decoder_bce.hip, K = 32 MFMAs); third entry: share of the N^2 logits that is evaluated
+LOSS_ISA = {
+    "symmetric": ({"trans": 64, "pk": 36, "cvt_pk": 32, "bfi": 32, "perm": 32, "lshl": 16, "plain": 120, "mfma": 56}, 0.5),
+    "full": ({"trans": 64, "pk": 36, "cvt_pk": 32, "bfi": 32, "perm": 0, "lshl": 16, "plain": 110, "mfma": 28}, 1.0),
+}
+
+
+def loss_slots_per_logit(kind):
+    isa, frac_eval = LOSS_ISA[kind]
+    return sum(SLOT_COST[k] * v for k, v in isa.items()) / 32.0, frac_eval
 
 
 def parse():
@@ -239,7 +253,7 @@ class CitationWorkload:
                      "optimizer": "adam lr=1e-2: " + opt_name, "parallelism": "1 GPU",
                      "launch": "hipGraph replay of the captured step" if self.use_graph else "eager",
                      "forward_products": "fp32 MFMA (exact fp32 embeddings)",
-                     "loss_products": "bf16x3 split products, fp32 accumulate (knobs bce_s_bf16=1, bce_pv_bf16=1)",
+                     "loss_products": "bf16x3 split products on K = 32 MFMAs, fp32 accumulate (knobs bce_s_bf16=1, bce_pv_bf16=1)",
                      "dW_products": "bf16x3 split products, fp32 accumulate (knob atb_bf16=1)",
                      "residency": f"operands of the dominant launch ({2 * n * self.F_in * 4 / 1e6:.0f} MB) stay in the "
                                   "256 MB Infinity Cache across the timed replays: its '% of 8 TB/s' is measured "
@@ -649,18 +663,21 @@ def main():
         t_loss = time_launches(wl.loss_launch(), iters=20, warmup=5)
         n = wl.n
         kind = "symmetric" if n >= 8192 else "full"          # gae_decoder_bce's own rule (bce_sym, d <= 16)
-        plain, trans, frac_eval = LOSS_OPS[kind]
-        units = (plain + TRANSCENDENTAL_COST * trans) * frac_eval * float(n) * n
+        per_logit, frac_eval = loss_slots_per_logit(kind)
+        units = per_logit * frac_eval * float(n) * n
+        isa = LOSS_ISA[kind][0]
         line["roofline_step_dominant"] = {
-            "bound": "valu", "kernel": f"fused decoder + BCE, loss and dZ ({kind} dense kernel + edge / prepare / finalize "
-                                       f"launches), N = {n}, d = 16",
-            "achieved": units / t_loss / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-ops/s",
-            "frac": units / t_loss / VALU_PEAK_LANE_OPS, "avg_launch_us": t_loss * 1e6,
+            "bound": "issue (VALU + MFMA)", "kernel": f"fused decoder + BCE, loss and dZ ({kind} dense kernel + edge / "
+                                                      f"prepare / finalize launches), N = {n}, d = 16",
+            "achieved": units / t_loss / 1e12, "peak": ISSUE_PEAK_LANE_SLOTS / 1e12, "unit": "T lane-slots/s",
+            "frac": units / t_loss / ISSUE_PEAK_LANE_SLOTS, "avg_launch_us": t_loss * 1e6,
             "logits_per_s": float(n) * n / t_loss,
-            "model": f"{plain} plain + {trans} transcendental (x{TRANSCENDENTAL_COST:g}) fp32 lane-ops per evaluated "
-                     f"logit, {frac_eval:g} N^2 logits evaluated; matrix-core work (bf16x3 S = Zt Zt^T, O += P Zt) "
-                     "runs on the MFMA pipe next to it",
-            "mfma_flops_per_s": (3 * 2 * 2 * 16 * frac_eval * (2 if kind == "symmetric" else 1)) * float(n) * n / t_loss,
+            "model": f"{per_logit:.1f} issue slots (v_fma_f32 equivalents, measured costs) per evaluated logit and "
+                     f"lane: {isa}, per 32 logits; {frac_eval:g} N^2 logits evaluated; MFMA and VALU time of a "
+                     "SIMD add up on gfx950 (tools/probes/inst_cost.hip), so the matrix-core work is part of the "
+                     "same budget; the launch sequence also holds the mirror reduction, the edge pass and two "
+                     "bookkeeping launches, which this model does not count",
+            "mfma_flops_per_s": isa["mfma"] * 16384.0 / 64 / 32 * frac_eval * float(n) * n / t_loss,
             "share_of_step": t_loss / (elapsed / args.steps)}
         # ---- the same step with exact-fp32 products everywhere (no bf16 x 3 split)
         if graphed:
@@ -688,8 +705,9 @@ def main():
         n = kb[0][1]; d = kb[0][2]
         line["decoder_loss"] = {"kernel": "fused decoder+BCE fwd+bwd (prepare + dense + edges + finalize)",
                                 "avg_us_event_pairs_in_eager_steps": tb * 1e6, "logits_per_s": n * n / tb,
-                                "bound": "valu: 2 transcendentals + ~6 fp32 ops per logit next to bf16x3 MFMA "
-                                         "(S = Zt Zt^T, O = sigmoid(S) Zt); rocprofv3 kernel time in profiles/"}
+                                "bound": "issue: 2 transcendentals + ~10 VALU ops + 0.9 (full kernel) / 1.75 "
+                                         "(symmetric) bf16 MFMAs per 32 logits and lane; rocprofv3 kernel time in "
+                                         "profiles/"}
     if not args.no_cpu_baseline and hasattr(wl, "cpu_baseline"):
         line["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
         line["cpu_baseline"]["cpu_model"] = cpu_model_name()

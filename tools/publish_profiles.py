@@ -32,7 +32,7 @@ def pmc_means(d):
 
 
 benches = {}
-for name in ("pubmed", "cora", "citeseer", "zinc", "zinc128", "rmat_s24_1gpu"):
+for name in ("pubmed", "cora", "citeseer", "zinc", "zinc128", "zinc_eager", "zinc128_eager", "rmat_s24_1gpu"):
     p = os.path.join(SRC, f"bench_{name}.json")
     if os.path.exists(p):
         benches[name] = last_json(p)
@@ -43,7 +43,8 @@ for w in ("pubmed", "cora", "zinc"):
         shutil.copy(st, os.path.join(DST, f"{TAG}_{w}_step_kernel_stats.csv"))
         shutil.copy(os.path.join(SRC, f"{w}_step_kernel_stats_top.txt"), os.path.join(DST, f"{TAG}_{w}_step_kernel_stats_top.txt"))
 for f in ("linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt",
-          "probe_gather_l2.txt", "probe_gather_l2b.txt", "probe_valu_rate.txt"):
+          "probe_gather_l2.txt", "probe_gather_l2b.txt", "probe_valu_rate.txt", "probe_inst_cost.txt",
+          "probe_mfma32_check.txt"):
     if os.path.exists(os.path.join(SRC, f)):
         shutil.copy(os.path.join(SRC, f), os.path.join(DST, f"{TAG}_{f}"))
 
@@ -57,7 +58,8 @@ traffic = {"_how": "rocprofv3 --pmc, one counter set per pass (tools/pmc.sh: FET
 shapes = {"pubmed500": ("pubmed-F500", "pubmed", 500), "pubmed500_plain": ("pubmed-F500-untiled", "pubmed", 500),
           "pubmed32": ("pubmed-F32", "pubmed", 32), "citeseer3703": ("citeseer-F3703", "citeseer", 3703),
           "cora1433": ("cora-F1433", "cora", 1433), "zincb39": ("zinc-batch4096-F39", "zinc", 39),
-          "zinc32": ("zinc250k-F32", "zinc", 32), "zinc39": ("zinc250k-F39-ld40", "zinc", 39)}
+          "zinc32": ("zinc250k-F32", "zinc", 32), "zinc39": ("zinc250k-F39-ld40", "zinc", 39),
+          "rmat32": ("rmat-s24-F32", "rmat", 32)}
 for sh, (key, graph, F) in shapes.items():
     d = os.path.join(SRC, f"pmc_{sh}")
     if not os.path.isdir(d):
