@@ -505,10 +505,11 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
 // Mirror traffic: N^2 / 4 bytes written and read once (Pubmed 97 MB against 1.9 x 10^8 logits saved).
 // Zero-padded columns (j >= n) are corrected in the kernel (their log2(1 + e^0) = 1 is subtracted).
 // ---------------------------------------------------------------------------
-// rows per panel = 64 RI (4 waves x RI subtiles of 16 rows); "bce_sym_ri" = 0 (auto = 2) | 2 | 4.  Taller panels halve
-// the mirror strips (N^2 / 8 bytes) at the price of registers.  With the K = 16 MFMAs of round 1 they paid from
-// ~32 k rows on (ZINC batch of 95 k rows: 3.38 -> 3.13 ms); the K = 32 form keeps pairs of fragments live and the
-// 256-row variant spills 43 VGPRs (ZINC batch: 128-row panels 3.00 ms, 256-row panels 3.48 ms): opt-in only.
+// rows per panel = 64 RI (4 waves x RI subtiles of 16 rows); "bce_sym_ri" = 0 (auto) | 2 | 4.  Taller panels halve
+// the mirror strips (N^2 / 8 bytes: 2.2 -> 1.1 GB written and read back on a ZINC batch) at the price of registers
+// (2 waves per SIMD): they pay from ~32 k rows on (ZINC batch of 95 k rows: 3.00 -> 2.92 ms; Pubmed, 20 k rows:
+// 185 -> 194 us).  With the K = 32 fragments the fully unrolled 256-row body spilled 43 VGPRs (3.48 ms); its
+// column-pair loop is therefore left rolled (238 VGPRs, no spill).
 thread_local int g_bce_sym_ri = 0;
 
 // the upper 16 bits of four fp32 values (exact when they are bf16 values): one v_perm_b32 per pair
@@ -519,7 +520,8 @@ __device__ __forceinline__ s16x4 upper_halves(const f32x4 &d)
     return __builtin_bit_cast(s16x4, u);
 }
 
-// float offset of panel I's strip in Wmir: strips are [16][NP - PR (I + 1)] with NP = n rounded up to 64
+// float offset of panel I's strip in Wmir: strips are [(NP - PR (I + 1)) / 64 column tiles][16][64] with NP = n
+// rounded up to 64
 __host__ __device__ inline int64_t sym_strip_offset(int64_t I, int64_t NP, int64_t PR)
 {
     return 16 * (I * NP - PR * (I * (I + 1) / 2));
@@ -642,13 +644,14 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     };
     // sum the 4 waves' mirror tiles of the tile that started at column j0 and store it to this panel's strip
     float *strip = Wmir + sym_strip_offset(I, NP, SYM_PR);
-    const int64_t strip_ld = NP - diag_end;
     auto flush_mirror = [&](int64_t j0) {
         const int f = tid >> 4, jq = (tid & 15) * 4;
         f32x4 v = *reinterpret_cast<const f32x4 *>(&MR[0][f * LDM + jq]);
 #pragma unroll
         for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(&MR[w][f * LDM + jq]);
-        *reinterpret_cast<f32x4 *>(strip + f * strip_ld + (j0 - diag_end) + jq) = v;
+        // tile-major strip: the 16 x 64 block of one column tile is 4 KB of contiguous memory (written here by one
+        // block, read back by one block of the reduction) instead of 16 pieces of 256 bytes
+        *reinterpret_cast<f32x4 *>(strip + (j0 - diag_end) * 16 + f * TJ + jq) = v;
     };
 
     // ---- one 64-column tile.  gfx950 runs v_mfma_f32_16x16x32_bf16 in the same 4 passes as the 16x16x16 form
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
         float tA[RI], tP[RI];
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri) { tA[ri] = 0.f; tP[ri] = 1.f; }
-#pragma unroll
+#pragma unroll(RI == 4 ? 1 : TJ / 32)
         for (int jp = 0; jp < TJ / 32; ++jp) {           // pairs of 16-column subtiles
             s16x8 ph[RI], pl[RI];                        // P of the pair: [subtile 2 jp | subtile 2 jp + 1]
 #pragma unroll
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(256) void bce_mirror_reduce_kernel(const float *__r
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     auto at = [&](int64_t I) {
         const int64_t de = SYM_PR * (I + 1);
-        return *reinterpret_cast<const f32x4 *>(Wmir + sym_strip_offset(I, NP, SYM_PR) + f * (NP - de) + (j0 - de) + jq);
+        return *reinterpret_cast<const f32x4 *>(Wmir + sym_strip_offset(I, NP, SYM_PR) + (j0 - de) * 16 + f * TJ + jq);
     };
     int64_t I = 0;
     for (; I + 8 <= n_left; I += 8) {
@@ -1065,7 +1068,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     p.wmir_bytes = p.omir_bytes = 0;
     if (g_bce_sym && n_local == n && p.KS == 1 && g_bce_s_bf16 && g_bce_pv_bf16 &&
         n >= (g_bce_sym > 1 ? 512 : 8192)) {           // below ~8 k rows the extra launch costs more than it saves
-        const int64_t SYM_PR = g_bce_sym_ri == 4 ? 256 : 128;   // 256-row panels spill since the K = 32 rewrite: opt-in only
+        const int64_t SYM_PR = (g_bce_sym_ri == 4 || (g_bce_sym_ri == 0 && n >= 32768)) ? 256 : 128;
         p.sym_pr = int(SYM_PR);
         const int64_t T = (n + SYM_PR - 1) / SYM_PR, NP = (n + 63) / 64 * 64;
         int64_t chunks = (g_bce_sym_grid + T - 1) / T; // half of the (panel, chunk) grid is live
