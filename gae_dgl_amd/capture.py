@@ -16,11 +16,12 @@ from . import ops
 
 
 class CapturedTrainStep:
-    """Construct it BEFORE running eager steps on the default stream, or after dropping every reference to their
-    losses / outputs: a live autograd graph of an earlier step keeps the parameters' AccumulateGrad nodes bound to
-    the default stream, and replaying them inside the capture breaks it (PyTorch warns "AccumulateGrad node's
-    stream does not match", then hipStreamEndCapture fails).  The warm-up steps of this class run on a side
-    stream for that reason."""
+    """The warm-up steps run on a side stream and the captured step takes its gradients through
+    ``torch.autograd.grad`` (``ops.backward(loss, params)``): an AccumulateGrad node of an earlier eager iteration
+    stays bound to that iteration's stream, and replaying it inside a capture invalidates the capture (PyTorch warns
+    "AccumulateGrad node's stream does not match", then hipStreamEndCapture fails).  A garbage collection in front
+    of the warm-up frees autograd graphs that only reference cycles keep alive.  The warm-up steps DO train the
+    model (``warmup`` real steps); use ``warmup=0`` after eager steps of your own if that matters."""
 
     def __init__(self, model, optimizer, graph, features, loss_fn=None, warmup=3):
         self.model, self.opt, self.g, self.x = model, optimizer, graph, features
