@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--torch-adam", action="store_true",
                     help="torch.optim.Adam(fused=True) instead of the library's one-launch Adam (same update rule)")
     ap.add_argument("--knobs", default="", help="comma-separated gae_tuning_set name=value pairs (experiments)")
+    ap.add_argument("--no-fused-layers", action="store_true",
+                    help="run narrow GCN layers as two launches (update_all, apply_nodes) instead of gae_gcn_layer_fused")
     ap.add_argument("--no-hipgraph", action="store_true",
                     help="citation workloads: launch the step eagerly.  Default: the timed steps replay the step as "
                          "one captured HIP graph (the ~30 launches are host-bound otherwise); HIP events cannot be "
@@ -537,6 +539,9 @@ def main():
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
+    if args.no_fused_layers:
+        from gae_dgl_amd import gae as _gae
+        _gae.FUSE_NARROW_LAYERS = False
     if world > 1:
         dist.barrier()
     from gae_dgl_amd import ops

@@ -65,6 +65,8 @@ SIGNATURES = {
     "gae_spmm_csr": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _int, _p, _p,
                             ctypes.POINTER(SpmmPlan), _p, _i64, _int, _p]),
     "gae_spmm_blockdiag_lds_bytes": (_i64, [_i64, _i64, _i64]),
+    "gae_gcn_layer_fused": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _p, _i64, _int,
+                                   _p, _i64, _p]),
     "gae_spmm_csr_blockdiag": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _int,
                                       _p]),
     "gae_linear_fwd_workspace_bytes": (_i64, [_i64, _i64, _i64]),

@@ -131,6 +131,11 @@ struct EllArgs {
     unsigned n_cols, F, nvec;     // nvec = ceil(F / NV)
     unsigned n_row_blocks, n_ftiles, tile_vecs;   // tile_vecs <= LPR: 16-byte vectors per feature tile
     int xcd_tiled, store_pad, store_mode;
+    // fused dense epilogue (EPI_J > 0):  Y = act(M W^T + b), W given as W[o * w_so + k * w_sk]
+    const float *W, *bias;
+    float *Y;
+    int64_t ldy;
+    int J, w_so, w_sk, act, store_m;
 };
 
 template <typename T>
@@ -223,10 +228,39 @@ __device__ __forceinline__ void ell_batch(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_
 // One wave = 64 / LPR lane groups x RPG rows of one feature tile.  (A persistent variant -- waves looping over
 // their items with the next item's table rows prefetched -- was measured and is 10 % SLOWER on every shape: the
 // stores of item i sit in front of the gathers of item i + 1 in the wave's in-order memory queue.)
-template <typename T, int LPR, int RPG, int W, int NB, bool SCALED>
+// sum over the LPR lanes of a group (8 or 16 lanes inside a 16-lane DPP row), every lane gets the total
+template <int LPR>
+__device__ __forceinline__ float group_allreduce(float p)
+{
+    constexpr int QUAD_1032 = 0xB1, QUAD_2301 = 0x4E, ROW_MIRROR = 0x140, ROW_HALF_MIRROR = 0x141;
+    p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), QUAD_1032, 0xF, 0xF, false));
+    p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), QUAD_2301, 0xF, 0xF, false));
+    p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), ROW_HALF_MIRROR, 0xF, 0xF, false));
+    if constexpr (LPR == 16)
+        p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), ROW_MIRROR, 0xF, 0xF, false));
+    return p;
+}
+
+// EPI_J = 0: plain aggregation.  EPI_J = 16 / 32 (fp32, the whole row in one lane group: F <= 4 LPR <= 64): the
+// GCN layer in one pass -- M = aggregate (stored only if a.store_m: the backward's dW needs it), then
+// Y = act(M W^T + b) from the row still in registers: every lane multiplies its 4 features with its 4 columns of
+// the weight rows (LDS copy, loaded once per block), a DPP butterfly adds the LPR lanes, lane l keeps outputs
+// l J / LPR ....  NodeApplyModule after update_all (gae.py:28-29) without the round trip of M through HBM and
+// without a second launch.
+template <typename T, int LPR, int RPG, int W, int NB, bool SCALED, int EPI_J = 0>
 __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
 {
     constexpr int NV = Vec16<T>::NV;
+    constexpr int LDW = 68;                         // floats per LDS weight row: 64 columns + 4 (bank spread)
+    __shared__ __attribute__((aligned(16))) float Ws[EPI_J > 0 ? EPI_J * LDW : 4];
+    if constexpr (EPI_J > 0) {
+        static_assert(sizeof(T) == 4 && RPG == 1 && (LPR == 8 || LPR == 16), "epilogue: fp32 rows of one lane group");
+        for (int idx = threadIdx.x; idx < EPI_J * 64; idx += 256) {
+            const int o = idx >> 6, k = idx & 63;
+            Ws[o * LDW + k] = (o < a.J && unsigned(k) < a.F) ? a.W[int64_t(o) * a.w_so + int64_t(k) * a.w_sk] : 0.f;
+        }
+        __syncthreads();
+    }
     constexpr int LP16 = LPR < 16 ? LPR : 16;      // lanes of one group inside a 16-lane DPP row
     constexpr int NREG = (W + LP16 - 1) / LP16;    // table registers per lane and row
     constexpr int GPB = 256 / LPR, RPB = GPB * RPG;
@@ -315,22 +349,50 @@ slots_done:
             }
         }
     }
-    if (!live) return;
+    if (EPI_J == 0 && !live) return;
 #pragma unroll
     for (int r = 0; r < RPG; ++r) {
-        if (row[r] >= a.n_rows) continue;
+        if (EPI_J == 0 && row[r] >= a.n_rows) continue;
         if (SCALED) {
-            const float rs = a.row_scale[row[r]];
+            const float rs = row[r] < a.n_rows ? a.row_scale[row[r]] : 0.f;
 #pragma unroll
             for (int i = 0; i < NV; ++i) acc[r][i] *= rs;
         }
-        T *mp = static_cast<T *>(a.M) + row[r] * a.ldm + int64_t(fvec) * NV;
-        if ((fvec + 1) * NV <= a.F || a.store_pad) {
-            store16(mp, Vec16<T>::pack(acc[r]), a.store_mode);
-        } else {
+        if (live && row[r] < a.n_rows && (EPI_J == 0 || a.store_m)) {
+            T *mp = static_cast<T *>(a.M) + row[r] * a.ldm + int64_t(fvec) * NV;
+            if ((fvec + 1) * NV <= a.F || a.store_pad) {
+                store16(mp, Vec16<T>::pack(acc[r]), a.store_mode);
+            } else {
 #pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (fvec * NV + i < a.F) store_elem(mp + i, acc[r][i]);
+                for (int i = 0; i < NV; ++i)
+                    if (fvec * NV + i < a.F) store_elem(mp + i, acc[r][i]);
+            }
+        }
+        if constexpr (EPI_J > 0) {
+            // dead lanes (beyond the row's last vector) and rows beyond n_rows carry zeros and take part in the
+            // butterfly; weight columns >= F are zero in LDS
+            constexpr int JPL = EPI_J / LPR;          // outputs kept per lane
+            float yv[JPL];
+#pragma unroll
+            for (int q = 0; q < JPL; ++q) yv[q] = 0.f;
+#pragma unroll
+            for (int j = 0; j < EPI_J; ++j) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(&Ws[j * LDW + 4 * lig]);
+                float p = fmaf(acc[r][3], w[3], fmaf(acc[r][2], w[2], fmaf(acc[r][1], w[1], acc[r][0] * w[0])));
+                p = group_allreduce<LPR>(p);
+                if (j / JPL == lig) yv[j % JPL] = p;
+            }
+            if (row[r] < a.n_rows) {
+#pragma unroll
+                for (int q = 0; q < JPL; ++q) {
+                    const int o = lig * JPL + q;
+                    if (o < a.J) {
+                        float y = yv[q] + (a.bias ? a.bias[o] : 0.f);
+                        if (a.act == GAE_ACT_RELU) y = fmaxf(y, 0.f);
+                        a.Y[row[r] * a.ldy + o] = y;
+                    }
+                }
+            }
         }
     }
 }
@@ -349,6 +411,28 @@ int launch_ell(const EllArgs &a, bool scaled, hipStream_t s)
     else hipLaunchKernelGGL((spmm_ell_kernel<T, LPR, RPG, W, NB, false>), grid, dim3(256), 0, s, b);
     GAE_CHECK_LAUNCH("spmm_ell_kernel");
     return GAE_OK;
+}
+
+template <int LPR, int W, int NB, int EPI_J>
+int launch_ell_epi(const EllArgs &a, bool scaled, hipStream_t s)
+{
+    constexpr int RPB = 256 / LPR;
+    EllArgs b = a;
+    b.n_row_blocks = unsigned((a.n_rows + RPB - 1) / RPB);
+    b.n_ftiles = 1;
+    const dim3 grid(b.n_row_blocks, 1);
+    if (scaled) hipLaunchKernelGGL((spmm_ell_kernel<float, LPR, 1, W, NB, true, EPI_J>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((spmm_ell_kernel<float, LPR, 1, W, NB, false, EPI_J>), grid, dim3(256), 0, s, b);
+    GAE_CHECK_LAUNCH("spmm_ell_kernel (fused layer)");
+    return GAE_OK;
+}
+
+template <int LPR, int EPI_J>
+int launch_ell_epi_w(const EllArgs &a, int W, bool scaled, hipStream_t s)
+{
+    if (W == 4) return launch_ell_epi<LPR, 4, 4, EPI_J>(a, scaled, s);
+    if (W == 8) return launch_ell_epi<LPR, 8, 8, EPI_J>(a, scaled, s);
+    return launch_ell_epi<LPR, 16, 8, EPI_J>(a, scaled, s);
 }
 
 template <typename T, int LPR, int RPG>
@@ -420,3 +504,48 @@ int spmm_ell_launch(const int32_t *indptr, const int32_t *indices, const int32_t
 }
 
 } // namespace gae
+
+// GCN.forward (gae_dgl/gae.py:26-31) in one launch: update_all(copy_src, sum) and NodeApplyModule (Linear + bias +
+// activation) -- see the EPI_J form of spmm_ell_kernel.
+extern "C" int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                                   const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
+                                   const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
+                                   const float *W, int64_t w_stride_out, int64_t w_stride_in, const float *bias,
+                                   int64_t J, int act, float *Y, int64_t ldy, void *stream)
+{
+    GAE_REQUIRE(n_rows >= 0 && n_cols >= 0, GAE_E_SIZE, "gae_gcn_layer_fused: negative size");
+    GAE_REQUIRE(F >= 1 && F <= 64 && J >= 1 && J <= 32, GAE_E_RANGE,
+                "gae_gcn_layer_fused: needs 1 <= F <= 64 and 1 <= J <= 32 (got %lld, %lld): use gae_spmm_csr + gae_linear_fwd",
+                (long long)F, (long long)J);
+    GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_RANGE, "gae_gcn_layer_fused: act %d", act);
+    GAE_REQUIRE((row_scale == nullptr) == (col_scale == nullptr), GAE_E_NULL,
+                "gae_gcn_layer_fused: row_scale and col_scale must both be given or both be NULL");
+    GAE_REQUIRE(plan && plan->ell && plan->n_heavy == 0 &&
+                    (plan->ell_width == 4 || plan->ell_width == 8 || plan->ell_width == GAE_SPMM_ELL_WIDTH),
+                GAE_E_RANGE, "gae_gcn_layer_fused: needs a plan with a packed neighbour table and no heavy rows");
+    if (n_rows == 0) return GAE_OK;
+    GAE_REQUIRE(indptr && H && W && Y, GAE_E_NULL, "gae_gcn_layer_fused: NULL pointer");
+    GAE_REQUIRE(ldh >= F && ldh % 4 == 0 && gae::aligned16(H), GAE_E_ALIGN,
+                "gae_gcn_layer_fused: rows of H must be whole 16-byte vectors");
+    GAE_REQUIRE(!M || (ldm >= F && ldm % 4 == 0 && gae::aligned16(M)), GAE_E_ALIGN,
+                "gae_gcn_layer_fused: rows of M must be whole 16-byte vectors");
+    GAE_REQUIRE(ldy >= J, GAE_E_SIZE, "gae_gcn_layer_fused: ldy < J");
+    GAE_REQUIRE(n_cols > 0 && n_cols * ldh * 4 + (int64_t(1) << 16) < (int64_t(1) << 32), GAE_E_SIZE,
+                "gae_gcn_layer_fused: H larger than a raw buffer resource addresses");
+    EllArgs a{};
+    a.indptr = indptr; a.indices = indices; a.ell = plan->ell;
+    a.H = H; a.M = M; a.row_scale = row_scale; a.col_scale = col_scale;
+    a.n_rows = n_rows; a.ldm = M ? ldm : 0;
+    a.ldh_bytes = unsigned(ldh * 4);
+    a.h_bytes = unsigned(n_cols * ldh * 4);
+    a.n_cols = unsigned(n_cols); a.F = unsigned(F); a.nvec = unsigned((F + 3) / 4);
+    a.tile_vecs = a.nvec;
+    a.xcd_tiled = 0; a.store_pad = 0; a.store_mode = 0;
+    a.W = W; a.bias = bias; a.Y = Y; a.ldy = ldy; a.J = int(J); a.w_so = int(w_stride_out); a.w_sk = int(w_stride_in);
+    a.act = act; a.store_m = M != nullptr;
+    hipStream_t s = gae::as_stream(stream);
+    const bool scaled = row_scale != nullptr;
+    const int ew = plan->ell_width;
+    if (a.nvec <= 8) return J <= 16 ? launch_ell_epi_w<8, 16>(a, ew, scaled, s) : launch_ell_epi_w<8, 32>(a, ew, scaled, s);
+    return J <= 16 ? launch_ell_epi_w<16, 16>(a, ew, scaled, s) : launch_ell_epi_w<16, 32>(a, ew, scaled, s);
+}

@@ -22,6 +22,13 @@ from . import ops
 from ._lib import ACT_IDENTITY, ACT_RELU
 
 
+# GCN layers with <= 64 input and <= 32 output features run as ONE launch (gae_gcn_layer_fused: aggregation + Linear +
+# bias + activation, backward of the identity-activation layer likewise) when the graph carries a packed neighbour
+# table; False restores the two launches per layer (update_all, apply_nodes) everywhere.  Same values up to fp32
+# rounding of the 32 -> 16 product.
+FUSE_NARROW_LAYERS = True
+
+
 def identity(x):
     return x
 
@@ -96,6 +103,17 @@ class GCN(nn.Module):
         # same traffic on g.ndata['h'] as the reference: set (gae.py:27), reduced in place (:28), transformed in
         # place (:29), removed (:30)
         g.ndata['h'] = feature
+        code = _act_code(self.apply_mod.activation)
+        if FUSE_NARROW_LAYERS and code is not None and not self.cache_aggregate and isinstance(feature, torch.Tensor) \
+                and feature.is_cuda:
+            g._follow(feature)
+            mode = g.norm_mode if self.norm is None else self.norm
+            lin = self.apply_mod.linear
+            out = ops.gcn_layer(g, feature, lin.weight, lin.bias, code, use_norm=(mode == "both")) \
+                if mode in ("none", "both") else None
+            if out is not None:
+                g.ndata.pop('h')
+                return out
         if self.cache_aggregate and not feature.requires_grad:
             key = (id(g), g.number_of_edges(), feature.data_ptr(), feature._version, tuple(feature.shape), self.norm)
             if self._agg_key != key:

@@ -719,6 +719,110 @@ class SpMMFunction(torch.autograd.Function):
                         scattered=sc), None, None
 
 
+FUSED_LAYER_MAX_IN, FUSED_LAYER_MAX_OUT = 64, 32      # gae_gcn_layer_fused: whole row in one lane group, <= 32 outputs
+
+
+def gcn_layer_fused_usable(H, n_out, plan):
+    """can gae_gcn_layer_fused run this layer?  fp32 rows of <= 64 features made of whole 16-byte vectors, <= 32
+    outputs, a plan that carries a packed neighbour table and no heavy rows"""
+    return (plan is not None and plan.ell is not None and plan.n_heavy == 0 and H.dtype == torch.float32
+            and H.dim() == 2 and 1 <= H.shape[1] <= FUSED_LAYER_MAX_IN and 1 <= n_out <= FUSED_LAYER_MAX_OUT
+            and H.shape[0] > 0 and H.stride(1) == 1 and H.stride(0) % 4 == 0 and H.data_ptr() % 16 == 0
+            and H.shape[0] * H.stride(0) * 4 + (1 << 16) < (1 << 32))
+
+
+def gcn_layer_fused_raw(indptr, indices, H, n_rows, plan, W, bias, act, row_scale=None, col_scale=None,
+                        w_transposed=False, want_m=True):
+    """(M or None, Y): the aggregation of spmm_raw and Y = act(M W^T + b) in one launch (gae_gcn_layer_fused).
+    ``w_transposed``: use W^T, i.e. Y = M W for W [F, J] stored as nn.Linear keeps it ([out = F][in = J]) -- the
+    backward form dH = (A^T dY) W."""
+    H, ldh = _rowmajor(_f32(_gpu(H, "H"), "gcn_layer_fused: H"), "H")
+    W = _f32(_gpu(W, "W"), "gcn_layer_fused: W")
+    if W.stride(1) != 1:
+        W = W.contiguous()
+    n_cols, F = H.shape
+    if w_transposed:
+        J, so, sk = W.shape[1], 1, W.stride(0)
+        if W.shape[0] != F:
+            raise GaeHipError("gcn_layer_fused: weight shape does not match the features")
+    else:
+        J, so, sk = W.shape[0], W.stride(0), 1
+        if W.shape[1] != F:
+            raise GaeHipError("gcn_layer_fused: weight shape does not match the features")
+    _f32(bias, "gcn_layer_fused: bias")
+    M = torch.empty(n_rows, padded_ld(F, torch.float32), dtype=torch.float32, device=H.device)[:, :F] if want_m else None
+    Y = torch.empty(n_rows, J, dtype=torch.float32, device=H.device)
+    with _on_device(H.device):
+        def launch():
+            _lib.call("gae_gcn_layer_fused", _ptr(indptr), _ptr(indices), n_rows, n_cols, _ptr(H), ldh, _ptr(M),
+                      M.stride(0) if M is not None else 0, F, _ptr(row_scale), _ptr(col_scale), ctypes.byref(plan.c),
+                      _ptr(W), so, sk, _ptr(bias), J, int(act), _ptr(Y), max(J, 1), _stream())
+        if profiler is not None:
+            profiler.wrap(("spmm", n_rows, n_cols, F, str(H.dtype)), launch)
+        else:
+            launch()
+    return M, Y
+
+
+class GCNLayerFusedFunction(torch.autograd.Function):
+    """GCN.forward (gae.py:26-31) as one launch: Y = act((A H) W^T + b).  Backward: dW = dYm^T M and db from the
+    stored aggregate (gae_linear_bwd), and dH = A^T (dYm W) -- for an identity activation as ONE launch of the
+    same kernel on the CSR of A^T, dH = (A^T dY) W (the aggregation then runs at the output width)."""
+
+    @staticmethod
+    def forward(ctx, H, W, b, graph, use_norm, act):
+        indptr, indices = graph.csr()
+        norm = graph.norm() if use_norm else None
+        n = graph.number_of_nodes()
+        need_w = ctx.needs_input_grad[1] or (b is not None and ctx.needs_input_grad[2])
+        M, Y = gcn_layer_fused_raw(indptr, indices, H, n, graph.spmm_plan(False), W, b, act, norm, norm,
+                                   want_m=need_w)
+        ctx.act, ctx.has_bias = act, b is not None
+        if ctx.needs_input_grad[0]:
+            ctx.bwd = (graph.csc(), n, norm, graph.spmm_plan(True), graph.block_diag, _scattered(graph, H))
+        ctx.save_for_backward(M, W, Y if act == ACT_RELU else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        M, W, Y = ctx.saved_tensors
+        need_dH, need_dW = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dW = db = dH = None
+        fused_bwd = need_dH and ctx.act == ACT_IDENTITY and gcn_layer_fused_usable(dY.contiguous(), W.shape[1],
+                                                                                 ctx.bwd[3])
+        if need_dW or need_db or (need_dH and not fused_bwd):
+            dW, db, dM = linear_bwd_raw(dY, Y, ctx.act, M if M is not None else dY.new_zeros(dY.shape[0], W.shape[1]),
+                                        W, need_dW, need_db, need_dH and not fused_bwd)
+        if need_dH:
+            (t_indptr, t_indices), n, norm, plan_t, blockdiag, sc = ctx.bwd
+            if fused_bwd:
+                _, dH = gcn_layer_fused_raw(t_indptr, t_indices, dY.contiguous(), n, plan_t, W, None, ACT_IDENTITY,
+                                            norm, norm, w_transposed=True, want_m=False)
+            else:
+                dH = spmm_raw(t_indptr, t_indices, dM, n, norm, norm, plan=plan_t, blockdiag=blockdiag, scattered=sc)
+        return dH, dW, db, None, None, None
+
+
+def gcn_layer(graph, H, W, b, act, use_norm=False):
+    """one GCN layer on ``graph``: fused launch when the shapes allow it (gcn_layer_fused_usable), None otherwise
+    (the caller then runs update_all + apply_nodes as two launches)"""
+    if not isinstance(H, torch.Tensor) or not H.is_cuda or H.dtype != torch.float32:
+        return None
+    if graph.number_of_edges() == 0:
+        return None
+    Hc, _ = _rowmajor(H, "H")
+    if Hc.stride(0) % 4 or Hc.data_ptr() % 16:
+        Hc = pad_rows(Hc)
+    bd = graph.block_diag
+    if bd is not None and bd.usable(Hc, Hc.shape[1], Hc.stride(0), Hc.stride(0)):
+        return None                  # whole-set molecule launches: the LDS-staged block-diagonal kernel is faster
+    plan = graph.spmm_plan(False)
+    if not gcn_layer_fused_usable(Hc, W.shape[0], plan):
+        return None
+    return GCNLayerFusedFunction.apply(Hc, W, b, graph, use_norm, act)
+
+
 class LinearFunction(torch.autograd.Function):
     """NodeApplyModule: act(M W^T + b)  (gae.py:13-16)."""
 

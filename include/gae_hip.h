@@ -220,6 +220,21 @@ int gae_spmm_csr_blockdiag(const int32_t *indptr, const int32_t *indices, const 
                            const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
                            const float *row_scale, const float *col_scale, int flags, void *stream);
 
+/* GCN.forward (gae_dgl/gae.py:26-31) in ONE launch for narrow layers: the aggregation of gae_spmm_csr followed by
+ * NodeApplyModule (gae.py:13-16), Y = act(M W^T + b), computed from the aggregated row while it is still in
+ * registers.  F <= 64 input features, J <= 32 outputs, fp32, H rows of whole 16-byte vectors; the plan must carry a
+ * packed neighbour table and no heavy rows.  W is addressed as W[o * w_stride_out + k * w_stride_in] (o < J, k < F):
+ * (ld, 1) for nn.Linear's [J][F] weight, (1, ld) for its transpose -- the backward of an identity-activation layer
+ * is the same launch on the CSR of A^T: dH = (A^T dY) W.  M (may be NULL) receives the aggregate the backward's
+ * dW = dY^T M needs.  Sums run in CSR order per row; Y differs from the two-launch chain by fp32 rounding only
+ * (the 4 + LPR-lane tree of the epilogue instead of the k-ordered chain of gae_linear_fwd). */
+int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                        const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
+                        const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
+                        const float *W, int64_t w_stride_out, int64_t w_stride_in, const float *bias,
+                        int64_t J, int act, float *Y, int64_t ldy, void *stream);
+
+
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16
  * M [n, f_in] (ldm), W [f_out, f_in] row-major contiguous (nn.Linear.weight,

@@ -1296,3 +1296,48 @@ def test_cache_first_aggregate_option(dev):
         assert torch.equal(plain.reconstruction_loss(g1).detach(), cached.reconstruction_loss(g2).detach())
     finally:
         ops.profiler = None
+
+
+@pytest.mark.parametrize("f_in,f_out,act,norm", [(32, 16, "identity", "none"), (39, 32, "relu", "none"),
+                                                 (16, 32, "identity", "both"), (64, 7, "relu", "both"),
+                                                 (5, 3, "identity", "none")])
+def test_fused_gcn_layer_matches_two_launches(f_in, f_out, act, norm, dev):
+    """gae_gcn_layer_fused (aggregation + Linear + bias + activation in one launch, backward of the identity layer
+    as one launch on A^T) == update_all + apply_nodes: forward and all three gradients, with and without the
+    D^-1/2 A D^-1/2 scales, widths with tails (39, 7, 5, 3), rows longer than the packed table"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import gae as GM
+    rng = np.random.default_rng(f_in * 100 + f_out)
+    n = 3000
+    src, dst = rand_graph(rng, n, 5 * n, hub=False)
+    src = np.concatenate([src, rng.integers(0, n, 40)]); dst = np.concatenate([dst, np.full(40, 7)])   # one 40+-edge row
+    X = rng.standard_normal((n, f_in)).astype(np.float32)
+    actf = GM.identity if act == "identity" else torch.relu
+    out = {}
+    for fused in (True, False):
+        GM.FUSE_NARROW_LAYERS = fused
+        try:
+            torch.manual_seed(5)
+            layer = GM.GCN(f_in, f_out, actf, norm=norm).to(dev)
+            g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+            x = t(X, dev).requires_grad_(True)
+            y = layer(g, x)
+            w = t(rng.standard_normal((n, f_out)).astype(np.float32), dev) if fused else out["w"]
+            out["w"] = w
+            (y * w).sum().backward()
+            out[fused] = (y.detach(), x.grad.clone(), layer.apply_mod.linear.weight.grad.clone(),
+                          layer.apply_mod.linear.bias.grad.clone())
+        finally:
+            GM.FUSE_NARROW_LAYERS = True
+    for a, b, tol in zip(out[True], out[False], (1e-5, 5e-5, 5e-5, 5e-5)):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6)
+    # and against the oracle's layer
+    from oracle import gae_oracle as O
+    ip, ix = O.csr_from_coo(src, dst, n)
+    layer_w = layer.apply_mod.linear.weight.detach().cpu().double().numpy()
+    layer_b = layer.apply_mod.linear.bias.detach().cpu().double().numpy()
+    nrm = O.norm_from_in_degrees(O.in_degrees(dst, n)) if norm == "both" else None
+    ref = O.gcn_layer(ip, ix, torch.as_tensor(X).double(), torch.as_tensor(layer_w), torch.as_tensor(layer_b), act,
+                      norm=None if nrm is None else torch.as_tensor(nrm).double())
+    assert float((out[True][0].cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
