@@ -153,11 +153,11 @@ class CapturedInductiveStep:
         self.g, self.x = g, feat[:, :F]
 
     def _step_body(self):
-        """select -> plan -> gather -> forward -> loss -> backward -> Adam, all on static buffers"""
+        """select + plan -> gather -> forward -> loss -> backward -> Adam, all on static buffers"""
         ds, g = self.ds, self.g
-        ops.batch_select(self.d_order, self.cursor, self.B, self.gids)
-        node_ptr, edge_ptr, t_edge_ptr = ops.batch_plan(ds.graph_ptr, ds.indptr, None if ds.symmetric else ds.t_indptr,
-                                                        self.gids, out=self.ptrs)
+        node_ptr, edge_ptr, t_edge_ptr = ops.batch_plan_next(ds.graph_ptr, ds.indptr,
+                                                             None if ds.symmetric else ds.t_indptr, self.d_order,
+                                                             self.cursor, self.gids, self.ptrs)
         ops.batch_gather(ds.graph_ptr, ds.indptr, ds.indices, ds.feat, self.gids, node_ptr, edge_ptr, self.cap_nodes,
                          self.cap_edges, ell_width=ds.ell_width, n_feat=ds.n_feat, out=self.fwd, pad_to_capacity=True,
                          counts=self.counts)

@@ -120,18 +120,29 @@ __global__ __launch_bounds__(1024) void batch_plan_kernel(const int64_t *__restr
                                                           const int32_t *__restrict__ t_indptr,
                                                           const int64_t *__restrict__ graph_ids, int64_t n_graphs,
                                                           int64_t *__restrict__ node_ptr, int64_t *__restrict__ edge_ptr,
-                                                          int64_t *__restrict__ t_edge_ptr)
+                                                          int64_t *__restrict__ t_edge_ptr,
+                                                          // gae_batch_plan_next: the ids come from an epoch order
+                                                          const int64_t *__restrict__ order, int64_t n_order,
+                                                          int64_t *__restrict__ cursor, int64_t *__restrict__ ids_out)
 {
     __shared__ long long wsum[3][16];
     __shared__ long long carry[3];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 3) carry[tid] = 0;
+    const int64_t cur = order ? *cursor : 0;
     __syncthreads();
     for (int64_t base = 0; base < n_graphs; base += 1024) {
         const int64_t b = base + tid;
         long long v[3] = {0, 0, 0};
         if (b < n_graphs) {
-            const int64_t g = graph_ids[b];
+            int64_t g;
+            if (order) {
+                const int64_t k = cur * n_graphs + b;
+                g = order[k < n_order ? k : n_order - 1];
+                ids_out[b] = g;
+            } else {
+                g = graph_ids[b];
+            }
             const int64_t n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
             v[0] = n1 - n0;
             v[1] = (long long)indptr[n1] - indptr[n0];
@@ -173,6 +184,7 @@ __global__ __launch_bounds__(1024) void batch_plan_kernel(const int64_t *__restr
         }
         __syncthreads();
     }
+    if (order && tid == 0) *cursor = cur + 1;      // every thread read the cursor before the first barrier
 }
 
 template <typename TI, typename TO>
@@ -367,7 +379,22 @@ extern "C" int gae_batch_plan(const int64_t *graph_ptr, const int32_t *ds_indptr
     }
     GAE_REQUIRE(graph_ptr && ds_indptr && graph_ids, GAE_E_NULL, "gae_batch_plan: NULL pointer");
     hipLaunchKernelGGL(batch_plan_kernel, dim3(1), dim3(1024), 0, s, graph_ptr, ds_indptr, ds_t_indptr, graph_ids,
-                       n_graphs, out_node_ptr, out_edge_ptr, out_t_edge_ptr);
+                       n_graphs, out_node_ptr, out_edge_ptr, out_t_edge_ptr, nullptr, 0, nullptr, nullptr);
+    GAE_CHECK_LAUNCH("batch_plan_kernel");
+    return GAE_OK;
+}
+
+extern "C" int gae_batch_plan_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
+                                   const int64_t *order, int64_t n_order, int64_t *cursor_dev, int64_t n_graphs,
+                                   int64_t *out_ids, int64_t *out_node_ptr, int64_t *out_edge_ptr,
+                                   int64_t *out_t_edge_ptr, void *stream)
+{
+    GAE_REQUIRE(n_graphs > 0 && n_order > 0, GAE_E_SIZE, "gae_batch_plan_next: sizes must be positive");
+    GAE_REQUIRE(graph_ptr && ds_indptr && order && cursor_dev && out_ids && out_node_ptr && out_edge_ptr, GAE_E_NULL,
+                "gae_batch_plan_next: NULL pointer");
+    hipLaunchKernelGGL(batch_plan_kernel, dim3(1), dim3(1024), 0, gae::as_stream(stream), graph_ptr, ds_indptr,
+                       ds_t_indptr, nullptr, n_graphs, out_node_ptr, out_edge_ptr, out_t_edge_ptr, order, n_order,
+                       cursor_dev, out_ids);
     GAE_CHECK_LAUNCH("batch_plan_kernel");
     return GAE_OK;
 }

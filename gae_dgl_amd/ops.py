@@ -214,6 +214,20 @@ def batch_select(order, cursor, batch_graphs, out_ids):
     return out_ids
 
 
+def batch_plan_next(graph_ptr, ds_indptr, ds_t_indptr, order, cursor, out_ids, out):
+    """batch_select + batch_plan in one launch (gae_batch_plan_next): the ids of batch ``cursor`` of ``order`` go to
+    ``out_ids`` (int64 [B]), their prefix sums to ``out`` (int64 [3 or 2, B + 1]), the cursor advances"""
+    B = out_ids.numel()
+    rows = 3 if ds_t_indptr is not None else 2
+    if out.shape != (rows, B + 1) or out.dtype != torch.int64 or not out.is_contiguous():
+        raise GaeHipError("batch_plan_next: `out` must be a contiguous int64 [rows, B + 1] buffer")
+    with _on_device(order.device):
+        _lib.call("gae_batch_plan_next", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_t_indptr), _ptr(order),
+                  order.numel(), _ptr(cursor), B, _ptr(out_ids), _ptr(out[0]), _ptr(out[1]),
+                  _ptr(out[2]) if rows == 3 else None, _stream())
+    return out[0], out[1], (out[2] if rows == 3 else None)
+
+
 def batch_feature_ld(ds_feat, n_feat=None):
     """(F, leading dimension, dtype) of the feature matrix gae_batch_gather writes for ``ds_feat``"""
     F = ds_feat.shape[1] if n_feat is None else int(n_feat)

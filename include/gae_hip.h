@@ -126,6 +126,12 @@ int gae_csr_to_dense(const int32_t *indptr, const int32_t *indices, int64_t n_ro
  * a replayed graph walks an epoch order that was uploaded once). */
 int gae_batch_select(const int64_t *order, int64_t n_order, int64_t *cursor_dev, int64_t batch_graphs,
                      int64_t *out_ids, void *stream);
+/* gae_batch_select + gae_batch_plan in one launch (the step of a captured HIP graph): ids of batch *cursor_dev of the
+ * epoch order -> out_ids, their prefix sums -> out_*_ptr, *cursor_dev += 1. */
+int gae_batch_plan_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
+                        const int64_t *order, int64_t n_order, int64_t *cursor_dev, int64_t n_graphs,
+                        int64_t *out_ids, int64_t *out_node_ptr, int64_t *out_edge_ptr, int64_t *out_t_edge_ptr,
+                        void *stream);
 int gae_batch_plan(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
                    const int64_t *graph_ids, int64_t n_graphs, int64_t *out_node_ptr, int64_t *out_edge_ptr,
                    int64_t *out_t_edge_ptr, void *stream);

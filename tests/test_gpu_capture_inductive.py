@@ -147,3 +147,25 @@ def test_captured_step_grows_and_rejects():
     r2 = CapturedInductiveStep(wide, Adam(wide.parameters()), ds, 16)
     with pytest.raises(ops.GaeHipError):
         r2.begin_epoch(ds.ids[:32])
+
+
+def test_batch_select_and_plan_next_walk_an_epoch_order():
+    """gae_batch_select and the fused gae_batch_plan_next: ids of batch `cursor` of an uploaded order, the cursor
+    advances on the device, prefix sums equal gae_batch_plan's on the same ids (bit-exact integer work)"""
+    from gae_dgl_amd import ops
+    ds, _ = _dataset(200)
+    B = 24
+    order = np.random.default_rng(4).permutation(ds.ids)
+    d_order = torch.from_numpy(order).to(DEV)
+    cur_a = torch.zeros(1, dtype=torch.int64, device=DEV); cur_b = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ids_a = torch.empty(B, dtype=torch.int64, device=DEV); ids_b = torch.empty(B, dtype=torch.int64, device=DEV)
+    ptrs = torch.empty(2, B + 1, dtype=torch.int64, device=DEV)
+    for k in range(len(order) // B):
+        ops.batch_select(d_order, cur_a, B, ids_a)
+        node_ptr, edge_ptr, _ = ops.batch_plan_next(ds.graph_ptr, ds.indptr, None, d_order, cur_b, ids_b, ptrs)
+        want = order[k * B:(k + 1) * B]
+        assert np.array_equal(ids_a.cpu().numpy(), want) and np.array_equal(ids_b.cpu().numpy(), want)
+        assert int(cur_a) == int(cur_b) == k + 1
+        ref = ops.batch_plan(ds.graph_ptr, ds.indptr, None, ids_a)
+        assert torch.equal(node_ptr, ref[0]) and torch.equal(edge_ptr, ref[1])
+        assert np.array_equal(node_ptr.cpu().numpy()[1:], np.cumsum(ds.sizes_host[want]))
