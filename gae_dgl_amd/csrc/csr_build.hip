@@ -236,23 +236,66 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
     const int64_t shift = on - n0;
     for (int32_t e = e0 + lane; e < e1; e += kWave)
         out_indices[oe + (e - e0)] = int32_t(ds_indices[e] + shift);
-    if (out_ell) {
-        const int W = ell_width;
-        for (int64_t idx = lane; idx < nn * W; idx += kWave) {
-            const int64_t i = idx / W;
-            const int k = int(idx - i * W);
-            const int32_t p = ds_indptr[n0 + i], deg = ds_indptr[n0 + i + 1] - p;
-            int32_t v;
-            if (deg > W && k == W - 1) v = -2;                    // row continues in the CSR arrays
-            else v = k < deg ? int32_t(ds_indices[p + k] + shift) : -1;
-            out_ell[(on + i) * W + k] = v;
+    // 32-bit index arithmetic below: a member graph has far fewer than 2^31 / ld_out rows, and a 64-bit division per
+    // copied element was most of this kernel's time on small batches
+    const unsigned nn32 = unsigned(nn);
+    if (out_ell && nn32 > 0) {
+        // same treatment as the feature copy below: UNR independent (row pointer -> column id) chains per trip,
+        // branch-free (clamped addresses, selection after the loads); an edge-less molecule loads no column ids
+        constexpr int UNR = 4;
+        const unsigned W = unsigned(ell_width), total = nn32 * W;
+        const bool has_edges = e1 > e0;                              // wave-uniform
+        for (unsigned base = lane; base < total; base += kWave * UNR) {
+            int32_t p[UNR], deg[UNR], col[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                unsigned idx = base + u * kWave;
+                idx = idx < total ? idx : total - 1;
+                const unsigned i = idx / W;
+                p[u] = ds_indptr[n0 + i];
+                deg[u] = ds_indptr[n0 + i + 1] - p[u];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                unsigned idx = base + u * kWave;
+                idx = idx < total ? idx : total - 1;
+                const unsigned i = idx / W, k = idx - i * W;
+                int32_t at = p[u] + int32_t(k);
+                at = at < e1 ? at : e1 - 1;
+                col[u] = has_edges ? ds_indices[at] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const unsigned idx = base + u * kWave;
+                const unsigned i = idx / W, k = idx - i * W;
+                int32_t v;
+                if (deg[u] > int32_t(W) && k == W - 1) v = -2;       // row continues in the CSR arrays
+                else v = int32_t(k) < deg[u] ? int32_t(col[u] + shift) : -1;
+                if (idx < total) out_ell[(on + i) * W + k] = v;
+            }
         }
     }
-    if (out_feat) {                        // whole output rows: the pad columns [F, ld_out) are written as zeros
-        const int64_t total = nn * ld_out;
-        for (int64_t i = lane; i < total; i += kWave) {
-            const int64_t r = i / ld_out, c = i - r * ld_out;
-            out_feat[(on + r) * ld_out + c] = c < F ? feat_convert<TI, TO>(ds_feat[(n0 + r) * ld_feat + c]) : TO(0);
+    if (out_feat && nn32 > 0) {            // whole output rows: the pad columns [F, ld_out) are written as zeros
+        // a molecule's copy is a chain of dependent round trips (cold rows of the dataset), not a byte stream: every
+        // trip issues UNR independent loads -- branch-free: indices clamped into the molecule, values selected after
+        // the loads -- before its first store (38 atoms x 40 columns: 3 trips instead of 24)
+        constexpr int UNR = 8;
+        const unsigned ldo = unsigned(ld_out), total = nn32 * ldo, F32 = unsigned(F);
+        for (unsigned base = lane; base < total; base += kWave * UNR) {
+            TI raw[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                unsigned i = base + u * kWave;
+                i = i < total ? i : total - 1;
+                const unsigned r = i / ldo, c = i - r * ldo;
+                raw[u] = ds_feat[(n0 + r) * ld_feat + (c < F32 ? c : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const unsigned i = base + u * kWave;
+                const unsigned r = i / ldo, c = i - r * ldo;
+                if (i < total) out_feat[(on + r) * ld_out + c] = c < F32 ? feat_convert<TI, TO>(raw[u]) : TO(0);
+            }
         }
     }
 }
