@@ -51,6 +51,7 @@ constexpr int PREP_ROWS = 64;    // rows per block of the prepare kernel
 thread_local int g_bce_ri = 2;
 thread_local int g_bce_minw = 0;
 thread_local int g_bce_s_bf16 = 1;
+thread_local int g_bce_grid = 2048;       // "bce_grid": target size of the (row block, column split) grid of the full-square kernel
 thread_local int g_bce_sym_grid = 16384;  // "bce_sym_grid": target size of the (panel, chunk) grid of the symmetric kernel
                              // (many short blocks even out the triangular work: ZINC batch 3.64 -> 3.35 ms)
 thread_local int g_bce_sym = 1;       // "bce_sym": 1 = symmetric dense kernel for full-square launches with d <= 16
@@ -1045,7 +1046,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     if (p.row_blocks < 1) p.row_blocks = 1;
     int64_t col_tiles = (n + TJ - 1) / TJ;
     if (col_tiles < 1) col_tiles = 1;
-    int64_t want = (2048 + p.row_blocks - 1) / p.row_blocks;  // ~8 blocks per CU
+    int64_t want = (g_bce_grid + p.row_blocks - 1) / p.row_blocks;  // ~8 blocks per CU
     if (want > col_tiles) want = col_tiles;
     if (want > 32) want = 32;                                 // each split is one more partial O' per row to add
     if (want < 1) want = 1;
@@ -1167,6 +1168,7 @@ int *bce_knob(const char *name)
     if (strcmp(name, "bce_pv_bf16") == 0) return &g_bce_pv_bf16;
     if (strcmp(name, "bce_sym") == 0) return &g_bce_sym;
     if (strcmp(name, "bce_sym_grid") == 0) return &g_bce_sym_grid;
+    if (strcmp(name, "bce_grid") == 0) return &g_bce_grid;
     if (strcmp(name, "bce_sym_ri") == 0) return &g_bce_sym_ri;
     return nullptr;
 }

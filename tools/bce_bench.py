@@ -37,6 +37,7 @@ for rnd in range(a.rounds + 1):
         _lib.call("gae_tuning_set", b"bce_sym", int(kv.get("sym", 1)))
         _lib.call("gae_tuning_set", b"bce_sym_grid", int(kv.get("grid", 16384)))
         _lib.call("gae_tuning_set", b"bce_sym_ri", int(kv.get("sri", 0)))
+        _lib.call("gae_tuning_set", b"bce_grid", int(kv.get("fgrid", 2048)))
         fn = lambda: ops.decoder_bce_raw(Z, mask, g.csr(), g.csc(), pw, True)
         loss, dz = fn(); torch.cuda.synchronize()
         if rnd == 0:
