@@ -52,6 +52,8 @@ thread_local int g_bce_ri = 2;
 thread_local int g_bce_minw = 0;
 thread_local int g_bce_s_bf16 = 1;
 thread_local int g_bce_grid = 2048;       // "bce_grid": target size of the (row block, column split) grid of the full-square kernel
+constexpr int kChipCus = 256;             // MI355X: the launch-shape heuristics below are written for this part
+thread_local int g_bce_sym_tiles = 0;     // "bce_sym_tiles": 64-column tiles per block of the symmetric kernel (0 = auto)
 thread_local int g_bce_sym_grid = 16384;  // "bce_sym_grid": target size of the (panel, chunk) grid of the symmetric kernel
                              // (many short blocks even out the triangular work: ZINC batch 3.64 -> 3.35 ms)
 thread_local int g_bce_sym = 1;       // "bce_sym": 1 = symmetric dense kernel for full-square launches with d <= 16
@@ -1076,7 +1078,32 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
         if (chunks > 28) chunks = 28;                  // every chunk is one more partial O' per row to write and add
         if (chunks > col_tiles) chunks = col_tiles;
         if (chunks < 1) chunks = 1;
-        const int64_t cpc = ((n + chunks - 1) / chunks + TJ - 1) / TJ * TJ;
+        int64_t cpc = ((n + chunks - 1) / chunks + TJ - 1) / TJ * TJ;
+        if (g_bce_sym_tiles > 0) {
+            cpc = int64_t(g_bce_sym_tiles) * TJ;
+        } else {
+            // Launches of a few rounds of blocks (Pubmed: ~2000 live blocks on 768 slots): pick the tiles per block,
+            // within a quarter of the value above, that fills the last round best (12 -> 11 tiles: 2060 -> 2250
+            // blocks = 2.93 rounds instead of 2.68; 169 -> 166 us).  Long launches keep the value: fewer partials.
+            const int64_t slots = int64_t(kChipCus) * (SYM_PR == 128 ? 3 : 2);
+            auto live_blocks = [&](int64_t t) {
+                int64_t L = 0;
+                for (int64_t I = 0; I < T; ++I) L += (n - SYM_PR * I + t * TJ - 1) / (t * TJ);
+                return L;
+            };
+            const int64_t t0 = cpc / TJ;
+            if ((live_blocks(t0) + slots - 1) / slots <= 6) {
+                double best = -1.0;
+                int64_t best_t = t0;
+                for (int64_t t = t0 - t0 / 4; t <= t0 + t0 / 4; ++t) {
+                    if (t < 1) continue;
+                    const int64_t L = live_blocks(t), rounds = (L + slots - 1) / slots;
+                    const double fill = double(L) / double(rounds * slots) - 0.002 * double(t > t0 ? t - t0 : t0 - t);
+                    if (fill > best) { best = fill; best_t = t; }
+                }
+                cpc = best_t * TJ;
+            }
+        }
         const int64_t last_len = NP - SYM_PR * T;      // strip length of the last panel (<= 0: it has no strip)
         const int64_t wfloats = sym_strip_offset(T - 1, NP, SYM_PR) + 16 * (last_len > 0 ? last_len : 0);
         if (wfloats * 4 <= (int64_t(8) << 30)) {
@@ -1169,6 +1196,7 @@ int *bce_knob(const char *name)
     if (strcmp(name, "bce_sym") == 0) return &g_bce_sym;
     if (strcmp(name, "bce_sym_grid") == 0) return &g_bce_sym_grid;
     if (strcmp(name, "bce_grid") == 0) return &g_bce_grid;
+    if (strcmp(name, "bce_sym_tiles") == 0) return &g_bce_sym_tiles;
     if (strcmp(name, "bce_sym_ri") == 0) return &g_bce_sym_ri;
     return nullptr;
 }

@@ -38,6 +38,7 @@ for rnd in range(a.rounds + 1):
         _lib.call("gae_tuning_set", b"bce_sym_grid", int(kv.get("grid", 16384)))
         _lib.call("gae_tuning_set", b"bce_sym_ri", int(kv.get("sri", 0)))
         _lib.call("gae_tuning_set", b"bce_grid", int(kv.get("fgrid", 2048)))
+        _lib.call("gae_tuning_set", b"bce_sym_tiles", int(kv.get("tiles", 0)))
         fn = lambda: ops.decoder_bce_raw(Z, mask, g.csr(), g.csc(), pw, True)
         loss, dz = fn(); torch.cuda.synchronize()
         if rnd == 0:
