@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const int32_t *__restric
 // tuning knobs (gae_tuning_set): read-mostly process-wide integers
 thread_local int g_spmm_variant = 2;   // 1 = v1 rowgroup, 2 = v2 rowgroup2
 thread_local int g_spmm_rpg = 0;       // rows per lane group (v2): 0 = auto (2 for launches of >= 32768 waves, else 1), 1, 2
-thread_local int g_spmm_nt = 1;        // store policy of M (v2): -1 = auto, 0 plain, 1 non-temporal, 2 write-through sc1
+thread_local int g_spmm_nt = -1;       // store policy of M (v2): -1 = auto (sc1 under feature tiles, else nt), 0 plain, 1 non-temporal, 2 write-through sc1
 thread_local int g_spmm_tile_vecs = 0; // 16-byte vectors per XCD feature tile: 0 = auto when GAE_SPMM_TILE is set, -1 = never, > 0 = forced
 thread_local int g_spmm_ell = 1;       // the plan's packed neighbour table: 0 = ignore it, 1 = spmm_ell.hip kernels (row-group
                           // kernel when they cannot run the launch), 2 = row-group kernel only
@@ -535,7 +535,10 @@ int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_
         const int tv = tile_vecs > 0 ? tile_vecs : (nvec < 64 ? nvec : 64);
         if (tv <= 64 && gae::spmm_ell_usable(n_cols, ldh, int(sizeof(T)), ell_width, tv)) {
             const int store_pad = ((flags & GAE_SPMM_STORE_PAD) && int64_t(nvec) * VEC <= ldm) ? 1 : 0;
-            const int store_mode = sizeof(T) != 4 ? 0 : st >= 0 ? st : 1;
+            // write-through (sc1) under feature tiles: the launch itself is 0.4 us faster on Pubmed and the Linear that
+            // reads M next finds it in the memory-side cache (non-temporal stores: 22.6 us instead of 17 us for that
+            // launch inside a Pubmed step); untiled launches (molecule batches) are faster with non-temporal stores
+            const int store_mode = sizeof(T) != 4 ? 0 : st >= 0 ? st : (tile_vecs > 0 ? 2 : 1);
             return gae::spmm_ell_launch(indptr, indices, ell, ell_width, n_rows, n_cols, H, ldh, M, ldm, F,
                                         sizeof(T) == 4 ? GAE_F32 : GAE_BF16, rs, cs, tv, tile_vecs > 0 ? 1 : 0,
                                         store_pad, store_mode, s);

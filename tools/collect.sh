@@ -16,6 +16,7 @@ MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 timeout 900 python bench.py --workload r
 for w in pubmed cora zinc; do
   timeout 600 tools/prof_bench.sh $TAG/prof_$w --workload $w --steps 30 --warmup 3 > $O/${w}_step_kernel_stats_top.txt
 done
+timeout 600 tools/prof_bench.sh $TAG/prof_zinc128 --workload zinc --batch-graphs 128 --steps 200 --warmup 20 > $O/zinc128_step_kernel_stats_top.txt
 export PMC_SETS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
 export PMC_FILTER=spmm
 for sh in pubmed500 pubmed32 cora1433 citeseer3703 zincb39 zinc32 zinc39; do
@@ -27,6 +28,7 @@ timeout 300 python tools/linear_bench.py --rows 256 2>/dev/null > $O/linear_benc
 timeout 300 python tools/spmm_bench.py --shapes pubmed500a,pband500 --variants v2:0:1:0:p,v2:0:1:0:pt,v2:0:1:0:pEt,v2:1:1:0:pet --rounds 5 2>/dev/null > $O/spmm_bench_pubmed.txt
 timeout 300 python tools/spmm_bench.py --shapes pdiag_zero,pdiag_col2k --variants v2:0:1:0:p,v2:1:1:16:pet --rounds 5 2>/dev/null > $O/spmm_bench_diag.txt
 timeout 300 python tools/bce_bench.py --variants "sym=1;sym=0;sym=0,sb=0,pb=0" --rounds 5 2>/dev/null > $O/bce_bench_pubmed.txt
+timeout 300 python tools/bce_bench.py --n 94752 --variants "sym=1;sym=1,sri=2;sym=0" --rounds 3 2>/dev/null > $O/bce_bench_zinc.txt
 timeout 200 tools/probes/bin/gather_l2 > $O/probe_gather_l2.txt 2>&1
 timeout 200 tools/probes/bin/gather_l2b > $O/probe_gather_l2b.txt 2>&1
 timeout 100 tools/probes/bin/valu_rate > $O/probe_valu_rate.txt 2>&1

@@ -37,12 +37,12 @@ for name in ("pubmed", "cora", "citeseer", "zinc", "zinc128", "zinc_eager", "zin
     if os.path.exists(p):
         benches[name] = last_json(p)
         json.dump(benches[name], open(os.path.join(DST, f"{TAG}_bench_{name}.json"), "w"), indent=1)
-for w in ("pubmed", "cora", "zinc"):
+for w in ("pubmed", "cora", "zinc", "zinc128"):
     st = os.path.join(SRC, f"prof_{w}", "bench_kernel_stats.csv")
     if os.path.exists(st):
         shutil.copy(st, os.path.join(DST, f"{TAG}_{w}_step_kernel_stats.csv"))
         shutil.copy(os.path.join(SRC, f"{w}_step_kernel_stats_top.txt"), os.path.join(DST, f"{TAG}_{w}_step_kernel_stats_top.txt"))
-for f in ("linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt",
+for f in ("linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt", "bce_bench_zinc.txt",
           "probe_gather_l2.txt", "probe_gather_l2b.txt", "probe_valu_rate.txt", "probe_inst_cost.txt",
           "probe_mfma32_check.txt"):
     if os.path.exists(os.path.join(SRC, f)):
