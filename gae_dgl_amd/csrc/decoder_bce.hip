@@ -53,6 +53,8 @@ thread_local int g_bce_minw = 0;
 thread_local int g_bce_s_bf16 = 1;
 thread_local int g_bce_grid = 2048;       // "bce_grid": target size of the (row block, column split) grid of the full-square kernel
 constexpr int kChipCus = 256;             // MI355X: the launch-shape heuristics below are written for this part
+thread_local int g_bce_strip_store = -1;  // "bce_strip_store": -1 auto (non-temporal from 32 k rows on: GBs of strips, 2.93 -> 2.88 ms on a ZINC
+                                          // batch; plain below: Pubmed 170 vs 174 us), 0 plain, 1 non-temporal, 2 write-through
 thread_local int g_bce_sym_tiles = 0;     // "bce_sym_tiles": 64-column tiles per block of the symmetric kernel (0 = auto)
 thread_local int g_bce_sym_grid = 16384;  // "bce_sym_grid": target size of the (panel, chunk) grid of the symmetric kernel
                              // (many short blocks even out the triangular work: ZINC batch 3.64 -> 3.35 ms)
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     const unsigned short *__restrict__ Zlo, int64_t n, int64_t cols_per_chunk,
     float *__restrict__ O_partial /*[chunks][n][16]*/, float *__restrict__ Wmir,
     double *__restrict__ loss_partial /*[chunks * panels][2]*/, const double *__restrict__ colsum_partial,
-    int64_t n_prep_blocks, double *__restrict__ S, float *__restrict__ S_all_f, unsigned n_panels)
+    int64_t n_prep_blocks, double *__restrict__ S, float *__restrict__ S_all_f, unsigned n_panels, int exp_strip)
 {
     constexpr int DP = 16, SYM_PR = 64 * RI;
     constexpr int LDH = DP + 4;          // bf16 LDS row stride (elements): 8-byte aligned rows
@@ -654,7 +656,10 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
         for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(&MR[w][f * LDM + jq]);
         // tile-major strip: the 16 x 64 block of one column tile is 4 KB of contiguous memory (written here by one
         // block, read back by one block of the reduction) instead of 16 pieces of 256 bytes
-        *reinterpret_cast<f32x4 *>(strip + (j0 - diag_end) * 16 + f * TJ + jq) = v;
+        f32x4 *sp = reinterpret_cast<f32x4 *>(strip + (j0 - diag_end) * 16 + f * TJ + jq);
+        if (exp_strip == 1) __builtin_nontemporal_store(v, sp);
+        else if (exp_strip == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(sp), "v"(v) : "memory");
+        else *sp = v;
     };
 
     // ---- one 64-column tile.  gfx950 runs v_mfma_f32_16x16x32_bf16 in the same 4 passes as the 16x16x16 form
@@ -1197,6 +1202,7 @@ int *bce_knob(const char *name)
     if (strcmp(name, "bce_sym_grid") == 0) return &g_bce_sym_grid;
     if (strcmp(name, "bce_grid") == 0) return &g_bce_grid;
     if (strcmp(name, "bce_sym_tiles") == 0) return &g_bce_sym_tiles;
+    if (strcmp(name, "bce_strip_store") == 0) return &g_bce_strip_store;
     if (strcmp(name, "bce_sym_ri") == 0) return &g_bce_sym_ri;
     return nullptr;
 }
@@ -1266,7 +1272,8 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
         const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
 #define GAE_SYM(WG, R)                                                                                             \
     hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
-                       lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks))
+                       lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks),                                    \
+                       g_bce_strip_store >= 0 ? g_bce_strip_store : (n >= 32768 ? 1 : 0))
         if (p.sym_pr == 256) { if (dZ) GAE_SYM(true, 4); else GAE_SYM(false, 4); }
         else { if (dZ) GAE_SYM(true, 2); else GAE_SYM(false, 2); }
 #undef GAE_SYM
