@@ -253,13 +253,19 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
     constexpr int NV = Vec16<T>::NV;
     constexpr int LDW = 68;                         // floats per LDS weight row: 64 columns + 4 (bank spread)
     __shared__ __attribute__((aligned(16))) float Ws[EPI_J > 0 ? EPI_J * LDW : 4];
+    // the weights travel to LDS through registers: requested here, written (and the block synchronised) only in
+    // front of the epilogue, so their round trip hides behind the table load and the gathers of this short block
+    constexpr int WREG = EPI_J > 0 ? EPI_J * 64 / 256 : 1;
+    float wreg[WREG];
     if constexpr (EPI_J > 0) {
         static_assert(sizeof(T) == 4 && RPG == 1 && (LPR == 8 || LPR == 16), "epilogue: fp32 rows of one lane group");
-        for (int idx = threadIdx.x; idx < EPI_J * 64; idx += 256) {
-            const int o = idx >> 6, k = idx & 63;
-            Ws[o * LDW + k] = (o < a.J && unsigned(k) < a.F) ? a.W[int64_t(o) * a.w_so + int64_t(k) * a.w_sk] : 0.f;
+#pragma unroll
+        for (int q = 0; q < WREG; ++q) {
+            const int idx = threadIdx.x + 256 * q, o = idx >> 6, k = idx & 63;
+            const bool in = o < a.J && unsigned(k) < a.F;
+            const float w = a.W[in ? int64_t(o) * a.w_so + int64_t(k) * a.w_sk : 0];      // branch-free load
+            wreg[q] = in ? w : 0.f;
         }
-        __syncthreads();
     }
     constexpr int LP16 = LPR < 16 ? LPR : 16;      // lanes of one group inside a 16-lane DPP row
     constexpr int NREG = (W + LP16 - 1) / LP16;    // table registers per lane and row
@@ -350,6 +356,14 @@ slots_done:
         }
     }
     if (EPI_J == 0 && !live) return;
+    if constexpr (EPI_J > 0) {
+#pragma unroll
+        for (int q = 0; q < WREG; ++q) {
+            const int idx = threadIdx.x + 256 * q;
+            Ws[(idx >> 6) * LDW + (idx & 63)] = wreg[q];
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < RPG; ++r) {
         if (EPI_J == 0 && row[r] >= a.n_rows) continue;
