@@ -21,6 +21,8 @@ using gae::kWave;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
+thread_local int g_linear_nw = 0;     // "linear_nw": waves per block of that kernel (0 = 4, 8)
+thread_local int g_linear_f32x16 = 1; // "linear_f32x16": exact-fp32 forward Linear through the 64-byte-piece loader (0 = gemm_stream_kernel)
 thread_local int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
 thread_local int g_linear_wlds = 1;  // tuning knob: 0 = never use linear_fwd_wlds_kernel, 1 = where measured faster, 2 = wherever it applies
 thread_local int g_linear_bf16 = 0;  // tuning knob: 0 = exact fp32 forward Linear (default: embeddings within 2e-7 of fp64 instead of
@@ -479,20 +481,23 @@ __global__ __launch_bounds__(512) void linear_fwd_wlds_kernel(
 // pipe does the products in a fifth of the fp32 MFMA time.  A block owns 32 rows (2 row tiles); its 4 waves split
 // the block's K range (split-K over blockIdx.y as in gemm_stream_kernel) and meet in LDS in fixed order.
 // ---------------------------------------------------------------------------
-template <bool WVEC>
-__global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(
+// EXACT = true: the same loader (64-byte row pieces: 2 requests per 128-byte line instead of the 4.3 of
+// gemm_stream_kernel's 32-byte pieces) feeding v_mfma_f32_16x16x4_f32 -- exact fp32 products; the 4 values a lane
+// holds go to 4 consecutive MFMAs, each of which contracts the k positions {4 g + r} of the 16-k step.
+template <bool WVEC, bool EXACT = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void linear_fwd_bf16_kernel(
     const float *__restrict__ A, int64_t lda, const float *__restrict__ W, int64_t ldw,
     const float *__restrict__ bias, int act, float *__restrict__ out, int64_t ldo, int64_t n, int K, int J,
     int ks_per_split, int64_t split_stride)
 {
-    __shared__ float red[4][16 * 64];
+    __shared__ float red[NW][16 * 64];      // NW waves split the block's K range
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const int64_t row0 = int64_t(blockIdx.x) * 32;
     const int ksteps = (K + 15) / 16;
     const int kss0 = blockIdx.y * ks_per_split, kss1 = min(kss0 + ks_per_split, ksteps);
-    const int per = (kss1 - kss0 + 3) / 4;
+    const int per = (kss1 - kss0 + NW - 1) / NW;
     const int ks0 = kss0 + wave * per, ks1 = min(ks0 + per, kss1);
     out += blockIdx.y * split_stride;
     const int K4 = (K + 3) & ~3;
@@ -541,14 +546,28 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(
         const bool live = ks < ks1;
         const bool kv0 = live && k + 0 < K, kv1 = live && k + 1 < K, kv2 = live && k + 2 < K, kv3 = live && k + 3 < K;
         gae::v4s ah[2], al[2], wh[2], wl[2];
+        gae::v4f avq[2], wvq[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const gae::v4f av = {(rv[q] && kv0) ? st.a[q].x : 0.f, (rv[q] && kv1) ? st.a[q].y : 0.f,
                                  (rv[q] && kv2) ? st.a[q].z : 0.f, (rv[q] && kv3) ? st.a[q].w : 0.f};
             const gae::v4f wv = {(jv[q] && kv0) ? st.w[q].x : 0.f, (jv[q] && kv1) ? st.w[q].y : 0.f,
                                  (jv[q] && kv2) ? st.w[q].z : 0.f, (jv[q] && kv3) ? st.w[q].w : 0.f};
-            gae::split_bf16x4(av, ah[q], al[q]);
-            gae::split_bf16x4(wv, wh[q], wl[q]);
+            avq[q] = av; wvq[q] = wv;
+            if (!EXACT) {
+                gae::split_bf16x4(av, ah[q], al[q]);
+                gae::split_bf16x4(wv, wh[q], wl[q]);
+            }
+        }
+        if (EXACT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(avq[mt][r], wvq[nt][r], acc[mt][nt], 0, 0, 0);
+            return;
         }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -579,6 +598,7 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][((mt * 2 + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
     __syncthreads();
+    if (wave >= 4) return;
     const int mt = wave >> 1, nt = wave & 1;
     const int j = 16 * nt + l15;                    // acc[mt][nt][r] = out[row0 + 16 mt + 4 g + r][16 nt + l15]
     const float bv = (bias && j < J) ? bias[j] : 0.f;
@@ -586,7 +606,7 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(
     for (int r = 0; r < 4; ++r) {
         float y = red[0][((mt * 2 + nt) * 4 + r) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) y += red[w][((mt * 2 + nt) * 4 + r) * 64 + lane];
+        for (int w = 1; w < NW; ++w) y += red[w][((mt * 2 + nt) * 4 + r) * 64 + lane];
         const int64_t orow = row0 + 16 * mt + 4 * g + r;
         if (orow < n && j < J) {
             y += bv;
@@ -648,18 +668,24 @@ int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t 
     // forward Linear with bf16 x 3 products and 64-byte row pieces (linear_fwd_bf16_kernel)
     // (short unaligned rows of W keep gemm_stream_kernel: ZINC K = 39 measured 10.3 -> 13.2 us; knob 2 forces it)
     const bool wvec_ok = (ldb % 4 == 0) && gae::aligned16(B) && ldb >= ((K + 3) & ~3);
-    if (NT == 1 && BT && PRO_A == PRO_NONE && (g_linear_bf16 > 1 || (g_linear_bf16 == 1 && (wvec_ok || K >= 128))) &&
+    const bool exact16 = g_linear_f32x16 && g_linear_bf16 == 0 && K >= 128;   // exact twin of the same loader
+    if (NT == 1 && BT && PRO_A == PRO_NONE &&
+        (exact16 || g_linear_bf16 > 1 || (g_linear_bf16 == 1 && (wvec_ok || K >= 128))) &&
         avec && lda >= ((K + 3) & ~3) && K >= 16 && n > 0) {
         const bool wvec = wvec_ok;
         const int ksteps = (K + 15) / 16;
         const int kspp = (ksteps + splits - 1) / splits;
         float *dst = splits > 1 ? split_ws : out;
         const dim3 grid(unsigned((n + 31) / 32), unsigned(splits));
-#define GAE_LB(WV)                                                                                                 \
-    hipLaunchKernelGGL((linear_fwd_bf16_kernel<WV>), grid, dim3(256), 0, s, A, lda, B, ldb,                        \
+#define GAE_LB(WV, EX, NW)                                                                                         \
+    hipLaunchKernelGGL((linear_fwd_bf16_kernel<WV, EX, NW>), grid, dim3(64 * NW), 0, s, A, lda, B, ldb,            \
                        splits > 1 ? nullptr : bias, splits > 1 ? int(GAE_ACT_IDENTITY) : act, dst,                 \
                        splits > 1 ? J : ldo, n, K, int(J), kspp, n * J)
-        if (wvec) GAE_LB(true); else GAE_LB(false);
+        const bool nw8 = g_linear_nw == 8;       // 8 waves per block: measured equal or slower on every layer shape
+        if (exact16 && wvec) { if (nw8) GAE_LB(true, true, 8); else GAE_LB(true, true, 4); }
+        else if (exact16) { if (nw8) GAE_LB(false, true, 8); else GAE_LB(false, true, 4); }
+        else if (wvec) GAE_LB(true, false, 4);
+        else GAE_LB(false, false, 4);
 #undef GAE_LB
         GAE_CHECK_LAUNCH("linear_fwd_bf16_kernel");
         if (splits > 1) {
@@ -1291,6 +1317,8 @@ namespace gae {
 int *dense_knob(const char *name)
 {
     if (strcmp(name, "gemm_stream") == 0) return &g_gemm_stream;
+    if (strcmp(name, "linear_f32x16") == 0) return &g_linear_f32x16;
+    if (strcmp(name, "linear_nw") == 0) return &g_linear_nw;
     if (strcmp(name, "atb_rows") == 0) return &g_atb_rows;
     if (strcmp(name, "atb_bf16") == 0) return &g_atb_bf16;
     if (strcmp(name, "linear_bf16") == 0) return &g_linear_bf16;
