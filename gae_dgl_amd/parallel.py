@@ -348,27 +348,41 @@ class ShardedSpMMFunction(torch.autograd.Function):
         return ShardedSpMMFunction._product(ctx.sg, dm_local.contiguous(), "bwd"), None
 
 
-def sharded_encode(model, sg, x_local):
-    """GAE.encode on a row block: same layers, aggregation through the sharded SpMM"""
+def sharded_encode(model, sg, x_local, transform_first=False):
+    """GAE.encode on a row block: same layers, aggregation through the sharded SpMM.
+    ``transform_first``: layers that narrow the features are evaluated as ``act(A (H W^T) + b)`` -- the value of the
+    reference's ``act((A H) W^T + b)`` up to fp32 rounding (gae.GCN's opt-in reorder): the
+    aggregation AND its backward then move f_out instead of f_in floats per edge, and the exchange between ranks
+    shrinks by the same factor (RMAT layer 2, 32 -> 16: half the gathered and exchanged bytes)."""
     from . import ops
     from .gae import _act_code
+    from ._lib import ACT_IDENTITY
     h = x_local
     for conv in model.layers:
         lin = conv.apply_mod.linear
         code = _act_code(conv.apply_mod.activation)
-        m = sg.spmm(h)
-        h = ops.linear(m, lin.weight, lin.bias, code if code is not None else 0)
+        if transform_first and lin.weight.shape[0] < lin.weight.shape[1]:
+            t = ops.linear(h, lin.weight, None, ACT_IDENTITY)                    # H W^T
+            m = sg.spmm(t)                                                       # A (H W^T)
+            eye = getattr(sg, "_eye", {}).get(m.shape[1])
+            if eye is None:
+                sg._eye = getattr(sg, "_eye", {})
+                eye = sg._eye[m.shape[1]] = torch.eye(m.shape[1], device=m.device)
+            h = ops.linear(m, eye, lin.bias, code if code is not None else 0)    # + b, activation (fused epilogue)
+        else:
+            m = sg.spmm(h)
+            h = ops.linear(m, lin.weight, lin.bias, code if code is not None else 0)
         if code is None:
             h = conv.apply_mod.activation(h)
     return h
 
 
-def sharded_loss(model, sg, x_local, mask_local=None):
+def sharded_loss(model, sg, x_local, mask_local=None, transform_first=False):
     """train_inductive.py:44-48 on a row-sharded graph: each rank evaluates its
     row block of the N x N loss against the all-gathered Z and the partial
     sums are all-reduced.  Returns the global mean loss (same on every rank)."""
     from . import ops
-    z_local = sharded_encode(model, sg, x_local)
+    z_local = sharded_encode(model, sg, x_local, transform_first)
     return ops.sharded_decoder_bce(z_local, mask_local, sg)
 
 

@@ -173,6 +173,16 @@ def test_one_rank_rccl_group_end_to_end():
         assert abs(float(loss.detach()) - float(ref.detach())) < 1e-6 * abs(float(ref.detach()))
         for a, p in zip(g1, model.parameters()):
             assert float((a - p.grad).abs().max()) <= 1e-6 * float(p.grad.abs().max())
+        # narrowing layers as A (H W^T): aggregation (and its backward, and the exchange) at the output width --
+        # the same loss and gradients up to fp32 rounding
+        for mode in ("allgather", "boundary"):
+            sg = ShardedGraph(n, src, dst, mode=mode, device=DEV, overlap=(mode == "boundary"))
+            model.zero_grad()
+            loss_tf = sharded_loss(model, sg, X, transform_first=True)
+            loss_tf.backward()
+            assert abs(float(loss_tf.detach()) - float(ref.detach())) < 1e-5 * abs(float(ref.detach()))
+            for a, p in zip(g1, model.parameters()):
+                assert float((a - p.grad).abs().max()) <= 5e-5 * float(a.abs().max())
     finally:
         if created:
             dist.destroy_process_group()
