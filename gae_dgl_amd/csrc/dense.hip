@@ -21,6 +21,7 @@ using gae::kWave;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
+thread_local int g_linear_depth = 3;  // "linear_depth": k-steps of loads in flight + 1 in that kernel (3, 4, 5)
 thread_local int g_linear_nw = 0;     // "linear_nw": waves per block of that kernel (0 = 4, 8)
 thread_local int g_linear_f32x16 = 1; // "linear_f32x16": exact-fp32 forward Linear through the 64-byte-piece loader (0 = gemm_stream_kernel)
 thread_local int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(512) void linear_fwd_wlds_kernel(
 // EXACT = true: the same loader (64-byte row pieces: 2 requests per 128-byte line instead of the 4.3 of
 // gemm_stream_kernel's 32-byte pieces) feeding v_mfma_f32_16x16x4_f32 -- exact fp32 products; the 4 values a lane
 // holds go to 4 consecutive MFMAs, each of which contracts the k positions {4 g + r} of the 16-k step.
-template <bool WVEC, bool EXACT = false, int NW = 4>
+template <bool WVEC, bool EXACT = false, int NW = 4, int DEPTH = 3>
 __global__ __launch_bounds__(64 * NW) void linear_fwd_bf16_kernel(
     const float *__restrict__ A, int64_t lda, const float *__restrict__ W, int64_t ldw,
     const float *__restrict__ bias, int act, float *__restrict__ out, int64_t ldo, int64_t n, int K, int J,
@@ -579,14 +580,23 @@ __global__ __launch_bounds__(64 * NW) void linear_fwd_bf16_kernel(
             }
     };
     if (ks0 < ks1) {
-        Stage s0, s1, s2;
+        // ring of DEPTH stages: DEPTH - 1 k-steps of loads are in flight ahead of the MFMAs (a wave lives as long as
+        // the launch -- 2.4 waves per SIMD on Pubmed -- so its time is steps x latency / depth)
+        Stage st[DEPTH];
         int ks = ks0;
 #define GAE_PIN() __builtin_amdgcn_sched_barrier(0)
-        load(s0, ks); load(s1, ks + 1); GAE_PIN();
-        while (true) {
-            load(s2, ks + 2); GAE_PIN(); compute(s0, ks); GAE_PIN(); if (++ks >= ks1) break;
-            load(s0, ks + 2); GAE_PIN(); compute(s1, ks); GAE_PIN(); if (++ks >= ks1) break;
-            load(s1, ks + 2); GAE_PIN(); compute(s2, ks); GAE_PIN(); if (++ks >= ks1) break;
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d) load(st[d], ks + d);
+        GAE_PIN();
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (more) {
+                    load(st[(d + DEPTH - 1) % DEPTH], ks + DEPTH - 1); GAE_PIN(); compute(st[d], ks); GAE_PIN();
+                    more = ++ks < ks1;
+                }
+            }
         }
 #undef GAE_PIN
     }
@@ -678,6 +688,15 @@ int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t 
         float *dst = splits > 1 ? split_ws : out;
         const dim3 grid(unsigned((n + 31) / 32), unsigned(splits));
 #define GAE_LB(WV, EX, NW)                                                                                         \
+    if (g_linear_depth == 5)                                                                                       \
+        hipLaunchKernelGGL((linear_fwd_bf16_kernel<WV, EX, NW, 5>), grid, dim3(64 * NW), 0, s, A, lda, B, ldb,     \
+                           splits > 1 ? nullptr : bias, splits > 1 ? int(GAE_ACT_IDENTITY) : act, dst,             \
+                           splits > 1 ? J : ldo, n, K, int(J), kspp, n * J);                                       \
+    else if (g_linear_depth == 4)                                                                                  \
+        hipLaunchKernelGGL((linear_fwd_bf16_kernel<WV, EX, NW, 4>), grid, dim3(64 * NW), 0, s, A, lda, B, ldb,     \
+                           splits > 1 ? nullptr : bias, splits > 1 ? int(GAE_ACT_IDENTITY) : act, dst,             \
+                           splits > 1 ? J : ldo, n, K, int(J), kspp, n * J);                                       \
+    else                                                                                                           \
     hipLaunchKernelGGL((linear_fwd_bf16_kernel<WV, EX, NW>), grid, dim3(64 * NW), 0, s, A, lda, B, ldb,            \
                        splits > 1 ? nullptr : bias, splits > 1 ? int(GAE_ACT_IDENTITY) : act, dst,                 \
                        splits > 1 ? J : ldo, n, K, int(J), kspp, n * J)
@@ -1319,6 +1338,7 @@ int *dense_knob(const char *name)
     if (strcmp(name, "gemm_stream") == 0) return &g_gemm_stream;
     if (strcmp(name, "linear_f32x16") == 0) return &g_linear_f32x16;
     if (strcmp(name, "linear_nw") == 0) return &g_linear_nw;
+    if (strcmp(name, "linear_depth") == 0) return &g_linear_depth;
     if (strcmp(name, "atb_rows") == 0) return &g_atb_rows;
     if (strcmp(name, "atb_bf16") == 0) return &g_atb_bf16;
     if (strcmp(name, "linear_bf16") == 0) return &g_linear_bf16;
