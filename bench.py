@@ -83,12 +83,13 @@ def parse():
     ap.add_argument("--balance", choices=["rows", "nnz"], default="nnz",
                     help="rmat: row blocks of equal row count or of equal edge count (RMAT puts 44 %% of the edges "
                          "into the first of 8 equal row blocks)")
-    ap.add_argument("--transform-first", action="store_true",
-                    help="rmat workload: layers that narrow the features run as A (H W^T) instead of (A H) W^T "
-                         "(gae.py:26-31; same value up to fp32 rounding): the 32 -> 16 layer then aggregates and "
-                         "exchanges 16 instead of 32 floats per row, forward and backward.  Halves the exchanged "
-                         "bytes; on ONE GPU it buys nothing (RMAT s24: 29.6 vs 29.2 ms -- the gather is bound by the "
-                         "number of random row fetches, not their size)")
+    ap.add_argument("--layer-order", choices=["auto", "aggregate-first", "transform-first"], default="auto",
+                    help="rmat workload: aggregate-first = every layer as (A H) W^T like gae.py:26-31; transform-first = "
+                         "layers that narrow the features run as A (H W^T) (same value up to fp32 rounding): the "
+                         "32 -> 16 layer then aggregates AND exchanges 16 instead of 32 floats per row, forward and "
+                         "backward.  auto = transform-first when the graph is sharded over more than one GPU (two of "
+                         "the three exchanges per step halve), aggregate-first on one GPU (RMAT s24: 29.2 vs 29.6 ms "
+                         "-- the gather is bound by the number of random row fetches, not their size)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="rmat: exchange, then one SpMM over the assembled rows (bit-identical to one GPU) instead of "
                          "the default own-column SpMM under the exchange + accumulated remote-column SpMM")
@@ -409,6 +410,7 @@ class RmatShardedWorkload:
         src, dst = W.rmat_edges(scale, 16, seed=0, device=dev)               # same list on every rank (seeded)
         E = int(src.numel())
         self.overlap = not args.no_overlap
+        self.transform_first = args.layer_order == "transform-first" or (args.layer_order == "auto" and world > 1)
         self.sg = ShardedGraph(n, src, dst, rank=rank, world=world, group=group, mode=args.exchange, device=dev,
                                balance=args.balance, overlap=self.overlap)
         del src, dst
@@ -439,8 +441,10 @@ class RmatShardedWorkload:
                      "overlap": "own-column SpMM under the exchange, then M += remote-column SpMM" if self.overlap
                                 else "exchange, then one SpMM (bit-identical to one GPU)",
                      "exchange_bytes_per_spmm_per_rank": self.sg.exchange_bytes(F),
+                     "exchange_bytes_per_step_per_rank": (self.sg.exchange_bytes(F) + 2 * self.sg.exchange_bytes(16))
+                     if self.transform_first else 3 * self.sg.exchange_bytes(F),
                      "decoder": "excluded (O(N^2) = 2.8e14 logits at N = 2^24); synthetic dZ",
-                     "layer_order": "(A H) W^T for every layer (gae.py:26-31)" if not args.transform_first else
+                     "layer_order": "(A H) W^T for every layer (gae.py:26-31)" if not self.transform_first else
                                     "32 -> 32 layer: (A H) W^T; 32 -> 16 layer: A (H W^T), aggregation and exchange at "
                                     "width 16 forward and backward (value of gae.py:26-31 up to fp32 rounding)",
                      "local_rows": p.n_local, "local_edges_fwd": e_local}
@@ -485,7 +489,7 @@ class RmatShardedWorkload:
 
     def step(self):
         from gae_dgl_amd.parallel import allreduce_grads, sharded_encode
-        z = sharded_encode(self.model, self.sg, self.X, transform_first=self.args.transform_first)
+        z = sharded_encode(self.model, self.sg, self.X, transform_first=self.transform_first)
         self.opt.zero_grad()
         z.backward(self.dZ)
         if self.world > 1:
