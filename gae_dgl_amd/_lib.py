@@ -37,6 +37,7 @@ class AdamTensor(ctypes.Structure):
 
 
 ADAM_MAX_TENSORS = 16
+ADAM_STATE_WORDS = 6      # uint64 words of gae_adam_step's device state
 
 # name -> (restype, argtypes); mirrors include/gae_hip.h one to one
 SIGNATURES = {

@@ -28,9 +28,16 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
     int k = 0;
     while (k + 1 < a.n_tensors && int(blockIdx.x) >= a.first_block[k + 1]) ++k;
     const gae_adam_tensor t = a.t[k];
-    const double step = double(state[0] + 1ull);                       // this is step number `step` (1-based)
-    const float bc1 = float(1.0 - pow(double(beta1), step));
-    const float bc2_sqrt = float(sqrt(1.0 - pow(double(beta2), step)));
+    // beta^t is carried in the state (doubles at [2..5]: beta1, beta1^steps, beta2, beta2^steps) and advanced by one
+    // multiplication per step: two double-precision pow() per thread were a third of this kernel's 6 us.  A state
+    // that does not hold this call's betas (fresh / resumed counter, changed hyper-parameters) takes the pow path.
+    const double steps_done = double(state[0]);
+    const double *sd = reinterpret_cast<const double *>(state);
+    const bool cached = sd[2] == double(beta1) && sd[4] == double(beta2);
+    const double b1t = (cached ? sd[3] : pow(double(beta1), steps_done)) * double(beta1);    // beta1^step, 1-based
+    const double b2t = (cached ? sd[5] : pow(double(beta2), steps_done)) * double(beta2);
+    const float bc1 = float(1.0 - b1t);
+    const float bc2_sqrt = float(sqrt(1.0 - b2t));
     const float step_size = lr / bc1;
     const int64_t base = int64_t(int(blockIdx.x) - a.first_block[k]) * kAdamChunk + threadIdx.x * 4;
 #pragma unroll
@@ -54,7 +61,9 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
     if (threadIdx.x == 0) {
         __threadfence();
         const unsigned long long ticket = atomicAdd(&state[1], 1ull);
-        if (ticket == gridDim.x - 1ull) {
+        if (ticket == gridDim.x - 1ull) {      // every block has read the state by now (its ticket came after its loads)
+            double *sw = reinterpret_cast<double *>(state);
+            sw[2] = double(beta1); sw[3] = b1t; sw[4] = double(beta2); sw[5] = b2t;
             state[1] = 0ull;
             state[0] += 1ull;
         }

@@ -24,7 +24,7 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("Adam: hyper-parameter out of range")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
                                       capturable=True))
-        self._counters = {}      # (group index, chunk) -> device int64[2]: steps taken, ticket
+        self._counters = {}      # (group index, chunk) -> device int64[6]: steps taken, ticket, cached beta^t
 
     def _moments(self, p):
         st = self.state[p]
@@ -88,7 +88,7 @@ class Adam(torch.optim.Optimizer):
                     arr[k] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
                 key = (gi, c0 // _lib.ADAM_MAX_TENSORS)        # one device counter pair per chunk of 16 tensors
                 if key not in self._counters:
-                    self._counters[key] = torch.zeros(2, dtype=torch.int64, device=dev)
+                    self._counters[key] = torch.zeros(_lib.ADAM_STATE_WORDS, dtype=torch.int64, device=dev)
                     resume = getattr(self, "_resume_steps", None)
                     if resume is not None and gi < len(resume):
                         self._counters[key][0] = resume[gi]

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GAE_VERSION 101 /* 0.1.1 */
+#define GAE_VERSION 102 /* 0.1.1 */
 
 enum {
     GAE_OK = 0,
@@ -381,10 +381,12 @@ int gae_segment_readout(const float *Z, int64_t ldz, int64_t n_nodes, int64_t d,
  * tensors in ONE launch:
  *   g += weight_decay p;  m = lerp(m, g, 1 - beta1);  v = beta2 v + (1 - beta2) g^2
  *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = state_dev[0] + 1
- * state_dev: 2 x uint64 on the device, zeroed by the caller once: [0] = steps taken so far (advanced by the
- * call, stream-ordered, so a replayed HIP graph counts its own steps), [1] = scratch ticket.
+ * state_dev: GAE_ADAM_STATE_WORDS (6) x uint64 on the device, zeroed by the caller once: [0] = steps taken so far
+ * (advanced by the call, stream-ordered, so a replayed HIP graph counts its own steps; may be preset to resume),
+ * [1] = scratch ticket, [2..5] = the library's cache of beta1, beta1^steps, beta2, beta2^steps (doubles).
  * `tensors` is a HOST array (copied into the kernel arguments). */
 #define GAE_ADAM_MAX_TENSORS 16
+#define GAE_ADAM_STATE_WORDS 6
 typedef struct gae_adam_tensor {
     float *param;          /* [n] updated in place            (device) */
     const float *grad;     /* [n]                              (device) */
