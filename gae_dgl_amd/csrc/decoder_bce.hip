@@ -55,6 +55,7 @@ thread_local int g_bce_grid = 2048;       // "bce_grid": target size of the (row
 constexpr int kChipCus = 256;             // MI355X: the launch-shape heuristics below are written for this part
 thread_local int g_bce_strip_store = -1;  // "bce_strip_store": -1 auto (non-temporal from 32 k rows on: GBs of strips, 2.93 -> 2.88 ms on a ZINC
                                           // batch; plain below: Pubmed 170 vs 174 us), 0 plain, 1 non-temporal, 2 write-through
+thread_local int g_bce_fold_mirror = 1;   // "bce_fold_mirror": 1 = the edge kernel folds the mirror strips (no separate reduction launch)
 thread_local int g_bce_sym_tiles = 0;     // "bce_sym_tiles": 64-column tiles per block of the symmetric kernel (0 = auto)
 thread_local int g_bce_sym_grid = 16384;  // "bce_sym_grid": target size of the (panel, chunk) grid of the symmetric kernel
                              // (many short blocks even out the triangular work: ZINC batch 3.64 -> 3.35 ms)
@@ -851,9 +852,39 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
     float pw, float inv_n2, const float *__restrict__ O_partial, int n_splits, int DP,
     const float *__restrict__ S_all_f, float *__restrict__ dZ, int64_t lddz, double *__restrict__ loss_partial,
     const float *__restrict__ O_mirror /*[n][16] or NULL*/, int64_t sym_cols_per_chunk, int SYM_PR,
-    const int64_t *__restrict__ counts, const double *__restrict__ scal)
+    const int64_t *__restrict__ counts, const double *__restrict__ scal,
+    const float *__restrict__ Wmir /*mirror strips: fold them here instead of reading O_mirror (LPR == 4), or NULL*/)
 {
     static_assert(VEC == 4, "edge kernel reads the padded Zt rows as float4");
+    // ---- symmetric dense kernel, d <= 16: this block's 64 rows are exactly one 64-column tile of the mirror strips.
+    //      The strip reduction of bce_mirror_reduce_kernel (same thread mapping, same panel order, same 8-deep
+    //      batches: bit-identical sums) runs here and hands its result over through LDS: one kernel node and the
+    //      O'_mirror round trip less, and its byte stream overlaps with the latency-bound edge walks of other blocks.
+    __shared__ __attribute__((aligned(16))) float Om[LPR == 4 ? TJ * 20 : 4];
+    const bool fold = LPR == 4 && Wmir != nullptr;
+    if (LPR == 4 && fold) {
+        const int64_t NP = (n_local + 63) / 64 * 64;
+        const int64_t j0 = int64_t(blockIdx.x) * TJ;
+        const int f = threadIdx.x >> 4, jq = (threadIdx.x & 15) * 4;
+        const int64_t n_left = j0 / SYM_PR;       // panels 0 .. n_left - 1 hold a mirror tile for these columns
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        auto at = [&](int64_t I) {
+            const int64_t de = SYM_PR * (I + 1);
+            return *reinterpret_cast<const f32x4 *>(Wmir + sym_strip_offset(I, NP, SYM_PR) + (j0 - de) * 16 + f * TJ + jq);
+        };
+        int64_t I = 0;
+        for (; I + 8 <= n_left; I += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = at(I + u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; I < n_left; ++I) acc += at(I);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Om[(jq + e) * 20 + f] = acc[e];
+        __syncthreads();
+    }
     if (scal) { pw = float(scal[0]); inv_n2 = float(scal[1]); }      // fixed-capacity batch: true sizes on the device
     const int64_t n_valid = counts ? counts[0] : n_local;
     __shared__ double red[4];
@@ -887,7 +918,8 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
         if (O_mirror) {     // symmetric dense kernel: row i's panel wrote ceil((n - panel start) / chunk) partials
             const int64_t rem = n - (i / SYM_PR) * SYM_PR;
             n_splits = int((rem + sym_cols_per_chunk - 1) / sym_cols_per_chunk);
-            osum = *reinterpret_cast<const f32x4 *>(O_mirror + i * DP + f0);
+            osum = fold ? *reinterpret_cast<const f32x4 *>(&Om[(tid / LPR) * 20 + f0])
+                        : *reinterpret_cast<const f32x4 *>(O_mirror + i * DP + f0);
         }
         int sp = 0;
         for (; sp + 8 <= n_splits; sp += 8) {        // 8 independent loads per trip, added in split order
@@ -1171,12 +1203,12 @@ template <int VEC, bool WITH_GRAD>
 int launch_edges(const BcePlan &p, const float *Zt, const float *mask, int64_t ldz, int64_t row_begin, int64_t n, int d,
                  const int32_t *ip, const int32_t *ix, const int32_t *tp, const int32_t *tx, float pw, float inv_n2,
                  const float *O, const float *S_all_f, float *dZ, int64_t lddz, double *lp, const float *Omir,
-                 const int64_t *counts, const double *scal, hipStream_t s)
+                 const int64_t *counts, const double *scal, const float *Wmir, hipStream_t s)
 {
 #define GAE_EDGE(LPR)                                                                                              \
     hipLaunchKernelGGL((bce_edges_kernel<VEC, LPR, WITH_GRAD>), dim3(unsigned(p.edge_blocks)), dim3(256), 0, s, Zt, \
                        mask, ldz, row_begin, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, S_all_f,  \
-                       dZ, lddz, lp, Omir, p.cols_per_split, p.sym_pr, counts, scal)
+                       dZ, lddz, lp, Omir, p.cols_per_split, p.sym_pr, counts, scal, Wmir)
     switch (p.LPR) {
     case 1: GAE_EDGE(1); break;
     case 2: GAE_EDGE(2); break;
@@ -1202,6 +1234,7 @@ int *bce_knob(const char *name)
     if (strcmp(name, "bce_sym_grid") == 0) return &g_bce_sym_grid;
     if (strcmp(name, "bce_grid") == 0) return &g_bce_grid;
     if (strcmp(name, "bce_sym_tiles") == 0) return &g_bce_sym_tiles;
+    if (strcmp(name, "bce_fold_mirror") == 0) return &g_bce_fold_mirror;
     if (strcmp(name, "bce_strip_store") == 0) return &g_bce_strip_store;
     if (strcmp(name, "bce_sym_ri") == 0) return &g_bce_sym_ri;
     return nullptr;
@@ -1278,7 +1311,7 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
         else { if (dZ) GAE_SYM(true, 2); else GAE_SYM(false, 2); }
 #undef GAE_SYM
         GAE_CHECK_LAUNCH("bce_dense_sym_kernel");
-        if (dZ) {
+        if (dZ && !(g_bce_fold_mirror && p.LPR == 4)) {     // otherwise the edge kernel folds the strips itself
             hipLaunchKernelGGL(bce_mirror_reduce_kernel, dim3(unsigned((n + TJ - 1) / TJ)), dim3(256), 0, s, Wmir, n,
                                Omir, p.sym_pr);
             GAE_CHECK_LAUNCH("bce_mirror_reduce_kernel");
@@ -1292,10 +1325,10 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
     double *lpe = lp + 2 * p.n_dense;
     rc = dZ ? launch_edges<4, true>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr, t_indices,
                                     pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, p.sym ? Omir : nullptr,
-                                    counts, scal, s)
+                                    counts, scal, (p.sym && g_bce_fold_mirror && p.LPR == 4) ? Wmir : nullptr, s)
             : launch_edges<4, false>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr,
                                      t_indices, pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, nullptr, counts,
-                                     scal, s);
+                                     scal, nullptr, s);
     if (rc) return rc;
     hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(1024), 0, s, lp, p.n_dense, lpe, p.edge_blocks, S, p.DP,
                        p.pad_terms, inv_n2, loss_out, dropout_p > 0.f ? draw_dev : nullptr, scal);
