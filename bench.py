@@ -522,7 +522,7 @@ def extras(dev):
     n = 1 << 24
     ip, ix = ops.csr_from_coo(dst, src, n, n)
     del src, dst
-    plan = ops.spmm_plan(ip)
+    plan = ops.spmm_plan(ip, indices=ix, ell=False, n_cols=n)
     r = spmm_probe(ip, ix, n, 32, plan=plan, label="rmat-s24-ef16 (1 GPU, skew plan)", iters=10)
     r["gather_bytes_no_reuse"] = 4 * (n + 1) + 4 * r["nnz"] + 4 * 32 * r["nnz"] + 4 * 32 * n
     r["achieved_GBs_no_reuse_model"] = r["gather_bytes_no_reuse"] / (r["us_per_launch"] * 1e-6) / 1e9

@@ -29,7 +29,7 @@ class DeviceInfo(ctypes.Structure):
 class SpmmPlan(ctypes.Structure):
     _fields_ = [("threshold", _i32), ("segment_edges", _i32), ("n_heavy", _i64), ("n_segments", _i64),
                 ("heavy_rows", _p), ("heavy_seg_base", _p), ("seg_heavy", _p), ("ell", _p), ("ell_width", _i32),
-                ("reserved", _i32)]
+                ("reserved", _i32), ("hot_indices", _p)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -44,6 +44,8 @@ SIGNATURES = {
     "gae_version": (_int, []),
     "gae_last_error": (ctypes.c_char_p, []),
     "gae_device_info_get": (_int, [_int, ctypes.POINTER(DeviceInfo)]),
+    "gae_spmm_col_freq": (_int, [_p, _i64, _i64, _p, _p]),
+    "gae_spmm_tag_hot": (_int, [_p, _i64, _p, _i32, _p, _p]),
     "gae_tuning_set": (_int, [ctypes.c_char_p, _i64]),
     "gae_tuning_get": (_int, [ctypes.c_char_p, _p]),
     "gae_csr_from_coo_workspace_bytes": (_i64, [_i64, _i64]),

@@ -333,13 +333,14 @@ class SpmmPlan:
     (heavy rows cut into segments) and / or the packed neighbour table"""
 
     def __init__(self, threshold, segment, n_heavy, n_segments, heavy_rows, heavy_seg_base, seg_heavy, ell=None,
-                 ell_width=None):
-        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy, ell)  # keep the device arrays alive
+                 ell_width=None, hot_indices=None):
+        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy, ell, hot_indices)  # keep the device arrays alive
         self.n_heavy, self.n_segments, self.ell = n_heavy, n_segments, ell
+        self.hot_indices = hot_indices
         self.ell_width = (ell_width or _lib.SPMM_ELL_WIDTH) if ell is not None else 0
         ptr = lambda t: None if t is None else t.data_ptr()
         self.c = _lib.SpmmPlan(threshold, segment, n_heavy, n_segments, ptr(heavy_rows), ptr(heavy_seg_base),
-                               ptr(seg_heavy), ptr(ell), self.ell_width, 0)
+                               ptr(seg_heavy), ptr(ell), self.ell_width, 0, ptr(hot_indices))
 
 
 def ell_width_for(max_deg):
@@ -369,12 +370,37 @@ def table_plan(table, ell_width):
     return SpmmPlan(SKEW_THRESHOLD, SKEW_SEGMENT, 0, 0, None, None, None, table, ell_width)
 
 
-def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_width=None):
+HOT_COLUMNS = 65536          # columns tagged hot in a skew plan (RMAT s24, F = 32: 2 k 9.2 ms, 8 k 7.8, 16 k 7.2,
+#                              32 k 6.9, 64 k 6.8, 256 k 7.2; untagged 7.8 -- streaming the moderately hot rows hurts)
+HOT_MIN_EDGES = 1 << 22      # graphs with fewer heavy-row edges fit the caches anyway
+
+
+def hot_indices_for(indices, n_cols, hot_columns=None):
+    """the column ids of a CSR with the sign bit set on its ``hot_columns`` most frequently gathered columns
+    (gae_spmm_col_freq + gae_spmm_tag_hot; the frequency threshold is picked with one torch.topk)"""
+    _gpu(indices, "indices")
+    dev = indices.device
+    E = indices.numel()
+    k = min(int(hot_columns or HOT_COLUMNS), int(n_cols))
+    if E == 0 or k <= 0:
+        return None
+    with _on_device(dev):
+        freq = torch.empty(n_cols, dtype=torch.int32, device=dev)
+        _lib.call("gae_spmm_col_freq", _ptr(indices), E, n_cols, _ptr(freq), _stream())
+        min_freq = max(int(torch.topk(freq, k, sorted=True).values[-1]), 2)      # a column gathered once is not hot
+        out = torch.empty(E, dtype=torch.int32, device=dev)
+        _lib.call("gae_spmm_tag_hot", _ptr(indices), E, _ptr(freq), min_freq, _ptr(out), _stream())
+    return out
+
+
+def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_width=None, hot=None, n_cols=None):
     """Build the plan of a CSR, or None when it needs none (one host read-back of three counters; done once per
     graph).  Skew part: with the default threshold only for graphs whose longest row has more than
     SKEW_MIN_MAXDEG edges.  Packed neighbour table: when ``indices`` is given and the graph has at most
     ELL_MAX_ROWS rows (``ell`` = True / False overrides); ``ell_width`` 4 / 8 / 16 slots per row, default: the
-    narrowest that holds the longest light row."""
+    narrowest that holds the longest light row.  Hot-column tags (``hot``; default: skew plans of graphs with at
+    least HOT_MIN_EDGES edges when ``indices`` is given; ``n_cols`` = columns of the CSR, default: its rows): a
+    tagged copy of ``indices`` that lets the heavy-row kernel stream the rarely gathered rows past the L2."""
     auto = threshold is None
     threshold = SKEW_THRESHOLD if threshold is None else threshold
     segment = SKEW_SEGMENT if segment is None else segment
@@ -406,7 +432,13 @@ def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_
             table = torch.empty(n * ell_width, dtype=torch.int32, device=dev)
             _lib.call("gae_spmm_ell_build", _ptr(indptr), _ptr(indices), n, ell_width,
                       threshold if heavy else 2 ** 31 - 1, _ptr(table), _stream())
-    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh, table, ell_width)
+        tags = None
+        want_hot = (heavy and indices is not None and indices.numel() >= HOT_MIN_EDGES) if hot is None else \
+            (bool(hot) and heavy and indices is not None)
+        if want_hot:
+            nc = int(n_cols) if n_cols is not None else max(n, int(indices.max()) + 1 if indices.numel() else n)
+            tags = hot_indices_for(indices, nc)
+    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh, table, ell_width, tags)
 
 
 def gather_distance(indptr, indices):

@@ -186,7 +186,13 @@ class ShardedGraph:
             from . import ops
             # explicit threshold: whether a row is segmented must depend on that row only, so that every
             # sharding of a graph (and the 1-rank case) produces bit-identical sums
-            self._plan[key] = ops.spmm_plan(self.csr(which, part)[0], threshold=ops.SKEW_THRESHOLD)
+            p = self.part
+            n_cols = p.n_cols[which] if part is None else p.n_local if part == "own" else \
+                p.split[which]["n_remote_cols"]
+            ip, ix = self.csr(which, part)
+            # (hot-column tags: cache hints for the heavy-row kernel, values unaffected)
+            self._plan[key] = ops.spmm_plan(ip, threshold=ops.SKEW_THRESHOLD, indices=ix, ell=False,
+                                            n_cols=max(int(n_cols), 1))
         return self._plan[key]
 
     def _timed(self, name, fn):

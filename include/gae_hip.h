@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GAE_VERSION 102 /* 0.1.1 */
+#define GAE_VERSION 103 /* 0.1.1 */
 
 enum {
     GAE_OK = 0,
@@ -63,7 +63,7 @@ int gae_device_info_get(int device, gae_device_info *out_host);
 /* Tuning / test knobs: integers local to the CALLING THREAD (thread_local; the launches of a thread see what that
  * thread set, other threads keep the defaults -- no process-wide mutable state).  Three kinds:
  *  - select among kernels with bit-identical results: "spmm_variant", "spmm_rpg", "spmm_nt", "spmm_tile_vecs",
- *    "spmm_ell", "spmm_ell_rpg", "bce_minw", "bce_strip_store", "bce_fold_mirror";
+ *    "spmm_ell", "spmm_ell_rpg", "spmm_hot", "bce_minw", "bce_strip_store", "bce_fold_mirror";
  *  - change the ORDER in which partial sums are added (results agree within the fp32 tolerance of DESIGN.md
  *    section 6, not bit for bit): "atb_rows", "gemm_stream", "linear_wlds", "linear_f32x16", "linear_nw", "linear_depth", "bce_ri", "bce_sym", "bce_sym_ri",
  *    "bce_sym_grid", "bce_sym_tiles", "bce_grid"; a skew
@@ -173,8 +173,17 @@ typedef struct gae_spmm_plan {
     const int32_t *ell;             /* [n_rows * ell_width] packed neighbour table (device) or NULL */
     int32_t ell_width;              /* 4, 8 or GAE_SPMM_ELL_WIDTH when `ell` is given, else 0 */
     int32_t reserved;
+    const int32_t *hot_indices;     /* [n_edges] the CSR's column ids with the sign bit set on the most gathered
+                                       columns (gae_spmm_tag_hot), or NULL: the heavy-row kernel then loads the
+                                       rows of all OTHER columns with the streaming hint, which keeps the hub
+                                       rows of a power-law graph in L2.  A cache hint only: values unchanged. */
 } gae_spmm_plan;
 
+/* Hot-column tags for a plan with heavy rows: gae_spmm_col_freq counts how often every column occurs in `indices`
+ * (int32 [n_cols], device); the caller picks min_freq (e.g. the frequency of the 65536th most frequent column) and gae_spmm_tag_hot writes the tagged copy of `indices` (int32 [n_edges]). */
+int gae_spmm_col_freq(const int32_t *indices, int64_t n_edges, int64_t n_cols, int32_t *freq_out, void *stream);
+int gae_spmm_tag_hot(const int32_t *indices, int64_t n_edges, const int32_t *col_freq, int32_t min_freq,
+                     int32_t *hot_indices_out, void *stream);
 /* counts_dev[0] = number of heavy rows, [1] = number of segments, [2] = maximum row degree (3 x uint64, device) */
 int gae_spmm_plan_count(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
                         uint64_t *counts_dev, void *stream);

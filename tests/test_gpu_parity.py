@@ -1341,3 +1341,34 @@ def test_fused_gcn_layer_matches_two_launches(f_in, f_out, act, norm, dev):
     ref = O.gcn_layer(ip, ix, torch.as_tensor(X).double(), torch.as_tensor(layer_w), torch.as_tensor(layer_b), act,
                       norm=None if nrm is None else torch.as_tensor(nrm).double())
     assert float((out[True][0].cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_spmm_hot_column_tags_are_only_cache_hints(dev, tuning):
+    """gae_spmm_col_freq / gae_spmm_tag_hot: exact column frequencies, the sign bit on the most gathered columns,
+    and a heavy-row SpMM whose result is bit-identical with and without the tags (fp32 and bf16 storage, scaled)"""
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(21)
+    n, e = 4000, 120000
+    dst = (rng.integers(0, n, e).astype(np.float64) ** 3 / n ** 2).astype(np.int64)          # heavy rows
+    src = (rng.integers(0, n, e).astype(np.float64) ** 4 / n ** 3).astype(np.int64)          # hub columns
+    ip, ix = ops.csr_from_coo(t(dst, dev), t(src, dev), n, n)
+    tags = ops.hot_indices_for(ix, n, hot_columns=64)
+    ixh, tg = ix.cpu().numpy(), tags.cpu().numpy()
+    freq = np.bincount(ixh, minlength=n)
+    kth = max(np.sort(freq)[::-1][63], 2)
+    assert np.array_equal(tg & 0x7fffffff, ixh)
+    assert np.array_equal(tg < 0, freq[ixh] >= kth) and 0 < (tg < 0).mean() < 1
+    plan_hot = ops.spmm_plan(ip, threshold=8, segment=64, indices=ix, ell=False, hot=True, n_cols=n)
+    plan_off = ops.spmm_plan(ip, threshold=8, segment=64, indices=ix, ell=False, hot=False, n_cols=n)
+    assert plan_hot.hot_indices is not None and plan_off.hot_indices is None and plan_hot.n_heavy > 0
+    deg, norm = ops.degree_norm(ip)
+    for dtype in (torch.float32, torch.bfloat16):
+        H = t(rng.standard_normal((n, 40)).astype(np.float32), dev).to(dtype)
+        for sc in (None, norm):
+            a = ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan_hot)
+            b = ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan_off)
+            assert torch.equal(a, b)
+            tuning("spmm_hot", 0)
+            c = ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan_hot)
+            tuning("spmm_hot", 1)
+            assert torch.equal(a, c)

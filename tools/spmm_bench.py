@@ -39,12 +39,15 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--no-plan", action="store_true")
     ap.add_argument("--blockdiag", type=int, default=0, help="member graphs per block (0 = off) for the zinc shapes")
+    ap.add_argument("--hot-cols", type=int, default=0, help="ops.HOT_COLUMNS for the rmat plan (0 = default)")
     ap.add_argument("--thr", type=int, default=64)
     ap.add_argument("--seg", type=int, default=512)
     ap.add_argument("--variants", default="v1:1:0,v2:1:0,v2:2:0,v2:1:1,v2:2:1")
     ap.add_argument("--shapes", default="pubmed500,pubmed32,zincb39,zincb32,zinc39,zinc32,rmat32")
     ap.add_argument("--knobs", default="", help="comma-separated gae_tuning_set name=value pairs applied to every variant")
     args = ap.parse_args()
+    if args.hot_cols:
+        ops.HOT_COLUMNS = args.hot_cols
     for kv in filter(None, args.knobs.split(",")):
         k, v = kv.split("=")
         knob(k, int(v))
@@ -115,7 +118,8 @@ def main():
             b.min_blocks = 0
     plans = {}
     if "rmat32" in shapes and not args.no_plan:
-        plans["rmat32"] = ops.spmm_plan(shapes["rmat32"][0], args.thr, args.seg)
+        plans["rmat32"] = ops.spmm_plan(shapes["rmat32"][0], args.thr, args.seg, indices=shapes["rmat32"][1], ell=False,
+                                        n_cols=shapes["rmat32"][2])
         pl = plans["rmat32"]
         print(f"rmat plan: thr={args.thr} seg={args.seg} heavy rows={pl.n_heavy} segments={pl.n_segments}")
     variants = []

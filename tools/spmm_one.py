@@ -46,7 +46,7 @@ if a.plain:
 elif name == "zincb":      # a training batch carries the packed table its gather wrote (dataset.DeviceGraphDataset)
     plan = ops.spmm_plan(ip, indices=ix, ell=True, ell_width=ops.ell_width_for_degrees(ip[1:] - ip[:-1]))
 else:
-    plan = ops.spmm_plan(ip, indices=ix if bd is None else None)
+    plan = ops.spmm_plan(ip, indices=ix if bd is None else None, n_cols=n)
 scattered = (not a.plain) and bd is None and F > ops.TILE_MIN_F and ops.gather_scattered(ip, ix, F * 4)
 for _ in range(a.iters):
     ops.spmm_raw(ip, ix, H, n, out=out, plan=plan, blockdiag=bd, out_padded=True, scattered=scattered)
