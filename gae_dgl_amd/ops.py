@@ -319,7 +319,7 @@ profiler = None  # set to an EventProfiler to time launches
 
 # ------------------------------------------------------------------ raw kernels
 SKEW_THRESHOLD = 8       # rows with more in-edges than this go through the segment kernels
-SKEW_SEGMENT = 256       # edges per segment (multiple of 64)
+SKEW_SEGMENT = 512       # edges per segment (multiple of 64; RMAT s24: 256 -> 6.81 ms, 512 -> 6.65, 1024 -> 6.59)
 SKEW_MIN_MAXDEG = 64     # graphs whose longest row is shorter need no plan (3 extra launches would not pay)
 
 
