@@ -787,7 +787,8 @@ __global__ __launch_bounds__(256) void spmm_segment_kernel(
     const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const T *__restrict__ H, int64_t ldh,
     int F, const float *__restrict__ col_scale, const int32_t *__restrict__ heavy_rows,
     const int32_t *__restrict__ heavy_seg_base, const int32_t *__restrict__ seg_heavy, int64_t n_segments, int seg,
-    float *__restrict__ partial, int ldp, const int32_t *__restrict__ hot_indices)
+    float *__restrict__ partial, int ldp, const int32_t *__restrict__ hot_indices,
+    const float *__restrict__ row_scale, T *__restrict__ M, int64_t ldm, int accumulate)
 {
     // hot_indices (plan, optional): the column ids again, with the sign bit set on the columns that are gathered
     // most often.  Rows of the other columns are loaded with the non-temporal hint, so the few thousand hub rows
@@ -802,8 +803,11 @@ __global__ __launch_bounds__(256) void spmm_segment_kernel(
     const int h = seg_heavy[sidx];
     const int64_t row = heavy_rows[h];
     const int k = int(sidx - heavy_seg_base[h]);
+    const int32_t r_end = indptr[row + 1];
     const int32_t e0 = indptr[row] + k * seg;
-    const int32_t e1 = min(e0 + seg, indptr[row + 1]);
+    const int32_t e1 = min(e0 + seg, r_end);
+    const bool single = k == 0 && e1 == r_end;     // the row's only segment: its sum goes straight to M (most heavy
+    //                                                rows of a power-law graph; the combine kernel skips them)
     const int f0 = blockIdx.y * (CH * TILE) + lig * VEC;
     bool live[CH];
 #pragma unroll
@@ -858,7 +862,23 @@ __global__ __launch_bounds__(256) void spmm_segment_kernel(
         for (int c = 0; c < CH; ++c)
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[c][i] += __shfl_xor(acc[c][i], off, 64);
-    if (g == 0) {
+    if (g == 0 && single) {                 // same arithmetic as spmm_combine_kernel with one partial: 0 + sum, scale, (+ old)
+        const float rs = row_scale ? row_scale[row] : 1.f;
+        T *mp = M + row * ldm + f0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (f0 + c * TILE + i < F) {
+                    float sv = (0.f + acc[c][i]) * rs;
+                    if (accumulate) {
+                        float t[1];
+                        VecIO<T, 1>::load(mp + c * TILE + i, t);
+                        sv += t[0];
+                    }
+                    store_scalar(mp + c * TILE + i, sv);
+                }
+    } else if (g == 0) {
         float *pp = partial + sidx * ldp + f0;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
@@ -882,6 +902,7 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t *__rest
     if (h >= n_heavy) return;
     const int64_t row = heavy_rows[h];
     const int ns = (indptr[row + 1] - indptr[row] + seg - 1) / seg;
+    if (ns <= 1) return;                          // written by the segment kernel itself
     const float *pp = partial + int64_t(heavy_seg_base[h]) * ldp;
     const float rs = row_scale ? row_scale[row] : 1.f;
     for (int f = lane; f < F; f += 64) {
@@ -899,28 +920,33 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t *__rest
 
 template <typename T, int VEC, int LPR, int CH>
 int launch_segments(const int32_t *indptr, const int32_t *indices, const T *H, int64_t ldh, int F, const float *cs,
-                    const gae_spmm_plan *plan, float *partial, int ldp, hipStream_t s)
+                    const gae_spmm_plan *plan, float *partial, int ldp, const float *rs, T *M, int64_t ldm,
+                    int accumulate, hipStream_t s)
 {
     const int nvec = (F + VEC - 1) / VEC;
     const dim3 grid(unsigned((plan->n_segments + 3) / 4), unsigned((nvec + LPR * CH - 1) / (LPR * CH)));
     if (cs)
         hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, true>), grid, dim3(256), 0, s, indptr, indices, H, ldh,
                            F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
-                           plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr);
+                           plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr, rs, M, ldm,
+                           accumulate);
     else
         hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, false>), grid, dim3(256), 0, s, indptr, indices, H,
                            ldh, F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
-                           plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr);
+                           plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr, rs, M, ldm,
+                           accumulate);
     GAE_CHECK_LAUNCH("spmm_segment_kernel");
     return GAE_OK;
 }
 
 template <typename T, int VEC>
 int dispatch_segments(const int32_t *indptr, const int32_t *indices, const T *H, int64_t ldh, int F, const float *cs,
-                      const gae_spmm_plan *plan, float *partial, int ldp, hipStream_t s)
+                      const gae_spmm_plan *plan, float *partial, int ldp, const float *rs, T *M, int64_t ldm,
+                      int accumulate, hipStream_t s)
 {
     const int nvec = (F + VEC - 1) / VEC;
-#define GAE_SEG(LPR, CH) return launch_segments<T, VEC, LPR, CH>(indptr, indices, H, ldh, F, cs, plan, partial, ldp, s)
+#define GAE_SEG(LPR, CH)                                                                                              \
+    return launch_segments<T, VEC, LPR, CH>(indptr, indices, H, ldh, F, cs, plan, partial, ldp, rs, M, ldm, accumulate, s)
     if (nvec <= 4) GAE_SEG(4, 1);
     if (nvec <= 8) GAE_SEG(8, 1);
     if (nvec <= 16) GAE_SEG(16, 1);
@@ -954,7 +980,8 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
     if (rc || !heavy) return rc;
     float *partial = static_cast<float *>(workspace);
     const int ldp = plan_ldp(f);
-    rc = dispatch_segments<T, VEC>(indptr, indices, h, ldh, f, cs, plan, partial, ldp, s);
+    rc = dispatch_segments<T, VEC>(indptr, indices, h, ldh, f, cs, plan, partial, ldp, rs, m, ldm,
+                                   (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0, s);
     if (rc) return rc;
     hipLaunchKernelGGL((spmm_combine_kernel<T>), dim3(unsigned((plan->n_heavy + 3) / 4)), dim3(256), 0, s, indptr,
                        plan->heavy_rows, plan->heavy_seg_base, plan->n_heavy, plan->segment_edges, partial, ldp, f, rs,
