@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void spmm_segment_kernel(
     // (RMAT s24, F = 32: L2 hit rate of this kernel 14 % -> ~30 %, 8.27 -> 7.40 ms; values are unaffected).
     constexpr int G = 64 / LPR;       // lane groups per wave = edges gathered per load instruction
     constexpr int TILE = LPR * VEC;
-    constexpr int NB = 4;             // edges in flight per group
+    constexpr int NB = 8;             // edges in flight per group
     const int lane = threadIdx.x & 63, lig = lane % LPR, g = lane / LPR;
     const int64_t sidx = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (sidx >= n_segments) return;
