@@ -29,7 +29,9 @@ class DeviceInfo(ctypes.Structure):
 class SpmmPlan(ctypes.Structure):
     _fields_ = [("threshold", _i32), ("segment_edges", _i32), ("n_heavy", _i64), ("n_segments", _i64),
                 ("heavy_rows", _p), ("heavy_seg_base", _p), ("seg_heavy", _p), ("ell", _p), ("ell_width", _i32),
-                ("reserved", _i32), ("hot_indices", _p)]
+                ("reserved", _i32), ("hot_indices", _p), ("vh_n_rows", _i64), ("vh_n_virtual", _i64), ("vh_rows", _p),
+                ("vh_indptr", _p), ("vh_indices", _p), ("vh_hot_indices", _p), ("vh_identity", _p),
+                ("vh_part_ptr", _p), ("vh_part_pos", _p)]
 
 
 class AdamTensor(ctypes.Structure):

@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256) void spmm_segment_kernel(
     int F, const float *__restrict__ col_scale, const int32_t *__restrict__ heavy_rows,
     const int32_t *__restrict__ heavy_seg_base, const int32_t *__restrict__ seg_heavy, int64_t n_segments, int seg,
     float *__restrict__ partial, int ldp, const int32_t *__restrict__ hot_indices,
-    const float *__restrict__ row_scale, T *__restrict__ M, int64_t ldm, int accumulate)
+    const float *__restrict__ row_scale, T *__restrict__ M, int64_t ldm, int accumulate, int direct)
 {
     // hot_indices (plan, optional): the column ids again, with the sign bit set on the columns that are gathered
     // most often.  Rows of the other columns are loaded with the non-temporal hint, so the few thousand hub rows
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) void spmm_segment_kernel(
     const int32_t r_end = indptr[row + 1];
     const int32_t e0 = indptr[row] + k * seg;
     const int32_t e1 = min(e0 + seg, r_end);
-    const bool single = k == 0 && e1 == r_end;     // the row's only segment: its sum goes straight to M (most heavy
+    const bool single = direct && k == 0 && e1 == r_end;     // the row's only segment: its sum goes straight to M (most heavy
     //                                                rows of a power-law graph; the combine kernel skips them)
     const int f0 = blockIdx.y * (CH * TILE) + lig * VEC;
     bool live[CH];
@@ -937,10 +937,55 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t *__rest
     }
 }
 
+// XCD-pinned part of a plan ("homed" rows, gae_spmm_plan::vh_*): M[row] = rs[row] * sum of the row's virtual-row
+// partials, in the plan's fixed order (home, chunk); one lane per (row, 4 features), 4 loads in flight.
+template <typename T>
+__global__ __launch_bounds__(256) void spmm_vh_combine_kernel(const int32_t *__restrict__ vh_rows,
+                                                              const int32_t *__restrict__ part_ptr,
+                                                              const int32_t *__restrict__ part_pos, int64_t n_vh,
+                                                              const float *__restrict__ partial, int ldp, int F,
+                                                              const float *__restrict__ row_scale,
+                                                              T *__restrict__ M, int64_t ldm, int accumulate,
+                                                              int lanes_per_row)
+{
+    const int64_t gt = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t r = gt / lanes_per_row;
+    const int f0 = int(gt - r * lanes_per_row) * 4;
+    if (r >= n_vh || f0 >= F) return;
+    const int32_t p0 = part_ptr[r], p1 = part_ptr[r + 1];
+    const int64_t row = vh_rows[r];
+    const float rs = row_scale ? row_scale[row] : 1.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int32_t k = p0;
+    for (; k + 4 <= p1; k += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = *reinterpret_cast<const float4 *>(partial + int64_t(part_pos[k + u]) * ldp + f0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
+    }
+    for (; k < p1; ++k) {
+        const float4 v = *reinterpret_cast<const float4 *>(partial + int64_t(part_pos[k]) * ldp + f0);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (f0 + i >= F) break;
+        float sv = s[i] * rs;
+        if (accumulate) {
+            float t[1];
+            VecIO<T, 1>::load(M + row * ldm + f0 + i, t);
+            sv += t[0];
+        }
+        store_scalar(M + row * ldm + f0 + i, sv);
+    }
+}
+
 template <typename T, int VEC, int LPR, int CH>
 int launch_segments(const int32_t *indptr, const int32_t *indices, const T *H, int64_t ldh, int F, const float *cs,
                     const gae_spmm_plan *plan, float *partial, int ldp, const float *rs, T *M, int64_t ldm,
-                    int accumulate, hipStream_t s)
+                    int accumulate, int direct, hipStream_t s)
 {
     const int nvec = (F + VEC - 1) / VEC;
     const dim3 grid(unsigned((plan->n_segments + 3) / 4), unsigned((nvec + LPR * CH - 1) / (LPR * CH)));
@@ -948,12 +993,12 @@ int launch_segments(const int32_t *indptr, const int32_t *indices, const T *H, i
         hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, true>), grid, dim3(256), 0, s, indptr, indices, H, ldh,
                            F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
                            plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr, rs, M, ldm,
-                           accumulate);
+                           accumulate, direct);
     else
         hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, false>), grid, dim3(256), 0, s, indptr, indices, H,
                            ldh, F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
                            plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr, rs, M, ldm,
-                           accumulate);
+                           accumulate, direct);
     GAE_CHECK_LAUNCH("spmm_segment_kernel");
     return GAE_OK;
 }
@@ -961,11 +1006,12 @@ int launch_segments(const int32_t *indptr, const int32_t *indices, const T *H, i
 template <typename T, int VEC>
 int dispatch_segments(const int32_t *indptr, const int32_t *indices, const T *H, int64_t ldh, int F, const float *cs,
                       const gae_spmm_plan *plan, float *partial, int ldp, const float *rs, T *M, int64_t ldm,
-                      int accumulate, hipStream_t s)
+                      int accumulate, int direct, hipStream_t s)
 {
     const int nvec = (F + VEC - 1) / VEC;
 #define GAE_SEG(LPR, CH)                                                                                              \
-    return launch_segments<T, VEC, LPR, CH>(indptr, indices, H, ldh, F, cs, plan, partial, ldp, rs, M, ldm, accumulate, s)
+    return launch_segments<T, VEC, LPR, CH>(indptr, indices, H, ldh, F, cs, plan, partial, ldp, rs, M, ldm, accumulate, \
+                                            direct, s)
     if (nvec <= 4) GAE_SEG(4, 1);
     if (nvec <= 8) GAE_SEG(8, 1);
     if (nvec <= 16) GAE_SEG(16, 1);
@@ -984,7 +1030,8 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
              void *workspace, int flags, hipStream_t s)
 {
     const bool heavy = plan && plan->n_heavy > 0;
-    const int skip = heavy ? plan->threshold : 0x7fffffff;
+    const bool homed = plan && plan->vh_n_virtual > 0;
+    const int skip = (heavy || homed) ? plan->threshold : 0x7fffffff;
     const int min_f = vec ? (sizeof(T) == 4 ? 12 : 24) : 3;
     int rc;
     if (g_spmm_variant == 2 && f > min_f)
@@ -992,22 +1039,43 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
                                         g_spmm_nt, n_cols, skip, flags,
                                         (plan && g_spmm_ell) ? plan->ell : nullptr, plan ? plan->ell_width : 0, s);
     else {
-        GAE_REQUIRE(!heavy, GAE_E_RANGE, "gae_spmm_csr: a skew plan needs F > %d for this layout", min_f);
+        GAE_REQUIRE(!heavy && !homed, GAE_E_RANGE, "gae_spmm_csr: a skew plan needs F > %d for this layout", min_f);
         rc = dispatch_rowgroup<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs,
                                        (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0, s);
     }
-    if (rc || !heavy) return rc;
+    if (rc || (!heavy && !homed)) return rc;
     float *partial = static_cast<float *>(workspace);
     const int ldp = plan_ldp(f);
-    rc = dispatch_segments<T, VEC>(indptr, indices, h, ldh, f, cs, plan, partial, ldp, rs, m, ldm,
-                                   (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0, s);
-    if (rc) return rc;
-    const int lanes_per_row = (f + 3) / 4;
-    const int64_t combine_threads = plan->n_heavy * lanes_per_row;
-    hipLaunchKernelGGL((spmm_combine_kernel<T>), dim3(unsigned((combine_threads + 255) / 256)), dim3(256), 0, s,
-                       indptr, plan->heavy_rows, plan->heavy_seg_base, plan->n_heavy, plan->segment_edges, partial, ldp, f, rs,
-                       m, ldm, (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0, lanes_per_row);
-    GAE_CHECK_LAUNCH("spmm_combine_kernel");
+    const int acc_flag = (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0;
+    if (heavy) {
+        rc = dispatch_segments<T, VEC>(indptr, indices, h, ldh, f, cs, plan, partial, ldp, rs, m, ldm, acc_flag, 1, s);
+        if (rc) return rc;
+        const int lanes_per_row = (f + 3) / 4;
+        const int64_t combine_threads = plan->n_heavy * lanes_per_row;
+        hipLaunchKernelGGL((spmm_combine_kernel<T>), dim3(unsigned((combine_threads + 255) / 256)), dim3(256), 0, s,
+                           indptr, plan->heavy_rows, plan->heavy_seg_base, plan->n_heavy, plan->segment_edges, partial, ldp, f, rs,
+                           m, ldm, acc_flag, lanes_per_row);
+        GAE_CHECK_LAUNCH("spmm_combine_kernel");
+    }
+    if (homed) {
+        // XCD-pinned rows: the plan's virtual CSR (one virtual row = one segment = one (row, home, chunk) group of
+        // column ids; position p is gathered by block p / 4, i.e. on XCD (p / 4) % 8 = the home of its columns) goes
+        // through the same segment kernel into float partials, which are then added per real row in plan order
+        float *pv = partial + (heavy ? align256(plan->n_segments * ldp * 4) / 4 : 0);
+        gae_spmm_plan v = *plan;
+        v.n_heavy = v.n_segments = plan->vh_n_virtual;
+        v.heavy_rows = v.heavy_seg_base = v.seg_heavy = plan->vh_identity;
+        v.hot_indices = plan->vh_hot_indices;
+        rc = dispatch_segments<T, VEC>(plan->vh_indptr, plan->vh_indices, h, ldh, f, cs, &v, pv, ldp, nullptr, m, ldm,
+                                       0, 0, s);
+        if (rc) return rc;
+        const int lanes_per_row = (f + 3) / 4;
+        const int64_t threads = plan->vh_n_rows * lanes_per_row;
+        hipLaunchKernelGGL((spmm_vh_combine_kernel<T>), dim3(unsigned((threads + 255) / 256)), dim3(256), 0, s,
+                           plan->vh_rows, plan->vh_part_ptr, plan->vh_part_pos, plan->vh_n_rows, pv, ldp, f, rs, m, ldm,
+                           acc_flag, lanes_per_row);
+        GAE_CHECK_LAUNCH("spmm_vh_combine_kernel");
+    }
     return GAE_OK;
 }
 
@@ -1071,8 +1139,11 @@ extern "C" int gae_spmm_ell_build(const int32_t *indptr, const int32_t *indices,
 extern "C" int64_t gae_spmm_workspace_bytes(const gae_spmm_plan *plan, int64_t F)
 {
     if (F < 0) return GAE_E_SIZE;
-    if (!plan || plan->n_heavy <= 0) return 0;
-    return align256(plan->n_segments * plan_ldp(F) * 4);
+    if (!plan) return 0;
+    int64_t b = 0;
+    if (plan->n_heavy > 0) b += align256(plan->n_segments * plan_ldp(F) * 4);
+    if (plan->vh_n_virtual > 0) b += align256(plan->vh_n_virtual * plan_ldp(F) * 4);
+    return b;
 }
 
 extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
@@ -1091,9 +1162,15 @@ extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64
     // `indices` may be NULL only for an edge-less graph (indptr all zero): it is never dereferenced then
     GAE_REQUIRE(n_cols == 0 || H, GAE_E_NULL, "gae_spmm_csr: H is NULL with n_cols > 0");
     GAE_REQUIRE((n_rows + 3) / 4 < (int64_t(1) << 31), GAE_E_SIZE, "gae_spmm_csr: too many rows for one launch");
-    if (plan && plan->n_heavy > 0) {
-        GAE_REQUIRE(plan->heavy_rows && plan->heavy_seg_base && plan->seg_heavy && plan->n_segments >= plan->n_heavy &&
-                        plan->threshold >= 1 && plan->segment_edges >= 64 && plan->segment_edges % 64 == 0,
+    if (plan && plan->vh_n_virtual > 0)
+        GAE_REQUIRE(plan->vh_n_rows > 0 && plan->vh_rows && plan->vh_indptr && plan->vh_indices && plan->vh_identity &&
+                        plan->vh_part_ptr && plan->vh_part_pos && plan->threshold >= 1 && plan->segment_edges >= 64 &&
+                        plan->segment_edges % 64 == 0,
+                    GAE_E_RANGE, "gae_spmm_csr: malformed plan (XCD-pinned part)");
+    if (plan && (plan->n_heavy > 0 || plan->vh_n_virtual > 0)) {
+        GAE_REQUIRE(plan->n_heavy == 0 ||
+                        (plan->heavy_rows && plan->heavy_seg_base && plan->seg_heavy && plan->n_segments >= plan->n_heavy &&
+                         plan->threshold >= 1 && plan->segment_edges >= 64 && plan->segment_edges % 64 == 0),
                     GAE_E_RANGE, "gae_spmm_csr: malformed plan");
         const int64_t need = gae_spmm_workspace_bytes(plan, F);
         GAE_REQUIRE(workspace && workspace_bytes >= need, GAE_E_WORKSPACE, "gae_spmm_csr: workspace %lld < %lld bytes",

@@ -333,14 +333,19 @@ class SpmmPlan:
     (heavy rows cut into segments) and / or the packed neighbour table"""
 
     def __init__(self, threshold, segment, n_heavy, n_segments, heavy_rows, heavy_seg_base, seg_heavy, ell=None,
-                 ell_width=None, hot_indices=None):
-        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy, ell, hot_indices)  # keep the device arrays alive
+                 ell_width=None, hot_indices=None, homed=None):
+        self.homed = homed          # dict of the XCD-pinned part (homed_plan_parts) or None
+        hv = tuple(homed[k] for k in ("rows", "indptr", "indices", "hot", "identity", "part_ptr", "part_pos")) \
+            if homed else ()
+        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy, ell, hot_indices) + hv  # keep the device arrays alive
         self.n_heavy, self.n_segments, self.ell = n_heavy, n_segments, ell
         self.hot_indices = hot_indices
         self.ell_width = (ell_width or _lib.SPMM_ELL_WIDTH) if ell is not None else 0
         ptr = lambda t: None if t is None else t.data_ptr()
         self.c = _lib.SpmmPlan(threshold, segment, n_heavy, n_segments, ptr(heavy_rows), ptr(heavy_seg_base),
-                               ptr(seg_heavy), ptr(ell), self.ell_width, 0, ptr(hot_indices))
+                               ptr(seg_heavy), ptr(ell), self.ell_width, 0, ptr(hot_indices),
+                               homed["rows"].numel() if homed else 0, homed["identity"].numel() if homed else 0,
+                               *(ptr(t) for t in hv) if homed else (None,) * 7)
 
 
 def ell_width_for(max_deg):
@@ -393,7 +398,85 @@ def hot_indices_for(indices, n_cols, hot_columns=None):
     return out
 
 
-def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_width=None, hot=None, n_cols=None):
+HOMED_MIN_DEGREE = 256       # rows with more in-edges than this are gathered XCD-pinned ("homed") ...
+HOMED_MIN_EDGES = 1 << 24    # ... when they hold at least this many edges together (RMAT s24: 175 M of 268 M)
+HOMED_HOT_COLUMNS = 1 << 20  # hot tags of the pinned part (RMAT s24: 128 k 5.66 ms, 256 k 5.36, 512 k 5.19, 1 M 5.06, 2 M+ 5.08)
+
+
+def column_home(cols):
+    """XCD (0..7) through whose L2 a column is gathered in the pinned part of a plan: a multiplicative hash (the low
+    bits of the hub ids of an R-MAT graph are all zero: ``col % 8`` would put 44 % of the edges on one XCD)"""
+    return ((cols.to(torch.int64) * 2654435761) >> 13) & 7
+
+
+def homed_plan_parts(indptr, indices, n_cols, min_degree=None, segment=None, hot_columns=None):
+    """XCD-pinned part of a skew plan (gae_spmm_plan::vh_*): the edges of the rows with more than ``min_degree``
+    in-edges regrouped into virtual rows (row, home(column), chunk of <= ``segment`` ids), laid out so that virtual
+    row p is gathered by thread block p / 4 = on XCD (p / 4) % 8 = its home.  Every column then goes through one of
+    the eight private L2s only and their capacities add up.  Built with torch sorts (plan time, once per graph);
+    returns None when no row qualifies."""
+    min_degree = HOMED_MIN_DEGREE if min_degree is None else int(min_degree)
+    seg = SKEW_SEGMENT if segment is None else int(segment)
+    dev = indptr.device
+    deg = (indptr[1:] - indptr[:-1]).to(torch.int64)
+    vh = torch.nonzero(deg > min_degree).flatten()
+    R = int(vh.numel())
+    if R == 0:
+        return None
+    d = deg[vh]
+    E = int(d.sum())
+    starts = indptr[vh].to(torch.int64)
+    off = torch.cumsum(d, 0) - d
+    eidx = torch.repeat_interleave(starts - off, d) + torch.arange(E, device=dev)
+    cols = indices[eidx].to(torch.int64)
+    rowslot = torch.repeat_interleave(torch.arange(R, device=dev), d)
+    del eidx
+    grp = rowslot * 8 + column_home(cols)
+    del rowslot
+    order = torch.argsort(grp * (1 << 31) + cols)              # (row, home, column): deterministic summation order
+    cols = cols[order]
+    grp = grp[order]
+    del order
+    cnt = torch.bincount(grp, minlength=R * 8)                 # edges per (row, home)
+    del grp
+    nchunk = (cnt + seg - 1) // seg
+    gstart = torch.cumsum(cnt, 0) - cnt
+    vg = torch.repeat_interleave(torch.arange(R * 8, device=dev), nchunk)      # group of every virtual row
+    first = torch.cumsum(nchunk, 0) - nchunk
+    vk = torch.arange(vg.numel(), device=dev) - first[vg]
+    v_e0 = gstart[vg] + vk * seg
+    v_len = torch.minimum(v_e0 + seg, gstart[vg] + cnt[vg]) - v_e0
+    v_home = vg % 8
+    # position of every virtual row: per home, 4 consecutive positions per thread block, blocks interleaved over XCDs
+    rank_in_home = torch.empty_like(vg)
+    L = 0
+    for h in range(8):
+        m = torch.nonzero(v_home == h).flatten()
+        rank_in_home[m] = torch.arange(m.numel(), device=dev)
+        L = max(L, int(m.numel()))
+    L = (L + 3) // 4 * 4
+    V = 8 * L
+    pos = (rank_in_home // 4) * 32 + v_home * 4 + (rank_in_home % 4)
+    lens = torch.zeros(V, dtype=torch.int64, device=dev)
+    lens[pos] = v_len
+    e0 = torch.zeros(V, dtype=torch.int64, device=dev)
+    e0[pos] = v_e0
+    ipv = torch.zeros(V + 1, dtype=torch.int64, device=dev)
+    ipv[1:] = torch.cumsum(lens, 0)
+    src = torch.repeat_interleave(e0 - ipv[:-1], lens) + torch.arange(E, device=dev)
+    ixv = cols[src].to(torch.int32).contiguous()
+    del src, cols
+    # partial lists: virtual rows of real row r in (home, chunk) order = their order in `vg`
+    per_row = nchunk.view(R, 8).sum(1)
+    part_ptr = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+    part_ptr[1:] = torch.cumsum(per_row, 0)
+    hot = hot_indices_for(ixv, n_cols, hot_columns or HOMED_HOT_COLUMNS)
+    return dict(rows=vh.to(torch.int32).contiguous(), indptr=ipv.to(torch.int32).contiguous(), indices=ixv, hot=hot,
+                identity=torch.arange(V, dtype=torch.int32, device=dev), part_ptr=part_ptr.to(torch.int32).contiguous(),
+                part_pos=pos.to(torch.int32).contiguous(), min_degree=min_degree, n_edges=E)
+
+
+def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_width=None, hot=None, n_cols=None, homed=None):
     """Build the plan of a CSR, or None when it needs none (one host read-back of three counters; done once per
     graph).  Skew part: with the default threshold only for graphs whose longest row has more than
     SKEW_MIN_MAXDEG edges.  Packed neighbour table: when ``indices`` is given and the graph has at most
@@ -418,7 +501,26 @@ def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_
         if not heavy and not want_ell:
             return None
         hr = hb = sh = table = None
-        if heavy:
+        parts = None
+        if heavy and indices is not None and homed is not False and max_deg > HOMED_MIN_DEGREE:
+            deg64 = (indptr[1:] - indptr[:-1]).to(torch.int64)
+            vh_edges = int(deg64[deg64 > HOMED_MIN_DEGREE].sum())
+            if homed or vh_edges >= HOMED_MIN_EDGES:
+                nc = int(n_cols) if n_cols is not None else max(n, int(indices.max()) + 1)
+                parts = homed_plan_parts(indptr, indices, nc, segment=segment)
+        if parts is not None:
+            # the segment lists then hold the rows with threshold < degree <= HOMED_MIN_DEGREE only (torch-built:
+            # gae_spmm_plan_fill has no upper bound)
+            d32 = indptr[1:] - indptr[:-1]
+            hrows = torch.nonzero((d32 > threshold) & (d32 <= HOMED_MIN_DEGREE)).flatten()
+            ns = (d32[hrows].to(torch.int64) + segment - 1) // segment
+            n_heavy, n_seg = int(hrows.numel()), int(ns.sum())
+            hr = hrows.to(torch.int32).contiguous()
+            hb = (torch.cumsum(ns, 0) - ns).to(torch.int32).contiguous()
+            sh = torch.repeat_interleave(torch.arange(n_heavy, dtype=torch.int32, device=dev), ns).contiguous()
+            if n_heavy == 0:
+                hr = hb = sh = None
+        elif heavy:
             hr = torch.empty(n_heavy, dtype=torch.int32, device=dev)
             hb = torch.empty(n_heavy, dtype=torch.int32, device=dev)
             sh = torch.empty(n_seg, dtype=torch.int32, device=dev)
@@ -438,7 +540,7 @@ def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_
         if want_hot:
             nc = int(n_cols) if n_cols is not None else max(n, int(indices.max()) + 1 if indices.numel() else n)
             tags = hot_indices_for(indices, nc)
-    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh, table, ell_width, tags)
+    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh, table, ell_width, tags, parts)
 
 
 def gather_distance(indptr, indices):

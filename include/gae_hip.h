@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GAE_VERSION 103 /* 0.1.1 */
+#define GAE_VERSION 104 /* 0.1.1 */
 
 enum {
     GAE_OK = 0,
@@ -177,6 +177,22 @@ typedef struct gae_spmm_plan {
                                        columns (gae_spmm_tag_hot), or NULL: the heavy-row kernel then loads the
                                        rows of all OTHER columns with the streaming hint, which keeps the hub
                                        rows of a power-law graph in L2.  A cache hint only: values unchanged. */
+    /* XCD-pinned ("homed") part, optional (vh_n_virtual = 0: none).  The rows in vh_rows -- the very long rows of a
+     * power-law graph; they must NOT appear in heavy_rows -- are evaluated from a virtual CSR: virtual row p holds
+     * the <= segment_edges column ids (tagged like hot_indices, optional) of one (row, home, chunk) group, where
+     * home(column) in 0..7 is any fixed hash, and p is ordered so that (p / 4) % 8 == home: thread block p / 4 runs
+     * on XCD (p / 4) % 8, so every column is gathered through ONE of the eight private L2s and their capacities add
+     * up (RMAT s24: 3.6 -> 2.6 ms for the rows with more than 256 edges).  Empty virtual rows pad the lists.  The
+     * partials of row vh_rows[r] are the virtual rows vh_part_pos[vh_part_ptr[r] .. vh_part_ptr[r + 1]), added in
+     * that order.  Changes the summation order of those rows (fp32 rounding), never the set of terms. */
+    int64_t vh_n_rows, vh_n_virtual;
+    const int32_t *vh_rows;         /* [vh_n_rows] */
+    const int32_t *vh_indptr;       /* [vh_n_virtual + 1] */
+    const int32_t *vh_indices;      /* [vh_indptr[vh_n_virtual]] column ids in virtual-row order */
+    const int32_t *vh_hot_indices;  /* the same with hot tags, or NULL */
+    const int32_t *vh_identity;     /* [vh_n_virtual] 0, 1, 2, ... */
+    const int32_t *vh_part_ptr;     /* [vh_n_rows + 1] */
+    const int32_t *vh_part_pos;     /* [vh_part_ptr[vh_n_rows]] */
 } gae_spmm_plan;
 
 /* Hot-column tags for a plan with heavy rows: gae_spmm_col_freq counts how often every column occurs in `indices`

@@ -1372,3 +1372,56 @@ def test_spmm_hot_column_tags_are_only_cache_hints(dev, tuning):
             c = ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan_hot)
             tuning("spmm_hot", 1)
             assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_spmm_homed_rows_match_oracle(dtype, dev):
+    """XCD-pinned ("homed") part of a skew plan: the very long rows are evaluated from virtual rows grouped by the
+    home of their columns -- same terms, another summation order: == the plain plan and the fp64 oracle to 1e-5 of
+    the scale (fp32), scaled and unscaled, with GAE_SPMM_ACCUMULATE, and the layout invariants of the plan hold"""
+    from gae_dgl_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.default_rng(33)
+    n, e = 6000, 400000
+    dst = (rng.integers(0, n, e).astype(np.float64) ** 4 / n ** 3).astype(np.int64)          # rows of thousands of edges
+    src = (rng.integers(0, n, e).astype(np.float64) ** 2 / n).astype(np.int64)
+    ip, ix = ops.csr_from_coo(t(dst, dev), t(src, dev), n, n)
+    plan = ops.spmm_plan(ip, threshold=8, segment=128, indices=ix, ell=False, hot=True, n_cols=n, homed=True)
+    plain = ops.spmm_plan(ip, threshold=8, segment=128, indices=ix, ell=False, hot=False, n_cols=n, homed=False)
+    hp = plan.homed
+    assert hp is not None and plain.homed is None
+    deg = (ip[1:] - ip[:-1]).cpu().numpy()
+    assert np.array_equal(hp["rows"].cpu().numpy(), np.nonzero(deg > ops.HOMED_MIN_DEGREE)[0])
+    if plan.n_heavy:
+        hr = plan.tensors[0].cpu().numpy()
+        assert ((deg[hr] > 8) & (deg[hr] <= ops.HOMED_MIN_DEGREE)).all()
+    ipv, ixv = hp["indptr"].cpu().numpy(), hp["indices"].cpu().numpy()
+    lens = np.diff(ipv)
+    assert lens.max() <= 128 and ipv[-1] == hp["n_edges"] == deg[deg > ops.HOMED_MIN_DEGREE].sum()
+    home = ops.column_home(torch.from_numpy(ixv.astype(np.int64))).numpy()
+    pos_of_edge = np.repeat(np.arange(len(lens)), lens)
+    assert np.array_equal(home, (pos_of_edge // 4) % 8)               # every column gathered on its home XCD
+    pp, pq = hp["part_ptr"].cpu().numpy(), hp["part_pos"].cpu().numpy()
+    assert len(np.unique(pq)) == len(pq) and pp[-1] == len(pq) == (lens > 0).sum()
+    deg_t, norm = ops.degree_norm(ip)
+    H = t(rng.standard_normal((n, 40)).astype(np.float32), dev).to(dtype)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for sc in (None, norm):
+        a = ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan)
+        b = ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plain)
+        Hn = H.float().cpu().numpy()
+        if sc is None:
+            ref = C.spmm_csr_acc64(ip.cpu().numpy(), ix.cpu().numpy(), Hn)
+        else:       # diag(s) A diag(s) H = s * (A (s * H)) with the scaling done in fp64 around the oracle's sum
+            sn = sc.cpu().numpy().astype(np.float64)
+            ref = sn[:, None] * C.spmm_csr_acc64(ip.cpu().numpy(), ix.cpu().numpy(),
+                                                 (sn[:, None] * Hn).astype(np.float32))
+        scale = float(np.abs(ref).max())
+        assert float((a.float() - b.float()).abs().max()) <= tol * scale
+        assert float(np.abs(a.float().cpu().numpy() - ref).max()) <= tol * scale
+        base = torch.randn(n, 40, device=dev).to(dtype)
+        acc = base.clone()
+        ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan, out=acc, accumulate=True)
+        assert float((acc.float() - (base.float() + a.float())).abs().max()) <= (1e-6 if dtype == torch.float32 else 2e-2) * scale
+    # deterministic
+    assert torch.equal(ops.spmm_raw(ip, ix, H, n, plan=plan), ops.spmm_raw(ip, ix, H, n, plan=plan))

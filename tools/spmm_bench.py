@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--no-plan", action="store_true")
     ap.add_argument("--blockdiag", type=int, default=0, help="member graphs per block (0 = off) for the zinc shapes")
     ap.add_argument("--hot-cols", type=int, default=0, help="ops.HOT_COLUMNS for the rmat plan (0 = default)")
+    ap.add_argument("--homed-deg", type=int, default=0, help="ops.HOMED_MIN_DEGREE (0 = default)")
+    ap.add_argument("--homed-hot", type=int, default=0, help="ops.HOMED_HOT_COLUMNS (0 = default)")
     ap.add_argument("--thr", type=int, default=64)
     ap.add_argument("--seg", type=int, default=512)
     ap.add_argument("--variants", default="v1:1:0,v2:1:0,v2:2:0,v2:1:1,v2:2:1")
@@ -48,6 +50,10 @@ def main():
     args = ap.parse_args()
     if args.hot_cols:
         ops.HOT_COLUMNS = args.hot_cols
+    if args.homed_deg:
+        ops.HOMED_MIN_DEGREE = args.homed_deg
+    if args.homed_hot:
+        ops.HOMED_HOT_COLUMNS = args.homed_hot
     for kv in filter(None, args.knobs.split(",")):
         k, v = kv.split("=")
         knob(k, int(v))
