@@ -9,7 +9,11 @@ A^T (backward structure), its rows of H, M and Z.
   backward  dH_p = A^T_p * dM    dM   = exchange(dM_p)     (one collective)
 
 so no reduce-scatter and no float atomics are needed and every rank's result
-is bit-identical to the rows the single-GPU kernel would produce.  Two exchange
+is bit-identical to the rows the single-GPU kernel would produce (exception:
+rows of more than ops.HOMED_MIN_DEGREE edges in a shard of at least
+ops.HOMED_MIN_EDGES such edges, whose XCD-pinned gather adds the row in (home,
+chunk) order -- deterministic, another association, <= 2e-6 of the scale
+measured on RMAT s24 shards, tools/r02/rmat_shard.py).  Two exchange
 modes:
   * "allgather": RCCL all-gather of the whole feature matrix (power-law graphs
     such as RMAT, where nearly every column is a boundary column);
@@ -38,11 +42,21 @@ def block_bounds(n, world):
     return np.minimum(np.arange(world + 1, dtype=np.int64) * b, n)
 
 
-def nnz_balanced_bounds(n, src, dst, world):
-    """contiguous row blocks with (almost) equal in+out edge counts: power-law graphs put most edges on
-    few rows, so equal ROW blocks would leave one rank with half of the work (RMAT s24, 8 ranks: 44 %)."""
+# Cost of one row of a block in units of one edge (a row's in- and out-edges count 1 each).  Measured, RMAT s24 on 8
+# virtual ranks, compute of one encoder step without the collectives (tools/r02/rmat_rank_step.py): a row costs what
+# ~16 edge visits cost (its share of the dense layers, the activations and the products' outputs: ~1.5 KB of HBM
+# traffic per step).  Slowest rank 7.56 ms at cost 1 (7.1 M rows of the tail), 5.78 at 8, 4.48 at 16, 3.64 at 32 (the
+# mean is 3.41); the hub-owning ranks receive more boundary rows the higher the cost (rank 0: 0.92 -> 1.12 GB per
+# step from 1 to 32), so 16 and not the compute-only optimum.
+ROW_COST = 16
+
+
+def nnz_balanced_bounds(n, src, dst, world, row_cost=None):
+    """contiguous row blocks with (almost) equal cost = in+out edge counts + ``row_cost`` per row: power-law graphs
+    put most edges on few rows, so equal ROW blocks would leave one rank with half of the work (RMAT s24, 8 ranks:
+    44 %); a row costs something too (its share of the dense layers, of the product's output and of the exchange)."""
     src = torch.as_tensor(src).to(torch.int64).reshape(-1); dst = torch.as_tensor(dst).to(torch.int64).reshape(-1)
-    w = torch.bincount(dst, minlength=n) + torch.bincount(src, minlength=n) + 1      # +1: rows cost something too
+    w = torch.bincount(dst, minlength=n) + torch.bincount(src, minlength=n) + int(ROW_COST if row_cost is None else row_cost)
     c = torch.cumsum(w, 0)
     targets = (torch.arange(1, world, device=c.device, dtype=torch.float64) * (float(c[-1]) / world)).to(c.dtype)
     cuts = torch.searchsorted(c, targets).clamp(max=n).cpu().numpy().astype(np.int64)
@@ -185,7 +199,8 @@ class ShardedGraph:
         if key not in self._plan:
             from . import ops
             # explicit threshold: whether a row is segmented must depend on that row only, so that every
-            # sharding of a graph (and the 1-rank case) produces bit-identical sums
+            # sharding of a graph (and the 1-rank case) produces bit-identical sums (below the size at which
+            # ops.spmm_plan pins the very long rows to XCDs, see the module docstring)
             p = self.part
             n_cols = p.n_cols[which] if part is None else p.n_local if part == "own" else \
                 p.split[which]["n_remote_cols"]
