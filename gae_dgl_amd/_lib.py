@@ -31,7 +31,7 @@ class SpmmPlan(ctypes.Structure):
                 ("heavy_rows", _p), ("heavy_seg_base", _p), ("seg_heavy", _p), ("ell", _p), ("ell_width", _i32),
                 ("reserved", _i32), ("hot_indices", _p), ("vh_n_rows", _i64), ("vh_n_virtual", _i64), ("vh_rows", _p),
                 ("vh_indptr", _p), ("vh_indices", _p), ("vh_hot_indices", _p), ("vh_identity", _p),
-                ("vh_part_ptr", _p), ("vh_part_pos", _p)]
+                ("vh_part_ptr", _p), ("vh_part_pos", _p), ("seg_desc", _p)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -66,6 +66,7 @@ SIGNATURES = {
     "gae_segment_readout": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),
     "gae_spmm_plan_count": (_int, [_p, _i64, _i32, _i32, _p, _p]),
     "gae_spmm_plan_fill": (_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
+    "gae_spmm_plan_desc": (_int, [_p, _p, _p, _p, _i64, _i32, _p, _p]),
     "gae_spmm_ell_build": (_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "gae_spmm_workspace_bytes": (_i64, [ctypes.POINTER(SpmmPlan), _i64]),
     "gae_spmm_csr": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _int, _p, _p,

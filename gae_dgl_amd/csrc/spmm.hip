@@ -484,6 +484,7 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const int32_t *__restric
 // tuning knobs (gae_tuning_set): read-mostly process-wide integers
 thread_local int g_spmm_variant = 2;   // 1 = v1 rowgroup, 2 = v2 rowgroup2
 thread_local int g_spmm_rpg = 0;       // rows per lane group (v2): 0 = auto (2 for launches of >= 32768 waves, else 1), 1, 2
+thread_local int g_spmm_desc = 1;      // "spmm_desc": segment descriptors / identity segments (1) or the plan's index chain (0); bit-identical
 thread_local int g_spmm_hot = 1;       // "spmm_hot": use the plan's hot-column tags (streaming loads of cold rows); 0 = plain loads
 thread_local int g_spmm_nt = -1;       // store policy of M (v2): -1 = auto (sc1 under feature tiles, else nt), 0 plain, 1 non-temporal, 2 write-through sc1
 thread_local int g_spmm_tile_vecs = 0; // 16-byte vectors per XCD feature tile: 0 = auto when GAE_SPMM_TILE is set, -1 = never, > 0 = forced
@@ -781,6 +782,24 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t *__restric
     }
 }
 
+// seg_desc[s] = {row, first edge, end edge, 1 if the segment is its row's only one}
+__global__ __launch_bounds__(256) void plan_desc_kernel(const int32_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ heavy_rows,
+                                                        const int32_t *__restrict__ heavy_seg_base,
+                                                        const int32_t *__restrict__ seg_heavy, int64_t n_segments,
+                                                        int seg, int32_t *__restrict__ seg_desc)
+{
+    const int64_t sidx = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (sidx >= n_segments) return;
+    const int h = seg_heavy[sidx];
+    const int32_t row = heavy_rows[h];
+    const int k = int(sidx - heavy_seg_base[h]);
+    const int32_t r_end = indptr[row + 1];
+    const int32_t e0 = indptr[row] + k * seg;
+    const int32_t e1 = min(e0 + seg, r_end);
+    *reinterpret_cast<int4 *>(seg_desc + sidx * 4) = make_int4(row, e0, e1, (k == 0 && e1 == r_end) ? 1 : 0);
+}
+
 // one wave per segment; partial[s][0..F)
 template <typename T, int VEC, int LPR, int CH, bool SCALED>
 __global__ __launch_bounds__(256) void spmm_segment_kernel(
@@ -788,7 +807,8 @@ __global__ __launch_bounds__(256) void spmm_segment_kernel(
     int F, const float *__restrict__ col_scale, const int32_t *__restrict__ heavy_rows,
     const int32_t *__restrict__ heavy_seg_base, const int32_t *__restrict__ seg_heavy, int64_t n_segments, int seg,
     float *__restrict__ partial, int ldp, const int32_t *__restrict__ hot_indices,
-    const float *__restrict__ row_scale, T *__restrict__ M, int64_t ldm, int accumulate, int direct)
+    const float *__restrict__ row_scale, T *__restrict__ M, int64_t ldm, int accumulate, int direct,
+    const int32_t *__restrict__ seg_desc)
 {
     // hot_indices (plan, optional): the column ids again, with the sign bit set on the columns that are gathered
     // most often.  Rows of the other columns are loaded with the non-temporal hint, so the few thousand hub rows
@@ -800,14 +820,31 @@ __global__ __launch_bounds__(256) void spmm_segment_kernel(
     const int lane = threadIdx.x & 63, lig = lane % LPR, g = lane / LPR;
     const int64_t sidx = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (sidx >= n_segments) return;
-    const int h = seg_heavy[sidx];
-    const int64_t row = heavy_rows[h];
-    const int k = int(sidx - heavy_seg_base[h]);
-    const int32_t r_end = indptr[row + 1];
-    const int32_t e0 = indptr[row] + k * seg;
-    const int32_t e1 = min(e0 + seg, r_end);
-    const bool single = direct && k == 0 && e1 == r_end;     // the row's only segment: its sum goes straight to M (most heavy
-    //                                                rows of a power-law graph; the combine kernel skips them)
+    // A wave of this kernel lives for a handful of memory round trips, one of which is the gather itself: the chain
+    // segment -> heavy slot -> row -> edge range -> column ids in front of it set the launch time of the 9..256-edge
+    // rows of RMAT s24 (2.2 M waves of ~35 edges).  Two shorter forms: the plan's 16-byte segment descriptor {row,
+    // first edge, end edge, only segment of its row} (gae_spmm_plan_desc), or -- heavy_rows == NULL -- segment s IS
+    // row s of the CSR handed in (the virtual rows of the XCD-pinned part).
+    int64_t row;
+    int32_t e0, e1;
+    bool single;
+    if (seg_desc) {
+        const int4 d = *reinterpret_cast<const int4 *>(seg_desc + sidx * 4);
+        row = d.x; e0 = d.y; e1 = d.z;
+        single = direct && d.w;
+    } else if (!heavy_rows) {
+        row = sidx; e0 = indptr[sidx]; e1 = indptr[sidx + 1];
+        single = direct != 0;
+    } else {
+        const int h = seg_heavy[sidx];
+        row = heavy_rows[h];
+        const int k = int(sidx - heavy_seg_base[h]);
+        const int32_t r_end = indptr[row + 1];
+        e0 = indptr[row] + k * seg;
+        e1 = min(e0 + seg, r_end);
+        single = direct && k == 0 && e1 == r_end;   // the row's only segment: its sum goes straight to M (most heavy
+        //                                             rows of a power-law graph; the combine kernel skips them)
+    }
     const int f0 = blockIdx.y * (CH * TILE) + lig * VEC;
     bool live[CH];
 #pragma unroll
@@ -993,12 +1030,12 @@ int launch_segments(const int32_t *indptr, const int32_t *indices, const T *H, i
         hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, true>), grid, dim3(256), 0, s, indptr, indices, H, ldh,
                            F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
                            plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr, rs, M, ldm,
-                           accumulate, direct);
+                           accumulate, direct, g_spmm_desc ? plan->seg_desc : nullptr);
     else
         hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, false>), grid, dim3(256), 0, s, indptr, indices, H,
                            ldh, F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
                            plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr, rs, M, ldm,
-                           accumulate, direct);
+                           accumulate, direct, g_spmm_desc ? plan->seg_desc : nullptr);
     GAE_CHECK_LAUNCH("spmm_segment_kernel");
     return GAE_OK;
 }
@@ -1064,7 +1101,8 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
         float *pv = partial + (heavy ? align256(plan->n_segments * ldp * 4) / 4 : 0);
         gae_spmm_plan v = *plan;
         v.n_heavy = v.n_segments = plan->vh_n_virtual;
-        v.heavy_rows = v.heavy_seg_base = v.seg_heavy = plan->vh_identity;
+        v.heavy_rows = v.heavy_seg_base = v.seg_heavy = g_spmm_desc ? nullptr : plan->vh_identity;   // NULL: segment s = row s
+        v.seg_desc = nullptr;
         v.hot_indices = plan->vh_hot_indices;
         rc = dispatch_segments<T, VEC>(plan->vh_indptr, plan->vh_indices, h, ldh, f, cs, &v, pv, ldp, nullptr, m, ldm,
                                        0, 0, s);
@@ -1116,6 +1154,23 @@ extern "C" int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t
     hipLaunchKernelGGL(plan_fill_kernel, dim3(unsigned(g)), dim3(256), 0, s, indptr, n_rows, threshold, segment_edges,
                        reinterpret_cast<unsigned long long *>(cursors_dev), heavy_rows, heavy_seg_base, seg_heavy);
     GAE_CHECK_LAUNCH("plan_fill_kernel");
+    return GAE_OK;
+}
+
+extern "C" int gae_spmm_plan_desc(const int32_t *indptr, const int32_t *heavy_rows, const int32_t *heavy_seg_base,
+                                  const int32_t *seg_heavy, int64_t n_segments, int32_t segment_edges,
+                                  int32_t *seg_desc, void *stream)
+{
+    GAE_REQUIRE(n_segments >= 0, GAE_E_SIZE, "gae_spmm_plan_desc: negative n_segments");
+    GAE_REQUIRE(segment_edges >= 64 && segment_edges % 64 == 0, GAE_E_RANGE,
+                "gae_spmm_plan_desc: segment_edges must be a positive multiple of 64");
+    if (n_segments == 0) return GAE_OK;
+    GAE_REQUIRE(indptr && heavy_rows && heavy_seg_base && seg_heavy && seg_desc, GAE_E_NULL,
+                "gae_spmm_plan_desc: NULL pointer");
+    GAE_REQUIRE(gae::aligned16(seg_desc), GAE_E_ALIGN, "gae_spmm_plan_desc: seg_desc not 16-byte aligned");
+    hipLaunchKernelGGL(plan_desc_kernel, dim3(unsigned((n_segments + 255) / 256)), dim3(256), 0, gae::as_stream(stream),
+                       indptr, heavy_rows, heavy_seg_base, seg_heavy, n_segments, segment_edges, seg_desc);
+    GAE_CHECK_LAUNCH("plan_desc_kernel");
     return GAE_OK;
 }
 
@@ -1326,7 +1381,8 @@ int *find_knob(const char *name)
 {
     const struct { const char *k; int *v; } knobs[] = {
         {"spmm_variant", &g_spmm_variant}, {"spmm_rpg", &g_spmm_rpg}, {"spmm_nt", &g_spmm_nt},
-        {"spmm_tile_vecs", &g_spmm_tile_vecs}, {"spmm_ell", &g_spmm_ell}, {"spmm_hot", &g_spmm_hot}};
+        {"spmm_tile_vecs", &g_spmm_tile_vecs}, {"spmm_ell", &g_spmm_ell}, {"spmm_hot", &g_spmm_hot},
+        {"spmm_desc", &g_spmm_desc}};
     for (const auto &kv : knobs)
         if (strcmp(kv.k, name) == 0) return kv.v;
     if (int *k = gae::spmm_ell_knob(name)) return k;

@@ -333,11 +333,20 @@ class SpmmPlan:
     (heavy rows cut into segments) and / or the packed neighbour table"""
 
     def __init__(self, threshold, segment, n_heavy, n_segments, heavy_rows, heavy_seg_base, seg_heavy, ell=None,
-                 ell_width=None, hot_indices=None, homed=None):
+                 ell_width=None, hot_indices=None, homed=None, indptr=None):
         self.homed = homed          # dict of the XCD-pinned part (homed_plan_parts) or None
+        # segment descriptors (one 16-byte record in front of a segment's column ids instead of a chain of three
+        # dependent index loads): built whenever the CSR is at hand
+        seg_desc = None
+        if indptr is not None and n_segments > 0:
+            seg_desc = torch.empty(n_segments, 4, dtype=torch.int32, device=indptr.device)
+            with _on_device(indptr.device):
+                _lib.call("gae_spmm_plan_desc", _ptr(indptr), _ptr(heavy_rows), _ptr(heavy_seg_base), _ptr(seg_heavy),
+                          n_segments, segment, _ptr(seg_desc), _stream())
+        self.seg_desc = seg_desc
         hv = tuple(homed[k] for k in ("rows", "indptr", "indices", "hot", "identity", "part_ptr", "part_pos")) \
             if homed else ()
-        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy, ell, hot_indices) + hv  # keep the device arrays alive
+        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy, ell, hot_indices) + hv + (seg_desc,)  # keep the device arrays alive
         self.n_heavy, self.n_segments, self.ell = n_heavy, n_segments, ell
         self.hot_indices = hot_indices
         self.ell_width = (ell_width or _lib.SPMM_ELL_WIDTH) if ell is not None else 0
@@ -345,7 +354,7 @@ class SpmmPlan:
         self.c = _lib.SpmmPlan(threshold, segment, n_heavy, n_segments, ptr(heavy_rows), ptr(heavy_seg_base),
                                ptr(seg_heavy), ptr(ell), self.ell_width, 0, ptr(hot_indices),
                                homed["rows"].numel() if homed else 0, homed["identity"].numel() if homed else 0,
-                               *(ptr(t) for t in hv) if homed else (None,) * 7)
+                               *((ptr(t) for t in hv) if homed else (None,) * 7), ptr(seg_desc))
 
 
 def ell_width_for(max_deg):
@@ -540,7 +549,7 @@ def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_
         if want_hot:
             nc = int(n_cols) if n_cols is not None else max(n, int(indices.max()) + 1 if indices.numel() else n)
             tags = hot_indices_for(indices, nc)
-    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh, table, ell_width, tags, parts)
+    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh, table, ell_width, tags, parts, indptr=indptr)
 
 
 def gather_distance(indptr, indices):

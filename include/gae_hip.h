@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GAE_VERSION 104 /* 0.1.1 */
+#define GAE_VERSION 105 /* 0.1.1 */
 
 enum {
     GAE_OK = 0,
@@ -63,7 +63,7 @@ int gae_device_info_get(int device, gae_device_info *out_host);
 /* Tuning / test knobs: integers local to the CALLING THREAD (thread_local; the launches of a thread see what that
  * thread set, other threads keep the defaults -- no process-wide mutable state).  Three kinds:
  *  - select among kernels with bit-identical results: "spmm_variant", "spmm_rpg", "spmm_nt", "spmm_tile_vecs",
- *    "spmm_ell", "spmm_ell_rpg", "spmm_hot", "bce_minw", "bce_strip_store", "bce_fold_mirror";
+ *    "spmm_ell", "spmm_ell_rpg", "spmm_hot", "spmm_desc", "bce_minw", "bce_strip_store", "bce_fold_mirror";
  *  - change the ORDER in which partial sums are added (results agree within the fp32 tolerance of DESIGN.md
  *    section 6, not bit for bit): "atb_rows", "gemm_stream", "linear_wlds", "linear_f32x16", "linear_nw", "linear_depth", "bce_ri", "bce_sym", "bce_sym_ri",
  *    "bce_sym_grid", "bce_sym_tiles", "bce_grid"; a skew
@@ -193,6 +193,11 @@ typedef struct gae_spmm_plan {
     const int32_t *vh_identity;     /* [vh_n_virtual] 0, 1, 2, ... */
     const int32_t *vh_part_ptr;     /* [vh_n_rows + 1] */
     const int32_t *vh_part_pos;     /* [vh_part_ptr[vh_n_rows]] */
+    const int32_t *seg_desc;        /* [n_segments][4] {row, first edge, end edge, 1 = the row's only segment}
+                                       (gae_spmm_plan_desc; 16-byte aligned) or NULL: one load in front of a
+                                       segment's column ids instead of the chain seg_heavy -> heavy_rows /
+                                       heavy_seg_base -> indptr (a wave of the heavy-row kernel lives for a handful
+                                       of round trips: RMAT s24 launch 5.05 -> 4.85 ms).  Same sums. */
 } gae_spmm_plan;
 
 /* Hot-column tags for a plan with heavy rows: gae_spmm_col_freq counts how often every column occurs in `indices`
@@ -207,6 +212,10 @@ int gae_spmm_plan_count(const int32_t *indptr, int64_t n_rows, int32_t threshold
 int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
                        uint64_t *cursors_dev, int32_t *heavy_rows, int32_t *heavy_seg_base,
                        int32_t *seg_heavy, void *stream);
+/* optional: the segment descriptors of a filled plan (int32 [n_segments][4], see gae_spmm_plan::seg_desc) */
+int gae_spmm_plan_desc(const int32_t *indptr, const int32_t *heavy_rows, const int32_t *heavy_seg_base,
+                       const int32_t *seg_heavy, int64_t n_segments, int32_t segment_edges, int32_t *seg_desc,
+                       void *stream);
 /* Packed neighbour table (optional, for launches of a few 10 MB): slot k of row r at ell[r * width + k] holds the
  * row's k-th column id in CSR order; -1 = empty; a row with more than `width` ids keeps width - 1 of them and the
  * marker -2 in its last slot (the kernel continues from indptr / indices); rows with more than `skip_degree` ids

@@ -1374,6 +1374,43 @@ def test_spmm_hot_column_tags_are_only_cache_hints(dev, tuning):
             assert torch.equal(a, c)
 
 
+def test_spmm_segment_descriptors_match_the_index_chain(dev, tuning):
+    """gae_spmm_plan_desc: {row, first edge, end edge, only segment} of every segment as the plan's index arrays
+    define them, and a heavy-row SpMM (plain, scaled, accumulating, with an XCD-pinned part) that is bit-identical
+    whether the kernel reads the descriptors / identity segments or walks the index chain (knob spmm_desc)"""
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(22)
+    n, e, seg = 5000, 300000, 128
+    dst = (rng.integers(0, n, e).astype(np.float64) ** 4 / n ** 3).astype(np.int64)
+    src = (rng.integers(0, n, e).astype(np.float64) ** 2 / n).astype(np.int64)
+    ip, ix = ops.csr_from_coo(t(dst, dev), t(src, dev), n, n)
+    for homed in (False, True):
+        plan = ops.spmm_plan(ip, threshold=8, segment=seg, indices=ix, ell=False, hot=True, n_cols=n, homed=homed)
+        assert plan.seg_desc is not None and plan.n_segments > 0 and (plan.homed is not None) == homed
+        hr, hb, sh = (x.cpu().numpy() for x in plan.tensors[:3])
+        d = plan.seg_desc.cpu().numpy()
+        ipn = ip.cpu().numpy()
+        rows = hr[sh]
+        k = np.arange(plan.n_segments) - hb[sh]
+        e0 = ipn[rows] + k * seg
+        e1 = np.minimum(e0 + seg, ipn[rows + 1])
+        assert np.array_equal(d[:, 0], rows) and np.array_equal(d[:, 1], e0) and np.array_equal(d[:, 2], e1)
+        assert np.array_equal(d[:, 3], ((k == 0) & (e1 == ipn[rows + 1])).astype(np.int32))
+        deg, norm = ops.degree_norm(ip)
+        for dtype in (torch.float32, torch.bfloat16):
+            H = t(rng.standard_normal((n, 40)).astype(np.float32), dev).to(dtype)
+            base = t(rng.standard_normal((n, 40)).astype(np.float32), dev).to(dtype)
+            for sc in (None, norm):
+                out = {}
+                for knob in (1, 0):
+                    tuning("spmm_desc", knob)
+                    acc = base.clone()
+                    ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan, out=acc, accumulate=True)
+                    out[knob] = (ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan), acc)
+                tuning("spmm_desc", 1)
+                assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_spmm_homed_rows_match_oracle(dtype, dev):
     """XCD-pinned ("homed") part of a skew plan: the very long rows are evaluated from virtual rows grouped by the
