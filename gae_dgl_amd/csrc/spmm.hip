@@ -975,37 +975,48 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t *__rest
 }
 
 // XCD-pinned part of a plan ("homed" rows, gae_spmm_plan::vh_*): M[row] = rs[row] * sum of the row's virtual-row
-// partials, in the plan's fixed order (home, chunk); one lane per (row, 4 features), 4 loads in flight.
-template <typename T>
+// partials in a fixed order.  One WAVE per row: lane = (slice, 4 features); slice s of the 64 / LPRC adds the
+// partials s, s + slices, ... of the plan's (home, chunk) order with 4 loads in flight, then the slices meet in a
+// fixed butterfly.  (One lane group per row made the launch as long as the longest row's serial walk: RMAT s24's
+// largest row has ~1000 partials, 0.15 ms for a 0.2 GB stream.)
+template <typename T, int LPRC>
 __global__ __launch_bounds__(256) void spmm_vh_combine_kernel(const int32_t *__restrict__ vh_rows,
                                                               const int32_t *__restrict__ part_ptr,
                                                               const int32_t *__restrict__ part_pos, int64_t n_vh,
                                                               const float *__restrict__ partial, int ldp, int F,
                                                               const float *__restrict__ row_scale,
-                                                              T *__restrict__ M, int64_t ldm, int accumulate,
-                                                              int lanes_per_row)
+                                                              T *__restrict__ M, int64_t ldm, int accumulate)
 {
-    const int64_t gt = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    const int64_t r = gt / lanes_per_row;
-    const int f0 = int(gt - r * lanes_per_row) * 4;
-    if (r >= n_vh || f0 >= F) return;
+    constexpr int SLICES = 64 / LPRC;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (r >= n_vh) return;
+    const int sl = lane / LPRC, f0 = (int(blockIdx.y) * LPRC + lane % LPRC) * 4;     // blockIdx.y: rows wider than 256 features
+    const bool fv = f0 < F;
     const int32_t p0 = part_ptr[r], p1 = part_ptr[r + 1];
     const int64_t row = vh_rows[r];
-    const float rs = row_scale ? row_scale[row] : 1.f;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    int32_t k = p0;
-    for (; k + 4 <= p1; k += 4) {
-        float4 v[4];
+    if (fv) {
+        int32_t k = p0 + sl;
+        for (; k + 3 * SLICES < p1; k += 4 * SLICES) {
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            v[u] = *reinterpret_cast<const float4 *>(partial + int64_t(part_pos[k + u]) * ldp + f0);
+            for (int u = 0; u < 4; ++u)
+                v[u] = *reinterpret_cast<const float4 *>(partial + int64_t(part_pos[k + u * SLICES]) * ldp + f0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
+            for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
+        }
+        for (; k < p1; k += SLICES) {
+            const float4 v = *reinterpret_cast<const float4 *>(partial + int64_t(part_pos[k]) * ldp + f0);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
     }
-    for (; k < p1; ++k) {
-        const float4 v = *reinterpret_cast<const float4 *>(partial + int64_t(part_pos[k]) * ldp + f0);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-    }
+#pragma unroll
+    for (int off = LPRC; off < 64; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] += __shfl_xor(s[i], off, 64);
+    if (sl != 0 || !fv) return;
+    const float rs = row_scale ? row_scale[row] : 1.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (f0 + i >= F) break;
@@ -1108,10 +1119,16 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
                                        0, 0, s);
         if (rc) return rc;
         const int lanes_per_row = (f + 3) / 4;
-        const int64_t threads = plan->vh_n_rows * lanes_per_row;
-        hipLaunchKernelGGL((spmm_vh_combine_kernel<T>), dim3(unsigned((threads + 255) / 256)), dim3(256), 0, s,
-                           plan->vh_rows, plan->vh_part_ptr, plan->vh_part_pos, plan->vh_n_rows, pv, ldp, f, rs, m, ldm,
-                           acc_flag, lanes_per_row);
+        const dim3 cgrid(unsigned((plan->vh_n_rows + 3) / 4), unsigned((lanes_per_row + 63) / 64));
+#define GAE_VHC(L)                                                                                                   \
+    hipLaunchKernelGGL((spmm_vh_combine_kernel<T, L>), cgrid, dim3(256), 0, s, plan->vh_rows, plan->vh_part_ptr,      \
+                       plan->vh_part_pos, plan->vh_n_rows, pv, ldp, f, rs, m, ldm, acc_flag)
+        if (lanes_per_row <= 4) GAE_VHC(4);
+        else if (lanes_per_row <= 8) GAE_VHC(8);
+        else if (lanes_per_row <= 16) GAE_VHC(16);
+        else if (lanes_per_row <= 32) GAE_VHC(32);
+        else GAE_VHC(64);
+#undef GAE_VHC
         GAE_CHECK_LAUNCH("spmm_vh_combine_kernel");
     }
     return GAE_OK;

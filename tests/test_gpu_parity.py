@@ -1411,8 +1411,8 @@ def test_spmm_segment_descriptors_match_the_index_chain(dev, tuning):
                 assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_spmm_homed_rows_match_oracle(dtype, dev):
+@pytest.mark.parametrize("dtype,F", [(torch.float32, 40), (torch.bfloat16, 40), (torch.float32, 300)])
+def test_spmm_homed_rows_match_oracle(dtype, F, dev):
     """XCD-pinned ("homed") part of a skew plan: the very long rows are evaluated from virtual rows grouped by the
     home of their columns -- same terms, another summation order: == the plain plan and the fp64 oracle to 1e-5 of
     the scale (fp32), scaled and unscaled, with GAE_SPMM_ACCUMULATE, and the layout invariants of the plan hold"""
@@ -1441,7 +1441,7 @@ def test_spmm_homed_rows_match_oracle(dtype, dev):
     pp, pq = hp["part_ptr"].cpu().numpy(), hp["part_pos"].cpu().numpy()
     assert len(np.unique(pq)) == len(pq) and pp[-1] == len(pq) == (lens > 0).sum()
     deg_t, norm = ops.degree_norm(ip)
-    H = t(rng.standard_normal((n, 40)).astype(np.float32), dev).to(dtype)
+    H = t(rng.standard_normal((n, F)).astype(np.float32), dev).to(dtype)
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     for sc in (None, norm):
         a = ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan)
@@ -1456,7 +1456,7 @@ def test_spmm_homed_rows_match_oracle(dtype, dev):
         scale = float(np.abs(ref).max())
         assert float((a.float() - b.float()).abs().max()) <= tol * scale
         assert float(np.abs(a.float().cpu().numpy() - ref).max()) <= tol * scale
-        base = torch.randn(n, 40, device=dev).to(dtype)
+        base = torch.randn(n, F, device=dev).to(dtype)
         acc = base.clone()
         ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan, out=acc, accumulate=True)
         assert float((acc.float() - (base.float() + a.float())).abs().max()) <= (1e-6 if dtype == torch.float32 else 2e-2) * scale
