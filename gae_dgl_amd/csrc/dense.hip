@@ -25,6 +25,8 @@ thread_local int g_linear_depth = 3;  // "linear_depth": k-steps of loads in fli
 thread_local int g_linear_nw = 0;     // "linear_nw": waves per block of that kernel (0 = 4, 8)
 thread_local int g_linear_f32x16 = 1; // "linear_f32x16": exact-fp32 forward Linear through the 64-byte-piece loader (0 = gemm_stream_kernel)
 thread_local int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
+thread_local int g_gemm_rows = 1;    // "gemm_rows": 0 = never use gemm_rows_kernel, 1 = operands of >= kGemmRowsMinN rows, 2 = wherever it applies
+constexpr int64_t kGemmRowsMinN = 1 << 18;
 thread_local int g_linear_wlds = 1;  // tuning knob: 0 = never use linear_fwd_wlds_kernel, 1 = where measured faster, 2 = wherever it applies
 thread_local int g_linear_bf16 = 0;  // tuning knob: 0 = exact fp32 forward Linear (default: embeddings within 2e-7 of fp64 instead of
                         // 7e-6, tools/encode_error.py), 1 = bf16 x 3 forward where measured faster (Pubmed L1 15.4 -> 13.0 us),
@@ -356,6 +358,116 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Very tall operands with short rows (K <= 64, millions of rows: the RMAT layers 32 -> 32 -> 16, forward and dM):
+// gemm_stream_kernel splits K over the 4 waves of a block, i.e. for K = 32 a block of 256 threads moves 4 KB of A,
+// fetches as many bytes of B again and pays a barrier plus a 16 KB LDS reduction -- 2.9 TB/s on 2^24 rows where a
+// device copy of the same bytes reaches 5.0.  Here a WAVE owns whole 32-row tiles: the B fragments of the whole K
+// range are loaded once per wave and stay in registers over `tiles_per_wave` tiles, A is read with one 16-byte load
+// per lane and k-block (all of a tile's loads issued together, the next tile's before this tile's MFMAs), no LDS, no
+// barrier.  Products are the same exact-fp32 MFMAs; a row's k terms are added in ONE chain in k order (the split
+// form adds four quarter chains): within the tolerance contract, not bit-identical to gemm_stream_kernel.
+// ---------------------------------------------------------------------------
+template <int NT, int KB, bool BT, int PRO_A, bool AVEC>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ Amask, int64_t ldam,
+    const float *__restrict__ B, int64_t ldb, const float *__restrict__ bias, int act, float *__restrict__ out,
+    int64_t ldo, int64_t n, int K, int J, int tiles_per_wave)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int K4 = (K + 3) & ~3;
+    float b[NT][KB][4], bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int j = t * 32 + i;
+        const int jc = j < J ? j : J - 1;
+        bv[t] = (bias && j < J) ? bias[jc] : 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = kb * 8 + 4 * h + q;
+                const int kc = k < K ? k : K - 1;
+                const float v = BT ? B[int64_t(jc) * ldb + kc] : B[int64_t(kc) * ldb + jc];
+                b[t][kb][q] = (k < K && j < J) ? v : 0.f;
+            }
+    }
+    struct Stage { float a[KB][4], m[KB][4]; };
+    auto load = [&](Stage &st, int64_t row0) {
+        const int64_t row = row0 + i;
+        const int64_t rowc = row < n ? row : n - 1;
+        const float *ap = A + rowc * lda;
+        const float *mp = PRO_A != PRO_NONE ? Amask + rowc * ldam : nullptr;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int k = kb * 8 + 4 * h;
+            if (AVEC) {
+                const int kc = k <= K4 - 4 ? k : K4 - 4;
+                const float4 t4 = *reinterpret_cast<const float4 *>(ap + kc);
+                st.a[kb][0] = t4.x; st.a[kb][1] = t4.y; st.a[kb][2] = t4.z; st.a[kb][3] = t4.w;
+                if (PRO_A != PRO_NONE) {
+                    const float4 m4 = *reinterpret_cast<const float4 *>(mp + kc);
+                    st.m[kb][0] = m4.x; st.m[kb][1] = m4.y; st.m[kb][2] = m4.z; st.m[kb][3] = m4.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kq = k + q < K ? k + q : K - 1;
+                    st.a[kb][q] = ap[kq];
+                    if (PRO_A != PRO_NONE) st.m[kb][q] = mp[kq];
+                }
+            }
+        }
+    };
+    auto tile = [&](const Stage &st, int64_t row0) {
+        const bool rv = row0 + i < n;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool kv = kb * 8 + 4 * h + q < K;
+                float av = (rv && kv) ? st.a[kb][q] : 0.f;
+                if (PRO_A == PRO_RELU_MASK) av = st.m[kb][q] > 0.f ? av : 0.f;
+                if (PRO_A == PRO_MUL_MASK) av *= st.m[kb][q];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[t][kb][q], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t orow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (orow < n && col < J) {
+                    float y = acc[t][r] + bv[t];
+                    if (act == GAE_ACT_RELU) y = y > 0.f ? y : 0.f;
+                    out[orow * ldo + col] = y;
+                }
+            }
+        }
+    };
+    const int64_t t0 = (int64_t(blockIdx.x) * 4 + wave) * tiles_per_wave;
+    const int64_t n_tiles = (n + 31) / 32;
+    if (t0 >= n_tiles) return;
+    const int64_t t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
+    Stage s0, s1;
+    load(s0, t0 * 32);
+    for (int64_t tt = t0; tt < t1; tt += 2) {
+        if (tt + 1 < t1) load(s1, (tt + 1) * 32);
+        tile(s0, tt * 32);
+        if (tt + 1 >= t1) break;
+        if (tt + 2 < t1) load(s0, (tt + 2) * 32);
+        tile(s1, (tt + 1) * 32);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Forward Linear with the weight slice in LDS: out[n, J <= 32] = act(A[n, K] W[J, K]^T + b).
 // In gemm_stream_kernel the W fragments are fetched from global memory in the same "32 rows x 32 bytes" pattern as
 // the A fragments, i.e. HALF of the kernel's line requests go to the (L2-resident) 64 KB weight matrix, and line
@@ -671,6 +783,22 @@ int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t 
     bool avec = (lda % 4 == 0) && gae::aligned16(A) && K >= 1;
     if (PRO_A != PRO_NONE) avec = avec && (ldam % 4 == 0) && gae::aligned16(Amask);
     const bool bvec = BT && (ldb % 4 == 0) && gae::aligned16(B) && K >= 4 && (K % 4 == 0);
+    // very tall operands with short rows: a wave owns whole row tiles, B stays in registers (gemm_rows_kernel)
+    if (g_gemm_rows && NT <= 2 && K >= 1 && K <= 64 && n >= (g_gemm_rows > 1 ? 1 : kGemmRowsMinN)) {
+        const int64_t tiles = (n + 31) / 32;
+        int tpw = int(tiles / (int64_t(256) * 4 * 8));       // >= 8 waves per SIMD's worth of tiles before a wave takes two
+        tpw = tpw < 1 ? 1 : tpw > 8 ? 8 : tpw;
+        const dim3 grid(unsigned((tiles + 4 * tpw - 1) / (4 * tpw)));
+#define GAE_GR(KBV, AV)                                                                                            \
+    hipLaunchKernelGGL((gemm_rows_kernel<NT, KBV, BT, PRO_A, AV>), grid, dim3(256), 0, s, A, lda, Amask, ldam, B,  \
+                       ldb, bias, act, out, ldo, n, K, int(J), tpw)
+        const bool av = avec && lda >= ((K + 3) & ~3) && (PRO_A == PRO_NONE || ldam >= ((K + 3) & ~3));
+        if (K <= 32) { if (av) GAE_GR(4, true); else GAE_GR(4, false); }
+        else { if (av) GAE_GR(8, true); else GAE_GR(8, false); }
+#undef GAE_GR
+        GAE_CHECK_LAUNCH("gemm_rows_kernel");
+        return GAE_OK;
+    }
     int splits = split_ws ? gemm_stream_splits(n, K) : 1;
     if (splits > 1 && split_ws_floats < int64_t(splits) * n * J) splits = 1;
     const int kblocks = (K + 7) / 8;
@@ -1336,6 +1464,7 @@ namespace gae {
 int *dense_knob(const char *name)
 {
     if (strcmp(name, "gemm_stream") == 0) return &g_gemm_stream;
+    if (strcmp(name, "gemm_rows") == 0) return &g_gemm_rows;
     if (strcmp(name, "linear_f32x16") == 0) return &g_linear_f32x16;
     if (strcmp(name, "linear_nw") == 0) return &g_linear_nw;
     if (strcmp(name, "linear_depth") == 0) return &g_linear_depth;

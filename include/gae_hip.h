@@ -65,7 +65,7 @@ int gae_device_info_get(int device, gae_device_info *out_host);
  *  - select among kernels with bit-identical results: "spmm_variant", "spmm_rpg", "spmm_nt", "spmm_tile_vecs",
  *    "spmm_ell", "spmm_ell_rpg", "spmm_hot", "spmm_desc", "bce_minw", "bce_strip_store", "bce_fold_mirror";
  *  - change the ORDER in which partial sums are added (results agree within the fp32 tolerance of DESIGN.md
- *    section 6, not bit for bit): "atb_rows", "gemm_stream", "linear_wlds", "linear_f32x16", "linear_nw", "linear_depth", "bce_ri", "bce_sym", "bce_sym_ri",
+ *    section 6, not bit for bit): "atb_rows", "gemm_stream", "gemm_rows", "linear_wlds", "linear_f32x16", "linear_nw", "linear_depth", "bce_ri", "bce_sym", "bce_sym_ri",
  *    "bce_sym_grid", "bce_sym_tiles", "bce_grid"; a skew
  *    plan (gae_spmm_plan with heavy rows) and GAE_SPMM_ACCUMULATE do the same for the rows they touch;
  *  - select the ARITHMETIC of matrix-core products: "bce_s_bf16" / "bce_pv_bf16" / "atb_bf16" (1 = bf16 x 3 split

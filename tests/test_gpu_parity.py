@@ -549,6 +549,48 @@ def test_linear_fuzz(seed, dev):
         assert rel_err(bd.grad, bt.grad) < 5 * TOL
 
 
+@pytest.mark.parametrize("n,fin,fout,mode", [(1, 32, 32, 0), (33, 32, 16, 0), (1000, 39, 32, 1), (777, 64, 64, 0),
+                                             (4100, 16, 32, 2), (513, 7, 5, 2), (300000, 32, 32, 0),
+                                             (262144 + 17, 32, 16, 0)])
+def test_linear_short_rows_wave_per_tile(n, fin, fout, mode, dev, tuning):
+    """gemm_rows_kernel (f_in <= 64: a wave owns whole 32-row tiles, the weights stay in registers): forced on
+    every shape it accepts (knob gemm_rows = 2; padded, odd and aligned leading dimensions), on its default shapes
+    (>= 2^18 rows), forward with bias + ReLU and the masked dM of the backward, against fp64 and against
+    gemm_stream_kernel"""
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(n + fin + fout)
+    M = rng.standard_normal((n, fin)).astype(np.float32)
+    W = (rng.standard_normal((fout, fin)) / np.sqrt(fin)).astype(np.float32)
+    b = rng.standard_normal(fout).astype(np.float32)
+    dY = rng.standard_normal((n, fout)).astype(np.float32)
+    Mt = torch.tensor(M, dtype=torch.float64, requires_grad=True)
+    Wt = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    pre = Mt @ Wt.t() + bt
+    # millions of pre-activations: a few lie within fp32 rounding of 0, where the ReLU mask of an fp32 kernel may
+    # differ from fp64's -- no gradient flows into those elements in this test
+    dY[(pre.detach().abs() < 1e-4).numpy()] = 0.0
+    Yref = torch.relu(pre)
+    Yref.backward(torch.tensor(dY, dtype=torch.float64))
+    Md = t(M, dev)
+    if mode == 1:
+        Md = ops.pad_rows(Md)
+    elif mode == 2:
+        Md = torch.cat([Md, torch.full((n, 5), 9.0, device=dev)], dim=1)[:, :fin]
+    res = {}
+    for knob in (2, 0, 1):
+        tuning("gemm_rows", knob)
+        Mg = Md.detach().requires_grad_(True)
+        Wd = t(W, dev).requires_grad_(True); bd = t(b, dev).requires_grad_(True)
+        Y = ops.linear(Mg, Wd, bd, 1)
+        Y.backward(t(dY, dev))
+        res[knob] = (Y.detach(), Mg.grad)
+        assert rel_err(Y, Yref) < TOL and rel_err(Mg.grad, Mt.grad) < 5 * TOL
+        assert rel_err(Wd.grad, Wt.grad) < 5 * TOL and rel_err(bd.grad, bt.grad) < 5 * TOL
+    assert rel_err(res[2][0], res[0][0].double().cpu()) < TOL and rel_err(res[2][1], res[0][1].double().cpu()) < TOL
+    assert torch.equal(res[1][0], res[2 if n >= (1 << 18) else 0][0])        # default: only very tall operands
+
+
 def test_linear_odd_ld_and_no_bias(dev):
     from gae_dgl_amd import ops
     M = torch.randn(70, 45, device=dev)[:, :39]  # ld 45: scalar staging path
