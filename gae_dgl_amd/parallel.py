@@ -44,10 +44,11 @@ def block_bounds(n, world):
 
 # Cost of one row of a block in units of one edge (a row's in- and out-edges count 1 each).  Measured, RMAT s24 on 8
 # virtual ranks, compute of one encoder step without the collectives (tools/r02/rmat_rank_step.py): a row costs what
-# ~16 edge visits cost (its share of the dense layers, the activations and the products' outputs: ~1.5 KB of HBM
-# traffic per step).  Slowest rank 7.56 ms at cost 1 (7.1 M rows of the tail), 5.78 at 8, 4.48 at 16, 3.64 at 32 (the
-# mean is 3.41); the hub-owning ranks receive more boundary rows the higher the cost (rank 0: 0.92 -> 1.12 GB per
-# step from 1 to 32), so 16 and not the compute-only optimum.
+# 16-24 edge visits cost (its share of the dense layers, the activations and the products' outputs: ~1.5 KB of HBM
+# traffic per step).  Slowest rank 7.56 ms at cost 1 (7.1 M rows of the tail; kernels of that day), with today's
+# kernels 4.84 ms at 8, 4.20 at 12, 3.76 at 16, 3.30 at 24 (the mean is 2.97); the hub-owning ranks receive more
+# boundary rows the higher the cost (rank 0: 0.92 -> 1.08 GB per step from 1 to 24), which at ~300 GB/s of
+# all-to-all bandwidth evens the ranks out around 16.
 ROW_COST = 16
 
 
