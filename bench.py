@@ -667,15 +667,16 @@ def main():
     if world > 1 and workload == "rmat":
         # the N = 1 default of this script is the Pubmed step (BASELINE configs[1]); the same row-sharded RMAT
         # workload on ONE GPU was measured with `--gpus 1 --workload rmat` and filed under profiles/
-        try:
-            ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                              "r01_bench_rmat_s24_1gpu.json")))
+        here = os.path.dirname(os.path.abspath(__file__))
+        for name in ("r02_bench_rmat_s24_1gpu.json", "r01_bench_rmat_s24_1gpu.json"):     # newest filed run first
+            try:
+                ref = json.load(open(os.path.join(here, "profiles", name)))
+            except Exception:
+                continue
             if ref["config"].get("n_nodes") == wl.meta.get("n_nodes"):
                 line["same_workload_1gpu"] = {"value": ref["value"], "ms_per_step": ref["ms_per_step"],
-                                              "speedup": value / ref["value"],
-                                              "source": "profiles/r01_bench_rmat_s24_1gpu.json"}
-        except Exception:
-            pass
+                                              "speedup": value / ref["value"], "source": "profiles/" + name}
+                break
     if world == 1 and hasattr(wl, "loss_launch"):
         # ---- the step's DOMINANT launch: fused decoder + weighted BCE (loss + dZ), VALU / transcendental bound
         t_loss = time_launches(wl.loss_launch(), iters=20, warmup=5)

@@ -17,6 +17,7 @@ for w in pubmed cora zinc; do
   timeout 600 tools/prof_bench.sh $TAG/prof_$w --workload $w --steps 30 --warmup 3 > $O/${w}_step_kernel_stats_top.txt
 done
 timeout 600 tools/prof_bench.sh $TAG/prof_zinc128 --workload zinc --batch-graphs 128 --steps 200 --warmup 20 > $O/zinc128_step_kernel_stats_top.txt
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 timeout 900 tools/prof_bench.sh $TAG/prof_rmat --workload rmat --steps 5 --warmup 2 --no-cpu-baseline > $O/rmat_step_kernel_stats_top.txt
 export PMC_SETS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
 export PMC_FILTER=spmm
 for sh in pubmed500 pubmed32 cora1433 citeseer3703 zincb39 zinc32 zinc39; do

@@ -37,7 +37,7 @@ for name in ("pubmed", "cora", "citeseer", "zinc", "zinc128", "zinc_eager", "zin
     if os.path.exists(p):
         benches[name] = last_json(p)
         json.dump(benches[name], open(os.path.join(DST, f"{TAG}_bench_{name}.json"), "w"), indent=1)
-for w in ("pubmed", "cora", "zinc", "zinc128"):
+for w in ("pubmed", "cora", "zinc", "zinc128", "rmat"):
     st = os.path.join(SRC, f"prof_{w}", "bench_kernel_stats.csv")
     if os.path.exists(st):
         shutil.copy(st, os.path.join(DST, f"{TAG}_{w}_step_kernel_stats.csv"))
