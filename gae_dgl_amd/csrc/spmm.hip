@@ -484,6 +484,7 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const int32_t *__restric
 // tuning knobs (gae_tuning_set): read-mostly process-wide integers
 thread_local int g_spmm_variant = 2;   // 1 = v1 rowgroup, 2 = v2 rowgroup2
 thread_local int g_spmm_rpg = 0;       // rows per lane group (v2): 0 = auto (2 for launches of >= 32768 waves, else 1), 1, 2
+thread_local int g_spmm_parts = 7;     // "spmm_parts" (experiments): which parts of a skew-plan launch run: 1 light rows | 2 segmented rows | 4 pinned rows
 thread_local int g_spmm_desc = 1;      // "spmm_desc": segment descriptors / identity segments (1) or the plan's index chain (0); bit-identical
 thread_local int g_spmm_hot = 1;       // "spmm_hot": use the plan's hot-column tags (streaming loads of cold rows); 0 = plain loads
 thread_local int g_spmm_nt = -1;       // store policy of M (v2): -1 = auto (sc1 under feature tiles, else nt), 0 plain, 1 non-temporal, 2 write-through sc1
@@ -1081,8 +1082,9 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
     const bool homed = plan && plan->vh_n_virtual > 0;
     const int skip = (heavy || homed) ? plan->threshold : 0x7fffffff;
     const int min_f = vec ? (sizeof(T) == 4 ? 12 : 24) : 3;
-    int rc;
-    if (g_spmm_variant == 2 && f > min_f)
+    int rc = GAE_OK;
+    if ((heavy || homed) && !(g_spmm_parts & 1)) {
+    } else if (g_spmm_variant == 2 && f > min_f)
         rc = dispatch_rowgroup2<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, g_spmm_rpg,
                                         g_spmm_nt, n_cols, skip, flags,
                                         (plan && g_spmm_ell) ? plan->ell : nullptr, plan ? plan->ell_width : 0, s);
@@ -1095,7 +1097,7 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
     float *partial = static_cast<float *>(workspace);
     const int ldp = plan_ldp(f);
     const int acc_flag = (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0;
-    if (heavy) {
+    if (heavy && (g_spmm_parts & 2)) {
         rc = dispatch_segments<T, VEC>(indptr, indices, h, ldh, f, cs, plan, partial, ldp, rs, m, ldm, acc_flag, 1, s);
         if (rc) return rc;
         const int lanes_per_row = (f + 3) / 4;
@@ -1105,7 +1107,7 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
                            m, ldm, acc_flag, lanes_per_row);
         GAE_CHECK_LAUNCH("spmm_combine_kernel");
     }
-    if (homed) {
+    if (homed && (g_spmm_parts & 4)) {
         // XCD-pinned rows: the plan's virtual CSR (one virtual row = one segment = one (row, home, chunk) group of
         // column ids; position p is gathered by block p / 4, i.e. on XCD (p / 4) % 8 = the home of its columns) goes
         // through the same segment kernel into float partials, which are then added per real row in plan order
@@ -1399,7 +1401,7 @@ int *find_knob(const char *name)
     const struct { const char *k; int *v; } knobs[] = {
         {"spmm_variant", &g_spmm_variant}, {"spmm_rpg", &g_spmm_rpg}, {"spmm_nt", &g_spmm_nt},
         {"spmm_tile_vecs", &g_spmm_tile_vecs}, {"spmm_ell", &g_spmm_ell}, {"spmm_hot", &g_spmm_hot},
-        {"spmm_desc", &g_spmm_desc}};
+        {"spmm_desc", &g_spmm_desc}, {"spmm_parts", &g_spmm_parts}};
     for (const auto &kv : knobs)
         if (strcmp(kv.k, name) == 0) return kv.v;
     if (int *k = gae::spmm_ell_knob(name)) return k;

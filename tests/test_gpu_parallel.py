@@ -83,6 +83,51 @@ def test_virtual_ranks_overlap_form(world, mode):
         first = (out, grad)
 
 
+@pytest.mark.parametrize("mode,overlap", [("boundary", True), ("allgather", False)])
+def test_virtual_ranks_rmat_shards_with_pinned_rows(mode, overlap):
+    """RMAT s22 (2^26 edges) on 2 virtual ranks: every rank's structure is large enough for the XCD-pinned part of
+    the skew plan (>= ops.HOMED_MIN_EDGES edges in rows of > 256), with hot-column tags and segment descriptors --
+    the plans bench.py --gpus N builds.  Forward and backward rows == the single-GPU product without a pinned part to
+    1e-5 of the scale (another summation order for the long rows), deterministic."""
+    from gae_dgl_amd import ops, workloads as W
+    from gae_dgl_amd.parallel import LocalGroup, ShardedGraph
+    scale, world, F = 22, 2, 32
+    n = 1 << scale
+    src, dst = W.rmat_edges(scale, 16, seed=0, device=DEV)
+    X = torch.rand(n, F, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    dM = torch.randn(n, F, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    ip, ix = ops.csr_from_coo(dst, src, n, n)
+    ref = ops.spmm_raw(ip, ix, X, n, plan=ops.spmm_plan(ip, threshold=ops.SKEW_THRESHOLD, indices=ix, ell=False,
+                                                        n_cols=n, homed=False))
+    del ip, ix
+    tp, tx = ops.csr_from_coo(src, dst, n, n)
+    refb = ops.spmm_raw(tp, tx, dM, n, plan=ops.spmm_plan(tp, threshold=ops.SKEW_THRESHOLD, indices=tx, ell=False,
+                                                         n_cols=n, homed=False))
+    del tp, tx
+    grp = LocalGroup(world)
+    pinned = 0
+    for trial in range(2):
+        outs, grads = [], []
+        for r in range(world):
+            sg = ShardedGraph(n, src, dst, rank=r, group=grp, mode=mode, device=DEV, balance="nnz", overlap=overlap)
+            p = sg.part
+            h = X[p.r0:p.r1].clone().requires_grad_(True)
+            grp.publish(X)
+            m = sg.spmm(h)
+            grp.publish(dM)
+            m.backward(dM[p.r0:p.r1])
+            outs.append(m.detach()); grads.append(h.grad)
+            pinned += sum(pl.homed is not None for pl in sg._plan.values())
+            del sg
+        out, grad = torch.cat(outs), torch.cat(grads)
+        assert float((out - ref).abs().max() / ref.abs().max()) < 1e-5
+        assert float((grad - refb).abs().max() / refb.abs().max()) < 1e-5
+        if trial:
+            assert torch.equal(out, first[0]) and torch.equal(grad, first[1])
+        first = (out, grad)
+    assert pinned > 0           # the case this test is about
+
+
 def test_spmm_accumulate_flag():
     """GAE_SPMM_ACCUMULATE: out += A H for every kernel family that takes it (row-group, v1, segment plan), scaled
     and unscaled, fp32 and bf16 storage"""
