@@ -332,6 +332,106 @@ class CitationWorkload:
                           f"{torch.get_num_threads()} threads, host cpu_count={os.cpu_count()})"}
 
 
+class VgaeWorkload(CitationWorkload):
+    """BASELINE config 5: VGAE (mu / log sigma heads, sampled Z Z^T decoder, BCE + KL) on Citeseer with bf16 feature
+    storage (fp32 accumulation everywhere)"""
+
+    def __init__(self, args, dev):
+        import gae_dgl_amd as G
+        from gae_dgl_amd import ops, workloads as W
+        from gae_dgl_amd.vgae import VGAE
+        self.args, self.dev = args, dev
+        n, src, dst, X = W.citation_graph("citeseer", seed=0)
+        self.n, self.src, self.dst, self.X = n, src, dst, X
+        self.F_in, self.hidden = X.shape[1], [32, 16]
+        torch.manual_seed(0)
+        self.model = VGAE(self.F_in, self.hidden, seed=11).to(dev)
+        self.use_graph = not args.no_hipgraph
+        self.opt, opt_name = make_adam(self.model.parameters(), 1e-2, args, self.use_graph)
+        self.g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+        self.Xd = ops.pad_rows(torch.from_numpy(X).to(dev).to(torch.bfloat16))     # rows of whole 128-byte lines
+        self.g.csr(); self.g.csc(); self.g.spmm_plan(False); self.g.spmm_plan(True); self.g.scattered()
+        E = self.g.number_of_edges()
+        self.edges_per_step = E * 5        # A X, A H (mu), A H (log sigma) forward; A^T dM of the two heads backward
+        self.meta = {"workload": "citeseer-vgae-bf16-features", "n_nodes": n, "n_edges": E, "in_dim": self.F_in,
+                     "hidden_dims": self.hidden, "heads": "mu, log sigma (identity GCN heads on the shared ReLU layer)",
+                     "loss": "fused BCE (sampled z) + KL", "optimizer": "adam lr=1e-2: " + opt_name,
+                     "parallelism": "1 GPU",
+                     "launch": "hipGraph replay of the captured step (the noise draw advances a device counter)"
+                               if self.use_graph else "eager",
+                     "feature_storage": "bf16 X (layer-1 aggregation: bf16 rows, fp32 accumulate, bf16 M); "
+                                        "everything after the first Linear in fp32"}
+        self.captured = None
+        self.dominant = ("spmm", n, n, self.F_in, "torch.bfloat16")
+        self.dominant_desc = f"spmm F={self.F_in}, bf16 storage (layer-1 aggregation A*X, {n} rows, {E} edges)"
+        self.alg_bytes = W.spmm_alg_bytes(n, n, E, self.F_in, 2)
+        self.pmc_key = ""
+        self.scaling = "weak"
+        self.dtype = "bf16 storage, f32 arithmetic"
+        self._params = list(self.model.parameters())
+
+    def dominant_launch(self):
+        from gae_dgl_amd import ops
+        ip, ix = self.g.csr()
+        out = ops.pad_rows(torch.empty(self.Xd.shape, dtype=self.Xd.dtype, device=self.dev))
+        plan = self.g.spmm_plan(False)
+        sc = self.Xd.shape[1] > ops.TILE_MIN_F and self.g.scattered(self.Xd.shape[1] * 2)
+        return lambda: ops.spmm_raw(ip, ix, self.Xd, self.n, out=out, plan=plan, out_padded=True, scattered=sc)
+
+    def capture(self):
+        from gae_dgl_amd.capture import CapturedTrainStep
+        # tensors of the last eager step (model.last, the z left in ndata) keep that step's autograd graph alive,
+        # and its AccumulateGrad nodes are bound to the eager stream: drop them before the capture
+        self.model.last = {}
+        self.g.ndata['h'] = self.Xd
+        self.opt.zero_grad(set_to_none=True)
+        self.captured = CapturedTrainStep(self.model, self.opt, self.g, self.Xd, loss_fn=lambda m, g: m.loss(g))
+
+    loss_launch = None
+
+    def step(self):
+        if self.captured is not None:
+            return self.captured()
+        from gae_dgl_amd import ops
+        self.g.ndata['h'] = self.Xd
+        loss = self.model.loss(self.g)
+        self.opt.zero_grad(); ops.backward(loss, self._params); self.opt.step()
+        self.model.last = {}
+        return loss.detach()
+
+    def cpu_baseline(self, seconds):
+        """the oracle's VGAE restatement (oracle/gae_oracle.py:vgae_forward + vgae_kl, dense N x N BCE) forward and
+        backward on the host cores, same sizes"""
+        from oracle import gae_oracle as O
+        Xo = torch.from_numpy(self.X)
+        P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in self.model.named_parameters()}
+        ip, ix = O.csr_from_coo(self.src, self.dst, self.n)
+        adj = O.dense_adjacency(self.src, self.dst, self.n)
+        pw = O.pos_weight_of(adj)
+        eps = torch.randn(self.n, self.hidden[-1])
+
+        def one():
+            mu, ls, z = O.vgae_forward(ip, ix, Xo, P["shared.apply_mod.linear.weight"], P["shared.apply_mod.linear.bias"],
+                                       P["mu_head.apply_mod.linear.weight"], P["mu_head.apply_mod.linear.bias"],
+                                       P["logstd_head.apply_mod.linear.weight"], P["logstd_head.apply_mod.linear.bias"],
+                                       eps)
+            loss = O.bce_with_logits_mean(z @ z.t(), adj, pw) + O.vgae_kl(mu, ls)
+            for v in P.values():
+                v.grad = None
+            loss.backward()
+        one()
+        t0 = time.perf_counter(); k = 0
+        while True:
+            one(); k += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or k >= 50:
+                break
+        return {"value": self.edges_per_step * k / el, "unit": "edges/s", "cores": torch.get_num_threads(),
+                "kind": "port", "ms_per_step": el / k * 1e3,
+                "sample": f"{k} forward + backward passes of the same VGAE step by oracle/gae_oracle.py (fp32, dense "
+                          f"N x N BCE, no optimizer update; torch CPU, {torch.get_num_threads()} threads)"}
+
+
 class ZincWorkload:
     """inductive step, batch of B molecules gathered on the device (train_inductive.py:31-53)"""
 
@@ -563,6 +663,8 @@ def main():
         wl = RmatShardedWorkload(args, dev, rank, world, group)
     elif workload == "zinc":
         wl = ZincWorkload(args, dev)
+    elif workload == "vgae":
+        wl = VgaeWorkload(args, dev)
     else:
         wl = CitationWorkload(workload, args, dev)
 
@@ -633,7 +735,7 @@ def main():
     line = {
         "metric": "edges aggregated/sec (SpMM fwd+bwd)", "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": getattr(wl, "dtype", "f32"), "data": "synthetic",
         "config": wl.meta,
         "epoch_time_s": elapsed / args.steps * (wl.meta.get("batches_per_epoch_at_239455_graphs", 1)),
         "spmm_only": {"edges_per_s": wl.edges_per_step / max(world, 1) * args.steps / spmm_t if spmm_t else None,
@@ -677,7 +779,7 @@ def main():
                 line["same_workload_1gpu"] = {"value": ref["value"], "ms_per_step": ref["ms_per_step"],
                                               "speedup": value / ref["value"], "source": "profiles/" + name}
                 break
-    if world == 1 and hasattr(wl, "loss_launch"):
+    if world == 1 and getattr(wl, "loss_launch", None) is not None:
         # ---- the step's DOMINANT launch: fused decoder + weighted BCE (loss + dZ), VALU / transcendental bound
         t_loss = time_launches(wl.loss_launch(), iters=20, warmup=5)
         n = wl.n

@@ -58,7 +58,7 @@ class NodeApplyModule(nn.Module):
     def forward(self, node):
         feats = node.data['h']
         if feats.dtype != torch.float32:  # bf16-stored features: aggregation ran in bf16 storage / fp32 accumulate
-            feats = feats.float()
+            feats = ops.float_rows(feats) if feats.is_cuda and feats.dim() == 2 else feats.float()
         fused = _act_code(self.activation)
         out = ops.linear(feats, self.linear.weight, self.linear.bias, ACT_IDENTITY if fused is None else fused)
         return {'h': out if fused is not None else self.activation(out)}

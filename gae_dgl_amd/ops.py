@@ -76,6 +76,20 @@ def pad_rows(t, multiple=None):
     return buf[:, :f]
 
 
+def float_rows(t):
+    """fp32 copy of a bf16-stored [N, F] operand in a row-padded buffer (see pad_rows): the Linear and dW kernels
+    that read it next then take their aligned 16-byte paths (a plain ``.float()`` of F = 3703 has rows of 14812
+    bytes: scalar loads; Citeseer VGAE layer-1 Linear 31 -> 22.5 us, dW 37.9 -> 14.9 us)"""
+    n, f = t.shape
+    ld = padded_ld(f, torch.float32)
+    buf = torch.empty(n, ld, dtype=torch.float32, device=t.device)
+    if ld > f:
+        buf[:, f:].zero_()
+    out = buf[:, :f]
+    out.copy_(t)
+    return out
+
+
 def _rowmajor(t, name):
     """(tensor, ld) with unit inner stride; copies only when needed."""
     _gpu(t, name)

@@ -8,6 +8,8 @@ mkdir -p $O
 cd $R
 timeout 900 python bench.py > $O/bench_pubmed.json 2> $O/bench_pubmed.err
 for w in cora citeseer zinc; do timeout 600 python bench.py --workload $w --no-extra 2>/dev/null | tail -1 > $O/bench_$w.json; done
+# BASELINE config 5: VGAE on Citeseer, bf16 feature storage
+timeout 600 python bench.py --workload vgae --no-extra 2>/dev/null | tail -1 > $O/bench_vgae.json
 timeout 600 python bench.py --workload zinc --batch-graphs 128 --steps 300 --warmup 30 --no-extra 2>/dev/null | tail -1 > $O/bench_zinc128.json
 # the same inductive steps launched eagerly (no captured step): what the HIP graph buys
 timeout 600 python bench.py --workload zinc --no-hipgraph --no-extra --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_zinc_eager.json

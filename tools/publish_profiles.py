@@ -32,7 +32,7 @@ def pmc_means(d):
 
 
 benches = {}
-for name in ("pubmed", "cora", "citeseer", "zinc", "zinc128", "zinc_eager", "zinc128_eager", "rmat_s24_1gpu"):
+for name in ("pubmed", "cora", "citeseer", "vgae", "zinc", "zinc128", "zinc_eager", "zinc128_eager", "rmat_s24_1gpu"):
     p = os.path.join(SRC, f"bench_{name}.json")
     if os.path.exists(p):
         benches[name] = last_json(p)
