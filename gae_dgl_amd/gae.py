@@ -89,7 +89,7 @@ class GCN(nn.Module):
     def _forward_transform_first(self, g, feature):
         lin, act = self.apply_mod.linear, self.apply_mod.activation
         if feature.dtype != torch.float32:
-            feature = feature.float()
+            feature = ops.float_rows(feature) if feature.is_cuda and feature.dim() == 2 else feature.float()
         g.ndata['h'] = ops.linear(feature, lin.weight, None, ACT_IDENTITY)        # H W^T
         g.update_all(gcn_msg, gcn_reduce, norm=self.norm)                         # A (H W^T)
         fused = _act_code(act)
