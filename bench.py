@@ -90,6 +90,9 @@ def parse():
                          "backward.  auto = transform-first when the graph is sharded over more than one GPU (two of "
                          "the three exchanges per step halve), aggregate-first on one GPU (RMAT s24: 29.2 vs 29.6 ms "
                          "-- the gather is bound by the number of random row fetches, not their size)")
+    ap.add_argument("--no-cache-input-exchange", action="store_true",
+                    help="rmat, N > 1: exchange the remote rows of the constant input features X in every step "
+                         "(default: once -- X does not change between steps, only its product A X is recomputed)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="rmat: exchange, then one SpMM over the assembled rows (bit-identical to one GPU) instead of "
                          "the default own-column SpMM under the exchange + accumulated remote-column SpMM")
@@ -514,6 +517,7 @@ class RmatShardedWorkload:
         self.sg = ShardedGraph(n, src, dst, rank=rank, world=world, group=group, mode=args.exchange, device=dev,
                                balance=args.balance, overlap=self.overlap)
         del src, dst
+        self.sg.cache_constant_inputs = not args.no_cache_input_exchange
         p = self.sg.part
         e_local = int(p.fwd_rows.numel())
         for w in ("fwd", "bwd"):
@@ -541,8 +545,12 @@ class RmatShardedWorkload:
                      "overlap": "own-column SpMM under the exchange, then M += remote-column SpMM" if self.overlap
                                 else "exchange, then one SpMM (bit-identical to one GPU)",
                      "exchange_bytes_per_spmm_per_rank": self.sg.exchange_bytes(F),
-                     "exchange_bytes_per_step_per_rank": (self.sg.exchange_bytes(F) + 2 * self.sg.exchange_bytes(16))
-                     if self.transform_first else 3 * self.sg.exchange_bytes(F),
+                     "exchange_bytes_per_step_per_rank":
+                         ((0 if self.sg.cache_constant_inputs else 1) * self.sg.exchange_bytes(F)
+                          + 2 * self.sg.exchange_bytes(16 if self.transform_first else F)),
+                     "input_exchange": "the remote rows of the constant input features X travel once, before the "
+                                       "timed steps (inputs resident); A X itself is evaluated in every step"
+                                       if self.sg.cache_constant_inputs else "every step",
                      "decoder": "excluded (O(N^2) = 2.8e14 logits at N = 2^24); synthetic dZ",
                      "layer_order": "(A H) W^T for every layer (gae.py:26-31)" if not self.transform_first else
                                     "32 -> 32 layer: (A H) W^T; 32 -> 16 layer: A (H W^T), aggregation and exchange at "

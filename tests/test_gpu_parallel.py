@@ -128,6 +128,44 @@ def test_virtual_ranks_rmat_shards_with_pinned_rows(mode, overlap):
     assert pinned > 0           # the case this test is about
 
 
+@pytest.mark.parametrize("mode,overlap", [("boundary", True), ("boundary", False), ("allgather", True)])
+def test_constant_input_exchange_is_cached(mode, overlap):
+    """ShardedGraph.cache_constant_inputs: the forward product of an operand that needs no gradient (the input
+    features of a transductive graph) exchanges its remote rows once and reuses them while the same tensor comes
+    back unchanged; operands that need a gradient, changed tensors (in-place edit: version counter) and the backward
+    always exchange.  Results are bit-identical with and without the cache."""
+    from gae_dgl_amd.parallel import LocalGroup, ShardedGraph
+    n, src, dst, X = graph()
+    world = 3
+    grp = LocalGroup(world)
+    grp.publish(X)
+    for r in range(world):
+        sg = ShardedGraph(n, src, dst, rank=r, group=grp, mode=mode, device=DEV, balance="nnz", overlap=overlap)
+        p = sg.part
+        x = X[p.r0:p.r1].clone()
+        ref = sg.spmm(x)
+        sg.cache_constant_inputs = True
+        sg.timers = {}
+        name = "exchange_start" if overlap else "exchange"
+        outs = [sg.spmm(x) for _ in range(3)]
+        assert len(sg.timers.get(name, [])) == 1                      # one exchange for three products
+        assert all(torch.equal(o, ref) for o in outs)
+        h = x.clone().requires_grad_(True)                            # needs a gradient: never cached
+        m = sg.spmm(h)
+        assert len(sg.timers[name]) == 2 and torch.equal(m.detach(), ref)
+        grp.publish(torch.randn_like(X))
+        m.backward(grp.full[p.r0:p.r1])                               # the backward exchanges
+        assert len(sg.timers[name]) == 3
+        X2 = X.clone(); X2[p.r0:p.r1] *= 2.0
+        grp.publish(X2)
+        x.mul_(2.0)                                                   # same storage, new version: exchanged again
+        o2 = sg.spmm(x)
+        assert len(sg.timers[name]) == 4
+        sg.cache_constant_inputs = False
+        assert torch.equal(o2, sg.spmm(x))
+        grp.publish(X)
+
+
 def test_spmm_accumulate_flag():
     """GAE_SPMM_ACCUMULATE: out += A H for every kernel family that takes it (row-group, v1, segment plan), scaled
     and unscaled, fp32 and bf16 storage"""
