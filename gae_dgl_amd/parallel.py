@@ -47,8 +47,9 @@ def block_bounds(n, world):
 # 16-24 edge visits cost (its share of the dense layers, the activations and the products' outputs: ~1.5 KB of HBM
 # traffic per step).  Slowest rank 7.56 ms at cost 1 (7.1 M rows of the tail; kernels of that day), with today's
 # kernels 4.84 ms at 8, 4.20 at 12, 3.76 at 16, 3.30 at 24 (the mean is 2.97); the hub-owning ranks receive more
-# boundary rows the higher the cost (rank 0: 0.92 -> 1.08 GB per step from 1 to 24), which at ~300 GB/s of
-# all-to-all bandwidth evens the ranks out around 16.
+# boundary rows the higher the cost (rank 0: 0.92 -> 1.08 GB per step from 1 to 24 when X is sent every step, half
+# of that with cache_constant_inputs), which at 150-300 GB/s of all-to-all bandwidth evens the ranks out between 16
+# and 24.
 ROW_COST = 16
 
 
