@@ -426,6 +426,9 @@ HOMED_MIN_EDGES = 1 << 24    # ... when they hold at least this many edges toget
 HOMED_HOT_COLUMNS = 1 << 20  # hot tags of the pinned part (RMAT s24: 128 k 5.66 ms, 256 k 5.36, 512 k 5.19, 1 M 5.06, 2 M+ 5.08)
 
 
+HOMED_COLUMN_SWEEP = True    # order the pinned chunks of a home by their first column (see homed_plan_parts)
+
+
 def column_home(cols):
     """XCD (0..7) through whose L2 a column is gathered in the pinned part of a plan: a multiplicative hash (the low
     bits of the hub ids of an R-MAT graph are all zero: ``col % 8`` would put 44 % of the edges on one XCD)"""
@@ -473,8 +476,13 @@ def homed_plan_parts(indptr, indices, n_cols, min_degree=None, segment=None, hot
     # position of every virtual row: per home, 4 consecutive positions per thread block, blocks interleaved over XCDs
     rank_in_home = torch.empty_like(vg)
     L = 0
+    v_first = cols[v_e0.clamp(max=max(E - 1, 0))] if HOMED_COLUMN_SWEEP else None
     for h in range(8):
         m = torch.nonzero(v_home == h).flatten()
+        if HOMED_COLUMN_SWEEP:
+            # launch order inside a home = ascending first column of the chunk: the chunks of the very long rows that
+            # run at the same time then cover the same stretch of the column space and share its rows in the home's L2
+            m = m[torch.argsort(v_first[m], stable=True)]
         rank_in_home[m] = torch.arange(m.numel(), device=dev)
         L = max(L, int(m.numel()))
     L = (L + 3) // 4 * 4

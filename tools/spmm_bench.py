@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--hot-cols", type=int, default=0, help="ops.HOT_COLUMNS for the rmat plan (0 = default)")
     ap.add_argument("--homed-deg", type=int, default=0, help="ops.HOMED_MIN_DEGREE (0 = default)")
     ap.add_argument("--homed-hot", type=int, default=0, help="ops.HOMED_HOT_COLUMNS (0 = default)")
+    ap.add_argument("--homed-sweep", type=int, default=-1, help="ops.HOMED_COLUMN_SWEEP (0 / 1; -1 = default)")
     ap.add_argument("--thr", type=int, default=64)
     ap.add_argument("--seg", type=int, default=512)
     ap.add_argument("--variants", default="v1:1:0,v2:1:0,v2:2:0,v2:1:1,v2:2:1")
@@ -54,6 +55,8 @@ def main():
         ops.HOMED_MIN_DEGREE = args.homed_deg
     if args.homed_hot:
         ops.HOMED_HOT_COLUMNS = args.homed_hot
+    if args.homed_sweep >= 0:
+        ops.HOMED_COLUMN_SWEEP = bool(args.homed_sweep)
     for kv in filter(None, args.knobs.split(",")):
         k, v = kv.split("=")
         knob(k, int(v))
