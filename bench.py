@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the GCN-encoder hot path on MI355X (metric / configs: BASELINE.json).
 
-  python bench.py --gpus 1 --steps K --warmup W [--workload pubmed|cora|citeseer|zinc|rmat]
+  python bench.py --gpus N --steps K --warmup W [--workload pubmed|cora|citeseer|zinc|vgae|rmat]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Started without a launcher (no WORLD_SIZE in the environment), `--gpus N` with N > 1 starts its N ranks itself (one
+process per GPU, re-executed under torch.distributed.run) and exits with code 2 when fewer than N GPUs are visible;
+under a launcher, WORLD_SIZE must equal --gpus.  `n_gpus` in the line is the size of the live process group.
 
 A "step" is one pass of the hot path over one batch of synthetic input:
 
@@ -638,20 +642,140 @@ def extras(dev):
     return out
 
 
+class MockWorkload:
+    """host-logic stand-in (tests/test_bench_launch_cpu.py): runs on the CPU over gloo so that the launcher, the
+    process group, the timed regions and the JSON line can be exercised without a GPU.  Never a bench result."""
+
+    def __init__(self, args, rank, world, group):
+        import torch.distributed as dist
+        self.dist, self.group, self.world = dist, group, world
+        self.t = torch.ones(16) * (rank + 1)
+        self.edges_per_step = 1000 * world
+        self.meta = {"workload": "mock (launcher self-test, CPU/gloo; not a measurement)", "parallelism": f"x{world}"}
+        self.scaling = "weak"
+
+    def step(self):
+        t = self.t.clone()
+        if self.world > 1:
+            self.dist.all_reduce(t, group=self.group)
+        return t
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks here, one
+    process per GPU, by re-executing this script under torch.distributed.run (the way the driver launches N > 1).
+    Refuses -- exit code 2, nothing measured -- when fewer than N GPUs are visible."""
+    import subprocess
+    n = args.gpus
+    if args.workload != "mock":
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n}: only {have} GPU(s) visible on this box; refusing to report a {n}-GPU number "
+                  f"from fewer devices", file=sys.stderr, flush=True)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def timed_regions(wl, args, barrier, world, dev, min_total_s=0.5, max_regions=200):
+    """The contract's timed region -- EXACTLY --steps steps between barrier + synchronize on both sides, MAX over
+    ranks -- repeated until the regions add up to >= min_total_s (a 20-step region of a 0.25 ms step is 5 ms: clock
+    ramp and scheduling noise).  Returns the per-region seconds (the same list on every rank)."""
+    import torch.distributed as dist
+    out = []
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt)
+        out.append(el)
+        if sum(out) >= min_total_s or len(out) >= max_regions:      # same decision on every rank (max-reduced times)
+            return out
+
+
+def region_stats(regions, steps):
+    ms = np.asarray(regions) / steps * 1e3
+    return {"regions": len(regions), "steps_per_region": steps, "ms_per_step_median": float(np.median(ms)),
+            "ms_per_step_min": float(ms.min()), "ms_per_step_max": float(ms.max()),
+            "ms_per_step_first_region": float(ms[0]),
+            "note": "every region is the contract's timed region (barrier + synchronize, exactly --steps steps, max "
+                    "over ranks); regions are repeated until they add up to >= 0.5 s; `ms_per_step` / `value` are "
+                    "the median region"}
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    workload = args.workload or ("pubmed" if world == 1 else "rmat")
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing (the line "
+              f"would carry the wrong n_gpus)", file=sys.stderr, flush=True)
+        sys.exit(2)
+    mock = args.workload == "mock"
     import torch.distributed as dist
+    if mock:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+            print(f"[bench] rank {rank}: needs GPU {local_rank}, {torch.cuda.device_count()} visible (bench.py "
+                  f"measures MI355X GPUs only)", file=sys.stderr, flush=True)
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    workload = args.workload or ("pubmed" if world == 1 else "rmat")
     group = None
     if world > 1 or workload == "rmat":
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # long timeout: after the N-rank regions rank 0 times the same workload on ONE GPU while the others wait
+        dist.init_process_group("gloo" if mock else "nccl", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(minutes=60))
+    n_gpus = dist.get_world_size() if dist.is_initialized() else 1       # from the LIVE process group
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        if not mock:
+            torch.cuda.synchronize()
+
+    if mock:
+        wl = MockWorkload(args, rank, world, group)
+        for _ in range(args.warmup):
+            wl.step()
+        regions = timed_regions(wl, args, barrier, world, dev, min_total_s=0.05, max_regions=5)
+        elapsed = float(np.median(regions))
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "edges aggregated/sec (SpMM fwd+bwd)",
+                              "value": wl.edges_per_step * args.steps / elapsed, "unit": "edges/s", "n_gpus": n_gpus,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": "f32",
+                              "data": "synthetic", "config": wl.meta, "timing": region_stats(regions, args.steps)}),
+                  flush=True)
+        return
+
     if args.knobs:
         from gae_dgl_amd import _lib
         for kv in args.knobs.split(","):
@@ -668,7 +792,10 @@ def main():
     from gae_dgl_amd import ops
 
     if workload == "rmat":
+        t_build0 = time.perf_counter()
         wl = RmatShardedWorkload(args, dev, rank, world, group)
+        torch.cuda.synchronize()
+        wl.meta["workload_build_s"] = time.perf_counter() - t_build0
     elif workload == "zinc":
         wl = ZincWorkload(args, dev)
     elif workload == "vgae":
@@ -676,18 +803,13 @@ def main():
     else:
         wl = CitationWorkload(workload, args, dev)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     graphed = getattr(wl, "use_graph", False)
+    prof = ops.EventProfiler()
     if graphed:
         # Events cannot be recorded inside a graph replay: the per-kernel HIP-event timings come from an eager
-        # pass of the SAME steps right before the capture; the timed region then replays the captured graph.
+        # pass of the SAME steps right before the capture; the timed regions then replay the captured graph.
         for _ in range(args.warmup):
             wl.step()
-        prof = ops.EventProfiler()
         ops.profiler = prof
         torch.cuda.synchronize()
         for _ in range(args.steps):
@@ -695,25 +817,39 @@ def main():
         torch.cuda.synchronize()
         ops.profiler = None
         wl.capture()
-    else:
-        prof = ops.EventProfiler()
     for _ in range(args.warmup):
         wl.step()
     if not graphed:
+        # eager workloads: HIP-event pairs around the SpMM launches of one extra pass of --steps steps (recording
+        # events costs host time; the timed regions run without them)
         ops.profiler = prof
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ops.profiler = None
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
+        barrier()
+        for _ in range(args.steps):
+            wl.step()
+        barrier()
+        ops.profiler = None
+    regions = timed_regions(wl, args, barrier, world, dev)
+    elapsed = float(np.median(regions))
     dom_fn = wl.dominant_launch() if hasattr(wl, "dominant_launch") else None   # may contain a collective
     comm = wl.comm_profile() if hasattr(wl, "comm_profile") else None              # collective: every rank
+    one_gpu = None
+    if world > 1 and workload == "rmat":
+        # the SAME workload on ONE GPU, timed in this invocation: rank 0 builds the whole graph on its GPU (in a
+        # 1-rank group) while the other ranks wait at the closing barrier
+        g1 = dist.new_group(ranks=[0])
+        if rank == 0:
+            torch.cuda.empty_cache()
+            w1 = RmatShardedWorkload(args, dev, 0, 1, g1)
+            for _ in range(max(2, min(args.warmup, 5))):
+                w1.step()
+            r1 = timed_regions(w1, args, torch.cuda.synchronize, 1, dev)
+            e1 = float(np.median(r1))
+            one_gpu = {"value": w1.edges_per_step * args.steps / e1, "ms_per_step": e1 / args.steps * 1e3,
+                       "timing": region_stats(r1, args.steps),
+                       "source": "same invocation: rank 0 alone on the whole graph (1-rank process group, same "
+                                 "kernels and plans), timed after the N-rank regions"}
+            del w1
+            torch.cuda.empty_cache()
     if rank != 0:
         if dist.is_initialized():
             dist.barrier()
@@ -742,7 +878,7 @@ def main():
     value = wl.edges_per_step * args.steps / elapsed
     line = {
         "metric": "edges aggregated/sec (SpMM fwd+bwd)", "value": value, "unit": "edges/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": getattr(wl, "dtype", "f32"), "data": "synthetic",
         "config": wl.meta,
         "epoch_time_s": elapsed / args.steps * (wl.meta.get("batches_per_epoch_at_239455_graphs", 1)),
@@ -774,19 +910,10 @@ def main():
             "note": "rank-0 HIP-event times over 5 extra steps outside the timed region; exchange_wait is what the "
                     "own-column SpMM did not hide; SpMM-only edges/s assumes every rank takes as long as rank 0 "
                     "(nnz-balanced blocks)"}
-    if world > 1 and workload == "rmat":
-        # the N = 1 default of this script is the Pubmed step (BASELINE configs[1]); the same row-sharded RMAT
-        # workload on ONE GPU was measured with `--gpus 1 --workload rmat` and filed under profiles/
-        here = os.path.dirname(os.path.abspath(__file__))
-        for name in ("r02_bench_rmat_s24_1gpu.json", "r01_bench_rmat_s24_1gpu.json"):     # newest filed run first
-            try:
-                ref = json.load(open(os.path.join(here, "profiles", name)))
-            except Exception:
-                continue
-            if ref["config"].get("n_nodes") == wl.meta.get("n_nodes"):
-                line["same_workload_1gpu"] = {"value": ref["value"], "ms_per_step": ref["ms_per_step"],
-                                              "speedup": value / ref["value"], "source": "profiles/" + name}
-                break
+    line["timing"] = region_stats(regions, args.steps)
+    if one_gpu is not None:
+        one_gpu["speedup"] = value / one_gpu["value"]
+        line["same_workload_1gpu"] = one_gpu
     if world == 1 and getattr(wl, "loss_launch", None) is not None:
         # ---- the step's DOMINANT launch: fused decoder + weighted BCE (loss + dZ), VALU / transcendental bound
         t_loss = time_launches(wl.loss_launch(), iters=20, warmup=5)
@@ -825,6 +952,7 @@ def main():
                     wl.step()
                 torch.cuda.synchronize()
                 line["ms_per_step_exact_fp32"] = (time.perf_counter() - t1) / args.steps * 1e3
+                line["value_exact_fp32"] = wl.edges_per_step / (line["ms_per_step_exact_fp32"] * 1e-3)
             finally:
                 for k in knobs:
                     _lib.call("gae_tuning_set", k, 1)

@@ -1,0 +1,52 @@
+"""bench.py's launcher logic on the CPU: `--gpus N` without a launcher starts N ranks itself, `n_gpus` comes from
+the live process group, a box with fewer GPUs than asked for is refused, and a launcher whose WORLD_SIZE disagrees
+with --gpus is refused.  The workload is bench.py's `mock` (gloo, CPU tensors): only the host logic is under test."""
+import json
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(argv, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + argv, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def test_gpus2_spawns_two_ranks():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "mock"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["config"]["parallelism"] == "x2"
+    assert line["timing"]["regions"] >= 1 and line["timing"]["steps_per_region"] == 3
+
+
+def test_gpus1_runs_in_process():
+    r = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--workload", "mock"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1
+
+
+def test_more_gpus_than_visible_is_refused():
+    """the default (real) workloads: asking for more GPUs than the box has must fail loudly, not report N = 1"""
+    n = torch.cuda.device_count() + 1
+    r = _run(["--gpus", str(max(n, 2)), "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 2
+    assert "refusing" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_world_size_mismatch_is_refused():
+    r = _run(["--gpus", "4", "--steps", "1", "--warmup", "0", "--workload", "mock"],
+             env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "refusing" in r.stderr

@@ -1,8 +1,13 @@
 """Entry points: the drop-in training scripts run end to end on the GPU and
 the device batcher reproduces dgl.batch semantics bit for bit."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -250,3 +255,16 @@ def test_transductive_eval_learns_communities(tmp_path):
     TT.main(["--dataset", "cora", "--data_root", str(tmp_path / "data"), "-e", "150", "-s", str(tmp_path), "--seed", "0",
              "--eval", "--log_every", "1000"])
     assert TT.main.last_eval["auc"] > 0.8 and TT.main.last_eval["ap"] > 0.75
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`bench.py --gpus N` on a box with fewer than N GPUs exits non-zero and prints no JSON line (it used to time
+    the 1-GPU step and report it)"""
+    import json
+    import subprocess
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 2 and "refusing" in r.stderr
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
