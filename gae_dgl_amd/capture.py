@@ -118,6 +118,7 @@ class CapturedInductiveStep:
         self.graph = None
         self.captures = 0
         self._order = None
+        self._done = self._n_full = 0
 
     # ---------------------------------------------------------------- static buffers
     def _allocate(self, cap_nodes, cap_edges):
@@ -126,7 +127,7 @@ class CapturedInductiveStep:
         self.cap_nodes, self.cap_edges = cap_nodes, cap_edges
         self.gids = torch.zeros(B, dtype=torch.int64, device=dev)
         self.ptrs = torch.zeros(2 if ds.symmetric else 3, B + 1, dtype=torch.int64, device=dev)
-        self.counts = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.counts = torch.zeros(3, dtype=torch.int64, device=dev)   # {nodes, edges, graphs dropped by the guard}
         F, ldo, odt = ops.batch_feature_ld(ds.feat, ds.n_feat)
         ip = torch.zeros(cap_nodes + 1, dtype=torch.int32, device=dev)
         ix = torch.zeros(cap_edges, dtype=torch.int32, device=dev)
@@ -176,48 +177,52 @@ class CapturedInductiveStep:
 
     # ---------------------------------------------------------------- capture
     def _state(self):
-        """tensors a warm-up step changes: parameters, optimiser state, device-side counters"""
-        ts = [p.data for p in self.model.parameters()]
-        for st in self.opt.state.values():
-            ts += [v for v in st.values() if isinstance(v, torch.Tensor)]
-        ts += list(getattr(self.opt, "_counters", {}).values())
-        ts += [m._draws for m in self.model.modules() if getattr(m, "_draws", None) is not None]
+        """name -> tensor of everything a warm-up step changes: parameters, optimiser state, device-side counters.
+        Keyed, not positional: a warm-up step may CREATE tensors (lazy optimiser state after a load_state_dict,
+        the decoder's draw counter), so the lists before and after differ in length and order."""
+        ts = {f"param/{k}": p.data for k, p in self.model.named_parameters()}
+        for i, (p, st) in enumerate(self.opt.state.items()):
+            pid = next((k for k, q in self.model.named_parameters() if q is p), f"#{i}")
+            for name, v in st.items():
+                if isinstance(v, torch.Tensor):
+                    ts[f"opt/{pid}/{name}"] = v
+        for key, c in getattr(self.opt, "_counters", {}).items():
+            ts[("counter",) + tuple(key)] = c
+        for k, m in self.model.named_modules():
+            if getattr(m, "_draws", None) is not None:
+                ts[f"draws/{k}"] = m._draws
         return ts
 
-    def _capture(self, cap_nodes, cap_edges):
+    def _capture(self, cap_nodes, cap_edges, warm_batch=0):
+        """``warm_batch``: index of a FULL batch of the uploaded order that is known to fit the capacities; every
+        warm-up step runs on it (the cursor is put back in front of it each time).  Warm-up steps must not walk on:
+        the batch behind the last full one is the ragged tail padded with a repeated graph and was never checked
+        against the capacities (the kernel's own guard would drop graphs, see gae_batch_gather)."""
         self.graph = None
         self._allocate(cap_nodes, cap_edges)
-        # the warm-up steps (allocator, lazy optimiser state, autograd streams) must not train the model: run one to
-        # create every lazily-built tensor, snapshot, run the rest, restore
+        # the warm-up steps (allocator, lazy optimiser state, autograd streams) must not train the model: snapshot
+        # every tensor they change BY NAME, run them, restore; tensors the warm-up created get their start values
         gc.collect()       # autograd graphs of earlier eager steps that only a collection frees keep AccumulateGrad
         #                    nodes bound to the default stream, which would invalidate the capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            had_state = len(self.opt.state) > 0 or len(getattr(self.opt, "_counters", {})) > 0
-            before = [t.clone() for t in self._state()] if had_state else None
-            params0 = [p.detach().clone() for p in self.model.parameters()]
-            draws0 = {id(m): (None if getattr(m, "_draws", None) is None else m._draws.clone())
-                      for m in self.model.modules() if hasattr(m, "_draws")}
+            before = {k: t.clone() for k, t in self._state().items()}
+            resume = getattr(self.opt, "_resume_steps", None) or []
             for _ in range(max(self.warmup, 1)):
+                self.cursor.fill_(int(warm_batch))
                 self.opt.zero_grad(set_to_none=True)
                 self._step_body()
-            if had_state:
-                for t, b in zip(self._state(), before):
-                    t.copy_(b)
-            else:                                   # first use: optimiser state was created by the warm-up -> zero it
-                for st in self.opt.state.values():
-                    for v in st.values():
-                        if isinstance(v, torch.Tensor):
-                            v.zero_()
-                for c in getattr(self.opt, "_counters", {}).values():
-                    c.zero_()
-                for p, p0 in zip(self.model.parameters(), params0):
-                    p.data.copy_(p0)
-                for m in self.model.modules():
-                    if getattr(m, "_draws", None) is not None:
-                        d0 = draws0.get(id(m))
-                        m._draws.zero_() if d0 is None else m._draws.copy_(d0)
+            for k, t in self._state().items():
+                if k in before:
+                    t.copy_(before[k])
+                elif isinstance(k, tuple):          # step counter created by the warm-up: back to the resume point
+                    t.zero_()                       # (word 0 = steps taken; zeros elsewhere = no cached beta^t)
+                    if k[1] < len(resume):
+                        t[0] = int(resume[k[1]])
+                else:                               # lazily created optimiser moments, a new draw counter
+                    t.zero_()
+            self.counts.zero_()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
@@ -251,16 +256,19 @@ class CapturedInductiveStep:
                 # round the capacities up (whole row blocks of the kernels, headroom for later epochs)
                 cap_n = max(-(-int(need_n * self.margin) // 64) * 64, self.cap_nodes)
                 cap_e = max(-(-int(need_e * self.margin) // 256) * 256, self.cap_edges, 1)
-                self.d_order[:len(order)].copy_(torch.from_numpy(order))   # the warm-up steps read it
-                self.cursor.zero_()
-                self._capture(cap_n, cap_e)
+                self.d_order[:len(order)].copy_(torch.from_numpy(order))   # the warm-up steps read batch 0 of it
+                self._capture(cap_n, cap_e, warm_batch=0)
         self.d_order[:len(order)].copy_(torch.from_numpy(order))
         self.cursor.zero_()
-        self._done = 0
+        self.counts.zero_()
+        self._done, self._n_full = 0, n_full
         return n_full
 
     def step(self):
         """next full batch of the epoch: one graph launch; returns the static loss tensor of this replay"""
+        if self._done >= self._n_full:
+            raise ops.GaeHipError("CapturedInductiveStep.step: no full batch left in this epoch (begin_epoch() "
+                                  "returns their number; the ragged tail goes through tail_step())")
         if self._hyper() != self._captured_hyper:
             self._recapture()
         self.graph.replay()
@@ -268,9 +276,15 @@ class CapturedInductiveStep:
         return self.loss
 
     def _recapture(self):
-        cur = self.cursor.clone()
-        self._capture(self.cap_nodes, self.cap_edges)
-        self.cursor.copy_(cur)
+        """same capacities, new hyper-parameters (a learning-rate scheduler stepping per batch): the warm-up runs
+        on the batch that comes next -- a full, validated batch, because step() checked that one is left"""
+        self._capture(self.cap_nodes, self.cap_edges, warm_batch=self._done)
+        self.cursor.fill_(self._done)
+
+    def dropped_graphs(self):
+        """graphs the device-side guard of gae_batch_gather left out since begin_epoch() (host read-back; 0 unless the
+        buffers were too small for a batch -- a bug in the capacity bookkeeping, never silent: epoch() raises)"""
+        return int(self.counts[2].item())
 
     def tail_step(self):
         """the ragged last batch (len(order) % batch_size graphs), eagerly; None when the epoch has no tail"""
@@ -290,11 +304,14 @@ class CapturedInductiveStep:
         n_full = self.begin_epoch(order)
         for _ in range(n_full):
             yield self.step()
+        if n_full and self.dropped_graphs():
+            raise ops.GaeHipError(f"CapturedInductiveStep: {self.dropped_graphs()} graphs did not fit the static "
+                                  f"batch buffers ({self.cap_nodes} rows / {self.cap_edges} edges) and were left out")
         tail = self.tail_step()
         if tail is not None:
             yield tail
 
     def batch_sizes(self):
         """true (nodes, edges) of the batch the last replay trained on (host read-back; debugging / tests)"""
-        n, e = self.counts.tolist()
+        n, e = self.counts[:2].tolist()
         return int(n), int(e)

@@ -4,9 +4,21 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "gae_hip.h"
 
 namespace gae {
+
+// Tuning knob (gae_tuning_set / gae_tuning_get): ONE value per process, read with relaxed atomics at launch time.
+// Process-wide on purpose: PyTorch runs the backward of an autograd Function on its engine's worker thread, so a
+// per-thread value set from Python would not reach the launches of backward() (the dW and A^T products).
+struct Knob {
+    std::atomic<int> v;
+    explicit constexpr Knob(int x) : v(x) {}
+    operator int() const { return v.load(std::memory_order_relaxed); }
+    Knob &operator=(int x) { v.store(x, std::memory_order_relaxed); return *this; }
+};
 
 // thread-local last-error message (defined in api.hip)
 void set_error(const char *fmt, ...);

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
     const int64_t *__restrict__ graph_ids, int64_t n_graphs, const int64_t *__restrict__ out_node_ptr,
     const int64_t *__restrict__ out_edge_ptr, int32_t *__restrict__ out_indptr,
     int32_t *__restrict__ out_indices, TO *__restrict__ out_feat, int64_t ld_out, int32_t *__restrict__ out_ell,
-    int ell_width, int64_t cap_nodes, int64_t *__restrict__ out_counts)
+    int ell_width, int64_t cap_nodes, int64_t cap_edges, int64_t *__restrict__ out_counts)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t b = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
@@ -237,10 +237,26 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
         //      into isolated zero-feature nodes -- empty CSR rows, zero features, an empty table row -- so that a
         //      captured HIP graph can run every batch on the same shapes; the true sizes go to out_counts
         if (cap_nodes <= 0) return;
-        const int64_t nb = out_node_ptr[n_graphs], eb = out_edge_ptr[n_graphs];
+        // Device-side guard: the host sized the buffers from the batches it knew about; a batch that does not fit
+        // (a replay past the validated batches, a stale order) must never write behind them.  Only the longest
+        // prefix of graphs that fits is gathered (the graph waves below test the same condition), the rest of the
+        // buffers becomes padding and the number of dropped graphs is ADDED to out_counts[2] for the host to see.
+        int64_t keep = n_graphs;
+        if (out_node_ptr[n_graphs] > cap_nodes || out_edge_ptr[n_graphs] > cap_edges) {
+            int64_t lo = 0, hi = n_graphs;                   // largest k with node_ptr[k] / edge_ptr[k] inside
+            while (lo < hi) {
+                const int64_t mid = (lo + hi + 1) >> 1;
+                if (out_node_ptr[mid] <= cap_nodes && out_edge_ptr[mid] <= cap_edges) lo = mid; else hi = mid - 1;
+            }
+            keep = lo;
+        }
+        const int64_t nb = out_node_ptr[keep], eb = out_edge_ptr[keep];
         const int64_t n_pad_waves = (int64_t(gridDim.x) * blockDim.x) / kWave - n_graphs;
         const int64_t w = b - n_graphs;
-        if (w == 0 && lane == 0 && out_counts) { out_counts[0] = nb; out_counts[1] = eb; }
+        if (w == 0 && lane == 0) {
+            out_indptr[nb] = int32_t(eb);                    // closes the last kept graph (or opens an empty batch)
+            if (out_counts) { out_counts[0] = nb; out_counts[1] = eb; out_counts[2] += n_graphs - keep; }
+        }
         for (int64_t i = nb + w; i < cap_nodes; i += n_pad_waves) {
             if (lane == 0) out_indptr[i + 1] = int32_t(eb);
             if (out_ell)
@@ -255,6 +271,7 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
     const int64_t on = out_node_ptr[b], oe = out_edge_ptr[b];
     const int32_t e0 = ds_indptr[n0], e1 = ds_indptr[n1];
     const int64_t nn = n1 - n0;
+    if (cap_nodes > 0 && (on + nn > cap_nodes || oe + (e1 - e0) > cap_edges)) return;   // see the guard above
     for (int64_t i = lane; i < nn; i += kWave)
         out_indptr[on + i] = int32_t(ds_indptr[n0 + i] - e0 + oe);
     if (b == n_graphs - 1 && lane == 0) out_indptr[on + nn] = int32_t(oe + (e1 - e0));
@@ -502,7 +519,7 @@ extern "C" int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indp
     hipLaunchKernelGGL((batch_gather_kernel<TI, TO>), dim3(unsigned(blocks)), dim3(256), 0, s, graph_ptr, ds_indptr,  \
                        ds_indices, static_cast<const TI *>(ds_feat), ld_feat, F, graph_ids, n_graphs, out_node_ptr,  \
                        out_edge_ptr, out_indptr, out_indices, static_cast<TO *>(out_feat), ld_out, out_ell,          \
-                       int(ell_width), cap_nodes, out_counts)
+                       int(ell_width), cap_nodes, n_batch_edges, out_counts)
     if (dtype == GAE_F32) GAE_BG(float, float);
     else if (dtype == GAE_BF16) GAE_BG(unsigned short, unsigned short);
     else GAE_BG(unsigned char, float);

@@ -48,19 +48,19 @@ constexpr int TJ = 64;   // columns staged per iteration
 constexpr int PREP_ROWS = 64;    // rows per block of the prepare kernel
 // tuning knobs (gae_tuning_set): "bce_ri" 16-row subtiles per wave (rows / block = 64 RI), "bce_minw" min
 // waves per SIMD hint, "bce_s_bf16" 1 = bf16x3 S product, 0 = exact fp32 S product
-thread_local int g_bce_ri = 2;
-thread_local int g_bce_minw = 0;
-thread_local int g_bce_s_bf16 = 1;
-thread_local int g_bce_grid = 2048;       // "bce_grid": target size of the (row block, column split) grid of the full-square kernel
+gae::Knob g_bce_ri{2};
+gae::Knob g_bce_minw{0};
+gae::Knob g_bce_s_bf16{1};
+gae::Knob g_bce_grid{2048};       // "bce_grid": target size of the (row block, column split) grid of the full-square kernel
 constexpr int kChipCus = 256;             // MI355X: the launch-shape heuristics below are written for this part
-thread_local int g_bce_strip_store = -1;  // "bce_strip_store": -1 auto (non-temporal from 32 k rows on: GBs of strips, 2.93 -> 2.88 ms on a ZINC
+gae::Knob g_bce_strip_store{-1};  // "bce_strip_store": -1 auto (non-temporal from 32 k rows on: GBs of strips, 2.93 -> 2.88 ms on a ZINC
                                           // batch; plain below: Pubmed 170 vs 174 us), 0 plain, 1 non-temporal, 2 write-through
-thread_local int g_bce_fold_mirror = 1;   // "bce_fold_mirror": 1 = the edge kernel folds the mirror strips (no separate reduction launch)
-thread_local int g_bce_sym_tiles = 0;     // "bce_sym_tiles": 64-column tiles per block of the symmetric kernel (0 = auto)
-thread_local int g_bce_sym_grid = 16384;  // "bce_sym_grid": target size of the (panel, chunk) grid of the symmetric kernel
+gae::Knob g_bce_fold_mirror{1};   // "bce_fold_mirror": 1 = the edge kernel folds the mirror strips (no separate reduction launch)
+gae::Knob g_bce_sym_tiles{0};     // "bce_sym_tiles": 64-column tiles per block of the symmetric kernel (0 = auto)
+gae::Knob g_bce_sym_grid{16384};  // "bce_sym_grid": target size of the (panel, chunk) grid of the symmetric kernel
                              // (many short blocks even out the triangular work: ZINC batch 3.64 -> 3.35 ms)
-thread_local int g_bce_sym = 1;       // "bce_sym": 1 = symmetric dense kernel for full-square launches with d <= 16
-thread_local int g_bce_pv_bf16 = 1;   // "bce_pv_bf16": 1 = bf16x3 for O' += P V as well (P split on the fly), 0 = exact fp32
+gae::Knob g_bce_sym{1};       // "bce_sym": 1 = symmetric dense kernel for full-square launches with d <= 16
+gae::Knob g_bce_pv_bf16{1};   // "bce_pv_bf16": 1 = bf16x3 for O' += P V as well (P split on the fly), 0 = exact fp32
 
 __device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
 {
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
 // (2 waves per SIMD): they pay from ~32 k rows on (ZINC batch of 95 k rows: 3.00 -> 2.92 ms; Pubmed, 20 k rows:
 // 185 -> 194 us).  With the K = 32 fragments the fully unrolled 256-row body spilled 43 VGPRs (3.48 ms); its
 // column-pair loop is therefore left rolled (238 VGPRs, no spill).
-thread_local int g_bce_sym_ri = 0;
+gae::Knob g_bce_sym_ri{0};
 
 // the upper 16 bits of four fp32 values (exact when they are bf16 values): one v_perm_b32 per pair
 __device__ __forceinline__ s16x4 upper_halves(const f32x4 &d)
@@ -1224,7 +1224,7 @@ int launch_edges(const BcePlan &p, const float *Zt, const float *mask, int64_t l
 } // namespace
 
 namespace gae {
-int *bce_knob(const char *name)
+Knob *bce_knob(const char *name)
 {
     if (strcmp(name, "bce_ri") == 0) return &g_bce_ri;
     if (strcmp(name, "bce_minw") == 0) return &g_bce_minw;

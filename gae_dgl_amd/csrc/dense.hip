@@ -21,18 +21,18 @@ using gae::kWave;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { PRO_NONE = 0, PRO_RELU_MASK = 1, PRO_MUL_MASK = 2 };
-thread_local int g_linear_depth = 3;  // "linear_depth": k-steps of loads in flight + 1 in that kernel (3, 4, 5)
-thread_local int g_linear_nw = 0;     // "linear_nw": waves per block of that kernel (0 = 4, 8)
-thread_local int g_linear_f32x16 = 1; // "linear_f32x16": exact-fp32 forward Linear through the 64-byte-piece loader (0 = gemm_stream_kernel)
-thread_local int g_gemm_stream = 1;  // tuning knob: 0 = LDS-tiled kernel for every shape
-thread_local int g_gemm_rows = 1;    // "gemm_rows": 0 = never use gemm_rows_kernel, 1 = operands of >= kGemmRowsMinN rows, 2 = wherever it applies
+gae::Knob g_linear_depth{3};  // "linear_depth": k-steps of loads in flight + 1 in that kernel (3, 4, 5)
+gae::Knob g_linear_nw{0};     // "linear_nw": waves per block of that kernel (0 = 4, 8)
+gae::Knob g_linear_f32x16{1}; // "linear_f32x16": exact-fp32 forward Linear through the 64-byte-piece loader (0 = gemm_stream_kernel)
+gae::Knob g_gemm_stream{1};  // tuning knob: 0 = LDS-tiled kernel for every shape
+gae::Knob g_gemm_rows{1};    // "gemm_rows": 0 = never use gemm_rows_kernel, 1 = operands of >= kGemmRowsMinN rows, 2 = wherever it applies
 constexpr int64_t kGemmRowsMinN = 1 << 18;
-thread_local int g_linear_wlds = 1;  // tuning knob: 0 = never use linear_fwd_wlds_kernel, 1 = where measured faster, 2 = wherever it applies
-thread_local int g_linear_bf16 = 0;  // tuning knob: 0 = exact fp32 forward Linear (default: embeddings within 2e-7 of fp64 instead of
+gae::Knob g_linear_wlds{1};  // tuning knob: 0 = never use linear_fwd_wlds_kernel, 1 = where measured faster, 2 = wherever it applies
+gae::Knob g_linear_bf16{0};  // tuning knob: 0 = exact fp32 forward Linear (default: embeddings within 2e-7 of fp64 instead of
                         // 7e-6, tools/encode_error.py), 1 = bf16 x 3 forward where measured faster (Pubmed L1 15.4 -> 13.0 us),
                         // 2 = wherever it applies
-thread_local int g_atb_bf16 = 1;     // tuning knob: 1 = bf16 x 3 matrix-core products in the dW kernel where the layout allows
-thread_local int g_atb_rows = 0;     // tuning knob: rows per block (= per partial) of the dW kernel; 0 = auto (atb_plan)
+gae::Knob g_atb_bf16{1};     // tuning knob: 1 = bf16 x 3 matrix-core products in the dW kernel where the layout allows
+gae::Knob g_atb_rows{0};     // tuning knob: rows per block (= per partial) of the dW kernel; 0 = auto (atb_plan)
 
 // ---------------------------------------------------------------------------
 // out[n, J] = epi( proA(A)[n, K] * proB(B) )      B given as [J, K] (BT) or [K, J]
@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(256) void vgae_head_bwd_kernel(const float *__restr
 } // namespace
 
 namespace gae {
-int *dense_knob(const char *name)
+Knob *dense_knob(const char *name)
 {
     if (strcmp(name, "gemm_stream") == 0) return &g_gemm_stream;
     if (strcmp(name, "gemm_rows") == 0) return &g_gemm_rows;

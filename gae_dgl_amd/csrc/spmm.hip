@@ -26,7 +26,7 @@ int spmm_ell_launch(const int32_t *indptr, const int32_t *indices, const int32_t
                     int64_t n_cols, const void *H, int64_t ldh, void *M, int64_t ldm, int F, int dtype,
                     const float *rs, const float *cs, int tile_vecs, int xcd_tiled, int store_pad, int store_mode,
                     hipStream_t s);
-int *spmm_ell_knob(const char *name);
+Knob *spmm_ell_knob(const char *name);
 }
 
 namespace {
@@ -482,14 +482,14 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const int32_t *__restric
 }
 
 // tuning knobs (gae_tuning_set): read-mostly process-wide integers
-thread_local int g_spmm_variant = 2;   // 1 = v1 rowgroup, 2 = v2 rowgroup2
-thread_local int g_spmm_rpg = 0;       // rows per lane group (v2): 0 = auto (2 for launches of >= 32768 waves, else 1), 1, 2
-thread_local int g_spmm_parts = 7;     // "spmm_parts" (experiments): which parts of a skew-plan launch run: 1 light rows | 2 segmented rows | 4 pinned rows
-thread_local int g_spmm_desc = 1;      // "spmm_desc": segment descriptors / identity segments (1) or the plan's index chain (0); bit-identical
-thread_local int g_spmm_hot = 1;       // "spmm_hot": use the plan's hot-column tags (streaming loads of cold rows); 0 = plain loads
-thread_local int g_spmm_nt = -1;       // store policy of M (v2): -1 = auto (sc1 under feature tiles, else nt), 0 plain, 1 non-temporal, 2 write-through sc1
-thread_local int g_spmm_tile_vecs = 0; // 16-byte vectors per XCD feature tile: 0 = auto when GAE_SPMM_TILE is set, -1 = never, > 0 = forced
-thread_local int g_spmm_ell = 1;       // the plan's packed neighbour table: 0 = ignore it, 1 = spmm_ell.hip kernels (row-group
+gae::Knob g_spmm_variant{2};   // 1 = v1 rowgroup, 2 = v2 rowgroup2
+gae::Knob g_spmm_rpg{0};       // rows per lane group (v2): 0 = auto (2 for launches of >= 32768 waves, else 1), 1, 2
+gae::Knob g_spmm_parts{7};     // "spmm_parts" (experiments): which parts of a skew-plan launch run: 1 light rows | 2 segmented rows | 4 pinned rows
+gae::Knob g_spmm_desc{1};      // "spmm_desc": segment descriptors / identity segments (1) or the plan's index chain (0); bit-identical
+gae::Knob g_spmm_hot{1};       // "spmm_hot": use the plan's hot-column tags (streaming loads of cold rows); 0 = plain loads
+gae::Knob g_spmm_nt{-1};       // store policy of M (v2): -1 = auto (sc1 under feature tiles, else nt), 0 plain, 1 non-temporal, 2 write-through sc1
+gae::Knob g_spmm_tile_vecs{0}; // 16-byte vectors per XCD feature tile: 0 = auto when GAE_SPMM_TILE is set, -1 = never, > 0 = forced
+gae::Knob g_spmm_ell{1};       // the plan's packed neighbour table: 0 = ignore it, 1 = spmm_ell.hip kernels (row-group
                           // kernel when they cannot run the launch), 2 = row-group kernel only
 
 constexpr int kEllWidth = 16;
@@ -1393,19 +1393,19 @@ extern "C" int gae_spmm_tag_hot(const int32_t *indices, int64_t n_edges, const i
     return GAE_OK;
 }
 
-namespace gae { int *dense_knob(const char *name); int *bce_knob(const char *name); }
+namespace gae { Knob *dense_knob(const char *name); Knob *bce_knob(const char *name); }
 
 namespace {
-int *find_knob(const char *name)
+gae::Knob *find_knob(const char *name)
 {
-    const struct { const char *k; int *v; } knobs[] = {
+    const struct { const char *k; gae::Knob *v; } knobs[] = {
         {"spmm_variant", &g_spmm_variant}, {"spmm_rpg", &g_spmm_rpg}, {"spmm_nt", &g_spmm_nt},
         {"spmm_tile_vecs", &g_spmm_tile_vecs}, {"spmm_ell", &g_spmm_ell}, {"spmm_hot", &g_spmm_hot},
         {"spmm_desc", &g_spmm_desc}, {"spmm_parts", &g_spmm_parts}};
     for (const auto &kv : knobs)
         if (strcmp(kv.k, name) == 0) return kv.v;
-    if (int *k = gae::spmm_ell_knob(name)) return k;
-    if (int *k = gae::dense_knob(name)) return k;
+    if (gae::Knob *k = gae::spmm_ell_knob(name)) return k;
+    if (gae::Knob *k = gae::dense_knob(name)) return k;
     return gae::bce_knob(name);
 }
 } // namespace
@@ -1413,7 +1413,7 @@ int *find_knob(const char *name)
 extern "C" int gae_tuning_set(const char *name, int64_t value)
 {
     GAE_REQUIRE(name != nullptr, GAE_E_NULL, "gae_tuning_set: name is NULL");
-    int *k = find_knob(name);
+    gae::Knob *k = find_knob(name);
     GAE_REQUIRE(k != nullptr, GAE_E_RANGE, "gae_tuning_set: unknown knob '%s'", name);
     *k = int(value);
     return GAE_OK;
@@ -1422,8 +1422,8 @@ extern "C" int gae_tuning_set(const char *name, int64_t value)
 extern "C" int gae_tuning_get(const char *name, int64_t *value_out)
 {
     GAE_REQUIRE(name != nullptr && value_out != nullptr, GAE_E_NULL, "gae_tuning_get: NULL argument");
-    const int *k = find_knob(name);
+    const gae::Knob *k = find_knob(name);
     GAE_REQUIRE(k != nullptr, GAE_E_RANGE, "gae_tuning_get: unknown knob '%s'", name);
-    *value_out = *k;
+    *value_out = int(*k);
     return GAE_OK;
 }

@@ -117,7 +117,7 @@ struct Vec16<unsigned short> {   // bf16 storage, fp32 accumulation
 
 }  // namespace
 namespace gae {
-thread_local int g_spmm_ell_rpg = 0;      // rows per lane group of the ell kernels: 0 = auto (1)
+gae::Knob g_spmm_ell_rpg{0};      // rows per lane group of the ell kernels: 0 = auto (1)
 }
 namespace {
 
@@ -478,7 +478,7 @@ int launch_ell_t(const EllArgs &a, int lpr, int rpg, int W, bool scaled, hipStre
 
 namespace gae {
 
-int *spmm_ell_knob(const char *name)
+Knob *spmm_ell_knob(const char *name)
 {
     if (strcmp(name, "spmm_ell_rpg") == 0) return &g_spmm_ell_rpg;
     return nullptr;
@@ -534,9 +534,9 @@ extern "C" int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices
     GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_RANGE, "gae_gcn_layer_fused: act %d", act);
     GAE_REQUIRE((row_scale == nullptr) == (col_scale == nullptr), GAE_E_NULL,
                 "gae_gcn_layer_fused: row_scale and col_scale must both be given or both be NULL");
-    GAE_REQUIRE(plan && plan->ell && plan->n_heavy == 0 &&
+    GAE_REQUIRE(plan && plan->ell && plan->n_heavy == 0 && plan->vh_n_virtual == 0 &&
                     (plan->ell_width == 4 || plan->ell_width == 8 || plan->ell_width == GAE_SPMM_ELL_WIDTH),
-                GAE_E_RANGE, "gae_gcn_layer_fused: needs a plan with a packed neighbour table and no heavy rows");
+                GAE_E_RANGE, "gae_gcn_layer_fused: needs a plan with a packed neighbour table and no heavy or XCD-pinned rows");
     if (n_rows == 0) return GAE_OK;
     GAE_REQUIRE(indptr && H && W && Y, GAE_E_NULL, "gae_gcn_layer_fused: NULL pointer");
     GAE_REQUIRE(ldh >= F && ldh % 4 == 0 && gae::aligned16(H), GAE_E_ALIGN,

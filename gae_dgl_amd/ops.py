@@ -903,8 +903,10 @@ FUSED_LAYER_MAX_IN, FUSED_LAYER_MAX_OUT = 64, 32      # gae_gcn_layer_fused: who
 
 def gcn_layer_fused_usable(H, n_out, plan):
     """can gae_gcn_layer_fused run this layer?  fp32 rows of <= 64 features made of whole 16-byte vectors, <= 32
-    outputs, a plan that carries a packed neighbour table and no heavy rows"""
-    return (plan is not None and plan.ell is not None and plan.n_heavy == 0 and H.dtype == torch.float32
+    outputs, a plan that carries a packed neighbour table and neither heavy nor XCD-pinned rows (their table rows
+    are skip markers: the fused kernel would leave them unwritten)"""
+    return (plan is not None and plan.ell is not None and plan.n_heavy == 0 and plan.homed is None
+            and H.dtype == torch.float32
             and H.dim() == 2 and 1 <= H.shape[1] <= FUSED_LAYER_MAX_IN and 1 <= n_out <= FUSED_LAYER_MAX_OUT
             and H.shape[0] > 0 and H.stride(1) == 1 and H.stride(0) % 4 == 0 and H.data_ptr() % 16 == 0
             and H.shape[0] * H.stride(0) * 4 + (1 << 16) < (1 << 32))

@@ -36,7 +36,10 @@ class Adam(torch.optim.Optimizer):
     def steps_taken(self, group=0, chunk=0):
         """number of steps the device-side counter of a parameter group has seen (host read-back)"""
         c = self._counters.get((group, chunk))
-        return int(c[0]) if c is not None else 0
+        if c is not None:
+            return int(c[0])
+        resume = getattr(self, "_resume_steps", None)      # loaded, no step taken yet: the checkpoint's count
+        return int(resume[group]) if resume is not None and group < len(resume) else 0
 
     def hyper_params(self):
         """the values a captured launch has frozen in"""
@@ -60,7 +63,13 @@ class Adam(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         for st in self.state.values():
             st.pop("step", None)
-        self._counters = {}
+        # counters that exist stay where they are (a captured HIP graph holds their addresses): set them to the
+        # checkpoint's count and invalidate their cached beta^t (zeros = "recompute with pow", see optim.hip);
+        # counters of groups that have not stepped yet are created at the resume point by step()
+        for (gi, _), c in self._counters.items():
+            c.zero_()
+            if gi < len(steps):
+                c[0] = steps[gi]
         self._resume_steps = steps
 
     @torch.no_grad()

@@ -60,8 +60,10 @@ typedef struct gae_device_info {
 int gae_version(void);
 const char *gae_last_error(void);
 int gae_device_info_get(int device, gae_device_info *out_host);
-/* Tuning / test knobs: integers local to the CALLING THREAD (thread_local; the launches of a thread see what that
- * thread set, other threads keep the defaults -- no process-wide mutable state).  Three kinds:
+/* Tuning / test knobs: ONE integer per process and knob (relaxed atomics, read at launch time).  Process-wide on
+ * purpose: PyTorch runs the backward of an autograd Function on its engine's worker thread, so a per-thread value
+ * would not reach the launches made in backward() (dW, A^T products).  Meant to be set once, before the launches
+ * they should affect; every other piece of library state is per call.  Three kinds:
  *  - select among kernels with bit-identical results: "spmm_variant", "spmm_rpg", "spmm_nt", "spmm_tile_vecs",
  *    "spmm_ell", "spmm_ell_rpg", "spmm_hot", "spmm_desc", "spmm_parts" (bit mask of the parts of a skew-plan
  *    launch that run; experiments only), "bce_minw", "bce_strip_store", "bce_fold_mirror";
@@ -72,7 +74,7 @@ int gae_device_info_get(int device, gae_device_info *out_host);
  *  - select the ARITHMETIC of matrix-core products: "bce_s_bf16" / "bce_pv_bf16" / "atb_bf16" (1 = bf16 x 3 split
  *    products, default; 0 = exact fp32 MFMA) and "linear_bf16" (default 0 = exact fp32 forward Linear). */
 int gae_tuning_set(const char *name, int64_t value);
-int gae_tuning_get(const char *name, int64_t *value_out);   /* the calling thread's current value */
+int gae_tuning_get(const char *name, int64_t *value_out);
 
 /* ---- graph structure -------------------------------------------------------
  * Replaces the DGL graph index built by DGLGraph.add_edges / dgl.batch
@@ -123,8 +125,12 @@ int gae_csr_to_dense(const int32_t *indptr, const int32_t *indices, int64_t n_ro
  * Fixed-capacity batches (HIP-graph capture of the inductive step: every replay must launch the same shapes):
  * gae_batch_gather with cap_nodes > 0 pads the batch to cap_nodes rows -- the rows behind the last member graph
  * become isolated nodes (empty CSR rows, zero features, empty table rows) -- and writes the true sizes {nodes,
- * edges} to out_counts (int64[2], device), which gae_decoder_bce_padded reads.  In that mode n_batch_nodes /
- * n_batch_edges are upper bounds (the capacity of the output arrays), not the exact totals.
+ * edges} to out_counts[0..1] (int64[3], device), which gae_decoder_bce_padded reads.  In that mode n_batch_nodes /
+ * n_batch_edges are upper bounds (the capacity of the output arrays), not the exact totals, and the kernel guards
+ * them ON THE DEVICE: of a batch whose prefix sums exceed cap_nodes rows or n_batch_edges edges only the longest
+ * prefix of member graphs that fits is gathered (nothing is ever written behind the arrays; the sizes in
+ * out_counts[0..1] are those of the kept prefix) and the number of graphs left out is ADDED to out_counts[2] --
+ * zero it before an epoch and read it afterwards (gae_dgl_amd/capture.py raises when it is not 0).
  * gae_batch_select: out_ids[b] = order[*cursor_dev * batch_graphs + b], then *cursor_dev += 1 (device-side cursor:
  * a replayed graph walks an epoch order that was uploaded once). */
 int gae_batch_select(const int64_t *order, int64_t n_order, int64_t *cursor_dev, int64_t batch_graphs,
@@ -379,7 +385,7 @@ int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, int64_t n, in
                          void *workspace, int64_t workspace_bytes, void *stream);
 
 /* The same loss on a FIXED-CAPACITY batch (gae_batch_gather with cap_nodes > 0): Z / mask / dZ have n_cap rows, the
- * CSRs n_cap rows; counts_dev (int64[2], device) holds the true {nodes, edges} of this batch.  Rows >= counts[0]
+ * CSRs n_cap rows; counts_dev (int64[>= 2], device) holds the true {nodes, edges} of this batch.  Rows >= counts[0]
  * are padding: they take no part in the loss (pos_weight and the mean use the true N and E, read on the device)
  * and receive a zero gradient.  Lets the inductive training step of gae_dgl/train_inductive.py:92-95 run as ONE
  * captured HIP graph although every batch has a different size.  Workspace: gae_decoder_bce_workspace_bytes(n_cap,

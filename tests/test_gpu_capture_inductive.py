@@ -37,11 +37,11 @@ def test_padded_loss_matches_unpadded(dropout, sym, tuning):
     Z = torch.randn(n, 16, device=DEV) * 0.5
     Zp = torch.zeros(cap_n, 16, device=DEV); Zp[:n] = Z; Zp[n:] = 3.0          # garbage in the padding rows
     node_ptr, edge_ptr, _ = ops.batch_plan(ds.graph_ptr, ds.indptr, None, torch.from_numpy(ids).to(DEV))
-    counts = torch.zeros(2, dtype=torch.int64, device=DEV)
+    counts = torch.zeros(3, dtype=torch.int64, device=DEV)
     ip, ix, feat, table = ops.batch_gather(ds.graph_ptr, ds.indptr, ds.indices, ds.feat, torch.from_numpy(ids).to(DEV),
                                            node_ptr, edge_ptr, cap_n, cap_e, ell_width=ds.ell_width, n_feat=ds.n_feat,
                                            pad_to_capacity=True, counts=counts)
-    assert counts.tolist() == [n, e]
+    assert counts.tolist() == [n, e, 0]
     # the padded structure: the batch's CSR, then empty rows / zero features / empty table rows
     assert torch.equal(ip[:n + 1], bg.csr()[0]) and torch.equal(ix[:e], bg.csr()[1])
     assert bool((ip[n:] == e).all()) and bool((feat[n:] == 0).all()) and torch.equal(feat[:n], bg.ndata['h'])
@@ -169,3 +169,122 @@ def test_batch_select_and_plan_next_walk_an_epoch_order():
         ref = ops.batch_plan(ds.graph_ptr, ds.indptr, None, ids_a)
         assert torch.equal(node_ptr, ref[0]) and torch.equal(edge_ptr, ref[1])
         assert np.array_equal(node_ptr.cpu().numpy()[1:], np.cumsum(ds.sizes_host[want]))
+
+
+def test_gather_guard_drops_what_does_not_fit():
+    """device-side guard of gae_batch_gather (fixed-capacity mode): a batch whose prefix sums exceed the buffers is cut
+    to the longest prefix of member graphs that fits -- nothing is written behind the arrays, the kept prefix is a
+    correct batch, out_counts[2] counts the graphs left out"""
+    from gae_dgl_amd import ops
+    ds, _ = _dataset()
+    ids = np.arange(10, 74)
+    gids = torch.from_numpy(ids).to(DEV)
+    node_ptr, edge_ptr, _ = ops.batch_plan(ds.graph_ptr, ds.indptr, None, gids)
+    npt, ept = node_ptr.cpu().numpy(), edge_ptr.cpu().numpy()
+    keep = 41                                                     # capacities between graph 41's and graph 42's end
+    cap_n, cap_e = int(npt[keep]) + 3, int(ept[keep]) + 5
+    assert cap_n < npt[keep + 1] or cap_e < ept[keep + 1]
+    F, ldo, odt = ops.batch_feature_ld(ds.feat, ds.n_feat)
+    W = ds.ell_width
+    guard = 4096                                                  # sentinel area behind every buffer
+    ip = torch.full((cap_n + 1 + guard,), -7, dtype=torch.int32, device=DEV)
+    ix = torch.full((cap_e + guard,), -7, dtype=torch.int32, device=DEV)
+    feat = torch.full((cap_n + guard // 8, ldo), -7.0, dtype=odt, device=DEV)
+    table = torch.full(((cap_n + guard // 8) * W,), -7, dtype=torch.int32, device=DEV)
+    counts = torch.zeros(3, dtype=torch.int64, device=DEV)
+    out = (ip[:cap_n + 1], ix[:cap_e], feat[:cap_n], table[:cap_n * W])
+    ops.batch_gather(ds.graph_ptr, ds.indptr, ds.indices, ds.feat, gids, node_ptr, edge_ptr, cap_n, cap_e,
+                     ell_width=W, n_feat=ds.n_feat, out=out, pad_to_capacity=True, counts=counts)
+    torch.cuda.synchronize()
+    assert counts.tolist() == [int(npt[keep]), int(ept[keep]), len(ids) - keep]
+    assert bool((ip[cap_n + 1:] == -7).all()) and bool((ix[cap_e:] == -7).all())
+    assert bool((feat[cap_n:] == -7).all()) and bool((table[cap_n * W:] == -7).all())
+    ref = ds.batch(ids[:keep])
+    n, e = ref.number_of_nodes(), ref.number_of_edges()
+    assert torch.equal(ip[:n + 1], ref.csr()[0]) and torch.equal(ix[:e], ref.csr()[1])
+    assert bool((ip[n:cap_n + 1] == e).all()) and torch.equal(feat[:n, :F], ref.ndata['h'])
+    assert bool((feat[n:cap_n] == 0).all()) and bool((table[n * W:cap_n * W] == -1).all())
+    # a second overflowing call ADDS to the counter; a batch that fits leaves it alone
+    ops.batch_gather(ds.graph_ptr, ds.indptr, ds.indices, ds.feat, gids, node_ptr, edge_ptr, cap_n, cap_e,
+                     ell_width=W, n_feat=ds.n_feat, out=out, pad_to_capacity=True, counts=counts)
+    assert int(counts[2]) == 2 * (len(ids) - keep)
+
+
+def test_capture_with_a_single_full_batch_and_per_step_lr():
+    """B <= len(order) < 2 B (the warm-up steps of the capture used to walk past the only full batch into the ragged
+    tail, whose size was never checked against the buffers) and a learning rate that changes on every step (the
+    re-capture at the LAST full batch had the same problem): no graph is dropped by the device guard, the losses
+    equal the eager loop's, the step counter and the dropout stream do not see the warm-up steps"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops
+    from gae_dgl_amd.capture import CapturedInductiveStep
+    from gae_dgl_amd.optim import Adam
+    ds, _ = _dataset(120)
+    B = 48
+    big_last = np.argsort(ds.sizes_host, kind="stable")             # the tail holds the LARGEST molecules
+    order = big_last[:B + 20].copy()                                # one full batch + a ragged tail of 20 large graphs
+    torch.manual_seed(5)
+    m_e = G.GAE(ds.n_feat, [32, 16]).to(DEV)
+    m_e.decoder.seed = 9
+    m_c = copy.deepcopy(m_e)
+    o_e, o_c = Adam(m_e.parameters(), lr=1e-2), Adam(m_c.parameters(), lr=1e-2)
+    runner = CapturedInductiveStep(m_c, o_c, ds, B, margin=1.0)
+    losses_c = [float(l) for l in runner.epoch(order)]
+    assert runner.dropped_graphs() == 0 and len(losses_c) == 2
+    d_order = torch.from_numpy(order).to(DEV)
+    losses_e = []
+    for lo in range(0, len(order), B):
+        bg = ds._assemble(d_order[lo:lo + B], order[lo:lo + B])
+        o_e.zero_grad()
+        loss = m_e.reconstruction_loss(bg)
+        ops.backward(loss); o_e.step()
+        losses_e.append(float(loss))
+    np.testing.assert_allclose(losses_c, losses_e, rtol=1e-5)
+    assert o_c.steps_taken() == o_e.steps_taken() == 2
+    with pytest.raises(ops.GaeHipError):
+        runner.step()                                               # no full batch left: refused, not replayed
+    # ---- a per-step LR schedule: every step re-captures, also the one at the last full batch
+    order2 = big_last[::-1][:3 * B].copy()
+    n_full = runner.begin_epoch(order2)
+    caps = runner.captures
+    for k in range(n_full):
+        for g in o_c.param_groups:
+            g["lr"] = 1e-2 / (k + 2)
+        loss = runner.step()
+        lo = order2[k * B:(k + 1) * B]
+        assert runner.batch_sizes() == (int(ds.sizes_host[lo].sum()), int(ds.edges_host[lo].sum()))
+    assert np.isfinite(float(loss)) and runner.captures == caps + n_full and runner.dropped_graphs() == 0
+    assert o_c.steps_taken() == 2 + n_full
+
+
+def test_adam_resume_survives_reload_and_capture():
+    """load_state_dict() then state_dict() keeps the step count (the counter does not exist before the first step);
+    a capture right after a load restores counter, moments and dropout draws to the resume point"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd.capture import CapturedInductiveStep
+    from gae_dgl_amd.optim import Adam
+    ds, _ = _dataset(100)
+    torch.manual_seed(1)
+    m = G.GAE(ds.n_feat, [32, 16]).to(DEV)
+    opt = Adam(m.parameters(), lr=1e-3)
+    r = CapturedInductiveStep(m, opt, ds, 25)
+    for _ in r.epoch(ds.ids[:75]):
+        pass
+    assert opt.steps_taken() == 3
+    sd = copy.deepcopy(opt.state_dict())
+    w0 = [p.detach().clone() for p in m.parameters()]
+    opt2 = Adam(m.parameters(), lr=1e-3)
+    opt2.load_state_dict(sd)
+    assert opt2.steps_taken() == 3                                   # before any step: the checkpoint's count
+    sd2 = opt2.state_dict()
+    assert all(float(st["step"]) == 3.0 for st in sd2["state"].values())
+    m.decoder._draws = None                                          # resume in a fresh process: no draw counter yet
+    r2 = CapturedInductiveStep(m, opt2, ds, 25)
+    r2.begin_epoch(ds.ids[:75])                                      # captures: warm-up steps must leave no trace
+    assert opt2.steps_taken() == 3 and int(m.decoder._draws) == 0
+    for p, q in zip(m.parameters(), w0):
+        assert torch.equal(p, q)
+    for a, b in zip(opt2.state_dict()["state"].values(), sd["state"].values()):
+        assert torch.equal(a["exp_avg"], b["exp_avg"]) and torch.equal(a["exp_avg_sq"], b["exp_avg_sq"])
+    r2.step()
+    assert opt2.steps_taken() == 4
