@@ -46,10 +46,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TJ = 64;   // columns staged per iteration
 constexpr int PREP_ROWS = 64;    // rows per block of the prepare kernel
-// tuning knobs (gae_tuning_set): "bce_ri" 16-row subtiles per wave (rows / block = 64 RI), "bce_minw" min
-// waves per SIMD hint, "bce_s_bf16" 1 = bf16x3 S product, 0 = exact fp32 S product
+// tuning knobs (gae_tuning_set): "bce_ri" 16-row subtiles per wave (rows / block = 64 RI),
+// "bce_s_bf16" 1 = bf16x3 S product, 0 = exact fp32 S product
 gae::Knob g_bce_ri{2};
-gae::Knob g_bce_minw{0};
 gae::Knob g_bce_s_bf16{1};
 gae::Knob g_bce_grid{2048};       // "bce_grid": target size of the (row block, column split) grid of the full-square kernel
 constexpr int kChipCus = 256;             // MI355X: the launch-shape heuristics below are written for this part
@@ -1185,7 +1184,6 @@ int launch_dense(const BcePlan &p, const float *Zt, const unsigned short *Zhi, c
     if (p.KS == 1) {
         if (p.RI == 1) { if (sb) GAE_BD(1, 1, 1, true); else GAE_BD(1, 1, 1, false); }
         else if (p.RI == 4) { if (sb) GAE_BD(1, 4, 1, true); else GAE_BD(1, 4, 1, false); }
-        else if (g_bce_minw >= 6) { if (sb) GAE_BD(1, 2, 6, true); else GAE_BD(1, 2, 6, false); }
         else { if (sb) GAE_BD(1, 2, 1, true); else GAE_BD(1, 2, 1, false); }
     } else if (p.KS == 2) {
         if (p.RI == 1) { if (sb) GAE_BD(2, 1, 1, true); else GAE_BD(2, 1, 1, false); }
@@ -1227,7 +1225,6 @@ namespace gae {
 Knob *bce_knob(const char *name)
 {
     if (strcmp(name, "bce_ri") == 0) return &g_bce_ri;
-    if (strcmp(name, "bce_minw") == 0) return &g_bce_minw;
     if (strcmp(name, "bce_s_bf16") == 0) return &g_bce_s_bf16;
     if (strcmp(name, "bce_pv_bf16") == 0) return &g_bce_pv_bf16;
     if (strcmp(name, "bce_sym") == 0) return &g_bce_sym;

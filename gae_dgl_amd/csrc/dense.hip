@@ -598,7 +598,7 @@ __global__ __launch_bounds__(512) void linear_fwd_wlds_kernel(
 // gemm_stream_kernel's 32-byte pieces) feeding v_mfma_f32_16x16x4_f32 -- exact fp32 products; the 4 values a lane
 // holds go to 4 consecutive MFMAs, each of which contracts the k positions {4 g + r} of the 16-k step.
 template <bool WVEC, bool EXACT = false, int NW = 4, int DEPTH = 3>
-__global__ __launch_bounds__(64 * NW) void linear_fwd_bf16_kernel(
+__global__ __launch_bounds__(64 * NW) void linear_fwd_pieces_kernel(
     const float *__restrict__ A, int64_t lda, const float *__restrict__ W, int64_t ldw,
     const float *__restrict__ bias, int act, float *__restrict__ out, int64_t ldo, int64_t n, int K, int J,
     int ks_per_split, int64_t split_stride)
@@ -803,7 +803,7 @@ int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t 
     if (splits > 1 && split_ws_floats < int64_t(splits) * n * J) splits = 1;
     const int kblocks = (K + 7) / 8;
     const int kbps = (kblocks + splits - 1) / splits;
-    // forward Linear with bf16 x 3 products and 64-byte row pieces (linear_fwd_bf16_kernel)
+    // forward Linear with bf16 x 3 products and 64-byte row pieces (linear_fwd_pieces_kernel)
     // (short unaligned rows of W keep gemm_stream_kernel: ZINC K = 39 measured 10.3 -> 13.2 us; knob 2 forces it)
     const bool wvec_ok = (ldb % 4 == 0) && gae::aligned16(B) && ldb >= ((K + 3) & ~3);
     const bool exact16 = g_linear_f32x16 && g_linear_bf16 == 0 && K >= 128;   // exact twin of the same loader
@@ -817,15 +817,15 @@ int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t 
         const dim3 grid(unsigned((n + 31) / 32), unsigned(splits));
 #define GAE_LB(WV, EX, NW)                                                                                         \
     if (g_linear_depth == 5)                                                                                       \
-        hipLaunchKernelGGL((linear_fwd_bf16_kernel<WV, EX, NW, 5>), grid, dim3(64 * NW), 0, s, A, lda, B, ldb,     \
+        hipLaunchKernelGGL((linear_fwd_pieces_kernel<WV, EX, NW, 5>), grid, dim3(64 * NW), 0, s, A, lda, B, ldb,     \
                            splits > 1 ? nullptr : bias, splits > 1 ? int(GAE_ACT_IDENTITY) : act, dst,             \
                            splits > 1 ? J : ldo, n, K, int(J), kspp, n * J);                                       \
     else if (g_linear_depth == 4)                                                                                  \
-        hipLaunchKernelGGL((linear_fwd_bf16_kernel<WV, EX, NW, 4>), grid, dim3(64 * NW), 0, s, A, lda, B, ldb,     \
+        hipLaunchKernelGGL((linear_fwd_pieces_kernel<WV, EX, NW, 4>), grid, dim3(64 * NW), 0, s, A, lda, B, ldb,     \
                            splits > 1 ? nullptr : bias, splits > 1 ? int(GAE_ACT_IDENTITY) : act, dst,             \
                            splits > 1 ? J : ldo, n, K, int(J), kspp, n * J);                                       \
     else                                                                                                           \
-    hipLaunchKernelGGL((linear_fwd_bf16_kernel<WV, EX, NW>), grid, dim3(64 * NW), 0, s, A, lda, B, ldb,            \
+    hipLaunchKernelGGL((linear_fwd_pieces_kernel<WV, EX, NW>), grid, dim3(64 * NW), 0, s, A, lda, B, ldb,            \
                        splits > 1 ? nullptr : bias, splits > 1 ? int(GAE_ACT_IDENTITY) : act, dst,                 \
                        splits > 1 ? J : ldo, n, K, int(J), kspp, n * J)
         const bool nw8 = g_linear_nw == 8;       // 8 waves per block: measured equal or slower on every layer shape
@@ -834,7 +834,7 @@ int launch_gemm_stream(const float *A, int64_t lda, const float *Amask, int64_t 
         else if (wvec) GAE_LB(true, false, 4);
         else GAE_LB(false, false, 4);
 #undef GAE_LB
-        GAE_CHECK_LAUNCH("linear_fwd_bf16_kernel");
+        GAE_CHECK_LAUNCH("linear_fwd_pieces_kernel");
         if (splits > 1) {
             const int64_t ne = n * J;
             hipLaunchKernelGGL(split_reduce_kernel, dim3(unsigned((ne + 255) / 256)), dim3(256), 0, s, split_ws, splits,

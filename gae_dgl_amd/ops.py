@@ -1101,6 +1101,39 @@ class DecoderDenseBCEFunction(torch.autograd.Function):
         return (dZ if _is_unit(g) else dZ * g), None, None
 
 
+class BCELogitsFunction(torch.autograd.Function):
+    """F.binary_cross_entropy_with_logits(logits, label, pos_weight=pw) (mean) on materialised matrices -- the
+    reference's own loss call (train_inductive.py:48) -- by gae_bce_logits: loss and dLoss/dLogits in one pass."""
+
+    @staticmethod
+    def forward(ctx, logits, label, pos_weight):
+        need = ctx.needs_input_grad[0]
+        X, ldx = _rowmajor(_f32(_gpu(logits, "logits"), "bce_logits: logits"), "logits")
+        Y, ldy = _rowmajor(_f32(_gpu(label, "label"), "bce_logits: labels"), "labels")
+        if X.shape != Y.shape:
+            raise GaeHipError("bce_with_logits: logits / labels shape mismatch")
+        n, m = X.shape
+        loss = torch.empty(1, dtype=torch.float32, device=X.device)
+        G = torch.empty(n, m, dtype=torch.float32, device=X.device) if need else None
+        with _on_device(X.device):
+            ws = _workspace(_lib.load().gae_bce_logits_workspace_bytes(), X.device)
+            _lib.call("gae_bce_logits", _ptr(X), ldx, _ptr(Y), ldy, n, m, float(pos_weight), _ptr(loss), _ptr(G),
+                      max(m, 1), _ptr(ws), ws.numel(), _stream())
+        ctx.save_for_backward(G)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (G,) = ctx.saved_tensors
+        return (G if _is_unit(g) else G * g), None, None
+
+
+def bce_with_logits(logits, label, pos_weight):
+    """drop-in for ``BCELoss(logits, label, pos_weight=pw)`` of the reference's Trainer (train_inductive.py:48) on the
+    HIP kernel; ``pos_weight`` may be a 0-dim / 1-element tensor like the reference's (read back once per call)"""
+    return BCELogitsFunction.apply(logits, label, float(pos_weight))
+
+
 FUSED_MAX_D = 64     # widest embedding of the fused decoder + BCE kernels (gae_decoder_bce)
 
 _UNIT = {}

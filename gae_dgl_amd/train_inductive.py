@@ -15,7 +15,6 @@ import os
 
 import numpy as np
 import torch
-from torch.nn.functional import binary_cross_entropy_with_logits as BCELoss
 from torch.utils.data import DataLoader
 
 import gae_dgl_amd as dgl
@@ -87,7 +86,7 @@ class Trainer:
         # the reference-shaped path (train_inductive.py:44-48): dense label, pos_weight against the imbalance, N x N logits
         label = g.adjacency_matrix().to_dense().to(device)
         n_pairs, n_pos = label.numel(), label.sum()
-        return BCELoss(self.model(g), label, pos_weight=(n_pairs - n_pos) / n_pos)
+        return ops.bce_with_logits(self.model(g), label, pos_weight=(n_pairs - n_pos) / n_pos)   # gae_bce_logits
 
     def iteration(self, g, train=True, as_tensor=False):
         with torch.set_grad_enabled(train):

@@ -66,7 +66,7 @@ int gae_device_info_get(int device, gae_device_info *out_host);
  * they should affect; every other piece of library state is per call.  Three kinds:
  *  - select among kernels with bit-identical results: "spmm_variant", "spmm_rpg", "spmm_nt", "spmm_tile_vecs",
  *    "spmm_ell", "spmm_ell_rpg", "spmm_hot", "spmm_desc", "spmm_parts" (bit mask of the parts of a skew-plan
- *    launch that run; experiments only), "bce_minw", "bce_strip_store", "bce_fold_mirror";
+ *    launch that run; experiments only), "bce_strip_store", "bce_fold_mirror";
  *  - change the ORDER in which partial sums are added (results agree within the fp32 tolerance of DESIGN.md
  *    section 6, not bit for bit): "atb_rows", "gemm_stream", "gemm_rows", "linear_wlds", "linear_f32x16", "linear_nw", "linear_depth", "bce_ri", "bce_sym", "bce_sym_ri",
  *    "bce_sym_grid", "bce_sym_tiles", "bce_grid"; a skew
