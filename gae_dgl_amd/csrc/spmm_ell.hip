@@ -136,6 +136,12 @@ struct EllArgs {
     float *Y;
     int64_t ldy;
     int J, w_so, w_sk, act, store_m;
+    // plain kernels (EPI_J = 0), fp32: M = act(aggregate + ep_bias) (ep_bias may be NULL; ep_act = GAE_ACT_*), and --
+    // MASKED instantiations -- the gathered rows are H (.) [Hmask > 0] (Hmask: same layout as H): the two halves
+    // around the dense product of a transform-first GCN layer (gae_spmm_csr_epilogue)
+    const float *ep_bias;
+    int ep_act;
+    const void *Hmask;
 };
 
 template <typename T>
@@ -161,10 +167,19 @@ __device__ __forceinline__ void slot_offsets(const unsigned (&off)[NREG], unsign
     ((out[U] = bcast_slot<LP16, (B0 + U) % LP16>(off[(B0 + U) / LP16]) + add), ...);
 }
 
+// v (.) [m > 0] on four fp32 values (the ReLU gate of a backward gather: v = dY, m = Y)
+__device__ __forceinline__ u32x4 relu_gate(u32x4 v, const u32x4 m)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(m[i]) > 0.f ? v[i] : 0u;
+    return v;
+}
+
 // Slots [B0, B0 + N) of the RPG rows, straight-line: every load is issued before the first add.  Rows of the wave
 // with fewer neighbours get zeros from the bounds check.
-template <typename T, int LP16, int RPG, int NREG, int B0, int N, bool SCALED>
+template <typename T, int LP16, int RPG, int NREG, int B0, int N, bool SCALED, bool MASKED>
 __device__ __forceinline__ void ell_slots(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_buffer_rsrc_t rs_c,
+                                          __amdgpu_buffer_rsrc_t rs_m,
                                           const unsigned (&off)[RPG][NREG], const unsigned (&coff)[RPG][NREG],
                                           unsigned lane_off, bool live, float (&acc)[RPG][Vec16<T>::NV])
 {
@@ -175,19 +190,21 @@ __device__ __forceinline__ void ell_slots(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_
         if (SCALED) slot_offsets<LP16, B0>(coff[r], 0u, co[r], std::make_integer_sequence<int, N>{});
     }
     if (live) {       // lanes beyond the row's last vector take no part in the memory traffic
-        u32x4 raw[RPG][N];
+        u32x4 raw[RPG][N], msk[RPG][MASKED ? N : 1];
         float cs[RPG][N];
 #pragma unroll
         for (int r = 0; r < RPG; ++r)
 #pragma unroll
             for (int u = 0; u < N; ++u) {
                 raw[r][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_h, vo[r][u], 0, 0);
+                if (MASKED) msk[r][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, vo[r][u], 0, 0);
                 if (SCALED) cs[r][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, co[r][u], 0, 0));
             }
 #pragma unroll
         for (int r = 0; r < RPG; ++r)
 #pragma unroll
             for (int u = 0; u < N; ++u) {
+                if (MASKED) raw[r][u] = relu_gate(raw[r][u], msk[r][u]);
                 if (SCALED) Vec16<T>::fma(acc[r], raw[r][u], cs[r][u]);
                 else Vec16<T>::add(acc[r], raw[r][u]);
             }
@@ -197,8 +214,9 @@ __device__ __forceinline__ void ell_slots(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_
 // One batch: slots [B0, B0 + NB).  Only as many slots as the longest row of the WAVE fills are touched (scalar
 // count from the ballots, one straight-line body per count): a bounds-checked load that returns zeros still costs
 // its address-unit cycles (no-edge launch of the Pubmed shape: 14.2 us with 8 such loads per row, 9 us without).
-template <typename T, int LP16, int RPG, int NREG, int B0, int NB, bool SCALED, int... U>
+template <typename T, int LP16, int RPG, int NREG, int B0, int NB, bool SCALED, bool MASKED, int... U>
 __device__ __forceinline__ void ell_batch(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_buffer_rsrc_t rs_c,
+                                          __amdgpu_buffer_rsrc_t rs_m,
                                           const unsigned (&off)[RPG][NREG], const unsigned (&coff)[RPG][NREG],
                                           const unsigned long long (&valid)[RPG][NREG], unsigned lane_off, bool live,
                                           float (&acc)[RPG][Vec16<T>::NV], std::integer_sequence<int, U...>)
@@ -216,7 +234,7 @@ __device__ __forceinline__ void ell_batch(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_
 #define GAE_ELL_CASE(N)                                                                                      \
     case N:                                                                                                  \
         if constexpr (N <= NB)                                                                               \
-            ell_slots<T, LP16, RPG, NREG, B0, (N <= NB ? N : 1), SCALED>(rs_h, rs_c, off, coff, lane_off, live, acc); \
+            ell_slots<T, LP16, RPG, NREG, B0, (N <= NB ? N : 1), SCALED, MASKED>(rs_h, rs_c, rs_m, off, coff, lane_off, live, acc); \
         break;
         GAE_ELL_CASE(1) GAE_ELL_CASE(2) GAE_ELL_CASE(3) GAE_ELL_CASE(4)
         GAE_ELL_CASE(5) GAE_ELL_CASE(6) GAE_ELL_CASE(7) GAE_ELL_CASE(8)
@@ -247,9 +265,10 @@ __device__ __forceinline__ float group_allreduce(float p)
 // the weight rows (LDS copy, loaded once per block), a DPP butterfly adds the LPR lanes, lane l keeps outputs
 // l J / LPR ....  NodeApplyModule after update_all (gae.py:28-29) without the round trip of M through HBM and
 // without a second launch.
-template <typename T, int LPR, int RPG, int W, int NB, bool SCALED, int EPI_J = 0>
+template <typename T, int LPR, int RPG, int W, int NB, bool SCALED, int EPI_J = 0, bool MASKED = false>
 __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
 {
+    static_assert(!MASKED || sizeof(T) == 4, "the gather gate is an fp32 form");
     constexpr int NV = Vec16<T>::NV;
     constexpr int LDW = 68;                         // floats per LDS weight row: 64 columns + 4 (bank spread)
     __shared__ __attribute__((aligned(16))) float Ws[EPI_J > 0 ? EPI_J * LDW : 4];
@@ -293,6 +312,8 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
     __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.H), 0, int(a.h_bytes), 0x00020000);
     __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(SCALED ? a.col_scale : nullptr), 0, SCALED ? int(a.n_cols * 4u) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(MASKED ? a.Hmask : nullptr), 0,
+                                                                    MASKED ? int(a.h_bytes) : 0, 0x00020000);
 
     int64_t row[RPG];
     unsigned off[RPG][NREG], coff[RPG][NREG];
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
         _Pragma("unroll") for (int r = 0; r < RPG; ++r)                                                            \
             more = more || (valid[r][(B0) / LP16] & holder_mask<LP16, (B0)>()) != 0;                               \
         if (!more) goto slots_done;                                                                                \
-        ell_batch<T, LP16, RPG, NREG, (B0), NB, SCALED>(rs_h, rs_c, off, coff, valid, lane_off, live, acc,         \
+        ell_batch<T, LP16, RPG, NREG, (B0), NB, SCALED, MASKED>(rs_h, rs_c, rs_m, off, coff, valid, lane_off, live, acc, \
                                                         std::make_integer_sequence<int, NB>{});                    \
     }
     GAE_ELL_BATCH(0)
@@ -348,7 +369,9 @@ slots_done:
                 const int32_t e1 = a.indptr[row[r] + 1];
                 for (int32_t e = a.indptr[row[r]] + (W - 1); e < e1; ++e) {
                     const unsigned j = unsigned(a.indices[e]);
-                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_h, j * a.ldh_bytes + lane_off, 0, 0);
+                    u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_h, j * a.ldh_bytes + lane_off, 0, 0);
+                    if (MASKED)
+                        raw = relu_gate(raw, __builtin_amdgcn_raw_buffer_load_b128(rs_m, j * a.ldh_bytes + lane_off, 0, 0));
                     if (SCALED) Vec16<T>::fma(acc[r], raw, a.col_scale[j]);
                     else Vec16<T>::add(acc[r], raw);
                 }
@@ -371,6 +394,17 @@ slots_done:
             const float rs = row[r] < a.n_rows ? a.row_scale[row[r]] : 0.f;
 #pragma unroll
             for (int i = 0; i < NV; ++i) acc[r][i] *= rs;
+        }
+        if constexpr (EPI_J == 0 && sizeof(T) == 4) {
+            if (a.ep_bias != nullptr || a.ep_act != GAE_ACT_IDENTITY) {     // scalar test: plain launches skip it
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const unsigned c = fvec * NV + i;
+                    float y = acc[r][i] + ((a.ep_bias != nullptr && live && c < a.F) ? a.ep_bias[c] : 0.f);
+                    if (a.ep_act == GAE_ACT_RELU) y = fmaxf(y, 0.f);
+                    acc[r][i] = y;
+                }
+            }
         }
         if (live && row[r] < a.n_rows && (EPI_J == 0 || a.store_m)) {
             T *mp = static_cast<T *>(a.M) + row[r] * a.ldm + int64_t(fvec) * NV;
@@ -562,4 +596,74 @@ extern "C" int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices
     const int ew = plan->ell_width;
     if (a.nvec <= 8) return J <= 16 ? launch_ell_epi_w<8, 16>(a, ew, scaled, s) : launch_ell_epi_w<8, 32>(a, ew, scaled, s);
     return J <= 16 ? launch_ell_epi_w<16, 16>(a, ew, scaled, s) : launch_ell_epi_w<16, 32>(a, ew, scaled, s);
+}
+
+namespace {
+template <int LPR, int W, int NB>
+int launch_ell_gated(const EllArgs &a, bool scaled, hipStream_t s)
+{
+    constexpr int RPB = 256 / LPR;
+    EllArgs b = a;
+    b.n_row_blocks = unsigned((a.n_rows + RPB - 1) / RPB);
+    b.n_ftiles = 1;
+    const dim3 grid(b.n_row_blocks, 1);
+    if (scaled) hipLaunchKernelGGL((spmm_ell_kernel<float, LPR, 1, W, NB, true, 0, true>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((spmm_ell_kernel<float, LPR, 1, W, NB, false, 0, true>), grid, dim3(256), 0, s, b);
+    GAE_CHECK_LAUNCH("spmm_ell_kernel (gated gather)");
+    return GAE_OK;
+}
+template <int LPR>
+int launch_ell_gated_w(const EllArgs &a, int W, bool scaled, hipStream_t s)
+{
+    if (W == 4) return launch_ell_gated<LPR, 4, 4>(a, scaled, s);
+    if (W == 8) return launch_ell_gated<LPR, 8, 8>(a, scaled, s);
+    return launch_ell_gated<LPR, 16, 8>(a, scaled, s);
+}
+} // namespace
+
+// The sparse half of a TRANSFORM-FIRST GCN layer, act(A (H W^T) + b) instead of act((A H) W^T + b) (gae_dgl/gae.py:
+// 26-31; same value up to fp32 rounding -- the aggregation then runs at the OUTPUT width and nothing of the input
+// width is written):
+//   forward   Y  = act(diag(rs) A diag(cs) P + b)               P = X W^T from gae_xw_fwd, Hmask = NULL
+//   backward  G  = diag(rs) A^T diag(cs) (dY (.) [Y > 0])        Hmask = Y (the layer's output), bias = NULL, identity
+// in one launch of the packed-table kernel (bias + activation at store time; the ReLU gate applied to the gathered
+// rows).  Needs a plan with a packed neighbour table and no heavy / XCD-pinned rows; F <= 64, fp32, rows of whole
+// 16-byte vectors; Hmask has the layout of H.  Sums run in CSR order (bit-identical to gae_spmm_csr on the same rows).
+extern "C" int gae_spmm_csr_epilogue(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                                     const float *H, int64_t ldh, const float *Hmask, float *Y, int64_t ldy, int64_t F,
+                                     const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
+                                     const float *bias, int act, void *stream)
+{
+    GAE_REQUIRE(n_rows >= 0 && n_cols >= 0, GAE_E_SIZE, "gae_spmm_csr_epilogue: negative size");
+    GAE_REQUIRE(F >= 1 && F <= 64, GAE_E_RANGE, "gae_spmm_csr_epilogue: needs 1 <= F <= 64 (got %lld)", (long long)F);
+    GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_RANGE, "gae_spmm_csr_epilogue: act %d", act);
+    GAE_REQUIRE((row_scale == nullptr) == (col_scale == nullptr), GAE_E_NULL,
+                "gae_spmm_csr_epilogue: row_scale and col_scale must both be given or both be NULL");
+    GAE_REQUIRE(plan && plan->ell && plan->n_heavy == 0 && plan->vh_n_virtual == 0 &&
+                    (plan->ell_width == 4 || plan->ell_width == 8 || plan->ell_width == GAE_SPMM_ELL_WIDTH),
+                GAE_E_RANGE, "gae_spmm_csr_epilogue: needs a plan with a packed neighbour table and no heavy or XCD-pinned rows");
+    if (n_rows == 0) return GAE_OK;
+    GAE_REQUIRE(indptr && H && Y, GAE_E_NULL, "gae_spmm_csr_epilogue: NULL pointer");
+    GAE_REQUIRE(ldh >= F && ldh % 4 == 0 && gae::aligned16(H) && (!Hmask || gae::aligned16(Hmask)), GAE_E_ALIGN,
+                "gae_spmm_csr_epilogue: rows of H (and Hmask) must be whole 16-byte vectors");
+    GAE_REQUIRE(ldy >= (F + 3) / 4 * 4 && ldy % 4 == 0 && gae::aligned16(Y), GAE_E_ALIGN,
+                "gae_spmm_csr_epilogue: rows of Y must be whole 16-byte vectors");
+    GAE_REQUIRE(n_cols > 0 && n_cols * ldh * 4 + (int64_t(1) << 16) < (int64_t(1) << 32), GAE_E_SIZE,
+                "gae_spmm_csr_epilogue: H larger than a raw buffer resource addresses");
+    EllArgs a{};
+    a.indptr = indptr; a.indices = indices; a.ell = plan->ell;
+    a.H = H; a.M = Y; a.row_scale = row_scale; a.col_scale = col_scale;
+    a.n_rows = n_rows; a.ldm = ldy;
+    a.ldh_bytes = unsigned(ldh * 4);
+    a.h_bytes = unsigned(n_cols * ldh * 4);
+    a.n_cols = unsigned(n_cols); a.F = unsigned(F); a.nvec = unsigned((F + 3) / 4);
+    a.tile_vecs = a.nvec;
+    a.xcd_tiled = 0; a.store_pad = 1; a.store_mode = 0;     // (rows of Y are whole vectors: checked above)
+    a.ep_bias = bias; a.ep_act = act; a.Hmask = Hmask;
+    hipStream_t s = gae::as_stream(stream);
+    const bool scaled = row_scale != nullptr;
+    const int ew = plan->ell_width;
+    if (Hmask != nullptr)
+        return a.nvec <= 8 ? launch_ell_gated_w<8>(a, ew, scaled, s) : launch_ell_gated_w<16>(a, ew, scaled, s);
+    return a.nvec <= 8 ? launch_ell_w<float, 8, 1>(a, ew, scaled, s) : launch_ell_w<float, 16, 1>(a, ew, scaled, s);
 }

@@ -1,0 +1,706 @@
+// K3/K4, "stream" family: the two dense products of a GCN layer whose input is WIDE and whose output is narrow
+// (layer 1 of the reference model: 500 / 1433 / 3703 input features -> 32, gae_dgl/gae.py:10,13-16,26-31)
+//
+//     forward   P [n, J]  = act(X [n, K] W [J, K]^T + b)        J <= 32
+//     backward  dW [J, K] = G [n, J]^T X [n, K],   db [J] = colsum(D (.) [Ym > 0])
+//
+// Both are passes over X that move 4 K bytes per row and do 2 J flops per byte: HBM-bound (intensity J / 2 = 16
+// flop/B against 157 TFLOP/s of fp32 MFMA / 8 TB/s = 20), provided X is read exactly ONCE, every CU pulls on HBM
+// for the whole launch, and nothing else of comparable size moves.  The kernels this file replaces for these
+// shapes (dense.hip: linear_fwd_pieces_kernel, atb_bf16_kernel) re-read the weights once per 32-row block (as many
+// L2 bytes as X has HBM bytes), lived for ~10 dependent round trips per wave and left a partial round of CUs idle:
+// 2.7 TB/s forward, 2.9 TB/s backward on Pubmed (profiles/r02_linear_bench.txt).  Here:
+//   * forward: W is STATIONARY in registers -- the 8 waves of a block split K into 256-byte (512-byte) column
+//     slices, each wave holds its 32 x 64 (32 x 128) slice of W as MFMA B-fragments for the whole launch and streams
+//     the block's row tiles (16 rows) through them: 4 (8) raw-buffer dwordx4 loads per wave and tile, three tiles
+//     in flight, no LDS and no barrier in front of the MFMAs; the 8 partial tiles meet in a double-buffered LDS
+//     area once per tile, in wave order (deterministic).  One block per CU, ceil(tiles / CUs) tiles each.
+//   * backward: a block owns (row partition, 64-column slice); its 8 waves interleave over the partition's 4-row
+//     groups, lane (n, g) loads X[row + g][slice + 4 n ..] -- one dwordx4 = 4 rows x 256 contiguous bytes per
+//     instruction -- whose 4 values are the B operands of 4 MFMAs (output columns 4 n + q); A = G^T comes as two
+//     dword loads.  The per-(partition, slice) partials (2 MB for Pubmed instead of one 64 KB tile per block) are
+//     added in partition order by a second small launch, which also finishes db.
+//   * rows / tiles / slices outside the operands are addressed BEHIND the raw buffer: the bounds check returns
+//     zeros without touching memory, so the pipelines are branch-free; columns >= K are zeroed by selects (the pad
+//     columns of a row may hold anything).
+// Products: exact fp32 (v_mfma_f32_16x16x4_f32 == an fmaf chain) for fp32 storage; bf16-stored X (BASELINE config 5)
+// feeds v_mfma_f32_16x16x32_bf16 directly in the forward, with W = hi + lo split into two bf16 fragments (fp32
+// accumulation), and is widened in registers for the fp32 MFMAs of the backward.
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+using gae::v4f;
+
+constexpr int kXwMaxWaves = 8;
+constexpr unsigned kBehind = 0xF0000000u;      // byte offset behind every operand (all below 0xE0000000 bytes, xw_usable):
+                                               // the bounds check returns zeros, also with a small offset added
+
+struct XwFwdArgs {
+    const void *X;
+    const float *W, *bias;
+    float *out;
+    int64_t n, ldo, split_stride;      // out + blockIdx.y * split_stride receives this split's rows (ldo floats apart)
+    unsigned x_bytes, ldx_bytes, w_bytes;
+    int K, J, ldw, act;
+    int tiles_per_block, k_per_block;  // columns per (block, split)
+};
+
+// workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (s_waitcnt vmcnt(0)): every row tile the wave has in flight would have to land before each barrier and
+// the prefetch ring would be worth nothing.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// zero the elements of one 16-byte load that lie at or behind column K (`left` = K - first column of the load)
+template <typename TX>
+__device__ __forceinline__ u32x4 mask_tail(u32x4 v, int left)
+{
+    if constexpr (sizeof(TX) == 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = r < left ? v[r] : 0u;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[d] = 2 * d + 1 < left ? v[d] : (2 * d < left ? (v[d] & 0xffffu) : 0u);
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------- forward
+template <typename TX, int NH, int SLICE_BYTES, int DBG = 0, int DEPTH = 2>
+__global__ __launch_bounds__(64 * kXwMaxWaves) void xw_fwd_kernel(const XwFwdArgs a)
+{
+    constexpr int ES = int(sizeof(TX));
+    constexpr int NL = SLICE_BYTES / 64;            // 16-byte loads per lane and row tile
+    constexpr int KW = SLICE_BYTES / ES;            // columns of a wave's slice
+    constexpr int CPL = 16 / ES;                    // columns per 16-byte load of one lane (4 fp32 / 8 bf16)
+    // DEPTH: row tiles in flight (this one + DEPTH - 1 ahead)
+    constexpr int OUTW = 16 * NH;
+    // partial tiles of up to TC row tiles x 8 waves: the waves run their tiles WITHOUT meeting (a barrier per tile kept
+    // the two waves of a SIMD in lockstep and the matrix pipe idle while they reduced: 11 us for the MFMAs alone on
+    // Pubmed, 4.3 us of which is issue time); one barrier and one reduction per chunk of TC tiles
+    constexpr int TC = 6;
+    __shared__ __attribute__((aligned(16))) float red[TC][kXwMaxWaves][NH * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = int(blockDim.x >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int kb = int(blockIdx.y) * a.k_per_block + wave * KW;     // first column of this wave's slice
+    const bool has_k = wave * KW < a.k_per_block && kb < a.K;
+
+    // ---- the wave's slice of W as B fragments, held for the whole launch
+    //      fp32: wf[i][r][nh] = W[16 nh + l15][kb + 16 i + 4 g + r]                      (MFMA (i, r) contracts those k)
+    //      bf16: whi / wlo[i][nh] = 8 consecutive k of row 16 nh + l15 from kb + 32 i + 8 g, W = hi + lo
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W), 0, int(a.w_bytes), 0x00020000);
+    float wf[sizeof(TX) == 4 ? NL : 1][4][NH];
+    bf16x8 whi[sizeof(TX) == 2 ? NL : 1][NH], wlo[sizeof(TX) == 2 ? NL : 1][NH];
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh) {
+            const int j = 16 * nh + l15;
+            float v[CPL];
+#pragma unroll
+            for (int c4 = 0; c4 < CPL; c4 += 4) {
+                // one 16-byte raw-buffer load per 4 columns (16 rows x 64 bytes per instruction), branch-free so that
+                // the first row tiles are requested before the weights have arrived: the row's last, partial vector
+                // starts at K - 4 and is shifted into place by selects; rows >= J and slices >= K read behind the
+                // buffer (zeros)
+                const int k = kb + i * (64 / ES) + CPL * g + c4;
+                const int ku = k <= a.K - 4 ? k : a.K - 4;
+                const bool in = has_k && j < a.J && k < a.K;
+                const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(rw, in ? unsigned(j * a.ldw + ku) * 4u : kBehind, 0, 0);
+                const int sh = k - ku;                        // 0 except in the tail vector (then 1..3)
+                v[c4 + 0] = __uint_as_float(sh == 0 ? l[0] : sh == 1 ? l[1] : sh == 2 ? l[2] : l[3]);
+                v[c4 + 1] = __uint_as_float(sh == 0 ? l[1] : sh == 1 ? l[2] : sh == 2 ? l[3] : 0u);
+                v[c4 + 2] = __uint_as_float(sh == 0 ? l[2] : sh == 1 ? l[3] : 0u);
+                v[c4 + 3] = __uint_as_float(sh == 0 ? l[3] : 0u);
+            }
+            if constexpr (sizeof(TX) == 4) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wf[i][c][nh] = v[c];
+            } else {
+                gae::v4s h0, l0, h1, l1;
+                gae::split_bf16x4(v4f{v[0], v[1], v[2], v[3]}, h0, l0);
+                gae::split_bf16x4(v4f{v[4], v[5], v[6], v[7]}, h1, l1);
+                struct P { gae::v4s a, b; };
+                whi[i][nh] = __builtin_bit_cast(bf16x8, (P{h0, h1}));
+                wlo[i][nh] = __builtin_bit_cast(bf16x8, (P{l0, l1}));
+            }
+        }
+
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.X), 0, int(a.x_bytes), 0x00020000);
+    const int64_t tile0 = int64_t(blockIdx.x) * a.tiles_per_block;
+    const int64_t n_tiles = (a.n + 15) / 16;
+    const int nt = int(min<int64_t>(a.tiles_per_block, n_tiles - tile0));      // tiles of this block (>= 1)
+    const unsigned col_off = unsigned(kb + CPL * g) * ES;
+    int left[NL];                                   // columns in front of K, counted from each load's first column
+#pragma unroll
+    for (int i = 0; i < NL; ++i) left[i] = a.K - (kb + i * (64 / ES) + CPL * g);
+
+    u32x4 st[DEPTH][NL];
+    auto issue = [&](u32x4 (&s)[NL], int t) {
+        const int64_t row = (tile0 + t) * 16 + l15;
+        const bool ok = has_k && t < nt && row < a.n;
+        const unsigned base = (ok && DBG != 2) ? unsigned(row) * a.ldx_bytes + col_off : kBehind;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) s[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + unsigned(i * 64), 0, 0);
+    };
+    float *out = a.out + int64_t(blockIdx.y) * a.split_stride;
+    const bool final_pass = a.bias != nullptr || a.act != GAE_ACT_IDENTITY;     // (split launches pass neither)
+
+    auto tile = [&](const u32x4 (&s)[NL], int t) {
+        v4f acc[NH];
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh) acc[nh] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const u32x4 x = mask_tail<TX>(s[i], left[i]);
+            if constexpr (DBG == 1) {
+#pragma unroll
+                for (int nh = 0; nh < NH; ++nh) acc[nh][0] += __uint_as_float(x[0] ^ x[1] ^ x[2] ^ x[3]);
+            } else if constexpr (sizeof(TX) == 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nh = 0; nh < NH; ++nh)
+                        acc[nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(x[r]), wf[i][r][nh], acc[nh], 0, 0, 0);
+            } else {
+                const bf16x8 xa = __builtin_bit_cast(bf16x8, x);
+#pragma unroll
+                for (int nh = 0; nh < NH; ++nh) {
+                    acc[nh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, wlo[i][nh], acc[nh], 0, 0, 0);
+                    acc[nh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, whi[i][nh], acc[nh], 0, 0, 0);
+                }
+            }
+        }
+        // ---- the partial tile goes to this wave's LDS slot; chunks of TC tiles are added in wave order
+        float *mine = &red[t % TC][wave][0];
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh) *reinterpret_cast<v4f *>(mine + (nh * 64 + lane) * 4) = acc[nh];
+        if ((t + 1) % TC == 0 || t + 1 == nt) {
+            const int c0 = t / TC * TC, cnt = t + 1 - c0;
+            lds_barrier();
+            for (int e = tid; e < cnt * 16 * OUTW; e += int(blockDim.x)) {
+                const int tt = e / (16 * OUTW), o = e % (16 * OUTW);
+                const int orow = o / OUTW, ocol = o % OUTW;
+                const int idx = (((ocol >> 4) * 64) + (orow >> 2) * 16 + (ocol & 15)) * 4 + (orow & 3);
+                float v[kXwMaxWaves];
+#pragma unroll
+                for (int w = 0; w < kXwMaxWaves; ++w) v[w] = red[tt][w < nw ? w : 0][idx];      // all requested together
+                float y = v[0];
+#pragma unroll
+                for (int w = 1; w < kXwMaxWaves; ++w) y += w < nw ? v[w] : 0.f;                 // wave order
+                const int64_t r = (tile0 + c0 + tt) * 16 + orow;
+                if (r < a.n && ocol < a.J) {
+                    if (final_pass) {
+                        if (a.bias) y += a.bias[ocol];
+                        if (a.act == GAE_ACT_RELU) y = fmaxf(y, 0.f);
+                    }
+                    out[r * a.ldo + ocol] = y;
+                }
+            }
+            if (t + 1 < nt) lds_barrier();          // the next chunk overwrites the slots
+        }
+    };
+
+#define GAE_PIN() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) issue(st[d], d);
+    GAE_PIN();
+    for (int t = 0; t < nt; t += DEPTH) {
+        bool more = true;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (more) {
+                issue(st[(d + DEPTH - 1) % DEPTH], t + d + DEPTH - 1); GAE_PIN(); tile(st[d], t + d); GAE_PIN();
+                more = t + d + 1 < nt;
+            }
+        }
+    }
+#undef GAE_PIN
+}
+
+// out[r][c] = act(bias[c] + sum_s partial[s][r][c])  -- second pass of a forward that was split along K
+__global__ __launch_bounds__(256) void xw_split_reduce_kernel(const float *__restrict__ partial, int splits, int64_t n,
+                                                              int J, const float *__restrict__ bias, int act,
+                                                              float *__restrict__ out, int64_t ldo)
+{
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= n * J) return;
+    float y = 0.f;
+    for (int s = 0; s < splits; ++s) y += partial[int64_t(s) * n * J + e];     // split order
+    const int64_t r = e / J;
+    const int c = int(e - r * J);
+    if (bias) y += bias[c];
+    if (act == GAE_ACT_RELU) y = fmaxf(y, 0.f);
+    out[r * ldo + c] = y;
+}
+
+// ---------------------------------------------------------------------------------------------------- backward
+struct XtgArgs {
+    const void *X;
+    const float *G, *Gmask;            // dW = (G (.) [Gmask > 0])^T X        (Gmask may be NULL)
+    const float *D, *Dmask;            // db = colsum(D (.) [Dmask > 0])      (D may be NULL: no db)
+    float *part, *dbpart;              // part[p][32][kp], dbpart[p][32]
+    int64_t n;
+    unsigned x_bytes, ldx_bytes, g_bytes, ldg_bytes, gm_bytes, ldgm_bytes;
+    int64_t ldd, lddm;
+    int K, J, kp, n_slices, xcd_map;
+    int64_t rows_per_part;             // multiple of 32
+};
+
+template <typename TX, int NH, bool MASKED, int DBG = 0, int NS = 4, int U = 2>
+__global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
+{
+    constexpr int ES = int(sizeof(TX));
+    constexpr int NQ = 16 / ES;                     // columns per lane (4 fp32 / 8 bf16): output columns NQ n + q
+    constexpr int SW = 16 * NQ;                     // columns of a block's slice (64 / 128)
+    // U: 4-row groups per pipeline stage, NS: stages (NS - 1 of them in flight while one is multiplied)
+    constexpr int DBU = 8;                          // db: elements per thread in flight
+    __shared__ __attribute__((aligned(16))) float red[8][16 * NH][SW + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    // block -> (partition, slice): consecutive (partition, slice) pairs run on ONE XCD next to each other (bijective
+    // XCD remap of the block id), so the 256-byte pieces of a row are requested from one L2 at about the same time
+    // (with slice = id % 8 every XCD pulled its own column stripe out of every DRAM page: 18.3 -> 17.0 us on Pubmed)
+    const unsigned lid = a.xcd_map ? gae::xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int part = int(lid / unsigned(a.n_slices)), slice = int(lid % unsigned(a.n_slices));
+    const int64_t rbeg = int64_t(part) * a.rows_per_part;
+    const int64_t rend = min(a.n, rbeg + a.rows_per_part);
+
+    // ---- db: the partition's rows are dealt to its column-slice blocks; this block adds D (.) [Dmask > 0] over its
+    //      share -- element e = tid + 512 i of the share's [rows][32] array, all requested before the main loop --
+    //      and leaves 32 column sums in dbpart[partition][slice]
+    float dsum = 0.f;
+    const bool want_db = a.D != nullptr;
+    if (want_db) {
+        const int64_t share = (a.rows_per_part / 32 + a.n_slices - 1) / a.n_slices * 32;    // rows per slice block
+        const int64_t d0 = rbeg + share * slice, d1 = min(rend, d0 + share);
+        const int j = tid & 31;
+        for (int64_t r0 = d0 + (tid >> 5); r0 < d1; r0 += 16 * DBU) {
+            float dv[DBU], mv[DBU];
+#pragma unroll
+            for (int u = 0; u < DBU; ++u) {
+                const int64_t r = r0 + 16 * u;
+                const int64_t rc = r < d1 ? r : d1 - 1;                        // clamped: loads stay branch-free
+                dv[u] = j < a.J ? a.D[rc * a.ldd + j] : 0.f;
+                mv[u] = (a.Dmask != nullptr && j < a.J) ? a.Dmask[rc * a.lddm + j] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < DBU; ++u) dsum += (r0 + 16 * u < d1 && mv[u] > 0.f) ? dv[u] : 0.f;
+        }
+    }
+
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.X), 0, int(a.x_bytes), 0x00020000);
+    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.G), 0, int(a.g_bytes), 0x00020000);
+    __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.Gmask), 0,
+                                                                  a.Gmask ? int(a.gm_bytes) : 0, 0x00020000);
+    constexpr bool masked = MASKED;
+    const unsigned xcol = unsigned(slice * SW + NQ * l15) * ES;
+    v4f acc[NH][NQ];
+#pragma unroll
+    for (int mh = 0; mh < NH; ++mh)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[mh][q] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    // A = G^T: MFMA mh of a step takes output row j = NH l15 + mh from lane (l15, g) -- the NH values of a lane are
+    // adjacent in G: ONE 4- / 8-byte load per step (rows j >= J: behind the buffer)
+    struct Stage { u32x4 x[U]; unsigned gv[U][NH], gm[MASKED ? U : 1][NH]; };
+    const unsigned gcol = unsigned(NH * l15) * 4u;
+    const bool j_ok = NH * l15 < a.J;           // (J odd: the pair's second value is masked below)
+    // group `it` of this wave: rows rbeg + 4 (wave + 8 (U it + u)) + g -- the 8 waves sweep 32 consecutive rows
+    auto issue = [&](Stage &s, int64_t it) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = rbeg + 4 * (wave + 8 * (U * it + u)) + g;
+            const bool ok = row < rend;
+            s.x[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (ok && DBG != 2) ? unsigned(row) * a.ldx_bytes + xcol : kBehind, 0, 0);
+            const unsigned go = (ok && j_ok) ? unsigned(row) * a.ldg_bytes + gcol : kBehind;
+            const unsigned mo = (ok && j_ok) ? unsigned(row) * a.ldgm_bytes + gcol : kBehind;
+            if constexpr (NH == 2) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rg, go, 0, 0));
+                s.gv[u][0] = v[0]; s.gv[u][1] = v[1];
+                if (masked) {
+                    const u32x2 m = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, mo, 0, 0));
+                    s.gm[u][0] = m[0]; s.gm[u][1] = m[1];
+                }
+            } else {
+                s.gv[u][0] = __builtin_amdgcn_raw_buffer_load_b32(rg, go, 0, 0);
+                if (masked) s.gm[u][0] = __builtin_amdgcn_raw_buffer_load_b32(rm, mo, 0, 0);
+            }
+        }
+    };
+    auto compute = [&](const Stage &s) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float xv[NQ];
+            if constexpr (sizeof(TX) == 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xv[q] = __uint_as_float(s.x[u][q]);
+            } else {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    xv[2 * d] = __uint_as_float(s.x[u][d] << 16);
+                    xv[2 * d + 1] = __uint_as_float(s.x[u][d] & 0xffff0000u);
+                }
+            }
+#pragma unroll
+            for (int mh = 0; mh < NH; ++mh) {
+                const bool on = NH * l15 + mh < a.J && (!masked || __uint_as_float(s.gm[u][mh]) > 0.f);
+                const float gval = on ? __uint_as_float(s.gv[u][mh]) : 0.f;
+                if constexpr (DBG == 1) {
+                    acc[mh][0][0] += gval * (xv[0] + xv[NQ - 1]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        acc[mh][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(gval, xv[q], acc[mh][q], 0, 0, 0);
+                }
+            }
+        }
+    };
+    const int64_t groups = (rend - rbeg + 3) / 4;                               // 4-row groups of the partition
+    const int64_t my_groups = groups > wave ? (groups - wave + 7) / 8 : 0;       // ... of this wave
+    const int64_t iters = (my_groups + U - 1) / U;
+#define GAE_PIN() __builtin_amdgcn_sched_barrier(0)
+    if (iters > 0) {
+        Stage st[NS];
+#pragma unroll
+        for (int d = 0; d < NS - 1; ++d) issue(st[d], d);
+        GAE_PIN();
+        for (int64_t it = 0; it < iters; it += NS) {
+            bool more = true;
+#pragma unroll
+            for (int d = 0; d < NS; ++d) {
+                if (more) {
+                    issue(st[(d + NS - 1) % NS], it + d + NS - 1); GAE_PIN(); compute(st[d]); GAE_PIN();
+                    more = it + d + 1 < iters;
+                }
+            }
+        }
+    }
+#undef GAE_PIN
+    // ---- the 8 waves' tiles meet in LDS: acc[mh][q][r] = dW[NH (4 g + r) + mh][slice SW + NQ l15 + q]
+#pragma unroll
+    for (int mh = 0; mh < NH; ++mh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q4 = 0; q4 < NQ; q4 += 4)
+                *reinterpret_cast<v4f *>(&red[wave][NH * (4 * g + r) + mh][NQ * l15 + q4]) =
+                    v4f{acc[mh][q4][r], acc[mh][q4 + 1][r], acc[mh][q4 + 2][r], acc[mh][q4 + 3][r]};
+    __syncthreads();
+    constexpr int VPR = SW / 4;                                  // float4 per output row of the slice
+    for (int e = tid; e < 16 * NH * VPR; e += 512) {
+        const int j = e / VPR, c4 = e % VPR;
+        v4f t = *reinterpret_cast<const v4f *>(&red[0][j][4 * c4]);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) t += *reinterpret_cast<const v4f *>(&red[w][j][4 * c4]);
+        *reinterpret_cast<v4f *>(a.part + (int64_t(part) * 32 + j) * a.kp + slice * SW + 4 * c4) = t;
+    }
+    if (want_db) {
+        __syncthreads();
+        float *dred = &red[0][0][0];
+        dred[tid] = dsum;                              // [sub = tid / 32][j = tid % 32]
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += dred[q * 32 + tid];
+            a.dbpart[(int64_t(part) * a.n_slices + slice) * 32 + tid] = t;
+        }
+    }
+}
+
+// dW[j][k] = sum_p part[p][j][k],  db[j] = sum_p dbpart[p][j]     (partition order)
+__global__ __launch_bounds__(256) void xtg_reduce_kernel(const float *__restrict__ part, const float *__restrict__ dbpart,
+                                                         int parts, int db_parts, int J, int K, int kp,
+                                                         float *__restrict__ dW, int64_t lddw, float *__restrict__ db)
+{
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (dW != nullptr && e < int64_t(J) * K) {
+        const int j = int(e / K), k = int(e - int64_t(j) * K);
+        const float *p = part + int64_t(j) * kp + k;
+        float s = 0.f;
+        for (int q0 = 0; q0 < parts; q0 += 32) {  // up to 32 partials requested together (branch-free), added in order
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = p[int64_t(q0 + u < parts ? q0 + u : parts - 1) * 32 * kp];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) s += q0 + u < parts ? v[u] : 0.f;
+        }
+        dW[int64_t(j) * lddw + k] = s;
+    }
+    if (db != nullptr && blockIdx.x == gridDim.x - 1) {
+        // db: thread (grp = tid / 32, j = tid % 32) adds the partials q = grp + 8 i in order -- all of them requested
+        // together -- and the 8 groups meet in LDS in order (the serial walk over 216 partials took 7 round trips)
+        __shared__ float dred[256];
+        const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
+        float s = 0.f;
+        for (int q0 = grp; q0 < db_parts; q0 += 8 * 32) {
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = dbpart[(q0 + 8 * u < db_parts ? q0 + 8 * u : db_parts - 1) * 32 + j];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) s += q0 + 8 * u < db_parts ? v[u] : 0.f;
+        }
+        dred[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < J) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += dred[q * 32 + threadIdx.x];
+            db[threadIdx.x] = t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- plans
+struct FwdPlan { int slice_bytes, nw, splits, k_per_block, tiles_per_block; int64_t row_blocks; };
+
+gae::Knob g_xw_rows{0};       // "xw_rows": rows per block of the forward (0 = auto: one block per CU)
+gae::Knob g_xw_parts{0};      // "xw_parts": row partitions of the backward (0 = auto)
+gae::Knob g_xw{1};            // "xw": 0 = never use this family (dense.hip kernels instead)
+gae::Knob g_xw_depth{0};      // "xw_depth" (experiments): other ring depths of the fp32 kernels (forward 3 / 4 / 5 tiles, default 2;
+                              // backward (stages, groups) (2, 4) / (3, 4) / (4, 4) / (6, 2), default (4, 2))
+gae::Knob g_xw_xcd{1};        // "xw_xcd": XCD-aware block order of the backward (1) or slice-major ids (0); same sums
+gae::Knob g_xw_dbg{0};        // "xw_dbg" (experiments, wrong results): 1 = forward without MFMAs, 2 = without X loads
+
+FwdPlan fwd_plan(int64_t n, int K, int elem)
+{
+    FwdPlan p{};
+    const int kw256 = 256 / elem, kw512 = 512 / elem;
+    if (K <= 8 * kw256) { p.slice_bytes = 256; p.splits = 1; }
+    else { p.slice_bytes = 512; p.splits = (K + 8 * kw512 - 1) / (8 * kw512); }
+    const int kw = p.slice_bytes / elem;
+    const int per = (K + p.splits - 1) / p.splits;
+    p.nw = (per + kw - 1) / kw;
+    if (p.nw < 1) p.nw = 1;
+    p.k_per_block = p.nw * kw;
+    // the last split may hold fewer columns; no split may be empty
+    while (p.splits > 1 && (p.splits - 1) * p.k_per_block >= K) --p.splits;
+    const int64_t tiles = (n + 15) / 16;
+    int64_t t = g_xw_rows > 0 ? (g_xw_rows + 15) / 16 : (tiles * p.splits + 255) / 256;
+    if (t < 1) t = 1;
+    if (t > (1 << 20)) t = 1 << 20;
+    p.tiles_per_block = int(t);
+    p.row_blocks = (tiles + t - 1) / t;
+    return p;
+}
+
+struct BwdPlan { int sw, n_slices, kp, parts; int64_t rows_per_part; };
+
+BwdPlan bwd_plan(int64_t n, int K, int elem)
+{
+    BwdPlan p{};
+    p.sw = 16 * (16 / elem);
+    p.n_slices = (K + p.sw - 1) / p.sw;
+    p.kp = p.n_slices * p.sw;
+    // ONE round of blocks: slices x partitions <= CUs (a block is 8 waves of ~160 VGPRs: one per CU; 288 blocks on
+    // 256 CUs ran as two rounds, 17 -> 34 us on Pubmed)
+    int parts = g_xw_parts > 0 ? int(g_xw_parts) : 256 / p.n_slices;
+    if (parts < 1) parts = 1;
+    int64_t rpp = (n + parts - 1) / parts;
+    rpp = (rpp + 31) / 32 * 32;                    // whole sweeps of the 8 waves
+    if (rpp < 32) rpp = 32;
+    p.rows_per_part = rpp;
+    p.parts = int((n + rpp - 1) / rpp);
+    if (p.parts < 1) p.parts = 1;
+    return p;
+}
+
+} // namespace
+
+namespace gae {
+
+Knob *xw_knob(const char *name)
+{
+    if (strcmp(name, "xw_rows") == 0) return &g_xw_rows;
+    if (strcmp(name, "xw_parts") == 0) return &g_xw_parts;
+    if (strcmp(name, "xw") == 0) return &g_xw;
+    if (strcmp(name, "xw_dbg") == 0) return &g_xw_dbg;
+    if (strcmp(name, "xw_xcd") == 0) return &g_xw_xcd;
+    if (strcmp(name, "xw_depth") == 0) return &g_xw_depth;
+    return nullptr;
+}
+
+// can the stream family run these operands?  (rows of whole 16-byte vectors, X addressable through one raw buffer)
+bool xw_usable(const void *X, int64_t ldx, int64_t n, int64_t K, int64_t J, int elem)
+{
+    return g_xw != 0 && n > 0 && K >= 193 && K < (1 << 24) && J >= 1 && J <= 32 && (ldx * elem) % 16 == 0 &&
+           ldx >= K && aligned16(X) && n * ldx * elem < int64_t(0xE0000000u);
+}
+
+int64_t xw_fwd_workspace_bytes(int64_t n, int64_t K, int64_t J, int elem)
+{
+    const FwdPlan p = fwd_plan(n, int(K), elem);
+    return p.splits > 1 ? (int64_t(p.splits) * n * J * 4 + 255) / 256 * 256 : 0;
+}
+
+int xw_fwd_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const float *W, int64_t ldw, const float *bias,
+                  int J, int act, float *out, int64_t ldo, void *ws, int64_t ws_bytes, hipStream_t s)
+{
+    FwdPlan p = fwd_plan(n, K, elem);
+    if (p.splits > 1 && (ws == nullptr || ws_bytes < int64_t(p.splits) * n * J * 4)) {
+        set_error("xw_fwd: operands split along K need %lld bytes of workspace", (long long)(int64_t(p.splits) * n * J * 4));
+        return GAE_E_SIZE;
+    }
+    XwFwdArgs a{};
+    a.X = X; a.W = W; a.n = n; a.K = K; a.J = J; a.ldw = int(ldw);
+    a.x_bytes = unsigned(n * ldx * elem); a.ldx_bytes = unsigned(ldx * elem);
+    a.w_bytes = unsigned(((int64_t(J) - 1) * ldw + K) * 4);
+    a.tiles_per_block = p.tiles_per_block; a.k_per_block = p.k_per_block;
+    if (p.splits > 1) { a.bias = nullptr; a.act = GAE_ACT_IDENTITY; a.out = static_cast<float *>(ws); a.ldo = J; a.split_stride = n * J; }
+    else { a.bias = bias; a.act = act; a.out = out; a.ldo = ldo; a.split_stride = 0; }
+    const dim3 grid(unsigned(p.row_blocks), unsigned(p.splits)), block(unsigned(64 * p.nw));
+#define GAE_XW(TX, NH, SB) hipLaunchKernelGGL((xw_fwd_kernel<TX, NH, SB>), grid, block, 0, s, a)
+    const bool wide = J > 16;
+    if (elem == 4) {
+        if (p.slice_bytes == 256 && wide && g_xw_depth == 4) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, 0, 4>), grid, block, 0, s, a);
+        else if (p.slice_bytes == 256 && wide && g_xw_depth == 5) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, 0, 5>), grid, block, 0, s, a);
+        else if (p.slice_bytes == 256 && wide && g_xw_depth == 3) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, 0, 3>), grid, block, 0, s, a);
+        else if (p.slice_bytes == 256 && wide && g_xw_dbg == 1) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, 1>), grid, block, 0, s, a);
+        else if (p.slice_bytes == 256 && wide && g_xw_dbg == 2) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, 2>), grid, block, 0, s, a);
+        else if (p.slice_bytes == 256) { if (wide) GAE_XW(float, 2, 256); else GAE_XW(float, 1, 256); }
+        else { if (wide) GAE_XW(float, 2, 512); else GAE_XW(float, 1, 512); }
+    } else {
+        if (p.slice_bytes == 256) { if (wide) GAE_XW(unsigned short, 2, 256); else GAE_XW(unsigned short, 1, 256); }
+        else { if (wide) GAE_XW(unsigned short, 2, 512); else GAE_XW(unsigned short, 1, 512); }
+    }
+#undef GAE_XW
+    GAE_CHECK_LAUNCH("xw_fwd_kernel");
+    if (p.splits > 1) {
+        const int64_t ne = n * J;
+        hipLaunchKernelGGL(xw_split_reduce_kernel, dim3(unsigned((ne + 255) / 256)), dim3(256), 0, s,
+                           static_cast<const float *>(ws), p.splits, n, J, bias, act, out, ldo);
+        GAE_CHECK_LAUNCH("xw_split_reduce_kernel");
+    }
+    return GAE_OK;
+}
+
+int64_t xtg_workspace_bytes(int64_t n, int64_t K, int elem)
+{
+    const BwdPlan p = bwd_plan(n, int(K), elem);
+    return (int64_t(p.parts) * 32 * p.kp + int64_t(p.parts) * (p.n_slices + 1) * 32) * 4 + 256;
+}
+
+int xtg_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const float *G, int64_t ldg, const float *Gmask,
+               int64_t ldgm, const float *D, int64_t ldd, const float *Dmask, int64_t lddm, int J, float *dW,
+               int64_t lddw, float *db, void *ws, int64_t ws_bytes, hipStream_t s)
+{
+    const BwdPlan p = bwd_plan(n, K, elem);
+    if (ws == nullptr || ws_bytes < xtg_workspace_bytes(n, K, elem)) {
+        set_error("xtg: workspace of %lld bytes needed", (long long)xtg_workspace_bytes(n, K, elem));
+        return GAE_E_SIZE;
+    }
+    XtgArgs a{};
+    a.X = X; a.G = G; a.Gmask = Gmask; a.D = db ? D : nullptr; a.Dmask = Dmask;
+    a.part = static_cast<float *>(ws);
+    a.dbpart = a.part + int64_t(p.parts) * 32 * p.kp;
+    a.n = n; a.K = K; a.J = J; a.kp = p.kp; a.n_slices = p.n_slices; a.rows_per_part = p.rows_per_part;
+    a.x_bytes = unsigned(n * ldx * elem); a.ldx_bytes = unsigned(ldx * elem);
+    a.g_bytes = unsigned(n * ldg * 4); a.ldg_bytes = unsigned(ldg * 4);
+    a.gm_bytes = unsigned(n * ldgm * 4); a.ldgm_bytes = unsigned(ldgm * 4);
+    a.ldd = ldd; a.lddm = lddm;
+    const bool want_dw = dW != nullptr, want_db = db != nullptr && D != nullptr;
+    if (!want_db) a.D = nullptr;
+    if (!want_dw) { a.x_bytes = 0; a.g_bytes = 0; a.gm_bytes = 0; a.Gmask = nullptr; }     // every load behind its buffer: zeros
+    // (db alone still sweeps the slices: its rows are dealt to the slice blocks; the products of an unwanted dW go to
+    // the workspace and are not reduced)
+    a.xcd_map = g_xw_xcd != 0;
+    const dim3 grid(unsigned(p.n_slices) * unsigned(p.parts));
+    const bool wide = J > 16;
+#define GAE_XTG(TX, NH, ...) do { if (a.Gmask) hipLaunchKernelGGL((xtg_kernel<TX, NH, true, __VA_ARGS__>), grid, dim3(512), 0, s, a); \
+                                   else hipLaunchKernelGGL((xtg_kernel<TX, NH, false, __VA_ARGS__>), grid, dim3(512), 0, s, a); } while (0)
+    if (elem == 4) {
+        if (wide && g_xw_dbg == 1) GAE_XTG(float, 2, 1);
+        else if (wide && g_xw_dbg == 2) GAE_XTG(float, 2, 2);
+        else if (wide && g_xw_depth == 2) GAE_XTG(float, 2, 0, 2, 4);
+        else if (wide && g_xw_depth == 4) GAE_XTG(float, 2, 0, 4, 4);
+        else if (wide && g_xw_depth == 3) GAE_XTG(float, 2, 0, 3, 4);
+        else if (wide && g_xw_depth == 6) GAE_XTG(float, 2, 0, 6, 2);
+        else if (wide) GAE_XTG(float, 2, 0);
+        else GAE_XTG(float, 1, 0);
+    } else {
+        if (wide) GAE_XTG(unsigned short, 2, 0); else GAE_XTG(unsigned short, 1, 0);
+    }
+#undef GAE_XTG
+    GAE_CHECK_LAUNCH("xtg_kernel");
+    const int64_t ne = want_dw ? int64_t(J) * K : 1;
+    hipLaunchKernelGGL(xtg_reduce_kernel, dim3(unsigned((ne + 255) / 256)), dim3(256), 0, s, a.part, a.dbpart, p.parts,
+                       p.parts * p.n_slices, J, K, p.kp, want_dw ? dW : nullptr, lddw, want_db ? db : nullptr);
+    GAE_CHECK_LAUNCH("xtg_reduce_kernel");
+    return GAE_OK;
+}
+
+} // namespace gae
+
+// ---------------------------------------------------------------------------------------------------- C ABI
+extern "C" int gae_xw_usable(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in, int64_t f_out)
+{
+    if (dtype != GAE_F32 && dtype != GAE_BF16) return 0;
+    return gae::xw_usable(X, ldx, n, f_in, f_out, dtype == GAE_F32 ? 4 : 2) ? 1 : 0;
+}
+
+extern "C" int64_t gae_xw_fwd_workspace_bytes(int64_t n, int64_t f_in, int64_t f_out, int dtype)
+{
+    if (n < 0 || f_in < 1 || f_out < 1 || f_out > 32 || f_in >= (1 << 24) || (dtype != GAE_F32 && dtype != GAE_BF16))
+        return GAE_E_SIZE;
+    return gae::xw_fwd_workspace_bytes(n, f_in, f_out, dtype == GAE_F32 ? 4 : 2);
+}
+
+extern "C" int gae_xw_fwd(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in, const float *W, int64_t ldw,
+                          const float *b, int64_t f_out, int act, float *P, int64_t ldp, void *workspace,
+                          int64_t workspace_bytes, void *stream)
+{
+    GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16, GAE_E_DTYPE, "gae_xw_fwd: dtype %d", dtype);
+    GAE_REQUIRE(n >= 0 && f_in >= 0 && f_out >= 0, GAE_E_SIZE, "gae_xw_fwd: negative size");
+    GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_DTYPE, "gae_xw_fwd: activation %d", act);
+    if (n == 0 || f_out == 0) return GAE_OK;
+    GAE_REQUIRE(X && W && P, GAE_E_NULL, "gae_xw_fwd: NULL pointer");
+    GAE_REQUIRE(ldw >= f_in && ldp >= f_out, GAE_E_SIZE, "gae_xw_fwd: leading dimension too small");
+    const int elem = dtype == GAE_F32 ? 4 : 2;
+    GAE_REQUIRE(gae::xw_usable(X, ldx, n, f_in, f_out, elem), GAE_E_RANGE,
+                "gae_xw_fwd: needs f_in >= 193, f_out <= 32, rows of whole 16-byte vectors and X below 4 GiB "
+                "(gae_xw_usable); use gae_linear_fwd");
+    GAE_REQUIRE(!workspace || gae::aligned16(workspace), GAE_E_ALIGN, "gae_xw_fwd: workspace not 16-byte aligned");
+    return gae::xw_fwd_launch(X, ldx, n, int(f_in), elem, W, ldw, b, int(f_out), act, P, ldp, workspace, workspace_bytes,
+                              gae::as_stream(stream));
+}
+
+extern "C" int64_t gae_xw_wgrad_workspace_bytes(int64_t n, int64_t f_in, int dtype)
+{
+    if (n < 0 || f_in < 1 || f_in >= (1 << 24) || (dtype != GAE_F32 && dtype != GAE_BF16)) return GAE_E_SIZE;
+    return gae::xtg_workspace_bytes(n, f_in, dtype == GAE_F32 ? 4 : 2);
+}
+
+extern "C" int gae_xw_wgrad(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in, const float *G, int64_t ldg,
+                            const float *Gmask, int64_t ldgm, const float *D, int64_t ldd, const float *Dmask,
+                            int64_t lddm, int64_t f_out, float *dW, int64_t lddw, float *db, void *workspace,
+                            int64_t workspace_bytes, void *stream)
+{
+    GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16, GAE_E_DTYPE, "gae_xw_wgrad: dtype %d", dtype);
+    GAE_REQUIRE(n >= 0 && f_in >= 0 && f_out >= 0, GAE_E_SIZE, "gae_xw_wgrad: negative size");
+    if (f_out == 0 || (!dW && !db)) return GAE_OK;
+    GAE_REQUIRE(n > 0, GAE_E_SIZE, "gae_xw_wgrad: needs at least one row");
+    GAE_REQUIRE(!dW || (X && G && ldg >= f_out && lddw >= f_in), GAE_E_NULL, "gae_xw_wgrad: dW needs X, G and lddw >= f_in");
+    GAE_REQUIRE(!Gmask || ldgm >= f_out, GAE_E_SIZE, "gae_xw_wgrad: ldgm < f_out");
+    GAE_REQUIRE(!db || (D && ldd >= f_out && (!Dmask || lddm >= f_out)), GAE_E_NULL, "gae_xw_wgrad: db needs D");
+    const int elem = dtype == GAE_F32 ? 4 : 2;
+    GAE_REQUIRE(!dW || gae::xw_usable(X, ldx, n, f_in, f_out, elem), GAE_E_RANGE,
+                "gae_xw_wgrad: needs f_in >= 193, f_out <= 32, rows of whole 16-byte vectors and X below 4 GiB "
+                "(gae_xw_usable); use gae_linear_bwd");
+    GAE_REQUIRE(n * ldg * 4 < int64_t(0xE0000000u) && (!Gmask || n * ldgm * 4 < int64_t(0xE0000000u)), GAE_E_SIZE,
+                "gae_xw_wgrad: G larger than a raw buffer resource addresses");
+    GAE_REQUIRE(workspace && gae::aligned16(workspace), GAE_E_ALIGN, "gae_xw_wgrad: workspace missing or not 16-byte aligned");
+    return gae::xtg_launch(X, ldx, n, int(f_in), elem, G, ldg, Gmask, ldgm, D, ldd, Dmask, lddm, int(f_out), dW, lddw, db,
+                           workspace, workspace_bytes, gae::as_stream(stream));
+}

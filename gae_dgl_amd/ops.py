@@ -1004,6 +1004,166 @@ def gcn_layer(graph, H, W, b, act, use_norm=False):
     return GCNLayerFusedFunction.apply(Hc, W, b, graph, use_norm, act)
 
 
+# ------------------------------------------------------------------ transform-first GCN layer (wide in, narrow out)
+def xw_usable(X, n_out):
+    """can gae_xw_fwd / gae_xw_wgrad take this operand?  (fp32 or bf16 rows of whole 16-byte vectors, f_in >= 193,
+    f_out <= 32, X below 3.5 GiB)"""
+    if not isinstance(X, torch.Tensor) or not X.is_cuda or X.dim() != 2 or X.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    if X.shape[0] == 0 or X.stride(1) != 1:
+        return False
+    return bool(_lib.load().gae_xw_usable(_ptr(X), X.stride(0), _dtype_code(X), X.shape[0], X.shape[1], int(n_out)))
+
+
+def xw_fwd_raw(X, W, b, act):
+    """P = act(X W^T + b) with X read once and W stationary in registers (gae_xw_fwd); X fp32 or bf16 storage"""
+    W = _f32(_gpu(W, "W"), "xw_fwd: W")
+    if W.stride(1) != 1:
+        W = W.contiguous()
+    _f32(b, "xw_fwd: b")
+    n, f_in = X.shape
+    f_out = W.shape[0]
+    code = _dtype_code(X)
+    P = torch.empty(n, f_out, dtype=torch.float32, device=X.device)
+    with _on_device(X.device):
+        nbytes = _lib.load().gae_xw_fwd_workspace_bytes(n, f_in, f_out, code)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "gae_xw_fwd_workspace_bytes")
+        ws = _workspace(nbytes, X.device) if nbytes > 0 else None
+
+        def launch():
+            _lib.call("gae_xw_fwd", _ptr(X), X.stride(0), code, n, f_in, _ptr(W), W.stride(0), _ptr(b), f_out, int(act),
+                      _ptr(P), max(f_out, 1), _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+        if profiler is not None:
+            profiler.wrap(("xw_fwd", n, f_in, f_out, str(X.dtype)), launch)
+        else:
+            launch()
+    return P
+
+
+def xw_wgrad_raw(X, G, Gmask, D, Dmask, f_out, need_dW=True, need_db=True):
+    """(dW [f_out, f_in] = (G (.) [Gmask > 0])^T X, db [f_out] = colsum(D (.) [Dmask > 0])) in one pass over X
+    (gae_xw_wgrad); masks may be None"""
+    n, f_in = X.shape
+    code = _dtype_code(X)
+    dev = X.device
+    G, ldg = _rowmajor(_f32(G, "xw_wgrad: G"), "G")
+    ldgm = ldd = lddm = 0
+    if Gmask is not None:
+        Gmask, ldgm = _rowmajor(_f32(Gmask, "xw_wgrad: Gmask"), "Gmask")
+    if D is not None:
+        D, ldd = _rowmajor(_f32(D, "xw_wgrad: D"), "D")
+    if Dmask is not None:
+        Dmask, lddm = _rowmajor(_f32(Dmask, "xw_wgrad: Dmask"), "Dmask")
+    dW = torch.empty(f_out, f_in, dtype=torch.float32, device=dev) if need_dW else None
+    db = torch.empty(f_out, dtype=torch.float32, device=dev) if need_db and D is not None else None
+    with _on_device(dev):
+        ws = _workspace(_lib.load().gae_xw_wgrad_workspace_bytes(n, f_in, code), dev)
+
+        def launch():
+            _lib.call("gae_xw_wgrad", _ptr(X), X.stride(0), code, n, f_in, _ptr(G), ldg, _ptr(Gmask), ldgm, _ptr(D), ldd,
+                      _ptr(Dmask), lddm, int(f_out), _ptr(dW), max(f_in, 1), _ptr(db), _ptr(ws), ws.numel(), _stream())
+        if profiler is not None:
+            profiler.wrap(("xw_wgrad", n, f_in, f_out, str(X.dtype)), launch)
+        else:
+            launch()
+    return dW, db
+
+
+def spmm_epilogue_raw(indptr, indices, H, n_rows, plan, bias=None, act=ACT_IDENTITY, Hmask=None, row_scale=None,
+                      col_scale=None):
+    """Y = act(diag(rs) A diag(cs) (H (.) [Hmask > 0]) + bias) in one launch of the packed-table kernel
+    (gae_spmm_csr_epilogue); H fp32 [n_cols, F <= 64] with rows of whole 16-byte vectors"""
+    H, ldh = _rowmajor(_f32(_gpu(H, "H"), "spmm_epilogue: H"), "H")
+    if ldh % 4 or H.data_ptr() % 16:
+        H = pad_rows(H); ldh = H.stride(0)
+    n_cols, F = H.shape
+    if Hmask is not None:
+        Hmask, ldk = _rowmajor(_f32(_gpu(Hmask, "Hmask"), "spmm_epilogue: Hmask"), "Hmask")
+        if ldk != ldh or Hmask.data_ptr() % 16:
+            buf = torch.empty(n_cols, ldh, dtype=torch.float32, device=H.device)[:, :F]
+            buf.copy_(Hmask)
+            Hmask = buf
+    _f32(bias, "spmm_epilogue: bias")
+    ldy = (F + 3) // 4 * 4
+    Y = torch.empty(n_rows, ldy, dtype=torch.float32, device=H.device)[:, :F]
+    with _on_device(H.device):
+        def launch():
+            _lib.call("gae_spmm_csr_epilogue", _ptr(indptr), _ptr(indices), n_rows, n_cols, _ptr(H), ldh, _ptr(Hmask),
+                      _ptr(Y), ldy, F, _ptr(row_scale), _ptr(col_scale), ctypes.byref(plan.c), _ptr(bias), int(act),
+                      _stream())
+        if profiler is not None:
+            profiler.wrap(("spmm", n_rows, n_cols, F, str(H.dtype)), launch)
+        else:
+            launch()
+    return Y
+
+
+def _table_only(plan):
+    return plan is not None and plan.ell is not None and plan.n_heavy == 0 and plan.homed is None
+
+
+def gcn_transform_first_usable(graph, H, n_out):
+    """can GCNTransformFirstFunction run this layer?  A layer that narrows wide features (gae_xw_usable), on a graph
+    whose plans carry a packed neighbour table and no heavy rows (every citation / molecule graph)"""
+    if not xw_usable(H, n_out) or graph.number_of_edges() == 0:
+        return False
+    n = graph.number_of_nodes()
+    if n != H.shape[0] or n * ((n_out + 3) // 4 * 4) * 4 + (1 << 16) >= (1 << 32):
+        return False
+    return _table_only(graph.spmm_plan(False)) and _table_only(graph.spmm_plan(True))
+
+
+class GCNTransformFirstFunction(torch.autograd.Function):
+    """GCN.forward (gae.py:26-31) of a layer that narrows its features, evaluated as Y = act(A (H W^T) + b) -- the
+    value of the reference's act((A H) W^T + b) up to fp32 rounding -- in three launches forward (gae_xw_fwd,
+    gae_spmm_csr_epilogue) and backward (gae_spmm_csr_epilogue on A^T with the ReLU gate in the gather,
+    gae_xw_wgrad): H is read once per direction and nothing of the input width is written."""
+
+    @staticmethod
+    def forward(ctx, H, W, b, graph, use_norm, act):
+        indptr, indices = graph.csr()
+        norm = graph.norm() if use_norm else None
+        n = graph.number_of_nodes()
+        P = xw_fwd_raw(H, W, None, ACT_IDENTITY)
+        Y = spmm_epilogue_raw(indptr, indices, P, n, graph.spmm_plan(False), b, act, None, norm, norm)
+        ctx.act, ctx.has_bias = act, b is not None
+        ctx.bwd = (graph.csc(), n, norm, graph.spmm_plan(True))
+        ctx.save_for_backward(H, W, Y if act == ACT_RELU else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        H, W, Y = ctx.saved_tensors
+        (t_indptr, t_indices), n, norm, plan_t = ctx.bwd
+        need_dH, need_dW = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dW = db = dH = None
+        dYc, _ = _rowmajor(_f32(dY, "dY"), "dY")
+        G = None
+        if need_dH or need_dW:
+            G = spmm_epilogue_raw(t_indptr, t_indices, dYc, n, plan_t, None, ACT_IDENTITY, Y, norm, norm)   # A^T dYm
+        if need_dW or need_db:
+            dW, db = xw_wgrad_raw(H, G if need_dW else dYc, None, dYc if need_db else None, Y, W.shape[0],
+                                  need_dW=need_dW, need_db=need_db)
+        if need_dH:
+            if H.dtype != torch.float32:
+                raise GaeHipError("transform-first layer: a bf16-stored input cannot receive a gradient")
+            _, _, dH = linear_bwd_raw(G, None, ACT_IDENTITY, H, W, False, False, True)      # dH = G W
+        return dH, dW, db, None, None, None
+
+
+def gcn_layer_transform_first(graph, H, W, b, act, use_norm=False):
+    """the layer as GCNTransformFirstFunction, or None when the shapes / the graph do not allow it"""
+    if not isinstance(H, torch.Tensor) or not H.is_cuda:
+        return None
+    if H.dtype == torch.float32 and (H.stride(1) != 1 or H.stride(0) % 4 or H.data_ptr() % 16):
+        H = pad_rows(H)
+    if not gcn_transform_first_usable(graph, H, W.shape[0]):
+        return None
+    return GCNTransformFirstFunction.apply(H, W, b, graph, use_norm, act)
+
+
 class LinearFunction(torch.autograd.Function):
     """NodeApplyModule: act(M W^T + b)  (gae.py:13-16)."""
 

@@ -284,6 +284,42 @@ int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices, int64_t n
                         int64_t J, int act, float *Y, int64_t ldy, void *stream);
 
 
+/* ---- transform-first GCN layer ----------------------------------------------
+ * GCN.forward (gae_dgl/gae.py:26-31) computes act((A H) W^T + b): update_all at the INPUT width, then the Linear.
+ * For a layer that narrows the features (layer 1: 500 / 1433 / 3703 -> 32) the same value -- up to fp32 rounding,
+ * measured 2e-7 of the scale -- is act(A (H W^T) + b): one dense pass over H at full HBM rate, the aggregation at
+ * the OUTPUT width, nothing of width f_in written (the reference's order writes M = A H, 39 MB on Pubmed, and reads
+ * it twice).  Three launches forward, three backward:
+ *   forward   P = H W^T                         gae_xw_fwd        (W stationary in registers, H read once)
+ *             Y = act(rs A cs P + b)            gae_spmm_csr_epilogue   (bias + activation at store time)
+ *   backward  G = rs A^T cs (dY (.) [Y > 0])    gae_spmm_csr_epilogue on the CSR of A^T, Hmask = Y
+ *             dW = G^T H, db = colsum(dY (.) [Y > 0])            gae_xw_wgrad   (H read once)
+ * gae_xw_fwd / gae_xw_wgrad take fp32 or bf16-stored H (dtype GAE_F32 / GAE_BF16; bf16 rows feed
+ * v_mfma_f32_16x16x32_bf16 directly in the forward, W split into hi + lo bf16 fragments, fp32 accumulation) with
+ * f_in >= 193, f_out <= 32, rows of whole 16-byte vectors, H below 3.5 GiB (gae_xw_usable says whether a call is
+ * accepted; other shapes: gae_linear_fwd / gae_linear_bwd, which use the same kernels where they apply).
+ *   gae_xw_fwd:   P [n, f_out] (ldp) = act(X W^T + b); W [f_out, f_in] (ldw), b may be NULL.  workspace:
+ *                 gae_xw_fwd_workspace_bytes (0 unless f_in is split over thread blocks: f_in > 1024 fp32 / 2048 bf16).
+ *   gae_xw_wgrad: dW [f_out, f_in] (lddw) = (G (.) [Gmask > 0])^T X   (Gmask may be NULL; dW may be NULL)
+ *                 db [f_out] = colsum(D (.) [Dmask > 0])              (db / D / Dmask may be NULL)
+ *                 partial sums per (row partition, column slice) are added in partition order: deterministic.
+ *   gae_spmm_csr_epilogue: Y = act(rs A cs (H (.) [Hmask > 0]) + bias); Hmask (may be NULL) has the layout of H;
+ *                 F <= 64, fp32, a plan with a packed neighbour table and no heavy / XCD-pinned rows; CSR-order sums. */
+int gae_xw_usable(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in, int64_t f_out);
+int64_t gae_xw_fwd_workspace_bytes(int64_t n, int64_t f_in, int64_t f_out, int dtype);
+int gae_xw_fwd(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in,
+               const float *W, int64_t ldw, const float *b, int64_t f_out, int act,
+               float *P, int64_t ldp, void *workspace, int64_t workspace_bytes, void *stream);
+int64_t gae_xw_wgrad_workspace_bytes(int64_t n, int64_t f_in, int dtype);
+int gae_xw_wgrad(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in,
+                 const float *G, int64_t ldg, const float *Gmask, int64_t ldgm,
+                 const float *D, int64_t ldd, const float *Dmask, int64_t lddm, int64_t f_out,
+                 float *dW, int64_t lddw, float *db, void *workspace, int64_t workspace_bytes, void *stream);
+int gae_spmm_csr_epilogue(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                          const float *H, int64_t ldh, const float *Hmask, float *Y, int64_t ldy, int64_t F,
+                          const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
+                          const float *bias, int act, void *stream);
+
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16
  * M [n, f_in] (ldm), W [f_out, f_in] row-major contiguous (nn.Linear.weight,

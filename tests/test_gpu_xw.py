@@ -1,0 +1,205 @@
+"""The one-pass layer-1 kernels (csrc/xw.hip, gae_spmm_csr_epilogue) and the transform-first GCN layer built from
+them: P = X W^T with W stationary, dW = G^T X in one pass over X, the sparse half with bias / activation / ReLU gate --
+each against an fp64 restatement, and the whole layer against the oracle's reference-order step (gae.py:26-31)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = a.detach().double().cpu(); b = torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def rand_graph(rng, n, e):
+    a = rng.integers(0, n, e); b = rng.integers(0, n, e)
+    return np.concatenate([a, b]).astype(np.int64), np.concatenate([b, a]).astype(np.int64)
+
+
+SHAPES = [(19717, 500, 32), (2708, 1433, 32), (3327, 3703, 32), (1000, 200, 16), (777, 300, 7), (5, 260, 32),
+          (16, 1025, 3), (4100, 513, 17)]
+
+
+@pytest.mark.parametrize("n,K,J", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_xw_fwd_matches_fp64(n, K, J, dtype, tuning):
+    """gae_xw_fwd: P = act(X W^T + b) for fp32 and bf16-stored X, every slice / split / tail shape; pad columns of X
+    hold NaN (the kernel must never let them reach a sum)"""
+    from gae_dgl_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(n + K)
+    X = torch.randn(n, K, generator=g)
+    W = torch.randn(J, K, generator=g) / K ** 0.5
+    b = torch.randn(J, generator=g)
+    Xd = X.to(DEV).to(dtype)
+    ld = ops.padded_ld(K, dtype)
+    buf = torch.full((n, ld), float("nan"), dtype=dtype, device=DEV)
+    buf[:, :K] = Xd
+    Xp = buf[:, :K]
+    assert ops.xw_usable(Xp, J)
+    ref_x = Xd.double().cpu()                                      # the values as stored
+    tol = TOL if dtype == torch.float32 else 3e-5                  # bf16 rows: W = hi + lo carries 16 mantissa bits
+    for act, bias in ((0, None), (1, b.to(DEV))):
+        P = ops.xw_fwd_raw(Xp, W.to(DEV), bias, act)
+        ref = ref_x @ W.double().t() + (b.double() if bias is not None else 0)
+        if act:
+            ref = torch.relu(ref)
+        assert P.shape == (n, J) and rel(P, ref) < tol
+    if n >= 1000:                                                  # other rows-per-block choices: same sums per tile
+        P0 = ops.xw_fwd_raw(Xp, W.to(DEV), None, 0)
+        tuning("xw_rows", 16)
+        P1 = ops.xw_fwd_raw(Xp, W.to(DEV), None, 0)
+        assert torch.equal(P0, P1)
+
+
+@pytest.mark.parametrize("n,K,J", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_xw_wgrad_matches_fp64(n, K, J, dtype, tuning):
+    """gae_xw_wgrad: dW = (G (.) [Gmask > 0])^T X and db = colsum(D (.) [Dmask > 0]); masks optional; partition count
+    changes the association only"""
+    from gae_dgl_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3 * n + K)
+    X = torch.randn(n, K, generator=g)
+    G = torch.randn(n, J, generator=g)
+    M = torch.randn(n, J, generator=g)
+    D = torch.randn(n, J, generator=g)
+    Xd = X.to(DEV).to(dtype)
+    ld = ops.padded_ld(K, dtype)
+    buf = torch.full((n, ld), float("nan"), dtype=dtype, device=DEV)
+    buf[:, :K] = Xd
+    Xp = buf[:, :K]
+    ref_x = Xd.double().cpu()
+    Gd, Md, Dd = G.to(DEV), M.to(DEV), D.to(DEV)
+    dW, db = ops.xw_wgrad_raw(Xp, Gd, Md, Dd, Md, J)
+    gm = G.double() * (M > 0)
+    assert rel(dW, gm.t() @ ref_x) < TOL and rel(db, (D.double() * (M > 0)).sum(0)) < TOL
+    dW2, db2 = ops.xw_wgrad_raw(Xp, Gd, None, Dd, None, J)
+    assert rel(dW2, G.double().t() @ ref_x) < TOL and rel(db2, D.double().sum(0)) < TOL
+    dW3, none = ops.xw_wgrad_raw(Xp, Gd, None, None, None, J)
+    assert none is None and torch.equal(dW3, dW2)
+    _, db4 = ops.xw_wgrad_raw(Xp, Gd, None, Dd, Md, J, need_dW=False)
+    assert torch.equal(db4, db)
+    tuning("xw_parts", 3)
+    dW5, _ = ops.xw_wgrad_raw(Xp, Gd, Md, Dd, Md, J)
+    assert rel(dW5, gm.t() @ ref_x) < TOL
+
+
+@pytest.mark.parametrize("F", [32, 16, 7, 48])
+@pytest.mark.parametrize("norm", [False, True])
+def test_spmm_epilogue_bias_act_and_gate(F, norm):
+    """gae_spmm_csr_epilogue: act(rs A cs H + b) equals the plain product followed by bias / ReLU bit for bit, and the
+    gated gather equals the plain product of the pre-gated operand bit for bit (CSR-order sums in both)"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops
+    rng = np.random.default_rng(F)
+    n = 3000
+    src, dst = rand_graph(rng, n, 9000)
+    src[:40] = 5                                                   # a row longer than the table (CSR continuation)
+    gr = G.DGLGraph((src, dst), num_nodes=n).to(DEV)
+    H = torch.randn(n, F, device=DEV)
+    Y = torch.randn(n, F, device=DEV)
+    b = torch.randn(F, device=DEV)
+    ip, ix = gr.csr()
+    tp, tx = gr.csc()
+    nv = gr.norm() if norm else None
+    plain = ops.spmm_raw(ip, ix, ops.pad_rows(H), n, nv, nv, plan=gr.spmm_plan(False))
+    out = ops.spmm_epilogue_raw(ip, ix, H, n, gr.spmm_plan(False), b, 1, None, nv, nv)
+    assert torch.equal(out, torch.relu(plain + b))
+    out = ops.spmm_epilogue_raw(ip, ix, H, n, gr.spmm_plan(False), None, 0, None, nv, nv)
+    assert torch.equal(out, plain)
+    gated = ops.spmm_epilogue_raw(tp, tx, H, n, gr.spmm_plan(True), None, 0, Y, nv, nv)
+    ref = ops.spmm_raw(tp, tx, ops.pad_rows(H * (Y > 0)), n, nv, nv, plan=gr.spmm_plan(True))
+    assert torch.equal(gated, ref)
+
+
+@pytest.mark.parametrize("hidden,F_in", [([32, 16], 300), ([24], 260), ([32, 20, 8], 500)])
+@pytest.mark.parametrize("norm", ["none", "both"])
+def test_transform_first_layer_matches_reference_order_oracle(hidden, F_in, norm):
+    """the default ("auto") evaluation order of a wide layer 1, act(A (X W^T) + b), against the oracle's
+    reference-order step act((A X) W^T + b) (gae.py:26-31): embeddings, loss and every parameter gradient within the
+    fp32 tolerance -- and bit-identical state-dict keys / side effects on g.ndata"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops
+    from oracle import gae_oracle as O
+    rng = np.random.default_rng(len(hidden) + F_in)
+    n = 700
+    src, dst = rand_graph(rng, n, 1600)
+    X = (rng.random((n, F_in)) < 0.1).astype(np.float32) * rng.random((n, F_in)).astype(np.float32)
+    torch.manual_seed(1)
+    model = G.GAE(F_in, hidden, norm=norm).to(DEV)
+    assert model.layers[0].transform_auto and not model.layers[0].transform_first
+    model.decoder.dropout = 0.0
+    gr = G.DGLGraph((src, dst), num_nodes=n).to(DEV)
+    gr.ndata['h'] = torch.from_numpy(X).to(DEV)
+    calls = []
+    orig = ops.xw_fwd_raw
+    ops.xw_fwd_raw = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        loss = model.reconstruction_loss(gr)
+    finally:
+        ops.xw_fwd_raw = orig
+    assert len(calls) == 1, "the one-pass layer did not run"
+    loss.backward()
+    Ws = [l.apply_mod.linear.weight.detach().cpu().numpy() for l in model.layers]
+    bs = [l.apply_mod.linear.bias.detach().cpu().numpy() for l in model.layers]
+    nv = None
+    if norm == "both":
+        deg = np.bincount(dst, minlength=n).astype(np.float64)
+        nv = np.where(deg > 0, deg ** -0.5, 0.0)
+    ref_loss, Z, _, dW, db = O.gae_loss_and_grads(src, dst, n, X.astype(np.float64), [w.astype(np.float64) for w in Ws],
+                                                  [b.astype(np.float64) for b in bs], norm=nv)
+    assert rel(gr.ndata['h'], Z) < TOL and abs(float(loss) - float(ref_loss)) < TOL * abs(float(ref_loss))
+    for l, w, b in zip(model.layers, dW, db):
+        assert rel(l.apply_mod.linear.weight.grad, w) < 5 * TOL and rel(l.apply_mod.linear.bias.grad, b) < 5 * TOL
+    # transform_first=False keeps the reference's order (and the dense kernels of that order agree too)
+    torch.manual_seed(1)
+    ref_model = G.GAE(F_in, hidden, norm=norm, transform_first=False).to(DEV)
+    ref_model.decoder.dropout = 0.0
+    gr.ndata['h'] = torch.from_numpy(X).to(DEV)
+    z2 = ref_model.encode(gr)
+    assert 'h' not in gr.ndata and rel(z2, Z) < TOL
+
+
+def test_transform_first_hidden_layer_input_gradient():
+    """a narrowing HIDDEN layer (256 -> 16) also takes the one-pass route and hands the right gradient upstream"""
+    import gae_dgl_amd as G
+    from oracle import gae_oracle as O
+    rng = np.random.default_rng(9)
+    n, F_in, hidden = 500, 64, [256, 16]
+    src, dst = rand_graph(rng, n, 1200)
+    X = rng.standard_normal((n, F_in)).astype(np.float32)
+    torch.manual_seed(2)
+    model = G.GAE(F_in, hidden).to(DEV)
+    model.decoder.dropout = 0.0
+    gr = G.DGLGraph((src, dst), num_nodes=n).to(DEV)
+    gr.ndata['h'] = torch.from_numpy(X).to(DEV)
+    loss = model.reconstruction_loss(gr)
+    loss.backward()
+    Ws = [l.apply_mod.linear.weight.detach().cpu().double().numpy() for l in model.layers]
+    bs = [l.apply_mod.linear.bias.detach().cpu().double().numpy() for l in model.layers]
+    ref_loss, Z, _, dW, db = O.gae_loss_and_grads(src, dst, n, X.astype(np.float64), Ws, bs)
+    assert rel(gr.ndata['h'], Z) < TOL
+    for l, w, b in zip(model.layers, dW, db):
+        assert rel(l.apply_mod.linear.weight.grad, w) < 5 * TOL and rel(l.apply_mod.linear.bias.grad, b) < 5 * TOL
+
+
+def test_linear_forward_uses_the_stream_family():
+    """gae_linear_fwd on a wide operand (the reference-order layer 1: Linear on M = A X) runs gae_xw_fwd's kernel: equal
+    bit for bit; gae_linear_bwd and gae_xw_wgrad agree within the fp32 tolerance (different kernels, both kept)"""
+    from gae_dgl_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n, K, J = 5000, 500, 32
+    M = ops.pad_rows(torch.randn(n, K, generator=g).to(DEV))
+    W = (torch.randn(J, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(J, generator=g).to(DEV)
+    Y = ops.linear_fwd_raw(M, W, b, 1)
+    assert torch.equal(Y, ops.xw_fwd_raw(M, W, b, 1))
+    dY = torch.randn(n, J, generator=g).to(DEV)
+    dW, db, dM = ops.linear_bwd_raw(dY, Y, 1, M, W, True, True, True)
+    dW2, db2 = ops.xw_wgrad_raw(M, dY, Y, dY, Y, J)
+    assert rel(dW, dW2) < TOL and rel(db, db2) < TOL
+    gm = (dY * (Y > 0)).double()
+    assert rel(dW, gm.t() @ M.double()) < TOL and rel(db, gm.sum(0)) < TOL and rel(dM, gm @ W.double()) < TOL
