@@ -103,6 +103,11 @@ def parse():
     ap.add_argument("--torch-adam", action="store_true",
                     help="torch.optim.Adam(fused=True) instead of the library's one-launch Adam (same update rule)")
     ap.add_argument("--knobs", default="", help="comma-separated gae_tuning_set name=value pairs (experiments)")
+    ap.add_argument("--layer1", choices=["transform-first", "reference"], default="transform-first",
+                    help="citation workloads, layer 1 (500 / 1433 / 3703 -> 32): transform-first = act(A (X W^T) + b), the "
+                         "library's default for layers that narrow wide features (X read once per direction, the 40 MB "
+                         "aggregate A X never exists; value of gae.py:26-31 up to fp32 rounding); reference = "
+                         "act((A X) W^T + b) in the reference's order (the F_in-wide SpMM is then the dominant launch)")
     ap.add_argument("--no-fused-layers", action="store_true",
                     help="run narrow GCN layers as two launches (update_all, apply_nodes) instead of gae_gcn_layer_fused")
     ap.add_argument("--no-hipgraph", action="store_true",
@@ -117,7 +122,7 @@ def parse():
 def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/pmc_traffic_r02.json, else _r01: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)."""
-    for name in ("pmc_traffic_r02.json", "pmc_traffic_r01.json"):
+    for name in ("pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic_r01.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
@@ -275,15 +280,32 @@ class CitationWorkload:
                                   "256 MB Infinity Cache across the timed replays: its '% of 8 TB/s' is measured "
                                   "against the on-die fabric, not DRAM"}
         self.captured = None
-        self.dominant = ("spmm", n, n, self.F_in, "torch.float32")
-        self.dominant_desc = f"spmm F={self.F_in} (layer-1 aggregation A*X, {n} rows, {E} edges)"
-        self.alg_bytes = W.spmm_alg_bytes(n, n, E, self.F_in, 4)
-        self.pmc_key = f"{name}-F{self.F_in}"
+        self.tf = args.layer1 == "transform-first"
+        J = self.hidden[0]
+        if self.tf:
+            # the step's HBM-dominant launch is the dense pass over X (gae_xw_fwd); its compulsory bytes: X + P + W
+            self.dominant = ("xw_fwd", n, self.F_in, J, "torch.float32")
+            self.dominant_desc = (f"xw_fwd P = X W^T, {n} x {self.F_in} -> {J} (layer 1 in transform-first order: the "
+                                  f"aggregation runs at F = {J}; X read once, W stationary in registers)")
+            self.alg_bytes = 4 * (n * self.F_in + n * J + J * self.F_in)
+            self.pmc_key = f"{name}-xw_fwd"
+            self.meta["layer1"] = ("act(A (X W^T) + b): gae_xw_fwd, gae_spmm_csr_epilogue; backward gae_spmm_csr_epilogue "
+                                   "(ReLU gate in the gather), gae_xw_wgrad -- value of gae.py:26-31 up to fp32 rounding, "
+                                   "4 SpMM launches per step at F <= 32 (3 counted in `value`: the reference's L + (L - 1))")
+        else:
+            self.dominant = ("spmm", n, n, self.F_in, "torch.float32")
+            self.dominant_desc = f"spmm F={self.F_in} (layer-1 aggregation A*X, {n} rows, {E} edges)"
+            self.alg_bytes = W.spmm_alg_bytes(n, n, E, self.F_in, 4)
+            self.pmc_key = f"{name}-F{self.F_in}"
+            self.meta["layer1"] = "act((A X) W^T + b), the reference's order (gae.py:26-31)"
         self.scaling = "weak"
 
     def dominant_launch(self):
-        """the step's dominant SpMM launch on its real operands (layer-1 aggregation A X)"""
+        """the step's dominant HBM launch on its real operands: X W^T (transform-first) or the aggregation A X"""
         from gae_dgl_amd import ops
+        if self.tf:
+            W1 = self.model.layers[0].apply_mod.linear.weight.detach()
+            return lambda: ops.xw_fwd_raw(self.Xd, W1, None, 0)
         ip, ix = self.g.csr()
         out = ops.pad_rows(torch.empty(self.Xd.shape, device=self.dev))
         plan = self.g.spmm_plan(False)
@@ -369,16 +391,31 @@ class VgaeWorkload(CitationWorkload):
                      "feature_storage": "bf16 X (layer-1 aggregation: bf16 rows, fp32 accumulate, bf16 M); "
                                         "everything after the first Linear in fp32"}
         self.captured = None
-        self.dominant = ("spmm", n, n, self.F_in, "torch.bfloat16")
-        self.dominant_desc = f"spmm F={self.F_in}, bf16 storage (layer-1 aggregation A*X, {n} rows, {E} edges)"
-        self.alg_bytes = W.spmm_alg_bytes(n, n, E, self.F_in, 2)
-        self.pmc_key = ""
+        self.tf = args.layer1 == "transform-first"
+        J = self.hidden[0]
+        if self.tf:
+            self.dominant = ("xw_fwd", n, self.F_in, J, "torch.bfloat16")
+            self.dominant_desc = (f"xw_fwd P = X W^T, bf16-stored X {n} x {self.F_in} -> {J} (v_mfma_f32_16x16x32_bf16 on the "
+                                  f"rows as stored, W = hi + lo bf16 fragments, fp32 accumulation)")
+            self.alg_bytes = 2 * n * self.F_in + 4 * (n * J + J * self.F_in)
+            self.pmc_key = "citeseer-bf16-xw_fwd"
+            self.meta["feature_storage"] = ("bf16 X read once per direction by gae_xw_fwd / gae_xw_wgrad (shared layer in "
+                                            "transform-first order: no bf16 aggregate, no fp32 copy of it); everything after "
+                                            "in fp32")
+        else:
+            self.dominant = ("spmm", n, n, self.F_in, "torch.bfloat16")
+            self.dominant_desc = f"spmm F={self.F_in}, bf16 storage (layer-1 aggregation A*X, {n} rows, {E} edges)"
+            self.alg_bytes = W.spmm_alg_bytes(n, n, E, self.F_in, 2)
+            self.pmc_key = "citeseer-bf16-F3703"
         self.scaling = "weak"
         self.dtype = "bf16 storage, f32 arithmetic"
         self._params = list(self.model.parameters())
 
     def dominant_launch(self):
         from gae_dgl_amd import ops
+        if self.tf:
+            W1 = self.model.shared.apply_mod.linear.weight.detach()
+            return lambda: ops.xw_fwd_raw(self.Xd, W1, None, 0)
         ip, ix = self.g.csr()
         out = ops.pad_rows(torch.empty(self.Xd.shape, dtype=self.Xd.dtype, device=self.dev))
         plan = self.g.spmm_plan(False)
@@ -610,10 +647,34 @@ class RmatShardedWorkload:
         return z
 
 
+def citation_spmm_probe(name, dev):
+    """the reference-order layer-1 aggregation A X of a citation shape at its input width (the north-star's SpMM;
+    not part of the default step, which aggregates at the output width): kernel-only, operands as
+    `--layer1 reference` launches them"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, workloads as W
+    n, src, dst, X = W.citation_graph(name, seed=0)
+    g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    ip, ix = g.csr()
+    Xd = ops.pad_rows(torch.from_numpy(X).to(dev))
+    F = X.shape[1]
+    out = ops.pad_rows(torch.empty(Xd.shape, device=dev))
+    plan = g.spmm_plan(False)
+    sc = F > ops.TILE_MIN_F and g.scattered(F * 4)
+    t = time_launches(lambda: ops.spmm_raw(ip, ix, Xd, n, out=out, plan=plan, out_padded=True, scattered=sc), iters=50,
+                      warmup=30)
+    E = int(ix.numel())
+    b = W.spmm_alg_bytes(n, n, E, F, 4)
+    return {"shape": f"{name} layer-1 aggregation A*X in the reference's order (not in the default step)", "n": n, "nnz": E,
+            "F": F, "ld": Xd.stride(0), "dtype": "float32", "us_per_launch": t * 1e6, "edges_per_s": E / t, "alg_bytes": b,
+            "achieved_GBs": b / t / 1e9, "frac_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(f"{name}-F{F}")}
+
+
 def extras(dev):
     """kernel-only SpMM numbers on the other BASELINE shapes (F quoted with each)"""
     from gae_dgl_amd import ops, workloads as W
-    out = []
+    out = [citation_spmm_probe(name, dev) for name in ("pubmed", "cora", "citeseer")]
     gptr, src, dst, X = W.zinc_like(249455, seed=0)
     N = int(gptr[-1])
     s = torch.from_numpy(src).to(dev); d = torch.from_numpy(dst).to(dev)
@@ -787,6 +848,9 @@ def main():
     if args.no_fused_layers:
         from gae_dgl_amd import gae as _gae
         _gae.FUSE_NARROW_LAYERS = False
+    if args.layer1 == "reference":
+        from gae_dgl_amd import gae as _gae
+        _gae.TRANSFORM_FIRST_AUTO = False
     if world > 1:
         dist.barrier()
     from gae_dgl_amd import ops

@@ -476,23 +476,33 @@ gae::Knob g_xw_dbg{0};        // "xw_dbg" (experiments, wrong results): 1 = forw
 
 FwdPlan fwd_plan(int64_t n, int K, int elem)
 {
+    // A block streams `tiles_per_block` row tiles through the W slices its waves hold, so it fetches its share of W
+    // once per launch: W bytes per block / X bytes per block = 4 J / (16 elem tiles_per_block).  Tall operands
+    // (Pubmed: 1233 tiles) give every CU ceil(tiles / 256) tiles and the whole of K.  Operands with few rows (Cora 170
+    // tiles, Citeseer 208) would run one tile per block and read W -- as large as X -- from L2 once per tile: they get 4
+    // tiles per block and are split along K over blocks instead (partials added in split order by a second launch).
     FwdPlan p{};
-    const int kw256 = 256 / elem, kw512 = 512 / elem;
-    if (K <= 8 * kw256) { p.slice_bytes = 256; p.splits = 1; }
-    else { p.slice_bytes = 512; p.splits = (K + 8 * kw512 - 1) / (8 * kw512); }
-    const int kw = p.slice_bytes / elem;
-    const int per = (K + p.splits - 1) / p.splits;
-    p.nw = (per + kw - 1) / kw;
-    if (p.nw < 1) p.nw = 1;
-    p.k_per_block = p.nw * kw;
-    // the last split may hold fewer columns; no split may be empty
-    while (p.splits > 1 && (p.splits - 1) * p.k_per_block >= K) --p.splits;
     const int64_t tiles = (n + 15) / 16;
-    int64_t t = g_xw_rows > 0 ? (g_xw_rows + 15) / 16 : (tiles * p.splits + 255) / 256;
+    int64_t t = g_xw_rows > 0 ? (g_xw_rows + 15) / 16 : (tiles + 255) / 256;
+    if (g_xw_rows == 0 && t < 4) t = tiles < 4 ? tiles : 4;
     if (t < 1) t = 1;
     if (t > (1 << 20)) t = 1 << 20;
     p.tiles_per_block = int(t);
     p.row_blocks = (tiles + t - 1) / t;
+    const int64_t k_bytes = int64_t(K) * elem;
+    int splits = int((k_bytes + 4095) / 4096);                      // at most 8 waves x 512 bytes per block
+    const int want = int(256 / p.row_blocks);                        // ... and enough blocks for every CU
+    if (want > splits) splits = want;
+    const int max_splits = int((k_bytes + 1023) / 1024);            // a block keeps at least 4 waves x 256 bytes busy
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int per = (K + splits - 1) / splits;
+    p.slice_bytes = int64_t(per) * elem <= 2048 ? 256 : 512;
+    const int kw = p.slice_bytes / elem;
+    p.nw = (per + kw - 1) / kw;
+    if (p.nw < 1) p.nw = 1;
+    p.k_per_block = p.nw * kw;
+    p.splits = (K + p.k_per_block - 1) / p.k_per_block;              // no empty split
     return p;
 }
 

@@ -48,11 +48,11 @@ def test_xw_fwd_matches_fp64(n, K, J, dtype, tuning):
         if act:
             ref = torch.relu(ref)
         assert P.shape == (n, J) and rel(P, ref) < tol
-    if n >= 1000:                                                  # other rows-per-block choices: same sums per tile
+    if n >= 1000:                    # other rows-per-block choices (and with them other splits along K): same value
         P0 = ops.xw_fwd_raw(Xp, W.to(DEV), None, 0)
         tuning("xw_rows", 16)
         P1 = ops.xw_fwd_raw(Xp, W.to(DEV), None, 0)
-        assert torch.equal(P0, P1)
+        assert rel(P1, P0) < 2e-6
 
 
 @pytest.mark.parametrize("n,K,J", SHAPES)
