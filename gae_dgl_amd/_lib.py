@@ -53,6 +53,7 @@ SIGNATURES = {
     "gae_csr_from_coo_workspace_bytes": (_i64, [_i64, _i64]),
     "gae_csr_from_coo": (_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _i64, _p, _p]),
     "gae_degree_norm": (_int, [_p, _i64, _p, _p, _p]),
+    "gae_rows_pack": (_int, [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "gae_csr_to_dense": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
     "gae_batch_plan": (_int, [_p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "gae_batch_select": (_int, [_p, _i64, _p, _i64, _p, _p]),

@@ -411,6 +411,53 @@ extern "C" int gae_csr_from_coo(const int64_t *row, const int64_t *col, int64_t 
     return GAE_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Row pack of the multi-GPU exchange (gae_dgl_amd/parallel.py): out[i] = H[idx[i]] (idx == NULL: H[i]) for
+// i < n_rows, zero rows behind up to n_out_rows.  The rows a rank sends to its peers go STRAIGHT into the send
+// buffer of the all-to-all, its own rows straight into their slot of the buffer the local CSR indexes -- no ATen
+// index_select / cat on the path between two products.  One thread per 16-byte vector (rows of whole vectors),
+// one per element otherwise.
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void rows_pack_kernel(const float *__restrict__ H, int64_t ldh,
+                                                        const int64_t *__restrict__ idx, int64_t n_rows,
+                                                        int64_t n_out_rows, int64_t F, float *__restrict__ out,
+                                                        int64_t ldo)
+{
+    const int64_t vpr = (F + VEC - 1) / VEC;
+    const int64_t total = n_out_rows * vpr;
+    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < total; e += int64_t(gridDim.x) * 256) {
+        const int64_t i = e / vpr, c = (e - i * vpr) * VEC;
+        if (VEC == 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n_rows) v = *reinterpret_cast<const float4 *>(H + (idx ? idx[i] : i) * ldh + c);
+            *reinterpret_cast<float4 *>(out + i * ldo + c) = v;
+        } else {
+            out[i * ldo + c] = i < n_rows ? H[(idx ? idx[i] : i) * ldh + c] : 0.f;
+        }
+    }
+}
+
+extern "C" int gae_rows_pack(const float *H, int64_t ldh, int64_t n_src_rows, const int64_t *idx, int64_t n_rows,
+                             int64_t n_out_rows, int64_t F, float *out, int64_t ldo, void *stream)
+{
+    GAE_REQUIRE(n_rows >= 0 && n_out_rows >= n_rows && F >= 0 && n_src_rows >= 0, GAE_E_SIZE,
+                "gae_rows_pack: bad sizes");
+    GAE_REQUIRE(ldh >= F && ldo >= F, GAE_E_SIZE, "gae_rows_pack: leading dimension < F");
+    GAE_REQUIRE(idx != nullptr || n_rows <= n_src_rows, GAE_E_SIZE, "gae_rows_pack: more rows than the source has");
+    if (n_out_rows == 0 || F == 0) return GAE_OK;
+    GAE_REQUIRE(out && (n_rows == 0 || H), GAE_E_NULL, "gae_rows_pack: NULL pointer");
+    const bool vec = F % 4 == 0 && ldh % 4 == 0 && ldo % 4 == 0 && gae::aligned16(H) && gae::aligned16(out);
+    const int64_t total = n_out_rows * (vec ? F / 4 : F);
+    const dim3 grid(unsigned(grid_for(total, 256, 256 * 16)));
+    if (vec) hipLaunchKernelGGL(rows_pack_kernel<4>, grid, dim3(256), 0, gae::as_stream(stream), H, ldh, idx, n_rows,
+                                n_out_rows, F, out, ldo);
+    else hipLaunchKernelGGL(rows_pack_kernel<1>, grid, dim3(256), 0, gae::as_stream(stream), H, ldh, idx, n_rows,
+                            n_out_rows, F, out, ldo);
+    GAE_CHECK_LAUNCH("rows_pack_kernel");
+    return GAE_OK;
+}
+
 extern "C" int gae_degree_norm(const int32_t *indptr, int64_t n_rows, int32_t *deg_out, float *norm_out,
                                void *stream)
 {

@@ -192,6 +192,26 @@ def degree_norm(indptr, want_deg=True, want_norm=True):
     return deg, norm
 
 
+def rows_pack(H, idx=None, out=None, n_out_rows=None):
+    """out[i] = H[idx[i]] (idx None: H[i]); rows behind the packed ones up to ``n_out_rows`` are zeroed
+    (gae_rows_pack).  ``out``: a [>= n_out_rows, F] fp32 row-major destination (a slice of an exchange buffer)."""
+    H, ldh = _rowmajor(_f32(_gpu(H, "H"), "rows_pack: H"), "H")
+    n_src, F = H.shape
+    n_rows = n_src if idx is None else int(idx.numel())
+    n_out = n_rows if n_out_rows is None else int(n_out_rows)
+    if idx is not None:
+        idx = _gpu(idx, "idx").to(torch.int64).contiguous()
+    if out is None:
+        out = torch.empty(n_out, F, dtype=torch.float32, device=H.device)
+    if out.dtype != torch.float32 or out.dim() != 2 or out.shape[1] != F or out.shape[0] < n_out or \
+            (F and out.stride(1) != 1):
+        raise GaeHipError("rows_pack: `out` must be an fp32 [>= n_out_rows, F] row-major tensor")
+    ldo = out.stride(0) if out.shape[0] > 1 else max(F, 1)
+    with _on_device(H.device):
+        _lib.call("gae_rows_pack", _ptr(H), ldh, n_src, _ptr(idx), n_rows, n_out, F, _ptr(out), max(ldo, F, 1), _stream())
+    return out[:n_out]
+
+
 def csr_to_dense(indptr, indices, n_rows, n_cols):
     _gpu(indptr, "indptr")
     out = torch.empty(n_rows, n_cols, dtype=torch.float32, device=indptr.device)

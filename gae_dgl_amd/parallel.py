@@ -249,7 +249,7 @@ class ShardedGraph:
             dist.all_to_all_single(req, need, output_split_sizes=send_counts.tolist(),
                                    input_split_sizes=counts.tolist(), group=self.group)
             self._a2a[k] = dict(need=need, recv_counts=counts.tolist(), send_counts=send_counts.tolist(),
-                                send_idx=req - p.r0)
+                                send_idx=(req - p.r0).to(self.device))
 
     def exchange(self, h_local, which="fwd"):
         """feature rows this rank's SpMM reads: [padded_n, F] (allgather) or
@@ -268,12 +268,27 @@ class ShardedGraph:
         if p.mode == "allgather":
             return self.allgather_rows(h_local)
         a = self._a2a[which]
+        nb = p.n_before[which]          # rows owned by lower ranks arrive first (ascending global id)
+        if h_local.is_cuda and dist.get_backend(self.group) == "nccl":
+            # HIP pack kernels + receive views: the rows to send go straight into the send buffer, the own rows
+            # straight into their slot of the assembled buffer, and every peer's rows land where the local CSR
+            # indexes them -- no ATen index_select / cat between two products
+            from . import ops
+            send = ops.rows_pack(h_local, a["send_idx"])
+            full = h_local.new_empty(p.n_local + sum(a["recv_counts"]), F)
+            ops.rows_pack(h_local, None, out=full[nb:nb + p.n_local])
+            outs, ins, so, ro = [], [], 0, 0
+            for q in range(p.world):
+                ins.append(send[so:so + a["send_counts"][q]]); so += a["send_counts"][q]
+                at = ro if ro < nb else ro + p.n_local                   # peers above this rank: behind the own rows
+                outs.append(full[at:at + a["recv_counts"][q]]); ro += a["recv_counts"][q]
+            dist.all_to_all(outs, ins, group=self.group)
+            return full
         send = h_local.index_select(0, a["send_idx"].to(h_local.device))
         recv = h_local.new_empty(sum(a["recv_counts"]), F)
         dist.all_to_all_single(recv, send, output_split_sizes=a["recv_counts"], input_split_sizes=a["send_counts"],
                                group=self.group)
-        nb = p.n_before[which]          # rows owned by lower ranks arrive first (ascending global id)
-        return torch.cat([recv[:nb], h_local, recv[nb:]])
+        return torch.cat([recv[:nb], h_local, recv[nb:]])          # (gloo, CPU host-logic tests)
 
     def exchange_start(self, h_local, which="fwd"):
         """overlap: start the exchange of the REMOTE rows and return (buffer the remote CSR indexes, wait()).  The
@@ -291,7 +306,11 @@ class ShardedGraph:
             full, works = self._allgather_async(h_local)
             return full, (lambda: [w.wait() for w in works])
         a = self._a2a[which]
-        send = h_local.index_select(0, a["send_idx"].to(h_local.device))
+        if h_local.is_cuda:
+            from . import ops
+            send = ops.rows_pack(h_local, a["send_idx"])             # HIP gather straight into the send buffer
+        else:
+            send = h_local.index_select(0, a["send_idx"].to(h_local.device))
         recv = h_local.new_empty(sum(a["recv_counts"]), F)
         work = dist.all_to_all_single(recv, send, output_split_sizes=a["recv_counts"],
                                       input_split_sizes=a["send_counts"], group=self.group, async_op=True)
@@ -304,7 +323,13 @@ class ShardedGraph:
         p = self.part
         if p.uniform:
             pad = p.block - p.n_local
-            mine = t_local if pad == 0 else torch.cat([t_local, t_local.new_zeros(pad, t_local.shape[1])])
+            if pad == 0:
+                mine = t_local
+            elif t_local.is_cuda and t_local.dtype == torch.float32:
+                from . import ops
+                mine = ops.rows_pack(t_local, None, n_out_rows=p.block)       # own rows + zero pad rows, one HIP launch
+            else:
+                mine = torch.cat([t_local, t_local.new_zeros(pad, t_local.shape[1])])
             full = t_local.new_empty(p.padded_n, t_local.shape[1])
             return full, [dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group, async_op=True)]
         full = t_local.new_empty(p.n, t_local.shape[1])

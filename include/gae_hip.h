@@ -95,6 +95,14 @@ int gae_csr_from_coo(const int64_t *row, const int64_t *col, int64_t n_edges,
                      void *workspace, int64_t workspace_bytes,
                      int32_t *status_dev, void *stream);
 
+/* Row pack of the row-sharded exchange (the reference has no multi-GPU code,
+ * gae_dgl/train_inductive.py:29 is its only device logic): out[i] = H[idx[i]] for i < n_rows (idx NULL: H[i]),
+ * zero rows from n_rows to n_out_rows.  idx (int64, device) entries must lie in [0, n_src_rows).  Lets the rows a
+ * rank sends go straight into the all-to-all's send buffer and its own rows straight into the buffer the local CSR
+ * indexes. */
+int gae_rows_pack(const float *H, int64_t ldh, int64_t n_src_rows, const int64_t *idx, int64_t n_rows,
+                  int64_t n_out_rows, int64_t F, float *out, int64_t ldo, void *stream);
+
 /* g.in_degrees() + norm = deg^-1/2, inf -> 0 (gae_dgl/train_transductive.py:55-58).
  * deg_out (int32, may be NULL), norm_out (fp32, may be NULL). */
 int gae_degree_norm(const int32_t *indptr, int64_t n_rows, int32_t *deg_out,

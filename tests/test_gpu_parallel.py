@@ -328,3 +328,24 @@ def test_two_rank_rccl_sharded_encoder():
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("F", [32, 16, 7, 33])
+def test_rows_pack_is_an_exact_gather(F):
+    """gae_rows_pack (the pack kernel of the exchange): out[i] = H[idx[i]] bit for bit, zero rows behind, packing
+    into a slice of a larger buffer leaves its other rows alone"""
+    from gae_dgl_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(F)
+    H = torch.randn(1000, F, generator=g).to(dev)
+    idx = torch.randint(0, 1000, (777,), generator=g).to(dev)
+    out = ops.rows_pack(H, idx)
+    assert torch.equal(out, H.index_select(0, idx))
+    padded = ops.rows_pack(H, idx, n_out_rows=800)
+    assert torch.equal(padded[:777], H[idx]) and bool((padded[777:] == 0).all()) and padded.shape == (800, F)
+    big = torch.full((1500, F), 7.0, device=dev)
+    ops.rows_pack(H, None, out=big[200:1200])
+    assert torch.equal(big[200:1200], H) and bool((big[:200] == 7).all()) and bool((big[1200:] == 7).all())
+    Hp = ops.pad_rows(torch.randn(50, 39, device=dev))                  # row-padded source (ld 40)
+    assert torch.equal(ops.rows_pack(Hp, idx[:20] % 50), Hp[idx[:20] % 50])
+    assert ops.rows_pack(H, idx[:0]).shape == (0, F)
