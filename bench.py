@@ -51,6 +51,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # kernels is the sum of their instructions' issue costs.  Costs in units of one v_fma_f32 (1.42 ns per wave64
 # instruction and SIMD at 4 waves / SIMD): transcendental 2.5, v_pk_*_f32 1.8, v_cvt_pk_bf16_f32 / v_bfi_b32 1.7,
 # v_perm_b32 1.4, v_lshlrev_b32 1.6, v_mfma_f32_16x16x{16,32}_bf16 5.2.
+SPEC_LANE_OPS = 157.3e12 / 2     # MI355X data sheet: 157.3 TFLOP/s fp32 vector = 78.6 T fused lane-operations per second
 SLOT_NS = 1.42
 ISSUE_PEAK_LANE_SLOTS = 256 * 4 * 64 / (SLOT_NS * 1e-9)      # lane-slots per second of the whole chip
 SLOT_COST = {"plain": 1.0, "trans": 2.5, "pk": 1.8, "cvt_pk": 1.7, "bfi": 1.7, "perm": 1.4, "lshl": 1.6, "mfma": 5.2}
@@ -165,6 +166,17 @@ def time_launches(fn, iters=50, warmup=5):
             print(f"[bench] graph-replay timing unavailable: {ex}", file=sys.stderr)
             torch.cuda.synchronize()
     return t
+
+
+def copy_bandwidth(nbytes, dev):
+    """measured device-copy rate (GB/s, read + write counted) of a copy that moves ``nbytes`` in total: SURVEY 8(d)'s
+    second denominator -- what the memory system delivers to the simplest possible kernel at this size"""
+    half = max(int(nbytes) // 2 // 16 * 16, 1 << 16)
+    src = torch.empty(half, dtype=torch.uint8, device=dev)
+    dst = torch.empty(half, dtype=torch.uint8, device=dev)
+    src.zero_()
+    t = time_launches(lambda: dst.copy_(src), iters=50 if nbytes < 1e9 else 10, warmup=5)
+    return 2 * half / t / 1e9
 
 
 def cpu_model_name():
@@ -520,6 +532,20 @@ class ZincWorkload:
         return lambda: ops.spmm_raw(ip, ix, H, bg.number_of_nodes(), out=out, out_padded=True,
                                     blockdiag=bg.block_diag, plan=bg.spmm_plan(False))
 
+    def loss_launch(self):
+        """the step's dominant launch sequence -- fused decoder + BCE of one batch (loss and dZ) -- on the embedding of
+        batch 0"""
+        from gae_dgl_amd import ops
+        bg = self.ds.batch(self.perm[:self.B])
+        with torch.no_grad():
+            Z = self.model.encode(bg).clone()
+        self.n = bg.number_of_nodes()
+        mask = ops.dropout_mask(tuple(Z.shape), 0.1, seed=1, device=self.dev)
+        csr, csc = bg.csr(), bg.csc()
+        E = bg.number_of_edges()
+        pw = (float(self.n) ** 2 - E) / E
+        return lambda: ops.decoder_bce_raw(Z, mask, csr, csc, pw, want_grad=True)
+
     def capture(self):
         from gae_dgl_amd.capture import CapturedInductiveStep
         self.runner = CapturedInductiveStep(self.model, self.opt, self.ds, self.B)
@@ -561,9 +587,22 @@ class RmatShardedWorkload:
         self.sg.cache_constant_inputs = not args.no_cache_input_exchange
         p = self.sg.part
         e_local = int(p.fwd_rows.numel())
+        # structure + plans, built once: their cost and size are part of the line (one-off, outside `value`)
+        torch.cuda.synchronize(); t_csr = time.perf_counter()
         for w in ("fwd", "bwd"):
             for part in (("own", "remote") if self.overlap else (None,)):
-                self.sg.csr(w, part); self.sg.plan(w, part)
+                self.sg.csr(w, part)
+        torch.cuda.synchronize(); t_plan = time.perf_counter()
+        plan_bytes = 0
+        for w in ("fwd", "bwd"):
+            for part in (("own", "remote") if self.overlap else (None,)):
+                pl = self.sg.plan(w, part)
+                if pl is not None:
+                    plan_bytes += sum(t.numel() * t.element_size() for t in pl.tensors if t is not None)
+        torch.cuda.synchronize()
+        self.plan_build_ms = (time.perf_counter() - t_plan) * 1e3
+        self.csr_build_ms = (t_plan - t_csr) * 1e3
+        self.plan_bytes = plan_bytes
         # the edge lists of the plan are not needed once the device CSRs exist (2 x 2^28 int64 per direction)
         p.fwd_rows = p.fwd_cols = p.bwd_rows = p.bwd_cols = None
         p.cols_global = {}
@@ -596,7 +635,13 @@ class RmatShardedWorkload:
                      "layer_order": "(A H) W^T for every layer (gae.py:26-31)" if not self.transform_first else
                                     "32 -> 32 layer: (A H) W^T; 32 -> 16 layer: A (H W^T), aggregation and exchange at "
                                     "width 16 forward and backward (value of gae.py:26-31 up to fp32 rounding)",
-                     "local_rows": p.n_local, "local_edges_fwd": e_local}
+                     "local_rows": p.n_local, "local_edges_fwd": e_local,
+                     "csr_build_ms": self.csr_build_ms, "plan_build_ms": self.plan_build_ms,
+                     "plan_bytes": self.plan_bytes,
+                     "plan_note": "per-rank one-off costs outside `value`: device CSRs of A and A^T (csr_build_ms) and "
+                                  "their gae_spmm_plan arrays (plan_build_ms, plan_bytes: heavy-row segments and "
+                                  "descriptors, hot-column tags, XCD-pinned virtual CSR)"}
+        self.pmc_key = f"rmat-s{scale}-F32" if world == 1 else ""
         self.dominant = None
         self.dominant_desc = (f"spmm F=32 on this rank's row block ({p.n_local} rows, {e_local} edges, skew plan"
                               + ("; own-column + remote-column launches" if self.overlap else "") + ")")
@@ -939,6 +984,7 @@ def main():
     # kernel duration (profiles/).
     t_dom = time_launches(dom_fn, iters=50 if wl.alg_bytes < 1e9 else 10) if dom_fn is not None else t_dom_instep
     spmm_t = sum(sum(times[k]) for k in spmm_keys)
+    copy_gbs = copy_bandwidth(wl.alg_bytes, dev) if dom_fn is not None else None
     value = wl.edges_per_step * args.steps / elapsed
     line = {
         "metric": "edges aggregated/sec (SpMM fwd+bwd)", "value": value, "unit": "edges/s",
@@ -956,6 +1002,9 @@ def main():
                      "traffic": pmc_traffic(getattr(wl, "pmc_key", "")),
                      "traffic_note": "HBM bytes/launch from separate rocprofv3 --pmc passes of the same kernel and "
                                      "shape (profiles/pmc_traffic_r0N.json), not collected in this run",
+                     "copy_GBs": copy_gbs, "frac_of_copy": (wl.alg_bytes / t_dom / 1e9 / copy_gbs) if copy_gbs else None,
+                     "copy_note": "copy_GBs = measured rate of a device copy moving alg_bytes_per_launch in total "
+                                  "(read + write), same timing method: the second denominator of SURVEY 8(d)",
                      "alg_bytes_per_launch": wl.alg_bytes, "avg_launch_us": t_dom * 1e6,
                      "avg_launch_us_event_pairs_inside_steps": t_dom_instep * 1e6, "launches_timed_inside_steps": len(dom)},
     }
@@ -980,8 +1029,9 @@ def main():
         line["same_workload_1gpu"] = one_gpu
     if world == 1 and getattr(wl, "loss_launch", None) is not None:
         # ---- the step's DOMINANT launch: fused decoder + weighted BCE (loss + dZ), VALU / transcendental bound
-        t_loss = time_launches(wl.loss_launch(), iters=20, warmup=5)
+        loss_fn = wl.loss_launch()                  # (sets wl.n for the molecule batches)
         n = wl.n
+        t_loss = time_launches(loss_fn, iters=20 if n < 50000 else 5, warmup=5 if n < 50000 else 2)
         kind = "symmetric" if n >= 8192 else "full"          # gae_decoder_bce's own rule (bce_sym, d <= 16)
         per_logit, frac_eval = loss_slots_per_logit(kind)
         units = per_logit * frac_eval * float(n) * n
@@ -991,6 +1041,9 @@ def main():
                                                       f"prepare / finalize launches), N = {n}, d = 16",
             "achieved": units / t_loss / 1e12, "peak": ISSUE_PEAK_LANE_SLOTS / 1e12, "unit": "T lane-slots/s",
             "frac": units / t_loss / ISSUE_PEAK_LANE_SLOTS, "avg_launch_us": t_loss * 1e6,
+            "peak_spec": SPEC_LANE_OPS / 1e12, "frac_spec": units / t_loss / SPEC_LANE_OPS,
+            "peak_note": "peak = the issue rate tools/probes/inst_cost.hip measures at 4 waves / SIMD (self-measured); "
+                         "peak_spec = the data sheet's fp32 vector rate, 157.3 TFLOP/s / 2 = 78.6 T lane-operations/s",
             "logits_per_s": float(n) * n / t_loss,
             "model": f"{per_logit:.1f} issue slots (v_fma_f32 equivalents, measured costs) per evaluated logit and "
                      f"lane: {isa}, per 32 logits; {frac_eval:g} N^2 logits evaluated; MFMA and VALU time of a "
@@ -1000,7 +1053,7 @@ def main():
             "mfma_flops_per_s": isa["mfma"] * 16384.0 / 64 / 32 * frac_eval * float(n) * n / t_loss,
             "share_of_step": t_loss / (elapsed / args.steps)}
         # ---- the same step with exact-fp32 products everywhere (no bf16 x 3 split)
-        if graphed:
+        if graphed and isinstance(wl, CitationWorkload):
             from gae_dgl_amd import _lib
             knobs = (b"bce_s_bf16", b"bce_pv_bf16", b"atb_bf16")
             for k in knobs:
