@@ -1,0 +1,47 @@
+#!/bin/bash
+# Runs on the GPU box: the round-3 measurements quoted in DESIGN.md / profiles/README.md -> gpurun_out/r03/
+# (tools/publish_profiles.py r03 files them under profiles/).   usage: tools/r03/collect.sh [part ...]
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r03
+mkdir -p $O
+cd $R
+PARTS=${@:-bench prof pmc micro}
+for part in $PARTS; do
+case $part in
+bench)
+  timeout 900 python bench.py > $O/bench_pubmed.json 2> $O/bench_pubmed.err
+  timeout 600 python bench.py --layer1 reference --no-extra --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_pubmed_reference_order.json
+  for w in cora citeseer zinc vgae; do timeout 600 python bench.py --workload $w --no-extra 2>/dev/null | tail -1 > $O/bench_$w.json; done
+  timeout 600 python bench.py --workload zinc --batch-graphs 128 --steps 300 --warmup 30 --no-extra 2>/dev/null | tail -1 > $O/bench_zinc128.json
+  MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 timeout 900 python bench.py --workload rmat --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_rmat_s24_1gpu.json
+  ;;
+prof)
+  for w in pubmed cora citeseer vgae zinc; do
+    timeout 600 tools/prof_bench.sh r03/prof_$w --workload $w --steps 30 --warmup 3 > $O/${w}_step_kernel_stats_top.txt
+  done
+  timeout 600 tools/prof_bench.sh r03/prof_zinc128 --workload zinc --batch-graphs 128 --steps 200 --warmup 20 > $O/zinc128_step_kernel_stats_top.txt
+  MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 timeout 900 tools/prof_bench.sh r03/prof_rmat --workload rmat --steps 5 --warmup 2 --no-cpu-baseline > $O/rmat_step_kernel_stats_top.txt
+  ;;
+pmc)
+  export PMC_SETS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+  export PMC_FILTER="xw_fwd xtg spmm"
+  for sh in pubmed cora citeseer; do
+    tools/pmc.sh r03/pmc_xwfwd_$sh tools/r03/xw_one.py --shape $sh --op fwd > $O/pmc_xwfwd_$sh.txt
+    tools/pmc.sh r03/pmc_xwgrad_$sh tools/r03/xw_one.py --shape $sh --op wgrad > $O/pmc_xwgrad_$sh.txt
+  done
+  tools/pmc.sh r03/pmc_xwfwd_citeseer_bf16 tools/r03/xw_one.py --shape citeseer --dtype bf16 --op fwd > $O/pmc_xwfwd_citeseer_bf16.txt
+  tools/pmc.sh r03/pmc_xwgrad_citeseer_bf16 tools/r03/xw_one.py --shape citeseer --dtype bf16 --op wgrad > $O/pmc_xwgrad_citeseer_bf16.txt
+  export PMC_FILTER=spmm
+  for sh in pubmed500 pubmed32 cora1433 citeseer3703 zincb39 zinc32 zinc39; do
+    tools/pmc.sh r03/pmc_$sh tools/spmm_one.py --shape $sh --iters 5 > $O/pmc_$sh.txt
+  done
+  PMC_TIMEOUT=300 tools/pmc.sh r03/pmc_rmat32 tools/spmm_one.py --shape rmat32 --rmat-scale 24 --iters 3 > $O/pmc_rmat32.txt
+  ;;
+micro)
+  timeout 300 python tools/r03/xw_bench.py 2>/dev/null > $O/xw_bench.txt
+  timeout 300 python tools/r03/xw_sweep.py pubmed 2>/dev/null > $O/xw_sweep_pubmed.txt
+  timeout 300 python tools/bce_bench.py --variants "sym=1;sym=0;sym=0,sb=0,pb=0" --rounds 5 2>/dev/null > $O/bce_bench_pubmed.txt
+  ;;
+esac
+done
+ls -la $O
