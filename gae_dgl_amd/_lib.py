@@ -35,7 +35,8 @@ class SpmmPlan(ctypes.Structure):
 
 
 class AdamTensor(ctypes.Structure):
-    _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("n", _i64)]
+    _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("n", _i64),
+                ("partials", _p), ("n_partials", _i64), ("partial_stride", _i64), ("row_len", _i64), ("row_pitch", _i64)]
 
 
 ADAM_MAX_TENSORS = 16
@@ -88,6 +89,9 @@ SIGNATURES = {
     "gae_linear_fwd_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gae_linear_fwd": (_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _i64, _p]),
     "gae_linear_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "gae_linear_bwd_partials": (_int, [_p, _i64, _p, _i64, _int, _p, _i64, _i64, _i64, _i64, _int, _int, _p, _i64, _p, _p]),
+    "gae_xw_wgrad_partials": (_int, [_p, _i64, _int, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _int, _int,
+                                     _p, _i64, _p, _p]),
     "gae_linear_bwd": (_int, [_p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _i64, _i64,
                               _p, _p, _p, _i64, _p, _i64, _p]),
     "gae_dropout_mask": (_int, [_p, _i64, _f, _u64, _u64, _p, _p]),

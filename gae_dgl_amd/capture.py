@@ -15,6 +15,26 @@ import torch
 from . import ops
 
 
+class _defer:
+    """ops.deferred_grad_reductions() when the optimiser is the library's Adam (which consumes the partial sums),
+    a no-op for any other optimiser"""
+
+    def __init__(self, opt):
+        from .optim import Adam
+        self.cm = ops.deferred_grad_reductions() if isinstance(opt, Adam) and DEFER_GRAD_REDUCTIONS else None
+
+    def __enter__(self):
+        if self.cm is not None:
+            self.cm.__enter__()
+
+    def __exit__(self, *exc):
+        if self.cm is not None:
+            return self.cm.__exit__(*exc)
+
+
+DEFER_GRAD_REDUCTIONS = True      # False: captured steps keep the separate reduction launches (experiments)
+
+
 class CapturedTrainStep:
     """The warm-up steps run on a side stream and the captured step takes its gradients through
     ``torch.autograd.grad`` (``ops.backward(loss, params)``): an AccumulateGrad node of an earlier eager iteration
@@ -55,8 +75,11 @@ class CapturedTrainStep:
     def _fwd_bwd_step(self):
         self.g.ndata['h'] = self.x
         loss = self.loss_fn(self.model, self.g)
-        ops.backward(loss, self._params)          # autograd.grad: no AccumulateGrad nodes (stream-bound) in the capture
-        self.opt.step()
+        # the optimiser launch follows the backward pass directly: the library's Adam adds the weight gradients'
+        # partial sums itself (two reduction launches less per step)
+        with _defer(self.opt):
+            ops.backward(loss, self._params)      # autograd.grad: no AccumulateGrad nodes (stream-bound) in the capture
+            self.opt.step()
         return loss.detach()
 
     def _eager_step(self):
@@ -171,8 +194,9 @@ class CapturedInductiveStep:
         g.ndata.clear()
         g.ndata['h'] = self.x
         loss = self.model.reconstruction_loss(g)
-        ops.backward(loss, self._params)          # autograd.grad: no AccumulateGrad nodes (stream-bound) in the capture
-        self.opt.step()
+        with _defer(self.opt):
+            ops.backward(loss, self._params)      # autograd.grad: no AccumulateGrad nodes (stream-bound) in the capture
+            self.opt.step()
         return loss.detach()
 
     # ---------------------------------------------------------------- capture

@@ -108,6 +108,47 @@ __device__ __forceinline__ void split_bf16x4(const v4f &v, v4s &hi, v4s &lo)
 }
 
 // ---------------------------------------------------------------------------
+// THE order in which a list of partial sums (per-block pieces of a weight gradient) is added, wherever it is added --
+// the stand-alone reduction launches of gae_xw_wgrad / gae_linear_bwd and gae_adam_step's deferred reduction -- so
+// that a training step gives the same bits whichever of them runs:
+//   lists of <= 32 partials: one lane per element (L = 1), partials 0, 1, 2, ... in order (16 loads in flight);
+//   longer lists: 64 lanes per element (L = 64), lane l adds partials l, l + 64, ... in order, then the lanes meet
+//   in the fixed shuffle-down tree 32, 16, ..., 1 (lane 0 holds the sum; all 64 lanes must call).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int partial_lanes(int64_t n_partials) { return n_partials > 32 ? 64 : 1; }
+
+__device__ __forceinline__ float sum_partials(const float *__restrict__ p0, int64_t n_partials, int64_t stride, int lane,
+                                              int L)
+{
+    float g = 0.f;
+    for (int64_t q0 = lane; q0 < n_partials; q0 += int64_t(16) * L) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int64_t q = q0 + int64_t(u) * L;
+            v[u] = p0[(q < n_partials ? q : n_partials - 1) * stride];        // clamped: loads stay branch-free
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) g += q0 + int64_t(u) * L < n_partials ? v[u] : 0.f;
+    }
+    if (L == 64) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off, 64);
+    }
+    return g;
+}
+
+// one list of partial sums and where its sums go: element e of `n` reads partial q at
+// base[q * stride + (e / row_len) * row_pitch + e % row_len] and is written to out[(e / row_len) * out_pitch + e % row_len]
+struct PartialList {
+    const float *base;
+    float *out;
+    int64_t n, n_partials, stride, row_len, row_pitch, out_pitch;
+};
+// reduction launch over up to two lists (a weight gradient and its bias gradient), defined in xw.hip
+int launch_partials_reduce(const PartialList &a, const PartialList &b, hipStream_t s);
+
+// ---------------------------------------------------------------------------
 // Philox4x32-10 counter RNG (dropout masks, VGAE noise): 4 x 32 random bits per (counter, seed)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1)

@@ -1541,6 +1541,32 @@ extern "C" int64_t gae_linear_bwd_workspace_bytes(int64_t n, int64_t f_in, int64
     return align256(pl.n_slots * pl.slot_stride * 4) + 256;
 }
 
+extern "C" int gae_linear_bwd_partials(const float *dY, int64_t lddy, const float *Y, int64_t ldy, int act, const float *M,
+                                       int64_t ldm, int64_t n, int64_t f_in, int64_t f_out, int want_dW, int want_db,
+                                       void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream)
+{
+    GAE_REQUIRE(n > 0 && f_in >= 0 && f_out > 0 && layout_out, GAE_E_SIZE, "gae_linear_bwd_partials: bad sizes");
+    GAE_REQUIRE(f_in < (1 << 24) && f_out < (1 << 24), GAE_E_SIZE, "gae_linear_bwd_partials: feature width too large");
+    GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_DTYPE, "gae_linear_bwd_partials: activation %d", act);
+    GAE_REQUIRE(dY && lddy >= f_out && (want_dW || want_db), GAE_E_NULL, "gae_linear_bwd_partials: dY missing");
+    GAE_REQUIRE(act != GAE_ACT_RELU || (Y && ldy >= f_out), GAE_E_NULL, "gae_linear_bwd_partials: RELU needs Y");
+    GAE_REQUIRE(!want_dW || (M && ldm >= f_in && f_in > 0), GAE_E_NULL, "gae_linear_bwd_partials: dW needs M");
+    const AtbPlan pl = atb_plan(n, f_out, f_in);
+    const int64_t need = align256(pl.n_slots * pl.slot_stride * 4);
+    GAE_REQUIRE(workspace && workspace_bytes >= need && gae::aligned16(workspace), GAE_E_WORKSPACE,
+                "gae_linear_bwd_partials: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    const bool relu = act == GAE_ACT_RELU;
+    const float *Q = want_dW ? M : dY;
+    const int64_t ldq = want_dW ? ldm : lddy;
+    const int I = want_dW ? int(f_in) : 0;
+    float *partial = static_cast<float *>(workspace);
+    hipStream_t s = gae::as_stream(stream);
+    const int rc = relu ? launch_atb<PRO_RELU_MASK>(dY, lddy, Y, ldy, Q, ldq, n, int(f_out), I, partial, want_db != 0, pl, s)
+                        : launch_atb<PRO_NONE>(dY, lddy, nullptr, 0, Q, ldq, n, int(f_out), I, partial, want_db != 0, pl, s);
+    layout_out[0] = pl.n_slots; layout_out[1] = pl.slot_stride; layout_out[2] = f_out * int64_t(I);
+    return rc;
+}
+
 extern "C" int gae_linear_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, int act, const float *M,
                               int64_t ldm, const float *W, int64_t n, int64_t f_in, int64_t f_out, float *dW,
                               float *db, float *dM, int64_t lddm, void *workspace, int64_t workspace_bytes,
@@ -1573,12 +1599,13 @@ extern "C" int gae_linear_bwd(const float *dY, int64_t lddy, const float *Y, int
         int rc = relu ? launch_atb<PRO_RELU_MASK>(dY, lddy, Y, ldy, Q, ldq, n, int(f_out), I, partial, db != nullptr, pl, s)
                       : launch_atb<PRO_NONE>(dY, lddy, nullptr, 0, Q, ldq, n, int(f_out), I, partial, db != nullptr, pl, s);
         if (rc) return rc;
+        // the slots' tiles and column sums are added in the library's one order for partial lists (gae::sum_partials):
+        // gae_adam_step's deferred reduction of the same slots gives the same bits
         const int64_t n_tile = f_out * I;
-        if (dW)
-            rc = launch_reduce(partial, pl.n_slots, pl.slot_stride, n_tile + (db ? f_out : 0), dW, f_in, f_in, 0, nullptr,
-                               0, db, n_tile, s);
-        else
-            rc = launch_reduce(partial, pl.n_slots, pl.slot_stride, f_out, db, f_out, f_out, 0, nullptr, 0, nullptr, 0, s);
+        gae::PartialList la{}, lb{};
+        if (dW) la = gae::PartialList{partial, dW, n_tile, pl.n_slots, pl.slot_stride, n_tile, n_tile, n_tile};
+        if (db) lb = gae::PartialList{partial + n_tile, db, f_out, pl.n_slots, pl.slot_stride, f_out, f_out, f_out};
+        rc = gae::launch_partials_reduce(la, lb, s);
         if (rc) return rc;
     }
     if (dM && n > 0) {

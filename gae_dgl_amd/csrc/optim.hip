@@ -39,21 +39,40 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
     const float bc1 = float(1.0 - b1t);
     const float bc2_sqrt = float(sqrt(1.0 - b2t));
     const float step_size = lr / bc1;
-    const int64_t base = int64_t(int(blockIdx.x) - a.first_block[k]) * kAdamChunk + threadIdx.x * 4;
+    auto update = [&](int64_t e, float g) {
+        const float p = t.param[e];
+        if (weight_decay != 0.f) g = fmaf(weight_decay, p, g);
+        float m = t.exp_avg[e], v = t.exp_avg_sq[e];
+        m = fmaf(g - m, 1.0f - beta1, m);                          // lerp(m, g, 1 - beta1)
+        v = fmaf(beta2, v, (1.0f - beta2) * g * g);
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        t.param[e] = p - step_size * (m / denom);
+        t.exp_avg[e] = m;
+        t.exp_avg_sq[e] = v;
+    };
+    const int lb = int(blockIdx.x) - a.first_block[k];
+    if (t.n_partials == 0) {
+        const int64_t base = int64_t(lb) * kAdamChunk + threadIdx.x * 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int64_t e = base + q;
-        if (e < t.n) {
-            float g = t.grad[e];
-            const float p = t.param[e];
-            if (weight_decay != 0.f) g = fmaf(weight_decay, p, g);
-            float m = t.exp_avg[e], v = t.exp_avg_sq[e];
-            m = fmaf(g - m, 1.0f - beta1, m);                          // lerp(m, g, 1 - beta1)
-            v = fmaf(beta2, v, (1.0f - beta2) * g * g);
-            const float denom = sqrtf(v) / bc2_sqrt + eps;
-            t.param[e] = p - step_size * (m / denom);
-            t.exp_avg[e] = m;
-            t.exp_avg_sq[e] = v;
+        for (int q = 0; q < 4; ++q) {
+            const int64_t e = base + q;
+            if (e < t.n) update(e, t.grad[e]);
+        }
+    } else {
+        // ---- deferred reduction: the gradient is still a list of partial sums (what gae_xw_wgrad_partials /
+        //      gae_linear_bwd_partials left in their workspace), added in the library's one order for such lists
+        //      (gae::sum_partials: the stand-alone reduction launches give the same bits); the sum is written to
+        //      `grad` and used at once.
+        const int L = gae::partial_lanes(t.n_partials);
+        const int64_t e = int64_t(lb) * (256 / L) + threadIdx.x / L;
+        const int lane = threadIdx.x % L;
+        const bool live = e < t.n;
+        const int64_t ec = live ? e : 0;
+        const float g = gae::sum_partials(t.partials + (ec / t.row_len) * t.row_pitch + ec % t.row_len, t.n_partials,
+                                          t.partial_stride, lane, L);
+        if (live && lane == 0) {
+            t.grad[e] = g;
+            update(e, g);
         }
     }
     // ---- the last block to finish advances the step counter
@@ -91,9 +110,12 @@ extern "C" int gae_adam_step(const gae_adam_tensor *tensors, int32_t n_tensors, 
         GAE_REQUIRE(t.n >= 0, GAE_E_SIZE, "gae_adam_step: tensor %d has a negative size", k);
         GAE_REQUIRE(t.n == 0 || (t.param && t.grad && t.exp_avg && t.exp_avg_sq), GAE_E_NULL,
                     "gae_adam_step: tensor %d has a NULL pointer", k);
+        GAE_REQUIRE(t.n_partials >= 0 && (t.n_partials == 0 || (t.partials && t.row_len > 0 && t.partial_stride >= 0)),
+                    GAE_E_SIZE, "gae_adam_step: tensor %d has a malformed partial-sum list", k);
         a.t[k] = t;
         a.first_block[k] = int32_t(blocks);
-        blocks += (t.n + kAdamChunk - 1) / kAdamChunk;
+        const int64_t per_block = t.n_partials == 0 ? kAdamChunk : (t.n_partials > 32 ? 256 / 64 : 256);
+        blocks += (t.n + per_block - 1) / per_block;
         GAE_REQUIRE(blocks < (int64_t(1) << 30), GAE_E_SIZE, "gae_adam_step: too many elements for one launch");
     }
     a.first_block[n_tensors] = int32_t(blocks);

@@ -420,47 +420,20 @@ __global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
     }
 }
 
-// dW[j][k] = sum_p part[p][j][k],  db[j] = sum_p dbpart[p][j]     (partition order)
-__global__ __launch_bounds__(256) void xtg_reduce_kernel(const float *__restrict__ part, const float *__restrict__ dbpart,
-                                                         int parts, int db_parts, int J, int K, int kp,
-                                                         float *__restrict__ dW, int64_t lddw, float *__restrict__ db)
+// the stand-alone reduction of one or two partial lists (gae::sum_partials order): blocks [0, nb_a) take list a
+__global__ __launch_bounds__(256) void partials_reduce_kernel(const gae::PartialList a, const gae::PartialList b, unsigned nb_a)
 {
-    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (dW != nullptr && e < int64_t(J) * K) {
-        const int j = int(e / K), k = int(e - int64_t(j) * K);
-        const float *p = part + int64_t(j) * kp + k;
-        float s = 0.f;
-        for (int q0 = 0; q0 < parts; q0 += 32) {  // up to 32 partials requested together (branch-free), added in order
-            float v[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) v[u] = p[int64_t(q0 + u < parts ? q0 + u : parts - 1) * 32 * kp];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) s += q0 + u < parts ? v[u] : 0.f;
-        }
-        dW[int64_t(j) * lddw + k] = s;
-    }
-    if (db != nullptr && blockIdx.x == gridDim.x - 1) {
-        // db: thread (grp = tid / 32, j = tid % 32) adds the partials q = grp + 8 i in order -- all of them requested
-        // together -- and the 8 groups meet in LDS in order (the serial walk over 216 partials took 7 round trips)
-        __shared__ float dred[256];
-        const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
-        float s = 0.f;
-        for (int q0 = grp; q0 < db_parts; q0 += 8 * 32) {
-            float v[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) v[u] = dbpart[(q0 + 8 * u < db_parts ? q0 + 8 * u : db_parts - 1) * 32 + j];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) s += q0 + 8 * u < db_parts ? v[u] : 0.f;
-        }
-        dred[threadIdx.x] = s;
-        __syncthreads();
-        if (threadIdx.x < J) {
-            float t = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) t += dred[q * 32 + threadIdx.x];
-            db[threadIdx.x] = t;
-        }
-    }
+    const bool second = blockIdx.x >= nb_a;
+    const gae::PartialList &t = second ? b : a;
+    const unsigned lb = second ? blockIdx.x - nb_a : blockIdx.x;
+    const int L = gae::partial_lanes(t.n_partials);
+    const int64_t e = int64_t(lb) * (256 / L) + threadIdx.x / L;
+    const int lane = threadIdx.x % L;
+    const bool live = e < t.n;
+    const int64_t ec = live ? e : 0;
+    const int64_t r = ec / t.row_len, c = ec % t.row_len;
+    const float g = gae::sum_partials(t.base + r * t.row_pitch + c, t.n_partials, t.stride, lane, L);
+    if (live && lane == 0) t.out[r * t.out_pitch + c] = g;
 }
 
 // ---------------------------------------------------------------------------------------------------- plans
@@ -596,6 +569,20 @@ int xw_fwd_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const 
     return GAE_OK;
 }
 
+int launch_partials_reduce(const PartialList &a, const PartialList &b, hipStream_t s)
+{
+    auto blocks = [](const PartialList &t) -> int64_t {
+        if (t.n <= 0 || t.out == nullptr) return 0;
+        const int per = t.n_partials > 32 ? 256 / 64 : 256;
+        return (t.n + per - 1) / per;
+    };
+    const int64_t na = blocks(a), nb = blocks(b);
+    if (na + nb == 0) return GAE_OK;
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3(unsigned(na + nb)), dim3(256), 0, s, a, b, unsigned(na));
+    GAE_CHECK_LAUNCH("partials_reduce_kernel");
+    return GAE_OK;
+}
+
 int64_t xtg_workspace_bytes(int64_t n, int64_t K, int elem)
 {
     const BwdPlan p = bwd_plan(n, int(K), elem);
@@ -604,7 +591,7 @@ int64_t xtg_workspace_bytes(int64_t n, int64_t K, int elem)
 
 int xtg_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const float *G, int64_t ldg, const float *Gmask,
                int64_t ldgm, const float *D, int64_t ldd, const float *Dmask, int64_t lddm, int J, float *dW,
-               int64_t lddw, float *db, void *ws, int64_t ws_bytes, hipStream_t s)
+               int64_t lddw, float *db, void *ws, int64_t ws_bytes, hipStream_t s, int64_t *layout_only = nullptr)
 {
     const BwdPlan p = bwd_plan(n, K, elem);
     if (ws == nullptr || ws_bytes < xtg_workspace_bytes(n, K, elem)) {
@@ -620,7 +607,11 @@ int xtg_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const flo
     a.g_bytes = unsigned(n * ldg * 4); a.ldg_bytes = unsigned(ldg * 4);
     a.gm_bytes = unsigned(n * ldgm * 4); a.ldgm_bytes = unsigned(ldgm * 4);
     a.ldd = ldd; a.lddm = lddm;
-    const bool want_dw = dW != nullptr, want_db = db != nullptr && D != nullptr;
+    bool want_dw = dW != nullptr, want_db = db != nullptr && D != nullptr;
+    if (layout_only) {                 // partials only: dW / db are flags here, nothing is written to them
+        layout_only[0] = p.parts; layout_only[1] = int64_t(32) * p.kp; layout_only[2] = p.kp;
+        layout_only[3] = int64_t(p.parts) * 32 * p.kp; layout_only[4] = int64_t(p.parts) * p.n_slices; layout_only[5] = 32;
+    }
     if (!want_db) a.D = nullptr;
     if (!want_dw) { a.x_bytes = 0; a.g_bytes = 0; a.gm_bytes = 0; a.Gmask = nullptr; }     // every load behind its buffer: zeros
     // (db alone still sweeps the slices: its rows are dealt to the slice blocks; the products of an unwanted dW go to
@@ -644,11 +635,11 @@ int xtg_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const flo
     }
 #undef GAE_XTG
     GAE_CHECK_LAUNCH("xtg_kernel");
-    const int64_t ne = want_dw ? int64_t(J) * K : 1;
-    hipLaunchKernelGGL(xtg_reduce_kernel, dim3(unsigned((ne + 255) / 256)), dim3(256), 0, s, a.part, a.dbpart, p.parts,
-                       p.parts * p.n_slices, J, K, p.kp, want_dw ? dW : nullptr, lddw, want_db ? db : nullptr);
-    GAE_CHECK_LAUNCH("xtg_reduce_kernel");
-    return GAE_OK;
+    if (layout_only) return GAE_OK;
+    PartialList la{}, lb{};
+    if (want_dw) la = PartialList{a.part, dW, int64_t(J) * K, p.parts, int64_t(32) * p.kp, K, p.kp, lddw};
+    if (want_db) lb = PartialList{a.dbpart, db, J, int64_t(p.parts) * p.n_slices, 32, J, J, J};
+    return launch_partials_reduce(la, lb, s);
 }
 
 } // namespace gae
@@ -713,4 +704,27 @@ extern "C" int gae_xw_wgrad(const void *X, int64_t ldx, int dtype, int64_t n, in
     GAE_REQUIRE(workspace && gae::aligned16(workspace), GAE_E_ALIGN, "gae_xw_wgrad: workspace missing or not 16-byte aligned");
     return gae::xtg_launch(X, ldx, n, int(f_in), elem, G, ldg, Gmask, ldgm, D, ldd, Dmask, lddm, int(f_out), dW, lddw, db,
                            workspace, workspace_bytes, gae::as_stream(stream));
+}
+
+extern "C" int gae_xw_wgrad_partials(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in, const float *G,
+                                     int64_t ldg, const float *Gmask, int64_t ldgm, const float *D, int64_t ldd,
+                                     const float *Dmask, int64_t lddm, int64_t f_out, int want_dW, int want_db,
+                                     void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream)
+{
+    GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16, GAE_E_DTYPE, "gae_xw_wgrad_partials: dtype %d", dtype);
+    GAE_REQUIRE(n > 0 && f_in > 0 && f_out > 0 && layout_out, GAE_E_SIZE, "gae_xw_wgrad_partials: bad sizes");
+    GAE_REQUIRE(want_dW || want_db, GAE_E_RANGE, "gae_xw_wgrad_partials: nothing to compute");
+    GAE_REQUIRE(!want_dW || (X && G && ldg >= f_out), GAE_E_NULL, "gae_xw_wgrad_partials: dW needs X and G");
+    GAE_REQUIRE(!Gmask || ldgm >= f_out, GAE_E_SIZE, "gae_xw_wgrad_partials: ldgm < f_out");
+    GAE_REQUIRE(!want_db || (D && ldd >= f_out && (!Dmask || lddm >= f_out)), GAE_E_NULL, "gae_xw_wgrad_partials: db needs D");
+    const int elem = dtype == GAE_F32 ? 4 : 2;
+    GAE_REQUIRE(!want_dW || gae::xw_usable(X, ldx, n, f_in, f_out, elem), GAE_E_RANGE,
+                "gae_xw_wgrad_partials: operand not accepted (gae_xw_usable)");
+    GAE_REQUIRE(n * ldg * 4 < int64_t(0xE0000000u) && (!Gmask || n * ldgm * 4 < int64_t(0xE0000000u)), GAE_E_SIZE,
+                "gae_xw_wgrad_partials: G larger than a raw buffer resource addresses");
+    GAE_REQUIRE(workspace && gae::aligned16(workspace), GAE_E_ALIGN, "gae_xw_wgrad_partials: workspace missing or unaligned");
+    float flag = 0.f;           // any non-NULL pointer: xtg_launch only tests dW / db for NULL in this mode
+    return gae::xtg_launch(X, ldx, n, int(f_in), elem, G, ldg, Gmask, ldgm, D, ldd, Dmask, lddm, int(f_out),
+                           want_dW ? &flag : nullptr, f_in, want_db ? &flag : nullptr, workspace, workspace_bytes,
+                           gae::as_stream(stream), layout_out);
 }

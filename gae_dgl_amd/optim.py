@@ -14,7 +14,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from .ops import _stream, _on_device
 
 
@@ -94,7 +94,14 @@ class Adam(torch.optim.Optimizer):
                         raise _lib.GaeHipError("gae_dgl_amd.optim.Adam: dense fp32 gradients only")
                     m, v = self._moments(p)
                     keep.append(g)
-                    arr[k] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+                    pend = ops.pending_partials(p.grad)       # deferred reduction (ops.deferred_grad_reductions)
+                    if pend is not None:
+                        keep.append(pend[0])
+                        arr[k] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                                 pend[1], pend[2], pend[3], pend[4], pend[5])
+                    else:
+                        arr[k] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                                 None, 0, 0, 1, 1)
                 key = (gi, c0 // _lib.ADAM_MAX_TENSORS)        # one device counter pair per chunk of 16 tensors
                 if key not in self._counters:
                     self._counters[key] = torch.zeros(_lib.ADAM_STATE_WORDS, dtype=torch.int64, device=dev)

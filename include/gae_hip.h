@@ -323,6 +323,16 @@ int gae_xw_wgrad(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in,
                  const float *G, int64_t ldg, const float *Gmask, int64_t ldgm,
                  const float *D, int64_t ldd, const float *Dmask, int64_t lddm, int64_t f_out,
                  float *dW, int64_t lddw, float *db, void *workspace, int64_t workspace_bytes, void *stream);
+/* The first half of gae_xw_wgrad only: the per-(row partition, column slice) partial products stay in `workspace`
+ * (gae_xw_wgrad_workspace_bytes) and layout_out describes them for gae_adam_step's deferred reduction:
+ *   layout_out[0] = partials of dW, [1] = floats between two of them, [2] = row pitch (floats) of a partial's [f_out]
+ *   rows (element (j, k) of partial q: workspace[q * [1] + j * [2] + k]); [3] = float offset of the db partials,
+ *   [4] = their count, [5] = floats between two of them (element j of partial q: workspace[[3] + q * [5] + j]). */
+int gae_xw_wgrad_partials(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in,
+                          const float *G, int64_t ldg, const float *Gmask, int64_t ldgm,
+                          const float *D, int64_t ldd, const float *Dmask, int64_t lddm, int64_t f_out,
+                          int want_dW, int want_db, void *workspace, int64_t workspace_bytes,
+                          int64_t *layout_out, void *stream);
 int gae_spmm_csr_epilogue(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                           const float *H, int64_t ldh, const float *Hmask, float *Y, int64_t ldy, int64_t F,
                           const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
@@ -346,6 +356,13 @@ int gae_linear_fwd(const float *M, int64_t ldm, int64_t n, int64_t f_in,
  *   dM [n, f_in]     = dYm W        (NULL to skip; layer 1 never needs it)
  * workspace: gae_linear_bwd_workspace_bytes(n, f_in, f_out). */
 int64_t gae_linear_bwd_workspace_bytes(int64_t n, int64_t f_in, int64_t f_out);
+/* The first half of gae_linear_bwd's (dW, db): the per-row-slot partial products stay in `workspace` for
+ * gae_adam_step's deferred reduction.  layout_out[0] = slots, [1] = floats between two slots (element e = o * f_in + i
+ * of slot q: workspace[q * [1] + e]), [2] = float offset of a slot's f_out column sums (db) inside the slot. */
+int gae_linear_bwd_partials(const float *dY, int64_t lddy, const float *Y, int64_t ldy, int act,
+                            const float *M, int64_t ldm, int64_t n, int64_t f_in, int64_t f_out,
+                            int want_dW, int want_db, void *workspace, int64_t workspace_bytes,
+                            int64_t *layout_out, void *stream);
 int gae_linear_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, int act,
                    const float *M, int64_t ldm, const float *W,
                    int64_t n, int64_t f_in, int64_t f_out,
@@ -474,10 +491,18 @@ int gae_segment_readout(const float *Z, int64_t ldz, int64_t n_nodes, int64_t d,
 #define GAE_ADAM_STATE_WORDS 6
 typedef struct gae_adam_tensor {
     float *param;          /* [n] updated in place            (device) */
-    const float *grad;     /* [n]                              (device) */
+    float *grad;           /* [n] read (n_partials = 0) or written (n_partials > 0)  (device) */
     float *exp_avg;        /* [n] first moment, in place       (device) */
     float *exp_avg_sq;     /* [n] second moment, in place      (device) */
     int64_t n;
+    /* Deferred reduction (n_partials > 0): the gradient has not been added up yet -- it is the list of partial sums
+     * gae_xw_wgrad_partials / gae_linear_bwd_partials left in their workspace,
+     *     grad[e] = sum over q < n_partials, in order, of partials[q * partial_stride + (e / row_len) * row_pitch + e % row_len].
+     * The kernel adds the list (deterministic order), WRITES the sum to grad[e] and applies the update: the separate
+     * reduction launch of every weight gradient disappears from a training step (two kernel nodes of ~5 us each).
+     * n_partials = 0: grad holds the gradient. */
+    const float *partials;
+    int64_t n_partials, partial_stride, row_len, row_pitch;
 } gae_adam_tensor;
 int gae_adam_step(const gae_adam_tensor *tensors_host, int32_t n_tensors, float lr, float beta1, float beta2,
                   float eps, float weight_decay, uint64_t *state_dev, void *stream);

@@ -203,3 +203,41 @@ def test_linear_forward_uses_the_stream_family():
     assert rel(dW, dW2) < TOL and rel(db, db2) < TOL
     gm = (dY * (Y > 0)).double()
     assert rel(dW, gm.t() @ M.double()) < TOL and rel(db, gm.sum(0)) < TOL and rel(dM, gm @ W.double()) < TOL
+
+
+def test_deferred_grad_reductions_match_the_separate_launches():
+    """ops.deferred_grad_reductions(): the weight-gradient kernels leave partial sums, gae_adam_step adds them inside the
+    optimiser launch -- gradients (written back by that launch) and updated weights agree with the ordinary
+    backward + step to fp32 rounding of another summation order; leaving the block with unconsumed partials raises"""
+    import copy
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops
+    from gae_dgl_amd.optim import Adam
+    rng = np.random.default_rng(3)
+    n, F_in = 900, 320
+    src, dst = rand_graph(rng, n, 2500)
+    X = torch.from_numpy(rng.standard_normal((n, F_in)).astype(np.float32)).to(DEV)
+    torch.manual_seed(4)
+    m_a = G.GAE(F_in, [32, 16]).to(DEV)
+    m_a.decoder.dropout = 0.0
+    m_b = copy.deepcopy(m_a)
+    o_a, o_b = Adam(m_a.parameters(), lr=1e-2), Adam(m_b.parameters(), lr=1e-2)
+    gr = G.DGLGraph((src, dst), num_nodes=n).to(DEV)
+    for step in range(3):
+        gr.ndata['h'] = X
+        la = m_a.reconstruction_loss(gr)
+        o_a.zero_grad(); ops.backward(la); o_a.step()
+        gr.ndata['h'] = X
+        with ops.deferred_grad_reductions():
+            lb = m_b.reconstruction_loss(gr)
+            ops.backward(lb, list(m_b.parameters()))
+            o_b.step()
+        assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))
+        for pa, pb in zip(m_a.parameters(), m_b.parameters()):
+            assert torch.equal(pb.grad, pa.grad), step         # Adam wrote the reduced gradient back: same order, same bits
+            assert torch.equal(pb, pa), step
+    assert o_a.steps_taken() == o_b.steps_taken() == 3
+    with pytest.raises(ops.GaeHipError):
+        with ops.deferred_grad_reductions():
+            gr.ndata['h'] = X
+            ops.backward(m_b.reconstruction_loss(gr), list(m_b.parameters()))      # no optimiser step inside
