@@ -64,21 +64,39 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
         //      (gae::sum_partials: the stand-alone reduction launches give the same bits); the sum is written to
         //      `grad` and used at once.
         const int L = gae::partial_lanes(t.n_partials);
-        const int64_t e = int64_t(lb) * (256 / L) + threadIdx.x / L;
-        const int lane = threadIdx.x % L;
-        const bool live = e < t.n;
-        const int64_t ec = live ? e : 0;
-        const float g = gae::sum_partials(t.partials + (ec / t.row_len) * t.row_pitch + ec % t.row_len, t.n_partials,
-                                          t.partial_stride, lane, L);
-        if (live && lane == 0) {
-            t.grad[e] = g;
-            update(e, g);
+        const unsigned row_len = unsigned(t.row_len), n32 = unsigned(t.n);          // (sizes checked on the host: < 2^31)
+        if (L == 1) {
+            // 4 elements per thread, block-strided (adjacent lanes read adjacent elements of every partial)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned e = unsigned(lb) * unsigned(kAdamChunk) + unsigned(q) * 256u + threadIdx.x;
+                const unsigned ec = e < n32 ? e : 0u;
+                const unsigned r = ec / row_len, c = ec - r * row_len;
+                const float g = gae::sum_partials(t.partials + int64_t(r) * t.row_pitch + c, t.n_partials,
+                                                  t.partial_stride, 0, 1);
+                if (e < n32) {
+                    t.grad[e] = g;
+                    update(e, g);
+                }
+            }
+        } else {
+            const unsigned e = unsigned(lb) * 4u + threadIdx.x / 64u;
+            const int lane = threadIdx.x % 64;
+            const unsigned ec = e < n32 ? e : 0u;
+            const unsigned r = ec / row_len, c = ec - r * row_len;
+            const float g = gae::sum_partials(t.partials + int64_t(r) * t.row_pitch + c, t.n_partials, t.partial_stride,
+                                              lane, 64);
+            if (e < n32 && lane == 0) {
+                t.grad[e] = g;
+                update(e, g);
+            }
         }
     }
     // ---- the last block to finish advances the step counter
+    // (no fence: every thread of this block has CONSUMED its reads of the state above -- they are complete -- before
+    //  the barrier, and the last block writes the state only after every other block's ticket, i.e. after their reads)
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         const unsigned long long ticket = atomicAdd(&state[1], 1ull);
         if (ticket == gridDim.x - 1ull) {      // every block has read the state by now (its ticket came after its loads)
             double *sw = reinterpret_cast<double *>(state);
@@ -114,7 +132,9 @@ extern "C" int gae_adam_step(const gae_adam_tensor *tensors, int32_t n_tensors, 
                     GAE_E_SIZE, "gae_adam_step: tensor %d has a malformed partial-sum list", k);
         a.t[k] = t;
         a.first_block[k] = int32_t(blocks);
-        const int64_t per_block = t.n_partials == 0 ? kAdamChunk : (t.n_partials > 32 ? 256 / 64 : 256);
+        GAE_REQUIRE(t.n < (int64_t(1) << 31) && t.row_len < (int64_t(1) << 31), GAE_E_SIZE,
+                    "gae_adam_step: tensor %d too large", k);
+        const int64_t per_block = t.n_partials > 32 ? 256 / 64 : kAdamChunk;
         blocks += (t.n + per_block - 1) / per_block;
         GAE_REQUIRE(blocks < (int64_t(1) << 30), GAE_E_SIZE, "gae_adam_step: too many elements for one launch");
     }
