@@ -314,6 +314,8 @@ def batch_gather(graph_ptr, ds_indptr, ds_indices, ds_feat, graph_ids, node_ptr,
     ``pad_to_capacity``: n_nodes / n_edges are CAPACITIES, the rows behind the batch become isolated zero-feature
     nodes and the true {nodes, edges} go to ``counts`` (int64[2], device)."""
     dev = ds_indptr.device
+    if counts is not None and (counts.dtype != torch.int64 or counts.numel() < 3):
+        raise GaeHipError("batch_gather: `counts` must be an int64[3] device tensor {nodes, edges, graphs dropped}")
     if out is not None:
         out_indptr, out_indices, out_feat, table = out
     else:
