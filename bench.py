@@ -109,10 +109,6 @@ def parse():
                          "library's default for layers that narrow wide features (X read once per direction, the 40 MB "
                          "aggregate A X never exists; value of gae.py:26-31 up to fp32 rounding); reference = "
                          "act((A X) W^T + b) in the reference's order (the F_in-wide SpMM is then the dominant launch)")
-    ap.add_argument("--features", choices=["dense", "sparse"], default="dense",
-                    help="citation workloads: dense = X as the reference holds it, a dense FloatTensor (default; the "
-                         "north-star's dense feature matrix); sparse = opt-in gae_dgl_amd.SparseFeatures, the non-zeros of "
-                         "the bag-of-words rows (1-10 %% of the entries): same layer-1 values from gae_spx_fwd / gae_spx_wgrad")
     ap.add_argument("--no-fused-layers", action="store_true",
                     help="run narrow GCN layers as two launches (update_all, apply_nodes) instead of gae_gcn_layer_fused")
     ap.add_argument("--no-hipgraph", action="store_true",
@@ -282,9 +278,6 @@ class CitationWorkload:
         self.opt, opt_name = make_adam(self.model.parameters(), 1e-2, args, self.use_graph)  # train_transductive.py:43
         self.g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
         self.Xd = ops.pad_rows(torch.from_numpy(X).to(dev))                  # rows padded to whole 128-B lines
-        self.sparse = getattr(args, "features", "dense") == "sparse"
-        if self.sparse:
-            self.Xd = G.SparseFeatures.from_dense(self.Xd)                   # once: X is constant across epochs
         self.g.csr(); self.g.csc(); self.g.spmm_plan(False); self.g.spmm_plan(True); self.g.scattered()   # static
         E = self.g.number_of_edges()
         self.edges_per_step = E * (2 * len(self.hidden) - 1)                   # L fwd + (L-1) bwd SpMM launches
@@ -301,16 +294,7 @@ class CitationWorkload:
         self.captured = None
         self.tf = args.layer1 == "transform-first"
         J = self.hidden[0]
-        if self.sparse:
-            nnz = self.Xd.nnz
-            self.dominant = ("spx_fwd", n, self.F_in, J, nnz)
-            self.dominant_desc = (f"spx_fwd P = X W^T from the {nnz} non-zeros of X ({100.0 * nnz / (n * self.F_in):.1f} % "
-                                  f"of {n} x {self.F_in}), opt-in sparse input features")
-            self.alg_bytes = 8 * nnz + 4 * (n + 1) + 4 * (n * J + J * self.F_in)
-            self.pmc_key = ""
-            self.meta["layer1"] = ("sparse input features (opt-in gae_dgl_amd.SparseFeatures): act(A (X W^T) + b) with "
-                                   "X W^T and dW = G^T X from the non-zeros of X (gae_spx_fwd / gae_spx_wgrad)")
-        elif self.tf:
+        if self.tf:
             # the step's HBM-dominant launch is the dense pass over X (gae_xw_fwd); its compulsory bytes: X + P + W
             self.dominant = ("xw_fwd", n, self.F_in, J, "torch.float32")
             self.dominant_desc = (f"xw_fwd P = X W^T, {n} x {self.F_in} -> {J} (layer 1 in transform-first order: the "
@@ -331,9 +315,6 @@ class CitationWorkload:
     def dominant_launch(self):
         """the step's dominant HBM launch on its real operands: X W^T (transform-first) or the aggregation A X"""
         from gae_dgl_amd import ops
-        if self.sparse:
-            W1 = self.model.layers[0].apply_mod.linear.weight.detach()
-            return lambda: ops.spx_fwd_raw(self.Xd, W1)
         if self.tf:
             W1 = self.model.layers[0].apply_mod.linear.weight.detach()
             return lambda: ops.xw_fwd_raw(self.Xd, W1, None, 0)
@@ -1092,28 +1073,6 @@ def main():
             finally:
                 for k in knobs:
                     _lib.call("gae_tuning_set", k, 1)
-    if world == 1 and isinstance(wl, CitationWorkload) and not isinstance(wl, VgaeWorkload) and not args.no_extra \
-            and args.features == "dense" and graphed:
-        # ---- the same step on OPT-IN compressed input features (gae_dgl_amd.SparseFeatures): reported beside the
-        #      headline, never instead of it (the headline keeps the dense feature matrix the reference holds)
-        import copy
-        a2 = copy.copy(args); a2.features = "sparse"
-        w2 = CitationWorkload(workload, a2, dev)
-        for _ in range(args.warmup):
-            w2.step()
-        w2.capture()
-        for _ in range(args.warmup):
-            w2.step()
-        r2 = timed_regions(w2, args, barrier, 1, dev, min_total_s=0.2)
-        e2 = float(np.median(r2))
-        line["sparse_features"] = {"ms_per_step": e2 / args.steps * 1e3, "value": w2.edges_per_step * args.steps / e2,
-                                   "nnz": w2.Xd.nnz, "density": w2.Xd.nnz / float(w2.n * w2.F_in),
-                                   "timing": region_stats(r2, args.steps),
-                                   "note": "same workload, X handed over as gae_dgl_amd.SparseFeatures (non-zeros of the "
-                                           "bag-of-words rows): layer 1 through gae_spx_fwd / gae_spx_wgrad, same values "
-                                           "(tests/test_gpu_sparse_features.py); `python bench.py --features sparse` "
-                                           "gives its full line"}
-        del w2
     if "decoder_bce" in {k[0] for k in times}:
         kb = [k for k in times if k[0] == "decoder_bce"]
         tb = float(np.mean([t for k in kb for t in times[k]]))
