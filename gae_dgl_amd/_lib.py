@@ -61,6 +61,8 @@ SIGNATURES = {
     "gae_batch_plan_next": (_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p]),
     "gae_batch_gather": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _p, _i64, _i64,
                                 _p, _p, _p, _i64, _p, _i32, _i64, _p, _p]),
+    "gae_batch_gather_next": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64,
+                                     _p, _p, _p, _i64, _p, _i32, _p, _p]),
     "gae_decoder_bce_padded": (_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _f, _u64, _u64, _p, _p, _p, _i64,
                                       _p, _i64, _p]),
     "gae_bce_logits_workspace_bytes": (_i64, []),

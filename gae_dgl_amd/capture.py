@@ -32,6 +32,7 @@ class _defer:
             return self.cm.__exit__(*exc)
 
 
+FUSED_COLLATE_MAX_GRAPHS = 1024   # batches up to this size collate in one launch (gae_batch_gather_next); 0 = never
 DEFER_GRAD_REDUCTIONS = True      # False: captured steps keep the separate reduction launches (experiments)
 
 
@@ -150,7 +151,7 @@ class CapturedInductiveStep:
         self.cap_nodes, self.cap_edges = cap_nodes, cap_edges
         self.gids = torch.zeros(B, dtype=torch.int64, device=dev)
         self.ptrs = torch.zeros(2 if ds.symmetric else 3, B + 1, dtype=torch.int64, device=dev)
-        self.counts = torch.zeros(3, dtype=torch.int64, device=dev)   # {nodes, edges, graphs dropped by the guard}
+        self.counts = torch.zeros(4, dtype=torch.int64, device=dev)   # {nodes, edges, graphs dropped by the guard, ticket}
         F, ldo, odt = ops.batch_feature_ld(ds.feat, ds.n_feat)
         ip = torch.zeros(cap_nodes + 1, dtype=torch.int32, device=dev)
         ix = torch.zeros(cap_edges, dtype=torch.int32, device=dev)
@@ -179,12 +180,19 @@ class CapturedInductiveStep:
     def _step_body(self):
         """select + plan -> gather -> forward -> loss -> backward -> Adam, all on static buffers"""
         ds, g = self.ds, self.g
-        node_ptr, edge_ptr, t_edge_ptr = ops.batch_plan_next(ds.graph_ptr, ds.indptr,
-                                                             None if ds.symmetric else ds.t_indptr, self.d_order,
-                                                             self.cursor, self.gids, self.ptrs)
-        ops.batch_gather(ds.graph_ptr, ds.indptr, ds.indices, ds.feat, self.gids, node_ptr, edge_ptr, self.cap_nodes,
-                         self.cap_edges, ell_width=ds.ell_width, n_feat=ds.n_feat, out=self.fwd, pad_to_capacity=True,
-                         counts=self.counts)
+        if ds.symmetric and self.B <= FUSED_COLLATE_MAX_GRAPHS:
+            # small batches are bound by the number of kernel nodes: select + plan + gather as ONE launch
+            ops.batch_gather_next(ds.graph_ptr, ds.indptr, ds.indices, ds.feat, self.d_order, self.cursor, self.gids,
+                                  self.ptrs, self.cap_nodes, self.cap_edges, self.fwd, self.counts,
+                                  ell_width=ds.ell_width, n_feat=ds.n_feat)
+            node_ptr = edge_ptr = t_edge_ptr = None
+        else:
+            node_ptr, edge_ptr, t_edge_ptr = ops.batch_plan_next(ds.graph_ptr, ds.indptr,
+                                                                 None if ds.symmetric else ds.t_indptr, self.d_order,
+                                                                 self.cursor, self.gids, self.ptrs)
+            ops.batch_gather(ds.graph_ptr, ds.indptr, ds.indices, ds.feat, self.gids, node_ptr, edge_ptr,
+                             self.cap_nodes, self.cap_edges, ell_width=ds.ell_width, n_feat=ds.n_feat, out=self.fwd,
+                             pad_to_capacity=True, counts=self.counts)
         if self.bwd is not None:
             ops.batch_gather(ds.graph_ptr, ds.t_indptr, ds.t_indices, None, self.gids, node_ptr, t_edge_ptr,
                              self.cap_nodes, self.cap_edges, ell_width=ds.ell_width, out=self.bwd,

@@ -228,10 +228,45 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
     const int64_t *__restrict__ graph_ids, int64_t n_graphs, const int64_t *__restrict__ out_node_ptr,
     const int64_t *__restrict__ out_edge_ptr, int32_t *__restrict__ out_indptr,
     int32_t *__restrict__ out_indices, TO *__restrict__ out_feat, int64_t ld_out, int32_t *__restrict__ out_ell,
-    int ell_width, int64_t cap_nodes, int64_t cap_edges, int64_t *__restrict__ out_counts)
+    int ell_width, int64_t cap_nodes, int64_t cap_edges, int64_t *__restrict__ out_counts,
+    // gae_batch_gather_next (order != NULL): select + plan + gather in ONE launch for batches of a few hundred graphs --
+    // every wave adds up the sizes of the graphs in front of its own itself (two coalesced passes over <= 1024 ids)
+    const int64_t *__restrict__ order, int64_t n_order, int64_t *__restrict__ cursor, int64_t *__restrict__ ids_out,
+    int64_t *__restrict__ node_ptr_out, int64_t *__restrict__ edge_ptr_out)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t b = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
+    int64_t in_on = 0, in_oe = 0, in_tn = 0, in_te = 0, in_g = 0, in_cur = 0;
+    if (order) {
+        in_cur = *cursor;
+        long long pn = 0, pe = 0, tn = 0, te = 0;
+        for (int64_t q = lane; q < n_graphs; q += kWave) {
+            const int64_t k = in_cur * n_graphs + q;
+            const int64_t gq = order[k < n_order ? k : n_order - 1];
+            const int64_t a0 = graph_ptr[gq], a1 = graph_ptr[gq + 1];
+            const long long nn_ = a1 - a0, ee_ = (long long)ds_indptr[a1] - ds_indptr[a0];
+            tn += nn_; te += ee_;
+            if (q < b) { pn += nn_; pe += ee_; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            pn += __shfl_xor(pn, off, 64); pe += __shfl_xor(pe, off, 64);
+            tn += __shfl_xor(tn, off, 64); te += __shfl_xor(te, off, 64);
+        }
+        in_on = pn; in_oe = pe; in_tn = tn; in_te = te;
+        if (b < n_graphs) {
+            const int64_t k = in_cur * n_graphs + b;
+            in_g = order[k < n_order ? k : n_order - 1];
+            if (lane == 0) { ids_out[b] = in_g; node_ptr_out[b] = in_on; edge_ptr_out[b] = in_oe; }
+        }
+        if (b == 0 && lane == 0) { node_ptr_out[n_graphs] = in_tn; edge_ptr_out[n_graphs] = in_te; }
+        // the cursor advances once every block has read it: the last block to pass here (ticket in out_counts[3])
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long *>(&out_counts[3]), 1ull);
+            if (t == gridDim.x - 1ull) { out_counts[3] = 0; *cursor = in_cur + 1; }
+        }
+    }
     if (b >= n_graphs) {
         // ---- fixed-capacity batch (cap_nodes > 0): the waves behind the last graph turn the rows [N_b, cap_nodes)
         //      into isolated zero-feature nodes -- empty CSR rows, zero features, an empty table row -- so that a
@@ -241,16 +276,31 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
         // (a replay past the validated batches, a stale order) must never write behind them.  Only the longest
         // prefix of graphs that fits is gathered (the graph waves below test the same condition), the rest of the
         // buffers becomes padding and the number of dropped graphs is ADDED to out_counts[2] for the host to see.
-        int64_t keep = n_graphs;
-        if (out_node_ptr[n_graphs] > cap_nodes || out_edge_ptr[n_graphs] > cap_edges) {
-            int64_t lo = 0, hi = n_graphs;                   // largest k with node_ptr[k] / edge_ptr[k] inside
-            while (lo < hi) {
-                const int64_t mid = (lo + hi + 1) >> 1;
-                if (out_node_ptr[mid] <= cap_nodes && out_edge_ptr[mid] <= cap_edges) lo = mid; else hi = mid - 1;
+        int64_t keep = n_graphs, nb, eb;
+        if (order) {
+            nb = in_tn; eb = in_te;
+            if (nb > cap_nodes || eb > cap_edges) {          // (never on a validated order) serial walk to the last fit
+                nb = eb = 0; keep = 0;
+                for (int64_t q = 0; q < n_graphs; ++q) {
+                    const int64_t k = in_cur * n_graphs + q;
+                    const int64_t gq = order[k < n_order ? k : n_order - 1];
+                    const int64_t a0 = graph_ptr[gq], a1 = graph_ptr[gq + 1];
+                    const int64_t e_ = int64_t(ds_indptr[a1]) - ds_indptr[a0];
+                    if (nb + (a1 - a0) > cap_nodes || eb + e_ > cap_edges) break;
+                    nb += a1 - a0; eb += e_; keep = q + 1;
+                }
             }
-            keep = lo;
+        } else {
+            if (out_node_ptr[n_graphs] > cap_nodes || out_edge_ptr[n_graphs] > cap_edges) {
+                int64_t lo = 0, hi = n_graphs;               // largest k with node_ptr[k] / edge_ptr[k] inside
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi + 1) >> 1;
+                    if (out_node_ptr[mid] <= cap_nodes && out_edge_ptr[mid] <= cap_edges) lo = mid; else hi = mid - 1;
+                }
+                keep = lo;
+            }
+            nb = out_node_ptr[keep]; eb = out_edge_ptr[keep];
         }
-        const int64_t nb = out_node_ptr[keep], eb = out_edge_ptr[keep];
         const int64_t n_pad_waves = (int64_t(gridDim.x) * blockDim.x) / kWave - n_graphs;
         const int64_t w = b - n_graphs;
         if (w == 0 && lane == 0) {
@@ -266,9 +316,9 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
         }
         return;
     }
-    const int64_t g = graph_ids[b];
+    const int64_t g = order ? in_g : graph_ids[b];
     const int64_t n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
-    const int64_t on = out_node_ptr[b], oe = out_edge_ptr[b];
+    const int64_t on = order ? in_on : out_node_ptr[b], oe = order ? in_oe : out_edge_ptr[b];
     const int32_t e0 = ds_indptr[n0], e1 = ds_indptr[n1];
     const int64_t nn = n1 - n0;
     if (cap_nodes > 0 && (on + nn > cap_nodes || oe + (e1 - e0) > cap_edges)) return;   // see the guard above
@@ -566,11 +616,49 @@ extern "C" int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indp
     hipLaunchKernelGGL((batch_gather_kernel<TI, TO>), dim3(unsigned(blocks)), dim3(256), 0, s, graph_ptr, ds_indptr,  \
                        ds_indices, static_cast<const TI *>(ds_feat), ld_feat, F, graph_ids, n_graphs, out_node_ptr,  \
                        out_edge_ptr, out_indptr, out_indices, static_cast<TO *>(out_feat), ld_out, out_ell,          \
-                       int(ell_width), cap_nodes, n_batch_edges, out_counts)
+                       int(ell_width), cap_nodes, n_batch_edges, out_counts, nullptr, int64_t(0), nullptr, nullptr,     \
+                       nullptr, nullptr)
     if (dtype == GAE_F32) GAE_BG(float, float);
     else if (dtype == GAE_BF16) GAE_BG(unsigned short, unsigned short);
     else GAE_BG(unsigned char, float);
 #undef GAE_BG
     GAE_CHECK_LAUNCH("batch_gather_kernel");
+    return GAE_OK;
+}
+
+// gae_batch_plan_next + gae_batch_gather in one launch (fixed-capacity batches of <= 1024 graphs): the captured
+// inductive step of the reference's default batch (128 molecules, gae_dgl/train_inductive.py:24) is bound by its
+// number of kernel nodes, and the plan of so few graphs is cheaper to recompute in every wave than to launch.
+extern "C" int gae_batch_gather_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_indices,
+                                     const void *ds_feat, int64_t ld_feat, int64_t F, int dtype, const int64_t *order,
+                                     int64_t n_order, int64_t *cursor_dev, int64_t n_graphs, int64_t *out_ids,
+                                     int64_t *out_node_ptr, int64_t *out_edge_ptr, int64_t cap_nodes, int64_t cap_edges,
+                                     int32_t *out_indptr, int32_t *out_indices, void *out_feat, int64_t ld_out,
+                                     int32_t *out_ell, int32_t ell_width, int64_t *out_counts, void *stream)
+{
+    GAE_REQUIRE(n_graphs >= 1 && n_graphs <= 1024 && n_order >= 1, GAE_E_RANGE,
+                "gae_batch_gather_next: 1 .. 1024 graphs per batch (larger batches: gae_batch_plan_next + gae_batch_gather)");
+    GAE_REQUIRE(cap_nodes >= 1 && cap_edges >= 0 && F >= 0, GAE_E_SIZE, "gae_batch_gather_next: bad capacities");
+    GAE_REQUIRE(ld_feat >= F && ld_out >= F, GAE_E_SIZE, "gae_batch_gather_next: leading dimension < F");
+    GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16 || dtype == GAE_U8, GAE_E_DTYPE, "gae_batch_gather_next: dtype %d", dtype);
+    GAE_REQUIRE(graph_ptr && ds_indptr && order && cursor_dev && out_ids && out_node_ptr && out_edge_ptr && out_indptr &&
+                    out_counts, GAE_E_NULL, "gae_batch_gather_next: NULL pointer");
+    GAE_REQUIRE(cap_edges == 0 || (ds_indices && out_indices), GAE_E_NULL, "gae_batch_gather_next: NULL index pointer");
+    GAE_REQUIRE(F == 0 || !out_feat || ds_feat, GAE_E_NULL, "gae_batch_gather_next: NULL feature pointer");
+    GAE_REQUIRE(!out_ell || ell_width == 4 || ell_width == 8 || ell_width == GAE_SPMM_ELL_WIDTH, GAE_E_RANGE,
+                "gae_batch_gather_next: ell_width must be 4, 8 or %d", GAE_SPMM_ELL_WIDTH);
+    hipStream_t s = gae::as_stream(stream);
+    const int64_t blocks = ((n_graphs + 256) * kWave + 255) / 256;       // one wave per graph + 256 padding waves
+#define GAE_BGN(TI, TO)                                                                                              \
+    hipLaunchKernelGGL((batch_gather_kernel<TI, TO>), dim3(unsigned(blocks)), dim3(256), 0, s, graph_ptr, ds_indptr,   \
+                       ds_indices, static_cast<const TI *>(ds_feat), ld_feat, F, nullptr, n_graphs, nullptr, nullptr,  \
+                       out_indptr, out_indices, static_cast<TO *>(out_feat), ld_out, out_ell, int(ell_width),          \
+                       cap_nodes, cap_edges, out_counts, order, n_order, cursor_dev, out_ids, out_node_ptr,            \
+                       out_edge_ptr)
+    if (dtype == GAE_F32) GAE_BGN(float, float);
+    else if (dtype == GAE_BF16) GAE_BGN(unsigned short, unsigned short);
+    else GAE_BGN(unsigned char, float);
+#undef GAE_BGN
+    GAE_CHECK_LAUNCH("batch_gather_kernel (select + plan + gather)");
     return GAE_OK;
 }

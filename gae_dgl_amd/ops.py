@@ -348,6 +348,32 @@ def batch_gather(graph_ptr, ds_indptr, ds_indices, ds_feat, graph_ids, node_ptr,
     return out_indptr, out_indices, (out_feat[:, :F] if out_feat is not None else None), table
 
 
+def batch_gather_next(graph_ptr, ds_indptr, ds_indices, ds_feat, order, cursor, out_ids, ptrs, cap_nodes, cap_edges, out,
+                      counts, ell_width=0, n_feat=None):
+    """select + plan + gather of the next batch of an uploaded epoch order in ONE launch (gae_batch_gather_next;
+    batches of <= 1024 graphs, symmetric datasets): the ids go to ``out_ids`` (int64 [B]), the prefix sums to ``ptrs``
+    (int64 [2, B + 1]), the capacity-padded batch to ``out`` = (indptr, indices, feat, table), the true sizes to
+    ``counts`` (int64[4], zero before the first call), the cursor advances"""
+    B = out_ids.numel()
+    out_indptr, out_indices, out_feat, table = out
+    feat, ldf = _rowmajor(ds_feat, "ds_feat")
+    F, ldo, odt = batch_feature_ld(feat, n_feat)
+    code = _lib.U8 if feat.dtype == torch.uint8 else _dtype_code(feat)
+    if ptrs.shape[0] < 2 or ptrs.shape[1] != B + 1 or ptrs.dtype != torch.int64 or not ptrs.is_contiguous():
+        raise GaeHipError("batch_gather_next: `ptrs` must be a contiguous int64 [>= 2, B + 1] buffer")
+    if counts.dtype != torch.int64 or counts.numel() < 4:
+        raise GaeHipError("batch_gather_next: `counts` must be an int64[4] device tensor")
+    if out_feat.shape != (cap_nodes, ldo) or out_feat.dtype != odt or out_indptr.numel() != cap_nodes + 1 or \
+            out_indices.numel() < cap_edges or (ell_width and table.numel() != cap_nodes * ell_width):
+        raise GaeHipError("batch_gather_next: `out` buffers have the wrong shape / dtype")
+    with _on_device(order.device):
+        _lib.call("gae_batch_gather_next", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_indices), _ptr(feat), max(ldf, F), F,
+                  code, _ptr(order), order.numel(), _ptr(cursor), B, _ptr(out_ids), _ptr(ptrs[0]), _ptr(ptrs[1]),
+                  int(cap_nodes), int(cap_edges), _ptr(out_indptr), _ptr(out_indices), _ptr(out_feat), max(ldo, F),
+                  _ptr(table) if ell_width else None, int(ell_width), _ptr(counts), _stream())
+    return ptrs[0], ptrs[1]
+
+
 def segment_readout(Z, graph_ptr):
     """[mean | sum | max] of the rows of Z [N, d] per member graph (README.md:54 of the reference: the 48-d molecule
     feature); ``graph_ptr`` int64 [G + 1] node offsets on the device.  Returns [G, 3 d] fp32.  Inference-side op:

@@ -156,6 +156,19 @@ int gae_batch_plan_next(const int64_t *graph_ptr, const int32_t *ds_indptr, cons
 int gae_batch_plan(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
                    const int64_t *graph_ids, int64_t n_graphs, int64_t *out_node_ptr, int64_t *out_edge_ptr,
                    int64_t *out_t_edge_ptr, void *stream);
+/* gae_batch_plan_next + gae_batch_gather (fixed-capacity form) in ONE launch, for batches of <= 1024 graphs: the ids
+ * of batch *cursor_dev of the epoch order, their prefix sums (out_ids [n_graphs], out_node_ptr / out_edge_ptr
+ * [n_graphs + 1]) and the gathered, capacity-padded batch; *cursor_dev += 1.  out_counts: int64[4], ZERO before the
+ * first call -- [0..2] as gae_batch_gather, [3] is the launch's block ticket (left zero).  The CSR of the batch is
+ * used for the transposed structure as well (symmetric datasets: every bond stored in both directions,
+ * gae_dgl/prepare_data.py:61-64). */
+int gae_batch_gather_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_indices,
+                          const void *ds_feat, int64_t ld_feat, int64_t F, int dtype,
+                          const int64_t *order, int64_t n_order, int64_t *cursor_dev, int64_t n_graphs,
+                          int64_t *out_ids, int64_t *out_node_ptr, int64_t *out_edge_ptr,
+                          int64_t cap_nodes, int64_t cap_edges,
+                          int32_t *out_indptr, int32_t *out_indices, void *out_feat, int64_t ld_out,
+                          int32_t *out_ell, int32_t ell_width, int64_t *out_counts, void *stream);
 int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_indices,
                      const void *ds_feat, int64_t ld_feat, int64_t F, int dtype,
                      const int64_t *graph_ids, int64_t n_graphs,

@@ -288,3 +288,53 @@ def test_adam_resume_survives_reload_and_capture():
         assert torch.equal(a["exp_avg"], b["exp_avg"]) and torch.equal(a["exp_avg_sq"], b["exp_avg_sq"])
     r2.step()
     assert opt2.steps_taken() == 4
+
+
+@pytest.mark.parametrize("B", [24, 128, 1000])
+def test_one_launch_collate_equals_plan_then_gather(B):
+    """gae_batch_gather_next (select + plan + gather in one launch) == gae_batch_plan_next followed by gae_batch_gather:
+    ids, prefix sums, CSR, features, packed table and counts bit for bit over consecutive batches of an epoch order; the
+    device cursor advances once per launch; a batch that does not fit is cut to the prefix that does"""
+    from gae_dgl_amd import ops
+    ds, _ = _dataset(max(3 * B + 7, 300))
+    order = np.random.default_rng(B).permutation(ds.ids)
+    d_order = torch.from_numpy(order).to(DEV)
+    n_full = len(order) // B
+    need_n = max(int(ds.sizes_host[order[k * B:(k + 1) * B]].sum()) for k in range(n_full))
+    need_e = max(int(ds.edges_host[order[k * B:(k + 1) * B]].sum()) for k in range(n_full))
+    cap_n, cap_e = need_n + 40, need_e + 100
+    F, ldo, odt = ops.batch_feature_ld(ds.feat, ds.n_feat)
+    W = ds.ell_width
+
+    def buffers():
+        return (torch.full((cap_n + 1,), -5, dtype=torch.int32, device=DEV), torch.full((cap_e,), -5, dtype=torch.int32, device=DEV),
+                torch.full((cap_n, ldo), -5.0, dtype=odt, device=DEV), torch.full((cap_n * W,), -5, dtype=torch.int32, device=DEV))
+    cur_a = torch.zeros(1, dtype=torch.int64, device=DEV); cur_b = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ids_a = torch.empty(B, dtype=torch.int64, device=DEV); ids_b = torch.empty(B, dtype=torch.int64, device=DEV)
+    p_a = torch.empty(2, B + 1, dtype=torch.int64, device=DEV); p_b = torch.empty(2, B + 1, dtype=torch.int64, device=DEV)
+    c_a = torch.zeros(4, dtype=torch.int64, device=DEV); c_b = torch.zeros(4, dtype=torch.int64, device=DEV)
+    for k in range(n_full):
+        out_a, out_b = buffers(), buffers()
+        npt, ept, _ = ops.batch_plan_next(ds.graph_ptr, ds.indptr, None, d_order, cur_a, ids_a, p_a)
+        ops.batch_gather(ds.graph_ptr, ds.indptr, ds.indices, ds.feat, ids_a, npt, ept, cap_n, cap_e, ell_width=W,
+                         n_feat=ds.n_feat, out=out_a, pad_to_capacity=True, counts=c_a)
+        ops.batch_gather_next(ds.graph_ptr, ds.indptr, ds.indices, ds.feat, d_order, cur_b, ids_b, p_b, cap_n, cap_e, out_b,
+                              c_b, ell_width=W, n_feat=ds.n_feat)
+        assert torch.equal(ids_a, ids_b) and torch.equal(p_a, p_b) and int(cur_b) == k + 1 == int(cur_a)
+        assert c_a[:3].tolist() == c_b[:3].tolist() and int(c_b[3]) == 0
+        e = int(c_a[1])
+        assert torch.equal(out_a[0], out_b[0]) and torch.equal(out_a[1][:e], out_b[1][:e])
+        assert torch.equal(out_a[2], out_b[2]) and torch.equal(out_a[3], out_b[3])
+    # ---- capacity guard: buffers one graph too small
+    small_n = int(p_a[0][B - 1]) + 2                                   # fits the first B - 1 graphs of the last batch
+    ip = torch.full((small_n + 1 + 512,), -7, dtype=torch.int32, device=DEV)
+    ix = torch.full((cap_e + 512,), -7, dtype=torch.int32, device=DEV)
+    ft = torch.full((small_n + 64, ldo), -7.0, dtype=odt, device=DEV)
+    tb = torch.full(((small_n + 64) * W,), -7, dtype=torch.int32, device=DEV)
+    cur = torch.full((1,), n_full - 1, dtype=torch.int64, device=DEV)
+    c = torch.zeros(4, dtype=torch.int64, device=DEV)
+    ops.batch_gather_next(ds.graph_ptr, ds.indptr, ds.indices, ds.feat, d_order, cur, ids_b, p_b, small_n, cap_e,
+                          (ip[:small_n + 1], ix[:cap_e], ft[:small_n], tb[:small_n * W]), c, ell_width=W, n_feat=ds.n_feat)
+    torch.cuda.synchronize()
+    assert int(c[2]) >= 1 and int(c[0]) <= small_n and int(c[0]) == int(p_a[0][B - int(c[2])])
+    assert bool((ip[small_n + 1:] == -7).all()) and bool((ft[small_n:] == -7).all()) and bool((tb[small_n * W:] == -7).all())
