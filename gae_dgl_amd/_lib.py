@@ -99,8 +99,10 @@ SIGNATURES = {
     "gae_dropout_mask": (_int, [_p, _i64, _f, _u64, _u64, _p, _p]),
     "gae_normal_noise": (_int, [_p, _i64, _u64, _u64, _p, _p]),
     "gae_vgae_head_workspace_bytes": (_i64, [_i64]),
-    "gae_vgae_head_fwd": (_int, [_p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _p]),
-    "gae_vgae_head_bwd": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p]),
+    "gae_vgae_head_fwd": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _p]),
+    "gae_vgae_head_bwd": (_int, [_p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _p, _p]),
+    "gae_gcn_layer_fused2": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _int, _i64,
+                                    _i64, _p, _p, _i64, _int, _p, _i64, _p]),
     "gae_decoder_dense": (_int, [_p, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "gae_decoder_dense_bwd_workspace_bytes": (_i64, [_i64, _i64]),
     "gae_decoder_dense_bwd": (_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),

@@ -1419,14 +1419,16 @@ __global__ __launch_bounds__(256) void normal_noise_kernel(float *__restrict__ o
 // forward writes z and per-block fp64 partial sums of the KL bracket; backward adds the KL gradient to
 // the gradient arriving through z.
 __global__ __launch_bounds__(256) void vgae_head_fwd_kernel(const float *__restrict__ mu, const float *__restrict__ ls,
-                                                            const float *__restrict__ eps, int64_t n_elems,
-                                                            float *__restrict__ z, double *__restrict__ partial)
+                                                            int64_t ldm, int d, const float *__restrict__ eps,
+                                                            int64_t n_elems, float *__restrict__ z,
+                                                            double *__restrict__ partial)
 {
     __shared__ double red[4];
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     double acc = 0.0;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
-        const float m = mu[e], l = ls[e];
+        const int64_t i = e / d, at = i * ldm + (e - i * d);        // mu / log sigma rows are ldm floats apart
+        const float m = mu[at], l = ls[at];
         const float s = __expf(l);
         z[e] = fmaf(eps[e], s, m);
         acc += double(1.0f + 2.0f * l - m * m - s * s);
@@ -1458,15 +1460,16 @@ __global__ __launch_bounds__(256) void vgae_head_bwd_kernel(const float *__restr
                                                             const float *__restrict__ ls, const float *__restrict__ eps,
                                                             const float *__restrict__ gkl_dev, float inv_n2,
                                                             int64_t n_elems, float *__restrict__ dmu,
-                                                            float *__restrict__ dls)
+                                                            float *__restrict__ dls, int64_t ldm, int d)
 {
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     const float gk = (gkl_dev ? *gkl_dev : 1.0f) * inv_n2;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
-        const float m = mu[e], l = ls[e], s = __expf(l);
+        const int64_t i = e / d, at = i * ldm + (e - i * d);        // mu / log sigma / their gradients: ldm floats apart
+        const float m = mu[at], l = ls[at], s = __expf(l);
         const float g = dz ? dz[e] : 0.f;
-        dmu[e] = fmaf(gk, m, g);
-        dls[e] = fmaf(g * eps[e], s, gk * (s * s - 1.0f));
+        dmu[at] = fmaf(gk, m, g);
+        dls[at] = fmaf(g * eps[e], s, gk * (s * s - 1.0f));
     }
 }
 
@@ -1721,16 +1724,16 @@ static int vgae_blocks(int64_t n_elems)
 
 extern "C" int64_t gae_vgae_head_workspace_bytes(int64_t n_elems) { return n_elems < 0 ? GAE_E_SIZE : 1024 * 8 + 256; }
 
-extern "C" int gae_vgae_head_fwd(const float *mu, const float *logstd, const float *eps, int64_t n, int64_t d,
+extern "C" int gae_vgae_head_fwd(const float *mu, const float *logstd, int64_t ldm, const float *eps, int64_t n, int64_t d,
                                  float *z, float *kl_out, void *workspace, int64_t workspace_bytes, void *stream)
 {
-    GAE_REQUIRE(n > 0 && d > 0, GAE_E_SIZE, "gae_vgae_head_fwd: n and d must be positive");
+    GAE_REQUIRE(n > 0 && d > 0 && ldm >= d && d < (1 << 24), GAE_E_SIZE, "gae_vgae_head_fwd: needs n, d > 0 and ldm >= d");
     GAE_REQUIRE(mu && logstd && eps && z && kl_out && workspace, GAE_E_NULL, "gae_vgae_head_fwd: NULL pointer");
     GAE_REQUIRE(workspace_bytes >= 1024 * 8, GAE_E_WORKSPACE, "gae_vgae_head_fwd: workspace too small");
     hipStream_t s = gae::as_stream(stream);
     const int g = vgae_blocks(n * d);
     double *partial = static_cast<double *>(workspace);
-    hipLaunchKernelGGL(vgae_head_fwd_kernel, dim3(g), dim3(256), 0, s, mu, logstd, eps, n * d, z, partial);
+    hipLaunchKernelGGL(vgae_head_fwd_kernel, dim3(g), dim3(256), 0, s, mu, logstd, ldm, int(d), eps, n * d, z, partial);
     GAE_CHECK_LAUNCH("vgae_head_fwd_kernel");
     // KL = -(0.5 / N) * (1 / N) * sum_ij (...)
     hipLaunchKernelGGL(vgae_kl_finalize_kernel, dim3(1), dim3(256), 0, s, partial, g, -0.5 / (double(n) * double(n)),
@@ -1739,13 +1742,13 @@ extern "C" int gae_vgae_head_fwd(const float *mu, const float *logstd, const flo
     return GAE_OK;
 }
 
-extern "C" int gae_vgae_head_bwd(const float *dz, const float *mu, const float *logstd, const float *eps,
+extern "C" int gae_vgae_head_bwd(const float *dz, const float *mu, const float *logstd, int64_t ldm, const float *eps,
                                  const float *gkl_dev, int64_t n, int64_t d, float *dmu, float *dlogstd, void *stream)
 {
-    GAE_REQUIRE(n > 0 && d > 0, GAE_E_SIZE, "gae_vgae_head_bwd: n and d must be positive");
+    GAE_REQUIRE(n > 0 && d > 0 && ldm >= d && d < (1 << 24), GAE_E_SIZE, "gae_vgae_head_bwd: needs n, d > 0 and ldm >= d");
     GAE_REQUIRE(mu && logstd && eps && dmu && dlogstd, GAE_E_NULL, "gae_vgae_head_bwd: NULL pointer");
     hipLaunchKernelGGL(vgae_head_bwd_kernel, dim3(vgae_blocks(n * d)), dim3(256), 0, gae::as_stream(stream), dz, mu,
-                       logstd, eps, gkl_dev, float(1.0 / (double(n) * double(n))), n * d, dmu, dlogstd);
+                       logstd, eps, gkl_dev, float(1.0 / (double(n) * double(n))), n * d, dmu, dlogstd, ldm, int(d));
     GAE_CHECK_LAUNCH("vgae_head_bwd_kernel");
     return GAE_OK;
 }

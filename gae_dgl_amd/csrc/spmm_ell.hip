@@ -142,6 +142,10 @@ struct EllArgs {
     const float *ep_bias;
     int ep_act;
     const void *Hmask;
+    // two-matrix form of the fused layer (gae_gcn_layer_fused2): stored rows >= w_split of the weight come from W2
+    // (same strides), outputs >= w_split of the bias from bias2 -- two heads on one aggregate, one launch
+    const float *W2, *bias2;
+    int w_split, w_t;             // w_t: W is addressed transposed (the stored row is the input index k, not the output o)
 };
 
 template <typename T>
@@ -282,7 +286,11 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
         for (int q = 0; q < WREG; ++q) {
             const int idx = threadIdx.x + 256 * q, o = idx >> 6, k = idx & 63;
             const bool in = o < a.J && unsigned(k) < a.F;
-            const float w = a.W[in ? int64_t(o) * a.w_so + int64_t(k) * a.w_sk : 0];      // branch-free load
+            const int srow = a.w_t ? k : o;                                   // row of the matrix as it is stored
+            const bool second = a.W2 != nullptr && srow >= a.w_split;
+            const int oo = (second && !a.w_t) ? o - a.w_split : o, kk = (second && a.w_t) ? k - a.w_split : k;
+            const float *wb = second ? a.W2 : a.W;
+            const float w = wb[in ? int64_t(oo) * a.w_so + int64_t(kk) * a.w_sk : 0];      // branch-free load
             wreg[q] = in ? w : 0.f;
         }
     }
@@ -435,7 +443,7 @@ slots_done:
                 for (int q = 0; q < JPL; ++q) {
                     const int o = lig * JPL + q;
                     if (o < a.J) {
-                        float y = yv[q] + (a.bias ? a.bias[o] : 0.f);
+                        float y = yv[q] + (a.bias ? ((a.bias2 != nullptr && o >= a.w_split) ? a.bias2[o - a.w_split] : a.bias[o]) : 0.f);
                         if (a.act == GAE_ACT_RELU) y = fmaxf(y, 0.f);
                         a.Y[row[r] * a.ldy + o] = y;
                     }
@@ -555,11 +563,45 @@ int spmm_ell_launch(const int32_t *indptr, const int32_t *indices, const int32_t
 
 // GCN.forward (gae_dgl/gae.py:26-31) in one launch: update_all(copy_src, sum) and NodeApplyModule (Linear + bias +
 // activation) -- see the EPI_J form of spmm_ell_kernel.
+static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                                const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F, const float *row_scale,
+                                const float *col_scale, const gae_spmm_plan *plan, const float *W, int64_t w_stride_out,
+                                int64_t w_stride_in, const float *bias, int64_t J, int act, float *Y, int64_t ldy,
+                                const float *W2, const float *bias2, int64_t w_split, int w_transposed, void *stream);
+
 extern "C" int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                                    const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
                                    const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
                                    const float *W, int64_t w_stride_out, int64_t w_stride_in, const float *bias,
                                    int64_t J, int act, float *Y, int64_t ldy, void *stream)
+{
+    return gcn_layer_fused_impl(indptr, indices, n_rows, n_cols, H, ldh, M, ldm, F, row_scale, col_scale, plan, W,
+                                w_stride_out, w_stride_in, bias, J, act, Y, ldy, nullptr, nullptr, 0, 0, stream);
+}
+
+// Two GCN heads on ONE aggregate in one launch (VGAE: mu and log sigma, gae_dgl_amd/vgae.py): the weight is the
+// stack [W; W2] along its STORED rows (both matrices share the strides; w_split rows belong to W), the bias [b; b2].
+// Forward (w_transposed = 0): Y[:, :w_split] = act(M W^T + b), Y[:, w_split:] = act(M W2^T + b2).  Backward of
+// identity heads (w_transposed = 1, strides swapped as in gae_gcn_layer_fused): dH = (A^T dY) [W; W2].
+extern "C" int gae_gcn_layer_fused2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                                    const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
+                                    const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
+                                    const float *W, const float *W2, int64_t w_split, int w_transposed,
+                                    int64_t w_stride_out, int64_t w_stride_in, const float *bias, const float *bias2,
+                                    int64_t J, int act, float *Y, int64_t ldy, void *stream)
+{
+    GAE_REQUIRE(W2 != nullptr && w_split >= 1, GAE_E_NULL, "gae_gcn_layer_fused2: W2 / w_split missing");
+    GAE_REQUIRE(w_split < (w_transposed ? F : J), GAE_E_RANGE, "gae_gcn_layer_fused2: w_split outside the stacked rows");
+    GAE_REQUIRE((bias == nullptr) == (bias2 == nullptr), GAE_E_NULL, "gae_gcn_layer_fused2: give both biases or none");
+    return gcn_layer_fused_impl(indptr, indices, n_rows, n_cols, H, ldh, M, ldm, F, row_scale, col_scale, plan, W,
+                                w_stride_out, w_stride_in, bias, J, act, Y, ldy, W2, bias2, w_split, w_transposed, stream);
+}
+
+static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                                const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F, const float *row_scale,
+                                const float *col_scale, const gae_spmm_plan *plan, const float *W, int64_t w_stride_out,
+                                int64_t w_stride_in, const float *bias, int64_t J, int act, float *Y, int64_t ldy,
+                                const float *W2, const float *bias2, int64_t w_split, int w_transposed, void *stream)
 {
     GAE_REQUIRE(n_rows >= 0 && n_cols >= 0, GAE_E_SIZE, "gae_gcn_layer_fused: negative size");
     GAE_REQUIRE(F >= 1 && F <= 64 && J >= 1 && J <= 32, GAE_E_RANGE,
@@ -591,6 +633,7 @@ extern "C" int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices
     a.xcd_tiled = 0; a.store_pad = 0; a.store_mode = 0;
     a.W = W; a.bias = bias; a.Y = Y; a.ldy = ldy; a.J = int(J); a.w_so = int(w_stride_out); a.w_sk = int(w_stride_in);
     a.act = act; a.store_m = M != nullptr;
+    a.W2 = W2; a.bias2 = bias2; a.w_split = int(w_split); a.w_t = w_transposed;
     hipStream_t s = gae::as_stream(stream);
     const bool scaled = row_scale != nullptr;
     const int ew = plan->ell_width;

@@ -801,13 +801,16 @@ def linear_fwd_raw(M, W, b, act):
     return Y
 
 
-def linear_bwd_raw(dY, Y, act, M, W, need_dW=True, need_db=True, need_dM=True):
+def linear_bwd_raw(dY, Y, act, M, W, need_dW=True, need_db=True, need_dM=True, f_out=None):
     dY, lddy = _rowmajor(_f32(dY, "linear backward: dY"), "dY")
     M, ldm = _rowmajor(_f32(M, "linear backward: M"), "M")
-    W = _f32(W, "linear backward: W").contiguous()
+    if W is not None:
+        W = _f32(W, "linear backward: W").contiguous()
+    elif need_dM or f_out is None:
+        raise GaeHipError("linear backward: dM needs W (and f_out must be given without it)")
     _f32(Y, "linear backward: Y")
     n, f_in = M.shape
-    f_out = W.shape[0]
+    f_out = W.shape[0] if W is not None else int(f_out)
     dev = M.device
     dW = torch.empty(f_out, f_in, dtype=torch.float32, device=dev) if need_dW else None
     db = torch.empty(f_out, dtype=torch.float32, device=dev) if need_db else None
@@ -868,7 +871,7 @@ class VGAEHeadFunction(torch.autograd.Function):
         kl = torch.empty(1, dtype=torch.float32, device=mu.device)
         with _on_device(mu.device):
             ws = _workspace(_lib.load().gae_vgae_head_workspace_bytes(n * d), mu.device)
-            _lib.call("gae_vgae_head_fwd", _ptr(mu), _ptr(logstd), _ptr(eps), n, d, _ptr(z), _ptr(kl), _ptr(ws),
+            _lib.call("gae_vgae_head_fwd", _ptr(mu), _ptr(logstd), d, _ptr(eps), n, d, _ptr(z), _ptr(kl), _ptr(ws),
                       ws.numel(), _stream())
         ctx.save_for_backward(mu, logstd, eps)
         return z, kl.reshape(())
@@ -881,9 +884,45 @@ class VGAEHeadFunction(torch.autograd.Function):
         dz = None if dz is None else dz.contiguous()
         gkl = (torch.zeros(1, device=mu.device) if dkl is None else dkl.reshape(1).float().contiguous())
         with _on_device(mu.device):
-            _lib.call("gae_vgae_head_bwd", _ptr(dz), _ptr(mu), _ptr(logstd), _ptr(eps), _ptr(gkl), n, d, _ptr(dmu),
+            _lib.call("gae_vgae_head_bwd", _ptr(dz), _ptr(mu), _ptr(logstd), d, _ptr(eps), _ptr(gkl), n, d, _ptr(dmu),
                       _ptr(dls), _stream())
         return dmu, dls, None
+
+
+class VGAEPackedHeadFunction(torch.autograd.Function):
+    """the same on both heads PACKED in one [n, 2 d] matrix [mu | logstd] (what GCNTwoHeadFunction produces): one
+    gradient matrix goes back, no slicing / concatenation kernels in between"""
+
+    @staticmethod
+    def forward(ctx, ml, eps):
+        ml = _gpu(ml, "ml").contiguous(); eps = eps.contiguous()
+        n, d2 = ml.shape
+        d = d2 // 2
+        z = torch.empty(n, d, dtype=torch.float32, device=ml.device)
+        kl = torch.empty(1, dtype=torch.float32, device=ml.device)
+        with _on_device(ml.device):
+            ws = _workspace(_lib.load().gae_vgae_head_workspace_bytes(n * d), ml.device)
+            _lib.call("gae_vgae_head_fwd", _ptr(ml), _vp(ml.data_ptr() + 4 * d), d2, _ptr(eps), n, d, _ptr(z), _ptr(kl),
+                      _ptr(ws), ws.numel(), _stream())
+        ctx.save_for_backward(ml, eps)
+        return z, kl.reshape(())
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        ml, eps = ctx.saved_tensors
+        n, d2 = ml.shape
+        d = d2 // 2
+        dml = torch.empty_like(ml)
+        dz = None if dz is None else dz.contiguous()
+        gkl = (torch.zeros(1, device=ml.device) if dkl is None else dkl.reshape(1).float().contiguous())
+        with _on_device(ml.device):
+            _lib.call("gae_vgae_head_bwd", _ptr(dz), _ptr(ml), _vp(ml.data_ptr() + 4 * d), d2, _ptr(eps), _ptr(gkl), n, d,
+                      _ptr(dml), _vp(dml.data_ptr() + 4 * d), _stream())
+        return dml, None
+
+
+def vgae_head_packed(ml, eps):
+    return VGAEPackedHeadFunction.apply(ml, eps)
 
 
 def vgae_head(mu, logstd, eps):
@@ -1082,6 +1121,94 @@ class GCNLayerFusedFunction(torch.autograd.Function):
             else:
                 dH = spmm_raw(t_indptr, t_indices, dM, n, norm, norm, plan=plan_t, blockdiag=blockdiag, scattered=sc)
         return dH, dW, db, None, None, None
+
+
+def _split_pending(t, rows):
+    """a deferred gradient ``t`` [R, ...] handed out as the two row blocks t[:rows], t[rows:]: register the partial
+    lists of the halves (same workspace, second one offset)"""
+    ent = _PENDING.pop(t.data_ptr(), None)
+    if ent is None:
+        return
+    ws, ptr, n_part, stride, _, _ = ent
+    per_row = t[0].numel() if t.dim() > 1 else 1
+    n0, n1 = rows * per_row, (t.shape[0] - rows) * per_row
+    _PENDING[t[:rows].data_ptr()] = (ws, ptr, n_part, stride, max(n0, 1), max(n0, 1))
+    _PENDING[t[rows:].data_ptr()] = (ws, ptr + 4 * n0, n_part, stride, max(n1, 1), max(n1, 1))
+
+
+class GCNTwoHeadFunction(torch.autograd.Function):
+    """two identity-activation GCN layers on the same input (VGAE's mu and log sigma heads) as ONE fused launch
+    (gae_gcn_layer_fused2): ML = [(A H) W1^T + b1 | (A H) W2^T + b2].  Backward: one dW launch for both heads
+    (dML^T M, split by rows), one fused launch dH = (A^T dML) [W1; W2] -- instead of two of each plus an add."""
+
+    @staticmethod
+    def forward(ctx, H, W1, b1, W2, b2, graph, use_norm):
+        indptr, indices = graph.csr()
+        norm = graph.norm() if use_norm else None
+        n = graph.number_of_nodes()
+        plan = graph.spmm_plan(False)
+        Hc, ldh = _rowmajor(_f32(_gpu(H, "H"), "two heads: H"), "H")
+        W1 = W1 if W1.stride(1) == 1 else W1.contiguous()
+        W2 = W2 if W2.stride(1) == 1 and W2.stride(0) == W1.stride(0) else W2.contiguous()
+        F, d1, d2 = Hc.shape[1], W1.shape[0], W2.shape[0]
+        need_w = any(ctx.needs_input_grad[1:5])
+        M = torch.empty(n, padded_ld(F, torch.float32), dtype=torch.float32, device=Hc.device)[:, :F] if need_w else None
+        Y = torch.empty(n, d1 + d2, dtype=torch.float32, device=Hc.device)
+        with _on_device(Hc.device):
+            _lib.call("gae_gcn_layer_fused2", _ptr(indptr), _ptr(indices), n, Hc.shape[0], _ptr(Hc), ldh, _ptr(M),
+                      M.stride(0) if M is not None else 0, F, _ptr(norm), _ptr(norm), ctypes.byref(plan.c), _ptr(W1),
+                      _ptr(W2), d1, 0, W1.stride(0), 1, _ptr(b1), _ptr(b2), d1 + d2, ACT_IDENTITY, _ptr(Y), d1 + d2,
+                      _stream())
+        ctx.bwd = (graph.csc(), n, norm, graph.spmm_plan(True), d1, d2, b1 is not None)
+        ctx.save_for_backward(M, W1, W2)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        M, W1, W2 = ctx.saved_tensors
+        (t_indptr, t_indices), n, norm, plan_t, d1, d2, has_bias = ctx.bwd
+        need_dH = ctx.needs_input_grad[0]
+        need_dW = ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+        need_db = has_bias and (ctx.needs_input_grad[2] or ctx.needs_input_grad[4])
+        dW1 = db1 = dW2 = db2 = dH = None
+        dYc = dY.contiguous()
+        if need_dW or need_db:
+            dW, db, _ = linear_bwd_raw(dYc, None, ACT_IDENTITY, M, None, need_dW, need_db, False, f_out=d1 + d2)
+            if dW is not None:
+                _split_pending(dW, d1)
+                dW1, dW2 = dW[:d1], dW[d1:]
+            if db is not None:
+                _split_pending(db, d1)
+                db1, db2 = db[:d1], db[d1:]
+        if need_dH:
+            F = W1.shape[1]
+            dH = torch.empty(n, F, dtype=torch.float32, device=dYc.device)
+            with _on_device(dYc.device):
+                # dH = (A^T dY) [W1; W2]: the stacked matrix addressed transposed (element (o, k) at row k, column o)
+                _lib.call("gae_gcn_layer_fused2", _ptr(t_indptr), _ptr(t_indices), n, n, _ptr(dYc), d1 + d2, None, 0,
+                          d1 + d2, _ptr(norm), _ptr(norm), ctypes.byref(plan_t.c), _ptr(W1), _ptr(W2), d1, 1, 1,
+                          W1.stride(0), None, None, F, ACT_IDENTITY, _ptr(dH), F, _stream())
+        return dH, dW1, db1, dW2, db2, None, None
+
+
+def gcn_two_heads(graph, H, lin1, lin2, use_norm=False):
+    """[head1 | head2] of two identity-activation GCN layers (nn.Linear modules lin1, lin2) on ``H`` in one launch, or
+    None when the shapes / the graph do not allow the fused layer"""
+    if not isinstance(H, torch.Tensor) or not H.is_cuda or H.dtype != torch.float32 or graph.number_of_edges() == 0:
+        return None
+    Hc, _ = _rowmajor(H, "H")
+    if Hc.stride(0) % 4 or Hc.data_ptr() % 16:
+        Hc = pad_rows(Hc)
+    d1, d2 = lin1.weight.shape[0], lin2.weight.shape[0]
+    plan, plan_t = graph.spmm_plan(False), graph.spmm_plan(True)
+    if lin1.weight.shape[1] != lin2.weight.shape[1] or (lin1.bias is None) != (lin2.bias is None):
+        return None
+    if not gcn_layer_fused_usable(Hc, d1 + d2, plan) or not _table_only(plan_t) or d1 + d2 > FUSED_LAYER_MAX_IN:
+        return None
+    bd = graph.block_diag
+    if bd is not None and bd.usable(Hc, Hc.shape[1], Hc.stride(0), Hc.stride(0)):
+        return None
+    return GCNTwoHeadFunction.apply(Hc, lin1.weight, lin1.bias, lin2.weight, lin2.bias, graph, use_norm)
 
 
 def gcn_layer(graph, H, W, b, act, use_norm=False):

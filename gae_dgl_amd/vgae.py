@@ -15,6 +15,11 @@ from . import ops
 from .gae import GCN, InnerProductDecoder, identity
 
 
+# mu and log sigma heads as ONE fused launch on the shared aggregate (gae_gcn_layer_fused2) and one packed gradient
+# path; False runs them as two GCN layers (same values up to the fp32 rounding of the dW summation order)
+FUSE_HEADS = True
+
+
 class VGAE(nn.Module):
     def __init__(self, in_dim, hidden_dims=(32, 16), *, norm=None, seed=None):
         super().__init__()
@@ -28,8 +33,23 @@ class VGAE(nn.Module):
         self.eps = None          # inject a fixed noise tensor for tests; None = draw from the library RNG
         self.last = {}
 
+    def _heads_packed(self, g, h):
+        """[mu | logstd] from ONE fused launch on the shared aggregate (ops.GCNTwoHeadFunction), or None"""
+        if not FUSE_HEADS:
+            return None
+        g._follow(h)
+        mode = g.norm_mode if self.mu_head.norm is None else self.mu_head.norm
+        if mode not in ("none", "both"):
+            return None
+        return ops.gcn_two_heads(g, h, self.mu_head.apply_mod.linear, self.logstd_head.apply_mod.linear,
+                                 use_norm=(mode == "both"))
+
     def encode(self, g):
         h = self.shared(g, g.ndata['h'])
+        ml = self._heads_packed(g, h)
+        if ml is not None:
+            d = ml.shape[1] // 2
+            return ml[:, :d], ml[:, d:]
         mu = self.mu_head(g, h)
         logstd = self.logstd_head(g, h)
         return mu, logstd
@@ -46,9 +66,18 @@ class VGAE(nn.Module):
 
     def loss(self, g):
         """reconstruction BCE (train_inductive.py:44-48 semantics, fused) + KL"""
-        mu, logstd = self.encode(g)
-        eps = self._noise(mu)
-        z, kl = ops.vgae_head(mu, logstd, eps)
+        h = self.shared(g, g.ndata['h'])
+        ml = self._heads_packed(g, h)
+        if ml is not None:                       # both heads in one launch, [mu | logstd] packed end to end
+            d = ml.shape[1] // 2
+            mu, logstd = ml[:, :d], ml[:, d:]
+            eps = self._noise(mu)
+            z, kl = ops.vgae_head_packed(ml, eps)
+        else:
+            mu = self.mu_head(g, h)
+            logstd = self.logstd_head(g, h)
+            eps = self._noise(mu)
+            z, kl = ops.vgae_head(mu, logstd, eps)
         g.ndata['h'] = z
         rec = self.decoder.loss(z, g)
         self.last = {"mu": mu, "logstd": logstd, "eps": eps, "z": z, "kl": kl, "rec": rec}

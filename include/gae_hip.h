@@ -355,6 +355,18 @@ int gae_spmm_csr_epilogue(const int32_t *indptr, const int32_t *indices, int64_t
                           const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
                           const float *bias, int act, void *stream);
 
+/* Two GCN heads on one aggregate in ONE launch (VGAE's mu and log sigma heads, gae_dgl_amd/vgae.py; the reference has
+ * a single head: gae_dgl/gae.py:36-45): gae_gcn_layer_fused with the weight given as two matrices stacked along their
+ * STORED rows ([W; W2], w_split rows in W, same strides) and the bias as [bias; bias2].  Forward (w_transposed = 0):
+ * Y = [act(M W^T + b) | act(M W2^T + b2)].  Backward of identity heads (w_transposed = 1, strides swapped as in
+ * gae_gcn_layer_fused): dH = (A^T dY) [W; W2]. */
+int gae_gcn_layer_fused2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                         const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
+                         const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
+                         const float *W, const float *W2, int64_t w_split, int w_transposed,
+                         int64_t w_stride_out, int64_t w_stride_in, const float *bias, const float *bias2,
+                         int64_t J, int act, float *Y, int64_t ldy, void *stream);
+
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16
  * M [n, f_in] (ldm), W [f_out, f_in] row-major contiguous (nn.Linear.weight,
@@ -411,15 +423,17 @@ int gae_decoder_dense_bwd(const float *G, int64_t ldg, const float *Z, const flo
  * gae_normal_noise : eps ~ N(0,1), Philox4x32-10 + Box-Muller, same (seed, offset, draw_dev) contract as
  *                    gae_dropout_mask.
  * gae_vgae_head_fwd: z = mu + eps * exp(logstd);  kl_out = -(0.5/N) * mean_i sum_j (1 + 2 logstd - mu^2 -
- *                    exp(2 logstd))   (one fp32 on the device); mu/logstd/eps/z contiguous [n, d].
+ *                    exp(2 logstd))   (one fp32 on the device); eps / z contiguous [n, d]; the rows of mu and of
+ *                    logstd (and of their gradients in gae_vgae_head_bwd) are ldm floats apart -- ldm = d for
+ *                    separate matrices, 2 d when both heads come packed as [mu | logstd] from gae_gcn_layer_fused2.
  * gae_vgae_head_bwd: dmu = dz + gkl * dKL/dmu, dlogstd = dz * eps * exp(logstd) + gkl * dKL/dlogstd, with
  *                    gkl = *gkl_dev (upstream gradient of the KL scalar; NULL = 1), dz may be NULL (= 0). */
 int gae_normal_noise(float *out, int64_t n_elems, uint64_t seed, uint64_t offset, const uint64_t *draw_dev,
                      void *stream);
 int64_t gae_vgae_head_workspace_bytes(int64_t n_elems);
-int gae_vgae_head_fwd(const float *mu, const float *logstd, const float *eps, int64_t n, int64_t d,
+int gae_vgae_head_fwd(const float *mu, const float *logstd, int64_t ldm, const float *eps, int64_t n, int64_t d,
                       float *z, float *kl_out, void *workspace, int64_t workspace_bytes, void *stream);
-int gae_vgae_head_bwd(const float *dz, const float *mu, const float *logstd, const float *eps,
+int gae_vgae_head_bwd(const float *dz, const float *mu, const float *logstd, int64_t ldm, const float *eps,
                       const float *gkl_dev, int64_t n, int64_t d, float *dmu, float *dlogstd, void *stream);
 
 /* ---- K7+K8+K9 fused: decoder + weighted BCE-with-logits, never materialising N x N

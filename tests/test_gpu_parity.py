@@ -1073,6 +1073,40 @@ def test_vgae_matches_oracle(dtype, tol, n_small, dev):
     assert float(l.detach()) < first
 
 
+def test_vgae_fused_heads_equal_two_layers(dev):
+    """mu and log sigma heads as ONE fused launch (gae_gcn_layer_fused2 + the packed head kernels) == the two GCN layers
+    they replace: forward values bit for bit (same aggregation order, same per-output product), every parameter gradient
+    within the fp32 tolerance (one dW launch for both heads, another summation order for dH)"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, vgae as V, workloads as W
+    n, src, dst, X = W.citation_graph("cora", seed=0)
+    g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    Xd = ops.pad_rows(torch.from_numpy(X).to(dev))
+    out = {}
+    for fused in (True, False):
+        V.FUSE_HEADS = fused
+        try:
+            torch.manual_seed(0)
+            model = V.VGAE(X.shape[1], [32, 16], seed=5).to(dev)
+            calls = []
+            orig = ops.gcn_two_heads
+            ops.gcn_two_heads = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            g.ndata['h'] = Xd
+            loss = model.loss(g)
+            ops.gcn_two_heads = orig
+            assert len(calls) == (1 if fused else 0)
+            loss.backward()
+            out[fused] = (float(loss), {k: v.detach().clone() for k, v in model.last.items() if k in ("mu", "logstd", "z")},
+                          {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+        finally:
+            V.FUSE_HEADS = True
+    assert out[True][0] == out[False][0]
+    for k in ("mu", "logstd", "z"):
+        assert torch.equal(out[True][1][k], out[False][1][k]), k
+    for k in out[True][2]:
+        assert rel_err(out[True][2][k], out[False][2][k]) < TOL, k
+
+
 def test_vgae_captured_step_equals_eager_steps(dev):
     """the VGAE step (noise drawn from a device-side draw counter) as one captured HIP graph: the replayed losses and
     the trained parameters equal those of the same steps launched eagerly, bit for bit"""
