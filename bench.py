@@ -317,7 +317,7 @@ class CitationWorkload:
         from gae_dgl_amd import ops
         if self.tf:
             W1 = self.model.layers[0].apply_mod.linear.weight.detach()
-            return lambda: ops.xw_fwd_raw(self.Xd, W1, None, 0)
+            return lambda: ops.xw_fwd_raw(self.Xd, W1, None, 0, keep_splits=True)      # as the step launches it
         ip, ix = self.g.csr()
         out = ops.pad_rows(torch.empty(self.Xd.shape, device=self.dev))
         plan = self.g.spmm_plan(False)
@@ -427,7 +427,7 @@ class VgaeWorkload(CitationWorkload):
         from gae_dgl_amd import ops
         if self.tf:
             W1 = self.model.shared.apply_mod.linear.weight.detach()
-            return lambda: ops.xw_fwd_raw(self.Xd, W1, None, 0)
+            return lambda: ops.xw_fwd_raw(self.Xd, W1, None, 0, keep_splits=True)      # as the step launches it
         ip, ix = self.g.csr()
         out = ops.pad_rows(torch.empty(self.Xd.shape, dtype=self.Xd.dtype, device=self.dev))
         plan = self.g.spmm_plan(False)

@@ -81,10 +81,11 @@ SIGNATURES = {
     "gae_spmm_csr_blockdiag": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _int,
                                       _p]),
     "gae_spmm_csr_epilogue": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p, _i64, _i64, _p, _p, ctypes.POINTER(SpmmPlan),
-                                     _p, _int, _p]),
+                                     _p, _int, _i64, _i64, _p]),
+    "gae_xw_fwd_splits": (_i64, [_i64, _i64, _i64, _int]),
     "gae_xw_usable": (_int, [_p, _i64, _int, _i64, _i64, _i64]),
     "gae_xw_fwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _int]),
-    "gae_xw_fwd": (_int, [_p, _i64, _int, _i64, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _p]),
+    "gae_xw_fwd": (_int, [_p, _i64, _int, _i64, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _int, _p]),
     "gae_xw_wgrad_workspace_bytes": (_i64, [_i64, _i64, _int]),
     "gae_xw_wgrad": (_int, [_p, _i64, _int, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _p,
                             _p, _i64, _p]),

@@ -1497,7 +1497,7 @@ namespace gae {
 bool xw_usable(const void *X, int64_t ldx, int64_t n, int64_t K, int64_t J, int elem);
 int64_t xw_fwd_workspace_bytes(int64_t n, int64_t K, int64_t J, int elem);
 int xw_fwd_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const float *W, int64_t ldw, const float *bias,
-                  int J, int act, float *out, int64_t ldo, void *ws, int64_t ws_bytes, hipStream_t s);
+                  int J, int act, float *out, int64_t ldo, void *ws, int64_t ws_bytes, hipStream_t s, bool keep_splits);
 int64_t xtg_workspace_bytes(int64_t n, int64_t K, int elem);
 int xtg_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const float *G, int64_t ldg, const float *Gmask,
                int64_t ldgm, const float *D, int64_t ldd, const float *Dmask, int64_t lddm, int J, float *dW,
@@ -1529,7 +1529,7 @@ extern "C" int gae_linear_fwd(const float *M, int64_t ldm, int64_t n, int64_t f_
         (gae::xw_fwd_workspace_bytes(n, f_in, f_out, 4) == 0 ||
          (workspace && workspace_bytes >= gae::xw_fwd_workspace_bytes(n, f_in, f_out, 4))))
         return gae::xw_fwd_launch(M, ldm, n, int(f_in), 4, W, f_in, b, int(f_out), act, Y, ldy, workspace, workspace_bytes,
-                                  gae::as_stream(stream));
+                                  gae::as_stream(stream), false);
     return dispatch_gemm<true, PRO_NONE, false>(M, ldm, nullptr, 0, W, f_in, nullptr, 0, b, act, Y, ldy, n, int(f_in),
                                                 f_out, gae::as_stream(stream), static_cast<float *>(workspace),
                                                 workspace ? workspace_bytes / 4 : 0);

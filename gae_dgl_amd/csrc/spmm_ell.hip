@@ -142,6 +142,11 @@ struct EllArgs {
     const float *ep_bias;
     int ep_act;
     const void *Hmask;
+    // GATHER MODE 2 (split-sum): H is the first of n_splits partial matrices split_bytes apart (what gae_xw_fwd leaves
+    // when it splits a long f_in over thread blocks); a gathered row is the sum of its n_splits partial rows, added in
+    // split order -- the value the stand-alone split reduction would have stored, without that launch
+    int n_splits;
+    unsigned split_bytes, empty_off;   // empty_off: byte offset of an empty table slot (behind every operand)
     // two-matrix form of the fused layer (gae_gcn_layer_fused2): stored rows >= w_split of the weight come from W2
     // (same strides), outputs >= w_split of the bias from bias2 -- two heads on one aggregate, one launch
     const float *W2, *bias2;
@@ -181,12 +186,14 @@ __device__ __forceinline__ u32x4 relu_gate(u32x4 v, const u32x4 m)
 
 // Slots [B0, B0 + N) of the RPG rows, straight-line: every load is issued before the first add.  Rows of the wave
 // with fewer neighbours get zeros from the bounds check.
-template <typename T, int LP16, int RPG, int NREG, int B0, int N, bool SCALED, bool MASKED>
+template <typename T, int LP16, int RPG, int NREG, int B0, int N, bool SCALED, int MODE>
 __device__ __forceinline__ void ell_slots(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_buffer_rsrc_t rs_c,
                                           __amdgpu_buffer_rsrc_t rs_m,
                                           const unsigned (&off)[RPG][NREG], const unsigned (&coff)[RPG][NREG],
-                                          unsigned lane_off, bool live, float (&acc)[RPG][Vec16<T>::NV])
+                                          unsigned lane_off, bool live, float (&acc)[RPG][Vec16<T>::NV], int n_splits,
+                                          unsigned split_bytes)
 {
+    constexpr bool MASKED = MODE == 1;
     unsigned vo[RPG][N], co[RPG][N];
 #pragma unroll
     for (int r = 0; r < RPG; ++r) {
@@ -204,6 +211,23 @@ __device__ __forceinline__ void ell_slots(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_
                 if (MASKED) msk[r][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, vo[r][u], 0, 0);
                 if (SCALED) cs[r][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, co[r][u], 0, 0));
             }
+        if constexpr (MODE == 2) {
+            for (int sp = 1; sp < n_splits; ++sp) {          // + the row's other partials, in split order
+                u32x4 more[RPG][N];
+#pragma unroll
+                for (int r = 0; r < RPG; ++r)
+#pragma unroll
+                    for (int u = 0; u < N; ++u)
+                        more[r][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_h, vo[r][u] + unsigned(sp) * split_bytes, 0, 0);
+#pragma unroll
+                for (int r = 0; r < RPG; ++r)
+#pragma unroll
+                    for (int u = 0; u < N; ++u)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            raw[r][u][i] = __float_as_uint(__uint_as_float(raw[r][u][i]) + __uint_as_float(more[r][u][i]));
+            }
+        }
 #pragma unroll
         for (int r = 0; r < RPG; ++r)
 #pragma unroll
@@ -218,12 +242,13 @@ __device__ __forceinline__ void ell_slots(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_
 // One batch: slots [B0, B0 + NB).  Only as many slots as the longest row of the WAVE fills are touched (scalar
 // count from the ballots, one straight-line body per count): a bounds-checked load that returns zeros still costs
 // its address-unit cycles (no-edge launch of the Pubmed shape: 14.2 us with 8 such loads per row, 9 us without).
-template <typename T, int LP16, int RPG, int NREG, int B0, int NB, bool SCALED, bool MASKED, int... U>
+template <typename T, int LP16, int RPG, int NREG, int B0, int NB, bool SCALED, int MODE, int... U>
 __device__ __forceinline__ void ell_batch(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_buffer_rsrc_t rs_c,
                                           __amdgpu_buffer_rsrc_t rs_m,
                                           const unsigned (&off)[RPG][NREG], const unsigned (&coff)[RPG][NREG],
                                           const unsigned long long (&valid)[RPG][NREG], unsigned lane_off, bool live,
-                                          float (&acc)[RPG][Vec16<T>::NV], std::integer_sequence<int, U...>)
+                                          float (&acc)[RPG][Vec16<T>::NV], int n_splits, unsigned split_bytes,
+                                          std::integer_sequence<int, U...>)
 {
     int cnt = 0;       // slots of this batch that hold a neighbour in some row of the wave (they fill from the left)
     (([&] {
@@ -238,7 +263,7 @@ __device__ __forceinline__ void ell_batch(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_
 #define GAE_ELL_CASE(N)                                                                                      \
     case N:                                                                                                  \
         if constexpr (N <= NB)                                                                               \
-            ell_slots<T, LP16, RPG, NREG, B0, (N <= NB ? N : 1), SCALED, MASKED>(rs_h, rs_c, rs_m, off, coff, lane_off, live, acc); \
+            ell_slots<T, LP16, RPG, NREG, B0, (N <= NB ? N : 1), SCALED, MODE>(rs_h, rs_c, rs_m, off, coff, lane_off, live, acc, n_splits, split_bytes); \
         break;
         GAE_ELL_CASE(1) GAE_ELL_CASE(2) GAE_ELL_CASE(3) GAE_ELL_CASE(4)
         GAE_ELL_CASE(5) GAE_ELL_CASE(6) GAE_ELL_CASE(7) GAE_ELL_CASE(8)
@@ -269,10 +294,11 @@ __device__ __forceinline__ float group_allreduce(float p)
 // the weight rows (LDS copy, loaded once per block), a DPP butterfly adds the LPR lanes, lane l keeps outputs
 // l J / LPR ....  NodeApplyModule after update_all (gae.py:28-29) without the round trip of M through HBM and
 // without a second launch.
-template <typename T, int LPR, int RPG, int W, int NB, bool SCALED, int EPI_J = 0, bool MASKED = false>
+template <typename T, int LPR, int RPG, int W, int NB, bool SCALED, int EPI_J = 0, int MODE = 0>
 __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
 {
-    static_assert(!MASKED || sizeof(T) == 4, "the gather gate is an fp32 form");
+    constexpr bool MASKED = MODE == 1;             // MODE: 0 plain gather, 1 ReLU-gated gather, 2 split-sum gather
+    static_assert(MODE == 0 || sizeof(T) == 4, "the gated and split-sum gathers are fp32 forms");
     constexpr int NV = Vec16<T>::NV;
     constexpr int LDW = 68;                         // floats per LDS weight row: 64 columns + 4 (bank spread)
     __shared__ __attribute__((aligned(16))) float Ws[EPI_J > 0 ? EPI_J * LDW : 4];
@@ -340,7 +366,7 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
             const int s = q * LP16 + (lane & (LP16 - 1));
             int32_t j = -1;
             if (row[r] < a.n_rows && s < W) j = a.ell[row[r] * W + s];
-            off[r][q] = min(unsigned(j), a.n_cols) * a.ldh_bytes;       // empty / marker -> behind the buffer
+            off[r][q] = unsigned(j) < a.n_cols ? unsigned(j) * a.ldh_bytes : a.empty_off;   // empty / marker -> behind the buffer
             if (SCALED) coff[r][q] = min(unsigned(j), a.n_cols) * 4u;
             valid[r][q] = __builtin_amdgcn_ballot_w64(j >= 0);
             if (s == 0) first = j;
@@ -357,7 +383,8 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
         _Pragma("unroll") for (int r = 0; r < RPG; ++r)                                                            \
             more = more || (valid[r][(B0) / LP16] & holder_mask<LP16, (B0)>()) != 0;                               \
         if (!more) goto slots_done;                                                                                \
-        ell_batch<T, LP16, RPG, NREG, (B0), NB, SCALED, MASKED>(rs_h, rs_c, rs_m, off, coff, valid, lane_off, live, acc, \
+        ell_batch<T, LP16, RPG, NREG, (B0), NB, SCALED, MODE>(rs_h, rs_c, rs_m, off, coff, valid, lane_off, live, acc, \
+                                                              a.n_splits, a.split_bytes,                           \
                                                         std::make_integer_sequence<int, NB>{});                    \
     }
     GAE_ELL_BATCH(0)
@@ -378,6 +405,14 @@ slots_done:
                 for (int32_t e = a.indptr[row[r]] + (W - 1); e < e1; ++e) {
                     const unsigned j = unsigned(a.indices[e]);
                     u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_h, j * a.ldh_bytes + lane_off, 0, 0);
+                    if constexpr (MODE == 2)
+                        for (int sp = 1; sp < a.n_splits; ++sp) {
+                            const u32x4 more = __builtin_amdgcn_raw_buffer_load_b128(
+                                rs_h, j * a.ldh_bytes + lane_off + unsigned(sp) * a.split_bytes, 0, 0);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                raw[i] = __float_as_uint(__uint_as_float(raw[i]) + __uint_as_float(more[i]));
+                        }
                     if (MASKED)
                         raw = relu_gate(raw, __builtin_amdgcn_raw_buffer_load_b128(rs_m, j * a.ldh_bytes + lane_off, 0, 0));
                     if (SCALED) Vec16<T>::fma(acc[r], raw, a.col_scale[j]);
@@ -550,6 +585,7 @@ int spmm_ell_launch(const int32_t *indptr, const int32_t *indices, const int32_t
     a.n_rows = n_rows; a.ldm = ldm;
     a.ldh_bytes = unsigned(ldh * elem);
     a.h_bytes = unsigned(n_cols * ldh * elem);
+    a.empty_off = a.h_bytes; a.n_splits = 1;
     a.n_cols = unsigned(n_cols); a.F = unsigned(F); a.nvec = unsigned((F + nv - 1) / nv);
     a.tile_vecs = unsigned(tile_vecs);
     a.xcd_tiled = xcd_tiled; a.store_pad = store_pad; a.store_mode = store_mode;
@@ -628,6 +664,7 @@ static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, i
     a.n_rows = n_rows; a.ldm = M ? ldm : 0;
     a.ldh_bytes = unsigned(ldh * 4);
     a.h_bytes = unsigned(n_cols * ldh * 4);
+    a.empty_off = a.h_bytes; a.n_splits = 1;
     a.n_cols = unsigned(n_cols); a.F = unsigned(F); a.nvec = unsigned((F + 3) / 4);
     a.tile_vecs = a.nvec;
     a.xcd_tiled = 0; a.store_pad = 0; a.store_mode = 0;
@@ -642,25 +679,25 @@ static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, i
 }
 
 namespace {
-template <int LPR, int W, int NB>
-int launch_ell_gated(const EllArgs &a, bool scaled, hipStream_t s)
+template <int LPR, int W, int NB, int MODE>
+int launch_ell_mode(const EllArgs &a, bool scaled, hipStream_t s)
 {
     constexpr int RPB = 256 / LPR;
     EllArgs b = a;
     b.n_row_blocks = unsigned((a.n_rows + RPB - 1) / RPB);
     b.n_ftiles = 1;
     const dim3 grid(b.n_row_blocks, 1);
-    if (scaled) hipLaunchKernelGGL((spmm_ell_kernel<float, LPR, 1, W, NB, true, 0, true>), grid, dim3(256), 0, s, b);
-    else hipLaunchKernelGGL((spmm_ell_kernel<float, LPR, 1, W, NB, false, 0, true>), grid, dim3(256), 0, s, b);
-    GAE_CHECK_LAUNCH("spmm_ell_kernel (gated gather)");
+    if (scaled) hipLaunchKernelGGL((spmm_ell_kernel<float, LPR, 1, W, NB, true, 0, MODE>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((spmm_ell_kernel<float, LPR, 1, W, NB, false, 0, MODE>), grid, dim3(256), 0, s, b);
+    GAE_CHECK_LAUNCH("spmm_ell_kernel (gated / split-sum gather)");
     return GAE_OK;
 }
-template <int LPR>
-int launch_ell_gated_w(const EllArgs &a, int W, bool scaled, hipStream_t s)
+template <int LPR, int MODE>
+int launch_ell_mode_w(const EllArgs &a, int W, bool scaled, hipStream_t s)
 {
-    if (W == 4) return launch_ell_gated<LPR, 4, 4>(a, scaled, s);
-    if (W == 8) return launch_ell_gated<LPR, 8, 8>(a, scaled, s);
-    return launch_ell_gated<LPR, 16, 8>(a, scaled, s);
+    if (W == 4) return launch_ell_mode<LPR, 4, 4, MODE>(a, scaled, s);
+    if (W == 8) return launch_ell_mode<LPR, 8, 8, MODE>(a, scaled, s);
+    return launch_ell_mode<LPR, 16, 8, MODE>(a, scaled, s);
 }
 } // namespace
 
@@ -675,8 +712,12 @@ int launch_ell_gated_w(const EllArgs &a, int W, bool scaled, hipStream_t s)
 extern "C" int gae_spmm_csr_epilogue(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                                      const float *H, int64_t ldh, const float *Hmask, float *Y, int64_t ldy, int64_t F,
                                      const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
-                                     const float *bias, int act, void *stream)
+                                     const float *bias, int act, int64_t n_splits, int64_t split_stride, void *stream)
 {
+    GAE_REQUIRE(n_splits >= 1 && (n_splits == 1 || (split_stride >= n_cols * ldh && Hmask == nullptr)), GAE_E_RANGE,
+                "gae_spmm_csr_epilogue: n_splits >= 1; split partials need split_stride >= n_cols * ldh and no Hmask");
+    GAE_REQUIRE(n_splits == 1 || n_splits * split_stride * 4 < (int64_t(1) << 27), GAE_E_SIZE,
+                "gae_spmm_csr_epilogue: split partials larger than 128 MiB");
     GAE_REQUIRE(n_rows >= 0 && n_cols >= 0, GAE_E_SIZE, "gae_spmm_csr_epilogue: negative size");
     GAE_REQUIRE(F >= 1 && F <= 64, GAE_E_RANGE, "gae_spmm_csr_epilogue: needs 1 <= F <= 64 (got %lld)", (long long)F);
     GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_RANGE, "gae_spmm_csr_epilogue: act %d", act);
@@ -702,11 +743,18 @@ extern "C" int gae_spmm_csr_epilogue(const int32_t *indptr, const int32_t *indic
     a.n_cols = unsigned(n_cols); a.F = unsigned(F); a.nvec = unsigned((F + 3) / 4);
     a.tile_vecs = a.nvec;
     a.xcd_tiled = 0; a.store_pad = 1; a.store_mode = 0;     // (rows of Y are whole vectors: checked above)
+    a.empty_off = a.h_bytes; a.n_splits = 1;
     a.ep_bias = bias; a.ep_act = act; a.Hmask = Hmask;
     hipStream_t s = gae::as_stream(stream);
     const bool scaled = row_scale != nullptr;
     const int ew = plan->ell_width;
+    if (n_splits > 1) {
+        a.n_splits = int(n_splits); a.split_bytes = unsigned(split_stride * 4);
+        a.h_bytes = unsigned(((n_splits - 1) * split_stride + n_cols * ldh) * 4);     // the buffer covers every partial
+        a.empty_off = 0xF0000000u;          // + (n_splits - 1) split_bytes stays behind the buffer (< 2^27 checked above)
+        return a.nvec <= 8 ? launch_ell_mode_w<8, 2>(a, ew, scaled, s) : launch_ell_mode_w<16, 2>(a, ew, scaled, s);
+    }
     if (Hmask != nullptr)
-        return a.nvec <= 8 ? launch_ell_gated_w<8>(a, ew, scaled, s) : launch_ell_gated_w<16>(a, ew, scaled, s);
+        return a.nvec <= 8 ? launch_ell_mode_w<8, 1>(a, ew, scaled, s) : launch_ell_mode_w<16, 1>(a, ew, scaled, s);
     return a.nvec <= 8 ? launch_ell_w<float, 8, 1>(a, ew, scaled, s) : launch_ell_w<float, 16, 1>(a, ew, scaled, s);
 }

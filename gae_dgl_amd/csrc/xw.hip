@@ -540,8 +540,10 @@ int64_t xw_fwd_workspace_bytes(int64_t n, int64_t K, int64_t J, int elem)
     return p.splits > 1 ? (int64_t(p.splits) * n * J * 4 + 255) / 256 * 256 : 0;
 }
 
+int xw_fwd_splits(int64_t n, int64_t K, int elem) { return fwd_plan(n, int(K), elem).splits; }
+
 int xw_fwd_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const float *W, int64_t ldw, const float *bias,
-                  int J, int act, float *out, int64_t ldo, void *ws, int64_t ws_bytes, hipStream_t s)
+                  int J, int act, float *out, int64_t ldo, void *ws, int64_t ws_bytes, hipStream_t s, bool keep_splits)
 {
     FwdPlan p = fwd_plan(n, K, elem);
     if (p.splits > 1 && (ws == nullptr || ws_bytes < int64_t(p.splits) * n * J * 4)) {
@@ -572,7 +574,7 @@ int xw_fwd_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const 
     }
 #undef GAE_XW
     GAE_CHECK_LAUNCH("xw_fwd_kernel");
-    if (p.splits > 1) {
+    if (p.splits > 1 && !keep_splits) {
         const int64_t ne = n * J;
         hipLaunchKernelGGL(xw_split_reduce_kernel, dim3(unsigned((ne + 255) / 256)), dim3(256), 0, s,
                            static_cast<const float *>(ws), p.splits, n, J, bias, act, out, ldo);
@@ -670,15 +672,24 @@ extern "C" int64_t gae_xw_fwd_workspace_bytes(int64_t n, int64_t f_in, int64_t f
     return gae::xw_fwd_workspace_bytes(n, f_in, f_out, dtype == GAE_F32 ? 4 : 2);
 }
 
+extern "C" int64_t gae_xw_fwd_splits(int64_t n, int64_t f_in, int64_t f_out, int dtype)
+{
+    if (n < 1 || f_in < 1 || f_out < 1 || f_out > 32 || f_in >= (1 << 24) || (dtype != GAE_F32 && dtype != GAE_BF16))
+        return GAE_E_SIZE;
+    return gae::xw_fwd_splits(n, f_in, dtype == GAE_F32 ? 4 : 2);
+}
+
 extern "C" int gae_xw_fwd(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in, const float *W, int64_t ldw,
                           const float *b, int64_t f_out, int act, float *P, int64_t ldp, void *workspace,
-                          int64_t workspace_bytes, void *stream)
+                          int64_t workspace_bytes, int keep_splits, void *stream)
 {
+    GAE_REQUIRE(!keep_splits || (b == nullptr && act == GAE_ACT_IDENTITY), GAE_E_RANGE,
+                "gae_xw_fwd: keep_splits leaves bias and activation to the consumer");
     GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16, GAE_E_DTYPE, "gae_xw_fwd: dtype %d", dtype);
     GAE_REQUIRE(n >= 0 && f_in >= 0 && f_out >= 0, GAE_E_SIZE, "gae_xw_fwd: negative size");
     GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_DTYPE, "gae_xw_fwd: activation %d", act);
     if (n == 0 || f_out == 0) return GAE_OK;
-    GAE_REQUIRE(X && W && P, GAE_E_NULL, "gae_xw_fwd: NULL pointer");
+    GAE_REQUIRE(X && W && (P || keep_splits), GAE_E_NULL, "gae_xw_fwd: NULL pointer");
     GAE_REQUIRE(ldw >= f_in && ldp >= f_out, GAE_E_SIZE, "gae_xw_fwd: leading dimension too small");
     const int elem = dtype == GAE_F32 ? 4 : 2;
     GAE_REQUIRE(gae::xw_usable(X, ldx, n, f_in, f_out, elem), GAE_E_RANGE,
@@ -686,7 +697,7 @@ extern "C" int gae_xw_fwd(const void *X, int64_t ldx, int dtype, int64_t n, int6
                 "(gae_xw_usable); use gae_linear_fwd");
     GAE_REQUIRE(!workspace || gae::aligned16(workspace), GAE_E_ALIGN, "gae_xw_fwd: workspace not 16-byte aligned");
     return gae::xw_fwd_launch(X, ldx, n, int(f_in), elem, W, ldw, b, int(f_out), act, P, ldp, workspace, workspace_bytes,
-                              gae::as_stream(stream));
+                              gae::as_stream(stream), keep_splits != 0);
 }
 
 extern "C" int64_t gae_xw_wgrad_workspace_bytes(int64_t n, int64_t f_in, int dtype)

@@ -1241,8 +1241,11 @@ def xw_usable(X, n_out):
     return bool(_lib.load().gae_xw_usable(_ptr(X), X.stride(0), _dtype_code(X), X.shape[0], X.shape[1], int(n_out)))
 
 
-def xw_fwd_raw(X, W, b, act):
-    """P = act(X W^T + b) with X read once and W stationary in registers (gae_xw_fwd); X fp32 or bf16 storage"""
+def xw_fwd_raw(X, W, b, act, keep_splits=False):
+    """P = act(X W^T + b) with X read once and W stationary in registers (gae_xw_fwd); X fp32 or bf16 storage.
+    ``keep_splits`` (b None, identity): when the library splits a long f_in over thread blocks, return the partial
+    products [splits, n, f_out] instead of their sum (a consumer adds them: spmm_epilogue_raw) -- returns (P, 1) when
+    there is no split"""
     W = _f32(_gpu(W, "W"), "xw_fwd: W")
     if W.stride(1) != 1:
         W = W.contiguous()
@@ -1250,20 +1253,30 @@ def xw_fwd_raw(X, W, b, act):
     n, f_in = X.shape
     f_out = W.shape[0]
     code = _dtype_code(X)
-    P = torch.empty(n, f_out, dtype=torch.float32, device=X.device)
+    lib = _lib.load()
+    splits = int(lib.gae_xw_fwd_splits(n, f_in, f_out, code)) if keep_splits else 1
+    keep = keep_splits and splits > 1
     with _on_device(X.device):
-        nbytes = _lib.load().gae_xw_fwd_workspace_bytes(n, f_in, f_out, code)
+        nbytes = lib.gae_xw_fwd_workspace_bytes(n, f_in, f_out, code)
         if nbytes < 0:
             _lib.check(int(nbytes), "gae_xw_fwd_workspace_bytes")
-        ws = _workspace(nbytes, X.device) if nbytes > 0 else None
+        if keep:       # the partials ARE the result: a buffer of their own, not the shared scratch
+            parts = torch.empty(splits, n, f_out, dtype=torch.float32, device=X.device)
+            ws, ws_n, P = parts, parts.numel() * 4, None
+        else:
+            ws = _workspace(nbytes, X.device) if nbytes > 0 else None
+            ws_n = ws.numel() if ws is not None else 0
+            P = torch.empty(n, f_out, dtype=torch.float32, device=X.device)
 
         def launch():
             _lib.call("gae_xw_fwd", _ptr(X), X.stride(0), code, n, f_in, _ptr(W), W.stride(0), _ptr(b), f_out, int(act),
-                      _ptr(P), max(f_out, 1), _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+                      _ptr(P), max(f_out, 1), _ptr(ws), ws_n, 1 if keep else 0, _stream())
         if profiler is not None:
             profiler.wrap(("xw_fwd", n, f_in, f_out, str(X.dtype)), launch)
         else:
             launch()
+    if keep_splits:
+        return (parts, splits) if keep else (P, 1)
     return P
 
 
@@ -1311,7 +1324,16 @@ def xw_wgrad_raw(X, G, Gmask, D, Dmask, f_out, need_dW=True, need_db=True):
 def spmm_epilogue_raw(indptr, indices, H, n_rows, plan, bias=None, act=ACT_IDENTITY, Hmask=None, row_scale=None,
                       col_scale=None):
     """Y = act(diag(rs) A diag(cs) (H (.) [Hmask > 0]) + bias) in one launch of the packed-table kernel
-    (gae_spmm_csr_epilogue); H fp32 [n_cols, F <= 64] with rows of whole 16-byte vectors"""
+    (gae_spmm_csr_epilogue); H fp32 [n_cols, F <= 64] with rows of whole 16-byte vectors -- or a contiguous stack
+    [splits, n_cols, F] of partial matrices (xw_fwd_raw(keep_splits=True)): a gathered row is then the sum of its
+    partial rows in split order"""
+    n_splits, split_stride = 1, 0
+    if H.dim() == 3:
+        if Hmask is not None or not H.is_contiguous() or H.shape[2] % 4 or H.data_ptr() % 16:
+            H = H.sum(0)                                    # (not reached by the library's own callers)
+        else:
+            n_splits, split_stride = int(H.shape[0]), int(H.shape[1] * H.shape[2])
+            H = H[0]
     H, ldh = _rowmajor(_f32(_gpu(H, "H"), "spmm_epilogue: H"), "H")
     if ldh % 4 or H.data_ptr() % 16:
         H = pad_rows(H); ldh = H.stride(0)
@@ -1329,7 +1351,7 @@ def spmm_epilogue_raw(indptr, indices, H, n_rows, plan, bias=None, act=ACT_IDENT
         def launch():
             _lib.call("gae_spmm_csr_epilogue", _ptr(indptr), _ptr(indices), n_rows, n_cols, _ptr(H), ldh, _ptr(Hmask),
                       _ptr(Y), ldy, F, _ptr(row_scale), _ptr(col_scale), ctypes.byref(plan.c), _ptr(bias), int(act),
-                      _stream())
+                      n_splits, split_stride, _stream())
         if profiler is not None:
             profiler.wrap(("spmm", n_rows, n_cols, F, str(H.dtype)), launch)
         else:
@@ -1363,7 +1385,8 @@ class GCNTransformFirstFunction(torch.autograd.Function):
         indptr, indices = graph.csr()
         norm = graph.norm() if use_norm else None
         n = graph.number_of_nodes()
-        P = xw_fwd_raw(H, W, None, ACT_IDENTITY)
+        # (a long f_in is split over thread blocks: the aggregation adds the partial rows itself, no reduction launch)
+        P, _ = xw_fwd_raw(H, W, None, ACT_IDENTITY, keep_splits=W.shape[0] % 4 == 0)
         Y = spmm_epilogue_raw(indptr, indices, P, n, graph.spmm_plan(False), b, act, None, norm, norm)
         ctx.act, ctx.has_bias = act, b is not None
         ctx.bwd = (graph.csc(), n, norm, graph.spmm_plan(True))

@@ -329,12 +329,20 @@ int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices, int64_t n
  *                 db [f_out] = colsum(D (.) [Dmask > 0])              (db / D / Dmask may be NULL)
  *                 partial sums per (row partition, column slice) are added in partition order: deterministic.
  *   gae_spmm_csr_epilogue: Y = act(rs A cs (H (.) [Hmask > 0]) + bias); Hmask (may be NULL) has the layout of H;
- *                 F <= 64, fp32, a plan with a packed neighbour table and no heavy / XCD-pinned rows; CSR-order sums. */
+ *                 F <= 64, fp32, a plan with a packed neighbour table and no heavy / XCD-pinned rows; CSR-order sums.
+ *                 n_splits > 1: H is the first of n_splits partial matrices split_stride floats apart -- what
+ *                 gae_xw_fwd leaves with keep_splits = 1 when it splits a long f_in over thread blocks -- and a gathered
+ *                 row is the sum of its partial rows in split order: the value the split reduction would have stored,
+ *                 without that launch (Cora / Citeseer: one kernel node less per step).
+ *   gae_xw_fwd_splits: the number of partial matrices gae_xw_fwd computes for these sizes (1: none). */
 int gae_xw_usable(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in, int64_t f_out);
 int64_t gae_xw_fwd_workspace_bytes(int64_t n, int64_t f_in, int64_t f_out, int dtype);
+int64_t gae_xw_fwd_splits(int64_t n, int64_t f_in, int64_t f_out, int dtype);
+/* keep_splits = 1 (b = NULL, act = identity, gae_xw_fwd_splits(...) > 1): the partial products [splits][n][f_out] stay
+ * in `workspace` for a consumer that adds them itself (gae_spmm_csr_epilogue); P is not written. */
 int gae_xw_fwd(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in,
                const float *W, int64_t ldw, const float *b, int64_t f_out, int act,
-               float *P, int64_t ldp, void *workspace, int64_t workspace_bytes, void *stream);
+               float *P, int64_t ldp, void *workspace, int64_t workspace_bytes, int keep_splits, void *stream);
 int64_t gae_xw_wgrad_workspace_bytes(int64_t n, int64_t f_in, int dtype);
 int gae_xw_wgrad(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in,
                  const float *G, int64_t ldg, const float *Gmask, int64_t ldgm,
@@ -353,7 +361,7 @@ int gae_xw_wgrad_partials(const void *X, int64_t ldx, int dtype, int64_t n, int6
 int gae_spmm_csr_epilogue(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                           const float *H, int64_t ldh, const float *Hmask, float *Y, int64_t ldy, int64_t F,
                           const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
-                          const float *bias, int act, void *stream);
+                          const float *bias, int act, int64_t n_splits, int64_t split_stride, void *stream);
 
 /* Two GCN heads on one aggregate in ONE launch (VGAE's mu and log sigma heads, gae_dgl_amd/vgae.py; the reference has
  * a single head: gae_dgl/gae.py:36-45): gae_gcn_layer_fused with the weight given as two matrices stacked along their

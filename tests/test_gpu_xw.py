@@ -163,6 +163,31 @@ def test_transform_first_layer_matches_reference_order_oracle(hidden, F_in, norm
     assert 'h' not in gr.ndata and rel(z2, Z) < TOL
 
 
+@pytest.mark.parametrize("name", ["cora", "citeseer"])
+def test_split_partials_are_added_by_the_gather(name):
+    """a long f_in is split over thread blocks by gae_xw_fwd; with keep_splits the partial matrices stay and
+    gae_spmm_csr_epilogue adds a gathered row's partials in split order: bit for bit the aggregation of the reduced P"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, workloads as W
+    n, src, dst, X = W.citation_graph(name, seed=0)
+    g = G.DGLGraph((src, dst), num_nodes=n).to(DEV)
+    Xd = ops.pad_rows(torch.from_numpy(X).to(DEV))
+    Wt = torch.randn(32, X.shape[1], device=DEV) / X.shape[1] ** 0.5
+    b = torch.randn(32, device=DEV)
+    parts, splits = ops.xw_fwd_raw(Xd, Wt, None, 0, keep_splits=True)
+    assert splits > 1 and parts.shape == (splits, n, 32)
+    P = ops.xw_fwd_raw(Xd, Wt, None, 0)
+    acc = parts[0].clone()
+    for sp in range(1, splits):
+        acc += parts[sp]
+    assert torch.equal(acc, P)                                  # the reduction launch adds in split order too
+    ip, ix = g.csr()
+    for nv in (None, g.norm()):
+        y_ref = ops.spmm_epilogue_raw(ip, ix, P, n, g.spmm_plan(False), b, 1, None, nv, nv)
+        y = ops.spmm_epilogue_raw(ip, ix, parts, n, g.spmm_plan(False), b, 1, None, nv, nv)
+        assert torch.equal(y, y_ref)
+
+
 def test_transform_first_hidden_layer_input_gradient():
     """a narrowing HIDDEN layer (256 -> 16) also takes the one-pass route and hands the right gradient upstream"""
     import gae_dgl_amd as G

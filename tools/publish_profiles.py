@@ -20,11 +20,11 @@ def last_json(path):
     return json.loads(lines[-1])
 
 
-def pmc_means(d):
+def pmc_means(d, needles=("spmm",)):
     out = {}
     for f in sorted(glob.glob(os.path.join(d, "p*", "pmc_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
-            if "spmm" not in r["Kernel_Name"]:
+            if not any(t in r["Kernel_Name"] for t in needles):
                 continue
             k = (r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0], r["Counter_Name"])
             out.setdefault(k, []).append(float(r["Counter_Value"]))
@@ -32,17 +32,18 @@ def pmc_means(d):
 
 
 benches = {}
-for name in ("pubmed", "cora", "citeseer", "vgae", "zinc", "zinc128", "zinc_eager", "zinc128_eager", "rmat_s24_1gpu"):
+for name in ("pubmed", "pubmed_reference_order", "cora", "citeseer", "vgae", "zinc", "zinc128", "zinc_eager", "zinc128_eager",
+             "rmat_s24_1gpu"):
     p = os.path.join(SRC, f"bench_{name}.json")
     if os.path.exists(p):
         benches[name] = last_json(p)
         json.dump(benches[name], open(os.path.join(DST, f"{TAG}_bench_{name}.json"), "w"), indent=1)
-for w in ("pubmed", "cora", "zinc", "zinc128", "rmat"):
+for w in ("pubmed", "cora", "citeseer", "vgae", "zinc", "zinc128", "rmat"):
     st = os.path.join(SRC, f"prof_{w}", "bench_kernel_stats.csv")
     if os.path.exists(st):
         shutil.copy(st, os.path.join(DST, f"{TAG}_{w}_step_kernel_stats.csv"))
         shutil.copy(os.path.join(SRC, f"{w}_step_kernel_stats_top.txt"), os.path.join(DST, f"{TAG}_{w}_step_kernel_stats_top.txt"))
-for f in ("linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt", "bce_bench_zinc.txt",
+for f in ("xw_bench.txt", "xw_sweep_pubmed.txt", "linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt", "bce_bench_zinc.txt",
           "probe_gather_l2.txt", "probe_gather_l2b.txt", "probe_valu_rate.txt", "probe_inst_cost.txt",
           "probe_mfma32_check.txt"):
     if os.path.exists(os.path.join(SRC, f)):
@@ -74,6 +75,31 @@ for sh, (key, graph, F) in shapes.items():
     traffic[key] = {"kernel": main, "launch": done[0] if done else "", "fetch_kib_raw": fetch, "write_kib": write,
                     "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
                     "alg_bytes": W.spmm_alg_bytes(n, n, nnz, F, 4) if n else None,
+                    "tcc_hit": m.get((main, "TCC_HIT_sum")), "tcc_miss": m.get((main, "TCC_MISS_sum"))}
+    dd = os.path.join(DST, f"{TAG}_pmc_{sh}")
+    os.makedirs(dd, exist_ok=True)
+    for i, f in enumerate(sorted(glob.glob(os.path.join(d, "p*", "pmc_counter_collection.csv"))), 1):
+        shutil.copy(f, os.path.join(dd, f"pass{i}.csv"))
+# ---- the layer-1 dense passes (tools/r03/xw_one.py): kernel xw_fwd_kernel / xtg_kernel; compulsory bytes X + P (+ W) / X + G
+xw = {"xwfwd_pubmed": ("pubmed-xw_fwd", "xw_fwd", 4), "xwfwd_cora": ("cora-xw_fwd", "xw_fwd", 4),
+      "xwfwd_citeseer": ("citeseer-xw_fwd", "xw_fwd", 4), "xwfwd_citeseer_bf16": ("citeseer-bf16-xw_fwd", "xw_fwd", 2),
+      "xwgrad_pubmed": ("pubmed-xw_wgrad", "xtg", 4), "xwgrad_cora": ("cora-xw_wgrad", "xtg", 4),
+      "xwgrad_citeseer": ("citeseer-xw_wgrad", "xtg", 4), "xwgrad_citeseer_bf16": ("citeseer-bf16-xw_wgrad", "xtg", 2)}
+for sh, (key, needle, elem) in xw.items():
+    d = os.path.join(SRC, f"pmc_{sh}")
+    if not os.path.isdir(d):
+        continue
+    m = pmc_means(d, (needle,))
+    kernels = sorted({k[0] for k in m})
+    if not kernels:
+        continue
+    main = max(kernels, key=lambda k: m.get((k, "FETCH_SIZE"), 0))
+    fetch, write = m.get((main, "FETCH_SIZE"), 0.0), m.get((main, "WRITE_SIZE"), 0.0)
+    done = [l for l in open(os.path.join(d, "p1.log")).read().splitlines() if l.startswith("done")]
+    n, K, J = (int(done[0].split()[2]), int(done[0].split()[3]), int(done[0].split()[4])) if done else (0, 0, 0)
+    alg = (elem * n * K + 4 * n * J + 4 * J * K) if needle == "xw_fwd" else (elem * n * K + 3 * 4 * n * J + 4 * J * K)
+    traffic[key] = {"kernel": main, "launch": done[0] if done else "", "fetch_kib_raw": fetch, "write_kib": write,
+                    "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024), "alg_bytes": alg,
                     "tcc_hit": m.get((main, "TCC_HIT_sum")), "tcc_miss": m.get((main, "TCC_MISS_sum"))}
     dd = os.path.join(DST, f"{TAG}_pmc_{sh}")
     os.makedirs(dd, exist_ok=True)

@@ -23,7 +23,7 @@ for name in names:
     Xd = ops.pad_rows(torch.from_numpy(X).to(dev))
     Wt = torch.randn(J, K, device=dev) / K ** 0.5
     b = torch.randn(J, device=dev)
-    P = ops.xw_fwd_raw(Xd, Wt, None, 0)
+    P, n_split = ops.xw_fwd_raw(Xd, Wt, None, 0, keep_splits=True)      # as the layer launches it: split partials kept
     Y = ops.spmm_epilogue_raw(ip, ix, P, n, g.spmm_plan(False), b, 1)
     dY = torch.randn(n, J, device=dev)
     Gt = ops.spmm_epilogue_raw(tp, tx, dY, n, g.spmm_plan(True), None, 0, Y)
@@ -42,8 +42,8 @@ for name in names:
         _lib.call("gae_tuning_set", b"xw", knob)
         t(f"linear fwd on M [{tag}]", lambda: ops.linear_fwd_raw(M, Wt, b, 1), x_mb)
         t(f"linear bwd dW, db on M [{tag}]", lambda: ops.linear_bwd_raw(dY, Y, 1, M, Wt, True, True, False), x_mb)
-    t("xw_fwd (X W^T)", lambda: ops.xw_fwd_raw(Xd, Wt, None, 0), x_mb)
-    t("spmm F_out + b, relu", lambda: ops.spmm_epilogue_raw(ip, ix, P, n, g.spmm_plan(False), b, 1), 0)
+    t(f"xw_fwd (X W^T, {n_split} split partials kept)", lambda: ops.xw_fwd_raw(Xd, Wt, None, 0, keep_splits=True), x_mb)
+    t("spmm F_out (+ split sum) + b, relu", lambda: ops.spmm_epilogue_raw(ip, ix, P, n, g.spmm_plan(False), b, 1), 0)
     t("gated spmm F_out on A^T", lambda: ops.spmm_epilogue_raw(tp, tx, dY, n, g.spmm_plan(True), None, 0, Y), 0)
     t("xw_wgrad (G^T X, db)", lambda: ops.xw_wgrad_raw(Xd, Gt, None, dY, Y, J), x_mb)
     print(f"== {name}: n = {n}, f_in = {K} (X {x_mb:.1f} MB)")
