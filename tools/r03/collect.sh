@@ -44,4 +44,8 @@ micro)
   ;;
 esac
 done
+# gpurun copies back at most 64 MiB: the per-dispatch traces are not needed (the stats tables are)
+find $O -name "*kernel_trace.csv" -delete
+find $O -name "*.db" -delete
+du -sh $O
 ls -la $O
