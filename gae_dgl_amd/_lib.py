@@ -39,6 +39,13 @@ class AdamTensor(ctypes.Structure):
                 ("partials", _p), ("n_partials", _i64), ("partial_stride", _i64), ("row_len", _i64), ("row_pitch", _i64)]
 
 
+class BceTail(ctypes.Structure):
+    """gae_bce_tail: the deferred final reduction of a fused loss call (gae_decoder_bce_defer_finalize)"""
+    _fields_ = [("dense_partial", _p), ("n_dense", _i64), ("edge_partial", _p), ("n_edge", _i64), ("S", _p),
+                ("DP", _i32), ("reserved", _i32), ("pad_terms", ctypes.c_double), ("inv_n2", ctypes.c_double),
+                ("loss_out", _p), ("bump_draw", _p), ("scal", _p)]
+
+
 ADAM_MAX_TENSORS = 16
 ADAM_STATE_WORDS = 6      # uint64 words of gae_adam_step's device state
 
@@ -108,6 +115,9 @@ SIGNATURES = {
     "gae_decoder_dense_bwd_workspace_bytes": (_i64, [_i64, _i64]),
     "gae_decoder_dense_bwd": (_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),
     "gae_adam_step": (_int, [ctypes.POINTER(AdamTensor), _i32, _f, _f, _f, _f, _f, _p, _p]),
+    "gae_adam_step_tail": (_int, [ctypes.POINTER(AdamTensor), _i32, _f, _f, _f, _f, _f, _p, ctypes.POINTER(BceTail), _p]),
+    "gae_decoder_bce_defer_finalize": (_int, [ctypes.POINTER(BceTail)]),
+    "gae_decoder_bce_finalize": (_int, [ctypes.POINTER(BceTail), _p]),
     "gae_decoder_bce_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gae_decoder_bce_rows": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _f, _f, _u64, _u64, _p,
                                     _p, _p, _i64, _p, _i64, _p]),

@@ -9,6 +9,7 @@ between kernels.  The decoder's dropout mask still changes every replay
 because its Philox draw counter lives in device memory (gae_decoder_bce), and so does Adam's step counter
 (gae_dgl_amd.optim.Adam / torch.optim.Adam(capturable=True))."""
 import gc
+import os
 
 import torch
 
@@ -19,21 +20,27 @@ class _defer:
     """ops.deferred_grad_reductions() when the optimiser is the library's Adam (which consumes the partial sums),
     a no-op for any other optimiser"""
 
-    def __init__(self, opt):
+    def __init__(self, opt, loss_too=False):
         from .optim import Adam
-        self.cm = ops.deferred_grad_reductions() if isinstance(opt, Adam) and DEFER_GRAD_REDUCTIONS else None
+        ours = isinstance(opt, Adam)
+        # loss_too: the step's loss is the fused decoder + BCE scalar itself and nothing reads it before the optimiser
+        # launch (a loss_fn of the caller's may do arithmetic on it: those steps keep the reduction launch)
+        self.cms = [cm for cm in (ops.deferred_grad_reductions() if ours and DEFER_GRAD_REDUCTIONS else None,
+                                  ops.deferred_loss_finalize() if ours and loss_too and DEFER_LOSS_FINALIZE else None)
+                    if cm is not None]
 
     def __enter__(self):
-        if self.cm is not None:
-            self.cm.__enter__()
+        for cm in self.cms:
+            cm.__enter__()
 
     def __exit__(self, *exc):
-        if self.cm is not None:
-            return self.cm.__exit__(*exc)
+        for cm in reversed(self.cms):
+            cm.__exit__(*exc)
 
 
 FUSED_COLLATE_MAX_GRAPHS = 1024   # batches up to this size collate in one launch (gae_batch_gather_next); 0 = never
 DEFER_GRAD_REDUCTIONS = True      # False: captured steps keep the separate reduction launches (experiments)
+DEFER_LOSS_FINALIZE = os.environ.get("GAE_DEFER_LOSS_FINALIZE", "1") != "0"   # False: the fused loss keeps its own final-reduction launch (experiments)
 
 
 class CapturedTrainStep:
@@ -47,6 +54,7 @@ class CapturedTrainStep:
     def __init__(self, model, optimizer, graph, features, loss_fn=None, warmup=3):
         self.model, self.opt, self.g, self.x = model, optimizer, graph, features
         self._params = [p for group in optimizer.param_groups for p in group["params"]]
+        self._defer_loss = loss_fn is None and hasattr(model, "reconstruction_loss")
         self.loss_fn = loss_fn or (lambda m, g: m.reconstruction_loss(g))
         for group in optimizer.param_groups:           # Adam must keep its step counter on the device
             if "capturable" in group and not group["capturable"]:
@@ -75,10 +83,11 @@ class CapturedTrainStep:
 
     def _fwd_bwd_step(self):
         self.g.ndata['h'] = self.x
-        loss = self.loss_fn(self.model, self.g)
         # the optimiser launch follows the backward pass directly: the library's Adam adds the weight gradients'
-        # partial sums itself (two reduction launches less per step)
-        with _defer(self.opt):
+        # partial sums itself (two reduction launches less per step) and finishes the loss scalar in an extra block
+        # (one more)
+        with _defer(self.opt, self._defer_loss):
+            loss = self.loss_fn(self.model, self.g)
             ops.backward(loss, self._params)      # autograd.grad: no AccumulateGrad nodes (stream-bound) in the capture
             self.opt.step()
         return loss.detach()
@@ -201,8 +210,8 @@ class CapturedInductiveStep:
             g._cache.pop(key, None)
         g.ndata.clear()
         g.ndata['h'] = self.x
-        loss = self.model.reconstruction_loss(g)
-        with _defer(self.opt):
+        with _defer(self.opt, True):
+            loss = self.model.reconstruction_loss(g)
             ops.backward(loss, self._params)      # autograd.grad: no AccumulateGrad nodes (stream-bound) in the capture
             self.opt.step()
         return loss.detach()

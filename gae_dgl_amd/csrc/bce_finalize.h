@@ -1,0 +1,51 @@
+// The last reduction of the fused decoder + BCE loss (dense partials, edge partials, analytic terms -> the scalar),
+// as a device function of ONE block: bce_finalize_kernel (decoder_bce.hip) runs it as its own launch, adam_step_kernel
+// (optim.hip) as one extra block of the optimiser launch when the caller deferred it (gae_decoder_bce_defer_finalize):
+// the scalar is not an input of the backward pass, so inside a captured training step the dependent ~5 us launch
+// disappears.  The order of the sums is that of a 1024-thread block whatever the real block size NT (a thread plays
+// 1024 / NT virtual threads, a wave 1024 / NT virtual waves): both forms give the same bits.
+#pragma once
+#include "common.h"
+
+namespace gae {
+
+template <int NT>
+__device__ __forceinline__ void bce_finalize_block(const gae_bce_tail &t, double (*red)[16] /* LDS [3][16] */)
+{
+    static_assert(1024 % NT == 0 && NT % 64 == 0, "virtual 1024-thread block");
+    if (t.loss_out == nullptr) return;
+    double inv_n2 = t.inv_n2, pad_terms = t.pad_terms;
+    if (t.scal) { inv_n2 = t.scal[1]; pad_terms = t.scal[2]; }
+    const int lane = threadIdx.x & 63;
+    const double2 *dp2 = reinterpret_cast<const double2 *>(t.dense_partial);   // {sum |x|, sum log2 t} pairs
+#pragma unroll 1
+    for (int v = 0; v < 1024 / NT; ++v) {
+        const int tid = int(threadIdx.x) + v * NT;          // virtual thread: 4 independent loads per trip
+        double a = 0.0, l = 0.0, e = 0.0;
+        int64_t k = tid;
+        for (; k + 3 * 1024 < t.n_dense; k += 4 * 1024) {
+            const double2 v0 = dp2[k], v1 = dp2[k + 1024], v2 = dp2[k + 2048], v3 = dp2[k + 3072];
+            a += (v0.x + v1.x) + (v2.x + v3.x);
+            l += (v0.y + v1.y) + (v2.y + v3.y);
+        }
+        for (; k < t.n_dense; k += 1024) { const double2 w = dp2[k]; a += w.x; l += w.y; }
+        for (int64_t q = tid; q < t.n_edge; q += 1024) e += t.edge_partial[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off, 64); l += __shfl_down(l, off, 64); e += __shfl_down(e, off, 64);
+        }
+        if (lane == 0) { red[0][tid >> 6] = a; red[1][tid >> 6] = l; red[2][tid >> 6] = e; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, l = 0.0, e = 0.0;
+        for (int w = 0; w < 16; ++w) { a += red[0][w]; l += red[1][w]; e += red[2][w]; }
+        double sx = 0.0;
+        for (int q = 0; q < t.DP; ++q) sx += t.S[q] * t.S[t.DP + q];          // sum_{i in window} sum_j x_ij
+        const double dense = 0.5 * sx + 0.5 * a + 0.69314718055994531 * (l - pad_terms);
+        *t.loss_out = float((dense + e) * inv_n2);
+        if (t.bump_draw) *t.bump_draw += 1;     // every read of the counter (prepare) is stream-ordered before this block
+    }
+}
+
+} // namespace gae

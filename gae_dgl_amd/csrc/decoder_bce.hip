@@ -35,6 +35,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "bce_finalize.h"
 
 namespace {
 
@@ -191,6 +192,15 @@ __device__ __forceinline__ f32x4 mfma32(const s16x8 &a, const s16x8 &b, const f3
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// 8 bytes per lane from LDS, the 16-bit elements exchanged inside every group of 16 lanes (gfx950 ds_read_b64_tr_b16,
+// tools/probes/ds_tr_probe.hip): with lane L of a group pointing at chunk L % 4 (4 elements) of row L / 4 of a
+// 4 x 16 block, lane l receives column l of the 4 rows -- a K-major LDS tile read straight into MFMA A / B fragments
+// (lane = m or n, registers = 4 consecutive k).
+__device__ __forceinline__ s16x4 lds_read_tr(const unsigned short *p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+}
+
 // split 4 fp32 values into bf16 hi and bf16 lo = bf16(v - hi): v_cvt_pk_bf16_f32 x4, 5 VALU ops per pair
 __device__ __forceinline__ void split_bf16x4(const f32x4 &v, s16x4 &hi, s16x4 &lo)
 {
@@ -208,7 +218,7 @@ __device__ __forceinline__ void split_bf16x4(const f32x4 &v, s16x4 &hi, s16x4 &l
     lo = __builtin_bit_cast(s16x4, ul);
 }
 
-template <int KS, bool WITH_GRAD, int RI, int MINW, bool SBF16, bool PBF16>
+template <int KS, bool WITH_GRAD, int RI, int MINW, bool SBF16, bool PBF16, bool TRV = false>
 __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     const float *__restrict__ Zt /*[n][16 KS]*/, const unsigned short *__restrict__ Zhi,
     const unsigned short *__restrict__ Zlo, int64_t n, int64_t row_begin, int64_t n_local, int64_t cols_per_split,
@@ -224,7 +234,8 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     constexpr int LDT = TJ + 4;          // transposed bf16 tile row stride (elements), 8-byte aligned rows
     constexpr bool NEED_F32 = !SBF16 || (WITH_GRAD && !PBF16);
     constexpr bool NEED_BF = SBF16 || (WITH_GRAD && PBF16);
-    constexpr bool NEED_T = WITH_GRAD && PBF16;
+    static_assert(!TRV || (SBF16 && PBF16 && WITH_GRAD), "transpose reads take the V fragments from the bf16 [j][k] tiles");
+    constexpr bool NEED_T = WITH_GRAD && PBF16 && !TRV;
     __shared__ __attribute__((aligned(16))) float Zs[2][NEED_F32 ? TJ * LDA : 4];            // fp32 column tile [j][k]
     __shared__ __attribute__((aligned(16))) unsigned short Hs[2][SBF16 ? TJ * LDH : 4];      // bf16 hi [j][k]
     __shared__ __attribute__((aligned(16))) unsigned short Ls[2][SBF16 ? TJ * LDH : 4];      // bf16 lo [j][k]
@@ -428,11 +439,18 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
                 // holds of the two subtiles, read from the transposed tiles; O' += lo.hi + hi.lo + hi.hi, K = 32
 #pragma unroll
                 for (int c = 0; c < KS; ++c) {
-                    const int at = (16 * c + l15) * LDT + jp * 32 + 4 * g;
-                    const s16x8 vh = cat(*reinterpret_cast<const s16x4 *>(&HT[buf][at]),
-                                         *reinterpret_cast<const s16x4 *>(&HT[buf][at + 16]));
-                    const s16x8 vl = cat(*reinterpret_cast<const s16x4 *>(&LT[buf][at]),
-                                         *reinterpret_cast<const s16x4 *>(&LT[buf][at + 16]));
+                    s16x8 vh, vl;
+                    if constexpr (TRV) {      // LDS transpose reads of the [j][k] tiles (see lds_read_tr)
+                        const int o = (jp * 32 + 4 * g + (l15 >> 2)) * LDH + 16 * c + 4 * (l15 & 3);
+                        vh = cat(lds_read_tr(&Hs[buf][o]), lds_read_tr(&Hs[buf][o + 16 * LDH]));
+                        vl = cat(lds_read_tr(&Ls[buf][o]), lds_read_tr(&Ls[buf][o + 16 * LDH]));
+                    } else {
+                        const int at = (16 * c + l15) * LDT + jp * 32 + 4 * g;
+                        vh = cat(*reinterpret_cast<const s16x4 *>(&HT[buf][at]),
+                                 *reinterpret_cast<const s16x4 *>(&HT[buf][at + 16]));
+                        vl = cat(*reinterpret_cast<const s16x4 *>(&LT[buf][at]),
+                                 *reinterpret_cast<const s16x4 *>(&LT[buf][at + 16]));
+                    }
 #pragma unroll
                     for (int ri = 0; ri < RI; ++ri) {
                         oacc[ri][c] = mfma32(pl[ri], vh, oacc[ri][c]);
@@ -516,6 +534,7 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
 // 185 -> 194 us).  With the K = 32 fragments the fully unrolled 256-row body spilled 43 VGPRs (3.48 ms); its
 // column-pair loop is therefore left rolled (238 VGPRs, no spill).
 gae::Knob g_bce_sym_ri{0};
+gae::Knob g_bce_sym_tr{1};    // "bce_sym_tr": 1 = V fragments by LDS transpose reads (ds_read_b64_tr_b16), 0 = from transposed tile copies
 
 // the upper 16 bits of four fp32 values (exact when they are bf16 values): one v_perm_b32 per pair
 __device__ __forceinline__ s16x4 upper_halves(const f32x4 &d)
@@ -532,7 +551,10 @@ __host__ __device__ inline int64_t sym_strip_offset(int64_t I, int64_t NP, int64
     return 16 * (I * NP - PR * (I * (I + 1) / 2));
 }
 
-template <bool WITH_GRAD, int RI>
+// TRV (default): the V fragments of O' += P V come from LDS transpose reads of the [j][k] tiles -- no second,
+// transposed copy of every tile (16 ds_write_b16 per thread and tile, 8.7 KB of LDS): Pubmed 170 -> 166 us, a ZINC
+// batch 2.92 -> 2.88 ms.  TRV = false keeps the round-2 form (knob "bce_sym_tr" = 0).
+template <bool WITH_GRAD, int RI, bool TRV>
 __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     const float *__restrict__ Zt /*[n][16]*/, const unsigned short *__restrict__ Zhi,
     const unsigned short *__restrict__ Zlo, int64_t n, int64_t cols_per_chunk,
@@ -547,8 +569,8 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     constexpr int LDM = TJ + 4;          // mirror tile row stride (floats)
     __shared__ __attribute__((aligned(16))) unsigned short Hs[2][TJ * LDH];       // bf16 hi [j][k]
     __shared__ __attribute__((aligned(16))) unsigned short Ls[2][TJ * LDH];       // bf16 lo [j][k]
-    __shared__ __attribute__((aligned(16))) unsigned short HT[2][DP * LDT];       // bf16 hi [k][j]
-    __shared__ __attribute__((aligned(16))) unsigned short LT[2][DP * LDT];       // bf16 lo [k][j]
+    __shared__ __attribute__((aligned(16))) unsigned short HT[2][TRV ? 4 : DP * LDT];       // bf16 hi [k][j]
+    __shared__ __attribute__((aligned(16))) unsigned short LT[2][TRV ? 4 : DP * LDT];       // bf16 lo [k][j]
     __shared__ __attribute__((aligned(16))) float MR[4][16 * LDM];                // mirror tiles [wave][f][j]
     __shared__ double red[4][2];
 
@@ -638,7 +660,7 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
             const int jj = idx / (DP / 4), kk = (idx % (DP / 4)) * 4;
             *reinterpret_cast<s16x4 *>(&Hs[buf][jj * LDH + kk]) = st.h[q];
             *reinterpret_cast<s16x4 *>(&Ls[buf][jj * LDH + kk]) = st.l[q];
-            if (WITH_GRAD) {
+            if (WITH_GRAD && !TRV) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     HT[buf][(kk + e) * LDT + jj] = (unsigned short)st.h[q][e];
@@ -715,10 +737,17 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
             }
             if (WITH_GRAD) {
                 const int jc = jp * 32 + 4 * g;
-                const s16x8 vh = cat(*reinterpret_cast<const s16x4 *>(&HT[buf][l15 * LDT + jc]),
-                                     *reinterpret_cast<const s16x4 *>(&HT[buf][l15 * LDT + jc + 16]));
-                const s16x8 vl = cat(*reinterpret_cast<const s16x4 *>(&LT[buf][l15 * LDT + jc]),
-                                     *reinterpret_cast<const s16x4 *>(&LT[buf][l15 * LDT + jc + 16]));
+                s16x8 vh, vl;                // lane (f = l15, g): Z[j = jc + r][f] | Z[j = jc + 16 + r][f]
+                if constexpr (TRV) {
+                    const int o = (jc + (l15 >> 2)) * LDH + 4 * (l15 & 3);
+                    vh = cat(lds_read_tr(&Hs[buf][o]), lds_read_tr(&Hs[buf][o + 16 * LDH]));
+                    vl = cat(lds_read_tr(&Ls[buf][o]), lds_read_tr(&Ls[buf][o + 16 * LDH]));
+                } else {
+                    vh = cat(*reinterpret_cast<const s16x4 *>(&HT[buf][l15 * LDT + jc]),
+                             *reinterpret_cast<const s16x4 *>(&HT[buf][l15 * LDT + jc + 16]));
+                    vl = cat(*reinterpret_cast<const s16x4 *>(&LT[buf][l15 * LDT + jc]),
+                             *reinterpret_cast<const s16x4 *>(&LT[buf][l15 * LDT + jc + 16]));
+                }
 #pragma unroll
                 for (int ri = 0; ri < RI; ++ri) {
                     oacc[ri] = mfma32(pl[ri], vh, oacc[ri]);
@@ -727,9 +756,11 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
                 }
                 if (offdiag) {
                     // mirror: (P^T Z_I)[j][f] += sum_i P[i][j] Z[i][f] needs P with lane = column j, registers = rows
-                    // i; this lane holds P[i = l15][j = 4 g + r].  One MFMA against the identity re-lays it out on
-                    // the matrix pipe: D = P_hi I has the C layout lane = j, regs = i, and its fp32 values are
-                    // exactly the bf16 inputs, so their upper halves are the A fragments wanted.
+                    // i; this lane holds P[i = l15][j = 4 g + r].
+                    // One MFMA against the identity re-lays P out on the matrix pipe: D = P_hi I has the C layout
+                    // lane = j, regs = i, and its fp32 values are exactly the bf16 inputs, so their upper halves
+                    // are the A fragments wanted.  (Wave-private LDS planes + transpose reads instead -- 16 MFMAs and
+                    // 32 v_perm fewer per tile and wave, 16 KB more LDS traffic -- measured slower: 170 -> 178 us.)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         f32x4 macc = {0.f, 0.f, 0.f, 0.f};
@@ -1019,43 +1050,10 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
 
 // single block: ordered sums of all partials -> mean
 //   N^2 loss = 1/2 S_win.S_all + 1/2 sum|x| + ln2 (sum log2(t) - pad_cols * n_local) + edges
-__global__ __launch_bounds__(1024) void bce_finalize_kernel(const double *__restrict__ dense_partial,
-                                                            int64_t n_dense, const double *__restrict__ edge_partial,
-                                                            int64_t n_edge, const double *__restrict__ S, int DP,
-                                                            double pad_terms, double inv_n2,
-                                                            float *__restrict__ loss_out,
-                                                            uint64_t *__restrict__ bump_draw,
-                                                            const double *__restrict__ scal)
+__global__ __launch_bounds__(1024) void bce_finalize_kernel(const gae_bce_tail t)
 {
-    if (scal) { inv_n2 = scal[1]; pad_terms = scal[2]; }
-    // 1024 threads, 4 independent loads per trip: the kernel is a few dependent round trips, nothing else
     __shared__ double red[3][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double a = 0.0, l = 0.0, e = 0.0;
-    const double2 *dp2 = reinterpret_cast<const double2 *>(dense_partial);   // {sum |x|, sum log2 t} pairs
-    int64_t k = tid;
-    for (; k + 3 * 1024 < n_dense; k += 4 * 1024) {
-        const double2 v0 = dp2[k], v1 = dp2[k + 1024], v2 = dp2[k + 2048], v3 = dp2[k + 3072];
-        a += (v0.x + v1.x) + (v2.x + v3.x);
-        l += (v0.y + v1.y) + (v2.y + v3.y);
-    }
-    for (; k < n_dense; k += 1024) { const double2 v = dp2[k]; a += v.x; l += v.y; }
-    for (int64_t q = tid; q < n_edge; q += 1024) e += edge_partial[q];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        a += __shfl_down(a, off, 64); l += __shfl_down(l, off, 64); e += __shfl_down(e, off, 64);
-    }
-    if (lane == 0) { red[0][wave] = a; red[1][wave] = l; red[2][wave] = e; }
-    __syncthreads();
-    if (tid == 0) {
-        a = l = e = 0.0;
-        for (int w = 0; w < 16; ++w) { a += red[0][w]; l += red[1][w]; e += red[2][w]; }
-        double sx = 0.0;
-        for (int q = 0; q < DP; ++q) sx += S[q] * S[DP + q];          // sum_{i in window} sum_j x_ij
-        const double dense = 0.5 * sx + 0.5 * a + 0.69314718055994531 * (l - pad_terms);
-        *loss_out = float((dense + e) * inv_n2);
-        if (bump_draw) *bump_draw += 1;     // every read of the counter (prepare) is stream-ordered before this kernel
-    }
+    gae::bce_finalize_block<1024>(t, red);
 }
 
 struct BcePlan {
@@ -1171,7 +1169,11 @@ int launch_dense(const BcePlan &p, const float *Zt, const unsigned short *Zhi, c
     const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
 #define GAE_BD(KS, RI, MW, SB)                                                                                     \
     do {                                                                                                           \
-        if (SB && g_bce_pv_bf16)                                                                                   \
+        if (SB && g_bce_pv_bf16 && WITH_GRAD && g_bce_sym_tr)                                                       \
+            hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW, SB, SB, SB && WITH_GRAD>), grid, dim3(256), 0, s, \
+                               Zt, Zhi, Zlo, n, row_begin, n_local, p.cols_per_split, O, lp, cs, p.prep_blocks, S, \
+                               S_all_f, unsigned(p.row_blocks));                                                   \
+        else if (SB && g_bce_pv_bf16)                                                                              \
             hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW, SB, SB>), grid, dim3(256), 0, s, Zt, Zhi,  \
                                Zlo, n, row_begin, n_local, p.cols_per_split, O, lp, cs, p.prep_blocks, S, S_all_f, \
                                unsigned(p.row_blocks));                                                            \
@@ -1234,6 +1236,7 @@ Knob *bce_knob(const char *name)
     if (strcmp(name, "bce_fold_mirror") == 0) return &g_bce_fold_mirror;
     if (strcmp(name, "bce_strip_store") == 0) return &g_bce_strip_store;
     if (strcmp(name, "bce_sym_ri") == 0) return &g_bce_sym_ri;
+    if (strcmp(name, "bce_sym_tr") == 0) return &g_bce_sym_tr;
     return nullptr;
 }
 } // namespace gae
@@ -1247,6 +1250,8 @@ extern "C" int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t n_local, i
 }
 
 namespace {
+thread_local gae_bce_tail *t_tail_out = nullptr;     // gae_decoder_bce_defer_finalize: receives the next call's final reduction
+
 int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,
                      int64_t row_begin, int64_t n_local, const int32_t *indptr,
                      const int32_t *indices, const int32_t *t_indptr, const int32_t *t_indices,
@@ -1288,6 +1293,7 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
     const double inv_n2 = 1.0 / (double(n) * double(n));
     if (n_local == 0) {
         GAE_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), s));
+        if (t_tail_out) { memset(t_tail_out, 0, sizeof(gae_bce_tail)); t_tail_out = nullptr; }   // nothing left to do
         return GAE_OK;
     }
     hipLaunchKernelGGL(bce_prepare_kernel, dim3(unsigned(p.prep_blocks)), dim3(256), 0, s, Z, mask, ldz, n, int(d), p.DP,
@@ -1300,12 +1306,13 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
     int rc;
     if (p.sym) {
         const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
-#define GAE_SYM(WG, R)                                                                                             \
-    hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
+#define GAE_SYM(WG, R, T)                                                                                           \
+    hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R, T>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
                        lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks),                                    \
                        g_bce_strip_store >= 0 ? g_bce_strip_store : (n >= 32768 ? 1 : 0))
-        if (p.sym_pr == 256) { if (dZ) GAE_SYM(true, 4); else GAE_SYM(false, 4); }
-        else { if (dZ) GAE_SYM(true, 2); else GAE_SYM(false, 2); }
+        if (!dZ) { if (p.sym_pr == 256) GAE_SYM(false, 4, false); else GAE_SYM(false, 2, false); }
+        else if (g_bce_sym_tr) { if (p.sym_pr == 256) GAE_SYM(true, 4, true); else GAE_SYM(true, 2, true); }
+        else { if (p.sym_pr == 256) GAE_SYM(true, 4, false); else GAE_SYM(true, 2, false); }
 #undef GAE_SYM
         GAE_CHECK_LAUNCH("bce_dense_sym_kernel");
         if (dZ && !(g_bce_fold_mirror && p.LPR == 4)) {     // otherwise the edge kernel folds the strips itself
@@ -1327,12 +1334,41 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
                                      t_indices, pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, nullptr, counts,
                                      scal, nullptr, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(1024), 0, s, lp, p.n_dense, lpe, p.edge_blocks, S, p.DP,
-                       p.pad_terms, inv_n2, loss_out, dropout_p > 0.f ? draw_dev : nullptr, scal);
+    gae_bce_tail tail;
+    memset(&tail, 0, sizeof(tail));
+    tail.dense_partial = lp; tail.n_dense = p.n_dense;
+    tail.edge_partial = lpe; tail.n_edge = p.edge_blocks;
+    tail.S = S; tail.DP = p.DP;
+    tail.pad_terms = p.pad_terms; tail.inv_n2 = inv_n2;
+    tail.loss_out = loss_out; tail.bump_draw = dropout_p > 0.f ? draw_dev : nullptr; tail.scal = scal;
+    if (t_tail_out) {               // armed by gae_decoder_bce_defer_finalize: the caller launches (or hands on) the reduction
+        *t_tail_out = tail;
+        t_tail_out = nullptr;
+        return GAE_OK;
+    }
+    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(1024), 0, s, tail);
     GAE_CHECK_LAUNCH("bce_finalize_kernel");
     return GAE_OK;
 }
 } // namespace
+
+extern "C" int gae_decoder_bce_defer_finalize(gae_bce_tail *tail_out)
+{
+    t_tail_out = tail_out;          // NULL disarms
+    return GAE_OK;
+}
+
+extern "C" int gae_decoder_bce_finalize(const gae_bce_tail *tail, void *stream)
+{
+    GAE_REQUIRE(tail != nullptr, GAE_E_NULL, "gae_decoder_bce_finalize: tail is NULL");
+    if (tail->loss_out == nullptr) return GAE_OK;
+    GAE_REQUIRE(tail->S && (tail->n_dense == 0 || tail->dense_partial) && (tail->n_edge == 0 || tail->edge_partial) &&
+                    tail->DP > 0 && tail->n_dense >= 0 && tail->n_edge >= 0,
+                GAE_E_NULL, "gae_decoder_bce_finalize: malformed tail (not one written by gae_decoder_bce*)");
+    hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(1024), 0, gae::as_stream(stream), *tail);
+    GAE_CHECK_LAUNCH("bce_finalize_kernel");
+    return GAE_OK;
+}
 
 extern "C" int gae_decoder_bce_rows(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,
                                     int64_t row_begin, int64_t n_local, const int32_t *indptr,

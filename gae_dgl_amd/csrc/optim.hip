@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "bce_finalize.h"
 
 namespace {
 
@@ -20,11 +21,23 @@ struct AdamArgs {
     gae_adam_tensor t[kAdamMaxTensors];
     int32_t first_block[kAdamMaxTensors + 1];   // block range of tensor k: [first_block[k], first_block[k + 1])
     int32_t n_tensors;
+    int32_t n_blocks;                           // optimiser blocks of the launch (a loss tail may follow them)
 };
 
+template <bool TAIL>
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, float beta1, float beta2, float eps,
-                                                        float weight_decay, unsigned long long *__restrict__ state)
+                                                        float weight_decay, unsigned long long *__restrict__ state,
+                                                        const gae_bce_tail tail)
 {
+    if constexpr (TAIL) {
+        // one block behind the optimiser's: the deferred final reduction of the loss (gae_adam_step_tail).  It takes
+        // no ticket: the step counter waits for the a.n_blocks optimiser blocks only.
+        if (blockIdx.x == unsigned(a.n_blocks)) {
+            __shared__ double red[3][16];
+            gae::bce_finalize_block<256>(tail, red);
+            return;
+        }
+    }
     int k = 0;
     while (k + 1 < a.n_tensors && int(blockIdx.x) >= a.first_block[k + 1]) ++k;
     const gae_adam_tensor t = a.t[k];
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long ticket = atomicAdd(&state[1], 1ull);
-        if (ticket == gridDim.x - 1ull) {      // every block has read the state by now (its ticket came after its loads)
+        if (ticket == (unsigned long long)(a.n_blocks) - 1ull) {      // every block has read the state by now (its ticket came after its loads)
             double *sw = reinterpret_cast<double *>(state);
             sw[2] = double(beta1); sw[3] = b1t; sw[4] = double(beta2); sw[5] = b2t;
             state[1] = 0ull;
@@ -109,15 +122,20 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
 
 } // namespace
 
-extern "C" int gae_adam_step(const gae_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, uint64_t *state_dev, void *stream)
+extern "C" int gae_adam_step_tail(const gae_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, uint64_t *state_dev, const gae_bce_tail *tail,
+                                  void *stream)
 {
+    const bool with_tail = tail != nullptr && tail->loss_out != nullptr;
+    GAE_REQUIRE(!with_tail || (tail->S && (tail->n_dense == 0 || tail->dense_partial) &&
+                               (tail->n_edge == 0 || tail->edge_partial) && tail->DP > 0),
+                GAE_E_NULL, "gae_adam_step_tail: malformed tail (not one written by gae_decoder_bce*)");
     GAE_REQUIRE(n_tensors >= 0 && n_tensors <= kAdamMaxTensors, GAE_E_RANGE,
                 "gae_adam_step: %d tensors per call (at most %d)", n_tensors, kAdamMaxTensors);
     GAE_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f &&
                     weight_decay >= 0.f,
                 GAE_E_RANGE, "gae_adam_step: hyper-parameter out of range");
-    if (n_tensors == 0) return GAE_OK;
+    if (n_tensors == 0) return with_tail ? gae_decoder_bce_finalize(tail, stream) : GAE_OK;
     GAE_REQUIRE(tensors && state_dev, GAE_E_NULL, "gae_adam_step: NULL pointer");
     AdamArgs a;
     memset(&a, 0, sizeof(a));
@@ -140,8 +158,19 @@ extern "C" int gae_adam_step(const gae_adam_tensor *tensors, int32_t n_tensors, 
     }
     a.first_block[n_tensors] = int32_t(blocks);
     if (blocks == 0) blocks = 1;        // still advances the step counter (a.t[0].n == 0: no element passes e < n)
-    hipLaunchKernelGGL(adam_step_kernel, dim3(unsigned(blocks)), dim3(256), 0, gae::as_stream(stream), a, lr, beta1,
-                       beta2, eps, weight_decay, reinterpret_cast<unsigned long long *>(state_dev));
+    a.n_blocks = int32_t(blocks);
+    if (with_tail)
+        hipLaunchKernelGGL(adam_step_kernel<true>, dim3(unsigned(blocks) + 1), dim3(256), 0, gae::as_stream(stream), a, lr,
+                           beta1, beta2, eps, weight_decay, reinterpret_cast<unsigned long long *>(state_dev), *tail);
+    else
+        hipLaunchKernelGGL(adam_step_kernel<false>, dim3(unsigned(blocks)), dim3(256), 0, gae::as_stream(stream), a, lr,
+                           beta1, beta2, eps, weight_decay, reinterpret_cast<unsigned long long *>(state_dev), gae_bce_tail{});
     GAE_CHECK_LAUNCH("adam_step_kernel");
     return GAE_OK;
+}
+
+extern "C" int gae_adam_step(const gae_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, uint64_t *state_dev, void *stream)
+{
+    return gae_adam_step_tail(tensors, n_tensors, lr, beta1, beta2, eps, weight_decay, state_dev, nullptr, stream);
 }

@@ -147,6 +147,42 @@ class deferred_grad_reductions:
                                   "gae_dgl_amd.optim.Adam.step() inside the block, after the backward pass")
 
 
+# Inside ``with deferred_loss_finalize():`` the fused loss (decoder_bce_raw) leaves its last launch -- the reduction of
+# the per-block partial sums to the scalar, which the backward pass does not read -- to gae_dgl_amd.optim.Adam.step(),
+# whose launch runs it as one extra block (gae_adam_step_tail).  The returned loss tensor is filled only then.  A
+# reduction nobody took (no optimiser step, a second loss call) is launched on its own.
+_DEFER_LOSS = False
+_PENDING_TAIL = []  # [(BceTail, keep-alive tensors)]
+
+
+def _flush_loss_tail():
+    while _PENDING_TAIL:
+        tail, keep = _PENDING_TAIL.pop()
+        with _on_device(keep[0].device):
+            _lib.call("gae_decoder_bce_finalize", ctypes.byref(tail), _stream())
+
+
+class deferred_loss_finalize:
+    def __enter__(self):
+        global _DEFER_LOSS
+        self.prev, _DEFER_LOSS = _DEFER_LOSS, True
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER_LOSS
+        _DEFER_LOSS = self.prev
+        if not _DEFER_LOSS:
+            if exc[0] is None:
+                _flush_loss_tail()
+            else:
+                _PENDING_TAIL.clear()
+
+
+def pending_loss_tail():
+    """(BceTail, keep-alive) of a loss whose final reduction was deferred (removed from the list), or None"""
+    return _PENDING_TAIL.pop() if _PENDING_TAIL else None
+
+
 def pending_partials(grad):
     """(keep-alive, ptr, n_partials, partial_stride, row_len, row_pitch) of a gradient whose reduction was deferred
     (removed from the table), or None"""
@@ -959,14 +995,16 @@ def decoder_dense_bwd_raw(G, Z, mask=None):
 
 
 def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, n_local=None, dropout=None,
-                    counts=None):
+                    counts=None, defer_ok=False):
     """fused decoder + weighted BCE (mean): returns (loss[1], dZ or None).
     ``counts`` (int64[2] on the device: true {nodes, edges}) = Z / csr are a fixed-capacity batch
     (gae_decoder_bce_padded): pos_weight and the mean come from the counts, ``pos_weight`` is ignored.
     ``row_begin/n_local`` select a row window (row-sharded form): Z/mask stay the
     full [n, d] arrays, csr/csc are the window's local row blocks.
     ``dropout`` = (p, seed, offset, draw_counter): the mask of this draw is generated inside the launch, written
-    to ``mask`` (an [n, d] output buffer then) and the device draw counter is advanced by the library."""
+    to ``mask`` (an [n, d] output buffer then) and the device draw counter is advanced by the library.
+    ``defer_ok``: inside ``deferred_loss_finalize()`` the final reduction may be left to the optimiser launch -- the
+    returned scalar is then NOT valid before ``optim.Adam.step()`` (or the end of the block) has run."""
     Z = _f32(_gpu(Z, "Z"), "decoder_bce: Z").contiguous()
     if mask is not None:
         mask = _f32(_gpu(mask, "mask"), "decoder_bce: mask").contiguous()
@@ -987,6 +1025,23 @@ def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, 
         ws = _workspace(nbytes, dev)
 
         def launch():
+            tail = None
+            if _PENDING_TAIL:
+                _flush_loss_tail()                 # an earlier loss nobody took: its partial sums may live in the
+                                                   # cached workspace this call is about to reuse
+            if _DEFER_LOSS and defer_ok and want_grad:
+                tail = _lib.BceTail()
+                _lib.call("gae_decoder_bce_defer_finalize", ctypes.byref(tail))
+            try:
+                launch_kernels()
+            except Exception:
+                if tail is not None:
+                    _lib.call("gae_decoder_bce_defer_finalize", None)
+                raise
+            if tail is not None:
+                _PENDING_TAIL.append((tail, (loss, ws, draws, counts)))
+
+        def launch_kernels():
             if counts is not None:
                 if row_begin or n_local != n:
                     raise GaeHipError("decoder_bce: a fixed-capacity batch has no row window")
@@ -1472,7 +1527,7 @@ class DecoderBCEFunction(torch.autograd.Function):
         pw = 0.0 if counts is not None else (float(n) * float(n) - float(nnz)) / float(nnz)  # train_inductive.py:46
         need = ctx.needs_input_grad[0]
         loss, dZ = decoder_bce_raw(Z, mask, graph.csr(), graph.csc() if need else None, pw, want_grad=need,
-                                   dropout=dropout, counts=counts)
+                                   dropout=dropout, counts=counts, defer_ok=True)
         ctx.save_for_backward(dZ)
         return loss.reshape(())
 

@@ -109,8 +109,14 @@ class Adam(torch.optim.Optimizer):
                     if resume is not None and gi < len(resume):
                         self._counters[key][0] = resume[gi]
                 counters = self._counters
+                # the step's loss may have left its final reduction to this launch (ops.deferred_loss_finalize)
+                pend_tail = ops.pending_loss_tail()
+                if pend_tail is not None and pend_tail[1][0].device != dev:
+                    ops._PENDING_TAIL.append(pend_tail)
+                    pend_tail = None
                 with _on_device(dev):
-                    _lib.call("gae_adam_step", arr, len(chunk), float(group["lr"]), float(group["betas"][0]),
+                    _lib.call("gae_adam_step_tail", arr, len(chunk), float(group["lr"]), float(group["betas"][0]),
                               float(group["betas"][1]), float(group["eps"]), float(group["weight_decay"]),
-                              ctypes.c_void_p(counters[key].data_ptr()), _stream())
+                              ctypes.c_void_p(counters[key].data_ptr()),
+                              ctypes.byref(pend_tail[0]) if pend_tail is not None else None, _stream())
         return loss

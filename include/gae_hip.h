@@ -497,6 +497,28 @@ int gae_decoder_bce_padded(const float *Z, float *mask, int64_t ldz, int64_t n_c
                            float *loss_out, float *dZ, int64_t lddz,
                            void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Deferred final reduction.  The last launch of gae_decoder_bce* adds the per-block partial sums to the scalar; the
+ * backward pass does not read that scalar, so a training step may run the reduction later, next to other work:
+ *   gae_decoder_bce_defer_finalize(&tail)  arms the calling thread: its NEXT gae_decoder_bce / _rows / _padded call
+ *                                          launches everything but the reduction and describes it in `tail` (pointers
+ *                                          into that call's workspace and outputs: keep them alive); NULL disarms.
+ *   gae_adam_step_tail(..., &tail, stream) runs it as one extra block of the optimiser launch (same bits as below),
+ *   gae_decoder_bce_finalize(&tail, stream) as a launch of its own (e.g. no optimiser step follows).
+ * Until one of the two has run on the stream, loss_out is not written and draw_dev not advanced.  A tail with
+ * loss_out == NULL (written for an empty row window) is a no-op. */
+typedef struct gae_bce_tail {
+    const double *dense_partial; int64_t n_dense;     /* {sum |x|, sum log2 t} per dense block          (device) */
+    const double *edge_partial;  int64_t n_edge;      /* sparse terms per edge block                    (device) */
+    const double *S;                                  /* column sums of Zt: all rows | row window [2][DP] (device) */
+    int32_t DP, reserved;
+    double pad_terms, inv_n2;
+    float *loss_out;                                  /* (device) */
+    uint64_t *bump_draw;                              /* draw counter to advance, or NULL               (device) */
+    const double *scal;                               /* device-side {pos_weight, 1 / N^2, pad pairs} of a padded batch, or NULL */
+} gae_bce_tail;
+int gae_decoder_bce_defer_finalize(gae_bce_tail *tail_out);
+int gae_decoder_bce_finalize(const gae_bce_tail *tail, void *stream);
+
 /* Reference-shaped loss on MATERIALISED logits: F.binary_cross_entropy_with_logits(adj_logits, adj,
  * pos_weight=pos_weight) with the default mean reduction (gae_dgl/train_inductive.py:48) and dLoss/dLogits.  Used
  * for embedding widths the fused kernel does not take (d > 64; gae_dgl/optuna_gae.py:29-34 samples hidden dims up
@@ -545,6 +567,10 @@ typedef struct gae_adam_tensor {
 } gae_adam_tensor;
 int gae_adam_step(const gae_adam_tensor *tensors_host, int32_t n_tensors, float lr, float beta1, float beta2,
                   float eps, float weight_decay, uint64_t *state_dev, void *stream);
+/* ... plus the deferred final reduction of the step's loss (gae_decoder_bce_defer_finalize; tail may be NULL) as one
+ * more block of the same launch: one kernel node fewer in a captured training step. */
+int gae_adam_step_tail(const gae_adam_tensor *tensors_host, int32_t n_tensors, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, uint64_t *state_dev, const gae_bce_tail *tail, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,118 @@
+"""The deferred final reduction of the fused loss (gae_decoder_bce_defer_finalize / gae_decoder_bce_finalize /
+gae_adam_step_tail): the same bits as the loss's own last launch, whoever runs it."""
+import copy
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _graph(n, seed=0, deg=4):
+    import gae_dgl_amd as G
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, deg * n); dst = rng.integers(0, n, deg * n)
+    g = G.DGLGraph((np.concatenate([src, dst]), np.concatenate([dst, src])), num_nodes=n).to(DEV)
+    g.csr(); g.csc()
+    return g
+
+
+@pytest.mark.parametrize("n,sym", [(700, 1), (2500, 2), (9000, 1)])
+def test_standalone_finalize_gives_the_same_loss(n, sym, tuning):
+    """armed call + gae_decoder_bce_finalize == plain call (loss bits, gradient bits, draw counter); the armed call
+    itself leaves the scalar and the counter alone"""
+    from gae_dgl_amd import _lib, ops
+    tuning("bce_sym", sym)
+    g = _graph(n)
+    torch.manual_seed(1)
+    Z = torch.randn(n, 16, device=DEV) * 0.4
+    pw = (n * n - g.number_of_edges()) / g.number_of_edges()
+    draws_a = torch.zeros(1, dtype=torch.int64, device=DEV)
+    draws_b = torch.zeros(1, dtype=torch.int64, device=DEV)
+    mask_a, mask_b = torch.empty_like(Z), torch.empty_like(Z)
+    loss_a, dz_a = ops.decoder_bce_raw(Z, mask_a, g.csr(), g.csc(), pw, True, dropout=(0.1, 5, 0, draws_a))
+    with ops.deferred_loss_finalize():
+        loss_b, dz_b = ops.decoder_bce_raw(Z, mask_b, g.csr(), g.csc(), pw, True, dropout=(0.1, 5, 0, draws_b),
+                                           defer_ok=True)
+        loss_b.fill_(-7.0)               # stream-ordered behind the armed call: nothing overwrites it ...
+        torch.cuda.synchronize()
+        assert float(loss_b) == -7.0 and int(draws_b) == 0
+        tail, keep = ops.pending_loss_tail()
+        assert ops.pending_loss_tail() is None
+        _lib.call("gae_decoder_bce_finalize", ctypes.byref(tail), ops._stream())
+    torch.cuda.synchronize()
+    assert int(draws_a) == int(draws_b) == 1
+    assert torch.equal(loss_a, loss_b) and torch.equal(dz_a, dz_b) and torch.equal(mask_a, mask_b)
+
+
+def test_block_exit_flushes_a_reduction_nobody_took():
+    from gae_dgl_amd import ops
+    n = 1200
+    g = _graph(n, seed=3)
+    Z = torch.randn(n, 16, device=DEV) * 0.3
+    pw = (n * n - g.number_of_edges()) / g.number_of_edges()
+    ref, _ = ops.decoder_bce_raw(Z, None, g.csr(), g.csc(), pw, True)
+    with ops.deferred_loss_finalize():
+        l1, _ = ops.decoder_bce_raw(Z, None, g.csr(), g.csc(), pw, True, defer_ok=True)
+        l2, _ = ops.decoder_bce_raw(Z * 0.5, None, g.csr(), g.csc(), pw, True, defer_ok=True)   # flushes l1 first
+        l3, _ = ops.decoder_bce_raw(Z, None, g.csr(), g.csc(), pw, True)                        # not deferrable
+    torch.cuda.synchronize()
+    assert torch.equal(l1, ref) and torch.equal(l3, ref) and float(l2) != float(ref)
+    ref2, _ = ops.decoder_bce_raw(Z * 0.5, None, g.csr(), g.csc(), pw, True)
+    assert torch.equal(l2, ref2)
+
+
+@pytest.mark.parametrize("n", [900, 8500])
+def test_adam_tail_block_equals_the_separate_launch(n):
+    """training steps whose loss is finished by the optimiser launch: losses and weights bit-identical to steps with
+    the reduction launch, eager and captured"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import capture, ops
+    from gae_dgl_amd.capture import CapturedTrainStep
+    from gae_dgl_amd.optim import Adam
+    g = _graph(n, seed=5)
+    X = torch.randn(n, 48, device=DEV)
+    torch.manual_seed(2)
+    m0 = G.GAE(48, [32, 16]).to(DEV)
+    m0.decoder.seed = 9
+    runs = {}
+    for defer in (False, True):
+        capture.DEFER_LOSS_FINALIZE = defer
+        try:
+            m = copy.deepcopy(m0)
+            opt = Adam(m.parameters(), lr=1e-2)
+            step = CapturedTrainStep(m, opt, g, X, warmup=2)
+            losses = []
+            for _ in range(4):
+                losses.append(float(step()))
+            runs[defer] = (losses, [p.detach().clone() for p in m.parameters()], opt.steps_taken())
+        finally:
+            capture.DEFER_LOSS_FINALIZE = True
+    assert runs[False][0] == runs[True][0]
+    assert runs[False][2] == runs[True][2] == 6
+    for a, b in zip(runs[False][1], runs[True][1]):
+        assert torch.equal(a, b)
+    assert not ops._PENDING_TAIL
+
+
+def test_a_loss_fn_of_the_callers_keeps_its_reduction_launch():
+    """CapturedTrainStep defers only the default reconstruction loss: a caller's loss_fn may read the scalar"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops
+    from gae_dgl_amd.capture import CapturedTrainStep
+    from gae_dgl_amd.optim import Adam
+    n = 600
+    g = _graph(n, seed=8)
+    X = torch.randn(n, 24, device=DEV)
+    torch.manual_seed(4)
+    m0 = G.GAE(24, [32, 16]).to(DEV)
+    m0.decoder.seed = 3
+    out = []
+    for fn in (None, lambda m, gg: m.reconstruction_loss(gg) * 1.0):
+        m = copy.deepcopy(m0)
+        step = CapturedTrainStep(m, Adam(m.parameters(), lr=1e-2), g, X, loss_fn=fn, warmup=1)
+        out.append([float(step()) for _ in range(3)])
+    assert out[0] == out[1]
