@@ -115,6 +115,9 @@ SIGNATURES = {
     "gae_decoder_dense_bwd_workspace_bytes": (_i64, [_i64, _i64]),
     "gae_decoder_dense_bwd": (_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),
     "gae_adam_step": (_int, [ctypes.POINTER(AdamTensor), _i32, _f, _f, _f, _f, _f, _p, _p]),
+    "gae_gcn_layer_fused_wgrad_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "gae_gcn_layer_fused_wgrad": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, ctypes.POINTER(SpmmPlan), _p, _i64, _i64, _p,
+                                         _i64, _p, _i64, _p, _p, _p, _i64, _p, _p]),
     "gae_adam_step_tail": (_int, [ctypes.POINTER(AdamTensor), _i32, _f, _f, _f, _f, _f, _p, ctypes.POINTER(BceTail), _p]),
     "gae_decoder_bce_defer_finalize": (_int, [ctypes.POINTER(BceTail)]),
     "gae_decoder_bce_finalize": (_int, [ctypes.POINTER(BceTail), _p]),

@@ -151,6 +151,14 @@ struct EllArgs {
     // (same strides), outputs >= w_split of the bias from bias2 -- two heads on one aggregate, one launch
     const float *W2, *bias2;
     int w_split, w_t;             // w_t: W is addressed transposed (the stored row is the input index k, not the output o)
+    // side work of a fused-layer launch on the block's OWN rows (gae_gcn_layer_fused_wgrad): the weight gradient of the
+    // layer whose backward this launch is, sw_part[block][o][i] = sum over the block's rows r of P[r][o] Q[r][i]
+    // (P = the gathered operand dY, Q = the forward's stored aggregate) and, behind it, the column sums of P (db) --
+    // per-block partial sums in row order, added up later (gae_adam_step's deferred reduction or a reduction launch)
+    const float *sw_P, *sw_Q;
+    float *sw_part;
+    int64_t sw_ldp, sw_ldq, sw_stride;
+    int sw_O, sw_I;
 };
 
 template <typename T>
@@ -343,6 +351,32 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
     const bool live = unsigned(lig) < a.tile_vecs && fvec < a.nvec;
     const unsigned lane_off = fvec * 16u;
 
+    // side work (EPI kernels): the block's own rows of P and Q are requested here, used behind the epilogue
+    constexpr int SW_ROWS = 256 / LPR;                         // = rows per block of the EPI kernels (RPG = 1)
+    constexpr int SWP = EPI_J > 0 ? SW_ROWS * 32 / 256 : 1, SWQ = EPI_J > 0 ? SW_ROWS * 64 / 256 : 1;
+    __shared__ float SwP[EPI_J > 0 ? SW_ROWS * 32 : 1], SwQ[EPI_J > 0 ? SW_ROWS * 64 : 1];
+    float swp[SWP], swq[SWQ];
+    if constexpr (EPI_J > 0) {
+        if (a.sw_part != nullptr) {                            // block-uniform
+#pragma unroll
+            for (int q = 0; q < SWP; ++q) {
+                const int idx = threadIdx.x + 256 * q, r = idx / a.sw_O, o = idx - r * a.sw_O;
+                const int64_t rw = int64_t(blk) * SW_ROWS + r;
+                const bool ok = r < SW_ROWS && rw < a.n_rows;
+                swp[q] = a.sw_P[ok ? rw * a.sw_ldp + o : 0];
+                swp[q] = ok ? swp[q] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < SWQ; ++q) {
+                const int idx = threadIdx.x + 256 * q, r = idx / a.sw_I, i = idx - r * a.sw_I;
+                const int64_t rw = int64_t(blk) * SW_ROWS + r;
+                const bool ok = r < SW_ROWS && rw < a.n_rows;
+                swq[q] = a.sw_Q[ok ? rw * a.sw_ldq + i : 0];
+                swq[q] = ok ? swq[q] : 0.f;
+            }
+        }
+    }
+
     __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.H), 0, int(a.h_bytes), 0x00020000);
     __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(SCALED ? a.col_scale : nullptr), 0, SCALED ? int(a.n_cols * 4u) : 0, 0x00020000);
@@ -486,6 +520,29 @@ slots_done:
             }
         }
     }
+    if constexpr (EPI_J > 0) {
+        if (a.sw_part != nullptr) {
+            const int O = a.sw_O, I = a.sw_I;
+#pragma unroll
+            for (int q = 0; q < SWP; ++q) SwP[threadIdx.x + 256 * q] = swp[q];       // [r][O], rows end to end
+#pragma unroll
+            for (int q = 0; q < SWQ; ++q) SwQ[threadIdx.x + 256 * q] = swq[q];       // [r][I]
+            __syncthreads();
+            float *pp = a.sw_part + int64_t(blk) * a.sw_stride;
+            for (int e = threadIdx.x; e < O * I; e += 256) {
+                const int o = e / I, i = e - o * I;
+                float t = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < SW_ROWS; ++r) t = fmaf(SwP[r * O + o], SwQ[r * I + i], t);       // row order
+                pp[e] = t;
+            }
+            if (int(threadIdx.x) < O) {
+                float t = 0.f;
+                for (int r = 0; r < SW_ROWS; ++r) t += SwP[r * O + threadIdx.x];
+                pp[O * I + threadIdx.x] = t;
+            }
+        }
+    }
 }
 
 template <typename T, int LPR, int RPG, int W, int NB>
@@ -597,13 +654,17 @@ int spmm_ell_launch(const int32_t *indptr, const int32_t *indices, const int32_t
 
 } // namespace gae
 
+// side work of a fused-layer launch (EllArgs::sw_*)
+struct FusedSide { const float *P, *Q; float *part; int64_t ldp, ldq, stride; int O, I; };
+
 // GCN.forward (gae_dgl/gae.py:26-31) in one launch: update_all(copy_src, sum) and NodeApplyModule (Linear + bias +
 // activation) -- see the EPI_J form of spmm_ell_kernel.
 static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                                 const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F, const float *row_scale,
                                 const float *col_scale, const gae_spmm_plan *plan, const float *W, int64_t w_stride_out,
                                 int64_t w_stride_in, const float *bias, int64_t J, int act, float *Y, int64_t ldy,
-                                const float *W2, const float *bias2, int64_t w_split, int w_transposed, void *stream);
+                                const float *W2, const float *bias2, int64_t w_split, int w_transposed, void *stream,
+                                const struct FusedSide *side = nullptr);
 
 extern "C" int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                                    const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
@@ -637,7 +698,8 @@ static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, i
                                 const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F, const float *row_scale,
                                 const float *col_scale, const gae_spmm_plan *plan, const float *W, int64_t w_stride_out,
                                 int64_t w_stride_in, const float *bias, int64_t J, int act, float *Y, int64_t ldy,
-                                const float *W2, const float *bias2, int64_t w_split, int w_transposed, void *stream)
+                                const float *W2, const float *bias2, int64_t w_split, int w_transposed, void *stream,
+                                const FusedSide *side)
 {
     GAE_REQUIRE(n_rows >= 0 && n_cols >= 0, GAE_E_SIZE, "gae_gcn_layer_fused: negative size");
     GAE_REQUIRE(F >= 1 && F <= 64 && J >= 1 && J <= 32, GAE_E_RANGE,
@@ -671,11 +733,55 @@ static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, i
     a.W = W; a.bias = bias; a.Y = Y; a.ldy = ldy; a.J = int(J); a.w_so = int(w_stride_out); a.w_sk = int(w_stride_in);
     a.act = act; a.store_m = M != nullptr;
     a.W2 = W2; a.bias2 = bias2; a.w_split = int(w_split); a.w_t = w_transposed;
+    if (side) {
+        a.sw_P = side->P; a.sw_Q = side->Q; a.sw_part = side->part;
+        a.sw_ldp = side->ldp; a.sw_ldq = side->ldq; a.sw_stride = side->stride; a.sw_O = side->O; a.sw_I = side->I;
+    }
     hipStream_t s = gae::as_stream(stream);
     const bool scaled = row_scale != nullptr;
     const int ew = plan->ell_width;
     if (a.nvec <= 8) return J <= 16 ? launch_ell_epi_w<8, 16>(a, ew, scaled, s) : launch_ell_epi_w<8, 32>(a, ew, scaled, s);
     return J <= 16 ? launch_ell_epi_w<16, 16>(a, ew, scaled, s) : launch_ell_epi_w<16, 32>(a, ew, scaled, s);
+}
+
+// The identity-activation backward of gae_gcn_layer_fused in ONE launch: dH = (A^T dY) W (the fused kernel on the CSR
+// of A^T, W addressed transposed) and -- side work of the same blocks on their own rows -- the partial sums of
+// dW = dY^T M and db = colsum(dY) (M = the aggregate the forward stored).  rows per block: 32 (F <= 32) or 16.
+static int64_t fused_wgrad_blocks(int64_t n_rows, int64_t F) { const int64_t rpb = (F + 3) / 4 <= 8 ? 32 : 16; return (n_rows + rpb - 1) / rpb; }
+
+extern "C" int64_t gae_gcn_layer_fused_wgrad_workspace_bytes(int64_t n_rows, int64_t F, int64_t I)
+{
+    if (n_rows < 0 || F < 1 || F > 32 || I < 1 || I > 64) return GAE_E_SIZE;
+    return fused_wgrad_blocks(n_rows, F) * (F * I + F) * 4 + 256;
+}
+
+extern "C" int gae_gcn_layer_fused_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
+                                         int64_t lddy, int64_t F, const float *row_scale, const float *col_scale,
+                                         const gae_spmm_plan *plan_t, const float *W, int64_t ldw, int64_t I, float *dH,
+                                         int64_t lddh, const float *M, int64_t ldm, float *dW, float *db,
+                                         void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream)
+{
+    GAE_REQUIRE(F >= 1 && F <= 32 && I >= 1 && I <= 32, GAE_E_RANGE,
+                "gae_gcn_layer_fused_wgrad: needs 1 <= f_out <= 32 and 1 <= f_in <= 32 (got %lld, %lld)", (long long)F,
+                (long long)I);
+    const int64_t need = gae_gcn_layer_fused_wgrad_workspace_bytes(n, F, I);
+    GAE_REQUIRE(need >= 0, GAE_E_SIZE, "gae_gcn_layer_fused_wgrad: negative size");
+    const int64_t blocks = fused_wgrad_blocks(n, F), stride = F * I + F;
+    if (layout_out) { layout_out[0] = blocks; layout_out[1] = stride; layout_out[2] = F * I; }
+    if (n == 0) return GAE_OK;
+    GAE_REQUIRE(M && workspace && workspace_bytes >= need && gae::aligned16(workspace), GAE_E_WORKSPACE,
+                "gae_gcn_layer_fused_wgrad: M / workspace missing or smaller than %lld bytes", (long long)need);
+    GAE_REQUIRE(ldm >= I && ldw >= I && lddy >= F, GAE_E_SIZE, "gae_gcn_layer_fused_wgrad: leading dimension too small");
+    FusedSide side{dY, M, static_cast<float *>(workspace), lddy, ldm, stride, int(F), int(I)};
+    // W [F][I] as nn.Linear stores it is the transposed weight of this launch: output j <- W[k][j]
+    int rc = gcn_layer_fused_impl(t_indptr, t_indices, n, n, dY, lddy, nullptr, 0, F, row_scale, col_scale, plan_t, W, 1,
+                                  ldw, nullptr, I, GAE_ACT_IDENTITY, dH, lddh, nullptr, nullptr, 0, 1, stream, &side);
+    if (rc || (!dW && !db)) return rc;
+    gae::PartialList la{}, lb{};
+    const float *part = static_cast<const float *>(workspace);
+    if (dW) la = gae::PartialList{part, dW, F * I, blocks, stride, F * I, F * I, F * I};
+    if (db) lb = gae::PartialList{part + F * I, db, F, blocks, stride, F, F, F};
+    return gae::launch_partials_reduce(la, lb, gae::as_stream(stream));
 }
 
 namespace {

@@ -1138,6 +1138,47 @@ def gcn_layer_fused_raw(indptr, indices, H, n_rows, plan, W, bias, act, row_scal
     return M, Y
 
 
+def gcn_layer_fused_wgrad_raw(t_indptr, t_indices, dY, n, plan_t, W, M, norm, want_dW=True, want_db=True):
+    """(dH, dW, db): the identity-activation backward of the fused layer in one launch (gae_gcn_layer_fused_wgrad).
+    Inside ``deferred_grad_reductions()`` dW / db are left as per-block partial sums for optim.Adam.step()."""
+    dY, lddy = _rowmajor(_f32(_gpu(dY, "dY"), "gcn_layer_fused_wgrad: dY"), "dY")
+    W = W if W.stride(1) == 1 else W.contiguous()
+    f_out, f_in = W.shape
+    if dY.shape[1] != f_out or M.shape[1] != f_in or M.stride(1) != 1:
+        raise GaeHipError("gcn_layer_fused_wgrad: operand shapes do not match the weight")
+    dev = dY.device
+    dH = torch.empty(n, f_in, dtype=torch.float32, device=dev)
+    dW = torch.empty(f_out, f_in, dtype=torch.float32, device=dev) if want_dW else None
+    db = torch.empty(f_out, dtype=torch.float32, device=dev) if want_db else None
+    defer = _DEFER and (want_dW or want_db)
+    with _on_device(dev):
+        nbytes = _lib.load().gae_gcn_layer_fused_wgrad_workspace_bytes(n, f_out, f_in)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "gae_gcn_layer_fused_wgrad_workspace_bytes")
+        # deferred partials outlive the call: they must not sit in the per-stream scratch cache
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev) if defer else _workspace(nbytes, dev)
+        lay = (ctypes.c_int64 * 3)()
+
+        def launch():
+            _lib.call("gae_gcn_layer_fused_wgrad", _ptr(t_indptr), _ptr(t_indices), n, _ptr(dY), lddy, f_out, _ptr(norm),
+                      _ptr(norm), ctypes.byref(plan_t.c), _ptr(W), W.stride(0), f_in, _ptr(dH), f_in, _ptr(M),
+                      M.stride(0), None if defer else _ptr(dW), None if defer else _ptr(db), _ptr(ws), ws.numel(), lay,
+                      _stream())
+        if profiler is not None:
+            profiler.wrap(("spmm", n, n, f_out, str(dY.dtype)), launch)
+        else:
+            launch()
+    if defer:
+        if dW is not None:
+            _PENDING[dW.data_ptr()] = (ws, ws.data_ptr(), lay[0], lay[1], f_out * f_in, f_out * f_in)
+        if db is not None:
+            _PENDING[db.data_ptr()] = (ws, ws.data_ptr() + 4 * lay[2], lay[0], lay[1], f_out, f_out)
+    return dH, dW, db
+
+
+FUSED_LAYER_WGRAD = True      # False: the fused layer's backward keeps its separate weight-gradient launch (experiments)
+
+
 class GCNLayerFusedFunction(torch.autograd.Function):
     """GCN.forward (gae.py:26-31) as one launch: Y = act((A H) W^T + b).  Backward: dW = dYm^T M and db from the
     stored aggregate (gae_linear_bwd), and dH = A^T (dYm W) -- for an identity activation as ONE launch of the
@@ -1165,6 +1206,12 @@ class GCNLayerFusedFunction(torch.autograd.Function):
         dW = db = dH = None
         fused_bwd = need_dH and ctx.act == ACT_IDENTITY and gcn_layer_fused_usable(dY.contiguous(), W.shape[1],
                                                                                  ctx.bwd[3])
+        if fused_bwd and FUSED_LAYER_WGRAD and need_dW and M is not None and W.shape[0] <= 32 and W.shape[1] <= 32:
+            # dH, dW and db from ONE launch: the blocks of the backward gather also add up dY^T M over their own rows
+            (t_indptr, t_indices), n, norm, plan_t, _, _ = ctx.bwd
+            dH, dW, db = gcn_layer_fused_wgrad_raw(t_indptr, t_indices, dY.contiguous(), n, plan_t, W, M, norm,
+                                                   True, need_db)
+            return dH, dW, db, None, None, None
         if need_dW or need_db or (need_dH and not fused_bwd):
             dW, db, dM = linear_bwd_raw(dY, Y, ctx.act, M if M is not None else dY.new_zeros(dY.shape[0], W.shape[1]),
                                         W, need_dW, need_db, need_dH and not fused_bwd)

@@ -375,6 +375,24 @@ int gae_gcn_layer_fused2(const int32_t *indptr, const int32_t *indices, int64_t 
                          int64_t w_stride_out, int64_t w_stride_in, const float *bias, const float *bias2,
                          int64_t J, int act, float *Y, int64_t ldy, void *stream);
 
+/* The identity-activation BACKWARD of gae_gcn_layer_fused (gae_dgl/gae.py:26-31 under autograd) in one launch:
+ *   dH [n, f_in] (lddh) = (A^T dY) W        the fused kernel on the CSR of A^T (plan_t: its plan), W [f_out, f_in] (ldw)
+ *                                            as nn.Linear stores it;
+ *   dW [f_out, f_in] = dY^T M,  db [f_out] = colsum(dY)     side work of the same thread blocks on their own 32 (16)
+ *                                            rows: M [n, f_in] (ldm) is the aggregate the forward stored.
+ * dY [n, f_out] (lddy: whole 16-byte vectors), f_out <= 32, f_in <= 32, square graph.  The weight gradient leaves the
+ * launch as per-block partial sums in `workspace` (gae_gcn_layer_fused_wgrad_workspace_bytes(n, f_out, f_in)):
+ * layout_out[0] = number of partials, [1] = floats between two partials, [2] = float offset of the db partials inside
+ * one (dW partial: element o * f_in + i).  dW / db != NULL: a second, small launch adds them up (the library's one
+ * order for partial lists); both NULL: the caller hands the list to gae_adam_step (gae_adam_tensor.partials) -- no
+ * weight-gradient launch at all in a captured training step. */
+int64_t gae_gcn_layer_fused_wgrad_workspace_bytes(int64_t n_rows, int64_t f_out, int64_t f_in);
+int gae_gcn_layer_fused_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
+                              int64_t lddy, int64_t f_out, const float *row_scale, const float *col_scale,
+                              const gae_spmm_plan *plan_t, const float *W, int64_t ldw, int64_t f_in, float *dH,
+                              int64_t lddh, const float *M, int64_t ldm, float *dW, float *db, void *workspace,
+                              int64_t workspace_bytes, int64_t *layout_out, void *stream);
+
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16
  * M [n, f_in] (ldm), W [f_out, f_in] row-major contiguous (nn.Linear.weight,
