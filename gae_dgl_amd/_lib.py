@@ -46,6 +46,12 @@ class BceTail(ctypes.Structure):
                 ("loss_out", _p), ("bump_draw", _p), ("scal", _p)]
 
 
+class BcePrep(ctypes.Structure):
+    """gae_bce_prep: where a producer kernel puts the prepare step's outputs (gae_decoder_bce_prep_layout)"""
+    _fields_ = [("Zt", _p), ("Zhi", _p), ("Zlo", _p), ("colsum_partial", _p), ("scal", _p),
+                ("all_pairs", ctypes.c_double), ("max_blocks", _i64), ("DP", _i32), ("reserved", _i32)]
+
+
 ADAM_MAX_TENSORS = 16
 ADAM_STATE_WORDS = 6      # uint64 words of gae_adam_step's device state
 
@@ -118,6 +124,12 @@ SIGNATURES = {
     "gae_gcn_layer_fused_wgrad_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gae_gcn_layer_fused_wgrad": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, ctypes.POINTER(SpmmPlan), _p, _i64, _i64, _p,
                                          _i64, _p, _i64, _p, _p, _p, _i64, _p, _p]),
+    "gae_decoder_bce_prep_layout": (_int, [_i64, _i64, _p, _i64, ctypes.POINTER(BcePrep)]),
+    "gae_gcn_layer_fused_prep": (_int, [_p, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, ctypes.POINTER(SpmmPlan), _p, _i64,
+                                        _i64, _p, _i64, _p, _i64, ctypes.POINTER(BcePrep), _p, _i64, _f, _u64, _u64, _p, _p,
+                                        _p, _p]),
+    "gae_decoder_bce_prepared": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f, _p, _f, _p, _i64, _p, _p, _i64, _p, _i64,
+                                        _p]),
     "gae_adam_step_tail": (_int, [ctypes.POINTER(AdamTensor), _i32, _f, _f, _f, _f, _f, _p, ctypes.POINTER(BceTail), _p]),
     "gae_decoder_bce_defer_finalize": (_int, [ctypes.POINTER(BceTail)]),
     "gae_decoder_bce_finalize": (_int, [ctypes.POINTER(BceTail), _p]),

@@ -1153,7 +1153,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     p.o_bytes = align256(p.n_splits * n_local * p.DP * 4);
     p.zt_bytes = align256(n * p.DP * 4);
     p.zh_bytes = align256(n * p.DP * 2);
-    p.cs_bytes = align256(p.prep_blocks * 2 * p.DP * 8);
+    p.cs_bytes = align256(((n + 15) / 16 + 1) * 2 * p.DP * 8);    // up to one partial per 16 rows (a producer kernel's blocks: gae_gcn_layer_fused_prep)
     p.s_bytes = align256(2 * p.DP * 8 + p.DP * 4 + 4 * 8);       // column sums (double x 2, float) + 3 scalars
     p.n_dense = p.row_blocks * p.n_splits;
     p.total_bytes = p.o_bytes + p.zt_bytes + 2 * p.zh_bytes + p.cs_bytes + p.s_bytes +
@@ -1250,6 +1250,13 @@ extern "C" int64_t gae_decoder_bce_workspace_bytes(int64_t n, int64_t n_local, i
 }
 
 namespace {
+// pairs the dense kernel leaves in its log2 sum: the symmetric kernel corrects its own pad columns (the n x n square
+// remains), the full kernel counts whole column tiles
+inline double bce_all_pairs(const BcePlan &p, int64_t n, int64_t n_local)
+{
+    return p.sym ? double(n) * double(n) : double(n_local) * double((n + TJ - 1) / TJ * TJ);
+}
+
 thread_local gae_bce_tail *t_tail_out = nullptr;     // gae_decoder_bce_defer_finalize: receives the next call's final reduction
 
 int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,
@@ -1257,8 +1264,11 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
                      const int32_t *indices, const int32_t *t_indptr, const int32_t *t_indices,
                      float pos_weight, float dropout_p, uint64_t seed, uint64_t offset,
                      uint64_t *draw_dev, float *loss_out, float *dZ, int64_t lddz, void *workspace,
-                     int64_t workspace_bytes, const int64_t *counts, void *stream)
+                     int64_t workspace_bytes, const int64_t *counts, void *stream, int64_t prepared_blocks = -1)
 {
+    // prepared_blocks >= 0: Zt / hi / lo / the column-sum partials (that many) / the padded-batch scalars are already
+    // in the workspace (gae_gcn_layer_fused_prep wrote them): no prepare launch, Z is not read
+    const bool prepared = prepared_blocks >= 0;
     GAE_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GAE_E_RANGE, "gae_decoder_bce: dropout_p = %g outside [0, 1)",
                 double(dropout_p));
     GAE_REQUIRE(dropout_p == 0.f || mask, GAE_E_NULL, "gae_decoder_bce: dropout_p > 0 needs the mask output buffer");
@@ -1269,12 +1279,17 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
                 (long long)d);
     GAE_REQUIRE(n < (int64_t(1) << 31), GAE_E_SIZE, "gae_decoder_bce: n too large");
     GAE_REQUIRE(ldz >= d && (!dZ || lddz >= d), GAE_E_SIZE, "gae_decoder_bce: leading dimension too small");
-    GAE_REQUIRE(Z && loss_out && workspace && (n_local == 0 || indptr), GAE_E_NULL, "gae_decoder_bce: NULL pointer");
+    GAE_REQUIRE((Z || prepared) && loss_out && workspace && (n_local == 0 || indptr), GAE_E_NULL, "gae_decoder_bce: NULL pointer");
     GAE_REQUIRE(!dZ || n_local == 0 || t_indptr, GAE_E_NULL, "gae_decoder_bce: the gradient needs the CSR of A^T");
     BcePlan p;
     bce_plan(n, n_local, d, true, p);
     GAE_REQUIRE(workspace_bytes >= p.total_bytes, GAE_E_WORKSPACE, "gae_decoder_bce: workspace %lld < %lld bytes",
                 (long long)workspace_bytes, (long long)p.total_bytes);
+    if (prepared) {
+        GAE_REQUIRE(prepared_blocks >= 1 && prepared_blocks * 2 * p.DP * 8 <= p.cs_bytes, GAE_E_RANGE,
+                    "gae_decoder_bce_prepared: %lld column-sum partials do not fit the workspace", (long long)prepared_blocks);
+        p.prep_blocks = prepared_blocks;
+    }
     GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_decoder_bce: workspace not 16-byte aligned");
     hipStream_t s = gae::as_stream(stream);
     char *w = static_cast<char *>(workspace);
@@ -1296,13 +1311,12 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
         if (t_tail_out) { memset(t_tail_out, 0, sizeof(gae_bce_tail)); t_tail_out = nullptr; }   // nothing left to do
         return GAE_OK;
     }
-    hipLaunchKernelGGL(bce_prepare_kernel, dim3(unsigned(p.prep_blocks)), dim3(256), 0, s, Z, mask, ldz, n, int(d), p.DP,
-                       row_begin, row_begin + n_local, Zt, Zhi, Zlo, cs, dropout_p, 1.0f / (1.0f - dropout_p), seed,
-                       offset, draw_dev, counts, scal,
-                       // pairs the dense kernel leaves in its log2 sum: the symmetric kernel corrects its own pad
-                       // columns (the n x n square remains), the full kernel counts whole column tiles
-                       p.sym ? double(n) * double(n) : double(n_local) * double((n + TJ - 1) / TJ * TJ));
-    GAE_CHECK_LAUNCH("bce_prepare_kernel");
+    if (!prepared) {
+        hipLaunchKernelGGL(bce_prepare_kernel, dim3(unsigned(p.prep_blocks)), dim3(256), 0, s, Z, mask, ldz, n, int(d), p.DP,
+                           row_begin, row_begin + n_local, Zt, Zhi, Zlo, cs, dropout_p, 1.0f / (1.0f - dropout_p), seed,
+                           offset, draw_dev, counts, scal, bce_all_pairs(p, n, n_local));
+        GAE_CHECK_LAUNCH("bce_prepare_kernel");
+    }
     int rc;
     if (p.sym) {
         const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
@@ -1401,4 +1415,42 @@ extern "C" int gae_decoder_bce(const float *Z, float *mask, int64_t ldz, int64_t
 {
     return gae_decoder_bce_rows(Z, mask, ldz, n, d, 0, n, indptr, indices, t_indptr, t_indices, pos_weight, dropout_p,
                                 seed, offset, draw_dev, loss_out, dZ, lddz, workspace, workspace_bytes, stream);
+}
+
+// Where a PRODUCER kernel (gae_gcn_layer_fused_prep: the last encoder layer) puts what bce_prepare_kernel would
+// compute, inside a workspace of gae_decoder_bce_workspace_bytes(n, n, d) bytes: gae_decoder_bce_prepared then starts
+// at the dense kernel.
+extern "C" int gae_decoder_bce_prep_layout(int64_t n, int64_t d, void *workspace, int64_t workspace_bytes,
+                                           gae_bce_prep *out)
+{
+    GAE_REQUIRE(out && workspace, GAE_E_NULL, "gae_decoder_bce_prep_layout: NULL pointer");
+    GAE_REQUIRE(n > 0 && d > 0 && d <= 64, GAE_E_RANGE, "gae_decoder_bce_prep_layout: n, d out of range");
+    BcePlan p;
+    bce_plan(n, n, d, true, p);
+    GAE_REQUIRE(workspace_bytes >= p.total_bytes && gae::aligned16(workspace), GAE_E_WORKSPACE,
+                "gae_decoder_bce_prep_layout: workspace %lld < %lld bytes (or not 16-byte aligned)",
+                (long long)workspace_bytes, (long long)p.total_bytes);
+    char *w = static_cast<char *>(workspace) + p.o_bytes;
+    out->Zt = reinterpret_cast<float *>(w); w += p.zt_bytes;
+    out->Zhi = reinterpret_cast<uint16_t *>(w); w += p.zh_bytes;
+    out->Zlo = reinterpret_cast<uint16_t *>(w); w += p.zh_bytes;
+    out->colsum_partial = reinterpret_cast<double *>(w); w += p.cs_bytes;
+    out->scal = reinterpret_cast<double *>(w + 2 * p.DP * 8 + ((p.DP * 4 + 7) & ~7));
+    out->all_pairs = bce_all_pairs(p, n, n);
+    out->max_blocks = p.cs_bytes / (2 * p.DP * 8);
+    out->DP = p.DP;
+    out->reserved = 0;
+    return GAE_OK;
+}
+
+extern "C" int gae_decoder_bce_prepared(float *mask, int64_t ldz, int64_t n, int64_t d, const int32_t *indptr,
+                                        const int32_t *indices, const int32_t *t_indptr, const int32_t *t_indices,
+                                        float pos_weight, const int64_t *counts_dev, float dropout_p,
+                                        uint64_t *draw_dev, int64_t n_prep_blocks, float *loss_out, float *dZ,
+                                        int64_t lddz, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    GAE_REQUIRE(n_prep_blocks >= 1, GAE_E_RANGE, "gae_decoder_bce_prepared: n_prep_blocks must be what the producer reported");
+    return decoder_bce_impl(nullptr, mask, ldz, n, d, 0, n, indptr, indices, t_indptr, t_indices, pos_weight, dropout_p,
+                            0, 0, draw_dev, loss_out, dZ, lddz, workspace, workspace_bytes, counts_dev, stream,
+                            n_prep_blocks);
 }

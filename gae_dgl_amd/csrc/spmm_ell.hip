@@ -159,6 +159,19 @@ struct EllArgs {
     float *sw_part;
     int64_t sw_ldp, sw_ldq, sw_stride;
     int sw_O, sw_I;
+    // prepare step of the fused loss in the epilogue of the layer that produces Z (gae_gcn_layer_fused_prep, EPI_J =
+    // 16): Zt = Y (.) dropout mask padded to 16 columns, its bf16 hi / lo, per-block fp64 column sums -- what
+    // bce_prepare_kernel (decoder_bce.hip) computes from the stored Z
+    float *pz_t;
+    unsigned short *pz_hi, *pz_lo;
+    double *pz_cs, *pz_scal;
+    float *pz_mask;
+    int64_t pz_ldmask;
+    float pz_drop_p, pz_drop_scale;
+    uint64_t pz_seed, pz_offset;
+    const uint64_t *pz_draw;
+    const int64_t *pz_counts;
+    double pz_all_pairs;
 };
 
 template <typename T>
@@ -515,8 +528,68 @@ slots_done:
                         float y = yv[q] + (a.bias ? ((a.bias2 != nullptr && o >= a.w_split) ? a.bias2[o - a.w_split] : a.bias[o]) : 0.f);
                         if (a.act == GAE_ACT_RELU) y = fmaxf(y, 0.f);
                         a.Y[row[r] * a.ldy + o] = y;
+                        yv[q] = y;
                     }
                 }
+            }
+            if constexpr (EPI_J == 16) {
+                if (a.pz_t != nullptr) {                                  // block-uniform
+                    // rows >= counts[0] of a fixed-capacity batch are padding: zero rows of Zt, zero mask
+                    const int64_t n_valid = a.pz_counts ? a.pz_counts[0] : a.n_rows;
+                    const bool draw = a.pz_drop_p > 0.f;
+                    const uint64_t draw_idx = (draw && a.pz_draw) ? *a.pz_draw : 0;
+                    const bool in = row[r] < a.n_rows;
+                    double *cred = reinterpret_cast<double *>(SwQ);       // [rows of the block][16]
+#pragma unroll
+                    for (int q = 0; q < JPL; ++q) {
+                        const int o = lig * JPL + q;
+                        const bool col = o < a.J;
+                        float v = 0.f;
+                        if (in && col) {
+                            float m = 1.f;
+                            if (row[r] >= n_valid) {
+                                m = 0.f;
+                                if (draw) a.pz_mask[row[r] * a.pz_ldmask + o] = 0.f;
+                            } else if (draw) {
+                                // the Philox stream of gae_dropout_mask: element e = i d + k of the [n, d] mask
+                                const int64_t e = row[r] * a.J + o;
+                                uint32_t c[4];
+                                gae::philox4x32_10(a.pz_offset + uint64_t(e >> 2), draw_idx, a.pz_seed, c);
+                                const uint32_t bits = (e & 2) ? ((e & 1) ? c[3] : c[2]) : ((e & 1) ? c[1] : c[0]);
+                                m = gae::dropout_multiplier(bits, a.pz_drop_p, a.pz_drop_scale);
+                                a.pz_mask[row[r] * a.pz_ldmask + o] = m;
+                            } else if (a.pz_mask) {
+                                m = a.pz_mask[row[r] * a.pz_ldmask + o];
+                            }
+                            v = yv[q] * m;
+                        }
+                        if (in) {
+                            a.pz_t[row[r] * 16 + o] = v;
+                            const unsigned short hi = gae::f32_to_bf16(v);
+                            a.pz_hi[row[r] * 16 + o] = hi;
+                            a.pz_lo[row[r] * 16 + o] = gae::f32_to_bf16(v - gae::bf16_to_f32(hi));
+                        }
+                        cred[grp * 16 + o] = double(v);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (EPI_J == 16) {
+        if (a.pz_t != nullptr) {
+            __syncthreads();
+            const double *cred = reinterpret_cast<const double *>(SwQ);
+            if (threadIdx.x < 16) {
+                double t = 0.0;
+                for (int g2 = 0; g2 < SW_ROWS; ++g2) t += cred[g2 * 16 + threadIdx.x];          // row order
+                a.pz_cs[(int64_t(blk) * 2 + 0) * 16 + threadIdx.x] = t;                        // all rows
+                a.pz_cs[(int64_t(blk) * 2 + 1) * 16 + threadIdx.x] = t;                        // ... = the row window
+            }
+            if (a.pz_counts && blk == 0 && threadIdx.x == 0) {
+                const double nv = double(a.pz_counts[0]), ev = double(a.pz_counts[1]);
+                a.pz_scal[0] = ev > 0 ? (nv * nv - ev) / ev : 0.0;      // pos_weight (train_inductive.py:46)
+                a.pz_scal[1] = nv > 0 ? 1.0 / (nv * nv) : 0.0;          // mean over the N^2 real pairs
+                a.pz_scal[2] = a.pz_all_pairs - nv * nv;                // evaluated pairs with a zero operand
             }
         }
     }
@@ -656,6 +729,11 @@ int spmm_ell_launch(const int32_t *indptr, const int32_t *indices, const int32_t
 
 // side work of a fused-layer launch (EllArgs::sw_*)
 struct FusedSide { const float *P, *Q; float *part; int64_t ldp, ldq, stride; int O, I; };
+// prepare step of the loss in the epilogue (EllArgs::pz_*)
+struct FusedPrep {
+    const gae_bce_prep *lay;
+    float *mask; int64_t ldmask; float drop_p; uint64_t seed, offset; const uint64_t *draw; const int64_t *counts;
+};
 
 // GCN.forward (gae_dgl/gae.py:26-31) in one launch: update_all(copy_src, sum) and NodeApplyModule (Linear + bias +
 // activation) -- see the EPI_J form of spmm_ell_kernel.
@@ -664,7 +742,7 @@ static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, i
                                 const float *col_scale, const gae_spmm_plan *plan, const float *W, int64_t w_stride_out,
                                 int64_t w_stride_in, const float *bias, int64_t J, int act, float *Y, int64_t ldy,
                                 const float *W2, const float *bias2, int64_t w_split, int w_transposed, void *stream,
-                                const struct FusedSide *side = nullptr);
+                                const FusedSide *side = nullptr, const FusedPrep *prep = nullptr);
 
 extern "C" int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                                    const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
@@ -699,7 +777,7 @@ static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, i
                                 const float *col_scale, const gae_spmm_plan *plan, const float *W, int64_t w_stride_out,
                                 int64_t w_stride_in, const float *bias, int64_t J, int act, float *Y, int64_t ldy,
                                 const float *W2, const float *bias2, int64_t w_split, int w_transposed, void *stream,
-                                const FusedSide *side)
+                                const FusedSide *side, const FusedPrep *prep)
 {
     GAE_REQUIRE(n_rows >= 0 && n_cols >= 0, GAE_E_SIZE, "gae_gcn_layer_fused: negative size");
     GAE_REQUIRE(F >= 1 && F <= 64 && J >= 1 && J <= 32, GAE_E_RANGE,
@@ -737,11 +815,44 @@ static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, i
         a.sw_P = side->P; a.sw_Q = side->Q; a.sw_part = side->part;
         a.sw_ldp = side->ldp; a.sw_ldq = side->ldq; a.sw_stride = side->stride; a.sw_O = side->O; a.sw_I = side->I;
     }
+    if (prep) {
+        a.pz_t = prep->lay->Zt; a.pz_hi = prep->lay->Zhi; a.pz_lo = prep->lay->Zlo; a.pz_cs = prep->lay->colsum_partial;
+        a.pz_scal = prep->lay->scal; a.pz_all_pairs = prep->lay->all_pairs;
+        a.pz_mask = prep->mask; a.pz_ldmask = prep->ldmask; a.pz_drop_p = prep->drop_p;
+        a.pz_drop_scale = 1.0f / (1.0f - prep->drop_p);
+        a.pz_seed = prep->seed; a.pz_offset = prep->offset; a.pz_draw = prep->draw; a.pz_counts = prep->counts;
+    }
     hipStream_t s = gae::as_stream(stream);
     const bool scaled = row_scale != nullptr;
     const int ew = plan->ell_width;
     if (a.nvec <= 8) return J <= 16 ? launch_ell_epi_w<8, 16>(a, ew, scaled, s) : launch_ell_epi_w<8, 32>(a, ew, scaled, s);
     return J <= 16 ? launch_ell_epi_w<16, 16>(a, ew, scaled, s) : launch_ell_epi_w<16, 32>(a, ew, scaled, s);
+}
+
+// gae_gcn_layer_fused on the LAST encoder layer of a training step, with the prepare step of the fused loss in its
+// epilogue (see gae_decoder_bce_prep_layout in include/gae_hip.h).
+extern "C" int gae_gcn_layer_fused_prep(const int32_t *indptr, const int32_t *indices, int64_t n, const float *H,
+                                        int64_t ldh, float *M, int64_t ldm, int64_t F, const float *row_scale,
+                                        const float *col_scale, const gae_spmm_plan *plan, const float *W,
+                                        int64_t w_stride_out, int64_t w_stride_in, const float *bias, int64_t J,
+                                        float *Z, int64_t ldz, const gae_bce_prep *prep, float *mask, int64_t ldmask,
+                                        float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *draw_dev,
+                                        const int64_t *counts_dev, int64_t *n_prep_blocks_out, void *stream)
+{
+    GAE_REQUIRE(prep && n_prep_blocks_out, GAE_E_NULL, "gae_gcn_layer_fused_prep: NULL pointer");
+    GAE_REQUIRE(J >= 1 && J <= 16 && prep->DP == 16, GAE_E_RANGE,
+                "gae_gcn_layer_fused_prep: the embedding must be at most 16 wide (got %lld)", (long long)J);
+    GAE_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GAE_E_RANGE, "gae_gcn_layer_fused_prep: dropout_p outside [0, 1)");
+    GAE_REQUIRE(dropout_p == 0.f || mask, GAE_E_NULL, "gae_gcn_layer_fused_prep: dropout_p > 0 needs the mask output buffer");
+    GAE_REQUIRE(!mask || ldmask >= J, GAE_E_SIZE, "gae_gcn_layer_fused_prep: ldmask < J");
+    GAE_REQUIRE(n >= 1, GAE_E_SIZE, "gae_gcn_layer_fused_prep: empty graph");
+    const int64_t rpb = (F + 3) / 4 <= 8 ? 32 : 16, blocks = (n + rpb - 1) / rpb;
+    GAE_REQUIRE(blocks <= prep->max_blocks && prep->Zt && prep->Zhi && prep->Zlo && prep->colsum_partial, GAE_E_WORKSPACE,
+                "gae_gcn_layer_fused_prep: layout not from gae_decoder_bce_prep_layout for this n");
+    *n_prep_blocks_out = blocks;
+    FusedPrep fp{prep, mask, ldmask, dropout_p, seed, offset, draw_dev, counts_dev};
+    return gcn_layer_fused_impl(indptr, indices, n, n, H, ldh, M, ldm, F, row_scale, col_scale, plan, W, w_stride_out,
+                                w_stride_in, bias, J, GAE_ACT_IDENTITY, Z, ldz, nullptr, nullptr, 0, 0, stream, nullptr, &fp);
 }
 
 // The identity-activation backward of gae_gcn_layer_fused in ONE launch: dH = (A^T dY) W (the fused kernel on the CSR

@@ -189,7 +189,14 @@ class GAE(nn.Module):
         by the fused HIP kernel: numerically the same quantity as
         ``BCELoss(self.forward(g), adj, pos_weight)`` without the N x N logits /
         label matrices.  Side effect on ``g.ndata['h']`` as in forward()."""
-        return self.decoder.loss(self._embed(g, write_back=True), g)
+        z = g.ndata['h']
+        for layer in self.layers[:-1]:
+            z = layer(g, z)
+        # the last layer may run the loss's prepare step in its epilogue (ops.loss_prepare_request)
+        with self.decoder.prepare_request(g, z, self.layers[-1].apply_mod.linear.out_features) as req:
+            z = self.layers[-1](g, z)
+        g.ndata['h'] = z
+        return self.decoder.loss(z, g, prepared=req.token)
 
 
 class InnerProductDecoder(nn.Module):
@@ -223,15 +230,31 @@ class InnerProductDecoder(nn.Module):
         self.last_mask = self._draw_mask(z)
         return self.activation(ops.decoder_dense(z, self.last_mask))
 
-    def loss(self, z, g):
-        """fused decoder + weighted BCE (identity activation = logits, gae.py:47).  The dropout mask of this call
-        is drawn inside the fused launch (same Philox stream as _draw_mask) and kept in ``last_mask``."""
+    def _loss_dropout(self, device):
+        """(p, seed, offset, draw counter) of a mask drawn inside a launch, or None (given mask / no dropout)"""
         if self.mask is not None or not self.dropout:
+            return None
+        seed = self.seed if self.seed is not None else int(torch.initial_seed())
+        if self._draws is None or self._draws.device != device:
+            self._draws = torch.zeros(1, dtype=torch.int64, device=device)
+        return (self.dropout, seed, 0, self._draws)
+
+    def prepare_request(self, g, h, d):
+        """the request a producer of Z answers by running this loss's prepare step in its own launch"""
+        on_gpu = isinstance(h, torch.Tensor) and h.is_cuda
+        return ops.loss_prepare_request(g if on_gpu else None, d, self.mask, self._loss_dropout(h.device) if on_gpu else None)
+
+    def loss(self, z, g, prepared=None):
+        """fused decoder + weighted BCE (identity activation = logits, gae.py:47).  The dropout mask of this call
+        is drawn inside the fused launch (same Philox stream as _draw_mask) and kept in ``last_mask``.
+        ``prepared``: the producer of z already ran the prepare step (prepare_request)."""
+        if prepared is not None:
+            self.last_mask = prepared["mask"]
+            return ops.decoder_bce(z, None, g, prepared=prepared)
+        drop = self._loss_dropout(z.device)
+        if drop is None:
             self.last_mask = self.mask
             return ops.decoder_bce(z, self.mask, g)
-        seed = self.seed if self.seed is not None else int(torch.initial_seed())
-        if self._draws is None or self._draws.device != z.device:
-            self._draws = torch.zeros(1, dtype=torch.int64, device=z.device)
         mask = torch.empty(tuple(z.shape), dtype=torch.float32, device=z.device)
         self.last_mask = mask
-        return ops.decoder_bce(z, mask, g, dropout=(self.dropout, seed, 0, self._draws))
+        return ops.decoder_bce(z, mask, g, dropout=drop)

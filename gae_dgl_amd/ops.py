@@ -995,7 +995,7 @@ def decoder_dense_bwd_raw(G, Z, mask=None):
 
 
 def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, n_local=None, dropout=None,
-                    counts=None, defer_ok=False):
+                    counts=None, defer_ok=False, prepared=None):
     """fused decoder + weighted BCE (mean): returns (loss[1], dZ or None).
     ``counts`` (int64[2] on the device: true {nodes, edges}) = Z / csr are a fixed-capacity batch
     (gae_decoder_bce_padded): pos_weight and the mean come from the counts, ``pos_weight`` is ignored.
@@ -1004,8 +1004,15 @@ def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, 
     ``dropout`` = (p, seed, offset, draw_counter): the mask of this draw is generated inside the launch, written
     to ``mask`` (an [n, d] output buffer then) and the device draw counter is advanced by the library.
     ``defer_ok``: inside ``deferred_loss_finalize()`` the final reduction may be left to the optimiser launch -- the
-    returned scalar is then NOT valid before ``optim.Adam.step()`` (or the end of the block) has run."""
+    returned scalar is then NOT valid before ``optim.Adam.step()`` (or the end of the block) has run.
+    ``prepared``: token of gcn_layer_fused_prep_raw -- the producer of Z already ran the prepare step (mask drawn,
+    workspace filled): mask / dropout / counts are the token's."""
     Z = _f32(_gpu(Z, "Z"), "decoder_bce: Z").contiguous()
+    if prepared is not None:
+        if prepared["z_ptr"] != Z.data_ptr() or tuple(Z.shape) != (prepared["n"], prepared["d"]) or row_begin or \
+                (n_local is not None and n_local != Z.shape[0]):
+            raise GaeHipError("decoder_bce: the prepared workspace belongs to another embedding")
+        mask, dropout, counts = prepared["mask"], prepared["dropout"], prepared["counts"]
     if mask is not None:
         mask = _f32(_gpu(mask, "mask"), "decoder_bce: mask").contiguous()
     p_drop, seed, offset, draws = dropout if dropout is not None else (0.0, 0, 0, None)
@@ -1019,10 +1026,13 @@ def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, 
     indptr, indices = csr
     t_indptr, t_indices = csc if csc is not None else (None, None)
     with _on_device(dev):
-        nbytes = _lib.load().gae_decoder_bce_workspace_bytes(n, n_local, d)
-        if nbytes < 0:
-            _lib.check(int(nbytes), "gae_decoder_bce_workspace_bytes")
-        ws = _workspace(nbytes, dev)
+        if prepared is not None:
+            ws = prepared["ws"]
+        else:
+            nbytes = _lib.load().gae_decoder_bce_workspace_bytes(n, n_local, d)
+            if nbytes < 0:
+                _lib.check(int(nbytes), "gae_decoder_bce_workspace_bytes")
+            ws = _workspace(nbytes, dev)
 
         def launch():
             tail = None
@@ -1042,6 +1052,12 @@ def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, 
                 _PENDING_TAIL.append((tail, (loss, ws, draws, counts)))
 
         def launch_kernels():
+            if prepared is not None:
+                STATS["prepared_losses"] += 1
+                _lib.call("gae_decoder_bce_prepared", _ptr(mask), max(d, 1), n, d, _ptr(indptr), _ptr(indices),
+                          _ptr(t_indptr), _ptr(t_indices), float(pos_weight), _ptr(counts), float(p_drop), _ptr(draws),
+                          prepared["blocks"], _ptr(loss), _ptr(dZ), max(d, 1), _ptr(ws), ws.numel(), _stream())
+                return
             if counts is not None:
                 if row_begin or n_local != n:
                     raise GaeHipError("decoder_bce: a fixed-capacity batch has no row window")
@@ -1138,6 +1154,74 @@ def gcn_layer_fused_raw(indptr, indices, H, n_rows, plan, W, bias, act, row_scal
     return M, Y
 
 
+# ---- the loss's prepare step in the epilogue of the layer that produces Z --------------------------------------
+# ``with loss_prepare_request(graph, d, mask, dropout) as req:`` around the LAST encoder layer: if that layer runs as
+# the fused launch (GCNLayerFusedFunction, identity activation, <= 16 outputs), the launch also writes Zt / hi / lo /
+# column sums (and draws the dropout mask) into a loss workspace, and ``req.token`` describes it for
+# ``decoder_bce(..., prepared=req.token)`` -- the loss then starts at its dense kernel (one kernel node fewer per step).
+FUSE_LOSS_PREPARE = True
+_PREP_REQ = None
+STATS = {"prepared_losses": 0}      # losses that started at the dense kernel (tests read this)
+
+
+class loss_prepare_request:
+    def __init__(self, graph, d, mask, dropout):
+        """``mask``: a given [n, d] multiplier (or None); ``dropout`` = (p, seed, offset, draw_counter) to draw one"""
+        self.graph, self.d, self.mask, self.dropout, self.token = graph, int(d), mask, dropout, None
+
+    def __enter__(self):
+        global _PREP_REQ
+        self.prev = _PREP_REQ
+        _PREP_REQ = self if FUSE_LOSS_PREPARE and self.d <= 16 else None
+        return self
+
+    def __exit__(self, *exc):
+        global _PREP_REQ
+        _PREP_REQ = self.prev
+
+
+def gcn_layer_fused_prep_raw(indptr, indices, H, n, plan, W, bias, row_scale, req, want_m=True):
+    """(M or None, Z, token): gae_gcn_layer_fused_prep -- the fused layer (identity activation) with the prepare step
+    of the loss in its epilogue; ``token`` goes to decoder_bce_raw(prepared=...)"""
+    H, ldh = _rowmajor(_f32(_gpu(H, "H"), "gcn_layer_fused_prep: H"), "H")
+    W = _f32(_gpu(W, "W"), "gcn_layer_fused_prep: W")
+    if W.stride(1) != 1:
+        W = W.contiguous()
+    _f32(bias, "gcn_layer_fused_prep: bias")
+    F, J = H.shape[1], W.shape[0]
+    dev = H.device
+    M = torch.empty(n, padded_ld(F, torch.float32), dtype=torch.float32, device=dev)[:, :F] if want_m else None
+    Z = torch.empty(n, J, dtype=torch.float32, device=dev)
+    p_drop, seed, offset, draws = req.dropout if req.dropout is not None else (0.0, 0, 0, None)
+    mask = req.mask
+    if p_drop:
+        mask = torch.empty(n, J, dtype=torch.float32, device=dev)
+    elif mask is not None:
+        mask = _f32(_gpu(mask, "mask"), "gcn_layer_fused_prep: mask").contiguous()
+    counts = getattr(req.graph, "batch_counts", None)
+    with _on_device(dev):
+        nbytes = _lib.load().gae_decoder_bce_workspace_bytes(n, n, J)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "gae_decoder_bce_workspace_bytes")
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)       # lives until the loss has run: not the scratch cache
+        lay = _lib.BcePrep()
+        _lib.call("gae_decoder_bce_prep_layout", n, J, _ptr(ws), ws.numel(), ctypes.byref(lay))
+        blocks = ctypes.c_int64(0)
+
+        def launch():
+            _lib.call("gae_gcn_layer_fused_prep", _ptr(indptr), _ptr(indices), n, _ptr(H), ldh, _ptr(M),
+                      M.stride(0) if M is not None else 0, F, _ptr(row_scale), _ptr(row_scale), ctypes.byref(plan.c),
+                      _ptr(W), W.stride(0), 1, _ptr(bias), J, _ptr(Z), J, ctypes.byref(lay), _ptr(mask), J, float(p_drop),
+                      int(seed) & (2 ** 64 - 1), int(offset), _ptr(draws), _ptr(counts), ctypes.byref(blocks), _stream())
+        if profiler is not None:
+            profiler.wrap(("spmm", n, n, F, str(H.dtype)), launch)
+        else:
+            launch()
+    token = {"ws": ws, "blocks": int(blocks.value), "mask": mask, "z_ptr": Z.data_ptr(), "n": n, "d": J,
+             "dropout": req.dropout, "counts": counts}
+    return M, Z, token
+
+
 def gcn_layer_fused_wgrad_raw(t_indptr, t_indices, dY, n, plan_t, W, M, norm, want_dW=True, want_db=True):
     """(dH, dW, db): the identity-activation backward of the fused layer in one launch (gae_gcn_layer_fused_wgrad).
     Inside ``deferred_grad_reductions()`` dW / db are left as per-block partial sums for optim.Adam.step()."""
@@ -1190,8 +1274,15 @@ class GCNLayerFusedFunction(torch.autograd.Function):
         norm = graph.norm() if use_norm else None
         n = graph.number_of_nodes()
         need_w = ctx.needs_input_grad[1] or (b is not None and ctx.needs_input_grad[2])
-        M, Y = gcn_layer_fused_raw(indptr, indices, H, n, graph.spmm_plan(False), W, b, act, norm, norm,
-                                   want_m=need_w)
+        req = _PREP_REQ
+        if (req is not None and req.token is None and req.graph is graph and act == ACT_IDENTITY
+                and W.shape[0] == req.d and H.shape[0] == n and n > 0):
+            # the last encoder layer of a training step: the loss's prepare step rides in this launch's epilogue
+            M, Y, req.token = gcn_layer_fused_prep_raw(indptr, indices, H, n, graph.spmm_plan(False), W, b, norm, req,
+                                                       want_m=need_w)
+        else:
+            M, Y = gcn_layer_fused_raw(indptr, indices, H, n, graph.spmm_plan(False), W, b, act, norm, norm,
+                                       want_m=need_w)
         ctx.act, ctx.has_bias = act, b is not None
         if ctx.needs_input_grad[0]:
             ctx.bwd = (graph.csc(), n, norm, graph.spmm_plan(True), graph.block_diag, _scattered(graph, H))
@@ -1567,14 +1658,14 @@ class DecoderBCEFunction(torch.autograd.Function):
     the same launch sequence as the loss (flash-style) and scaled in backward."""
 
     @staticmethod
-    def forward(ctx, Z, mask, graph, dropout=None):
+    def forward(ctx, Z, mask, graph, dropout=None, prepared=None):
         n = graph.number_of_nodes()
         nnz = graph.number_of_edges()
         counts = getattr(graph, "batch_counts", None)             # fixed-capacity batch: true sizes on the device
         pw = 0.0 if counts is not None else (float(n) * float(n) - float(nnz)) / float(nnz)  # train_inductive.py:46
         need = ctx.needs_input_grad[0]
         loss, dZ = decoder_bce_raw(Z, mask, graph.csr(), graph.csc() if need else None, pw, want_grad=need,
-                                   dropout=dropout, counts=counts, defer_ok=True)
+                                   dropout=dropout, counts=counts, defer_ok=True, prepared=prepared)
         ctx.save_for_backward(dZ)
         return loss.reshape(())
 
@@ -1582,8 +1673,8 @@ class DecoderBCEFunction(torch.autograd.Function):
     def backward(ctx, g):
         (dZ,) = ctx.saved_tensors
         if _is_unit(g):
-            return dZ, None, None, None          # upstream gradient is the cached constant 1 (ops.backward)
-        return dZ * g, None, None, None
+            return dZ, None, None, None, None    # upstream gradient is the cached constant 1 (ops.backward)
+        return dZ * g, None, None, None, None
 
 
 def bce_logits_raw(logits, labels, pos_weight, want_grad=True):
@@ -1685,9 +1776,12 @@ def backward(loss, params=None):
         p.grad = g
 
 
-def decoder_bce(Z, mask, graph, dropout=None):
+def decoder_bce(Z, mask, graph, dropout=None, prepared=None):
     """``dropout`` = (p, seed, offset, draw_counter): draw the mask inside the fused launch into ``mask``.
+    ``prepared``: token of a producer launch that already ran the prepare step (loss_prepare_request).
     Embeddings wider than FUSED_MAX_D take the dense HIP chain (same value, O(N^2) memory)."""
+    if prepared is not None:
+        return DecoderBCEFunction.apply(Z, prepared["mask"], graph, prepared["dropout"], prepared)
     if Z.shape[1] > FUSED_MAX_D:
         if getattr(graph, "batch_counts", None) is not None:
             raise GaeHipError(f"fixed-capacity batches need an embedding width <= {FUSED_MAX_D}")

@@ -515,6 +515,45 @@ int gae_decoder_bce_padded(const float *Z, float *mask, int64_t ldz, int64_t n_c
                            float *loss_out, float *dZ, int64_t lddz,
                            void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Prepare step folded into the PRODUCER of Z.  gae_decoder_bce* start with a small launch that applies the dropout
+ * mask to Z, pads it to 16 columns, splits it into bf16 hi / lo and adds up its columns.  When Z comes out of
+ * gae_gcn_layer_fused (the last encoder layer of gae_dgl/gae.py:55-57 followed by the loss of
+ * train_inductive.py:44-48), that launch can do the same work in its epilogue:
+ *   gae_decoder_bce_prep_layout(n, d, ws, bytes, &prep)   where the pieces go inside the loss workspace `ws`
+ *                                                         (gae_decoder_bce_workspace_bytes(n, n, d) bytes), d <= 16;
+ *   gae_gcn_layer_fused_prep(..., &prep, mask, ...)       the layer + the prepare work (see there);
+ *   gae_decoder_bce_prepared(..., n_prep_blocks, ..., ws) the loss from the dense kernel on: same arguments as
+ *                                                         gae_decoder_bce / _padded (counts_dev != NULL: padded batch,
+ *                                                         pos_weight ignored) minus Z / seed / offset.
+ * One kernel node fewer per training step; the values are those of the three-launch form up to the order of the
+ * column sums (fp64). */
+typedef struct gae_bce_prep {
+    float *Zt;                   /* [n][DP] fp32                                  (device, inside the workspace) */
+    uint16_t *Zhi, *Zlo;         /* [n][DP] bf16 hi / lo */
+    double *colsum_partial;      /* [blocks][2][DP] */
+    double *scal;                /* [3]: pos_weight, 1 / N^2, pad pairs of a padded batch */
+    double all_pairs;            /* pairs the dense kernel evaluates (for scal[2]) */
+    int64_t max_blocks;          /* room in colsum_partial */
+    int32_t DP, reserved;
+} gae_bce_prep;
+int gae_decoder_bce_prep_layout(int64_t n, int64_t d, void *workspace, int64_t workspace_bytes, gae_bce_prep *out);
+/* gae_gcn_layer_fused (identity activation, square graph, J <= 16 outputs = the embedding Z [n, J], ldz) + the prepare
+ * work of the loss that follows: mask [n, J] (ldmask) is the dropout multiplier -- drawn here (dropout_p > 0: the
+ * Philox stream of gae_dropout_mask with *draw_dev as the draw index, written to `mask`) or given (dropout_p == 0, mask
+ * may be NULL = all ones); counts_dev != NULL: fixed-capacity batch, rows >= counts_dev[0] are padding.
+ * *n_prep_blocks_out = the number of column-sum partials written (pass it to gae_decoder_bce_prepared). */
+int gae_gcn_layer_fused_prep(const int32_t *indptr, const int32_t *indices, int64_t n, const float *H, int64_t ldh,
+                             float *M, int64_t ldm, int64_t F, const float *row_scale, const float *col_scale,
+                             const gae_spmm_plan *plan, const float *W, int64_t w_stride_out, int64_t w_stride_in,
+                             const float *bias, int64_t J, float *Z, int64_t ldz, const gae_bce_prep *prep, float *mask,
+                             int64_t ldmask, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *draw_dev,
+                             const int64_t *counts_dev, int64_t *n_prep_blocks_out, void *stream);
+int gae_decoder_bce_prepared(float *mask, int64_t ldz, int64_t n, int64_t d, const int32_t *indptr,
+                             const int32_t *indices, const int32_t *t_indptr, const int32_t *t_indices,
+                             float pos_weight, const int64_t *counts_dev, float dropout_p, uint64_t *draw_dev,
+                             int64_t n_prep_blocks, float *loss_out, float *dZ, int64_t lddz, void *workspace,
+                             int64_t workspace_bytes, void *stream);
+
 /* Deferred final reduction.  The last launch of gae_decoder_bce* adds the per-block partial sums to the scalar; the
  * backward pass does not read that scalar, so a training step may run the reduction later, next to other work:
  *   gae_decoder_bce_defer_finalize(&tail)  arms the calling thread: its NEXT gae_decoder_bce / _rows / _padded call

@@ -116,3 +116,69 @@ def test_a_loss_fn_of_the_callers_keeps_its_reduction_launch():
         step = CapturedTrainStep(m, Adam(m.parameters(), lr=1e-2), g, X, loss_fn=fn, warmup=1)
         out.append([float(step()) for _ in range(3)])
     assert out[0] == out[1]
+
+
+@pytest.mark.parametrize("n,dims,dropout", [(900, [32, 16], 0.1), (900, [32, 16], 0.0), (8700, [32, 16], 0.1),
+                                             (1500, [32, 8], 0.1), (1300, [16], 0.1), (2100, [48, 24, 12], 0.2)])
+def test_prepare_step_in_the_last_layers_epilogue(n, dims, dropout):
+    """reconstruction_loss with the loss's prepare step folded into the last encoder launch (gae_gcn_layer_fused_prep
+    + gae_decoder_bce_prepared) against the three-launch form: same mask bits, same loss and gradients up to the
+    order of the fp64 column sums"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops
+    g = _graph(n, seed=n)
+    torch.manual_seed(n)
+    X = torch.randn(n, 40, device=DEV)
+    m = G.GAE(40, dims).to(DEV)
+    m.decoder.seed = 21
+    m.decoder.dropout = dropout
+    res = []
+    for fuse in (True, False):
+        ops.FUSE_LOSS_PREPARE = fuse
+        try:
+            m.decoder._draws = None
+            m.zero_grad(set_to_none=True)
+            g.ndata['h'] = X
+            before = ops.STATS["prepared_losses"]
+            loss = m.reconstruction_loss(g)
+            assert ops.STATS["prepared_losses"] - before == (1 if fuse else 0)
+            ops.backward(loss, list(m.parameters()))
+            torch.cuda.synchronize()
+            res.append((float(loss), [p.grad.clone() for p in m.parameters()],
+                        None if m.decoder.last_mask is None else m.decoder.last_mask.clone(), g.ndata['h'].clone(),
+                        int(m.decoder._draws) if m.decoder._draws is not None else 0))
+        finally:
+            ops.FUSE_LOSS_PREPARE = True
+    (la, ga, ma, za, da), (lb, gb, mb, zb, db) = res
+    assert abs(la - lb) <= 1e-6 * abs(lb) and da == db == (1 if dropout else 0)
+    assert torch.equal(za, zb) and ((ma is None and mb is None) or torch.equal(ma, mb))
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-6)
+
+
+def test_prepared_loss_on_fixed_capacity_batches():
+    """the padded-batch form (device-side true sizes, captured inductive step): an epoch with the prepare step in the
+    last layer's epilogue == an epoch with the prepare launch"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, workloads as W
+    from gae_dgl_amd.capture import CapturedInductiveStep
+    from gae_dgl_amd.dataset import DeviceGraphDataset
+    from gae_dgl_amd.optim import Adam
+    gp, src, dst, X = W.zinc_like(240, seed=4)
+    ds = DeviceGraphDataset(gp, src, dst, X, device=DEV)
+    torch.manual_seed(1)
+    m0 = G.GAE(ds.n_feat, [32, 16]).to(DEV)
+    m0.decoder.seed = 2
+    order = np.random.default_rng(0).permutation(ds.ids)
+    out = []
+    for fuse in (True, False):
+        ops.FUSE_LOSS_PREPARE = fuse
+        try:
+            m = copy.deepcopy(m0)
+            runner = CapturedInductiveStep(m, Adam(m.parameters(), lr=1e-2), ds, 48)
+            out.append(([float(l) for l in runner.epoch(order)], [p.detach().clone() for p in m.parameters()]))
+        finally:
+            ops.FUSE_LOSS_PREPARE = True
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-6)
+    for a, b in zip(out[0][1], out[1][1]):
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-3)
