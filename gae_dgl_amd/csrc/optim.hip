@@ -16,9 +16,20 @@ namespace {
 
 constexpr int kAdamMaxTensors = GAE_ADAM_MAX_TENSORS;
 constexpr int kAdamChunk = 1024;      // elements per block: 256 threads x float4
+}
+namespace gae {
+// "adam_chunk": elements per block of a tensor whose gradient is a short partial-sum list (<= 32 partials): 256 (one
+// per thread), 1024 (four per thread, one after another) or 0 = auto: 256 from 8 partials on (the sum is a chain of
+// dependent round trips: Pubmed, 32 partials, 0.232 -> 0.228 ms per step; Cora, 11: 0.083 -> 0.082), 1024 below
+// (Citeseer, 4 partials of 118 k elements: 0.105 -> 0.103 with the fewer, longer blocks)
+Knob g_adam_chunk{0};
+Knob *optim_knob(const char *name) { return strcmp(name, "adam_chunk") == 0 ? &g_adam_chunk : nullptr; }
+}
+namespace {
 
 struct AdamArgs {
     gae_adam_tensor t[kAdamMaxTensors];
+    int32_t chunk[kAdamMaxTensors];             // elements per block of tensor k
     int32_t first_block[kAdamMaxTensors + 1];   // block range of tensor k: [first_block[k], first_block[k + 1])
     int32_t n_tensors;
     int32_t n_blocks;                           // optimiser blocks of the launch (a loss tail may follow them)
@@ -79,10 +90,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
         const int L = gae::partial_lanes(t.n_partials);
         const unsigned row_len = unsigned(t.row_len), n32 = unsigned(t.n);          // (sizes checked on the host: < 2^31)
         if (L == 1) {
-            // 4 elements per thread, block-strided (adjacent lanes read adjacent elements of every partial)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned e = unsigned(lb) * unsigned(kAdamChunk) + unsigned(q) * 256u + threadIdx.x;
+            // ONE element per thread (adjacent lanes read adjacent elements of every partial): the sum is a chain of
+            // ceil(n_partials / 16) dependent round trips per element, so elements go side by side, not one after
+            // another in a thread (4 per thread: 12.2 us for Pubmed's 16 k weights, 8 round trips)
+            const unsigned chunk = unsigned(a.chunk[k]);
+            for (unsigned q = 0; q < chunk / 256u; ++q) {
+                const unsigned e = unsigned(lb) * chunk + q * 256u + threadIdx.x;
                 const unsigned ec = e < n32 ? e : 0u;
                 const unsigned r = ec / row_len, c = ec - r * row_len;
                 const float g = gae::sum_partials(t.partials + int64_t(r) * t.row_pitch + c, t.n_partials,
@@ -152,7 +165,11 @@ extern "C" int gae_adam_step_tail(const gae_adam_tensor *tensors, int32_t n_tens
         a.first_block[k] = int32_t(blocks);
         GAE_REQUIRE(t.n < (int64_t(1) << 31) && t.row_len < (int64_t(1) << 31), GAE_E_SIZE,
                     "gae_adam_step: tensor %d too large", k);
-        const int64_t per_block = t.n_partials > 32 ? 256 / 64 : kAdamChunk;
+        const int knob = int(gae::g_adam_chunk);
+        const int64_t per_block = t.n_partials > 32 ? 256 / 64
+                                  : t.n_partials > 0 ? ((knob == 256 || knob == 1024) ? knob : (t.n_partials >= 8 ? 256 : 1024))
+                                                     : kAdamChunk;
+        a.chunk[k] = int32_t(per_block);
         blocks += (t.n + per_block - 1) / per_block;
         GAE_REQUIRE(blocks < (int64_t(1) << 30), GAE_E_SIZE, "gae_adam_step: too many elements for one launch");
     }

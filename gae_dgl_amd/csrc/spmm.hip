@@ -1393,7 +1393,7 @@ extern "C" int gae_spmm_tag_hot(const int32_t *indices, int64_t n_edges, const i
     return GAE_OK;
 }
 
-namespace gae { Knob *dense_knob(const char *name); Knob *bce_knob(const char *name); Knob *xw_knob(const char *name); }
+namespace gae { Knob *dense_knob(const char *name); Knob *bce_knob(const char *name); Knob *xw_knob(const char *name); Knob *optim_knob(const char *name); }
 
 namespace {
 gae::Knob *find_knob(const char *name)
@@ -1407,6 +1407,7 @@ gae::Knob *find_knob(const char *name)
     if (gae::Knob *k = gae::spmm_ell_knob(name)) return k;
     if (gae::Knob *k = gae::dense_knob(name)) return k;
     if (gae::Knob *k = gae::xw_knob(name)) return k;
+    if (gae::Knob *k = gae::optim_knob(name)) return k;
     return gae::bce_knob(name);
 }
 } // namespace

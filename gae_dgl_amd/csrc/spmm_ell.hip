@@ -371,22 +371,27 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
     float swp[SWP], swq[SWQ];
     if constexpr (EPI_J > 0) {
         if (a.sw_part != nullptr) {                            // block-uniform
+            // element idx of the block's [rows][width] tile; rows that are stored end to end (ld == width: the usual
+            // case) are one contiguous piece of memory -- no division per element
+            auto tile_load = [&](const float *base, int64_t ld, int width, int idx) {
+                int64_t off;
+                bool ok;
+                if (ld == width) {
+                    off = int64_t(blk) * SW_ROWS * width + idx;
+                    ok = idx < SW_ROWS * width && off < a.n_rows * width;
+                } else {
+                    const int r = idx / width, c = idx - r * width;
+                    const int64_t rw = int64_t(blk) * SW_ROWS + r;
+                    off = rw * ld + c;
+                    ok = r < SW_ROWS && rw < a.n_rows;
+                }
+                const float v = base[ok ? off : 0];
+                return ok ? v : 0.f;
+            };
 #pragma unroll
-            for (int q = 0; q < SWP; ++q) {
-                const int idx = threadIdx.x + 256 * q, r = idx / a.sw_O, o = idx - r * a.sw_O;
-                const int64_t rw = int64_t(blk) * SW_ROWS + r;
-                const bool ok = r < SW_ROWS && rw < a.n_rows;
-                swp[q] = a.sw_P[ok ? rw * a.sw_ldp + o : 0];
-                swp[q] = ok ? swp[q] : 0.f;
-            }
+            for (int q = 0; q < SWP; ++q) swp[q] = tile_load(a.sw_P, a.sw_ldp, a.sw_O, threadIdx.x + 256 * q);
 #pragma unroll
-            for (int q = 0; q < SWQ; ++q) {
-                const int idx = threadIdx.x + 256 * q, r = idx / a.sw_I, i = idx - r * a.sw_I;
-                const int64_t rw = int64_t(blk) * SW_ROWS + r;
-                const bool ok = r < SW_ROWS && rw < a.n_rows;
-                swq[q] = a.sw_Q[ok ? rw * a.sw_ldq + i : 0];
-                swq[q] = ok ? swq[q] : 0.f;
-            }
+            for (int q = 0; q < SWQ; ++q) swq[q] = tile_load(a.sw_Q, a.sw_ldq, a.sw_I, threadIdx.x + 256 * q);
         }
     }
 
@@ -540,6 +545,8 @@ slots_done:
                     const uint64_t draw_idx = (draw && a.pz_draw) ? *a.pz_draw : 0;
                     const bool in = row[r] < a.n_rows;
                     double *cred = reinterpret_cast<double *>(SwQ);       // [rows of the block][16]
+                    uint32_t c[4] = {0u, 0u, 0u, 0u};
+                    int64_t c_of = -1;                                    // the counter c belongs to
 #pragma unroll
                     for (int q = 0; q < JPL; ++q) {
                         const int o = lig * JPL + q;
@@ -551,10 +558,13 @@ slots_done:
                                 m = 0.f;
                                 if (draw) a.pz_mask[row[r] * a.pz_ldmask + o] = 0.f;
                             } else if (draw) {
-                                // the Philox stream of gae_dropout_mask: element e = i d + k of the [n, d] mask
+                                // the Philox stream of gae_dropout_mask: element e = i d + k of the [n, d] mask; a
+                                // lane's outputs are adjacent elements and mostly share one counter (4 per draw)
                                 const int64_t e = row[r] * a.J + o;
-                                uint32_t c[4];
-                                gae::philox4x32_10(a.pz_offset + uint64_t(e >> 2), draw_idx, a.pz_seed, c);
+                                if ((e >> 2) != c_of) {
+                                    c_of = e >> 2;
+                                    gae::philox4x32_10(a.pz_offset + uint64_t(c_of), draw_idx, a.pz_seed, c);
+                                }
                                 const uint32_t bits = (e & 2) ? ((e & 1) ? c[3] : c[2]) : ((e & 1) ? c[1] : c[0]);
                                 m = gae::dropout_multiplier(bits, a.pz_drop_p, a.pz_drop_scale);
                                 a.pz_mask[row[r] * a.pz_ldmask + o] = m;
@@ -602,12 +612,28 @@ slots_done:
             for (int q = 0; q < SWQ; ++q) SwQ[threadIdx.x + 256 * q] = swq[q];       // [r][I]
             __syncthreads();
             float *pp = a.sw_part + int64_t(blk) * a.sw_stride;
-            for (int e = threadIdx.x; e < O * I; e += 256) {
-                const int o = e / I, i = e - o * I;
-                float t = 0.f;
+            if (I == 32 && (O & 7) == 0) {
+                // thread (i = tid % 32, o0 = tid / 32): outputs o0, o0 + 8, ... share the Q value of every row
+                const int i = threadIdx.x & 31, o0 = threadIdx.x >> 5;
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-                for (int r = 0; r < SW_ROWS; ++r) t = fmaf(SwP[r * O + o], SwQ[r * I + i], t);       // row order
-                pp[e] = t;
+                for (int r = 0; r < SW_ROWS; ++r) {
+                    const float qv = SwQ[r * 32 + i];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (o0 + 8 * k < O) t[k] = fmaf(SwP[r * O + o0 + 8 * k], qv, t[k]);           // row order
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (o0 + 8 * k < O) pp[(o0 + 8 * k) * 32 + i] = t[k];
+            } else {
+                for (int e = threadIdx.x; e < O * I; e += 256) {
+                    const int o = e / I, i = e - o * I;
+                    float t = 0.f;
+#pragma unroll 8
+                    for (int r = 0; r < SW_ROWS; ++r) t = fmaf(SwP[r * O + o], SwQ[r * I + i], t);   // row order
+                    pp[e] = t;
+                }
             }
             if (int(threadIdx.x) < O) {
                 float t = 0.f;

@@ -4,6 +4,7 @@ Tensors are only carriers of device pointers here: every op below launches
 hand-written HIP kernels from libgae_hip.so on PyTorch's current HIP stream.
 There is no CPU / eager fallback -- a CPU tensor raises."""
 import ctypes
+import os
 
 import torch
 
@@ -1159,7 +1160,7 @@ def gcn_layer_fused_raw(indptr, indices, H, n_rows, plan, W, bias, act, row_scal
 # the fused launch (GCNLayerFusedFunction, identity activation, <= 16 outputs), the launch also writes Zt / hi / lo /
 # column sums (and draws the dropout mask) into a loss workspace, and ``req.token`` describes it for
 # ``decoder_bce(..., prepared=req.token)`` -- the loss then starts at its dense kernel (one kernel node fewer per step).
-FUSE_LOSS_PREPARE = True
+FUSE_LOSS_PREPARE = os.environ.get("GAE_FUSE_LOSS_PREPARE", "1") != "0"
 _PREP_REQ = None
 STATS = {"prepared_losses": 0}      # losses that started at the dense kernel (tests read this)
 
@@ -1260,7 +1261,7 @@ def gcn_layer_fused_wgrad_raw(t_indptr, t_indices, dY, n, plan_t, W, M, norm, wa
     return dH, dW, db
 
 
-FUSED_LAYER_WGRAD = True      # False: the fused layer's backward keeps its separate weight-gradient launch (experiments)
+FUSED_LAYER_WGRAD = os.environ.get("GAE_FUSED_LAYER_WGRAD", "1") != "0"      # False: the fused layer's backward keeps its separate weight-gradient launch (experiments)
 
 
 class GCNLayerFusedFunction(torch.autograd.Function):
