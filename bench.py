@@ -1051,7 +1051,11 @@ def main():
                      "same budget; the launch sequence also holds the mirror reduction, the edge pass and two "
                      "bookkeeping launches, which this model does not count",
             "mfma_flops_per_s": isa["mfma"] * 16384.0 / 64 / 32 * frac_eval * float(n) * n / t_loss,
-            "share_of_step": t_loss / (elapsed / args.steps)}
+            "share_of_step": t_loss / (elapsed / args.steps),
+            "sequence_note": "avg_launch_us = the loss called on its own: prepare + dense + edges + final reduction "
+                             "(4 launches).  Inside the captured step the prepare work rides in the last encoder "
+                             "launch's epilogue and the final reduction in the optimiser launch (2 launches, about "
+                             "10 us less): share_of_step is an upper bound"}
         # ---- the same step with exact-fp32 products everywhere (no bf16 x 3 split)
         if graphed and isinstance(wl, CitationWorkload):
             from gae_dgl_amd import _lib
