@@ -118,6 +118,7 @@ struct Vec16<unsigned short> {   // bf16 storage, fp32 accumulation
 }  // namespace
 namespace gae {
 gae::Knob g_spmm_ell_rpg{0};      // rows per lane group of the ell kernels: 0 = auto (1)
+gae::Knob g_ell_side{14};          // "ell_side" (experiments): side work of the fused layer -- bit 3 = operands straight from global memory when the output is at most 4 tiles (default), bit 2 = outer product on the matrix cores (default), bit 0 = shared-Q scalar loop, bit 1 = tile loads without division (default)
 }
 namespace {
 
@@ -158,7 +159,7 @@ struct EllArgs {
     const float *sw_P, *sw_Q;
     float *sw_part;
     int64_t sw_ldp, sw_ldq, sw_stride;
-    int sw_O, sw_I;
+    int sw_O, sw_I, sw_variant;
     // prepare step of the fused loss in the epilogue of the layer that produces Z (gae_gcn_layer_fused_prep, EPI_J =
     // 16): Zt = Y (.) dropout mask padded to 16 columns, its bf16 hi / lo, per-block fp64 column sums -- what
     // bce_prepare_kernel (decoder_bce.hip) computes from the stored Z
@@ -369,14 +370,52 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
     constexpr int SWP = EPI_J > 0 ? SW_ROWS * 32 / 256 : 1, SWQ = EPI_J > 0 ? SW_ROWS * 64 / 256 : 1;
     __shared__ float SwP[EPI_J > 0 ? SW_ROWS * 32 : 1], SwQ[EPI_J > 0 ? SW_ROWS * 64 : 1];
     float swp[SWP], swq[SWQ];
+    constexpr int JPL_K = EPI_J > 0 ? EPI_J / LPR : 1;        // outputs a lane keeps of its row
+    double pz_sum[JPL_K];                                      // (prepare epilogue) this lane's Zt values, for the column sums
+#pragma unroll
+    for (int q = 0; q < JPL_K; ++q) pz_sum[q] = 0.0;
+    // direct form of the side work (at most 4 output tiles: one per wave): every lane requests the MFMA operands of
+    // its wave's tile HERE, straight from P / Q (4 rows x 16 columns per instruction: whole 64-byte pieces of rows) --
+    // no LDS staging, no barrier; they arrive while the wave gathers
+    constexpr int SW_K = EPI_J > 0 ? SW_ROWS / 4 : 1;
+    float sda[SW_K], sdb[SW_K];
+    bool sw_direct = false;
+    int sd_mt = 0, sd_nt = 0;
+    bool sd_ones = false, sd_live = false;
     if constexpr (EPI_J > 0) {
-        if (a.sw_part != nullptr) {                            // block-uniform
+        if (a.sw_part != nullptr && (a.sw_variant & 8)) {
+            const int mt_n = (a.sw_O + 15) >> 4, nt_n = (a.sw_I + 15) >> 4;
+            sw_direct = mt_n * nt_n + mt_n <= 4;
+            if (sw_direct) {
+                const int tile = 3 - int(threadIdx.x >> 6);       // tile ids: column sums (db) first, then products
+                sd_live = tile < mt_n * nt_n + mt_n;
+                sd_ones = tile < mt_n;
+                const int pt = tile - mt_n;
+                sd_mt = sd_ones ? tile : pt / nt_n;
+                sd_nt = sd_ones ? 0 : pt - sd_mt * nt_n;
+                const int l15 = threadIdx.x & 15, g4 = (threadIdx.x & 63) >> 4;
+                const int o = sd_mt * 16 + l15, i = sd_nt * 16 + l15;
+#pragma unroll
+                for (int st = 0; st < SW_K; ++st) {
+                    const int64_t rw = int64_t(blk) * SW_ROWS + 4 * st + g4;
+                    const bool okr = sd_live && rw < a.n_rows;
+                    const bool oka = okr && o < a.sw_O, okb = okr && !sd_ones && i < a.sw_I;
+                    const float av = a.sw_P[oka ? rw * a.sw_ldp + o : 0];
+                    const float bv = a.sw_Q[okb ? rw * a.sw_ldq + i : 0];
+                    sda[st] = oka ? av : 0.f;
+                    sdb[st] = sd_ones ? 1.f : (okb ? bv : 0.f);
+                }
+            }
+        }
+    }
+    if constexpr (EPI_J > 0) {
+        if (a.sw_part != nullptr && !sw_direct) {              // block-uniform
             // element idx of the block's [rows][width] tile; rows that are stored end to end (ld == width: the usual
             // case) are one contiguous piece of memory -- no division per element
             auto tile_load = [&](const float *base, int64_t ld, int width, int idx) {
                 int64_t off;
                 bool ok;
-                if (ld == width) {
+                if (ld == width && (a.sw_variant & 2)) {
                     off = int64_t(blk) * SW_ROWS * width + idx;
                     ok = idx < SW_ROWS * width && off < a.n_rows * width;
                 } else {
@@ -544,7 +583,6 @@ slots_done:
                     const bool draw = a.pz_drop_p > 0.f;
                     const uint64_t draw_idx = (draw && a.pz_draw) ? *a.pz_draw : 0;
                     const bool in = row[r] < a.n_rows;
-                    double *cred = reinterpret_cast<double *>(SwQ);       // [rows of the block][16]
                     uint32_t c[4] = {0u, 0u, 0u, 0u};
                     int64_t c_of = -1;                                    // the counter c belongs to
 #pragma unroll
@@ -579,7 +617,7 @@ slots_done:
                             a.pz_hi[row[r] * 16 + o] = hi;
                             a.pz_lo[row[r] * 16 + o] = gae::f32_to_bf16(v - gae::bf16_to_f32(hi));
                         }
-                        cred[grp * 16 + o] = double(v);
+                        pz_sum[q] = double(v);
                     }
                 }
             }
@@ -587,11 +625,18 @@ slots_done:
     }
     if constexpr (EPI_J == 16) {
         if (a.pz_t != nullptr) {
+            // column sums of the block's rows, fixed order: butterfly over the rows of a wave (lanes with the same
+            // outputs are LPR apart), then the 4 waves in order
+            double *cred = reinterpret_cast<double *>(SwQ);              // [wave][16]
+#pragma unroll
+            for (int q = 0; q < JPL_K; ++q) {
+#pragma unroll
+                for (int off = LPR; off < 64; off <<= 1) pz_sum[q] += __shfl_xor(pz_sum[q], off, 64);
+                if ((threadIdx.x & 63) < LPR) cred[(threadIdx.x >> 6) * 16 + lig * JPL_K + q] = pz_sum[q];
+            }
             __syncthreads();
-            const double *cred = reinterpret_cast<const double *>(SwQ);
             if (threadIdx.x < 16) {
-                double t = 0.0;
-                for (int g2 = 0; g2 < SW_ROWS; ++g2) t += cred[g2 * 16 + threadIdx.x];          // row order
+                const double t = ((cred[threadIdx.x] + cred[16 + threadIdx.x]) + cred[32 + threadIdx.x]) + cred[48 + threadIdx.x];
                 a.pz_cs[(int64_t(blk) * 2 + 0) * 16 + threadIdx.x] = t;                        // all rows
                 a.pz_cs[(int64_t(blk) * 2 + 1) * 16 + threadIdx.x] = t;                        // ... = the row window
             }
@@ -604,7 +649,24 @@ slots_done:
         }
     }
     if constexpr (EPI_J > 0) {
-        if (a.sw_part != nullptr) {
+        if (a.sw_part != nullptr && sw_direct) {
+            if (sd_live) {                                        // wave-uniform
+                const int O = a.sw_O, I = a.sw_I;
+                const int l15 = threadIdx.x & 15, g4 = (threadIdx.x & 63) >> 4;
+                typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < SW_K; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sda[st], sdb[st], acc, 0, 0, 0);
+                float *pp = a.sw_part + int64_t(blk) * a.sw_stride;
+                const int i = sd_nt * 16 + l15;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int oo = sd_mt * 16 + 4 * g4 + q;
+                    if (sd_ones) { if (oo < O && l15 == 0) pp[O * I + oo] = acc[q]; }
+                    else if (oo < O && i < I) pp[oo * I + i] = acc[q];
+                }
+            }
+        } else if (a.sw_part != nullptr) {
             const int O = a.sw_O, I = a.sw_I;
 #pragma unroll
             for (int q = 0; q < SWP; ++q) SwP[threadIdx.x + 256 * q] = swp[q];       // [r][O], rows end to end
@@ -612,7 +674,36 @@ slots_done:
             for (int q = 0; q < SWQ; ++q) SwQ[threadIdx.x + 256 * q] = swq[q];       // [r][I]
             __syncthreads();
             float *pp = a.sw_part + int64_t(blk) * a.sw_stride;
-            if (I == 32 && (O & 7) == 0) {
+            if (a.sw_variant & 4) {
+                // the outer product on the matrix cores: out [O x I] = P^T [O x rows] Q [rows x I], 16 x 16 output
+                // tiles dealt to the 4 waves, K = the block's rows in steps of 4 (v_mfma_f32_16x16x4_f32: exact fp32
+                // products, one fixed accumulation order)
+                const int wv = threadIdx.x >> 6, l15 = threadIdx.x & 15, g4 = (threadIdx.x & 63) >> 4;
+                const int mt_n = (O + 15) >> 4, nt_n = (I + 15) >> 4;
+                // tiles mt_n * nt_n .. + mt_n - 1: the column sums of P (db) as P^T times a column of ones; the
+                // highest waves take them first (they have the fewest product tiles)
+                for (int tile = 3 - wv; tile < mt_n * nt_n + mt_n; tile += 4) {
+                    const bool ones = tile < mt_n;                        // (tile ids: column sums first, then products)
+                    const int pt = tile - mt_n;
+                    const int mt = ones ? tile : pt / nt_n, nt = ones ? 0 : pt - mt * nt_n;
+                    const int o = mt * 16 + l15, i = nt * 16 + l15;
+                    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int st = 0; st < SW_ROWS / 4; ++st) {
+                        const int r = 4 * st + g4;
+                        const float av = o < O ? SwP[r * O + o] : 0.f;
+                        const float bv = ones ? 1.f : (i < I ? SwQ[r * I + i] : 0.f);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int oo = mt * 16 + 4 * g4 + q;
+                        if (ones) { if (oo < O && l15 == 0) pp[O * I + oo] = acc[q]; }
+                        else if (oo < O && i < I) pp[oo * I + i] = acc[q];
+                    }
+                }
+            } else if (I == 32 && (O & 7) == 0 && (a.sw_variant & 1)) {
                 // thread (i = tid % 32, o0 = tid / 32): outputs o0, o0 + 8, ... share the Q value of every row
                 const int i = threadIdx.x & 31, o0 = threadIdx.x >> 5;
                 float t[4] = {0.f, 0.f, 0.f, 0.f};
@@ -635,7 +726,7 @@ slots_done:
                     pp[e] = t;
                 }
             }
-            if (int(threadIdx.x) < O) {
+            if (!(a.sw_variant & 4) && int(threadIdx.x) < O) {
                 float t = 0.f;
                 for (int r = 0; r < SW_ROWS; ++r) t += SwP[r * O + threadIdx.x];
                 pp[O * I + threadIdx.x] = t;
@@ -714,6 +805,7 @@ namespace gae {
 Knob *spmm_ell_knob(const char *name)
 {
     if (strcmp(name, "spmm_ell_rpg") == 0) return &g_spmm_ell_rpg;
+    if (strcmp(name, "ell_side") == 0) return &g_ell_side;
     return nullptr;
 }
 
@@ -840,6 +932,7 @@ static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, i
     if (side) {
         a.sw_P = side->P; a.sw_Q = side->Q; a.sw_part = side->part;
         a.sw_ldp = side->ldp; a.sw_ldq = side->ldq; a.sw_stride = side->stride; a.sw_O = side->O; a.sw_I = side->I;
+        a.sw_variant = int(gae::g_ell_side);
     }
     if (prep) {
         a.pz_t = prep->lay->Zt; a.pz_hi = prep->lay->Zhi; a.pz_lo = prep->lay->Zlo; a.pz_cs = prep->lay->colsum_partial;
