@@ -237,6 +237,10 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t b = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
     int64_t in_on = 0, in_oe = 0, in_tn = 0, in_te = 0, in_g = 0, in_cur = 0;
+    // the wave's own graph as the prefix pass saw it (the lane that visited q == b broadcasts: two dependent round
+    // trips -- graph_ptr[g], ds_indptr[n0] -- less in front of the copies)
+    long long own_g = 0, own_n0 = 0, own_n1 = 0;
+    int own_e0 = 0, own_e1 = 0;
     if (order) {
         in_cur = *cursor;
         long long pn = 0, pe = 0, tn = 0, te = 0;
@@ -244,9 +248,11 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
             const int64_t k = in_cur * n_graphs + q;
             const int64_t gq = order[k < n_order ? k : n_order - 1];
             const int64_t a0 = graph_ptr[gq], a1 = graph_ptr[gq + 1];
-            const long long nn_ = a1 - a0, ee_ = (long long)ds_indptr[a1] - ds_indptr[a0];
+            const int ei0 = ds_indptr[a0], ei1 = ds_indptr[a1];
+            const long long nn_ = a1 - a0, ee_ = (long long)ei1 - ei0;
             tn += nn_; te += ee_;
             if (q < b) { pn += nn_; pe += ee_; }
+            if (q == b) { own_g = gq; own_n0 = a0; own_n1 = a1; own_e0 = ei0; own_e1 = ei1; }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -255,8 +261,10 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
         }
         in_on = pn; in_oe = pe; in_tn = tn; in_te = te;
         if (b < n_graphs) {
-            const int64_t k = in_cur * n_graphs + b;
-            in_g = order[k < n_order ? k : n_order - 1];
+            const int src = int(b % kWave);
+            own_g = __shfl(own_g, src, 64); own_n0 = __shfl(own_n0, src, 64); own_n1 = __shfl(own_n1, src, 64);
+            own_e0 = __shfl(own_e0, src, 64); own_e1 = __shfl(own_e1, src, 64);
+            in_g = own_g;
             if (lane == 0) { ids_out[b] = in_g; node_ptr_out[b] = in_on; edge_ptr_out[b] = in_oe; }
         }
         if (b == 0 && lane == 0) { node_ptr_out[n_graphs] = in_tn; edge_ptr_out[n_graphs] = in_te; }
@@ -317,9 +325,9 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
         return;
     }
     const int64_t g = order ? in_g : graph_ids[b];
-    const int64_t n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
+    const int64_t n0 = order ? int64_t(own_n0) : graph_ptr[g], n1 = order ? int64_t(own_n1) : graph_ptr[g + 1];
     const int64_t on = order ? in_on : out_node_ptr[b], oe = order ? in_oe : out_edge_ptr[b];
-    const int32_t e0 = ds_indptr[n0], e1 = ds_indptr[n1];
+    const int32_t e0 = order ? own_e0 : ds_indptr[n0], e1 = order ? own_e1 : ds_indptr[n1];
     const int64_t nn = n1 - n0;
     if (cap_nodes > 0 && (on + nn > cap_nodes || oe + (e1 - e0) > cap_edges)) return;   // see the guard above
     for (int64_t i = lane; i < nn; i += kWave)
