@@ -583,7 +583,9 @@ def homed_plan_parts(indptr, indices, n_cols, min_degree=None, segment=None, hot
     cols = cols[order]
     grp = grp[order]
     del order
-    cnt = torch.bincount(grp, minlength=R * 8)                 # edges per (row, home)
+    # edges per (row, home): grp is sorted, so the counts are differences of bucket boundaries (torch.bincount's
+    # histogram kernel took 28 ms per plan on RMAT s24: 175 M atomics)
+    cnt = torch.diff(torch.searchsorted(grp, torch.arange(R * 8 + 1, device=dev, dtype=grp.dtype)))
     del grp
     nchunk = (cnt + seg - 1) // seg
     gstart = torch.cumsum(cnt, 0) - cnt
