@@ -371,6 +371,16 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
     __shared__ float SwP[EPI_J > 0 ? SW_ROWS * 32 : 1], SwQ[EPI_J > 0 ? SW_ROWS * 64 : 1];
     float swp[SWP], swq[SWQ];
     constexpr int JPL_K = EPI_J > 0 ? EPI_J / LPR : 1;        // outputs a lane keeps of its row
+    // (prepare epilogue) the two device-side scalars it needs, requested HERE: a load issued where they are used would
+    // stall every wave at the end of the kernel for a full round trip
+    int64_t pz_n_valid = a.n_rows;
+    uint64_t pz_draw_idx = 0;
+    if constexpr (EPI_J == 16) {
+        if (a.pz_t != nullptr) {
+            if (a.pz_counts) pz_n_valid = a.pz_counts[0];
+            if (a.pz_drop_p > 0.f && a.pz_draw) pz_draw_idx = *a.pz_draw;
+        }
+    }
     double pz_sum[JPL_K];                                      // (prepare epilogue) this lane's Zt values, for the column sums
 #pragma unroll
     for (int q = 0; q < JPL_K; ++q) pz_sum[q] = 0.0;
@@ -579,9 +589,9 @@ slots_done:
             if constexpr (EPI_J == 16) {
                 if (a.pz_t != nullptr) {                                  // block-uniform
                     // rows >= counts[0] of a fixed-capacity batch are padding: zero rows of Zt, zero mask
-                    const int64_t n_valid = a.pz_counts ? a.pz_counts[0] : a.n_rows;
+                    const int64_t n_valid = pz_n_valid;
                     const bool draw = a.pz_drop_p > 0.f;
-                    const uint64_t draw_idx = (draw && a.pz_draw) ? *a.pz_draw : 0;
+                    const uint64_t draw_idx = pz_draw_idx;
                     const bool in = row[r] < a.n_rows;
                     uint32_t c[4] = {0u, 0u, 0u, 0u};
                     int64_t c_of = -1;                                    // the counter c belongs to
