@@ -118,7 +118,11 @@ struct Vec16<unsigned short> {   // bf16 storage, fp32 accumulation
 }  // namespace
 namespace gae {
 gae::Knob g_spmm_ell_rpg{0};      // rows per lane group of the ell kernels: 0 = auto (1)
-gae::Knob g_ell_side{14};          // "ell_side" (experiments): side work of the fused layer -- bit 3 = operands straight from global memory when the output is at most 4 tiles (default), bit 2 = outer product on the matrix cores (default), bit 0 = shared-Q scalar loop, bit 1 = tile loads without division (default)
+// "ell_side": how the side work of the fused layer (gae_gcn_layer_fused_wgrad) forms its outer product.  Bit 3: MFMA
+// operands straight from global memory, no LDS, no barrier, when the output is at most 4 tiles of 16 x 16 (Pubmed:
+// launch 9.0 us; gather alone 7.5); bit 2: on the matrix cores from LDS tiles (9.6 us; the form for larger outputs);
+// neither: scalar LDS loop (10.4 us); bit 1: tile loads without a division per element (off: 11.9 us).  Default: all.
+gae::Knob g_ell_side{14};
 }
 namespace {
 
@@ -713,20 +717,6 @@ slots_done:
                         else if (oo < O && i < I) pp[oo * I + i] = acc[q];
                     }
                 }
-            } else if (I == 32 && (O & 7) == 0 && (a.sw_variant & 1)) {
-                // thread (i = tid % 32, o0 = tid / 32): outputs o0, o0 + 8, ... share the Q value of every row
-                const int i = threadIdx.x & 31, o0 = threadIdx.x >> 5;
-                float t[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-                for (int r = 0; r < SW_ROWS; ++r) {
-                    const float qv = SwQ[r * 32 + i];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (o0 + 8 * k < O) t[k] = fmaf(SwP[r * O + o0 + 8 * k], qv, t[k]);           // row order
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (o0 + 8 * k < O) pp[(o0 + 8 * k) * 32 + i] = t[k];
             } else {
                 for (int e = threadIdx.x; e < O * I; e += 256) {
                     const int o = e / I, i = e - o * I;

@@ -109,3 +109,21 @@ def test_padding_rows_of_a_capacity_batch_add_nothing():
     assert torch.equal(res[0][0][:n], res[1][0])
     for a, b in zip(res[0][1:], res[1][1:]):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("variant", [0, 2, 6, 14])
+@pytest.mark.parametrize("n,f_in,f_out", [(1234, 32, 16), (900, 24, 32)])
+def test_every_form_of_the_side_work_gives_the_same_gradient(n, f_in, f_out, variant, tuning):
+    """knob ell_side: scalar LDS loop / matrix cores from LDS tiles / operands straight from global memory"""
+    from gae_dgl_amd import ops
+    g, src, dst = _graph(n, seed=3)
+    torch.manual_seed(7)
+    dY = torch.randn(n, f_out, device=DEV)
+    W = torch.randn(f_out, f_in, device=DEV) * 0.2
+    M = torch.randn(n, f_in, device=DEV)
+    tuning("ell_side", variant)
+    dH, dW, db = ops.gcn_layer_fused_wgrad_raw(*g.csc(), dY, n, g.spmm_plan(True), W, M, None)
+    rW = dY.double().t() @ M.double()
+    rb = dY.double().sum(0)
+    assert float((dW.double() - rW).abs().max()) <= 2e-6 * float(rW.abs().max())
+    assert float((db.double() - rb).abs().max()) <= 2e-6 * float(rb.abs().max())
