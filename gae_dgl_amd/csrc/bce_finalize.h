@@ -18,23 +18,58 @@ __device__ __forceinline__ void bce_finalize_block(const gae_bce_tail &t, double
     if (t.scal) { inv_n2 = t.scal[1]; pad_terms = t.scal[2]; }
     const int lane = threadIdx.x & 63;
     const double2 *dp2 = reinterpret_cast<const double2 *>(t.dense_partial);   // {sum |x|, sum log2 t} pairs
-#pragma unroll 1
-    for (int v = 0; v < 1024 / NT; ++v) {
-        const int tid = int(threadIdx.x) + v * NT;          // virtual thread: 4 independent loads per trip
-        double a = 0.0, l = 0.0, e = 0.0;
-        int64_t k = tid;
-        for (; k + 3 * 1024 < t.n_dense; k += 4 * 1024) {
-            const double2 v0 = dp2[k], v1 = dp2[k + 1024], v2 = dp2[k + 2048], v3 = dp2[k + 3072];
-            a += (v0.x + v1.x) + (v2.x + v3.x);
-            l += (v0.y + v1.y) + (v2.y + v3.y);
-        }
-        for (; k < t.n_dense; k += 1024) { const double2 w = dp2[k]; a += w.x; l += w.y; }
-        for (int64_t q = tid; q < t.n_edge; q += 1024) e += t.edge_partial[q];
+    // every virtual thread keeps the order of the 1024-thread kernel (quads (k, k + 1024, k + 2048, k + 3072) added
+    // pairwise, then single elements), but the V virtual threads of a real thread advance side by side: their loads
+    // are independent and go out together (one after the other they made the tail block the longest of the launch)
+    constexpr int V = 1024 / NT;
+    double a[V], l[V], e[V];
+    int64_t k[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { a[v] = l[v] = e[v] = 0.0; k[v] = int64_t(threadIdx.x) + v * NT; }
+    for (bool any = true; any;) {
+        any = false;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            if (k[v] + 3 * 1024 < t.n_dense) {
+                const double2 v0 = dp2[k[v]], v1 = dp2[k[v] + 1024], v2 = dp2[k[v] + 2048], v3 = dp2[k[v] + 3072];
+                a[v] += (v0.x + v1.x) + (v2.x + v3.x);
+                l[v] += (v0.y + v1.y) + (v2.y + v3.y);
+                k[v] += 4 * 1024;
+                any = true;
+            }
+    }
+    for (bool any = true; any;) {
+        any = false;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            if (k[v] < t.n_dense) {
+                const double2 w = dp2[k[v]];
+                a[v] += w.x; l[v] += w.y;
+                k[v] += 1024;
+                any = true;
+            }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) k[v] = int64_t(threadIdx.x) + v * NT;
+    for (bool any = true; any;) {
+        any = false;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            if (k[v] < t.n_edge) {
+                e[v] += t.edge_partial[k[v]];
+                k[v] += 1024;
+                any = true;
+            }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        double av = a[v], lv = l[v], ev = e[v];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            a += __shfl_down(a, off, 64); l += __shfl_down(l, off, 64); e += __shfl_down(e, off, 64);
+            av += __shfl_down(av, off, 64); lv += __shfl_down(lv, off, 64); ev += __shfl_down(ev, off, 64);
         }
-        if (lane == 0) { red[0][tid >> 6] = a; red[1][tid >> 6] = l; red[2][tid >> 6] = e; }
+        const int tid = int(threadIdx.x) + v * NT;          // the virtual thread
+        if (lane == 0) { red[0][tid >> 6] = av; red[1][tid >> 6] = lv; red[2][tid >> 6] = ev; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
