@@ -182,3 +182,38 @@ def test_prepared_loss_on_fixed_capacity_batches():
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-6)
     for a, b in zip(out[0][1], out[1][1]):
         assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-3)
+
+
+@pytest.mark.parametrize("case", ["wide_last_layer", "norm_both", "given_mask"])
+def test_prepare_epilogue_variants(case):
+    """the prepare epilogue on 16-lane row groups (last layer with 33..64 inputs), with the symmetric degree
+    normalisation, and with a caller-provided dropout mask instead of a drawn one"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops
+    n = 1700
+    g = _graph(n, seed=12)
+    torch.manual_seed(3)
+    X = torch.randn(n, 40, device=DEV)
+    dims = [48, 16] if case == "wide_last_layer" else [32, 16]
+    m = G.GAE(40, dims, norm="both" if case == "norm_both" else None).to(DEV)
+    m.decoder.seed = 6
+    if case == "given_mask":
+        m.decoder.mask = ops.dropout_mask((n, 16), 0.1, 99, device=DEV)
+    res = []
+    for fuse in (True, False):
+        ops.FUSE_LOSS_PREPARE = fuse
+        try:
+            m.decoder._draws = None
+            m.zero_grad(set_to_none=True)
+            g.ndata['h'] = X
+            before = ops.STATS["prepared_losses"]
+            loss = m.reconstruction_loss(g)
+            assert ops.STATS["prepared_losses"] - before == (1 if fuse else 0)
+            ops.backward(loss, list(m.parameters()))
+            torch.cuda.synchronize()
+            res.append((float(loss.detach()), [p.grad.clone() for p in m.parameters()], m.decoder.last_mask.clone()))
+        finally:
+            ops.FUSE_LOSS_PREPARE = True
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0]) and torch.equal(res[0][2], res[1][2])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-6)
