@@ -441,7 +441,8 @@ class VgaeWorkload(CitationWorkload):
         self.model.last = {}
         self.g.ndata['h'] = self.Xd
         self.opt.zero_grad(set_to_none=True)
-        self.captured = CapturedTrainStep(self.model, self.opt, self.g, self.Xd, loss_fn=lambda m, g: m.loss(g))
+        self.captured = CapturedTrainStep(self.model, self.opt, self.g, self.Xd, loss_fn=lambda m, g: m.loss(g),
+                                          defer_loss=True)
 
     loss_launch = None
 

@@ -43,7 +43,8 @@ class BceTail(ctypes.Structure):
     """gae_bce_tail: the deferred final reduction of a fused loss call (gae_decoder_bce_defer_finalize)"""
     _fields_ = [("dense_partial", _p), ("n_dense", _i64), ("edge_partial", _p), ("n_edge", _i64), ("S", _p),
                 ("DP", _i32), ("reserved", _i32), ("pad_terms", ctypes.c_double), ("inv_n2", ctypes.c_double),
-                ("loss_out", _p), ("bump_draw", _p), ("scal", _p)]
+                ("loss_out", _p), ("bump_draw", _p), ("scal", _p),
+                ("kl_partial", _p), ("n_kl", _i64), ("kl_scale", ctypes.c_double), ("kl_out", _p), ("rec_out", _p)]
 
 
 class BcePrep(ctypes.Structure):
@@ -130,6 +131,10 @@ SIGNATURES = {
                                         _p, _p]),
     "gae_decoder_bce_prepared": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f, _p, _f, _p, _i64, _p, _p, _i64, _p, _i64,
                                         _p]),
+    "gae_vgae_head_prep": (_int, [_p, _p, _i64, _p, _int, _u64, _u64, _p, _i64, _i64, _p, ctypes.POINTER(BcePrep), _p, _i64,
+                                  _p, _p]),
+    "gae_gcn_layer_fused2_wgrad": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, ctypes.POINTER(SpmmPlan), _p, _p, _i64, _i64,
+                                          _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _p]),
     "gae_adam_step_tail": (_int, [ctypes.POINTER(AdamTensor), _i32, _f, _f, _f, _f, _f, _p, ctypes.POINTER(BceTail), _p]),
     "gae_decoder_bce_defer_finalize": (_int, [ctypes.POINTER(BceTail)]),
     "gae_decoder_bce_finalize": (_int, [ctypes.POINTER(BceTail), _p]),

@@ -51,10 +51,14 @@ class CapturedTrainStep:
     of the warm-up frees autograd graphs that only reference cycles keep alive.  The warm-up steps DO train the
     model (``warmup`` real steps); use ``warmup=0`` after eager steps of your own if that matters."""
 
-    def __init__(self, model, optimizer, graph, features, loss_fn=None, warmup=3):
+    def __init__(self, model, optimizer, graph, features, loss_fn=None, warmup=3, defer_loss=None):
         self.model, self.opt, self.g, self.x = model, optimizer, graph, features
         self._params = [p for group in optimizer.param_groups for p in group["params"]]
-        self._defer_loss = loss_fn is None and hasattr(model, "reconstruction_loss")
+        # defer_loss: may the loss's final reduction ride in the optimiser launch?  Only if nothing reads the scalar
+        # inside the step.  None = yes for the default reconstruction loss, no for a caller's loss_fn; True = the
+        # caller vouches for its loss_fn (e.g. VGAE.loss, which returns the fused scalar itself)
+        self._defer_loss = (loss_fn is None and hasattr(model, "reconstruction_loss")) if defer_loss is None \
+            else bool(defer_loss)
         self.loss_fn = loss_fn or (lambda m, g: m.reconstruction_loss(g))
         for group in optimizer.param_groups:           # Adam must keep its step counter on the device
             if "capturable" in group and not group["capturable"]:

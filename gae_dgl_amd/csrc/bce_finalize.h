@@ -72,13 +72,29 @@ __device__ __forceinline__ void bce_finalize_block(const gae_bce_tail &t, double
         if (lane == 0) { red[0][tid >> 6] = av; red[1][tid >> 6] = lv; red[2][tid >> 6] = ev; }
     }
     __syncthreads();
+    // an additive term on top (VGAE: the KL partials of gae_vgae_head_prep), summed by the first wave: lane l takes
+    // partials l, l + 64, ..., then a fixed shuffle tree
+    double extra = 0.0;
+    if (t.kl_partial != nullptr && threadIdx.x < 64) {
+        for (int64_t q = threadIdx.x; q < t.n_kl; q += 64) extra += t.kl_partial[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) extra += __shfl_down(extra, off, 64);
+    }
     if (threadIdx.x == 0) {
         double a = 0.0, l = 0.0, e = 0.0;
         for (int w = 0; w < 16; ++w) { a += red[0][w]; l += red[1][w]; e += red[2][w]; }
         double sx = 0.0;
         for (int q = 0; q < t.DP; ++q) sx += t.S[q] * t.S[t.DP + q];          // sum_{i in window} sum_j x_ij
         const double dense = 0.5 * sx + 0.5 * a + 0.69314718055994531 * (l - pad_terms);
-        *t.loss_out = float((dense + e) * inv_n2);
+        const float rec = float((dense + e) * inv_n2);
+        float total = rec;
+        if (t.kl_partial != nullptr) {
+            const float klf = float(extra * t.kl_scale);
+            if (t.kl_out) *t.kl_out = klf;
+            total = rec + klf;                  // (fp32, as the sum of the two fp32 scalars would be)
+        }
+        if (t.rec_out) *t.rec_out = rec;
+        *t.loss_out = total;
         if (t.bump_draw) *t.bump_draw += 1;     // every read of the counter (prepare) is stream-ordered before this block
     }
 }

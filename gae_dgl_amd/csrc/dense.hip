@@ -1440,6 +1440,103 @@ __global__ __launch_bounds__(256) void vgae_head_fwd_kernel(const float *__restr
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// N(0, 1) quad q of a draw: exactly normal_noise_kernel's values (same Philox stream, same Box-Muller)
+__device__ __forceinline__ void normal_quad(int64_t q, uint64_t seed, uint64_t offset, uint64_t draw, float (&z)[4])
+{
+    const uint64_t ctr = offset + uint64_t(q);
+    uint32_t c[4] = {uint32_t(ctr), uint32_t(ctr >> 32), 0x6e6f726du ^ uint32_t(draw >> 32), uint32_t(draw)};
+    uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = (float(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);     // (0, 1)
+        const float u2 = float(c[2 * h + 1] >> 8) * (1.0f / 16777216.0f);          // [0, 1)
+        const float rad = sqrtf(-2.0f * __logf(u1));
+        float sn, cs;
+        __sincosf(6.28318530717958648f * u2, &sn, &cs);
+        z[2 * h] = rad * cs; z[2 * h + 1] = rad * sn;
+    }
+}
+
+// VGAE head + everything between it and the loss's dense kernel in ONE launch (d = 16): the noise of this draw (unless
+// given), z = mu + eps exp(log sigma), the KL partial of the block, and the prepare step of the fused loss on z (no
+// dropout: Zt = z, its bf16 hi / lo, fp64 column sums per block of 64 rows) -- replaces normal_noise_kernel,
+// vgae_head_fwd_kernel and bce_prepare_kernel.  Thread = 4 consecutive elements of a row, block = 64 rows.
+__global__ __launch_bounds__(256) void vgae_head_prep_kernel(const float *__restrict__ mu, const float *__restrict__ ls,
+                                                             int64_t ldm, float *__restrict__ eps, int draw_eps,
+                                                             uint64_t seed, uint64_t offset,
+                                                             const uint64_t *__restrict__ draw_dev, int64_t n,
+                                                             float *__restrict__ z, float *__restrict__ Zt,
+                                                             unsigned short *__restrict__ Zhi,
+                                                             unsigned short *__restrict__ Zlo,
+                                                             double *__restrict__ colsum_partial,
+                                                             double *__restrict__ kl_partial)
+{
+    __shared__ double red[4][17];
+    const int64_t q = int64_t(blockIdx.x) * 256 + threadIdx.x;       // quad id: row q / 4, columns 4 (q % 4) ..
+    const int64_t i = q >> 2;
+    const int k4 = int(q & 3) * 4;
+    const bool in = i < n;
+    float ev[4] = {0.f, 0.f, 0.f, 0.f}, zv[4] = {0.f, 0.f, 0.f, 0.f};
+    double kl = 0.0;
+    if (in) {
+        const float4 m = *reinterpret_cast<const float4 *>(mu + i * ldm + k4);
+        const float4 l = *reinterpret_cast<const float4 *>(ls + i * ldm + k4);
+        if (draw_eps) {
+            normal_quad(q, seed, offset, draw_dev ? *draw_dev : 0, ev);
+            *reinterpret_cast<float4 *>(eps + q * 4) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+        } else {
+            const float4 e4 = *reinterpret_cast<const float4 *>(eps + q * 4);
+            ev[0] = e4.x; ev[1] = e4.y; ev[2] = e4.z; ev[3] = e4.w;
+        }
+        const float mm[4] = {m.x, m.y, m.z, m.w}, ll[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float sg = __expf(ll[c]);
+            zv[c] = fmaf(ev[c], sg, mm[c]);
+            kl += double(1.0f + 2.0f * ll[c] - mm[c] * mm[c] - sg * sg);
+        }
+        const float4 z4 = make_float4(zv[0], zv[1], zv[2], zv[3]);
+        *reinterpret_cast<float4 *>(z + q * 4) = z4;
+        *reinterpret_cast<float4 *>(Zt + q * 4) = z4;
+        unsigned short hi[4], lo[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            hi[c] = gae::f32_to_bf16(zv[c]);
+            lo[c] = gae::f32_to_bf16(zv[c] - gae::bf16_to_f32(hi[c]));
+        }
+        *reinterpret_cast<uint2 *>(Zhi + q * 4) = make_uint2(hi[0] | (unsigned(hi[1]) << 16), hi[2] | (unsigned(hi[3]) << 16));
+        *reinterpret_cast<uint2 *>(Zlo + q * 4) = make_uint2(lo[0] | (unsigned(lo[1]) << 16), lo[2] | (unsigned(lo[3]) << 16));
+    }
+    // column sums over the block's 64 rows (lanes with the same columns are 4 apart) and the block's KL partial,
+    // fixed order: butterfly inside the wave, then the 4 waves
+    double cs[4] = {double(zv[0]), double(zv[1]), double(zv[2]), double(zv[3])};
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cs[c] += __shfl_xor(cs[c], off, 64);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kl += __shfl_xor(kl, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[wave][lane * 4 + c] = cs[c];
+    }
+    if (lane == 0) red[wave][16] = kl;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const double t = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        colsum_partial[(int64_t(blockIdx.x) * 2 + 0) * 16 + threadIdx.x] = t;
+        colsum_partial[(int64_t(blockIdx.x) * 2 + 1) * 16 + threadIdx.x] = t;
+    }
+    if (threadIdx.x == 16) kl_partial[blockIdx.x] = ((red[0][16] + red[1][16]) + red[2][16]) + red[3][16];
+}
+
 __global__ __launch_bounds__(256) void vgae_kl_finalize_kernel(const double *__restrict__ partial, int n_partial,
                                                                double scale, float *__restrict__ kl_out)
 {
@@ -1739,6 +1836,29 @@ extern "C" int gae_vgae_head_fwd(const float *mu, const float *logstd, int64_t l
     hipLaunchKernelGGL(vgae_kl_finalize_kernel, dim3(1), dim3(256), 0, s, partial, g, -0.5 / (double(n) * double(n)),
                        kl_out);
     GAE_CHECK_LAUNCH("vgae_kl_finalize_kernel");
+    return GAE_OK;
+}
+
+// see include/gae_hip.h
+extern "C" int gae_vgae_head_prep(const float *mu, const float *logstd, int64_t ldm, float *eps, int draw_eps,
+                                  uint64_t seed, uint64_t offset, const uint64_t *draw_dev, int64_t n, int64_t d, float *z,
+                                  const gae_bce_prep *prep, double *kl_partial, int64_t kl_capacity,
+                                  int64_t *n_blocks_out, void *stream)
+{
+    GAE_REQUIRE(d == 16, GAE_E_RANGE, "gae_vgae_head_prep: the fused form takes d = 16 (got %lld): use gae_vgae_head_fwd", (long long)d);
+    GAE_REQUIRE(n > 0 && ldm >= d && ldm % 4 == 0, GAE_E_SIZE, "gae_vgae_head_prep: needs n > 0 and rows of whole 16-byte vectors");
+    GAE_REQUIRE(mu && logstd && eps && z && prep && kl_partial && n_blocks_out, GAE_E_NULL, "gae_vgae_head_prep: NULL pointer");
+    GAE_REQUIRE(gae::aligned16(mu) && gae::aligned16(logstd) && gae::aligned16(eps) && gae::aligned16(z), GAE_E_ALIGN,
+                "gae_vgae_head_prep: operands must be 16-byte aligned");
+    const int64_t blocks = (n + 63) / 64;
+    GAE_REQUIRE(prep->DP == 16 && blocks <= prep->max_blocks && blocks <= kl_capacity && prep->Zt && prep->Zhi &&
+                    prep->Zlo && prep->colsum_partial,
+                GAE_E_WORKSPACE, "gae_vgae_head_prep: layout / KL buffer too small for %lld blocks", (long long)blocks);
+    *n_blocks_out = blocks;
+    hipLaunchKernelGGL(vgae_head_prep_kernel, dim3(unsigned(blocks)), dim3(256), 0, gae::as_stream(stream), mu, logstd, ldm,
+                       eps, draw_eps, seed, offset, draw_dev, n, z, prep->Zt, prep->Zhi, prep->Zlo, prep->colsum_partial,
+                       kl_partial);
+    GAE_CHECK_LAUNCH("vgae_head_prep_kernel");
     return GAE_OK;
 }
 

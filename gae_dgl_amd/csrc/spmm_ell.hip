@@ -985,11 +985,11 @@ extern "C" int64_t gae_gcn_layer_fused_wgrad_workspace_bytes(int64_t n_rows, int
     return fused_wgrad_blocks(n_rows, F) * (F * I + F) * 4 + 256;
 }
 
-extern "C" int gae_gcn_layer_fused_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
-                                         int64_t lddy, int64_t F, const float *row_scale, const float *col_scale,
-                                         const gae_spmm_plan *plan_t, const float *W, int64_t ldw, int64_t I, float *dH,
-                                         int64_t lddh, const float *M, int64_t ldm, float *dW, float *db,
-                                         void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream)
+static int fused_wgrad_impl(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY, int64_t lddy,
+                            int64_t F, const float *row_scale, const float *col_scale, const gae_spmm_plan *plan_t,
+                            const float *W, const float *W2, int64_t w_split, int64_t ldw, int64_t I, float *dH,
+                            int64_t lddh, const float *M, int64_t ldm, float *dW, float *db, void *workspace,
+                            int64_t workspace_bytes, int64_t *layout_out, void *stream)
 {
     GAE_REQUIRE(F >= 1 && F <= 32 && I >= 1 && I <= 32, GAE_E_RANGE,
                 "gae_gcn_layer_fused_wgrad: needs 1 <= f_out <= 32 and 1 <= f_in <= 32 (got %lld, %lld)", (long long)F,
@@ -1002,16 +1002,43 @@ extern "C" int gae_gcn_layer_fused_wgrad(const int32_t *t_indptr, const int32_t 
     GAE_REQUIRE(M && workspace && workspace_bytes >= need && gae::aligned16(workspace), GAE_E_WORKSPACE,
                 "gae_gcn_layer_fused_wgrad: M / workspace missing or smaller than %lld bytes", (long long)need);
     GAE_REQUIRE(ldm >= I && ldw >= I && lddy >= F, GAE_E_SIZE, "gae_gcn_layer_fused_wgrad: leading dimension too small");
+    GAE_REQUIRE(!W2 || (w_split >= 1 && w_split < F), GAE_E_RANGE, "gae_gcn_layer_fused2_wgrad: w_split outside (0, f_out)");
     FusedSide side{dY, M, static_cast<float *>(workspace), lddy, ldm, stride, int(F), int(I)};
     // W [F][I] as nn.Linear stores it is the transposed weight of this launch: output j <- W[k][j]
     int rc = gcn_layer_fused_impl(t_indptr, t_indices, n, n, dY, lddy, nullptr, 0, F, row_scale, col_scale, plan_t, W, 1,
-                                  ldw, nullptr, I, GAE_ACT_IDENTITY, dH, lddh, nullptr, nullptr, 0, 1, stream, &side);
+                                  ldw, nullptr, I, GAE_ACT_IDENTITY, dH, lddh, W2, nullptr, W2 ? w_split : 0, 1, stream,
+                                  &side);
     if (rc || (!dW && !db)) return rc;
     gae::PartialList la{}, lb{};
     const float *part = static_cast<const float *>(workspace);
     if (dW) la = gae::PartialList{part, dW, F * I, blocks, stride, F * I, F * I, F * I};
     if (db) lb = gae::PartialList{part + F * I, db, F, blocks, stride, F, F, F};
     return gae::launch_partials_reduce(la, lb, gae::as_stream(stream));
+}
+
+extern "C" int gae_gcn_layer_fused_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
+                                         int64_t lddy, int64_t F, const float *row_scale, const float *col_scale,
+                                         const gae_spmm_plan *plan_t, const float *W, int64_t ldw, int64_t I, float *dH,
+                                         int64_t lddh, const float *M, int64_t ldm, float *dW, float *db,
+                                         void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream)
+{
+    return fused_wgrad_impl(t_indptr, t_indices, n, dY, lddy, F, row_scale, col_scale, plan_t, W, nullptr, 0, ldw, I, dH,
+                            lddh, M, ldm, dW, db, workspace, workspace_bytes, layout_out, stream);
+}
+
+// ... of gae_gcn_layer_fused2 (two identity heads on one aggregate): dY = [dY1 | dY2] ([n, f_out], f_out = d1 + d2),
+// the weight is the stack [W; W2] along its stored rows (w_split = d1 rows in W, same ldw), dW [f_out, f_in] stacked
+// alike (rows < w_split = dW1), db [f_out].
+extern "C" int gae_gcn_layer_fused2_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
+                                          int64_t lddy, int64_t F, const float *row_scale, const float *col_scale,
+                                          const gae_spmm_plan *plan_t, const float *W, const float *W2, int64_t w_split,
+                                          int64_t ldw, int64_t I, float *dH, int64_t lddh, const float *M, int64_t ldm,
+                                          float *dW, float *db, void *workspace, int64_t workspace_bytes,
+                                          int64_t *layout_out, void *stream)
+{
+    GAE_REQUIRE(W2 != nullptr, GAE_E_NULL, "gae_gcn_layer_fused2_wgrad: W2 is NULL");
+    return fused_wgrad_impl(t_indptr, t_indices, n, dY, lddy, F, row_scale, col_scale, plan_t, W, W2, w_split, ldw, I, dH,
+                            lddh, M, ldm, dW, db, workspace, workspace_bytes, layout_out, stream);
 }
 
 namespace {

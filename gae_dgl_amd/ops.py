@@ -964,6 +964,101 @@ def vgae_head_packed(ml, eps):
     return VGAEPackedHeadFunction.apply(ml, eps)
 
 
+VGAE_FUSED_LOSS = os.environ.get("GAE_VGAE_FUSED_LOSS", "1") != "0"
+
+
+class VGAEHeadLossFunction(torch.autograd.Function):
+    """The VGAE head, the KL term and the fused reconstruction loss on the PACKED heads [mu | logstd] (d = 16) as
+    three launches: gae_vgae_head_prep (noise of this draw, z, KL partials, the loss's prepare step), then the dense
+    and the edge kernel of gae_decoder_bce_prepared; the scalar rec + KL comes out of the loss's final reduction,
+    which also adds the KL partials (gae_bce_tail::kl_*) -- inside ``deferred_loss_finalize()`` as one block of the
+    optimiser launch.  Replaces gae_normal_noise, gae_vgae_head_fwd (2 launches), the prepare and final-reduction
+    launches of the loss, the draw-counter increment and the ``rec + kl`` addition: 5 launches instead of 12.
+    Returns (loss, z, kl, rec, eps); only ``loss`` carries a gradient (to ``ml``)."""
+
+    @staticmethod
+    def forward(ctx, ml, graph, eps, noise):
+        ml = _f32(_gpu(ml, "ml"), "vgae loss: ml").contiguous()
+        n, d2 = ml.shape
+        d = d2 // 2
+        dev = ml.device
+        draw = eps is None
+        seed, offset, draws = noise if noise is not None else (0, 0, None)
+        eps_t = torch.empty(n, d, dtype=torch.float32, device=dev) if draw else _f32(_gpu(eps, "eps"), "eps").contiguous()
+        z = torch.empty(n, d, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad[0]
+        nnz = graph.number_of_edges()
+        pw = (float(n) * float(n) - float(nnz)) / float(nnz)
+        indptr, indices = graph.csr()
+        t_indptr, t_indices = graph.csc() if need else (None, None)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        kl = torch.empty(1, dtype=torch.float32, device=dev)
+        rec = torch.empty(1, dtype=torch.float32, device=dev)
+        dZ = torch.empty(n, d, dtype=torch.float32, device=dev) if need else None
+        with _on_device(dev):
+            nbytes = _lib.load().gae_decoder_bce_workspace_bytes(n, n, d)
+            if nbytes < 0:
+                _lib.check(int(nbytes), "gae_decoder_bce_workspace_bytes")
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            klp = torch.empty((n + 63) // 64, dtype=torch.float64, device=dev)
+            lay = _lib.BcePrep()
+            _lib.call("gae_decoder_bce_prep_layout", n, d, _ptr(ws), ws.numel(), ctypes.byref(lay))
+            blocks = ctypes.c_int64(0)
+            if _PENDING_TAIL:
+                _flush_loss_tail()
+            _lib.call("gae_vgae_head_prep", _ptr(ml), _vp(ml.data_ptr() + 4 * d), d2, _ptr(eps_t), 1 if draw else 0,
+                      int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _ptr(draws) if draw else None, n, d, _ptr(z),
+                      ctypes.byref(lay), _ptr(klp), klp.numel(), ctypes.byref(blocks), _stream())
+            tail = _lib.BceTail()
+            _lib.call("gae_decoder_bce_defer_finalize", ctypes.byref(tail))
+            try:
+                STATS["prepared_losses"] += 1
+                _lib.call("gae_decoder_bce_prepared", None, d, n, d, _ptr(indptr), _ptr(indices), _ptr(t_indptr),
+                          _ptr(t_indices), float(pw), None, 0.0, None, int(blocks.value), _ptr(loss), _ptr(dZ), d, _ptr(ws),
+                          ws.numel(), _stream())
+            except Exception:
+                _lib.call("gae_decoder_bce_defer_finalize", None)
+                raise
+            tail.kl_partial = klp.data_ptr(); tail.n_kl = int(blocks.value); tail.kl_scale = -0.5 / (float(n) * float(n))
+            tail.kl_out = kl.data_ptr(); tail.rec_out = rec.data_ptr()
+            if draw and draws is not None:
+                tail.bump_draw = draws.data_ptr()          # the noise counter advances with the loss's last block
+            keep = (loss, ws, klp, kl, rec, draws)
+            if _DEFER_LOSS and need:
+                _PENDING_TAIL.append((tail, keep))
+            else:
+                _lib.call("gae_decoder_bce_finalize", ctypes.byref(tail), _stream())
+        ctx.save_for_backward(ml, eps_t, dZ)
+        kl0, rec0 = kl.reshape(()), rec.reshape(())
+        ctx.mark_non_differentiable(z, kl0, rec0, eps_t)     # (the returned objects themselves: autograd would otherwise
+        ctx.set_materialize_grads(False)                      #  fill a zero gradient for each of them in every backward)
+        return loss.reshape(()), z, kl0, rec0, eps_t
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        ml, eps, dZ = ctx.saved_tensors
+        n, d2 = ml.shape
+        d = d2 // 2
+        dml = torch.empty_like(ml)
+        unit = _is_unit(g)
+        dz = dZ if unit else dZ * g
+        gkl = g.reshape(1).float().contiguous()              # d loss / d kl = the upstream gradient
+        with _on_device(ml.device):
+            _lib.call("gae_vgae_head_bwd", _ptr(dz), _ptr(ml), _vp(ml.data_ptr() + 4 * d), d2, _ptr(eps), _ptr(gkl), n, d,
+                      _ptr(dml), _vp(dml.data_ptr() + 4 * d), _stream())
+        return dml, None, None, None
+
+
+def vgae_head_loss(ml, graph, eps=None, noise=None):
+    """(loss, z, kl, rec, eps) -- see VGAEHeadLossFunction; None when the fused form does not apply (d != 16, no
+    edges, fixed-capacity batch)"""
+    if (not VGAE_FUSED_LOSS or not isinstance(ml, torch.Tensor) or not ml.is_cuda or ml.dim() != 2 or ml.shape[1] != 32
+            or ml.dtype != torch.float32 or graph.number_of_edges() == 0
+            or getattr(graph, "batch_counts", None) is not None or ml.shape[0] != graph.number_of_nodes()):
+        return None
+    return VGAEHeadLossFunction.apply(ml, graph, eps, noise)
+
+
 def vgae_head(mu, logstd, eps):
     return VGAEHeadFunction.apply(mu, logstd, eps)
 
@@ -1368,6 +1463,35 @@ class GCNTwoHeadFunction(torch.autograd.Function):
         need_db = has_bias and (ctx.needs_input_grad[2] or ctx.needs_input_grad[4])
         dW1 = db1 = dW2 = db2 = dH = None
         dYc = dY.contiguous()
+        if (FUSED_LAYER_WGRAD and need_dH and need_dW and M is not None and d1 + d2 <= 32 and W1.shape[1] <= 32
+                and M.stride(1) == 1):
+            # dH, dW and db of both heads from ONE launch (gae_gcn_layer_fused2_wgrad: side work of the gather's blocks)
+            f_out, f_in = d1 + d2, W1.shape[1]
+            dev = dYc.device
+            dH = torch.empty(n, f_in, dtype=torch.float32, device=dev)
+            dW = torch.empty(f_out, f_in, dtype=torch.float32, device=dev)
+            db = torch.empty(f_out, dtype=torch.float32, device=dev) if need_db else None
+            defer = _DEFER
+            with _on_device(dev):
+                nbytes = _lib.load().gae_gcn_layer_fused_wgrad_workspace_bytes(n, f_out, f_in)
+                if nbytes < 0:
+                    _lib.check(int(nbytes), "gae_gcn_layer_fused_wgrad_workspace_bytes")
+                ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev) if defer else _workspace(nbytes, dev)
+                lay = (ctypes.c_int64 * 3)()
+                _lib.call("gae_gcn_layer_fused2_wgrad", _ptr(t_indptr), _ptr(t_indices), n, _ptr(dYc), f_out, f_out,
+                          _ptr(norm), _ptr(norm), ctypes.byref(plan_t.c), _ptr(W1), _ptr(W2), d1, W1.stride(0), f_in,
+                          _ptr(dH), f_in, _ptr(M), M.stride(0), None if defer else _ptr(dW), None if defer else _ptr(db),
+                          _ptr(ws), ws.numel(), lay, _stream())
+            if defer:
+                _PENDING[dW.data_ptr()] = (ws, ws.data_ptr(), lay[0], lay[1], f_out * f_in, f_out * f_in)
+                if db is not None:
+                    _PENDING[db.data_ptr()] = (ws, ws.data_ptr() + 4 * lay[2], lay[0], lay[1], f_out, f_out)
+            _split_pending(dW, d1)
+            dW1, dW2 = dW[:d1], dW[d1:]
+            if db is not None:
+                _split_pending(db, d1)
+                db1, db2 = db[:d1], db[d1:]
+            return dH, dW1, db1, dW2, db2, None, None
         if need_dW or need_db:
             dW, db, _ = linear_bwd_raw(dYc, None, ACT_IDENTITY, M, None, need_dW, need_db, False, f_out=d1 + d2)
             if dW is not None:

@@ -64,6 +64,19 @@ class VGAE(nn.Module):
         self._draws += 1
         return eps
 
+    def _fused_loss(self, g, ml):
+        """head + KL + reconstruction loss as ops.VGAEHeadLossFunction (noise drawn inside its first launch with the
+        stream _noise() uses), or None"""
+        if self.decoder.dropout or self.decoder.mask is not None or not ml.is_cuda:
+            return None
+        noise = None
+        if self.eps is None:
+            if self._draws is None or self._draws.device != ml.device:
+                self._draws = torch.zeros(1, dtype=torch.int64, device=ml.device)
+            seed = self.seed if self.seed is not None else int(torch.initial_seed())
+            noise = (seed, 0, self._draws)
+        return ops.vgae_head_loss(ml, g, self.eps, noise)
+
     def loss(self, g):
         """reconstruction BCE (train_inductive.py:44-48 semantics, fused) + KL"""
         h = self.shared(g, g.ndata['h'])
@@ -71,6 +84,13 @@ class VGAE(nn.Module):
         if ml is not None:                       # both heads in one launch, [mu | logstd] packed end to end
             d = ml.shape[1] // 2
             mu, logstd = ml[:, :d], ml[:, d:]
+            fused = self._fused_loss(g, ml)
+            if fused is not None:
+                loss, z, kl, rec, eps = fused
+                g.ndata['h'] = z
+                self.decoder.last_mask = None
+                self.last = {"mu": mu, "logstd": logstd, "eps": eps, "z": z, "kl": kl, "rec": rec}
+                return loss
             eps = self._noise(mu)
             z, kl = ops.vgae_head_packed(ml, eps)
         else:

@@ -392,6 +392,14 @@ int gae_gcn_layer_fused_wgrad(const int32_t *t_indptr, const int32_t *t_indices,
                               const gae_spmm_plan *plan_t, const float *W, int64_t ldw, int64_t f_in, float *dH,
                               int64_t lddh, const float *M, int64_t ldm, float *dW, float *db, void *workspace,
                               int64_t workspace_bytes, int64_t *layout_out, void *stream);
+/* ... and of gae_gcn_layer_fused2 (two identity heads on one aggregate): dY = [dY1 | dY2] ([n, f_out], f_out = d1 + d2),
+ * the weight is the stack [W; W2] along its stored rows (w_split = d1 rows come from W; both ldw apart), dW [f_out, f_in]
+ * is stacked alike (rows < w_split = dW1), db [f_out]. */
+int gae_gcn_layer_fused2_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
+                               int64_t lddy, int64_t f_out, const float *row_scale, const float *col_scale,
+                               const gae_spmm_plan *plan_t, const float *W, const float *W2, int64_t w_split,
+                               int64_t ldw, int64_t f_in, float *dH, int64_t lddh, const float *M, int64_t ldm, float *dW,
+                               float *db, void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream);
 
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16
@@ -554,6 +562,16 @@ int gae_decoder_bce_prepared(float *mask, int64_t ldz, int64_t n, int64_t d, con
                              int64_t n_prep_blocks, float *loss_out, float *dZ, int64_t lddz, void *workspace,
                              int64_t workspace_bytes, void *stream);
 
+/* The VGAE head AND everything between it and the dense kernel of the loss in one launch (d = 16): eps of this draw
+ * (draw_eps != 0: generated with gae_normal_noise's stream -- seed, offset, *draw_dev -- and WRITTEN to eps [n, d];
+ * draw_eps == 0: eps is read), z = mu + eps exp(logstd) [n, d], the KL term as one partial per block of 64 rows in
+ * kl_partial (capacity kl_capacity >= ceil(n / 64) doubles; scale -0.5 / n^2: put both into gae_bce_tail::kl_*), and
+ * the prepare step of gae_decoder_bce on z without dropout (prep: gae_decoder_bce_prep_layout; then
+ * gae_decoder_bce_prepared with *n_blocks_out).  mu / logstd: rows ldm floats apart (packed [mu | logstd]: ldm = 2 d). */
+int gae_vgae_head_prep(const float *mu, const float *logstd, int64_t ldm, float *eps, int draw_eps, uint64_t seed,
+                       uint64_t offset, const uint64_t *draw_dev, int64_t n, int64_t d, float *z, const gae_bce_prep *prep,
+                       double *kl_partial, int64_t kl_capacity, int64_t *n_blocks_out, void *stream);
+
 /* Deferred final reduction.  The last launch of gae_decoder_bce* adds the per-block partial sums to the scalar; the
  * backward pass does not read that scalar, so a training step may run the reduction later, next to other work:
  *   gae_decoder_bce_defer_finalize(&tail)  arms the calling thread: its NEXT gae_decoder_bce / _rows / _padded call
@@ -572,6 +590,11 @@ typedef struct gae_bce_tail {
     float *loss_out;                                  /* (device) */
     uint64_t *bump_draw;                              /* draw counter to advance, or NULL               (device) */
     const double *scal;                               /* device-side {pos_weight, 1 / N^2, pad pairs} of a padded batch, or NULL */
+    /* optional additive term (set by the caller after the loss call filled the rest; all zero = none): the block also
+     * adds kl_partial[0 .. n_kl) (doubles), scales the sum, and writes loss_out = rec + kl, kl_out, rec_out -- the KL
+     * term of a VGAE (gae_vgae_head_prep) without launches of its own */
+    const double *kl_partial; int64_t n_kl; double kl_scale;
+    float *kl_out, *rec_out;                          /* may be NULL */
 } gae_bce_tail;
 int gae_decoder_bce_defer_finalize(gae_bce_tail *tail_out);
 int gae_decoder_bce_finalize(const gae_bce_tail *tail, void *stream);

@@ -217,3 +217,80 @@ def test_prepare_epilogue_variants(case):
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0]) and torch.equal(res[0][2], res[1][2])
     for a, b in zip(res[0][1], res[1][1]):
         assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-6)
+
+
+def test_vgae_head_kl_and_loss_in_three_launches():
+    """ops.VGAEHeadLossFunction (noise + head + KL partials + loss prepare in one launch, KL added by the loss's final
+    reduction) against the launch-by-launch path: same noise, z bit for bit; KL / loss / gradients within fp32 rounding;
+    the noise counter advances once per loss"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, workloads as W
+    from gae_dgl_amd.vgae import VGAE
+    n, src, dst, X = W.citation_graph("cora", seed=0)
+    g = G.DGLGraph((src, dst), num_nodes=n).to(DEV)
+    Xd = ops.pad_rows(torch.from_numpy(X).to(DEV))
+    out = {}
+    for fused in (True, False):
+        ops.VGAE_FUSED_LOSS = fused
+        try:
+            torch.manual_seed(0)
+            model = VGAE(X.shape[1], [32, 16], seed=5).to(DEV)
+            vals = []
+            for _ in range(2):                               # two draws: the counter must advance in both forms
+                g.ndata['h'] = Xd
+                before = ops.STATS["prepared_losses"]
+                loss = model.loss(g)
+                assert ops.STATS["prepared_losses"] - before == (1 if fused else 0)
+                model.zero_grad(set_to_none=True)
+                ops.backward(loss, list(model.parameters()))
+                torch.cuda.synchronize()
+                vals.append((float(loss.detach()), {k: v.detach().clone() for k, v in model.last.items()},
+                             [p.grad.clone() for p in model.parameters()]))
+            assert int(model._draws) == 2
+            out[fused] = vals
+        finally:
+            ops.VGAE_FUSED_LOSS = True
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a[1]["eps"], b[1]["eps"]) and torch.equal(a[1]["z"], b[1]["z"])
+        assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0])
+        assert abs(float(a[1]["kl"]) - float(b[1]["kl"])) <= 2e-6 * abs(float(b[1]["kl"]))
+        assert abs(float(a[1]["rec"]) - float(b[1]["rec"])) <= 2e-6 * abs(float(b[1]["rec"]))
+        assert abs(float(a[1]["rec"]) + float(a[1]["kl"]) - a[0]) <= 1e-6 * abs(a[0])
+        for ga, gb in zip(a[2], b[2]):
+            assert float((ga - gb).abs().max()) <= 2e-6 * max(float(gb.abs().max()), 1e-6)
+    assert not torch.equal(out[True][0][1]["eps"], out[True][1][1]["eps"])
+
+
+def test_vgae_captured_step_with_the_loss_tail_in_adam():
+    """CapturedTrainStep(defer_loss=True): the VGAE loss (rec + KL) is finished by the optimiser launch -- losses and
+    weights equal the eager steps bit for bit"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, workloads as W
+    from gae_dgl_amd.capture import CapturedTrainStep
+    from gae_dgl_amd.optim import Adam
+    from gae_dgl_amd.vgae import VGAE
+    n, src, dst, X = W.citation_graph("cora", seed=0)
+    g = G.DGLGraph((src, dst), num_nodes=n).to(DEV)
+    Xd = ops.pad_rows(torch.from_numpy(X).to(DEV))
+    runs = {}
+    for mode in ("eager", "captured"):
+        torch.manual_seed(0)
+        model = VGAE(X.shape[1], [32, 16], seed=5).to(DEV)
+        opt = Adam(model.parameters(), lr=1e-2)
+        params = list(model.parameters())
+        if mode == "eager":
+            losses = []
+            for _ in range(7):
+                g.ndata['h'] = Xd
+                loss = model.loss(g)
+                opt.zero_grad(set_to_none=True); ops.backward(loss, params); opt.step()
+                model.last = {}
+                losses.append(float(loss.detach()))
+        else:
+            step = CapturedTrainStep(model, opt, g, Xd, loss_fn=lambda m, gg: m.loss(gg), warmup=2, defer_loss=True)
+            losses = [None, None] + [float(step()) for _ in range(5)]
+        runs[mode] = (losses, [p.detach().clone() for p in params])
+    assert runs["eager"][0][2:] == runs["captured"][0][2:]
+    for a, b in zip(runs["eager"][1], runs["captured"][1]):
+        assert torch.equal(a, b)
+    assert not ops._PENDING_TAIL
