@@ -63,10 +63,10 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
     const float bc1 = float(1.0 - b1t);
     const float bc2_sqrt = float(sqrt(1.0 - b2t));
     const float step_size = lr / bc1;
-    auto update = [&](int64_t e, float g) {
-        const float p = t.param[e];
+    // (p, m, v are passed in: the deferred branches request them BEFORE they add up the partial sums -- the two round
+    //  trips overlap instead of following each other)
+    auto update = [&](int64_t e, float g, float p, float m, float v) {
         if (weight_decay != 0.f) g = fmaf(weight_decay, p, g);
-        float m = t.exp_avg[e], v = t.exp_avg_sq[e];
         m = fmaf(g - m, 1.0f - beta1, m);                          // lerp(m, g, 1 - beta1)
         v = fmaf(beta2, v, (1.0f - beta2) * g * g);
         const float denom = sqrtf(v) / bc2_sqrt + eps;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t e = base + q;
-            if (e < t.n) update(e, t.grad[e]);
+            if (e < t.n) update(e, t.grad[e], t.param[e], t.exp_avg[e], t.exp_avg_sq[e]);
         }
     } else {
         // ---- deferred reduction: the gradient is still a list of partial sums (what gae_xw_wgrad_partials /
@@ -98,11 +98,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
                 const unsigned e = unsigned(lb) * chunk + q * 256u + threadIdx.x;
                 const unsigned ec = e < n32 ? e : 0u;
                 const unsigned r = ec / row_len, c = ec - r * row_len;
+                const float p0 = t.param[ec], m0 = t.exp_avg[ec], v0 = t.exp_avg_sq[ec];
                 const float g = gae::sum_partials(t.partials + int64_t(r) * t.row_pitch + c, t.n_partials,
                                                   t.partial_stride, 0, 1);
                 if (e < n32) {
                     t.grad[e] = g;
-                    update(e, g);
+                    update(e, g, p0, m0, v0);
                 }
             }
         } else {
@@ -110,11 +111,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
             const int lane = threadIdx.x % 64;
             const unsigned ec = e < n32 ? e : 0u;
             const unsigned r = ec / row_len, c = ec - r * row_len;
+            const float p0 = t.param[ec], m0 = t.exp_avg[ec], v0 = t.exp_avg_sq[ec];
             const float g = gae::sum_partials(t.partials + int64_t(r) * t.row_pitch + c, t.n_partials, t.partial_stride,
                                               lane, 64);
             if (e < n32 && lane == 0) {
                 t.grad[e] = g;
-                update(e, g);
+                update(e, g, p0, m0, v0);
             }
         }
     }
