@@ -386,6 +386,9 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
         }
     }
     double pz_sum[JPL_K];                                      // (prepare epilogue) this lane's Zt values, for the column sums
+    float pz_m[JPL_K];                                         // ... and its dropout multipliers
+#pragma unroll
+    for (int q = 0; q < JPL_K; ++q) pz_m[q] = 1.f;
 #pragma unroll
     for (int q = 0; q < JPL_K; ++q) pz_sum[q] = 0.0;
     // direct form of the side work (at most 4 output tiles: one per wave): every lane requests the MFMA operands of
@@ -466,11 +469,51 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
         // ---- the table row: slot q * LP16 + (lane % LP16) sits in register q (every 16-lane row of a wide group
         //      holds its own copy: the re-read is served by the same L1 line)
         int32_t first = -1, last = -1;
+        int32_t jraw[NREG];
 #pragma unroll
         for (int q = 0; q < NREG; ++q) {
             const int s = q * LP16 + (lane & (LP16 - 1));
-            int32_t j = -1;
-            if (row[r] < a.n_rows && s < W) j = a.ell[row[r] * W + s];
+            jraw[q] = -1;
+            if (row[r] < a.n_rows && s < W) jraw[q] = a.ell[row[r] * W + s];
+        }
+        if constexpr (EPI_J == 16) {
+            // (prepare epilogue) this lane's dropout multipliers, computed while the table row is on its way: the
+            // Philox rounds would otherwise sit at the very end of the kernel, behind the gather
+            if (a.pz_t != nullptr && r == 0) {
+                const bool draw = a.pz_drop_p > 0.f;
+                uint32_t c[4] = {0u, 0u, 0u, 0u};
+                int64_t c_of = -1;                                        // the counter c belongs to
+#pragma unroll
+                for (int q = 0; q < JPL_K; ++q) {
+                    const int o = lig * JPL_K + q;
+                    float m = 1.f;
+                    if (row[r] < a.n_rows && o < a.J) {
+                        if (row[r] >= pz_n_valid) {       // padding row of a fixed-capacity batch: zero row of Zt, zero mask
+                            m = 0.f;
+                            if (draw) a.pz_mask[row[r] * a.pz_ldmask + o] = 0.f;
+                        } else if (draw) {
+                            // the Philox stream of gae_dropout_mask: element e = i d + k of the [n, d] mask; a lane's
+                            // outputs are adjacent elements and mostly share one counter (4 per draw)
+                            const int64_t e = row[r] * a.J + o;
+                            if ((e >> 2) != c_of) {
+                                c_of = e >> 2;
+                                gae::philox4x32_10(a.pz_offset + uint64_t(c_of), pz_draw_idx, a.pz_seed, c);
+                            }
+                            const uint32_t bits = (e & 2) ? ((e & 1) ? c[3] : c[2]) : ((e & 1) ? c[1] : c[0]);
+                            m = gae::dropout_multiplier(bits, a.pz_drop_p, a.pz_drop_scale);
+                            a.pz_mask[row[r] * a.pz_ldmask + o] = m;
+                        } else if (a.pz_mask) {
+                            m = a.pz_mask[row[r] * a.pz_ldmask + o];
+                        }
+                    }
+                    pz_m[q] = m;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NREG; ++q) {
+            const int s = q * LP16 + (lane & (LP16 - 1));
+            const int32_t j = jraw[q];
             off[r][q] = unsigned(j) < a.n_cols ? unsigned(j) * a.ldh_bytes : a.empty_off;   // empty / marker -> behind the buffer
             if (SCALED) coff[r][q] = min(unsigned(j), a.n_cols) * 4u;
             valid[r][q] = __builtin_amdgcn_ballot_w64(j >= 0);
@@ -592,39 +635,11 @@ slots_done:
             }
             if constexpr (EPI_J == 16) {
                 if (a.pz_t != nullptr) {                                  // block-uniform
-                    // rows >= counts[0] of a fixed-capacity batch are padding: zero rows of Zt, zero mask
-                    const int64_t n_valid = pz_n_valid;
-                    const bool draw = a.pz_drop_p > 0.f;
-                    const uint64_t draw_idx = pz_draw_idx;
                     const bool in = row[r] < a.n_rows;
-                    uint32_t c[4] = {0u, 0u, 0u, 0u};
-                    int64_t c_of = -1;                                    // the counter c belongs to
 #pragma unroll
                     for (int q = 0; q < JPL; ++q) {
                         const int o = lig * JPL + q;
-                        const bool col = o < a.J;
-                        float v = 0.f;
-                        if (in && col) {
-                            float m = 1.f;
-                            if (row[r] >= n_valid) {
-                                m = 0.f;
-                                if (draw) a.pz_mask[row[r] * a.pz_ldmask + o] = 0.f;
-                            } else if (draw) {
-                                // the Philox stream of gae_dropout_mask: element e = i d + k of the [n, d] mask; a
-                                // lane's outputs are adjacent elements and mostly share one counter (4 per draw)
-                                const int64_t e = row[r] * a.J + o;
-                                if ((e >> 2) != c_of) {
-                                    c_of = e >> 2;
-                                    gae::philox4x32_10(a.pz_offset + uint64_t(c_of), draw_idx, a.pz_seed, c);
-                                }
-                                const uint32_t bits = (e & 2) ? ((e & 1) ? c[3] : c[2]) : ((e & 1) ? c[1] : c[0]);
-                                m = gae::dropout_multiplier(bits, a.pz_drop_p, a.pz_drop_scale);
-                                a.pz_mask[row[r] * a.pz_ldmask + o] = m;
-                            } else if (a.pz_mask) {
-                                m = a.pz_mask[row[r] * a.pz_ldmask + o];
-                            }
-                            v = yv[q] * m;
-                        }
+                        const float v = (in && o < a.J) ? yv[q] * pz_m[q] : 0.f;      // (multipliers: see the table load)
                         if (in) {
                             a.pz_t[row[r] * 16 + o] = v;
                             const unsigned short hi = gae::f32_to_bf16(v);
