@@ -547,6 +547,7 @@ HOMED_HOT_COLUMNS = 1 << 20  # hot tags of the pinned part (RMAT s24: 128 k 5.66
 
 
 HOMED_COLUMN_SWEEP = True    # order the pinned chunks of a home by their first column (see homed_plan_parts)
+HOMED_SEGMENT = None         # edges per pinned chunk (None: the plan's segment length)
 
 
 def column_home(cols):
@@ -660,7 +661,7 @@ def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_
             vh_edges = int(deg64[deg64 > HOMED_MIN_DEGREE].sum())
             if homed or vh_edges >= HOMED_MIN_EDGES:
                 nc = int(n_cols) if n_cols is not None else max(n, int(indices.max()) + 1)
-                parts = homed_plan_parts(indptr, indices, nc, segment=segment)
+                parts = homed_plan_parts(indptr, indices, nc, segment=HOMED_SEGMENT or segment)
         if parts is not None:
             # the segment lists then hold the rows with threshold < degree <= HOMED_MIN_DEGREE only (torch-built:
             # gae_spmm_plan_fill has no upper bound)
