@@ -1,6 +1,6 @@
 """Datasets for the inductive entry point.
 
-``MolDataset`` mirrors gae_dgl/dataset.py:3-12 (a list wrapper for DataLoader).
+``MolDataset`` keeps the interface of gae_dgl/dataset.py:3-12 (a list of graphs for the DataLoader).
 
 ``DeviceGraphDataset`` is the MI355X-native replacement of the pickled list of
 DGLGraphs (gae_dgl/prepare_data.py:102-103, gae_dgl/train_inductive.py:76-85):
@@ -84,16 +84,30 @@ def featuriser_contract_errors(graph_ptr, src, dst, feat, max_report=5):
     return errs
 
 
-class MolDataset(Dataset):
-    def __init__(self, graphs):
-        self.graphs = graphs
-        print('Dataset includes {:d} graphs'.format(len(graphs)))
+class SequenceDataset(Dataset):
+    """any indexable collection as a map-style torch Dataset"""
+
+    def __init__(self, items):
+        self.items = items
 
     def __len__(self):
-        return len(self.graphs)
+        return len(self.items)
 
-    def __getitem__(self, item):
-        return self.graphs[item]
+    def __getitem__(self, index):
+        return self.items[index]
+
+
+class MolDataset(SequenceDataset):
+    """the reference's dataset class (gae_dgl/dataset.py:3-12): the list of molecule graphs handed to the DataLoader of
+    train_inductive.py:84-85, under the attribute name ``graphs``; reports its size like the reference does"""
+
+    def __init__(self, graphs):
+        super().__init__(graphs)
+        print(f"Dataset includes {len(graphs):d} graphs")
+
+    @property
+    def graphs(self):
+        return self.items
 
 
 class GraphView:

@@ -1131,7 +1131,11 @@ def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, 
             nbytes = _lib.load().gae_decoder_bce_workspace_bytes(n, n_local, d)
             if nbytes < 0:
                 _lib.check(int(nbytes), "gae_decoder_bce_workspace_bytes")
-            ws = _workspace(nbytes, dev)
+            # a deferred final reduction reads the partial sums in the optimiser launch: they must not sit in the
+            # per-stream scratch cache, which any launch in between (dM of gae_linear_bwd, a weight-gradient
+            # reduction) may hand out again
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev) if (_DEFER_LOSS and defer_ok and want_grad) \
+                else _workspace(nbytes, dev)
 
         def launch():
             tail = None
@@ -1260,7 +1264,8 @@ def gcn_layer_fused_raw(indptr, indices, H, n_rows, plan, W, bias, act, row_scal
 # ``decoder_bce(..., prepared=req.token)`` -- the loss then starts at its dense kernel (one kernel node fewer per step).
 FUSE_LOSS_PREPARE = os.environ.get("GAE_FUSE_LOSS_PREPARE", "1") != "0"
 _PREP_REQ = None
-STATS = {"prepared_losses": 0}      # losses that started at the dense kernel (tests read this)
+STATS = {"prepared_losses": 0,      # losses that started at the dense kernel (tests read this)
+         "xw_fwd": 0, "xw_wgrad": 0}  # launches of the one-pass layer-1 kernels (transform-first order)
 
 
 class loss_prepare_request:
@@ -1526,6 +1531,11 @@ def gcn_two_heads(graph, H, lin1, lin2, use_norm=False):
         return None
     if not gcn_layer_fused_usable(Hc, d1 + d2, plan) or not _table_only(plan_t) or d1 + d2 > FUSED_LAYER_MAX_IN:
         return None
+    # the backward is gae_gcn_layer_fused2(_wgrad) on the CSR of A^T with dML [n, d1 + d2] as the gathered operand and
+    # the heads' INPUT width as its output: rows of whole 16-byte vectors and <= 32 outputs, or the two separate
+    # layers (which have their own fallbacks) must run instead
+    if lin1.weight.shape[1] > FUSED_LAYER_MAX_OUT or (d1 + d2) % 4 != 0:
+        return None
     bd = graph.block_diag
     if bd is not None and bd.usable(Hc, Hc.shape[1], Hc.stride(0), Hc.stride(0)):
         return None
@@ -1575,6 +1585,7 @@ def xw_fwd_raw(X, W, b, act, keep_splits=False):
     f_out = W.shape[0]
     code = _dtype_code(X)
     lib = _lib.load()
+    STATS["xw_fwd"] += 1
     splits = int(lib.gae_xw_fwd_splits(n, f_in, f_out, code)) if keep_splits else 1
     keep = keep_splits and splits > 1
     with _on_device(X.device):
@@ -1607,6 +1618,7 @@ def xw_wgrad_raw(X, G, Gmask, D, Dmask, f_out, need_dW=True, need_db=True):
     n, f_in = X.shape
     code = _dtype_code(X)
     dev = X.device
+    STATS["xw_wgrad"] += 1
     G, ldg = _rowmajor(_f32(G, "xw_wgrad: G"), "G")
     ldgm = ldd = lddm = 0
     if Gmask is not None:
@@ -1707,7 +1719,12 @@ class GCNTransformFirstFunction(torch.autograd.Function):
         norm = graph.norm() if use_norm else None
         n = graph.number_of_nodes()
         # (a long f_in is split over thread blocks: the aggregation adds the partial rows itself, no reduction launch)
-        P, _ = xw_fwd_raw(H, W, None, ACT_IDENTITY, keep_splits=W.shape[0] % 4 == 0)
+        # (gae_spmm_csr_epilogue addresses the stack of partials through one raw buffer: splits * n * f_out * 4 < 2^27 bytes;
+        # larger operands let gae_xw_fwd reduce the splits itself)
+        f_out = W.shape[0]
+        splits = int(_lib.load().gae_xw_fwd_splits(H.shape[0], H.shape[1], f_out, _dtype_code(H))) if f_out % 4 == 0 else 1
+        P, _ = xw_fwd_raw(H, W, None, ACT_IDENTITY,
+                          keep_splits=f_out % 4 == 0 and splits > 1 and splits * H.shape[0] * f_out * 4 < (1 << 27))
         Y = spmm_epilogue_raw(indptr, indices, P, n, graph.spmm_plan(False), b, act, None, norm, norm)
         ctx.act, ctx.has_bias = act, b is not None
         ctx.bwd = (graph.csc(), n, norm, graph.spmm_plan(True))

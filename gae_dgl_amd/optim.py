@@ -60,9 +60,18 @@ class Adam(torch.optim.Optimizer):
             seen = [float(state_dict["state"][i]["step"]) for i in group["params"]
                     if i in state_dict["state"] and "step" in state_dict["state"][i]]
             steps.append(int(max(seen)) if seen else 0)
+        # moment tensors that exist stay where they are, too: a captured HIP graph has their addresses baked in, so the
+        # loaded values are copied INTO them (torch.optim.Optimizer.load_state_dict would bind new tensors, and the
+        # replays would go on updating the old ones with the checkpoint's step count)
+        old = {p: (st.get("exp_avg"), st.get("exp_avg_sq")) for p, st in self.state.items()}
         super().load_state_dict(state_dict)
-        for st in self.state.values():
+        for p, st in self.state.items():
             st.pop("step", None)
+            for key, t_old in zip(("exp_avg", "exp_avg_sq"), old.get(p, (None, None))):
+                t_new = st.get(key)
+                if t_old is not None and t_new is not None and t_new is not t_old and t_old.shape == t_new.shape:
+                    t_old.copy_(t_new)
+                    st[key] = t_old
         # counters that exist stay where they are (a captured HIP graph holds their addresses): set them to the
         # checkpoint's count and invalidate their cached beta^t (zeros = "recompute with pow", see optim.hip);
         # counters of groups that have not stepped yet are created at the resume point by step()

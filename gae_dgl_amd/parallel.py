@@ -269,7 +269,7 @@ class ShardedGraph:
             return self.allgather_rows(h_local)
         a = self._a2a[which]
         nb = p.n_before[which]          # rows owned by lower ranks arrive first (ascending global id)
-        if h_local.is_cuda and dist.get_backend(self.group) == "nccl":
+        if h_local.is_cuda and h_local.dtype == torch.float32 and dist.get_backend(self.group) == "nccl":
             # HIP pack kernels + receive views: the rows to send go straight into the send buffer, the own rows
             # straight into their slot of the assembled buffer, and every peer's rows land where the local CSR
             # indexes them -- no ATen index_select / cat between two products
@@ -306,8 +306,8 @@ class ShardedGraph:
             full, works = self._allgather_async(h_local)
             return full, (lambda: [w.wait() for w in works])
         a = self._a2a[which]
-        if h_local.is_cuda:
-            from . import ops
+        if h_local.is_cuda and h_local.dtype == torch.float32:      # (gae_rows_pack moves fp32 rows; bf16-stored features
+            from . import ops                                         #  take the index_select below)
             send = ops.rows_pack(h_local, a["send_idx"])             # HIP gather straight into the send buffer
         else:
             send = h_local.index_select(0, a["send_idx"].to(h_local.device))

@@ -8,7 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ["tiny", "sym200", "deep3", "single", "mol8"]
+# wide300 / wide2k (round 4): f_in >= 193 -> the default GAE(...) runs layer 1 through gae_xw_fwd / gae_spmm_csr_epilogue /
+# gae_xw_wgrad (transform-first order); the vectors are the reference's own act((A H) W^T + b)
+CASES = ["tiny", "sym200", "deep3", "single", "mol8", "wide300", "wide2k"]
+WIDE_CASES = ["wide300", "wide2k"]
 
 
 def pytest_configure(config):

@@ -150,6 +150,31 @@ def build_cases():
     return cases, mols
 
 
+def build_wide_cases():
+    """round 4: inputs WIDE enough (f_in >= 193, f_out <= 32) for the layer order the build now runs by default on such
+    layers, act(A (H W^T) + b) -- pinned here by the reference's own act((A H) W^T + b) (gae.py:26-31).  Drawn from a
+    generator of their own AFTER everything above, so the earlier fixtures regenerate bit-identically."""
+    rng = np.random.default_rng(4)
+    cases = {}
+    # symmetric graph, bag-of-words-like rows (row-normalised, ~3 % non-zeros), citation widths [32, 16]
+    n, f = 384, 300
+    a = rng.integers(0, n, 900); b = rng.integers(0, n, 900)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    X = np.where(rng.random((n, f)) < 0.03, rng.random((n, f)) + 0.05, 0.0).astype(np.float32)
+    X /= np.maximum(X.sum(1, keepdims=True), 1e-6)
+    cases["wide300"] = dict(n=n, src=np.concatenate([a, b]), dst=np.concatenate([b, a]), X=X.astype(np.float32),
+                            hidden=[32, 16])
+    # directed multigraph (duplicate edges, self-loops, zero-in-degree nodes), signed dense-ish rows, f_in ~ 2000
+    n, f = 256, 2003
+    src = rng.integers(0, n, 1400); dst = rng.integers(0, n - 16, 1400)      # the last 16 nodes receive nothing
+    src[:40] = src[40:80]; dst[:40] = dst[40:80]                              # 40 duplicated edges
+    src[80:90] = dst[80:90]                                                   # 10 self-loops
+    X = np.where(rng.random((n, f)) < 0.02, rng.standard_normal((n, f)), 0.0).astype(np.float32)
+    cases["wide2k"] = dict(n=n, src=src.astype(np.int64), dst=dst.astype(np.int64), X=X, hidden=[32, 16])
+    return cases
+
+
 def run_case(ref, name, n, src, dst, X, hidden, seed):
     torch.manual_seed(seed)
     model = ref.GAE(X.shape[1], hidden)
@@ -238,6 +263,8 @@ def main():
         per[f"g{i}/n"] = np.int64(n); per[f"g{i}/src"] = s; per[f"g{i}/dst"] = d; per[f"g{i}/X"] = X
     np.savez_compressed(os.path.join(OUT, "mol8_parts.npz"), n_graphs=np.int64(len(mols)), **per)
     run_case(ref, "mol8", bg.n, bg.src.numpy(), bg.dst.numpy(), bg.ndata["h"].numpy(), [32, 16], seed=99)
+    for i, (name, c) in enumerate(build_wide_cases().items()):
+        run_case(ref, name, c["n"], c["src"], c["dst"], c["X"], c["hidden"], seed=200 + i)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,95 @@
+"""Round-4 regression tests for the ADVICE findings of round 3 (GPU side)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def sym_graph(rng, n, e):
+    import gae_dgl_amd as G
+    a = rng.integers(0, n, e); b = rng.integers(0, n, e)
+    g = G.DGLGraph((np.concatenate([a, b]), np.concatenate([b, a])), num_nodes=n).to(DEV)
+    return g, np.concatenate([a, b]).astype(np.int64), np.concatenate([b, a]).astype(np.int64)
+
+
+@pytest.mark.parametrize("hidden,F_in", [((64, 5), 20), ((64, 16), 40), ((32, 6), 24), ((48, 8), 33)])
+def test_vgae_heads_with_shapes_the_fused_backward_cannot_run(hidden, F_in):
+    """the packed-heads launch was taken on forward shapes alone; its backward needs the heads'
+    input width <= 32 and 2 d a multiple of 4.  Such models must train (through the two separate layers) and agree
+    with the oracle's VGAE restatement."""
+    from gae_dgl_amd.vgae import VGAE
+    from oracle import gae_oracle as O
+    rng = np.random.default_rng(hidden[0] + hidden[1])
+    n = 300
+    g, src, dst = sym_graph(rng, n, 700)
+    X = rng.standard_normal((n, F_in)).astype(np.float32)
+    torch.manual_seed(1)
+    model = VGAE(F_in, hidden).to(DEV)
+    eps = torch.from_numpy(rng.standard_normal((n, hidden[1])).astype(np.float32)).to(DEV)
+    model.eps = eps
+    g.ndata['h'] = torch.from_numpy(X).to(DEV)
+    loss = model.loss(g)
+    loss.backward()                                          # raised GaeHipError before the guard
+    grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+    assert all(torch.isfinite(v).all() for v in grads.values())
+    # oracle (Kipf & Welling restatement; unpinned by construction) on the same eps
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    ip, ix = O.csr_from_coo(src, dst, n)
+    mu, ls, z = O.vgae_forward(ip, ix, torch.from_numpy(X), P["shared.apply_mod.linear.weight"],
+                               P["shared.apply_mod.linear.bias"], P["mu_head.apply_mod.linear.weight"],
+                               P["mu_head.apply_mod.linear.bias"], P["logstd_head.apply_mod.linear.weight"],
+                               P["logstd_head.apply_mod.linear.bias"], eps.cpu())
+    adj = O.dense_adjacency(src, dst, n)
+    ref = O.bce_with_logits_mean(z @ z.t(), adj, O.pos_weight_of(adj)) + O.vgae_kl(mu, ls)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+    for k in grads:
+        r = P[k].grad.double()
+        assert float((grads[k].double() - r).abs().max() / r.abs().max().clamp(min=1e-12)) < 2e-4, k
+
+
+def test_adam_checkpoint_loaded_after_capture_matches_eager():
+    """load_state_dict() on an optimiser whose step is already captured must land in the tensors
+    the graph holds (moments AND step counters): replays after the load == eager steps from the same checkpoint"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import capture, optim
+    rng = np.random.default_rng(3)
+    n, F_in = 500, 24
+    g, _, _ = sym_graph(rng, n, 1500)
+    X = torch.from_numpy(rng.standard_normal((n, F_in)).astype(np.float32)).to(DEV)
+
+    def make(seed=5):
+        torch.manual_seed(seed)
+        m = G.GAE(F_in, [32, 16]).to(DEV)
+        m.decoder.dropout = 0.0
+        return m
+
+    # checkpoint after 4 eager steps
+    m0 = make(); o0 = optim.Adam(m0.parameters(), lr=1e-2)
+    for _ in range(4):
+        g.ndata['h'] = X
+        loss = m0.reconstruction_loss(g); o0.zero_grad(); loss.backward(); o0.step()
+    ck_model = {k: v.clone() for k, v in m0.state_dict().items()}
+    ck_opt = o0.state_dict()
+    # eager continuation: 3 more steps
+    want = []
+    for _ in range(3):
+        g.ndata['h'] = X
+        loss = m0.reconstruction_loss(g); o0.zero_grad(); loss.backward(); o0.step()
+        want.append(float(loss.detach()))
+    # a captured step that has already run on another trajectory, then loads the checkpoint
+    m1 = make(seed=9); o1 = optim.Adam(m1.parameters(), lr=1e-2)
+    step = capture.CapturedTrainStep(m1, o1, g, X, warmup=2)
+    step(); step()
+    with torch.no_grad():
+        for k, v in m1.state_dict().items():
+            v.copy_(ck_model[k])
+    o1.load_state_dict(ck_opt)
+    got = [float(step()) for _ in range(3)]
+    np.testing.assert_allclose(got, want, rtol=2e-5)
+    for k, v in m1.state_dict().items():
+        ref = m0.state_dict()[k]
+        assert float((v - ref).abs().max() / ref.abs().max().clamp(min=1e-6)) < 1e-4, k
+    assert o1.steps_taken() == 7
