@@ -38,6 +38,17 @@ class _defer:
             cm.__exit__(*exc)
 
 
+def _state_outside_capture(opt):
+    """optimiser state (moments, step counters) must exist BEFORE the capture: created lazily inside it, it would sit in
+    the graph's private pool and be zero-filled again by every replay.  The library's Adam creates it on request; any
+    other optimiser must have taken a step (warm-up or the caller's own eager steps)."""
+    from .optim import Adam
+    if isinstance(opt, Adam):
+        opt.materialize_state()
+    elif any(p.requires_grad and len(opt.state.get(p, {})) == 0 for g in opt.param_groups for p in g["params"]):
+        raise ValueError("capture needs the optimiser's state in place: run at least one step (warmup >= 1) before it")
+
+
 FUSED_COLLATE_MAX_GRAPHS = 1024   # batches up to this size collate in one launch (gae_batch_gather_next); 0 = never
 DEFER_GRAD_REDUCTIONS = True      # False: captured steps keep the separate reduction launches (experiments)
 DEFER_LOSS_FINALIZE = os.environ.get("GAE_DEFER_LOSS_FINALIZE", "1") != "0"   # False: the fused loss keeps its own final-reduction launch (experiments)
@@ -72,6 +83,10 @@ class CapturedTrainStep:
             for _ in range(warmup):
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
+        _state_outside_capture(optimizer)
+        for m in model.modules():          # device-side draw counters (dropout mask, VGAE noise): same rule
+            if getattr(m, "_draws", False) is None:
+                m._draws = torch.zeros(1, dtype=torch.int64, device=features.device)
         self._capture()
 
     def _hyper(self):

@@ -33,6 +33,26 @@ class Adam(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st["exp_avg"], st["exp_avg_sq"]
 
+    def materialize_state(self):
+        """create the moments and the device-side step counters of every parameter NOW.  A HIP-graph capture must
+        find them in place: state that step() creates lazily INSIDE a capture lives in the graph's private pool and
+        its zero fill becomes a captured node -- every replay would restart the moments and the step count at zero."""
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.requires_grad]
+            for p in ps:
+                self._moments(p)
+            for c in range((len(ps) + _lib.ADAM_MAX_TENSORS - 1) // _lib.ADAM_MAX_TENSORS):
+                self._counter(gi, c, ps[0].device)
+
+    def _counter(self, gi, chunk, dev):
+        key = (gi, chunk)
+        if key not in self._counters:
+            self._counters[key] = torch.zeros(_lib.ADAM_STATE_WORDS, dtype=torch.int64, device=dev)
+            resume = getattr(self, "_resume_steps", None)
+            if resume is not None and gi < len(resume):
+                self._counters[key][0] = resume[gi]
+        return self._counters[key]
+
     def steps_taken(self, group=0, chunk=0):
         """number of steps the device-side counter of a parameter group has seen (host read-back)"""
         c = self._counters.get((group, chunk))
@@ -112,11 +132,7 @@ class Adam(torch.optim.Optimizer):
                         arr[k] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                                                  None, 0, 0, 1, 1)
                 key = (gi, c0 // _lib.ADAM_MAX_TENSORS)        # one device counter pair per chunk of 16 tensors
-                if key not in self._counters:
-                    self._counters[key] = torch.zeros(_lib.ADAM_STATE_WORDS, dtype=torch.int64, device=dev)
-                    resume = getattr(self, "_resume_steps", None)
-                    if resume is not None and gi < len(resume):
-                        self._counters[key][0] = resume[gi]
+                self._counter(key[0], key[1], dev)
                 counters = self._counters
                 # the step's loss may have left its final reduction to this launch (ops.deferred_loss_finalize)
                 pend_tail = ops.pending_loss_tail()

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""How far are the default loss products (bf16 hi + lo split, hi.hi + hi.lo + lo.hi (+ lo.lo) on K = 32 MFMAs) from
+an fp32 product on embeddings that are NOT well conditioned?  ('parity first'.)
+Cases: (a) N(0, 0.7) embeddings; (b) components of +-30 that cancel in most inner products; (c) a Cora-shaped model
+after 200 captured training steps.  For each: loss and dZ of the default kernels and of the exact-fp32 S product
+(bce_s_bf16 = 0; bce_pv_bf16 = 0) against the fp64 oracle, errors relative to the SCALE of the gradient, and the
+per-logit error of an emulation of the split product.
+  python tools/r04/loss_condition.py"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import gae_dgl_amd as G
+from gae_dgl_amd import _lib, ops, workloads as W, capture, optim
+from oracle import gae_oracle as O
+
+dev = torch.device("cuda:0")
+
+
+def bf16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def split_logit_error(Z):
+    """max |S_split - S_fp64| with hi = bf16(z), lo = bf16(z - hi), products accumulated in fp32 (all four pieces)"""
+    Zf = torch.as_tensor(Z, dtype=torch.float32)
+    hi = bf16(Zf); lo = bf16(Zf - hi)
+    S = (hi @ hi.t()) + (hi @ lo.t()) + (lo @ hi.t()) + (lo @ lo.t())
+    S64 = Zf.double() @ Zf.double().t()
+    S32 = Zf @ Zf.t()
+    return float((S.double() - S64).abs().max()), float((S32.double() - S64).abs().max()), float(S64.abs().max())
+
+
+def study(name, Z, src, dst, n):
+    adj = O.dense_adjacency(src, dst, n, dtype=torch.float64)
+    pw = O.pos_weight_of(adj)
+    Zt = torch.tensor(Z, dtype=torch.float64, requires_grad=True)
+    ref = O.bce_with_logits_mean(O.decoder_logits(Zt, None), adj, pw)
+    ref.backward()
+    gscale = float(Zt.grad.abs().max())
+    gr = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    e_split, e_f32, smax = split_logit_error(Z)
+    print(f"== {name}: n {n}, max|logit| {smax:.3g}; per-logit error: split {e_split:.3g}  fp32 product {e_f32:.3g}")
+    for label, sb, pb in (("default (S, PV split)", 1, 1), ("S exact, PV split", 0, 1), ("S, PV exact fp32", 0, 0)):
+        _lib.call("gae_tuning_set", b"bce_s_bf16", sb); _lib.call("gae_tuning_set", b"bce_pv_bf16", pb)
+        Zd = torch.tensor(Z, device=dev).requires_grad_(True)
+        loss = ops.decoder_bce(Zd, None, gr)
+        loss.backward()
+        le = abs(float(loss) - float(ref)) / max(abs(float(ref)), 1e-30)
+        ge = float((Zd.grad.double().cpu() - Zt.grad).abs().max()) / gscale
+        print(f"   {label:24s} loss rel err {le:.2e}   dZ err / max|dZ| {ge:.2e}")
+    _lib.call("gae_tuning_set", b"bce_s_bf16", 1); _lib.call("gae_tuning_set", b"bce_pv_bf16", 1)
+
+
+rng = np.random.default_rng(0)
+n, d = 2048, 16
+a = rng.integers(0, n, 6000); b = rng.integers(0, n, 6000)
+src = np.concatenate([a, b]); dst = np.concatenate([b, a])
+study("N(0, 0.7)", (rng.standard_normal((n, d)) * 0.7).astype(np.float32), src, dst, n)
+Z = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+sign = rng.choice([-1.0, 1.0], size=n).astype(np.float32)
+Z[:, 0] = 30.0 * sign + Z[:, 0]; Z[:, 1] = 30.0 + Z[:, 1]
+# z_i . z_j = 900 s_i s_j + 900 + small: the two large terms cancel whenever s_i != s_j
+study("components +-30 that cancel", Z, src, dst, n)
+# (c) Cora-shaped model after 200 captured steps
+nn_, s2, d2, X = W.citation_graph("cora", seed=0)
+torch.manual_seed(0)
+model = G.GAE(X.shape[1], [32, 16]).to(dev)
+g = G.DGLGraph((s2, d2), num_nodes=nn_).to(dev)
+Xd = torch.from_numpy(X).to(dev)
+opt = optim.Adam(model.parameters(), lr=1e-2)
+step = capture.CapturedTrainStep(model, opt, g, Xd, warmup=0)
+for _ in range(200):
+    l = step()
+torch.cuda.synchronize()
+print("cora: loss after 200 steps", float(l))
+g.ndata['h'] = Xd
+with torch.no_grad():
+    Zc = model.encode(g).cpu().numpy()
+print("cora: max|z|", float(np.abs(Zc).max()))
+study("Cora-shaped GAE after 200 steps", Zc, s2, d2, nn_)
