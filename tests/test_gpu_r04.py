@@ -1,4 +1,6 @@
 """Round-4 regression tests for the ADVICE findings of round 3 (GPU side)."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -72,7 +74,7 @@ def test_adam_checkpoint_loaded_after_capture_matches_eager():
         g.ndata['h'] = X
         loss = m0.reconstruction_loss(g); o0.zero_grad(); loss.backward(); o0.step()
     ck_model = {k: v.clone() for k, v in m0.state_dict().items()}
-    ck_opt = o0.state_dict()
+    ck_opt = copy.deepcopy(o0.state_dict())          # (state_dict() hands out the live moment tensors)
     # eager continuation: 3 more steps
     want = []
     for _ in range(3):
