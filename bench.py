@@ -264,6 +264,13 @@ def spmm_probe(indptr, indices, n, F, ld=None, plan=None, label="", iters=50, bl
 
 
 # ---------------------------------------------------------------------------------------------- workloads
+# `dtype` of the line: what the arithmetic is carried out in.  Storage, the aggregations, the Linear forward and every
+# accumulation are fp32; the products of the fused loss and of the weight gradients run on the bf16 matrix pipe as
+# split-operand products (see config.loss_products / dW_products; `value_exact_fp32` is the same step with exact
+# fp32 products everywhere)
+DTYPE_SPLIT = "f32 (loss / dW products: bf16 split operands on the matrix cores, f32 accumulate)"
+
+
 class CitationWorkload:
     def __init__(self, name, args, dev):
         import gae_dgl_amd as G
@@ -292,6 +299,7 @@ class CitationWorkload:
                                   "256 MB Infinity Cache across the timed replays: its '% of 8 TB/s' is measured "
                                   "against the on-die fabric, not DRAM"}
         self.captured = None
+        self.dtype = DTYPE_SPLIT if args.loss == "fused" else "f32"
         self.tf = args.layer1 == "transform-first"
         J = self.hidden[0]
         if self.tf:
@@ -420,7 +428,7 @@ class VgaeWorkload(CitationWorkload):
             self.alg_bytes = W.spmm_alg_bytes(n, n, E, self.F_in, 2)
             self.pmc_key = "citeseer-bf16-F3703"
         self.scaling = "weak"
-        self.dtype = "bf16 storage, f32 arithmetic"
+        self.dtype = "bf16 feature storage; " + DTYPE_SPLIT
         self._params = list(self.model.parameters())
 
     def dominant_launch(self):
@@ -519,6 +527,7 @@ class ZincWorkload:
                                "capture.CapturedInductiveStep)" if self.use_graph else "eager",
                      "batches_per_epoch_at_239455_graphs": int(np.ceil(239455 / B))}
         self.dominant = None
+        self.dtype = DTYPE_SPLIT
         self.pmc_key = "zinc-batch4096-F39" if B == 4096 else ""
         self.W = W
         self.scaling = "weak"
