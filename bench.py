@@ -89,12 +89,10 @@ def parse():
                     help="rmat: row blocks of equal row count or of equal edge count (RMAT puts 44 %% of the edges "
                          "into the first of 8 equal row blocks)")
     ap.add_argument("--layer-order", choices=["auto", "aggregate-first", "transform-first"], default="auto",
-                    help="rmat workload: aggregate-first = every layer as (A H) W^T like gae.py:26-31; transform-first = "
-                         "layers that narrow the features run as A (H W^T) (same value up to fp32 rounding): the "
-                         "32 -> 16 layer then aggregates AND exchanges 16 instead of 32 floats per row, forward and "
-                         "backward.  auto = transform-first when the graph is sharded over more than one GPU (two of "
-                         "the three exchanges per step halve), aggregate-first on one GPU (RMAT s24: 29.2 vs 29.6 ms "
-                         "-- the gather is bound by the number of random row fetches, not their size)")
+                    help="rmat workload: aggregate-first = every layer as (A H) W^T like gae.py:26-31; transform-first "
+                         "(= auto) = the 32 -> 16 layer as A (H W^T) + b and its backward from G = A^T dZ (same values up to "
+                         "fp32 rounding): two of the three aggregations and exchanges per step run at width 16, the dense "
+                         "halves are two one-pass kernels (parallel.ShardedEncoder2Function)")
     ap.add_argument("--no-cache-input-exchange", action="store_true",
                     help="rmat, N > 1: exchange the remote rows of the constant input features X in every step "
                          "(default: once -- X does not change between steps, only its product A X is recomputed)")
@@ -590,7 +588,9 @@ class RmatShardedWorkload:
         src, dst = W.rmat_edges(scale, 16, seed=0, device=dev)               # same list on every rank (seeded)
         E = int(src.numel())
         self.overlap = not args.no_overlap
-        self.transform_first = args.layer_order == "transform-first" or (args.layer_order == "auto" and world > 1)
+        # auto = the one-pass encoder (parallel.ShardedEncoder2Function): last layer as A (H W^T) + b, dense halves in two
+        # one-pass kernels; "aggregate-first" keeps (A H) W^T for every layer (gae.py:26-31 literally)
+        self.transform_first = args.layer_order in ("transform-first", "auto")
         self.sg = ShardedGraph(n, src, dst, rank=rank, world=world, group=group, mode=args.exchange, device=dev,
                                balance=args.balance, overlap=self.overlap)
         del src, dst
@@ -643,8 +643,10 @@ class RmatShardedWorkload:
                                        if self.sg.cache_constant_inputs else "every step",
                      "decoder": "excluded (O(N^2) = 2.8e14 logits at N = 2^24); synthetic dZ",
                      "layer_order": "(A H) W^T for every layer (gae.py:26-31)" if not self.transform_first else
-                                    "32 -> 32 layer: (A H) W^T; 32 -> 16 layer: A (H W^T), aggregation and exchange at "
-                                    "width 16 forward and backward (value of gae.py:26-31 up to fp32 rounding)",
+                                    "32 -> 32 layer: (A X) W1^T; 32 -> 16 layer: A (H1 W2^T) + b2, its backward from "
+                                    "G = A^T dZ: two of the three aggregations (and exchanges) run at width 16; dense "
+                                    "halves: gae_linear2_fwd + gae_gcn2_bwd_dense, one pass each (value of gae.py:26-31 "
+                                    "up to fp32 rounding)",
                      "local_rows": p.n_local, "local_edges_fwd": e_local,
                      "csr_build_ms": self.csr_build_ms, "plan_build_ms": self.plan_build_ms,
                      "plan_bytes": self.plan_bytes,

@@ -63,6 +63,11 @@ SIGNATURES = {
     "gae_device_info_get": (_int, [_int, ctypes.POINTER(DeviceInfo)]),
     "gae_spmm_col_freq": (_int, [_p, _i64, _i64, _p, _p]),
     "gae_spmm_tag_hot": (_int, [_p, _i64, _p, _i32, _p, _p]),
+    "gae_spmm_csr_ep": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _int, _p, _int, _p]),
+    "gae_linear2_fwd": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _i64, _p, _i64, _p, _i64, _p]),
+    "gae_gcn2_bwd_dense_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
+    "gae_gcn2_bwd_dense": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p, _p,
+                                  _p, _p, _p, _i64, _p, _p]),
     "gae_tuning_set": (_int, [ctypes.c_char_p, _i64]),
     "gae_tuning_get": (_int, [ctypes.c_char_p, _p]),
     "gae_csr_from_coo_workspace_bytes": (_i64, [_i64, _i64]),

@@ -142,6 +142,20 @@ __device__ __forceinline__ void add_old(const T *p, float (&v)[VEC], int valid)
 __device__ __forceinline__ void store_scalar(float *p, float v) { *p = v; }
 __device__ __forceinline__ void store_scalar(unsigned short *p, float v) { *p = gae::f32_to_bf16(v); }
 
+// store-time epilogue of gae_spmm_csr_ep: v = act(v + bias[f .. f + VEC)) (bias may be NULL; features >= F untouched).
+// The test on (bias, act) is wave-uniform: plain launches skip it.
+template <int VEC>
+__device__ __forceinline__ void epilogue(float (&v)[VEC], const float *__restrict__ bias, int act, int f, int F)
+{
+    if (bias == nullptr && act == GAE_ACT_IDENTITY) return;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        float y = v[i] + ((bias != nullptr && f + i < F) ? bias[f + i] : 0.f);
+        if (act == GAE_ACT_RELU) y = fmaxf(y, 0.f);
+        v[i] = y;
+    }
+}
+
 template <typename T, int VEC, int LPR, int CH, bool SCALED>
 __global__ __launch_bounds__(256) void spmm_rowgroup_kernel(
     const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t n_rows,
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
     const T *__restrict__ H, int64_t ldh, T *__restrict__ M, int64_t ldm, int F,
     const float *__restrict__ row_scale, const float *__restrict__ col_scale, unsigned n_row_blocks,
     unsigned n_ftiles, int xcd_tiled, int tile_w, int skip_deg, int store_pad, int store_mode,
-    const int32_t *__restrict__ ell, int accumulate)
+    const int32_t *__restrict__ ell, int accumulate, const float *__restrict__ ep_bias, int ep_act)
 {
     constexpr int GPB = 256 / LPR;            // groups per block
     constexpr int RPB = GPB * RPG;            // rows per block
@@ -448,6 +462,7 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
             }
             const int f = f0 + c * TILE;
             if (accumulate) add_old<T, VEC>(mp + c * TILE, acc[r][c], F - f);   // GAE_SPMM_ACCUMULATE: M += result
+            epilogue<VEC>(acc[r][c], ep_bias, ep_act, f, F);                     // gae_spmm_csr_ep: + bias, activation
             // store_pad: M's rows are padded to a whole vector and the caller allows the pad columns to be
             // overwritten -> the tail vector is written whole (full 16-byte stores, no partially written sectors)
             if (VEC == 1 || f + VEC <= F || store_pad) {
@@ -497,7 +512,8 @@ constexpr int kEllWidth = 16;
 template <typename T, int VEC, int LPR, int CH, int RPG>
 int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
                      int64_t ldm, int F, const float *rs, const float *cs, int st, int tile_vecs, int skip_deg,
-                     int flags, const int32_t *ell, hipStream_t s)
+                     int flags, const int32_t *ell, hipStream_t s, const float *ep_bias = nullptr,
+                     int ep_act = GAE_ACT_IDENTITY)
 {
     const int store_pad = ((flags & GAE_SPMM_STORE_PAD) && (F + VEC - 1) / VEC * VEC <= ldm) ? 1 : 0;
     constexpr int RPB = (256 / LPR) * RPG;
@@ -510,7 +526,7 @@ int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_ro
 #define GAE_L2(SC, EW)                                                                                              \
     hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, EW>), grid, dim3(256), 0, s, indptr, indices,  \
                        n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, tw * VEC, skip_deg, store_pad, store_mode, ell,        \
-                       (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0)
+                       (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0, ep_bias, ep_act)
     constexpr int EW = VEC > 1 ? kEllWidth : 0;
     // store policy: 0 plain, 1 non-temporal, 2 write-through sc1; auto (-1) = sc1 under XCD feature tiles (the
     // output stream must not evict the tile's L2-resident slice of H), non-temporal otherwise
@@ -542,10 +558,12 @@ inline int auto_tile_vecs(int nvec, int64_t n_cols)
 template <typename T, int VEC>
 int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
                        int64_t ldm, int F, const float *rs, const float *cs, int rpg, int st, int64_t n_cols,
-                       int skip_deg, int flags, const int32_t *ell, int ell_width, hipStream_t s)
+                       int skip_deg, int flags, const int32_t *ell, int ell_width, hipStream_t s,
+                       const float *ep_bias = nullptr, int ep_act = GAE_ACT_IDENTITY)
 {
     const int nvec = (F + VEC - 1) / VEC;
     int tile_vecs = 0;
+    if (ep_bias != nullptr || ep_act != GAE_ACT_IDENTITY) ell = nullptr;   // the epilogue lives in the row-group kernel
     // XCD feature tiles (GAE_SPMM_TILE): wide rows, poor gather locality, rows made of whole 128-byte lines
     if (VEC > 1 && nvec > 16 && g_spmm_tile_vecs >= 0) {
         const bool lines = (ldh * sizeof(T)) % 128 == 0 && (ldm * sizeof(T)) % 128 == 0 &&
@@ -578,9 +596,9 @@ int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_
         const int rpg_ = rpg > 0 ? rpg : (waves_ >= 32768 ? 2 : 1);                                               \
         if (rpg_ >= 2 && CH == 1)                                                                                 \
             return launch_rowgroup2<T, VEC, LPR, CH, 2>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, st,   \
-                                                        tile_vecs, skip_deg, flags, ell, s);                      \
+                                                        tile_vecs, skip_deg, flags, ell, s, ep_bias, ep_act);     \
         return launch_rowgroup2<T, VEC, LPR, CH, 1>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, st,       \
-                                                    tile_vecs, skip_deg, flags, ell, s);                          \
+                                                    tile_vecs, skip_deg, flags, ell, s, ep_bias, ep_act);         \
     } while (0)
     if (tile_vecs > 0) {
         const int tv = tile_vecs;
@@ -809,7 +827,7 @@ __global__ __launch_bounds__(256) void spmm_segment_kernel(
     const int32_t *__restrict__ heavy_seg_base, const int32_t *__restrict__ seg_heavy, int64_t n_segments, int seg,
     float *__restrict__ partial, int ldp, const int32_t *__restrict__ hot_indices,
     const float *__restrict__ row_scale, T *__restrict__ M, int64_t ldm, int accumulate, int direct,
-    const int32_t *__restrict__ seg_desc)
+    const int32_t *__restrict__ seg_desc, const float *__restrict__ ep_bias, int ep_act)
 {
     // hot_indices (plan, optional): the column ids again, with the sign bit set on the columns that are gathered
     // most often.  Rows of the other columns are loaded with the non-temporal hint, so the few thousand hub rows
@@ -908,13 +926,14 @@ __global__ __launch_bounds__(256) void spmm_segment_kernel(
 #pragma unroll
             for (int i = 0; i < VEC; ++i)
                 if (f0 + c * TILE + i < F) {
-                    float sv = (0.f + acc[c][i]) * rs;
+                    float sv[1] = {(0.f + acc[c][i]) * rs};
                     if (accumulate) {
                         float t[1];
                         VecIO<T, 1>::load(mp + c * TILE + i, t);
-                        sv += t[0];
+                        sv[0] += t[0];
                     }
-                    store_scalar(mp + c * TILE + i, sv);
+                    epilogue<1>(sv, ep_bias, ep_act, f0 + c * TILE + i, F);
+                    store_scalar(mp + c * TILE + i, sv[0]);
                 }
     } else if (g == 0) {
         float *pp = partial + sidx * ldp + f0;
@@ -937,7 +956,8 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t *__rest
                                                            int64_t n_heavy, int seg,
                                                            const float *__restrict__ partial, int ldp, int F,
                                                            const float *__restrict__ row_scale, T *__restrict__ M,
-                                                           int64_t ldm, int accumulate, int lanes_per_row)
+                                                           int64_t ldm, int accumulate, int lanes_per_row,
+                                                           const float *__restrict__ ep_bias, int ep_act)
 {
     const int64_t gt = int64_t(blockIdx.x) * 256 + threadIdx.x;
     const int64_t h = gt / lanes_per_row;
@@ -965,13 +985,14 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t *__rest
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (f0 + i >= F) break;
-        float sv = s[i] * rs;
+        float sv[1] = {s[i] * rs};
         if (accumulate) {
             float t[1];
             VecIO<T, 1>::load(M + row * ldm + f0 + i, t);
-            sv += t[0];
+            sv[0] += t[0];
         }
-        store_scalar(M + row * ldm + f0 + i, sv);
+        epilogue<1>(sv, ep_bias, ep_act, f0 + i, F);
+        store_scalar(M + row * ldm + f0 + i, sv[0]);
     }
 }
 
@@ -986,7 +1007,8 @@ __global__ __launch_bounds__(256) void spmm_vh_combine_kernel(const int32_t *__r
                                                               const int32_t *__restrict__ part_pos, int64_t n_vh,
                                                               const float *__restrict__ partial, int ldp, int F,
                                                               const float *__restrict__ row_scale,
-                                                              T *__restrict__ M, int64_t ldm, int accumulate)
+                                                              T *__restrict__ M, int64_t ldm, int accumulate,
+                                                              const float *__restrict__ ep_bias, int ep_act)
 {
     constexpr int SLICES = 64 / LPRC;
     const int lane = threadIdx.x & 63;
@@ -1021,20 +1043,21 @@ __global__ __launch_bounds__(256) void spmm_vh_combine_kernel(const int32_t *__r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (f0 + i >= F) break;
-        float sv = s[i] * rs;
+        float sv[1] = {s[i] * rs};
         if (accumulate) {
             float t[1];
             VecIO<T, 1>::load(M + row * ldm + f0 + i, t);
-            sv += t[0];
+            sv[0] += t[0];
         }
-        store_scalar(M + row * ldm + f0 + i, sv);
+        epilogue<1>(sv, ep_bias, ep_act, f0 + i, F);
+        store_scalar(M + row * ldm + f0 + i, sv[0]);
     }
 }
 
 template <typename T, int VEC, int LPR, int CH>
 int launch_segments(const int32_t *indptr, const int32_t *indices, const T *H, int64_t ldh, int F, const float *cs,
                     const gae_spmm_plan *plan, float *partial, int ldp, const float *rs, T *M, int64_t ldm,
-                    int accumulate, int direct, hipStream_t s)
+                    int accumulate, int direct, hipStream_t s, const float *ep_bias, int ep_act)
 {
     const int nvec = (F + VEC - 1) / VEC;
     const dim3 grid(unsigned((plan->n_segments + 3) / 4), unsigned((nvec + LPR * CH - 1) / (LPR * CH)));
@@ -1042,12 +1065,12 @@ int launch_segments(const int32_t *indptr, const int32_t *indices, const T *H, i
         hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, true>), grid, dim3(256), 0, s, indptr, indices, H, ldh,
                            F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
                            plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr, rs, M, ldm,
-                           accumulate, direct, g_spmm_desc ? plan->seg_desc : nullptr);
+                           accumulate, direct, g_spmm_desc ? plan->seg_desc : nullptr, ep_bias, ep_act);
     else
         hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, false>), grid, dim3(256), 0, s, indptr, indices, H,
                            ldh, F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
                            plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr, rs, M, ldm,
-                           accumulate, direct, g_spmm_desc ? plan->seg_desc : nullptr);
+                           accumulate, direct, g_spmm_desc ? plan->seg_desc : nullptr, ep_bias, ep_act);
     GAE_CHECK_LAUNCH("spmm_segment_kernel");
     return GAE_OK;
 }
@@ -1055,12 +1078,13 @@ int launch_segments(const int32_t *indptr, const int32_t *indices, const T *H, i
 template <typename T, int VEC>
 int dispatch_segments(const int32_t *indptr, const int32_t *indices, const T *H, int64_t ldh, int F, const float *cs,
                       const gae_spmm_plan *plan, float *partial, int ldp, const float *rs, T *M, int64_t ldm,
-                      int accumulate, int direct, hipStream_t s)
+                      int accumulate, int direct, hipStream_t s, const float *ep_bias = nullptr,
+                      int ep_act = GAE_ACT_IDENTITY)
 {
     const int nvec = (F + VEC - 1) / VEC;
 #define GAE_SEG(LPR, CH)                                                                                              \
     return launch_segments<T, VEC, LPR, CH>(indptr, indices, H, ldh, F, cs, plan, partial, ldp, rs, M, ldm, accumulate, \
-                                            direct, s)
+                                            direct, s, ep_bias, ep_act)
     if (nvec <= 4) GAE_SEG(4, 1);
     if (nvec <= 8) GAE_SEG(8, 1);
     if (nvec <= 16) GAE_SEG(16, 1);
@@ -1076,19 +1100,22 @@ inline int plan_ldp(int64_t F) { return int((F + 3) / 4 * 4); }
 template <typename T, int VEC>
 int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols, const T *h, int64_t ldh,
              T *m, int64_t ldm, int f, const float *rs, const float *cs, bool vec, const gae_spmm_plan *plan,
-             void *workspace, int flags, hipStream_t s)
+             void *workspace, int flags, hipStream_t s, const float *ep_bias = nullptr, int ep_act = GAE_ACT_IDENTITY)
 {
+    const bool epi = ep_bias != nullptr || ep_act != GAE_ACT_IDENTITY;
     const bool heavy = plan && plan->n_heavy > 0;
     const bool homed = plan && plan->vh_n_virtual > 0;
     const int skip = (heavy || homed) ? plan->threshold : 0x7fffffff;
     const int min_f = vec ? (sizeof(T) == 4 ? 12 : 24) : 3;
     int rc = GAE_OK;
     if ((heavy || homed) && !(g_spmm_parts & 1)) {
-    } else if (g_spmm_variant == 2 && f > min_f)
+    } else if ((g_spmm_variant == 2 || epi) && f > min_f)
         rc = dispatch_rowgroup2<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, g_spmm_rpg,
                                         g_spmm_nt, n_cols, skip, flags,
-                                        (plan && g_spmm_ell) ? plan->ell : nullptr, plan ? plan->ell_width : 0, s);
+                                        (plan && g_spmm_ell) ? plan->ell : nullptr, plan ? plan->ell_width : 0, s,
+                                        ep_bias, ep_act);
     else {
+        GAE_REQUIRE(!epi, GAE_E_RANGE, "gae_spmm_csr_ep: needs F > %d for this layout", min_f);
         GAE_REQUIRE(!heavy && !homed, GAE_E_RANGE, "gae_spmm_csr: a skew plan needs F > %d for this layout", min_f);
         rc = dispatch_rowgroup<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs,
                                        (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0, s);
@@ -1098,13 +1125,14 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
     const int ldp = plan_ldp(f);
     const int acc_flag = (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0;
     if (heavy && (g_spmm_parts & 2)) {
-        rc = dispatch_segments<T, VEC>(indptr, indices, h, ldh, f, cs, plan, partial, ldp, rs, m, ldm, acc_flag, 1, s);
+        rc = dispatch_segments<T, VEC>(indptr, indices, h, ldh, f, cs, plan, partial, ldp, rs, m, ldm, acc_flag, 1, s,
+                                       ep_bias, ep_act);
         if (rc) return rc;
         const int lanes_per_row = (f + 3) / 4;
         const int64_t combine_threads = plan->n_heavy * lanes_per_row;
         hipLaunchKernelGGL((spmm_combine_kernel<T>), dim3(unsigned((combine_threads + 255) / 256)), dim3(256), 0, s,
                            indptr, plan->heavy_rows, plan->heavy_seg_base, plan->n_heavy, plan->segment_edges, partial, ldp, f, rs,
-                           m, ldm, acc_flag, lanes_per_row);
+                           m, ldm, acc_flag, lanes_per_row, ep_bias, ep_act);
         GAE_CHECK_LAUNCH("spmm_combine_kernel");
     }
     if (homed && (g_spmm_parts & 4)) {
@@ -1124,7 +1152,7 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
         const dim3 cgrid(unsigned((plan->vh_n_rows + 3) / 4), unsigned((lanes_per_row + 63) / 64));
 #define GAE_VHC(L)                                                                                                   \
     hipLaunchKernelGGL((spmm_vh_combine_kernel<T, L>), cgrid, dim3(256), 0, s, plan->vh_rows, plan->vh_part_ptr,      \
-                       plan->vh_part_pos, plan->vh_n_rows, pv, ldp, f, rs, m, ldm, acc_flag)
+                       plan->vh_part_pos, plan->vh_n_rows, pv, ldp, f, rs, m, ldm, acc_flag, ep_bias, ep_act)
         if (lanes_per_row <= 4) GAE_VHC(4);
         else if (lanes_per_row <= 8) GAE_VHC(8);
         else if (lanes_per_row <= 16) GAE_VHC(16);
@@ -1220,10 +1248,11 @@ extern "C" int64_t gae_spmm_workspace_bytes(const gae_spmm_plan *plan, int64_t F
     return b;
 }
 
-extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
-                            const void *H, int64_t ldh, void *M, int64_t ldm, int64_t F, int dtype,
-                            const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
-                            void *workspace, int64_t workspace_bytes, int flags, void *stream)
+static int spmm_csr_impl(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                         const void *H, int64_t ldh, void *M, int64_t ldm, int64_t F, int dtype,
+                         const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
+                         void *workspace, int64_t workspace_bytes, int flags, void *stream, const float *ep_bias,
+                         int ep_act)
 {
     GAE_REQUIRE(n_rows >= 0 && n_cols >= 0 && F >= 0, GAE_E_SIZE, "gae_spmm_csr: negative size");
     GAE_REQUIRE(F < (int64_t(1) << 24), GAE_E_SIZE, "gae_spmm_csr: F too large");
@@ -1260,14 +1289,39 @@ extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64
         const float *h = static_cast<const float *>(H);
         float *m = static_cast<float *>(M);
         const bool vec = (ldh % 4 == 0) && (ldm % 4 == 0) && gae::aligned16(H) && gae::aligned16(M);
-        if (vec) return run_spmm<float, 4>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, true, plan, workspace, flags, s);
-        return run_spmm<float, 1>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, false, plan, workspace, flags, s);
+        if (vec) return run_spmm<float, 4>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, true, plan, workspace, flags, s, ep_bias, ep_act);
+        return run_spmm<float, 1>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, false, plan, workspace, flags, s, ep_bias, ep_act);
     }
+    GAE_REQUIRE(ep_bias == nullptr && ep_act == GAE_ACT_IDENTITY, GAE_E_DTYPE, "gae_spmm_csr_ep: fp32 operands only");
     const unsigned short *h = static_cast<const unsigned short *>(H);
     unsigned short *m = static_cast<unsigned short *>(M);
     const bool vec = (ldh % 8 == 0) && (ldm % 8 == 0) && gae::aligned16(H) && gae::aligned16(M);
     if (vec) return run_spmm<unsigned short, 8>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, true, plan, workspace, flags, s);
     return run_spmm<unsigned short, 1>(indptr, indices, n_rows, n_cols, h, ldh, m, ldm, f, row_scale, col_scale, false, plan, workspace, flags, s);
+}
+
+extern "C" int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                            const void *H, int64_t ldh, void *M, int64_t ldm, int64_t F, int dtype,
+                            const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
+                            void *workspace, int64_t workspace_bytes, int flags, void *stream)
+{
+    return spmm_csr_impl(indptr, indices, n_rows, n_cols, H, ldh, M, ldm, F, dtype, row_scale, col_scale, plan, workspace,
+                         workspace_bytes, flags, stream, nullptr, GAE_ACT_IDENTITY);
+}
+
+// gae_spmm_csr with a store-time epilogue: M = act(diag(rs) A diag(cs) H (+ M if GAE_SPMM_ACCUMULATE) + bias), fp32,
+// ANY plan (degree-skew segments and XCD-pinned rows included: every kernel that stores a finished row applies it).
+// The sparse half of a GCN layer evaluated as act(A (H W^T) + b) on a power-law graph -- gae.py:26-31 up to fp32
+// rounding -- where gae_spmm_csr_epilogue (packed-table plans only) does not apply.
+extern "C" int gae_spmm_csr_ep(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                               const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F, const float *row_scale,
+                               const float *col_scale, const gae_spmm_plan *plan, void *workspace,
+                               int64_t workspace_bytes, int flags, const float *bias, int act, void *stream)
+{
+    GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_RANGE, "gae_spmm_csr_ep: act %d", act);
+    GAE_REQUIRE(!(flags & GAE_SPMM_TILE), GAE_E_RANGE, "gae_spmm_csr_ep: XCD feature tiles are not available with an epilogue");
+    return spmm_csr_impl(indptr, indices, n_rows, n_cols, H, ldh, M, ldm, F, GAE_F32, row_scale, col_scale, plan,
+                         workspace, workspace_bytes, flags, stream, bias, act);
 }
 
 extern "C" int64_t gae_spmm_blockdiag_lds_bytes(int64_t max_block_rows, int64_t max_block_edges, int64_t ldh)

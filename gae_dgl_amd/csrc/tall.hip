@@ -1,0 +1,404 @@
+// Dense halves of a two-layer GCN encoder on a graph with MILLIONS of rows (BASELINE config 4: R-MAT, 2^24 nodes,
+// widths 32 -> 32 -> 16), written for one pass over every operand.
+//
+// The reference evaluates  H1 = relu((A X) W1^T + b1),  Z = (A H1) W2^T + b2  (gae_dgl/gae.py:26-31,36-45) and its
+// autograd (train_inductive.py:51).  With M1 = A X stored, the same values (up to fp32 rounding of the re-associated
+// products, the tolerance contract of DESIGN.md section 6) come from
+//   forward   T  = H1 W2^T                  (gae_linear2_fwd: M1 -> H1 and T in ONE pass, H1 never re-read)
+//             Z  = A T + b2                 (gae_spmm_csr_ep: the second aggregation runs at width 16, not 32)
+//   backward  G  = A^T dZ                   (gae_spmm_csr at width 16)
+//             dW2 = G^T H1, db2 = colsum(dZ), dY1 = (G W2) (.) [H1 > 0], dW1 = dY1^T M1, db1 = colsum(dY1)
+//                                           (gae_gcn2_bwd_dense: ONE pass over G, dZ, H1, M1; dY1 is never stored)
+// instead of four Linear / weight-gradient launches that each stream a [N, 32] operand again, and the aggregate of
+// layer 2 (A H1, [N, 32]) is neither written nor read.
+//
+// Both kernels are HBM-bound streams (roofline: bytes of the operands they read and write once); the products run on
+// v_mfma_f32_32x32x2_f32 (exact fp32) and hide behind the loads.  A WAVE owns whole 32-row tiles; the weights stay in
+// its registers for its whole row range; no LDS in the row loop.
+//
+// MFMA bookkeeping (32x32x2, D[i][n] += sum_k A[i][k] B[k][n]): lane l = (i = l & 31, h = l >> 5) supplies
+// A[i][k = h] and B[k = h][n = i]; accumulator register r of lane (n, h) is D[rho(r, h)][n] with
+// rho(r, h) = (r & 3) + 8 (r >> 2) + 4 h.  Which k a (step, h) pair stands for is free as long as both operands agree.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// gae_linear2_fwd:  Y1 = act(A W1^T + b1) [n, J1],  T = Y1 W2^T [n, J2];  K1 <= 64, J1 <= 32, J2 <= 32.
+// Both products are evaluated TRANSPOSED (D1[j][row], D2[j2][row]): the rows of the tile sit in the lanes, so
+// the accumulator registers of the first product ARE the B operands of the second (step r, half h <-> j = rho(r, h)).
+// ---------------------------------------------------------------------------------------------------------------
+template <int KB>
+__global__ __launch_bounds__(256) void linear2_rows_kernel(const float *__restrict__ A, int64_t lda,
+                                                           const float *__restrict__ W1, int64_t ldw1,
+                                                           const float *__restrict__ b1, int act1,
+                                                           const float *__restrict__ W2, int64_t ldw2,
+                                                           float *__restrict__ Y1, int64_t ldy1, float *__restrict__ T,
+                                                           int64_t ldt, int64_t n, int K1, int J1, int J2,
+                                                           int tiles_per_wave)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    // weights of this wave: w1[kb][q] = W1[j = i][k = 8 kb + 4 h + q], w2[r] = W2[j2 = i][j = rho(r, h)], bias of the
+    // 16 outputs this lane holds of its row
+    float w1[KB][4], w2[16], bv[16];
+    {
+        const int jc = i < J1 ? i : J1 - 1, j2c = i < J2 ? i : J2 - 1;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = kb * 8 + 4 * h + q;
+                const float v = W1[int64_t(jc) * ldw1 + (k < K1 ? k : K1 - 1)];
+                w1[kb][q] = (k < K1 && i < J1) ? v : 0.f;
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = rho(r, h);
+            const int jj = j < J1 ? j : J1 - 1;
+            const float v = W2[int64_t(j2c) * ldw2 + jj];
+            w2[r] = (j < J1 && i < J2) ? v : 0.f;
+            const float b = b1 ? b1[jj] : 0.f;
+            bv[r] = (b1 && j < J1) ? b : 0.f;
+        }
+    }
+    const int K4 = (K1 + 3) & ~3;
+    struct Stage { float a[KB][4]; };
+    auto load = [&](Stage &st, int64_t row0) {
+        const int64_t row = row0 + i;
+        const float *ap = A + (row < n ? row : n - 1) * lda;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int k = kb * 8 + 4 * h;
+            const float4 t4 = *reinterpret_cast<const float4 *>(ap + (k <= K4 - 4 ? k : K4 - 4));
+            st.a[kb][0] = t4.x; st.a[kb][1] = t4.y; st.a[kb][2] = t4.z; st.a[kb][3] = t4.w;
+        }
+    };
+    auto tile = [&](const Stage &st, int64_t row0) {
+        const int64_t row = row0 + i;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float av = (kb * 8 + 4 * h + q < K1) ? st.a[kb][q] : 0.f;      // pad columns may hold anything
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[kb][q], av, acc, 0, 0, 0);
+            }
+        // lane (row i, h) now holds D1[j = rho(r, h)][row]: bias, activation, store, and feed the second product
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float y = acc[r] + bv[r];
+            if (act1 == GAE_ACT_RELU) y = fmaxf(y, 0.f);
+            acc[r] = y;
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[r], y, acc2, 0, 0, 0);
+        }
+        if (row < n) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int j0 = 8 * q4 + 4 * h;
+                if (Y1 != nullptr) {
+                    float *yp = Y1 + row * ldy1 + j0;
+                    if (j0 + 4 <= J1) *reinterpret_cast<float4 *>(yp) = make_float4(acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]);
+                    else
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (j0 + u < J1) yp[u] = acc[4 * q4 + u];
+                }
+                float *tp = T + row * ldt + j0;
+                if (j0 + 4 <= J2) *reinterpret_cast<float4 *>(tp) = make_float4(acc2[4 * q4], acc2[4 * q4 + 1], acc2[4 * q4 + 2], acc2[4 * q4 + 3]);
+                else
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (j0 + u < J2) tp[u] = acc2[4 * q4 + u];
+            }
+        }
+    };
+    const int64_t t0 = (int64_t(blockIdx.x) * 4 + wave) * tiles_per_wave;
+    const int64_t n_tiles = (n + 31) / 32;
+    if (t0 >= n_tiles) return;
+    const int64_t t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
+    Stage s0, s1;
+    load(s0, t0 * 32);
+    for (int64_t tt = t0; tt < t1; tt += 2) {
+        if (tt + 1 < t1) load(s1, (tt + 1) * 32);
+        tile(s0, tt * 32);
+        if (tt + 1 >= t1) break;
+        if (tt + 2 < t1) load(s0, (tt + 2) * 32);
+        tile(s1, (tt + 1) * 32);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gae_gcn2_bwd_dense: per-block partial sums of
+//     dW2 = G^T Y1 [J2, J1],  db2 = colsum(dZ) [J2],  dY1 = (G W2) (.) act1'(Y1),  dW1 = dY1^T M1 [J1, K1],
+//     db1 = colsum(dY1) [J1]                                            (J2, J1, K1 <= 32)
+// in ONE pass over G, dZ [n, J2], Y1 [n, J1] and M1 [n, K1].  Per 32-row tile:
+//   dH = G W2  : A = G rows (lane = row; k = j2), B = W2 -> accumulator lane (j, h), register r = dH[rho(r, h)][j];
+//   that register file, gated by Y1 > 0, is directly the A operand of dW1 += dY1^T M1 (k = the tile's rows, step r
+//   <-> row rho(r, h)); its B operand is M1 read column-per-lane in the same row order; dW2 += G^T Y1 likewise with
+//   G and Y1 read column-per-lane.  No LDS in the row loop; the 4 waves of a block meet in LDS once, in fixed order.
+// partial layout per block: [dW1 J1 x K1 | db1 J1 | dW2 J2 x J1 | db2 J2]  (gae_gcn2_bwd_dense_layout)
+// ---------------------------------------------------------------------------------------------------------------
+template <int KB2, bool RELU>
+__global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restrict__ G, int64_t ldg,
+                                                            const float *__restrict__ dZ, int64_t lddz,
+                                                            const float *__restrict__ Y1, int64_t ldy1,
+                                                            const float *__restrict__ M1, int64_t ldm1,
+                                                            const float *__restrict__ W2, int64_t ldw2, int64_t n,
+                                                            int K1, int J1, int J2, int64_t tiles_per_wave,
+                                                            float *__restrict__ partial, int64_t stride)
+{
+    __shared__ float red[2][34 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    // W2 as the B operand of dH = G W2: w2[kb][q] = W2[j2 = 8 kb + 4 h + q][j = i]
+    float w2[KB2][4];
+    {
+        const int jc = i < J1 ? i : J1 - 1;
+#pragma unroll
+        for (int kb = 0; kb < KB2; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j2 = kb * 8 + 4 * h + q;
+                const float v = W2[int64_t(j2 < J2 ? j2 : J2 - 1) * ldw2 + jc];
+                w2[kb][q] = (j2 < J2 && i < J1) ? v : 0.f;
+            }
+    }
+    f32x16 accW1, accW2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accW1[r] = 0.f; accW2[r] = 0.f; }
+    float sdb1 = 0.f;                  // column j = i of dY1, rows rho(., h) of every tile
+    float sz[KB2][4];                  // columns 8 kb + 4 h + q of dZ, row i of every tile
+#pragma unroll
+    for (int kb = 0; kb < KB2; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sz[kb][q] = 0.f;
+
+    const int J24 = (J2 + 3) & ~3;
+    const int jy = i < J1 ? i : J1 - 1, km = i < K1 ? i : K1 - 1, jg = i < J2 ? i : J2 - 1;
+    struct Stage { float g[KB2][4], z[KB2][4], y[16], m[16], gc[16]; };
+    auto load = [&](Stage &st, int64_t row0) {
+        const int64_t row = row0 + i < n ? row0 + i : n - 1;
+#pragma unroll
+        for (int kb = 0; kb < KB2; ++kb) {
+            const int k = kb * 8 + 4 * h, kc = k <= J24 - 4 ? k : J24 - 4;
+            const float4 g4 = *reinterpret_cast<const float4 *>(G + row * ldg + kc);
+            const float4 z4 = *reinterpret_cast<const float4 *>(dZ + row * lddz + kc);
+            st.g[kb][0] = g4.x; st.g[kb][1] = g4.y; st.g[kb][2] = g4.z; st.g[kb][3] = g4.w;
+            st.z[kb][0] = z4.x; st.z[kb][1] = z4.y; st.z[kb][2] = z4.z; st.z[kb][3] = z4.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t rr = row0 + rho(r, h) < n ? row0 + rho(r, h) : n - 1;
+            st.y[r] = Y1[rr * ldy1 + jy];
+            st.m[r] = M1[rr * ldm1 + km];
+            st.gc[r] = G[rr * ldg + jg];
+        }
+    };
+    auto tile = [&](const Stage &st, int64_t row0) {
+        const bool rv = row0 + i < n;
+        f32x16 dh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB2; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool kv = kb * 8 + 4 * h + q < J2;
+                dh = __builtin_amdgcn_mfma_f32_32x32x2f32((rv && kv) ? st.g[kb][q] : 0.f, w2[kb][q], dh, 0, 0, 0);
+                sz[kb][q] += (rv && kv) ? st.z[kb][q] : 0.f;
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool rr = row0 + rho(r, h) < n;
+            const float y = (rr && i < J1) ? st.y[r] : 0.f;
+            float dy = rr ? dh[r] : 0.f;                       // dH[rho(r, h)][j = i]
+            if (RELU) dy = y > 0.f ? dy : 0.f;
+            sdb1 += dy;
+            accW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dy, (rr && i < K1) ? st.m[r] : 0.f, accW1, 0, 0, 0);
+            accW2 = __builtin_amdgcn_mfma_f32_32x32x2f32((rr && i < J2) ? st.gc[r] : 0.f, y, accW2, 0, 0, 0);
+        }
+    };
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t t0 = (int64_t(blockIdx.x) * 4 + wave) * tiles_per_wave;
+    const int64_t t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
+    if (t0 < t1) {
+        Stage s0, s1;
+        load(s0, t0 * 32);
+        for (int64_t tt = t0; tt < t1; tt += 2) {
+            if (tt + 1 < t1) load(s1, (tt + 1) * 32);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(s0, tt * 32);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tt + 1 >= t1) break;
+            if (tt + 2 < t1) load(s0, (tt + 2) * 32);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(s1, (tt + 1) * 32);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- column sums: db1 over the two halves; db2 over the 32 rows-in-lanes (fixed shuffle tree)
+    sdb1 += __shfl_xor(sdb1, 32, 64);
+#pragma unroll
+    for (int kb = 0; kb < KB2; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) sz[kb][q] += __shfl_xor(sz[kb][q], off, 64);
+    // ---- the 4 waves meet in LDS, fixed tree order: (w) += (w + 2), then (0) += (1)
+    float extra[2] = {sdb1, 0.f};     // per-lane scalars parked behind the accumulators: db1, db2 (below)
+    // db2 value of column j2 = 8 kb + 4 h + q sits (equal) in all lanes of half h: lane (i, h) keeps column i if it owns it
+#pragma unroll
+    for (int kb = 0; kb < KB2; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j2 = kb * 8 + 4 * h + q;
+            if (j2 == i) extra[1] = sz[kb][q];            // lane (i, h) with i in the half's column set
+        }
+    // (a column j2 with ((j2 >> 2) & 1) == h is held by lane (j2, h); the other half's lane (j2, 1 - h) holds 0)
+#pragma unroll
+    for (int half = 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+            float *rp = red[wave - half];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { rp[r * 64 + lane] = accW1[r]; rp[(16 + r) * 64 + lane] = accW2[r]; }
+            rp[32 * 64 + lane] = extra[0]; rp[33 * 64 + lane] = extra[1];
+        }
+        __syncthreads();
+        if (wave < half) {
+            const float *rp = red[wave];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accW1[r] += rp[r * 64 + lane]; accW2[r] += rp[(16 + r) * 64 + lane]; }
+            extra[0] += rp[32 * 64 + lane]; extra[1] += rp[33 * 64 + lane];
+        }
+        if (half > 1) __syncthreads();
+    }
+    if (wave != 0) return;
+    float *pp = partial + int64_t(blockIdx.x) * stride;
+    float *pW1 = pp, *pb1 = pp + J1 * K1, *pW2 = pb1 + J1, *pb2 = pW2 + J2 * J1;
+    // accW1 register r of lane (n = k, h) = dW1[j = rho(r, h)][k]; accW2 register r of lane (n = j, h) = dW2[j2 = rho(r, h)][j]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = rho(r, h);
+        if (o < J1 && i < K1) pW1[o * K1 + i] = accW1[r];
+        if (o < J2 && i < J1) pW2[o * J1 + i] = accW2[r];
+    }
+    if (h == 0 && i < J1) pb1[i] = extra[0];
+    const float b2 = extra[1] + __shfl_xor(extra[1], 32, 64);      // the owning half + 0
+    if (h == 0 && i < J2) pb2[i] = b2;
+}
+
+inline int64_t tall_tiles_per_wave(int64_t n, int64_t max_blocks)
+{
+    const int64_t n_tiles = (n + 31) / 32;
+    int64_t tpw = (n_tiles + max_blocks * 4 - 1) / (max_blocks * 4);
+    return tpw < 1 ? 1 : tpw;
+}
+
+} // namespace
+
+extern "C" int gae_linear2_fwd(const float *A, int64_t lda, int64_t n, int64_t f_in, const float *W1, int64_t ldw1,
+                               const float *b1, int64_t f_mid, int act1, const float *W2, int64_t ldw2, int64_t f_out,
+                               float *Y1, int64_t ldy1, float *T, int64_t ldt, void *stream)
+{
+    GAE_REQUIRE(n >= 0 && f_in >= 1 && f_mid >= 1 && f_out >= 1, GAE_E_SIZE, "gae_linear2_fwd: bad size");
+    GAE_REQUIRE(f_in <= 64 && f_mid <= 32 && f_out <= 32, GAE_E_RANGE,
+                "gae_linear2_fwd: needs f_in <= 64, f_mid <= 32, f_out <= 32 (use two gae_linear_fwd calls)");
+    GAE_REQUIRE(act1 == GAE_ACT_IDENTITY || act1 == GAE_ACT_RELU, GAE_E_RANGE, "gae_linear2_fwd: act %d", act1);
+    if (n == 0) return GAE_OK;
+    GAE_REQUIRE(A && W1 && W2 && T, GAE_E_NULL, "gae_linear2_fwd: NULL pointer");
+    GAE_REQUIRE(lda >= (f_in + 3) / 4 * 4 && lda % 4 == 0 && gae::aligned16(A), GAE_E_ALIGN,
+                "gae_linear2_fwd: rows of A must be whole 16-byte vectors");
+    GAE_REQUIRE(ldw1 >= f_in && ldw2 >= f_mid, GAE_E_SIZE, "gae_linear2_fwd: weight leading dimension too small");
+    GAE_REQUIRE((!Y1 || (ldy1 >= f_mid && ldy1 % 4 == 0 && gae::aligned16(Y1))) && ldt >= f_out && ldt % 4 == 0 &&
+                    gae::aligned16(T), GAE_E_ALIGN, "gae_linear2_fwd: rows of Y1 / T must be whole 16-byte vectors");
+    hipStream_t s = gae::as_stream(stream);
+    const int64_t tpw = tall_tiles_per_wave(n, 4096);
+    const int64_t n_tiles = (n + 31) / 32;
+    const dim3 grid(unsigned((n_tiles + 4 * tpw - 1) / (4 * tpw)));
+    const int kb = int((f_in + 7) / 8);
+#define GAE_L2F(KBV)                                                                                                     \
+    hipLaunchKernelGGL((linear2_rows_kernel<KBV>), grid, dim3(256), 0, s, A, lda, W1, ldw1, b1, act1, W2, ldw2, Y1, ldy1, \
+                       T, ldt, n, int(f_in), int(f_mid), int(f_out), int(tpw))
+    switch (kb) {
+    case 1: GAE_L2F(1); break; case 2: GAE_L2F(2); break; case 3: GAE_L2F(3); break; case 4: GAE_L2F(4); break;
+    case 5: GAE_L2F(5); break; case 6: GAE_L2F(6); break; case 7: GAE_L2F(7); break; default: GAE_L2F(8); break;
+    }
+#undef GAE_L2F
+    GAE_CHECK_LAUNCH("linear2_rows_kernel");
+    return GAE_OK;
+}
+
+// layout_out = {n_partials (blocks), floats per partial, offset of db1, offset of dW2, offset of db2} (dW1 at 0)
+static void gcn2_layout(int64_t n, int64_t f_in, int64_t f_mid, int64_t f_out, int64_t *lay, int64_t *tpw_out)
+{
+    const int64_t tpw = tall_tiles_per_wave(n, 1024);
+    const int64_t n_tiles = (n + 31) / 32;
+    lay[0] = (n_tiles + 4 * tpw - 1) / (4 * tpw);
+    lay[2] = f_mid * f_in;
+    lay[3] = lay[2] + f_mid;
+    lay[4] = lay[3] + f_out * f_mid;
+    lay[1] = (lay[4] + f_out + 3) / 4 * 4;
+    if (tpw_out) *tpw_out = tpw;
+}
+
+extern "C" int64_t gae_gcn2_bwd_dense_workspace_bytes(int64_t n, int64_t f_in, int64_t f_mid, int64_t f_out)
+{
+    if (n < 0 || f_in < 1 || f_mid < 1 || f_out < 1 || f_in > 32 || f_mid > 32 || f_out > 32) return GAE_E_SIZE;
+    int64_t lay[5];
+    gcn2_layout(n > 0 ? n : 1, f_in, f_mid, f_out, lay, nullptr);
+    return lay[0] * lay[1] * 4 + 256;
+}
+
+extern "C" int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, int64_t lddz, const float *Y1, int64_t ldy1,
+                                  int act1, const float *M1, int64_t ldm1, const float *W2, int64_t ldw2, int64_t n,
+                                  int64_t f_in, int64_t f_mid, int64_t f_out, float *dW1, float *db1, float *dW2,
+                                  float *db2, void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream)
+{
+    GAE_REQUIRE(n >= 1 && f_in >= 1 && f_mid >= 1 && f_out >= 1, GAE_E_SIZE, "gae_gcn2_bwd_dense: bad size");
+    GAE_REQUIRE(f_in <= 32 && f_mid <= 32 && f_out <= 32, GAE_E_RANGE, "gae_gcn2_bwd_dense: widths above 32");
+    GAE_REQUIRE(act1 == GAE_ACT_IDENTITY || act1 == GAE_ACT_RELU, GAE_E_RANGE, "gae_gcn2_bwd_dense: act %d", act1);
+    GAE_REQUIRE(G && dZ && Y1 && M1 && W2 && workspace, GAE_E_NULL, "gae_gcn2_bwd_dense: NULL pointer");
+    const int64_t j24 = (f_out + 3) / 4 * 4;
+    GAE_REQUIRE(ldg >= j24 && ldg % 4 == 0 && gae::aligned16(G) && lddz >= j24 && lddz % 4 == 0 && gae::aligned16(dZ),
+                GAE_E_ALIGN, "gae_gcn2_bwd_dense: rows of G / dZ must be whole 16-byte vectors");
+    GAE_REQUIRE(ldy1 >= f_mid && ldm1 >= f_in && ldw2 >= f_mid, GAE_E_SIZE, "gae_gcn2_bwd_dense: leading dimension too small");
+    GAE_REQUIRE(workspace_bytes >= gae_gcn2_bwd_dense_workspace_bytes(n, f_in, f_mid, f_out) && gae::aligned16(workspace),
+                GAE_E_WORKSPACE, "gae_gcn2_bwd_dense: workspace too small or misaligned");
+    int64_t lay[5], tpw = 1;
+    gcn2_layout(n, f_in, f_mid, f_out, lay, &tpw);
+    hipStream_t s = gae::as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    const dim3 grid{unsigned(lay[0])};
+    const int kb2 = int((f_out + 7) / 8);
+#define GAE_G2B(KBV, RL)                                                                                                 \
+    hipLaunchKernelGGL((gcn2_bwd_rows_kernel<KBV, RL>), grid, dim3(256), 0, s, G, ldg, dZ, lddz, Y1, ldy1, M1, ldm1, W2,  \
+                       ldw2, n, int(f_in), int(f_mid), int(f_out), tpw, partial, lay[1])
+#define GAE_G2K(RL)                                                                                                      \
+    do { if (kb2 == 1) GAE_G2B(1, RL); else if (kb2 == 2) GAE_G2B(2, RL); else if (kb2 == 3) GAE_G2B(3, RL); else GAE_G2B(4, RL); } while (0)
+    if (act1 == GAE_ACT_RELU) GAE_G2K(true); else GAE_G2K(false);
+#undef GAE_G2K
+#undef GAE_G2B
+    GAE_CHECK_LAUNCH("gcn2_bwd_rows_kernel");
+    if (layout_out) {
+        for (int k = 0; k < 5; ++k) layout_out[k] = lay[k];
+        return GAE_OK;                   // partials only: the caller (gae_adam_step's deferred reduction) adds them
+    }
+    using gae::PartialList;
+    PartialList a{partial, dW1, f_mid * f_in, lay[0], lay[1], f_mid * f_in, f_mid * f_in, f_mid * f_in};
+    PartialList b{partial + lay[2], db1, f_mid, lay[0], lay[1], f_mid, f_mid, f_mid};
+    int rc = gae::launch_partials_reduce(a, b, s);
+    if (rc) return rc;
+    PartialList c{partial + lay[3], dW2, f_out * f_mid, lay[0], lay[1], f_out * f_mid, f_out * f_mid, f_out * f_mid};
+    PartialList d{partial + lay[4], db2, f_out, lay[0], lay[1], f_out, f_out, f_out};
+    return gae::launch_partials_reduce(c, d, s);
+}

@@ -15,7 +15,8 @@ parity suite holds it to the same 1e-5 as everything else) -- because the
 aggregation then runs at the OUTPUT width and the 40 MB aggregate ``A H`` is
 neither written nor re-read (gae_xw_fwd / gae_spmm_csr_epilogue /
 gae_xw_wgrad); ``transform_first=False`` keeps the reference's order
-everywhere, ``True`` reorders every narrowing layer.  ``cache_aggregate``
+everywhere, ``True`` asks for the reorder on every narrowing layer (it takes
+effect wherever the one-pass kernels apply, like "auto").  ``cache_aggregate``
 (opt-in) keeps ``A H`` of a parameter-independent input across steps."""
 import torch
 import torch.nn as nn
@@ -93,8 +94,6 @@ class GCN(nn.Module):
         self.transform_auto = transform_first is None and in_feats > out_feats and not cache_aggregate
         self.cache_aggregate = bool(cache_aggregate)
         self._agg_key = self._agg = None
-        if self.transform_first:
-            self.register_buffer("_eye", torch.eye(out_feats), persistent=False)
 
     def _one_pass(self, g, feature):
         """the layer through ops.GCNTransformFirstFunction, or None when shapes / graph do not allow it"""
@@ -108,28 +107,14 @@ class GCN(nn.Module):
         lin = self.apply_mod.linear
         return ops.gcn_layer_transform_first(g, feature, lin.weight, lin.bias, code, use_norm=(mode == "both"))
 
-    def _forward_transform_first(self, g, feature):
-        out = self._one_pass(g, feature)
-        if out is not None:
-            return out
-        lin, act = self.apply_mod.linear, self.apply_mod.activation
-        if feature.dtype != torch.float32:
-            feature = ops.float_rows(feature) if feature.is_cuda and feature.dim() == 2 else feature.float()
-        g.ndata['h'] = ops.linear(feature, lin.weight, None, ACT_IDENTITY)        # H W^T
-        g.update_all(gcn_msg, gcn_reduce, norm=self.norm)                         # A (H W^T)
-        fused = _act_code(act)
-        # bias + activation through the same fused epilogue (identity weight): db and the ReLU mask come for free
-        out = ops.linear(g.ndata.pop('h'), self._eye, lin.bias, ACT_IDENTITY if fused is None else fused)
-        return out if fused is not None else act(out)
-
     def forward(self, g, feature):
-        if self.transform_first:
-            return self._forward_transform_first(g, feature)
         # same traffic on g.ndata['h'] as the reference: set (gae.py:27), reduced in place (:28), transformed in
         # place (:29), removed (:30)
         g.ndata['h'] = feature
         code = _act_code(self.apply_mod.activation)
-        if self.transform_auto and TRANSFORM_FIRST_AUTO:
+        if self.transform_first or (self.transform_auto and TRANSFORM_FIRST_AUTO):
+            # (where the one-pass kernels do not apply -- narrow inputs, graphs with heavy rows -- the layer keeps
+            #  the reference's order)
             out = self._one_pass(g, feature)
             if out is not None:
                 g.ndata.pop('h')

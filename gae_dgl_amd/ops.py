@@ -826,6 +826,121 @@ def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=Non
     return out
 
 
+def spmm_ep_raw(indptr, indices, H, n_rows, plan=None, bias=None, act=ACT_IDENTITY, row_scale=None, col_scale=None,
+                out=None, accumulate=False):
+    """M = act(diag(rs) A diag(cs) H (+ out, ``accumulate``) + bias): gae_spmm_csr with a store-time epilogue for ANY
+    plan (gae_spmm_csr_ep) -- the sparse half of a layer evaluated as act(A (H W^T) + b) on graphs whose plans carry
+    degree-skew segments / XCD-pinned rows.  fp32."""
+    H, ldh = _rowmajor(_f32(_gpu(H, "H"), "spmm_ep: H"), "H")
+    n_cols, F = H.shape
+    _f32(bias, "spmm_ep: bias")
+    if accumulate and out is None:
+        raise GaeHipError("spmm_ep: accumulate=True adds to `out`")
+    padded = out is None
+    if out is None:
+        out = torch.empty(n_rows, padded_ld(F, torch.float32), dtype=torch.float32, device=H.device)[:, :F]
+    out2, ldm = _rowmajor(out, "out")
+    if out2 is not out:
+        raise GaeHipError("spmm_ep: `out` must be row-major with unit inner stride")
+    flags = (_lib.SPMM_STORE_PAD if padded else 0) | (_lib.SPMM_ACCUMULATE if accumulate else 0)
+    with _on_device(H.device):
+        pc, ws, ws_bytes = None, None, 0
+        if plan is not None:
+            pc = ctypes.byref(plan.c)
+            ws_bytes = _lib.load().gae_spmm_workspace_bytes(pc, F)
+            ws = _workspace(ws_bytes, H.device)
+
+        def launch():
+            _lib.call("gae_spmm_csr_ep", _ptr(indptr), _ptr(indices), n_rows, n_cols, _ptr(H), ldh, _ptr(out), ldm, F,
+                      _ptr(row_scale), _ptr(col_scale), pc, _ptr(ws), ws_bytes, flags, _ptr(bias), int(act), _stream())
+        if profiler is not None:
+            profiler.wrap(("spmm", n_rows, n_cols, F, str(H.dtype)), launch)
+        else:
+            launch()
+    return out
+
+
+def linear2_usable(A, f_mid, f_out):
+    """can gae_linear2_fwd / gae_gcn2_bwd_dense take this operand?  fp32 rows of whole 16-byte vectors, widths <= 32"""
+    return (isinstance(A, torch.Tensor) and A.is_cuda and A.dtype == torch.float32 and A.dim() == 2 and A.shape[0] > 0
+            and 1 <= A.shape[1] <= 32 and 1 <= f_mid <= 32 and 1 <= f_out <= 32)
+
+
+def linear2_fwd_raw(A, W1, b1, act1, W2, want_y1=True):
+    """(Y1, T): Y1 = act1(A W1^T + b1), T = Y1 W2^T in ONE pass over A (gae_linear2_fwd); Y1 None when not wanted.
+    Both outputs have rows of whole 16-byte vectors."""
+    A, lda = _rowmajor(_f32(_gpu(A, "A"), "linear2: A"), "A")
+    if lda % 4 or A.data_ptr() % 16:
+        A = pad_rows(A); lda = A.stride(0)
+    W1 = _f32(_gpu(W1, "W1"), "linear2: W1"); W2 = _f32(_gpu(W2, "W2"), "linear2: W2")
+    W1 = W1 if W1.stride(1) == 1 else W1.contiguous()
+    W2 = W2 if W2.stride(1) == 1 else W2.contiguous()
+    _f32(b1, "linear2: b1")
+    n, f_in = A.shape
+    f_mid, f_out = W1.shape[0], W2.shape[0]
+    if W1.shape[1] != f_in or W2.shape[1] != f_mid:
+        raise GaeHipError("linear2: weight shapes do not chain")
+    dev = A.device
+    ld1, ld2 = (f_mid + 3) // 4 * 4, (f_out + 3) // 4 * 4
+    Y1 = torch.empty(n, ld1, dtype=torch.float32, device=dev)[:, :f_mid] if want_y1 else None
+    T = torch.empty(n, ld2, dtype=torch.float32, device=dev)[:, :f_out]
+    with _on_device(dev):
+        def launch():
+            _lib.call("gae_linear2_fwd", _ptr(A), lda, n, f_in, _ptr(W1), W1.stride(0), _ptr(b1), f_mid, int(act1),
+                      _ptr(W2), W2.stride(0), f_out, _ptr(Y1), ld1, _ptr(T), ld2, _stream())
+        if profiler is not None:
+            profiler.wrap(("linear2", n, f_in, f_mid, f_out), launch)
+        else:
+            launch()
+    return Y1, T
+
+
+def gcn2_bwd_dense_raw(G, dZ, Y1, act1, M1, W2):
+    """(dW1, db1, dW2, db2) of a two-layer encoder from G = A^T dZ in ONE pass over G, dZ, Y1, M1 (gae_gcn2_bwd_dense):
+    dW2 = G^T Y1, db2 = colsum(dZ), dY1 = (G W2) (.) act1'(Y1), dW1 = dY1^T M1, db1 = colsum(dY1).  Inside
+    ``deferred_grad_reductions()`` the four gradients stay per-block partial sums for optim.Adam.step()."""
+    G, ldg = _rowmajor(_f32(_gpu(G, "G"), "gcn2_bwd: G"), "G")
+    dZ, lddz = _rowmajor(_f32(_gpu(dZ, "dZ"), "gcn2_bwd: dZ"), "dZ")
+    if ldg % 4 or G.data_ptr() % 16:
+        G = pad_rows(G); ldg = G.stride(0)
+    if lddz % 4 or dZ.data_ptr() % 16:
+        dZ = pad_rows(dZ); lddz = dZ.stride(0)
+    Y1, ldy1 = _rowmajor(_f32(Y1, "gcn2_bwd: Y1"), "Y1")
+    M1, ldm1 = _rowmajor(_f32(M1, "gcn2_bwd: M1"), "M1")
+    W2 = _f32(W2, "gcn2_bwd: W2")
+    W2 = W2 if W2.stride(1) == 1 else W2.contiguous()
+    n, f_out = G.shape
+    f_mid, f_in = Y1.shape[1], M1.shape[1]
+    if dZ.shape != G.shape or W2.shape != (f_out, f_mid) or Y1.shape[0] != n or M1.shape[0] != n:
+        raise GaeHipError("gcn2_bwd: operand shapes do not match")
+    dev = G.device
+    dW1 = torch.empty(f_mid, f_in, dtype=torch.float32, device=dev)
+    db1 = torch.empty(f_mid, dtype=torch.float32, device=dev)
+    dW2 = torch.empty(f_out, f_mid, dtype=torch.float32, device=dev)
+    db2 = torch.empty(f_out, dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        nbytes = _lib.load().gae_gcn2_bwd_dense_workspace_bytes(n, f_in, f_mid, f_out)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "gae_gcn2_bwd_dense_workspace_bytes")
+        defer = _DEFER
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev) if defer else _workspace(nbytes, dev)
+        lay = (ctypes.c_int64 * 5)()
+
+        def launch():
+            _lib.call("gae_gcn2_bwd_dense", _ptr(G), ldg, _ptr(dZ), lddz, _ptr(Y1), ldy1, int(act1), _ptr(M1), ldm1,
+                      _ptr(W2), W2.stride(0), n, f_in, f_mid, f_out, _ptr(dW1), _ptr(db1), _ptr(dW2), _ptr(db2), _ptr(ws),
+                      ws.numel(), lay if defer else None, _stream())
+        if profiler is not None:
+            profiler.wrap(("gcn2_bwd", n, f_in, f_mid, f_out), launch)
+        else:
+            launch()
+    if defer:
+        base = ws.data_ptr()
+        for t, off, ne in ((dW1, 0, f_mid * f_in), (db1, lay[2], f_mid), (dW2, lay[3], f_out * f_mid), (db2, lay[4], f_out)):
+            _PENDING[t.data_ptr()] = (ws, base + 4 * off, lay[0], lay[1], ne, ne)
+    return dW1, db1, dW2, db2
+
+
 def linear_fwd_raw(M, W, b, act):
     M, ldm = _rowmajor(_f32(M, "linear: M"), "M")
     W = _f32(_gpu(W, "W"), "linear: W").contiguous()

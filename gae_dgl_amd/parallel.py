@@ -370,74 +370,133 @@ class ShardedGraph:
         return ShardedSpMMFunction.apply(h_local, self)
 
 
+def _rank_product(sg, t_local, which, constant=False, bias=None, act=0):
+    """this rank's rows of  act(A exchange(t) + bias)  (``which`` = "fwd": A_p, "bwd": A^T_p).  ``constant``: the
+    operand does not change between steps (input features): its exchanged rows are kept (sg.cache_constant_inputs).
+    The epilogue (bias, activation: ops.spmm_ep_raw) rides in the launch that finishes a row -- with the overlapped
+    exchange that is the remote-column product, which adds to the own-column one."""
+    from . import ops
+    n_local = sg.part.n_local
+    epi = bias is not None or act != 0
+    key = (t_local.data_ptr(), tuple(t_local.shape), t_local._version) if constant else None
+    hit = sg._xcache.get(which) if constant else None
+    hit = hit[1] if hit is not None and hit[0] == key else None
+
+    def product(ip, ix, H, plan, out=None, accumulate=False, last=True):
+        if epi and last:
+            return ops.spmm_ep_raw(ip, ix, H, n_local, plan, bias, act, out=out, accumulate=accumulate)
+        return ops.spmm_raw(ip, ix, H, n_local, out=out, plan=plan, accumulate=accumulate)
+
+    if not sg.part.overlap:
+        full = hit if hit is not None else sg._timed("exchange", lambda: sg.exchange(t_local, which))
+        if constant:
+            sg._xcache[which] = (key, full)
+        ip, ix = sg.csr(which)
+        return sg._timed("spmm", lambda: product(ip, ix, full, sg.plan(which)))
+    # own columns while the remote rows travel, then M += A_remote * received
+    if hit is not None:
+        recv, wait = hit, (lambda: None)
+    else:
+        recv, wait = sg._timed("exchange_start", lambda: sg.exchange_start(t_local, which))
+    oip, oix = sg.csr(which, "own")
+    rip, rix = sg.csr(which, "remote")
+    remote = rix.numel() > 0
+    out = sg._timed("spmm_own", lambda: product(oip, oix, t_local, sg.plan(which, "own"), last=not remote))
+    if hit is None:
+        sg._timed("exchange_wait", wait)
+        if constant:
+            sg._xcache[which] = (key, recv)
+    if remote:
+        sg._timed("spmm_remote", lambda: product(rip, rix, recv, sg.plan(which, "remote"), out=out, accumulate=True))
+    return out
+
+
 class ShardedSpMMFunction(torch.autograd.Function):
     """M_p = A_p exchange(H_p);  dH_p = A^T_p exchange(dM_p)"""
 
-    @staticmethod
-    def _product(sg, t_local, which, constant=False):
-        from . import ops
-        n_local = sg.part.n_local
-        key = (t_local.data_ptr(), tuple(t_local.shape), t_local._version) if constant else None
-        hit = sg._xcache.get(which) if constant else None
-        hit = hit[1] if hit is not None and hit[0] == key else None
-        if not sg.part.overlap:
-            full = hit if hit is not None else sg._timed("exchange", lambda: sg.exchange(t_local, which))
-            if constant:
-                sg._xcache[which] = (key, full)
-            ip, ix = sg.csr(which)
-            return sg._timed("spmm", lambda: ops.spmm_raw(ip, ix, full, n_local, plan=sg.plan(which)))
-        # own columns while the remote rows travel, then M += A_remote * received
-        if hit is not None:
-            recv, wait = hit, (lambda: None)
-        else:
-            recv, wait = sg._timed("exchange_start", lambda: sg.exchange_start(t_local, which))
-        oip, oix = sg.csr(which, "own")
-        out = sg._timed("spmm_own", lambda: ops.spmm_raw(oip, oix, t_local, n_local, plan=sg.plan(which, "own")))
-        if hit is None:
-            sg._timed("exchange_wait", wait)
-            if constant:
-                sg._xcache[which] = (key, recv)
-        rip, rix = sg.csr(which, "remote")
-        if rix.numel():
-            sg._timed("spmm_remote", lambda: ops.spmm_raw(rip, rix, recv, n_local, out=out, accumulate=True,
-                                                           plan=sg.plan(which, "remote")))
-        return out
+    _product = staticmethod(_rank_product)
 
     @staticmethod
     def forward(ctx, h_local, sg):
         ctx.sg = sg
         constant = bool(sg.cache_constant_inputs) and not ctx.needs_input_grad[0]
-        return ShardedSpMMFunction._product(sg, h_local.contiguous(), "fwd", constant)
+        return _rank_product(sg, h_local.contiguous(), "fwd", constant)
 
     @staticmethod
     def backward(ctx, dm_local):
-        return ShardedSpMMFunction._product(ctx.sg, dm_local.contiguous(), "bwd"), None
+        return _rank_product(ctx.sg, dm_local.contiguous(), "bwd"), None
+
+
+class ShardedEncoder2Function(torch.autograd.Function):
+    """The two-layer encoder of gae.py:36-45 on a row block, Z = A act1((A X) W1^T + b1) W2^T + b2, with the second
+    layer evaluated as A (H1 W2^T) + b2 and the backward pass from G = A^T dZ (csrc/tall.hip):
+
+        forward    M1 = A X                       product at the input width (exchange of X: once, if it is constant)
+                   H1, T = gae_linear2_fwd(M1)    one pass: H1 = act1(M1 W1^T + b1), T = H1 W2^T
+                   Z = A T + b2                   product at the OUTPUT width, bias in its epilogue (gae_spmm_csr_ep)
+        backward   G = A^T dZ                     product at the output width
+                   dW1, db1, dW2, db2 = gae_gcn2_bwd_dense(G, dZ, H1, M1)     one pass, dY1 never stored
+
+    Three products and two dense passes per step instead of three products at the hidden width and five dense
+    launches; A H1 is never formed, so two of the three exchanges between ranks move the output width.  Values equal the
+    reference's order up to fp32 rounding (tests/test_gpu_tall.py against the oracle).  X receives no gradient (input
+    features: train_transductive.py:38)."""
+
+    @staticmethod
+    def forward(ctx, x_local, W1, b1, W2, b2, sg, act1):
+        from . import ops
+        ctx.sg, ctx.act1 = sg, act1
+        constant = bool(sg.cache_constant_inputs)
+        M1 = _rank_product(sg, x_local.contiguous(), "fwd", constant)
+        need = any(ctx.needs_input_grad[1:5])
+        H1, T = sg._timed("dense_fwd", lambda: ops.linear2_fwd_raw(M1, W1, b1, act1, W2, want_y1=need))
+        Z = _rank_product(sg, T, "fwd", bias=b2)
+        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        if need:
+            ctx.save_for_backward(M1, H1, W2)
+        return Z
+
+    @staticmethod
+    def backward(ctx, dZ):
+        from . import ops
+        M1, H1, W2 = ctx.saved_tensors
+        sg = ctx.sg
+        dZc = dZ.contiguous()
+        G = _rank_product(sg, dZc, "bwd")
+        dW1, db1, dW2, db2 = sg._timed("dense_bwd", lambda: ops.gcn2_bwd_dense_raw(G, dZc, H1, ctx.act1, M1, W2))
+        return None, dW1, (db1 if ctx.has_b1 else None), dW2, (db2 if ctx.has_b2 else None), None, None
+
+
+def encoder2_usable(model, x_local):
+    """can ShardedEncoder2Function run this model?  Two layers, widths <= 32, fused-epilogue activations, fp32 input"""
+    from . import ops
+    from .gae import _act_code
+    if len(model.layers) != 2:
+        return False
+    l1, l2 = (m.apply_mod for m in model.layers)
+    if _act_code(l1.activation) is None or _act_code(l2.activation) != 0:
+        return False
+    return ops.linear2_usable(x_local, l1.linear.weight.shape[0], l2.linear.weight.shape[0])
 
 
 def sharded_encode(model, sg, x_local, transform_first=False):
     """GAE.encode on a row block: same layers, aggregation through the sharded SpMM.
-    ``transform_first``: layers that narrow the features are evaluated as ``act(A (H W^T) + b)`` -- the value of the
-    reference's ``act((A H) W^T + b)`` up to fp32 rounding (gae.GCN's opt-in reorder): the
-    aggregation AND its backward then move f_out instead of f_in floats per edge, and the exchange between ranks
-    shrinks by the same factor (RMAT layer 2, 32 -> 16: half the gathered and exchanged bytes)."""
+    ``transform_first``: evaluate the LAST layer as ``A (H W^T) + b`` -- the value of the reference's
+    ``(A H) W^T + b`` up to fp32 rounding -- through ShardedEncoder2Function (two-layer encoders of widths <= 32, e.g.
+    BASELINE config 4: 32 -> 32 -> 16): the second aggregation, its backward and both of their exchanges move the
+    output width, and the dense halves of the step are two one-pass kernels.  Other models keep the reference's order."""
     from . import ops
     from .gae import _act_code
-    from ._lib import ACT_IDENTITY
+    if transform_first and encoder2_usable(model, x_local):
+        l1, l2 = (m.apply_mod for m in model.layers)
+        return ShardedEncoder2Function.apply(x_local, l1.linear.weight, l1.linear.bias, l2.linear.weight, l2.linear.bias,
+                                             sg, _act_code(l1.activation))
     h = x_local
     for conv in model.layers:
         lin = conv.apply_mod.linear
         code = _act_code(conv.apply_mod.activation)
-        if transform_first and lin.weight.shape[0] < lin.weight.shape[1]:
-            t = ops.linear(h, lin.weight, None, ACT_IDENTITY)                    # H W^T
-            m = sg.spmm(t)                                                       # A (H W^T)
-            eye = getattr(sg, "_eye", {}).get(m.shape[1])
-            if eye is None:
-                sg._eye = getattr(sg, "_eye", {})
-                eye = sg._eye[m.shape[1]] = torch.eye(m.shape[1], device=m.device)
-            h = ops.linear(m, eye, lin.bias, code if code is not None else 0)    # + b, activation (fused epilogue)
-        else:
-            m = sg.spmm(h)
-            h = ops.linear(m, lin.weight, lin.bias, code if code is not None else 0)
+        m = sg.spmm(h)
+        h = ops.linear(m, lin.weight, lin.bias, code if code is not None else 0)
         if code is None:
             h = conv.apply_mod.activation(h)
     return h

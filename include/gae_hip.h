@@ -401,6 +401,39 @@ int gae_gcn_layer_fused2_wgrad(const int32_t *t_indptr, const int32_t *t_indices
                                int64_t ldw, int64_t f_in, float *dH, int64_t lddh, const float *M, int64_t ldm, float *dW,
                                float *db, void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream);
 
+/* gae_spmm_csr with a store-time epilogue, for ANY plan (degree-skew segments and XCD-pinned rows included):
+ *     M = act(diag(rs) A diag(cs) H (+ M, flag GAE_SPMM_ACCUMULATE) + bias)          fp32; bias [F] may be NULL
+ * The sparse half of a GCN layer evaluated as act(A (H W^T) + b) -- the value of gae_dgl/gae.py:26-31 up to fp32
+ * rounding -- on power-law graphs, where gae_spmm_csr_epilogue (packed-table plans) does not apply: R-MAT's 32 -> 16
+ * layer aggregates 16 instead of 32 floats per edge.  Same arguments, workspace and summation orders as gae_spmm_csr
+ * (GAE_SPMM_TILE is not accepted). */
+int gae_spmm_csr_ep(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                    const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F, const float *row_scale,
+                    const float *col_scale, const gae_spmm_plan *plan, void *workspace, int64_t workspace_bytes,
+                    int flags, const float *bias, int act, void *stream);
+
+/* ---- dense halves of a two-layer encoder on very tall operands (csrc/tall.hip) ---------------------------------
+ * gae_linear2_fwd:  Y1 = act1(A W1^T + b1) [n, f_mid],  T = Y1 W2^T [n, f_out]  in ONE pass over A [n, f_in]:
+ * NodeApplyModule of layer 1 (gae_dgl/gae.py:13-16) and the dense half of layer 2 evaluated transform-first.
+ * f_in <= 64, f_mid <= 32, f_out <= 32; rows of A, Y1, T whole 16-byte vectors; W1 [f_mid, f_in] (ldw1), W2 [f_out,
+ * f_mid] (ldw2) as nn.Linear stores them; b1 may be NULL; Y1 may be NULL (inference: only T is wanted). */
+int gae_linear2_fwd(const float *A, int64_t lda, int64_t n, int64_t f_in, const float *W1, int64_t ldw1,
+                    const float *b1, int64_t f_mid, int act1, const float *W2, int64_t ldw2, int64_t f_out,
+                    float *Y1, int64_t ldy1, float *T, int64_t ldt, void *stream);
+/* gae_gcn2_bwd_dense: every dense product of that encoder's backward pass in ONE pass over its four tall operands
+ * (train_inductive.py:51 for the model of gae.py:36-45 with two layers), given G = A^T dZ [n, f_out]:
+ *     dW2 = G^T Y1,  db2 = colsum(dZ),  dY1 = (G W2) (.) act1'(Y1),  dW1 = dY1^T M1,  db1 = colsum(dY1)
+ * Y1 [n, f_mid] = the output of layer 1, M1 [n, f_in] = its stored aggregate A X; widths <= 32; rows of G and dZ whole
+ * 16-byte vectors.  dY1 is never stored.  Per-block partial sums go to `workspace` (gae_gcn2_bwd_dense_workspace_bytes)
+ * and are added in block order (deterministic).  layout_out != NULL: stop after the partials (dW1 .. db2 are not
+ * written) and report {n_partials, floats per partial, offset of db1, of dW2, of db2} (dW1 at 0) for gae_adam_step's
+ * deferred reduction. */
+int64_t gae_gcn2_bwd_dense_workspace_bytes(int64_t n, int64_t f_in, int64_t f_mid, int64_t f_out);
+int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, int64_t lddz, const float *Y1, int64_t ldy1,
+                       int act1, const float *M1, int64_t ldm1, const float *W2, int64_t ldw2, int64_t n,
+                       int64_t f_in, int64_t f_mid, int64_t f_out, float *dW1, float *db1, float *dW2, float *db2,
+                       void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream);
+
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16
  * M [n, f_in] (ldm), W [f_out, f_in] row-major contiguous (nn.Linear.weight,

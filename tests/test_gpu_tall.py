@@ -1,0 +1,212 @@
+"""Round 4: the two-layer encoder for graphs with millions of rows (BASELINE config 4) -- gae_spmm_csr_ep (store-time
+bias / activation for ANY plan), gae_linear2_fwd, gae_gcn2_bwd_dense (csrc/tall.hip) and the row-sharded function built
+from them (parallel.ShardedEncoder2Function) -- each against an fp64 restatement of gae.py:26-31,36-45 and its
+autograd; the composed step against the oracle's reference-order encoder."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu(); b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def skew_graph(seed, n, e):
+    """heavy rows (thousands of edges), duplicates, empty rows"""
+    rng = np.random.default_rng(seed)
+    dst = (rng.integers(0, n, e).astype(np.float64) ** 4 / n ** 3).astype(np.int64)
+    src = (rng.integers(0, n, e).astype(np.float64) ** 2 / n).astype(np.int64)
+    return rng, torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV)
+
+
+def dense_A(src, dst, n):
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A.index_put_((dst.cpu(), src.cpu()), torch.ones(src.numel(), dtype=torch.float64), accumulate=True)
+    return A
+
+
+@pytest.mark.parametrize("F", [16, 32, 20])
+@pytest.mark.parametrize("kind", ["none", "segments", "pinned"])
+def test_spmm_ep_bias_activation_every_plan(F, kind):
+    """act(A H + bias) at store time: light rows (row-group kernel), single-segment rows, combined segments, XCD-pinned
+    rows; with the accumulate flag the epilogue applies to the accumulated value"""
+    from gae_dgl_amd import ops
+    n, e = 5000, 300000
+    rng, src, dst = skew_graph(F, n, e)
+    ip, ix = ops.csr_from_coo(dst, src, n, n)
+    plan = None
+    if kind == "segments":
+        plan = ops.spmm_plan(ip, threshold=8, segment=128, indices=ix, ell=False, hot=False, n_cols=n, homed=False)
+        assert plan.n_heavy > 0
+    elif kind == "pinned":
+        plan = ops.spmm_plan(ip, threshold=8, segment=128, indices=ix, ell=False, hot=True, n_cols=n, homed=True)
+        assert plan.homed is not None
+    H = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rng.standard_normal(F).astype(np.float32)).to(DEV)
+    A = dense_A(src, dst, n)
+    ref = A @ H.double().cpu()
+    scale = float(ref.abs().max())
+    for bias, act in ((b, 0), (b, 1), (None, 1), (None, 0)):
+        y = ops.spmm_ep_raw(ip, ix, H, n, plan, bias, act)
+        want = ref + (bias.double().cpu() if bias is not None else 0)
+        want = torch.relu(want) if act else want
+        assert float((y.double().cpu() - want).abs().max()) <= TOL * scale
+    # plain launches are untouched by the epilogue arguments: same bits as gae_spmm_csr
+    assert torch.equal(ops.spmm_ep_raw(ip, ix, H, n, plan, None, 0), ops.spmm_raw(ip, ix, H, n, plan=plan))
+    # accumulate: out = relu(base + A H + b)
+    base = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(DEV)
+    out = base.clone()
+    ops.spmm_ep_raw(ip, ix, H, n, plan, b, 1, out=out, accumulate=True)
+    want = torch.relu(base.double().cpu() + ref + b.double().cpu())
+    assert float((out.double().cpu() - want).abs().max()) <= TOL * max(scale, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("n,f_in,f_mid,f_out", [(5000, 32, 32, 16), (777, 17, 20, 7), (33, 32, 32, 32), (4097, 8, 5, 3),
+                                                (100000, 32, 32, 16)])
+@pytest.mark.parametrize("act", [1, 0])
+def test_linear2_fwd_matches_fp64(n, f_in, f_mid, f_out, act):
+    from gae_dgl_amd import ops
+    g = torch.Generator().manual_seed(n + f_in)
+    A = torch.randn(n, f_in, generator=g)
+    W1 = torch.randn(f_mid, f_in, generator=g) / f_in ** 0.5
+    b1 = torch.randn(f_mid, generator=g)
+    W2 = torch.randn(f_out, f_mid, generator=g) / f_mid ** 0.5
+    ld = (f_in + 3) // 4 * 4
+    buf = torch.full((n, ld), float("nan"), device=DEV)            # pad columns must never reach a sum
+    buf[:, :f_in] = A.to(DEV)
+    y_ref = A.double() @ W1.double().t() + b1.double()
+    y_ref = torch.relu(y_ref) if act else y_ref
+    t_ref = y_ref @ W2.double().t()
+    for bias in (b1.to(DEV), None):
+        Y1, T = ops.linear2_fwd_raw(buf[:, :f_in], W1.to(DEV), bias, act, W2.to(DEV))
+        if bias is None:
+            yr = A.double() @ W1.double().t()
+            yr = torch.relu(yr) if act else yr
+            assert rel(Y1, yr) < TOL and rel(T, yr @ W2.double().t()) < TOL
+        else:
+            assert Y1.shape == (n, f_mid) and T.shape == (n, f_out)
+            assert rel(Y1, y_ref) < TOL and rel(T, t_ref) < TOL
+    _, T2 = ops.linear2_fwd_raw(buf[:, :f_in], W1.to(DEV), b1.to(DEV), act, W2.to(DEV), want_y1=False)
+    assert rel(T2, t_ref) < TOL
+
+
+@pytest.mark.parametrize("n,f_in,f_mid,f_out", [(5000, 32, 32, 16), (777, 17, 20, 7), (33, 32, 32, 32), (4097, 8, 5, 3),
+                                                (100000, 32, 32, 16)])
+@pytest.mark.parametrize("act", [1, 0])
+def test_gcn2_bwd_dense_matches_fp64(n, f_in, f_mid, f_out, act):
+    from gae_dgl_amd import ops
+    g = torch.Generator().manual_seed(n + f_out)
+    G = torch.randn(n, f_out, generator=g)
+    dZ = torch.randn(n, f_out, generator=g)
+    Y1 = torch.randn(n, f_mid, generator=g)
+    if act:
+        Y1 = torch.relu(Y1)
+    M1 = torch.randn(n, f_in, generator=g)
+    W2 = torch.randn(f_out, f_mid, generator=g)
+    dW1, db1, dW2, db2 = ops.gcn2_bwd_dense_raw(G.to(DEV), dZ.to(DEV), Y1.to(DEV), act, M1.to(DEV), W2.to(DEV))
+    Gd, Yd = G.double(), Y1.double()
+    dY1 = Gd @ W2.double()
+    if act:
+        dY1 = dY1 * (Yd > 0)
+    assert rel(dW2, Gd.t() @ Yd) < TOL
+    assert rel(db2, dZ.double().sum(0)) < TOL
+    assert rel(dW1, dY1.t() @ M1.double()) < TOL
+    assert rel(db1, dY1.sum(0)) < TOL
+    # deterministic
+    again = ops.gcn2_bwd_dense_raw(G.to(DEV), dZ.to(DEV), Y1.to(DEV), act, M1.to(DEV), W2.to(DEV))
+    assert all(torch.equal(a, b) for a, b in zip((dW1, db1, dW2, db2), again))
+
+
+def _encoder_reference(src, dst, n, X, Ws, bs, dZ):
+    """fp64: Z = A relu((A X) W1^T + b1) W2^T + b2 (gae.py:26-31,36-45) and the gradients of <Z, dZ>"""
+    A = dense_A(src, dst, n)
+    P = [torch.as_tensor(t).double().clone().requires_grad_(True) for t in (Ws[0], bs[0], Ws[1], bs[1])]
+    H1 = torch.relu((A @ X.double().cpu()) @ P[0].t() + P[1])
+    Z = (A @ H1) @ P[2].t() + P[3]
+    (Z * dZ.double().cpu()).sum().backward()
+    return Z.detach(), [p.grad for p in P]
+
+
+@pytest.mark.parametrize("mode,overlap", [("allgather", False), ("boundary", False), ("boundary", True), ("allgather", True)])
+def test_encoder2_one_rank_group_matches_reference_order(mode, overlap):
+    """the whole function under a real (1-rank RCCL) process group: embeddings and all four gradients against the fp64
+    reference-order encoder; with deferred gradient reductions + the library's Adam the update equals the eager one"""
+    import torch.distributed as dist
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, optim
+    from gae_dgl_amd.parallel import ShardedGraph, sharded_encode, encoder2_usable
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29657")
+    torch.cuda.set_device(0)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        n, e, F = 4000, 200000, 32
+        rng, src, dst = skew_graph(7, n, e)
+        X = torch.from_numpy(rng.random((n, F)).astype(np.float32)).to(DEV)
+        dZ = torch.from_numpy(rng.standard_normal((n, 16)).astype(np.float32)).to(DEV) / n
+        torch.manual_seed(0)
+        model = G.GAE(F, [32, 16]).to(DEV)
+        assert encoder2_usable(model, X)
+        sg = ShardedGraph(n, src, dst, mode=mode, device=DEV, overlap=overlap)
+        sg.cache_constant_inputs = True
+        Ws = [l.apply_mod.linear.weight.detach().cpu() for l in model.layers]
+        bs = [l.apply_mod.linear.bias.detach().cpu() for l in model.layers]
+        z_ref, g_ref = _encoder_reference(src, dst, n, X, Ws, bs, dZ)
+        for rep in range(2):                       # second pass: the exchanged rows of X come from the cache
+            model.zero_grad()
+            z = sharded_encode(model, sg, X, transform_first=True)
+            z.backward(dZ)
+            assert rel(z, z_ref) < TOL
+            got = [model.layers[0].apply_mod.linear.weight.grad, model.layers[0].apply_mod.linear.bias.grad,
+                   model.layers[1].apply_mod.linear.weight.grad, model.layers[1].apply_mod.linear.bias.grad]
+            for a, b in zip(got, g_ref):
+                assert rel(a, b) < 5 * TOL
+        # reference order through the same sharded graph: same values within the tolerance
+        model.zero_grad()
+        z0 = sharded_encode(model, sg, X, transform_first=False)
+        assert rel(z0, z_ref) < TOL
+        # deferred reductions: partial sums consumed by the optimiser launch == eager gradients + eager Adam
+        import copy
+        m_a, m_b = copy.deepcopy(model), copy.deepcopy(model)
+        o_a, o_b = optim.Adam(m_a.parameters(), lr=1e-2), optim.Adam(m_b.parameters(), lr=1e-2)
+        za = sharded_encode(m_a, sg, X, transform_first=True); o_a.zero_grad(); za.backward(dZ); o_a.step()
+        with ops.deferred_grad_reductions():
+            zb = sharded_encode(m_b, sg, X, transform_first=True)
+            ops.backward((zb * dZ).sum(), list(m_b.parameters()))
+            o_b.step()
+        for pa, pb in zip(m_a.parameters(), m_b.parameters()):
+            assert float((pa - pb).abs().max()) <= 1e-6 * float(pa.abs().max())
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3])
+@pytest.mark.parametrize("mode,overlap", [("allgather", False), ("boundary", False), ("boundary", True)])
+def test_virtual_ranks_product_with_epilogue(world, mode, overlap):
+    """the sharded product with bias + activation in its last launch: every virtual rank's rows == the single-GPU rows"""
+    from gae_dgl_amd import ops
+    from gae_dgl_amd.parallel import LocalGroup, ShardedGraph, _rank_product
+    n, e, F = 3000, 150000, 16
+    rng, src, dst = skew_graph(11, n, e)
+    T = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rng.standard_normal(F).astype(np.float32)).to(DEV)
+    want = torch.relu(dense_A(src, dst, n) @ T.double().cpu() + b.double().cpu())
+    grp = LocalGroup(world)
+    rows = []
+    for r in range(world):
+        sg = ShardedGraph(n, src, dst, rank=r, group=grp, mode=mode, device=DEV, overlap=overlap)
+        p = sg.part
+        grp.publish(T)
+        rows.append(_rank_product(sg, T[p.r0:p.r1].contiguous(), "fwd", bias=b, act=1))
+    got = torch.cat(rows)
+    assert float((got.double().cpu() - want).abs().max()) <= TOL * float(want.abs().max())
