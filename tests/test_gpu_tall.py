@@ -51,22 +51,23 @@ def test_spmm_ep_bias_activation_every_plan(F, kind):
         assert plan.homed is not None
     H = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(DEV)
     b = torch.from_numpy(rng.standard_normal(F).astype(np.float32)).to(DEV)
-    A = dense_A(src, dst, n)
-    ref = A @ H.double().cpu()
+    M = ops.spmm_raw(ip, ix, H, n, plan=plan)                      # (itself held to the oracle by test_gpu_parity.py)
+    ref = dense_A(src, dst, n) @ H.double().cpu()
     scale = float(ref.abs().max())
+    assert float((M.double().cpu() - ref).abs().max()) <= (TOL if plan is not None else 1e-4) * scale   # ('none': rows of
+    #                                                       60 k terms in one fp32 chain)
     for bias, act in ((b, 0), (b, 1), (None, 1), (None, 0)):
         y = ops.spmm_ep_raw(ip, ix, H, n, plan, bias, act)
-        want = ref + (bias.double().cpu() if bias is not None else 0)
+        want = M + bias if bias is not None else M                 # one fp32 add, then max: the kernel's own arithmetic
         want = torch.relu(want) if act else want
-        assert float((y.double().cpu() - want).abs().max()) <= TOL * scale
-    # plain launches are untouched by the epilogue arguments: same bits as gae_spmm_csr
-    assert torch.equal(ops.spmm_ep_raw(ip, ix, H, n, plan, None, 0), ops.spmm_raw(ip, ix, H, n, plan=plan))
-    # accumulate: out = relu(base + A H + b)
+        assert torch.equal(y, want)
+    # accumulate: out = relu((A H + base) + b), the epilogue on the accumulated value
     base = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(DEV)
     out = base.clone()
     ops.spmm_ep_raw(ip, ix, H, n, plan, b, 1, out=out, accumulate=True)
-    want = torch.relu(base.double().cpu() + ref + b.double().cpu())
-    assert float((out.double().cpu() - want).abs().max()) <= TOL * max(scale, float(want.abs().max()))
+    acc = base.clone()
+    ops.spmm_raw(ip, ix, H, n, out=acc, plan=plan, accumulate=True)
+    assert torch.equal(out, torch.relu(acc + b))
 
 
 @pytest.mark.parametrize("n,f_in,f_mid,f_out", [(5000, 32, 32, 16), (777, 17, 20, 7), (33, 32, 32, 32), (4097, 8, 5, 3),
