@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
     const T *__restrict__ H, int64_t ldh, T *__restrict__ M, int64_t ldm, int F,
     const float *__restrict__ row_scale, const float *__restrict__ col_scale, unsigned n_row_blocks,
     unsigned n_ftiles, int xcd_tiled, int tile_w, int skip_deg, int store_pad, int store_mode,
-    const int32_t *__restrict__ ell, int accumulate, const float *__restrict__ ep_bias, int ep_act)
+    const int32_t *__restrict__ ell, int accumulate, const float *__restrict__ ep_bias, int ep_act,
+    const int32_t *__restrict__ light_desc, int64_t n_light)
 {
     constexpr int GPB = 256 / LPR;            // groups per block
     constexpr int RPB = GPB * RPG;            // rows per block
@@ -362,7 +363,19 @@ __global__ __launch_bounds__(256) void spmm_rowgroup2_kernel(
             for (int i = 0; i < VEC; ++i) acc[r][c][i] = 0.f;
     }
 
-    if (ELLW > 0) {
+    if (ELLW == 0 && light_desc != nullptr) {
+        // ---- light-row list of a skew plan (gae_spmm_plan::light_desc): item -> {row, first edge, end edge}; every
+        //      lane group of the wave has edges to gather, no row-pointer loads
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) {
+            const int64_t item = row[r];
+            const bool iv = item < n_light;
+            const int4 d = *reinterpret_cast<const int4 *>(light_desc + (iv ? item : 0) * 4);
+            row[r] = iv ? int64_t(d.x) : n_rows;
+            pos[r] = iv ? d.y : 0;
+            end[r] = iv ? d.z : 0;
+        }
+    } else if (ELLW > 0) {
         // ---- packed-table phase: slot k of a row sits in lane k % LPR, register k / LPR of its group
         constexpr int KI = ELLW > LPR ? ELLW / LPR : 1;
         int32_t slot[RPG][KI];
@@ -496,10 +509,121 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const int32_t *__restric
     ell[idx] = v;
 }
 
+// Empty rows of a skew plan with a light-row list: M[row] = act(0 (+ M[row]) + bias) for every row WITHOUT in-edges --
+// a pure stream (one lane per 16-byte vector; the row pointers come from L1).  Rows with edges are written by the
+// list / segment / combine kernels.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void spmm_fill_empty_kernel(const int32_t *__restrict__ indptr, int64_t n_rows,
+                                                              T *__restrict__ M, int64_t ldm, int F, int nvec,
+                                                              int store_pad, int accumulate,
+                                                              const float *__restrict__ ep_bias, int ep_act)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_rows * nvec; t += stride) {
+        const int64_t row = t / nvec;
+        const int f = int(t - row * nvec) * VEC;
+        if (indptr[row + 1] != indptr[row]) continue;
+        T *mp = M + row * ldm + f;
+        float v[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+        if (accumulate) add_old<T, VEC>(mp, v, F - f);
+        epilogue<VEC>(v, ep_bias, ep_act, f, F);
+        if (VEC == 1 || f + VEC <= F || store_pad) {
+            VecIO<T, VEC>::store_nt(mp, v);
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (f + i < F) store_scalar(mp + i, v[i]);
+        }
+    }
+}
+
+// ---- light-row list of a plan: deterministic compaction (ascending rows) in three launches
+constexpr int kLightRowsPerBlock = 1024;
+__device__ __forceinline__ bool is_light(const int32_t *indptr, int64_t r, int64_t n_rows, int threshold)
+{
+    if (r >= n_rows) return false;
+    const int d = indptr[r + 1] - indptr[r];
+    return d >= 1 && d <= threshold;
+}
+__global__ __launch_bounds__(256) void light_count_kernel(const int32_t *__restrict__ indptr, int64_t n_rows, int threshold,
+                                                          unsigned long long *__restrict__ block_counts,
+                                                          unsigned long long *__restrict__ total)
+{
+    const int64_t r0 = int64_t(blockIdx.x) * kLightRowsPerBlock;
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c += is_light(indptr, r0 + q * 256 + threadIdx.x, n_rows, threshold) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    __shared__ int wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+        if (block_counts) block_counts[blockIdx.x] = t;
+        if (total && t) atomicAdd(total, t);                      // integer count: order does not matter
+    }
+}
+// exclusive prefix sums of the block counts, in place (one block; n_blocks is a few ten thousand)
+__global__ __launch_bounds__(1024) void light_scan_kernel(unsigned long long *__restrict__ counts, int64_t n_blocks)
+{
+    __shared__ unsigned long long part[1024];
+    const int64_t per = (n_blocks + 1023) / 1024;
+    const int64_t b0 = int64_t(threadIdx.x) * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+    unsigned long long sum = 0;
+    for (int64_t b = b0; b < b1; ++b) sum += counts[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int t = 0; t < 1024; ++t) { const unsigned long long v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (int64_t b = b0; b < b1; ++b) { const unsigned long long v = counts[b]; counts[b] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void light_fill_kernel(const int32_t *__restrict__ indptr, int64_t n_rows, int threshold,
+                                                         const unsigned long long *__restrict__ block_offsets,
+                                                         int32_t *__restrict__ light_desc, int64_t n_light)
+{
+    __shared__ int wbase[4][4];
+    const int64_t r0 = int64_t(blockIdx.x) * kLightRowsPerBlock;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool f[4];
+    int before[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {          // rows r0 + q * 256 + tid: ascending with (q, wave, lane)
+        f[q] = is_light(indptr, r0 + q * 256 + threadIdx.x, n_rows, threshold);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(f[q]);
+        before[q] = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wbase[q][wave] = __builtin_popcountll(m);
+    }
+    __syncthreads();
+    int base = 0;                          // listed rows of this block in front of (q, wave, lane 0)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int mine = base;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) mine += wbase[q][w];
+            base += wbase[q][w];
+        }
+        if (f[q]) {
+            const int64_t r = r0 + q * 256 + threadIdx.x;
+            const int64_t slot = int64_t(block_offsets[blockIdx.x]) + mine + before[q];
+            if (slot < n_light)
+                *reinterpret_cast<int4 *>(light_desc + slot * 4) = make_int4(int32_t(r), indptr[r], indptr[r + 1], 0);
+        }
+    }
+}
+
 // tuning knobs (gae_tuning_set): read-mostly process-wide integers
 gae::Knob g_spmm_variant{2};   // 1 = v1 rowgroup, 2 = v2 rowgroup2
 gae::Knob g_spmm_rpg{0};       // rows per lane group (v2): 0 = auto (2 for launches of >= 32768 waves, else 1), 1, 2
 gae::Knob g_spmm_parts{7};     // "spmm_parts" (experiments): which parts of a skew-plan launch run: 1 light rows | 2 segmented rows | 4 pinned rows
+gae::Knob g_spmm_light{1};     // "spmm_light": use the plan's light-row list (1) or sweep all rows with the row-group kernel (0); bit-identical
 gae::Knob g_spmm_desc{1};      // "spmm_desc": segment descriptors / identity segments (1) or the plan's index chain (0); bit-identical
 gae::Knob g_spmm_hot{1};       // "spmm_hot": use the plan's hot-column tags (streaming loads of cold rows); 0 = plain loads
 gae::Knob g_spmm_nt{-1};       // store policy of M (v2): -1 = auto (sc1 under feature tiles, else nt), 0 plain, 1 non-temporal, 2 write-through sc1
@@ -513,20 +637,22 @@ template <typename T, int VEC, int LPR, int CH, int RPG>
 int launch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
                      int64_t ldm, int F, const float *rs, const float *cs, int st, int tile_vecs, int skip_deg,
                      int flags, const int32_t *ell, hipStream_t s, const float *ep_bias = nullptr,
-                     int ep_act = GAE_ACT_IDENTITY)
+                     int ep_act = GAE_ACT_IDENTITY, const int32_t *light_desc = nullptr, int64_t n_light = 0)
 {
     const int store_pad = ((flags & GAE_SPMM_STORE_PAD) && (F + VEC - 1) / VEC * VEC <= ldm) ? 1 : 0;
     constexpr int RPB = (256 / LPR) * RPG;
     const int nvec = (F + VEC - 1) / VEC;
     const bool tiled = tile_vecs > 0;
     const int tw = tiled ? tile_vecs : LPR * CH;   // 16-byte vectors per feature tile
-    const unsigned nrb = unsigned((n_rows + RPB - 1) / RPB), nft = unsigned((nvec + tw - 1) / tw);
+    const int64_t n_items = light_desc ? n_light : n_rows;
+    if (n_items == 0) return GAE_OK;
+    const unsigned nrb = unsigned((n_items + RPB - 1) / RPB), nft = unsigned((nvec + tw - 1) / tw);
     const dim3 grid = tiled ? dim3(gae::kNumXcd * ((nft + gae::kNumXcd - 1) / gae::kNumXcd) * nrb) : dim3(nrb, nft);
     const int xt = tiled ? 1 : 0;
 #define GAE_L2(SC, EW)                                                                                              \
     hipLaunchKernelGGL((spmm_rowgroup2_kernel<T, VEC, LPR, CH, RPG, SC, EW>), grid, dim3(256), 0, s, indptr, indices,  \
                        n_rows, H, ldh, M, ldm, F, rs, cs, nrb, nft, xt, tw * VEC, skip_deg, store_pad, store_mode, ell,        \
-                       (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0, ep_bias, ep_act)
+                       (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0, ep_bias, ep_act, light_desc, n_light)
     constexpr int EW = VEC > 1 ? kEllWidth : 0;
     // store policy: 0 plain, 1 non-temporal, 2 write-through sc1; auto (-1) = sc1 under XCD feature tiles (the
     // output stream must not evict the tile's L2-resident slice of H), non-temporal otherwise
@@ -559,11 +685,13 @@ template <typename T, int VEC>
 int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, const T *H, int64_t ldh, T *M,
                        int64_t ldm, int F, const float *rs, const float *cs, int rpg, int st, int64_t n_cols,
                        int skip_deg, int flags, const int32_t *ell, int ell_width, hipStream_t s,
-                       const float *ep_bias = nullptr, int ep_act = GAE_ACT_IDENTITY)
+                       const float *ep_bias = nullptr, int ep_act = GAE_ACT_IDENTITY,
+                       const int32_t *light_desc = nullptr, int64_t n_light = 0)
 {
     const int nvec = (F + VEC - 1) / VEC;
     int tile_vecs = 0;
     if (ep_bias != nullptr || ep_act != GAE_ACT_IDENTITY) ell = nullptr;   // the epilogue lives in the row-group kernel
+    if (light_desc != nullptr) ell = nullptr;
     // XCD feature tiles (GAE_SPMM_TILE): wide rows, poor gather locality, rows made of whole 128-byte lines
     if (VEC > 1 && nvec > 16 && g_spmm_tile_vecs >= 0) {
         const bool lines = (ldh * sizeof(T)) % 128 == 0 && (ldm * sizeof(T)) % 128 == 0 &&
@@ -592,13 +720,15 @@ int dispatch_rowgroup2(const int32_t *indptr, const int32_t *indices, int64_t n_
         /* two rows per lane group halve the wave count: pays once the launch is many occupancy rounds long   \
          * (ZINC set 362 -> 288 us), costs parallelism on short ones (Pubmed F = 32: 4.0 -> 5.2 us) */           \
         const int64_t tw_ = tile_vecs > 0 ? tile_vecs : LPR * CH;      /* vectors per feature tile */           \
-        const int64_t waves_ = n_rows * LPR / 64 * ((nvec + tw_ - 1) / tw_);                                     \
+        const int64_t waves_ = (light_desc ? n_light : n_rows) * LPR / 64 * ((nvec + tw_ - 1) / tw_);            \
         const int rpg_ = rpg > 0 ? rpg : (waves_ >= 32768 ? 2 : 1);                                               \
         if (rpg_ >= 2 && CH == 1)                                                                                 \
             return launch_rowgroup2<T, VEC, LPR, CH, 2>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, st,   \
-                                                        tile_vecs, skip_deg, flags, ell, s, ep_bias, ep_act);     \
+                                                        tile_vecs, skip_deg, flags, ell, s, ep_bias, ep_act,      \
+                                                        light_desc, n_light);                                     \
         return launch_rowgroup2<T, VEC, LPR, CH, 1>(indptr, indices, n_rows, H, ldh, M, ldm, F, rs, cs, st,       \
-                                                    tile_vecs, skip_deg, flags, ell, s, ep_bias, ep_act);         \
+                                                    tile_vecs, skip_deg, flags, ell, s, ep_bias, ep_act,          \
+                                                    light_desc, n_light);                                         \
     } while (0)
     if (tile_vecs > 0) {
         const int tv = tile_vecs;
@@ -1108,7 +1238,21 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
     const int skip = (heavy || homed) ? plan->threshold : 0x7fffffff;
     const int min_f = vec ? (sizeof(T) == 4 ? 12 : 24) : 3;
     int rc = GAE_OK;
+    const bool listed = (heavy || homed) && plan->light_desc != nullptr && g_spmm_light && f > min_f;
     if ((heavy || homed) && !(g_spmm_parts & 1)) {
+    } else if (listed) {
+        // empty rows: a pure stream; rows with 1 .. threshold edges: the plan's list (every lane group has work)
+        const int nvec = (f + VEC - 1) / VEC;
+        const int store_pad = ((flags & GAE_SPMM_STORE_PAD) && int64_t(nvec) * VEC <= ldm) ? 1 : 0;
+        const int acc_f = (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0;
+        if (!acc_f || epi) {
+            const int64_t want = (n_rows * nvec + 255) / 256;
+            hipLaunchKernelGGL((spmm_fill_empty_kernel<T, VEC>), dim3(unsigned(want < 16384 ? want : 16384)), dim3(256), 0, s,
+                               indptr, n_rows, m, ldm, f, nvec, store_pad, acc_f, ep_bias, ep_act);
+            GAE_CHECK_LAUNCH("spmm_fill_empty_kernel");
+        }
+        rc = dispatch_rowgroup2<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, g_spmm_rpg, g_spmm_nt, n_cols,
+                                        skip, flags, nullptr, 0, s, ep_bias, ep_act, plan->light_desc, plan->n_light);
     } else if ((g_spmm_variant == 2 || epi) && f > min_f)
         rc = dispatch_rowgroup2<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, g_spmm_rpg,
                                         g_spmm_nt, n_cols, skip, flags,
@@ -1201,6 +1345,48 @@ extern "C" int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t
     hipLaunchKernelGGL(plan_fill_kernel, dim3(unsigned(g)), dim3(256), 0, s, indptr, n_rows, threshold, segment_edges,
                        reinterpret_cast<unsigned long long *>(cursors_dev), heavy_rows, heavy_seg_base, seg_heavy);
     GAE_CHECK_LAUNCH("plan_fill_kernel");
+    return GAE_OK;
+}
+
+extern "C" int gae_spmm_plan_light_count(const int32_t *indptr, int64_t n_rows, int32_t threshold, uint64_t *count_dev,
+                                         void *stream)
+{
+    GAE_REQUIRE(n_rows >= 0 && threshold >= 1, GAE_E_SIZE, "gae_spmm_plan_light_count: bad size");
+    GAE_REQUIRE(count_dev != nullptr, GAE_E_NULL, "gae_spmm_plan_light_count: NULL pointer");
+    hipStream_t s = gae::as_stream(stream);
+    GAE_HIP(hipMemsetAsync(count_dev, 0, sizeof(uint64_t), s));
+    if (n_rows == 0) return GAE_OK;
+    GAE_REQUIRE(indptr != nullptr, GAE_E_NULL, "gae_spmm_plan_light_count: NULL pointer");
+    const int64_t nb = (n_rows + kLightRowsPerBlock - 1) / kLightRowsPerBlock;
+    hipLaunchKernelGGL(light_count_kernel, dim3(unsigned(nb)), dim3(256), 0, s, indptr, n_rows, int(threshold), nullptr,
+                       reinterpret_cast<unsigned long long *>(count_dev));
+    GAE_CHECK_LAUNCH("light_count_kernel");
+    return GAE_OK;
+}
+
+extern "C" int64_t gae_spmm_plan_light_workspace_bytes(int64_t n_rows)
+{
+    if (n_rows < 0) return GAE_E_SIZE;
+    return ((n_rows + kLightRowsPerBlock - 1) / kLightRowsPerBlock + 1) * 8 + 256;
+}
+
+extern "C" int gae_spmm_plan_light(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t *light_desc,
+                                   int64_t n_light, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    GAE_REQUIRE(n_rows >= 0 && threshold >= 1 && n_light >= 0, GAE_E_SIZE, "gae_spmm_plan_light: bad size");
+    if (n_rows == 0 || n_light == 0) return GAE_OK;
+    GAE_REQUIRE(indptr && light_desc && workspace, GAE_E_NULL, "gae_spmm_plan_light: NULL pointer");
+    GAE_REQUIRE(gae::aligned16(light_desc) && gae::aligned16(workspace) &&
+                    workspace_bytes >= gae_spmm_plan_light_workspace_bytes(n_rows), GAE_E_WORKSPACE,
+                "gae_spmm_plan_light: workspace too small or buffers not 16-byte aligned");
+    hipStream_t s = gae::as_stream(stream);
+    unsigned long long *bc = static_cast<unsigned long long *>(workspace);
+    const int64_t nb = (n_rows + kLightRowsPerBlock - 1) / kLightRowsPerBlock;
+    hipLaunchKernelGGL(light_count_kernel, dim3(unsigned(nb)), dim3(256), 0, s, indptr, n_rows, int(threshold), bc, nullptr);
+    hipLaunchKernelGGL(light_scan_kernel, dim3(1), dim3(1024), 0, s, bc, nb);
+    hipLaunchKernelGGL(light_fill_kernel, dim3(unsigned(nb)), dim3(256), 0, s, indptr, n_rows, int(threshold), bc, light_desc,
+                       n_light);
+    GAE_CHECK_LAUNCH("light_fill_kernel");
     return GAE_OK;
 }
 
@@ -1455,7 +1641,7 @@ gae::Knob *find_knob(const char *name)
     const struct { const char *k; gae::Knob *v; } knobs[] = {
         {"spmm_variant", &g_spmm_variant}, {"spmm_rpg", &g_spmm_rpg}, {"spmm_nt", &g_spmm_nt},
         {"spmm_tile_vecs", &g_spmm_tile_vecs}, {"spmm_ell", &g_spmm_ell}, {"spmm_hot", &g_spmm_hot},
-        {"spmm_desc", &g_spmm_desc}, {"spmm_parts", &g_spmm_parts}};
+        {"spmm_desc", &g_spmm_desc}, {"spmm_parts", &g_spmm_parts}, {"spmm_light", &g_spmm_light}};
     for (const auto &kv : knobs)
         if (strcmp(kv.k, name) == 0) return kv.v;
     if (gae::Knob *k = gae::spmm_ell_knob(name)) return k;

@@ -462,6 +462,9 @@ SCATTER_L2_BYTES = 2 << 20   # half of one XCD's 4 MiB L2: the window of H rows 
 ELL_MAX_ROWS = 1 << 18   # packed neighbour table only for graphs whose launches are latency-bound, not byte-bound
 
 
+LIGHT_LIST = True        # skew plans carry the list of their rows with 1 .. threshold edges (gae_spmm_plan::light_desc)
+
+
 class SpmmPlan:
     """per-CSR acceleration data of gae_spmm_csr (gae_spmm_plan in include/gae_hip.h): the degree-skew plan
     (heavy rows cut into segments) and / or the packed neighbour table"""
@@ -478,9 +481,23 @@ class SpmmPlan:
                 _lib.call("gae_spmm_plan_desc", _ptr(indptr), _ptr(heavy_rows), _ptr(heavy_seg_base), _ptr(seg_heavy),
                           n_segments, segment, _ptr(seg_desc), _stream())
         self.seg_desc = seg_desc
+        # light-row list (rows with 1 .. threshold edges) of a plan with heavy or XCD-pinned rows
+        light, n_light = None, 0
+        if indptr is not None and LIGHT_LIST and (n_heavy > 0 or homed):
+            n = indptr.numel() - 1
+            with _on_device(indptr.device):
+                cnt = torch.zeros(1, dtype=torch.int64, device=indptr.device)
+                _lib.call("gae_spmm_plan_light_count", _ptr(indptr), n, threshold, _ptr(cnt), _stream())
+                n_light = int(cnt.item())
+                if n_light > 0:
+                    light = torch.empty(n_light, 4, dtype=torch.int32, device=indptr.device)
+                    ws = _workspace(_lib.load().gae_spmm_plan_light_workspace_bytes(n), indptr.device)
+                    _lib.call("gae_spmm_plan_light", _ptr(indptr), n, threshold, _ptr(light), n_light, _ptr(ws), ws.numel(),
+                              _stream())
+        self.light_desc, self.n_light = light, n_light
         hv = tuple(homed[k] for k in ("rows", "indptr", "indices", "hot", "identity", "part_ptr", "part_pos")) \
             if homed else ()
-        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy, ell, hot_indices) + hv + (seg_desc,)  # keep the device arrays alive
+        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy, ell, hot_indices) + hv + (seg_desc, light)  # keep the device arrays alive
         self.n_heavy, self.n_segments, self.ell = n_heavy, n_segments, ell
         self.hot_indices = hot_indices
         self.ell_width = (ell_width or _lib.SPMM_ELL_WIDTH) if ell is not None else 0
@@ -488,7 +505,7 @@ class SpmmPlan:
         self.c = _lib.SpmmPlan(threshold, segment, n_heavy, n_segments, ptr(heavy_rows), ptr(heavy_seg_base),
                                ptr(seg_heavy), ptr(ell), self.ell_width, 0, ptr(hot_indices),
                                homed["rows"].numel() if homed else 0, homed["identity"].numel() if homed else 0,
-                               *((ptr(t) for t in hv) if homed else (None,) * 7), ptr(seg_desc))
+                               *((ptr(t) for t in hv) if homed else (None,) * 7), ptr(seg_desc), ptr(light), n_light)
 
 
 def ell_width_for(max_deg):

@@ -230,6 +230,13 @@ typedef struct gae_spmm_plan {
                                        segment's column ids instead of the chain seg_heavy -> heavy_rows /
                                        heavy_seg_base -> indptr (a wave of the heavy-row kernel lives for a handful
                                        of round trips: RMAT s24 launch 5.05 -> 4.85 ms).  Same sums. */
+    /* Light-row list of a skew plan, optional (round 4): {row, first edge, end edge, 0} of every row with 1 ..
+     * threshold in-edges, ascending rows (gae_spmm_plan_light; 16-byte aligned).  On a power-law graph most rows are
+     * EMPTY (R-MAT s24: 11.7 M of 16.8 M): with the list the light rows are produced by waves whose every lane group
+     * has edges to gather (one descriptor load instead of two row-pointer loads in front of the column ids), and the
+     * empty rows by a pure stream that writes act(bias).  Same sums, same bits. */
+    const int32_t *light_desc;
+    int64_t n_light;
 } gae_spmm_plan;
 
 /* Hot-column tags for a plan with heavy rows: gae_spmm_col_freq counts how often every column occurs in `indices`
@@ -244,6 +251,13 @@ int gae_spmm_plan_count(const int32_t *indptr, int64_t n_rows, int32_t threshold
 int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
                        uint64_t *cursors_dev, int32_t *heavy_rows, int32_t *heavy_seg_base,
                        int32_t *seg_heavy, void *stream);
+/* optional: the light-row list of a plan (gae_spmm_plan::light_desc).  gae_spmm_plan_light_count: *count_dev (uint64,
+ * device) = rows with 1 .. threshold in-edges; gae_spmm_plan_light fills light_desc [count][4] in ascending row order
+ * (workspace: gae_spmm_plan_light_workspace_bytes(n_rows), 16-byte aligned). */
+int gae_spmm_plan_light_count(const int32_t *indptr, int64_t n_rows, int32_t threshold, uint64_t *count_dev, void *stream);
+int64_t gae_spmm_plan_light_workspace_bytes(int64_t n_rows);
+int gae_spmm_plan_light(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t *light_desc, int64_t n_light,
+                        void *workspace, int64_t workspace_bytes, void *stream);
 /* optional: the segment descriptors of a filled plan (int32 [n_segments][4], see gae_spmm_plan::seg_desc) */
 int gae_spmm_plan_desc(const int32_t *indptr, const int32_t *heavy_rows, const int32_t *heavy_seg_base,
                        const int32_t *seg_heavy, int64_t n_segments, int32_t segment_edges, int32_t *seg_desc,

@@ -211,3 +211,35 @@ def test_virtual_ranks_product_with_epilogue(world, mode, overlap):
         rows.append(_rank_product(sg, T[p.r0:p.r1].contiguous(), "fwd", bias=b, act=1))
     got = torch.cat(rows)
     assert float((got.double().cpu() - want).abs().max()) <= TOL * float(want.abs().max())
+
+
+@pytest.mark.parametrize("F", [16, 32])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_light_row_list_is_bit_identical(F, pinned, tuning):
+    """gae_spmm_plan::light_desc: rows with 1 .. threshold edges from the plan's list + the empty rows from the fill
+    stream == one sweep of the row-group kernel over all rows, with and without epilogue / accumulate; the list is the
+    ascending sequence of those rows"""
+    from gae_dgl_amd import ops
+    n, e = 20000, 300000
+    rng, src, dst = skew_graph(100 + F, n, e)
+    dst = dst // 3 * 3                                      # two thirds of the rows are empty
+    ip, ix = ops.csr_from_coo(dst, src, n, n)
+    plan = ops.spmm_plan(ip, threshold=8, segment=128, indices=ix, ell=False, hot=pinned, n_cols=n, homed=pinned)
+    assert plan.light_desc is not None and (plan.homed is not None) == pinned
+    deg = (ip[1:] - ip[:-1]).cpu().numpy()
+    ipn = ip.cpu().numpy()
+    want_rows = np.nonzero((deg >= 1) & (deg <= 8))[0]
+    ld = plan.light_desc.cpu().numpy()
+    assert np.array_equal(ld[:, 0], want_rows) and np.array_equal(ld[:, 1], ipn[want_rows]) and \
+        np.array_equal(ld[:, 2], ipn[want_rows + 1])
+    H = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rng.standard_normal(F).astype(np.float32)).to(DEV)
+    base = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(DEV)
+    outs = {}
+    for light in (1, 0):
+        tuning("spmm_light", light)
+        o_acc = base.clone(); ops.spmm_raw(ip, ix, H, n, out=o_acc, plan=plan, accumulate=True)
+        o_ep = base.clone(); ops.spmm_ep_raw(ip, ix, H, n, plan, b, 1, out=o_ep, accumulate=True)
+        outs[light] = (ops.spmm_raw(ip, ix, H, n, plan=plan), ops.spmm_ep_raw(ip, ix, H, n, plan, b, 1), o_acc, o_ep)
+    for a, c in zip(outs[1], outs[0]):
+        assert torch.equal(a, c)
