@@ -46,3 +46,14 @@ for F in (32, 16):
         print(f"F={F} spmm_light={light}: all {res['all']:.3f} ms  light {res['light']:.3f}  mid {res['mid']:.3f}  "
               f"pinned {res['pinned']:.3f}  identical to previous: {same}", flush=True)
 _lib.call("gae_tuning_set", b"spmm_light", 1)
+# cache hints of the heavy-row kernels: hot-column tags (streaming loads for the other columns) vs plain loads
+H = torch.rand(n, 32, device=dev); out = torch.empty(n, 32, device=dev)
+for hot in (1, 0):
+    _lib.call("gae_tuning_set", b"spmm_hot", hot)
+    res = {}
+    for name, parts in (("all", 7), ("mid", 2), ("pinned", 4)):
+        _lib.call("gae_tuning_set", b"spmm_parts", parts)
+        res[name] = timeit(lambda: ops.spmm_raw(ip, ix, H, n, out=out, plan=plan))
+    _lib.call("gae_tuning_set", b"spmm_parts", 7)
+    print(f"F=32 spmm_hot={hot}: all {res['all']:.3f} ms  mid {res['mid']:.3f}  pinned {res['pinned']:.3f}", flush=True)
+_lib.call("gae_tuning_set", b"spmm_hot", 1)
