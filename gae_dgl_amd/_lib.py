@@ -31,7 +31,8 @@ class SpmmPlan(ctypes.Structure):
                 ("heavy_rows", _p), ("heavy_seg_base", _p), ("seg_heavy", _p), ("ell", _p), ("ell_width", _i32),
                 ("reserved", _i32), ("hot_indices", _p), ("vh_n_rows", _i64), ("vh_n_virtual", _i64), ("vh_rows", _p),
                 ("vh_indptr", _p), ("vh_indices", _p), ("vh_hot_indices", _p), ("vh_identity", _p),
-                ("vh_part_ptr", _p), ("vh_part_pos", _p), ("seg_desc", _p), ("light_desc", _p), ("n_light", _i64)]
+                ("vh_part_ptr", _p), ("vh_part_pos", _p), ("seg_desc", _p), ("light_desc", _p), ("n_light", _i64),
+                ("mid_indices", _p), ("mid_tagged", _i32), ("reserved2", _i32), ("vh_desc", _p)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -71,6 +72,11 @@ SIGNATURES = {
     "gae_spmm_plan_light_count": (_int, [_p, _i64, _i32, _p, _p]),
     "gae_spmm_plan_light_workspace_bytes": (_i64, [_i64]),
     "gae_spmm_plan_light": (_int, [_p, _i64, _i32, _p, _i64, _p, _i64, _p]),
+    "gae_spmm_plan_sizes": (_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p]),
+    "gae_spmm_plan_scratch_bytes": (_i64, [_i64, _i64, _i64, _i64, _i32]),
+    "gae_spmm_plan_build_rows": (_int, [_p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                        _i64, _p, _p]),
+    "gae_spmm_plan_build_pinned": (_int, [_p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
     "gae_tuning_set": (_int, [ctypes.c_char_p, _i64]),
     "gae_tuning_get": (_int, [ctypes.c_char_p, _p]),
     "gae_csr_from_coo_workspace_bytes": (_i64, [_i64, _i64]),

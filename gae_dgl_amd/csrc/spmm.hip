@@ -1191,16 +1191,24 @@ int launch_segments(const int32_t *indptr, const int32_t *indices, const T *H, i
 {
     const int nvec = (F + VEC - 1) / VEC;
     const dim3 grid(unsigned((plan->n_segments + 3) / 4), unsigned((nvec + LPR * CH - 1) / (LPR * CH)));
+    // device-built plans: the segments read a compact copy of their ids (seg_desc indexes it), tagged or not
+    const int32_t *hot = g_spmm_hot ? plan->hot_indices : nullptr;
+    const int32_t *desc = g_spmm_desc ? plan->seg_desc : nullptr;
+    if (plan->mid_indices) {
+        indices = plan->mid_indices;
+        hot = (plan->mid_tagged && g_spmm_hot) ? plan->mid_indices : nullptr;
+        desc = plan->seg_desc;
+    }
     if (cs)
         hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, true>), grid, dim3(256), 0, s, indptr, indices, H, ldh,
                            F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
-                           plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr, rs, M, ldm,
-                           accumulate, direct, g_spmm_desc ? plan->seg_desc : nullptr, ep_bias, ep_act);
+                           plan->segment_edges, partial, ldp, hot, rs, M, ldm,
+                           accumulate, direct, desc, ep_bias, ep_act);
     else
         hipLaunchKernelGGL((spmm_segment_kernel<T, VEC, LPR, CH, false>), grid, dim3(256), 0, s, indptr, indices, H,
                            ldh, F, cs, plan->heavy_rows, plan->heavy_seg_base, plan->seg_heavy, plan->n_segments,
-                           plan->segment_edges, partial, ldp, g_spmm_hot ? plan->hot_indices : nullptr, rs, M, ldm,
-                           accumulate, direct, g_spmm_desc ? plan->seg_desc : nullptr, ep_bias, ep_act);
+                           plan->segment_edges, partial, ldp, hot, rs, M, ldm,
+                           accumulate, direct, desc, ep_bias, ep_act);
     GAE_CHECK_LAUNCH("spmm_segment_kernel");
     return GAE_OK;
 }
@@ -1289,6 +1297,11 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
         v.heavy_rows = v.heavy_seg_base = v.seg_heavy = g_spmm_desc ? nullptr : plan->vh_identity;   // NULL: segment s = row s
         v.seg_desc = nullptr;
         v.hot_indices = plan->vh_hot_indices;
+        v.mid_indices = nullptr;
+        if (plan->vh_desc) {                // device-built: {p, first, end} into the (row, home, column)-ordered ids
+            v.mid_indices = plan->vh_indices; v.mid_tagged = 0; v.seg_desc = plan->vh_desc; v.hot_indices = nullptr;
+            v.heavy_rows = v.heavy_seg_base = v.seg_heavy = nullptr;
+        }
         rc = dispatch_segments<T, VEC>(plan->vh_indptr, plan->vh_indices, h, ldh, f, cs, &v, pv, ldp, nullptr, m, ldm,
                                        0, 0, s);
         if (rc) return rc;
@@ -1452,11 +1465,12 @@ static int spmm_csr_impl(const int32_t *indptr, const int32_t *indices, int64_t 
     GAE_REQUIRE(n_cols == 0 || H, GAE_E_NULL, "gae_spmm_csr: H is NULL with n_cols > 0");
     GAE_REQUIRE((n_rows + 3) / 4 < (int64_t(1) << 31), GAE_E_SIZE, "gae_spmm_csr: too many rows for one launch");
     if (plan && plan->vh_n_virtual > 0)
-        GAE_REQUIRE(plan->vh_n_rows > 0 && plan->vh_rows && plan->vh_indptr && plan->vh_indices && plan->vh_identity &&
+        GAE_REQUIRE(plan->vh_n_rows > 0 && plan->vh_rows && plan->vh_indices && (plan->vh_desc || (plan->vh_indptr && plan->vh_identity)) &&
                         plan->vh_part_ptr && plan->vh_part_pos && plan->threshold >= 1 && plan->segment_edges >= 64 &&
                         plan->segment_edges % 64 == 0,
                     GAE_E_RANGE, "gae_spmm_csr: malformed plan (XCD-pinned part)");
     if (plan && (plan->n_heavy > 0 || plan->vh_n_virtual > 0)) {
+        GAE_REQUIRE(!plan->mid_indices || plan->seg_desc, GAE_E_RANGE, "gae_spmm_csr: a plan with mid_indices needs seg_desc");
         GAE_REQUIRE(plan->n_heavy == 0 ||
                         (plan->heavy_rows && plan->heavy_seg_base && plan->seg_heavy && plan->n_segments >= plan->n_heavy &&
                          plan->threshold >= 1 && plan->segment_edges >= 64 && plan->segment_edges % 64 == 0),

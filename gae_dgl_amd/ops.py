@@ -463,49 +463,53 @@ ELL_MAX_ROWS = 1 << 18   # packed neighbour table only for graphs whose launches
 
 
 LIGHT_LIST = True        # skew plans carry the list of their rows with 1 .. threshold edges (gae_spmm_plan::light_desc)
+INT32_MAX = 2 ** 31 - 1
 
 
 class SpmmPlan:
-    """per-CSR acceleration data of gae_spmm_csr (gae_spmm_plan in include/gae_hip.h): the degree-skew plan
-    (heavy rows cut into segments) and / or the packed neighbour table"""
+    """per-CSR acceleration data of gae_spmm_csr (gae_spmm_plan in include/gae_hip.h): the degree-skew plan (light-row
+    list, mid rows cut into segments, XCD-pinned very long rows -- built on the device by csrc/plan_build.hip) and / or
+    the packed neighbour table.  ``parts``: dict of the device arrays by their field name in gae_spmm_plan."""
 
-    def __init__(self, threshold, segment, n_heavy, n_segments, heavy_rows, heavy_seg_base, seg_heavy, ell=None,
-                 ell_width=None, hot_indices=None, homed=None, indptr=None):
-        self.homed = homed          # dict of the XCD-pinned part (homed_plan_parts) or None
-        # segment descriptors (one 16-byte record in front of a segment's column ids instead of a chain of three
-        # dependent index loads): built whenever the CSR is at hand
-        seg_desc = None
-        if indptr is not None and n_segments > 0:
-            seg_desc = torch.empty(n_segments, 4, dtype=torch.int32, device=indptr.device)
-            with _on_device(indptr.device):
-                _lib.call("gae_spmm_plan_desc", _ptr(indptr), _ptr(heavy_rows), _ptr(heavy_seg_base), _ptr(seg_heavy),
-                          n_segments, segment, _ptr(seg_desc), _stream())
-        self.seg_desc = seg_desc
-        # light-row list (rows with 1 .. threshold edges) of a plan with heavy or XCD-pinned rows
-        light, n_light = None, 0
-        if indptr is not None and LIGHT_LIST and (n_heavy > 0 or homed):
-            n = indptr.numel() - 1
-            with _on_device(indptr.device):
-                cnt = torch.zeros(1, dtype=torch.int64, device=indptr.device)
-                _lib.call("gae_spmm_plan_light_count", _ptr(indptr), n, threshold, _ptr(cnt), _stream())
-                n_light = int(cnt.item())
-                if n_light > 0:
-                    light = torch.empty(n_light, 4, dtype=torch.int32, device=indptr.device)
-                    ws = _workspace(_lib.load().gae_spmm_plan_light_workspace_bytes(n), indptr.device)
-                    _lib.call("gae_spmm_plan_light", _ptr(indptr), n, threshold, _ptr(light), n_light, _ptr(ws), ws.numel(),
-                              _stream())
-        self.light_desc, self.n_light = light, n_light
-        hv = tuple(homed[k] for k in ("rows", "indptr", "indices", "hot", "identity", "part_ptr", "part_pos")) \
-            if homed else ()
-        self.tensors = (heavy_rows, heavy_seg_base, seg_heavy, ell, hot_indices) + hv + (seg_desc, light)  # keep the device arrays alive
-        self.n_heavy, self.n_segments, self.ell = n_heavy, n_segments, ell
-        self.hot_indices = hot_indices
+    def __init__(self, threshold, segment, parts=None, ell=None, ell_width=None, n_virtual=0, mid_tagged=False):
+        parts = dict(parts or {})
+        g = parts.get
+        self.parts = parts
+        self.threshold, self.segment = int(threshold), int(segment)
+        self.ell = ell
         self.ell_width = (ell_width or _lib.SPMM_ELL_WIDTH) if ell is not None else 0
+        self.n_heavy = 0 if g("heavy_rows") is None else int(g("heavy_rows").numel())
+        self.n_segments = 0 if g("seg_heavy") is None else int(g("seg_heavy").numel())
+        self.seg_desc = g("seg_desc")
+        self.light_desc = g("light_desc")
+        self.n_light = 0 if self.light_desc is None else int(self.light_desc.shape[0])
+        self.mid_ids = g("mid_indices")
+        self.hot_indices = self.mid_ids if mid_tagged else None       # (the tagged ids of the segment kernel, if any)
+        self.homed = None
+        if g("vh_rows") is not None:
+            self.homed = dict(rows=g("vh_rows"), cols=g("vh_indices"), desc=g("vh_desc"), part_ptr=g("vh_part_ptr"),
+                              part_pos=g("vh_part_pos"), n_edges=int(g("vh_indices").numel()), n_virtual=int(n_virtual))
+        # heavy_rows first: tests read tensors[:3]; everything listed here is kept alive and counted as plan bytes
+        self.tensors = tuple(parts.get(k) for k in ("heavy_rows", "heavy_seg_base", "seg_heavy", "seg_desc", "light_desc",
+                                                    "mid_indices", "vh_rows", "vh_indices", "vh_desc", "vh_part_ptr",
+                                                    "vh_part_pos")) + (ell,)
         ptr = lambda t: None if t is None else t.data_ptr()
-        self.c = _lib.SpmmPlan(threshold, segment, n_heavy, n_segments, ptr(heavy_rows), ptr(heavy_seg_base),
-                               ptr(seg_heavy), ptr(ell), self.ell_width, 0, ptr(hot_indices),
-                               homed["rows"].numel() if homed else 0, homed["identity"].numel() if homed else 0,
-                               *((ptr(t) for t in hv) if homed else (None,) * 7), ptr(seg_desc), ptr(light), n_light)
+        c = _lib.SpmmPlan()
+        c.threshold, c.segment_edges = self.threshold, self.segment
+        c.n_heavy, c.n_segments = self.n_heavy, self.n_segments
+        c.heavy_rows, c.heavy_seg_base, c.seg_heavy = ptr(g("heavy_rows")), ptr(g("heavy_seg_base")), ptr(g("seg_heavy"))
+        c.ell, c.ell_width = ptr(ell), self.ell_width
+        c.seg_desc = ptr(self.seg_desc)
+        c.light_desc, c.n_light = ptr(self.light_desc), self.n_light
+        c.mid_indices, c.mid_tagged = ptr(self.mid_ids), 1 if (mid_tagged and self.mid_ids is not None) else 0
+        if self.homed is not None:
+            c.vh_n_rows, c.vh_n_virtual = int(g("vh_rows").numel()), int(n_virtual)
+            c.vh_rows, c.vh_indices, c.vh_desc = ptr(g("vh_rows")), ptr(g("vh_indices")), ptr(g("vh_desc"))
+            c.vh_part_ptr, c.vh_part_pos = ptr(g("vh_part_ptr")), ptr(g("vh_part_pos"))
+        self.c = c
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.tensors if t is not None)
 
 
 def ell_width_for(max_deg):
@@ -532,186 +536,103 @@ def ell_width_for_degrees(deg, cap=None):
 
 def table_plan(table, ell_width):
     """plan that only carries an already-built packed neighbour table (no heavy rows)"""
-    return SpmmPlan(SKEW_THRESHOLD, SKEW_SEGMENT, 0, 0, None, None, None, table, ell_width)
+    return SpmmPlan(SKEW_THRESHOLD, SKEW_SEGMENT, None, table, ell_width)
 
 
-HOT_COLUMNS = 65536          # columns tagged hot in a skew plan (RMAT s24, F = 32: 2 k 9.2 ms, 8 k 7.8, 16 k 7.2,
+HOT_COLUMNS = 65536          # columns tagged hot for the mid rows of a skew plan (RMAT s24, F = 32: 2 k 9.2 ms, 8 k 7.8, 16 k 7.2,
 #                              32 k 6.9, 64 k 6.8, 256 k 7.2; untagged 7.8 -- streaming the moderately hot rows hurts)
-HOT_MIN_EDGES = 1 << 22      # graphs with fewer heavy-row edges fit the caches anyway
-
-
-def hot_indices_for(indices, n_cols, hot_columns=None):
-    """the column ids of a CSR with the sign bit set on its ``hot_columns`` most frequently gathered columns
-    (gae_spmm_col_freq + gae_spmm_tag_hot; the frequency threshold is picked with one torch.topk)"""
-    _gpu(indices, "indices")
-    dev = indices.device
-    E = indices.numel()
-    k = min(int(hot_columns or HOT_COLUMNS), int(n_cols))
-    if E == 0 or k <= 0:
-        return None
-    with _on_device(dev):
-        freq = torch.empty(n_cols, dtype=torch.int32, device=dev)
-        _lib.call("gae_spmm_col_freq", _ptr(indices), E, n_cols, _ptr(freq), _stream())
-        min_freq = max(int(torch.topk(freq, k, sorted=True).values[-1]), 2)      # a column gathered once is not hot
-        out = torch.empty(E, dtype=torch.int32, device=dev)
-        _lib.call("gae_spmm_tag_hot", _ptr(indices), E, _ptr(freq), min_freq, _ptr(out), _stream())
-    return out
-
+HOT_MIN_EDGES = 1 << 22      # graphs with fewer edges fit the caches anyway
 
 HOMED_MIN_DEGREE = 256       # rows with more in-edges than this are gathered XCD-pinned ("homed") ...
 HOMED_MIN_EDGES = 1 << 24    # ... when they hold at least this many edges together (RMAT s24: 175 M of 268 M)
-HOMED_HOT_COLUMNS = 1 << 20  # hot tags of the pinned part (RMAT s24: 128 k 5.66 ms, 256 k 5.36, 512 k 5.19, 1 M 5.06, 2 M+ 5.08)
-
-
-HOMED_COLUMN_SWEEP = True    # order the pinned chunks of a home by their first column (see homed_plan_parts)
-HOMED_SEGMENT = None         # edges per pinned chunk (None: the plan's segment length)
+# (round 4: the pinned part carries NO hot tags -- with every column going through one L2, streaming loads for the
+#  other columns cost more than they save: RMAT s24 pinned launch 1.90 ms tagged, 1.83 ms plain)
 
 
 def column_home(cols):
     """XCD (0..7) through whose L2 a column is gathered in the pinned part of a plan: a multiplicative hash (the low
-    bits of the hub ids of an R-MAT graph are all zero: ``col % 8`` would put 44 % of the edges on one XCD)"""
+    bits of the hub ids of an R-MAT graph are all zero: ``col % 8`` would put 44 % of the edges on one XCD).  The
+    device builder (csrc/plan_build.hip) uses the same function."""
     return ((cols.to(torch.int64) * 2654435761) >> 13) & 7
 
 
-def homed_plan_parts(indptr, indices, n_cols, min_degree=None, segment=None, hot_columns=None):
-    """XCD-pinned part of a skew plan (gae_spmm_plan::vh_*): the edges of the rows with more than ``min_degree``
-    in-edges regrouped into virtual rows (row, home(column), chunk of <= ``segment`` ids), laid out so that virtual
-    row p is gathered by thread block p / 4 = on XCD (p / 4) % 8 = its home.  Every column then goes through one of
-    the eight private L2s only and their capacities add up.  Built with torch sorts (plan time, once per graph);
-    returns None when no row qualifies."""
-    min_degree = HOMED_MIN_DEGREE if min_degree is None else int(min_degree)
-    seg = SKEW_SEGMENT if segment is None else int(segment)
-    dev = indptr.device
-    deg = (indptr[1:] - indptr[:-1]).to(torch.int64)
-    vh = torch.nonzero(deg > min_degree).flatten()
-    R = int(vh.numel())
-    if R == 0:
-        return None
-    d = deg[vh]
-    E = int(d.sum())
-    starts = indptr[vh].to(torch.int64)
-    off = torch.cumsum(d, 0) - d
-    eidx = torch.repeat_interleave(starts - off, d) + torch.arange(E, device=dev)
-    cols = indices[eidx].to(torch.int64)
-    rowslot = torch.repeat_interleave(torch.arange(R, device=dev), d)
-    del eidx
-    grp = rowslot * 8 + column_home(cols)
-    del rowslot
-    order = torch.argsort(grp * (1 << 31) + cols)              # (row, home, column): deterministic summation order
-    cols = cols[order]
-    grp = grp[order]
-    del order
-    # edges per (row, home): grp is sorted, so the counts are differences of bucket boundaries (torch.bincount's
-    # histogram kernel took 28 ms per plan on RMAT s24: 175 M atomics)
-    cnt = torch.diff(torch.searchsorted(grp, torch.arange(R * 8 + 1, device=dev, dtype=grp.dtype)))
-    del grp
-    nchunk = (cnt + seg - 1) // seg
-    gstart = torch.cumsum(cnt, 0) - cnt
-    vg = torch.repeat_interleave(torch.arange(R * 8, device=dev), nchunk)      # group of every virtual row
-    first = torch.cumsum(nchunk, 0) - nchunk
-    vk = torch.arange(vg.numel(), device=dev) - first[vg]
-    v_e0 = gstart[vg] + vk * seg
-    v_len = torch.minimum(v_e0 + seg, gstart[vg] + cnt[vg]) - v_e0
-    v_home = vg % 8
-    # position of every virtual row: per home, 4 consecutive positions per thread block, blocks interleaved over XCDs
-    rank_in_home = torch.empty_like(vg)
-    L = 0
-    v_first = cols[v_e0.clamp(max=max(E - 1, 0))] if HOMED_COLUMN_SWEEP else None
-    for h in range(8):
-        m = torch.nonzero(v_home == h).flatten()
-        if HOMED_COLUMN_SWEEP:
-            # launch order inside a home = ascending first column of the chunk: the chunks of the very long rows that
-            # run at the same time then cover the same stretch of the column space and share its rows in the home's L2
-            m = m[torch.argsort(v_first[m], stable=True)]
-        rank_in_home[m] = torch.arange(m.numel(), device=dev)
-        L = max(L, int(m.numel()))
-    L = (L + 3) // 4 * 4
-    V = 8 * L
-    pos = (rank_in_home // 4) * 32 + v_home * 4 + (rank_in_home % 4)
-    lens = torch.zeros(V, dtype=torch.int64, device=dev)
-    lens[pos] = v_len
-    e0 = torch.zeros(V, dtype=torch.int64, device=dev)
-    e0[pos] = v_e0
-    ipv = torch.zeros(V + 1, dtype=torch.int64, device=dev)
-    ipv[1:] = torch.cumsum(lens, 0)
-    src = torch.repeat_interleave(e0 - ipv[:-1], lens) + torch.arange(E, device=dev)
-    ixv = cols[src].to(torch.int32).contiguous()
-    del src, cols
-    # partial lists: virtual rows of real row r in (home, chunk) order = their order in `vg`
-    per_row = nchunk.view(R, 8).sum(1)
-    part_ptr = torch.zeros(R + 1, dtype=torch.int64, device=dev)
-    part_ptr[1:] = torch.cumsum(per_row, 0)
-    hot = hot_indices_for(ixv, n_cols, hot_columns or HOMED_HOT_COLUMNS)
-    return dict(rows=vh.to(torch.int32).contiguous(), indptr=ipv.to(torch.int32).contiguous(), indices=ixv, hot=hot,
-                identity=torch.arange(V, dtype=torch.int32, device=dev), part_ptr=part_ptr.to(torch.int32).contiguous(),
-                part_pos=pos.to(torch.int32).contiguous(), min_degree=min_degree, n_edges=E)
-
-
 def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_width=None, hot=None, n_cols=None, homed=None):
-    """Build the plan of a CSR, or None when it needs none (one host read-back of three counters; done once per
-    graph).  Skew part: with the default threshold only for graphs whose longest row has more than
-    SKEW_MIN_MAXDEG edges.  Packed neighbour table: when ``indices`` is given and the graph has at most
-    ELL_MAX_ROWS rows (``ell`` = True / False overrides); ``ell_width`` 4 / 8 / 16 slots per row, default: the
-    narrowest that holds the longest light row.  Hot-column tags (``hot``; default: skew plans of graphs with at
-    least HOT_MIN_EDGES edges when ``indices`` is given; ``n_cols`` = columns of the CSR, default: its rows): a
-    tagged copy of ``indices`` that lets the heavy-row kernel stream the rarely gathered rows past the L2."""
+    """Build the plan of a CSR on the device (gae_spmm_plan_sizes / _build_rows / _build_pinned; no torch kernels), or
+    None when it needs none.  Skew part: with the default threshold only for graphs whose longest row has more than
+    SKEW_MIN_MAXDEG edges.  Packed neighbour table: when ``indices`` is given and the graph has at most ELL_MAX_ROWS
+    rows (``ell`` = True / False overrides); ``ell_width`` 4 / 8 / 16 slots per row, default: the narrowest that holds
+    the longest light row.  ``hot`` (default: skew plans of graphs with at least HOT_MIN_EDGES edges when ``indices``
+    is given; ``n_cols`` = columns of the CSR, default: its rows): the mid rows read a compact copy of their column
+    ids with the sign bit on the HOT_COLUMNS most gathered columns, which lets the kernel stream the rarely gathered
+    rows past the L2.  ``homed``: XCD-pinned regrouping of the rows with more than HOMED_MIN_DEGREE edges (default:
+    when they hold at least HOMED_MIN_EDGES edges; True / False forces)."""
     auto = threshold is None
-    threshold = SKEW_THRESHOLD if threshold is None else threshold
-    segment = SKEW_SEGMENT if segment is None else segment
+    threshold = SKEW_THRESHOLD if threshold is None else int(threshold)
+    segment = SKEW_SEGMENT if segment is None else int(segment)
     _gpu(indptr, "indptr")
     dev = indptr.device
     n = indptr.numel() - 1
     want_ell = (indices is not None and 0 < n <= ELL_MAX_ROWS) if ell is None else bool(ell)
     if want_ell and indices is None:
         raise GaeHipError("spmm_plan: the packed neighbour table needs `indices`")
+    if n <= 0:
+        return None
+    lib = _lib.load()
     with _on_device(dev):
-        counts = torch.zeros(3, dtype=torch.int64, device=dev)
-        _lib.call("gae_spmm_plan_count", _ptr(indptr), n, threshold, segment, _ptr(counts), _stream())
-        n_heavy, n_seg, max_deg = (int(v) for v in counts.tolist())
-        heavy = n_heavy > 0 and not (auto and max_deg <= SKEW_MIN_MAXDEG)
+        tiny = torch.empty(256, dtype=torch.uint8, device=dev)
+        sizes = (ctypes.c_int64 * 8)()
+        t2 = max(HOMED_MIN_DEGREE, threshold) if (indices is not None and homed is not False) else INT32_MAX
+        _lib.call("gae_spmm_plan_sizes", _ptr(indptr), n, threshold, t2, segment, sizes, _ptr(tiny), tiny.numel(), _stream())
+        nl, nm, sm, em, npin, epin, max_deg = (int(sizes[k]) for k in range(7))
+        heavy = (nm + npin) > 0 and not (auto and max_deg <= SKEW_MIN_MAXDEG)
         if not heavy and not want_ell:
             return None
-        hr = hb = sh = table = None
-        parts = None
-        if heavy and indices is not None and homed is not False and max_deg > HOMED_MIN_DEGREE:
-            deg64 = (indptr[1:] - indptr[:-1]).to(torch.int64)
-            vh_edges = int(deg64[deg64 > HOMED_MIN_DEGREE].sum())
-            if homed or vh_edges >= HOMED_MIN_EDGES:
-                nc = int(n_cols) if n_cols is not None else max(n, int(indices.max()) + 1)
-                parts = homed_plan_parts(indptr, indices, nc, segment=HOMED_SEGMENT or segment)
-        if parts is not None:
-            # the segment lists then hold the rows with threshold < degree <= HOMED_MIN_DEGREE only (torch-built:
-            # gae_spmm_plan_fill has no upper bound)
-            d32 = indptr[1:] - indptr[:-1]
-            hrows = torch.nonzero((d32 > threshold) & (d32 <= HOMED_MIN_DEGREE)).flatten()
-            ns = (d32[hrows].to(torch.int64) + segment - 1) // segment
-            n_heavy, n_seg = int(hrows.numel()), int(ns.sum())
-            hr = hrows.to(torch.int32).contiguous()
-            hb = (torch.cumsum(ns, 0) - ns).to(torch.int32).contiguous()
-            sh = torch.repeat_interleave(torch.arange(n_heavy, dtype=torch.int32, device=dev), ns).contiguous()
-            if n_heavy == 0:
-                hr = hb = sh = None
-        elif heavy:
-            hr = torch.empty(n_heavy, dtype=torch.int32, device=dev)
-            hb = torch.empty(n_heavy, dtype=torch.int32, device=dev)
-            sh = torch.empty(n_seg, dtype=torch.int32, device=dev)
-            _lib.call("gae_spmm_plan_fill", _ptr(indptr), n, threshold, segment, _ptr(counts), _ptr(hr), _ptr(hb),
-                      _ptr(sh), _stream())
-        else:
-            n_heavy = n_seg = 0
+        pin = heavy and npin > 0 and t2 != INT32_MAX and (bool(homed) or epin >= HOMED_MIN_EDGES)
+        if heavy and npin > 0 and not pin:           # the long rows stay ordinary segmented rows
+            t2 = INT32_MAX
+            _lib.call("gae_spmm_plan_sizes", _ptr(indptr), n, threshold, t2, segment, sizes, _ptr(tiny), tiny.numel(), _stream())
+            nl, nm, sm, em, npin, epin, max_deg = (int(sizes[k]) for k in range(7))
+        parts, n_virtual, tagged = {}, 0, False
+        if heavy:
+            n_edges = int(indices.numel()) if indices is not None else 0
+            tagged = ((n_edges >= HOT_MIN_EDGES) if hot is None else bool(hot)) and indices is not None and em > 0
+            nc = int(n_cols) if n_cols is not None else n
+            i32 = lambda *shape: torch.empty(*shape, dtype=torch.int32, device=dev)
+            if LIGHT_LIST and nl:
+                parts["light_desc"] = i32(nl, 4)
+            if nm:
+                parts.update(heavy_rows=i32(nm), heavy_seg_base=i32(nm), seg_heavy=i32(sm), seg_desc=i32(sm, 4))
+                if tagged:
+                    parts["mid_indices"] = i32(em)
+            if npin:
+                parts.update(vh_rows=i32(npin), vh_part_ptr=i32(npin + 1))
+            sb = int(lib.gae_spmm_plan_scratch_bytes(n, nc, npin, epin, segment))
+            scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+            ph = (ctypes.c_int64 * 4)()
+            g = parts.get
+            _lib.call("gae_spmm_plan_build_rows", _ptr(indptr), _ptr(indices), n, nc, threshold, t2, segment, sizes,
+                      int(HOT_COLUMNS if tagged else 0), _ptr(g("light_desc")), _ptr(g("heavy_rows")),
+                      _ptr(g("heavy_seg_base")), _ptr(g("seg_heavy")), _ptr(g("seg_desc")), _ptr(g("mid_indices")),
+                      _ptr(g("vh_rows")), _ptr(g("vh_part_ptr")), _ptr(scratch), sb, ph, _stream())
+            if npin:
+                parts["vh_indices"] = i32(epin)
+                _lib.call("gae_spmm_plan_build_pinned", _ptr(indptr), _ptr(indices), n, nc, segment, sizes, _ptr(g("vh_rows")),
+                          _ptr(parts["vh_indices"]), None, None, _ptr(scratch), sb, ph, _stream())
+                n_virtual = int(ph[1])
+                parts["vh_desc"] = i32(n_virtual, 4)
+                parts["vh_part_pos"] = i32(int(ph[0]))
+                _lib.call("gae_spmm_plan_build_pinned", _ptr(indptr), _ptr(indices), n, nc, segment, sizes, _ptr(g("vh_rows")),
+                          _ptr(parts["vh_indices"]), _ptr(parts["vh_desc"]), _ptr(parts["vh_part_pos"]), _ptr(scratch), sb, ph,
+                          _stream())
+            del scratch
+        table = None
         if want_ell:
             if ell_width is None:
                 ell_width = ell_width_for_degrees(indptr[1:] - indptr[:-1], threshold if heavy else None)
             table = torch.empty(n * ell_width, dtype=torch.int32, device=dev)
             _lib.call("gae_spmm_ell_build", _ptr(indptr), _ptr(indices), n, ell_width,
                       threshold if heavy else 2 ** 31 - 1, _ptr(table), _stream())
-        tags = None
-        want_hot = (heavy and indices is not None and indices.numel() >= HOT_MIN_EDGES) if hot is None else \
-            (bool(hot) and heavy and indices is not None)
-        if want_hot:
-            nc = int(n_cols) if n_cols is not None else max(n, int(indices.max()) + 1 if indices.numel() else n)
-            tags = hot_indices_for(indices, nc)
-    return SpmmPlan(threshold, segment, n_heavy, n_seg, hr, hb, sh, table, ell_width, tags, parts, indptr=indptr)
+    return SpmmPlan(threshold, segment, parts, table, ell_width, n_virtual, tagged)
 
 
 def gather_distance(indptr, indices):

@@ -237,6 +237,14 @@ typedef struct gae_spmm_plan {
      * empty rows by a pure stream that writes act(bias).  Same sums, same bits. */
     const int32_t *light_desc;
     int64_t n_light;
+    /* Device-built plans (gae_spmm_plan_build_rows / _pinned, round 4): */
+    const int32_t *mid_indices;     /* compact copy of the column ids of the rows in heavy_rows, or NULL.  When given,
+                                       seg_desc (mandatory then) indexes THIS array instead of the CSR's `indices`; */
+    int32_t mid_tagged;             /* 1: its ids carry hot-column tags (sign bit), like hot_indices */
+    int32_t reserved2;
+    const int32_t *vh_desc;         /* [vh_n_virtual][4] {p, first, end, 0} into vh_indices for virtual row p (empty
+                                       positions: zeros), or NULL.  When given, vh_indptr / vh_identity are not read and
+                                       vh_indices holds the pinned rows' ids in (row, home, column) order. */
 } gae_spmm_plan;
 
 /* Hot-column tags for a plan with heavy rows: gae_spmm_col_freq counts how often every column occurs in `indices`
@@ -251,6 +259,31 @@ int gae_spmm_plan_count(const int32_t *indptr, int64_t n_rows, int32_t threshold
 int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
                        uint64_t *cursors_dev, int32_t *heavy_rows, int32_t *heavy_seg_base,
                        int32_t *seg_heavy, void *stream);
+/* ---- plan construction on the device (csrc/plan_build.hip): classification of the rows, descriptors, compact tagged
+ * ids of the mid rows, XCD-pinned regrouping of the very long rows -- integer work, deterministic (ascending rows, stable
+ * partition, stable sort).  Every call synchronises `stream` once to hand counters to the host.
+ *   sizes_host[0..6] = {light rows (1 .. threshold edges), mid rows (threshold < d <= pin_degree), their segments, their
+ *                       edges, pinned rows (d > pin_degree), their edges, maximum degree};  scratch >= 64 bytes
+ *   pin_degree = INT32_MAX: no pinned rows (every row above the threshold is a mid row). */
+int gae_spmm_plan_sizes(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t pin_degree, int32_t segment_edges,
+                        int64_t *sizes_host, void *scratch, int64_t scratch_bytes, void *stream);
+int64_t gae_spmm_plan_scratch_bytes(int64_t n_rows, int64_t n_cols, int64_t n_pinned, int64_t pinned_edges,
+                                    int32_t segment_edges);
+/* light_desc [n_light][4] (or NULL: no list); heavy_rows, heavy_seg_base [n_mid]; seg_heavy [segments]; seg_desc [segments][4]; mid_ids
+ * [mid_edges] or NULL (no compact copy; hot_columns > 0 needs it: the ids of the hot_columns most gathered columns get the
+ * tag); vh_rows [n_pinned]; vh_part_ptr [n_pinned + 1].  pinned_host_out[0] = virtual rows NV, [2] = tag threshold. */
+int gae_spmm_plan_build_rows(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                             int32_t threshold, int32_t pin_degree, int32_t segment_edges, const int64_t *sizes,
+                             int64_t hot_columns, int32_t *light_desc, int32_t *heavy_rows, int32_t *heavy_seg_base,
+                             int32_t *seg_heavy, int32_t *seg_desc, int32_t *mid_ids, int32_t *vh_rows,
+                             int32_t *vh_part_ptr, void *scratch, int64_t scratch_bytes, int64_t *pinned_host_out,
+                             void *stream);
+/* pinned rows, two calls on the SAME scratch: vh_desc == NULL partitions the ids into vh_cols [pinned_edges], sorts the
+ * chunks and reports pinned_host_out[1] = V; the second call fills vh_desc [V][4] and vh_part_pos [NV]. */
+int gae_spmm_plan_build_pinned(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                               int32_t segment_edges, const int64_t *sizes, const int32_t *vh_rows, int32_t *vh_cols,
+                               int32_t *vh_desc, int32_t *vh_part_pos, void *scratch, int64_t scratch_bytes,
+                               int64_t *pinned_host_out, void *stream);
 /* optional: the light-row list of a plan (gae_spmm_plan::light_desc).  gae_spmm_plan_light_count: *count_dev (uint64,
  * device) = rows with 1 .. threshold in-edges; gae_spmm_plan_light fills light_desc [count][4] in ascending row order
  * (workspace: gae_spmm_plan_light_workspace_bytes(n_rows), 16-byte aligned). */

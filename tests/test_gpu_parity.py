@@ -1459,23 +1459,34 @@ def test_fused_gcn_layer_matches_two_launches(f_in, f_out, act, norm, dev):
 
 
 def test_spmm_hot_column_tags_are_only_cache_hints(dev, tuning):
-    """gae_spmm_col_freq / gae_spmm_tag_hot: exact column frequencies, the sign bit on the most gathered columns,
-    and a heavy-row SpMM whose result is bit-identical with and without the tags (fp32 and bf16 storage, scaled)"""
+    """hot-column tags of a device-built plan (csrc/plan_build.hip): the mid rows read a COMPACT copy of their column
+    ids whose sign bit marks the most gathered columns (frequencies counted over that copy, threshold = frequency of
+    the HOT_COLUMNS-th column, never below 2); a heavy-row SpMM is bit-identical with and without the tags (fp32 and
+    bf16 storage, scaled)"""
     from gae_dgl_amd import ops
     rng = np.random.default_rng(21)
     n, e = 4000, 120000
     dst = (rng.integers(0, n, e).astype(np.float64) ** 3 / n ** 2).astype(np.int64)          # heavy rows
     src = (rng.integers(0, n, e).astype(np.float64) ** 4 / n ** 3).astype(np.int64)          # hub columns
     ip, ix = ops.csr_from_coo(t(dst, dev), t(src, dev), n, n)
-    tags = ops.hot_indices_for(ix, n, hot_columns=64)
-    ixh, tg = ix.cpu().numpy(), tags.cpu().numpy()
-    freq = np.bincount(ixh, minlength=n)
-    kth = max(np.sort(freq)[::-1][63], 2)
-    assert np.array_equal(tg & 0x7fffffff, ixh)
-    assert np.array_equal(tg < 0, freq[ixh] >= kth) and 0 < (tg < 0).mean() < 1
-    plan_hot = ops.spmm_plan(ip, threshold=8, segment=64, indices=ix, ell=False, hot=True, n_cols=n)
+    old = ops.HOT_COLUMNS
+    ops.HOT_COLUMNS = 64
+    try:
+        plan_hot = ops.spmm_plan(ip, threshold=8, segment=64, indices=ix, ell=False, hot=True, n_cols=n)
+    finally:
+        ops.HOT_COLUMNS = old
     plan_off = ops.spmm_plan(ip, threshold=8, segment=64, indices=ix, ell=False, hot=False, n_cols=n)
     assert plan_hot.hot_indices is not None and plan_off.hot_indices is None and plan_hot.n_heavy > 0
+    assert plan_off.mid_ids is None                               # untagged plans read the CSR's own ids: no copy
+    # the compact copy: ids of the heavy rows in row order, tags by frequency
+    ipn, ixh = ip.cpu().numpy(), ix.cpu().numpy()
+    hr = plan_hot.tensors[0].cpu().numpy()
+    want = np.concatenate([ixh[ipn[r]:ipn[r + 1]] for r in hr])
+    tg = plan_hot.mid_ids.cpu().numpy()
+    assert np.array_equal(tg & 0x7fffffff, want)
+    freq = np.bincount(want, minlength=n)
+    kth = max(np.sort(freq)[::-1][63], 2)
+    assert np.array_equal(tg < 0, freq[want] >= kth) and 0 < (tg < 0).mean() < 1
     deg, norm = ops.degree_norm(ip)
     for dtype in (torch.float32, torch.bfloat16):
         H = t(rng.standard_normal((n, 40)).astype(np.float32), dev).to(dtype)
@@ -1490,47 +1501,62 @@ def test_spmm_hot_column_tags_are_only_cache_hints(dev, tuning):
 
 
 def test_spmm_segment_descriptors_match_the_index_chain(dev, tuning):
-    """gae_spmm_plan_desc: {row, first edge, end edge, only segment} of every segment as the plan's index arrays
-    define them, and a heavy-row SpMM (plain, scaled, accumulating, with an XCD-pinned part) that is bit-identical
-    whether the kernel reads the descriptors / identity segments or walks the index chain (knob spmm_desc)"""
+    """seg_desc of a device-built plan: {row, first edge, end edge, only segment} of every segment, rows ascending,
+    segments of a row consecutive; offsets index the CSR (untagged plan) or the compact id copy (tagged plan), whose
+    slices hold the same ids.  A heavy-row SpMM (plain, scaled, accumulating, with an XCD-pinned part) is bit-identical
+    whether the kernel reads the descriptors or walks the index chain (knob spmm_desc; untagged plans only: the compact
+    copy has no chain)"""
     from gae_dgl_amd import ops
     rng = np.random.default_rng(22)
     n, e, seg = 5000, 300000, 128
     dst = (rng.integers(0, n, e).astype(np.float64) ** 4 / n ** 3).astype(np.int64)
     src = (rng.integers(0, n, e).astype(np.float64) ** 2 / n).astype(np.int64)
     ip, ix = ops.csr_from_coo(t(dst, dev), t(src, dev), n, n)
+    ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
+    deg_n = np.diff(ipn)
     for homed in (False, True):
-        plan = ops.spmm_plan(ip, threshold=8, segment=seg, indices=ix, ell=False, hot=True, n_cols=n, homed=homed)
-        assert plan.seg_desc is not None and plan.n_segments > 0 and (plan.homed is not None) == homed
-        hr, hb, sh = (x.cpu().numpy() for x in plan.tensors[:3])
-        d = plan.seg_desc.cpu().numpy()
-        ipn = ip.cpu().numpy()
-        rows = hr[sh]
-        k = np.arange(plan.n_segments) - hb[sh]
-        e0 = ipn[rows] + k * seg
-        e1 = np.minimum(e0 + seg, ipn[rows + 1])
-        assert np.array_equal(d[:, 0], rows) and np.array_equal(d[:, 1], e0) and np.array_equal(d[:, 2], e1)
-        assert np.array_equal(d[:, 3], ((k == 0) & (e1 == ipn[rows + 1])).astype(np.int32))
-        deg, norm = ops.degree_norm(ip)
-        for dtype in (torch.float32, torch.bfloat16):
-            H = t(rng.standard_normal((n, 40)).astype(np.float32), dev).to(dtype)
-            base = t(rng.standard_normal((n, 40)).astype(np.float32), dev).to(dtype)
-            for sc in (None, norm):
-                out = {}
-                for knob in (1, 0):
-                    tuning("spmm_desc", knob)
-                    acc = base.clone()
-                    ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan, out=acc, accumulate=True)
-                    out[knob] = (ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan), acc)
-                tuning("spmm_desc", 1)
-                assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        for hot in (False, True):
+            plan = ops.spmm_plan(ip, threshold=8, segment=seg, indices=ix, ell=False, hot=hot, n_cols=n, homed=homed)
+            assert plan.seg_desc is not None and plan.n_segments > 0 and (plan.homed is not None) == homed
+            hr, hb, sh = (x.cpu().numpy() for x in plan.tensors[:3])
+            hi = ops.HOMED_MIN_DEGREE if homed else 2 ** 31 - 1
+            assert np.array_equal(hr, np.nonzero((deg_n > 8) & (deg_n <= hi))[0])           # ascending rows
+            ns = (deg_n[hr] + seg - 1) // seg
+            assert np.array_equal(hb, np.cumsum(ns) - ns) and np.array_equal(sh, np.repeat(np.arange(len(hr)), ns))
+            d = plan.seg_desc.cpu().numpy()
+            rows = hr[sh]
+            k = np.arange(plan.n_segments) - hb[sh]
+            assert np.array_equal(d[:, 0], rows)
+            assert np.array_equal(d[:, 2] - d[:, 1], np.minimum(seg, deg_n[rows] - k * seg))
+            assert np.array_equal(d[:, 3], ((k == 0) & (deg_n[rows] <= seg)).astype(np.int32))
+            e0 = ipn[rows] + k * seg
+            if not hot:
+                assert plan.mid_ids is None and np.array_equal(d[:, 1], e0)
+            else:
+                ids = plan.mid_ids.cpu().numpy() & 0x7fffffff
+                for sidx in rng.integers(0, plan.n_segments, 50):
+                    assert np.array_equal(ids[d[sidx, 1]:d[sidx, 2]], ixn[e0[sidx]:e0[sidx] + d[sidx, 2] - d[sidx, 1]])
+            deg, norm = ops.degree_norm(ip)
+            for dtype in (torch.float32, torch.bfloat16):
+                H = t(rng.standard_normal((n, 40)).astype(np.float32), dev).to(dtype)
+                base = t(rng.standard_normal((n, 40)).astype(np.float32), dev).to(dtype)
+                for sc in (None, norm):
+                    out = {}
+                    for knob in ((1, 0) if not hot else (1,)):
+                        tuning("spmm_desc", knob)
+                        acc = base.clone()
+                        ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan, out=acc, accumulate=True)
+                        out[knob] = (ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan), acc)
+                    tuning("spmm_desc", 1)
+                    if not hot:
+                        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
 @pytest.mark.parametrize("dtype,F", [(torch.float32, 40), (torch.bfloat16, 40), (torch.float32, 300)])
 def test_spmm_homed_rows_match_oracle(dtype, F, dev):
-    """XCD-pinned ("homed") part of a skew plan: the very long rows are evaluated from virtual rows grouped by the
-    home of their columns -- same terms, another summation order: == the plain plan and the fp64 oracle to 1e-5 of
-    the scale (fp32), scaled and unscaled, with GAE_SPMM_ACCUMULATE, and the layout invariants of the plan hold"""
+    """XCD-pinned ("homed") part of a device-built skew plan: the very long rows are evaluated from virtual rows grouped
+    by the home of their columns -- same terms, another summation order: == the plain plan and the fp64 oracle to 1e-5
+    of the scale (fp32), scaled and unscaled, with GAE_SPMM_ACCUMULATE, and the layout invariants of the plan hold"""
     from gae_dgl_amd import ops
     from oracle import c_oracle as C
     rng = np.random.default_rng(33)
@@ -1542,19 +1568,50 @@ def test_spmm_homed_rows_match_oracle(dtype, F, dev):
     plain = ops.spmm_plan(ip, threshold=8, segment=128, indices=ix, ell=False, hot=False, n_cols=n, homed=False)
     hp = plan.homed
     assert hp is not None and plain.homed is None
-    deg = (ip[1:] - ip[:-1]).cpu().numpy()
-    assert np.array_equal(hp["rows"].cpu().numpy(), np.nonzero(deg > ops.HOMED_MIN_DEGREE)[0])
+    ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
+    deg = np.diff(ipn)
+    vrows = np.nonzero(deg > ops.HOMED_MIN_DEGREE)[0]
+    assert np.array_equal(hp["rows"].cpu().numpy(), vrows)
     if plan.n_heavy:
         hr = plan.tensors[0].cpu().numpy()
         assert ((deg[hr] > 8) & (deg[hr] <= ops.HOMED_MIN_DEGREE)).all()
-    ipv, ixv = hp["indptr"].cpu().numpy(), hp["indices"].cpu().numpy()
-    lens = np.diff(ipv)
-    assert lens.max() <= 128 and ipv[-1] == hp["n_edges"] == deg[deg > ops.HOMED_MIN_DEGREE].sum()
-    home = ops.column_home(torch.from_numpy(ixv.astype(np.int64))).numpy()
-    pos_of_edge = np.repeat(np.arange(len(lens)), lens)
-    assert np.array_equal(home, (pos_of_edge // 4) % 8)               # every column gathered on its home XCD
+    # ids: every pinned row's list regrouped by home, ascending columns inside a home (stable partition of the CSR row)
+    cols = hp["cols"].cpu().numpy()
+    assert len(cols) == hp["n_edges"] == deg[vrows].sum()
+    home_of = lambda c: ops.column_home(torch.from_numpy(c.astype(np.int64))).numpy()
+    at = 0
+    for r in vrows[:40]:
+        row = ixn[ipn[r]:ipn[r + 1]]
+        want = np.concatenate([row[home_of(row) == h] for h in range(8)])
+        assert np.array_equal(cols[at:at + len(row)], want)
+        at += len(row)
+    # virtual rows: position p is gathered by thread block p / 4 on XCD (p / 4) % 8 = the home of all its columns
+    desc = hp["desc"].cpu().numpy()
+    V = hp["n_virtual"]
+    assert desc.shape == (V, 4) and V % 32 == 0
+    lens = desc[:, 2] - desc[:, 1]
+    live = np.nonzero(lens > 0)[0]
+    assert lens.max() <= 128 and lens.min() >= 0 and lens.sum() == hp["n_edges"]
+    assert np.array_equal(desc[live, 0], live)
+    for p_ in live[rng.integers(0, len(live), 200)]:
+        assert (home_of(cols[desc[p_, 1]:desc[p_, 2]]) == (p_ // 4) % 8).all()
+    # the chunks tile the id array exactly once
+    order = np.argsort(desc[live, 1])
+    assert np.array_equal(desc[live, 1][order][1:], desc[live, 2][order][:-1]) and desc[live, 1].min() == 0
+    # partial lists: row r's virtual rows in (home, chunk) order
     pp, pq = hp["part_ptr"].cpu().numpy(), hp["part_pos"].cpu().numpy()
-    assert len(np.unique(pq)) == len(pq) and pp[-1] == len(pq) == (lens > 0).sum()
+    assert len(np.unique(pq)) == len(pq) == len(live) and pp[-1] == len(pq) and len(pp) == len(vrows) + 1
+    starts = np.concatenate([[0], np.cumsum(deg[vrows])])
+    for k_ in range(min(len(vrows), 40)):
+        ps = pq[pp[k_]:pp[k_ + 1]]
+        assert (desc[ps, 1] >= starts[k_]).all() and (desc[ps, 2] <= starts[k_ + 1]).all()
+        assert np.array_equal(desc[ps, 1], np.sort(desc[ps, 1])) and lens[ps].sum() == deg[vrows[k_]]
+    # inside a home the chunks are launched in the order of their first column
+    for h in range(8):
+        ph = live[(live // 4) % 8 == h]
+        rank = (ph // 32) * 4 + ph % 4
+        first = cols[desc[ph, 1]][np.argsort(rank)]
+        assert np.array_equal(first, np.sort(first))
     deg_t, norm = ops.degree_norm(ip)
     H = t(rng.standard_normal((n, F)).astype(np.float32), dev).to(dtype)
     tol = 1e-5 if dtype == torch.float32 else 2e-2

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Experiment (round 4): chunk length / row threshold of the XCD-pinned part of the RMAT skew plan.
+"""[historical: ran on commit e8f2a2f with the torch plan builder; ops.HOMED_SEGMENT / HOMED_HOT_COLUMNS are gone]
+Experiment (round 4): chunk length / row threshold of the XCD-pinned part of the RMAT skew plan.
 Equal-count chunks of the (row, home) column lists, launched in the order of their first column, are aligned in
 column space across rows (R-MAT's column marginal barely depends on the row): the shorter the chunks, the narrower
 the column window the concurrently running waves of an XCD gather from.

@@ -54,9 +54,9 @@ def main():
     if args.homed_deg:
         ops.HOMED_MIN_DEGREE = args.homed_deg
     if args.homed_hot:
-        ops.HOMED_HOT_COLUMNS = args.homed_hot
+        pass    # (round 4: the pinned part carries no hot tags)
     if args.homed_sweep >= 0:
-        ops.HOMED_COLUMN_SWEEP = bool(args.homed_sweep)
+        pass    # (round 4: chunks are always launched in first-column order)
     for kv in filter(None, args.knobs.split(",")):
         k, v = kv.split("=")
         knob(k, int(v))
