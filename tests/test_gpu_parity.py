@@ -1631,6 +1631,8 @@ def test_spmm_homed_rows_match_oracle(dtype, F, dev):
         base = torch.randn(n, F, device=dev).to(dtype)
         acc = base.clone()
         ops.spmm_raw(ip, ix, H, n, sc, sc, plan=plan, out=acc, accumulate=True)
-        assert float((acc.float() - (base.float() + a.float())).abs().max()) <= (1e-6 if dtype == torch.float32 else 2e-2) * scale
+        # (bf16: one rounding of base + a, whose magnitude is that of the unseeded N(0, 1) base, not of the product)
+        bound = 1e-6 * scale if dtype == torch.float32 else 2e-2 * max(scale, float(base.float().abs().max()))
+        assert float((acc.float() - (base.float() + a.float())).abs().max()) <= bound
     # deterministic
     assert torch.equal(ops.spmm_raw(ip, ix, H, n, plan=plan), ops.spmm_raw(ip, ix, H, n, plan=plan))
