@@ -1776,8 +1776,10 @@ class GCNTransformFirstFunction(torch.autograd.Function):
         # larger operands let gae_xw_fwd reduce the splits itself)
         f_out = W.shape[0]
         splits = int(_lib.load().gae_xw_fwd_splits(H.shape[0], H.shape[1], f_out, _dtype_code(H))) if f_out % 4 == 0 else 1
-        P, _ = xw_fwd_raw(H, W, None, ACT_IDENTITY,
-                          keep_splits=f_out % 4 == 0 and splits > 1 and splits * H.shape[0] * f_out * 4 < (1 << 27))
+        keep = f_out % 4 == 0 and splits > 1 and splits * H.shape[0] * f_out * 4 < (1 << 27)
+        P = xw_fwd_raw(H, W, None, ACT_IDENTITY, keep_splits=keep)
+        if keep:
+            P = P[0]
         Y = spmm_epilogue_raw(indptr, indices, P, n, graph.spmm_plan(False), b, act, None, norm, norm)
         ctx.act, ctx.has_bias = act, b is not None
         ctx.bwd = (graph.csc(), n, norm, graph.spmm_plan(True))
