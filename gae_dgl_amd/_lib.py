@@ -68,7 +68,7 @@ SIGNATURES = {
     "gae_linear2_fwd": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _i64, _p, _i64, _p, _i64, _p]),
     "gae_gcn2_bwd_dense_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "gae_gcn2_bwd_dense": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p, _p,
-                                  _p, _p, _p, _i64, _p, _p]),
+                                  _p, _p, _p, _i64, _p, _p, _i64, _p, _p]),
     "gae_spmm_plan_light_count": (_int, [_p, _i64, _i32, _p, _p]),
     "gae_spmm_plan_light_workspace_bytes": (_i64, [_i64]),
     "gae_spmm_plan_light": (_int, [_p, _i64, _i32, _p, _i64, _p, _i64, _p]),

@@ -163,14 +163,19 @@ __global__ __launch_bounds__(256) void linear2_rows_kernel(const float *__restri
 //   G and Y1 read column-per-lane.  No LDS in the row loop; the 4 waves of a block meet in LDS once, in fixed order.
 // partial layout per block: [dW1 J1 x K1 | db1 J1 | dW2 J2 x J1 | db2 J2]  (gae_gcn2_bwd_dense_layout)
 // ---------------------------------------------------------------------------------------------------------------
-template <int KB2, bool RELU>
+// RECOMP: Y1 is not read but RECOMPUTED from the tile of M1 that the pass reads anyway, Y1 = act1(M1 W1^T + b1), with
+// the forward's own products in the forward's own order (gae_linear2_fwd: same k sequence, same fma chain -> the same
+// bits): the forward then never stores Y1 (2 GiB per step on R-MAT s24) and this pass never reads it.
+template <int KB2, bool RELU, bool RECOMP>
 __global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restrict__ G, int64_t ldg,
                                                             const float *__restrict__ dZ, int64_t lddz,
                                                             const float *__restrict__ Y1, int64_t ldy1,
                                                             const float *__restrict__ M1, int64_t ldm1,
                                                             const float *__restrict__ W2, int64_t ldw2, int64_t n,
                                                             int K1, int J1, int J2, int64_t tiles_per_wave,
-                                                            float *__restrict__ partial, int64_t stride)
+                                                            float *__restrict__ partial, int64_t stride,
+                                                            const float *__restrict__ W1, int64_t ldw1,
+                                                            const float *__restrict__ b1)
 {
     __shared__ float red[2][34 * 64];
     const int lane = threadIdx.x & 63;
@@ -189,6 +194,22 @@ __global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restr
                 w2[kb][q] = (j2 < J2 && i < J1) ? v : 0.f;
             }
     }
+    // (RECOMP) W1 as the B operand of Y1 = M1 W1^T: w1[kb][q] = W1[j = i][k = 8 kb + 4 h + q]; bias of column j = i
+    float w1[RECOMP ? 4 : 1][4], b1v = 0.f;
+    if (RECOMP) {
+        const int jc = i < J1 ? i : J1 - 1;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = kb * 8 + 4 * h + q;
+                const float v = W1[int64_t(jc) * ldw1 + (k < K1 ? k : K1 - 1)];
+                w1[kb][q] = (k < K1 && i < J1) ? v : 0.f;
+            }
+        const float b = b1 ? b1[jc] : 0.f;
+        b1v = (b1 && i < J1) ? b : 0.f;
+    }
+    const int K4 = (K1 + 3) & ~3;
     f32x16 accW1, accW2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accW1[r] = 0.f; accW2[r] = 0.f; }
@@ -212,10 +233,18 @@ __global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restr
             st.g[kb][0] = g4.x; st.g[kb][1] = g4.y; st.g[kb][2] = g4.z; st.g[kb][3] = g4.w;
             st.z[kb][0] = z4.x; st.z[kb][1] = z4.y; st.z[kb][2] = z4.z; st.z[kb][3] = z4.w;
         }
+        if (RECOMP) {                     // y[4 kb + q] = M1[row i][8 kb + 4 h + q]: the rows of the tile in the lanes
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const int k = kb * 8 + 4 * h;
+                const float4 m4 = *reinterpret_cast<const float4 *>(M1 + row * ldm1 + (k <= K4 - 4 ? k : K4 - 4));
+                st.y[4 * kb] = m4.x; st.y[4 * kb + 1] = m4.y; st.y[4 * kb + 2] = m4.z; st.y[4 * kb + 3] = m4.w;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t rr = row0 + rho(r, h) < n ? row0 + rho(r, h) : n - 1;
-            st.y[r] = Y1[rr * ldy1 + jy];
+            if (!RECOMP) st.y[r] = Y1[rr * ldy1 + jy];
             st.m[r] = M1[rr * ldm1 + km];
             st.gc[r] = G[rr * ldg + jg];
         }
@@ -233,10 +262,28 @@ __global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restr
                 dh = __builtin_amdgcn_mfma_f32_32x32x2f32((rv && kv) ? st.g[kb][q] : 0.f, w2[kb][q], dh, 0, 0, 0);
                 sz[kb][q] += (rv && kv) ? st.z[kb][q] : 0.f;
             }
+        f32x16 yv;
+        if (RECOMP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yv[r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool kv = kb * 8 + 4 * h + q < K1;
+                    yv = __builtin_amdgcn_mfma_f32_32x32x2f32((rv && kv) ? st.y[4 * kb + q] : 0.f, w1[kb][q], yv, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float y = yv[r] + b1v;
+                if (RELU) y = fmaxf(y, 0.f);
+                yv[r] = y;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool rr = row0 + rho(r, h) < n;
-            const float y = (rr && i < J1) ? st.y[r] : 0.f;
+            const float y = (rr && i < J1) ? (RECOMP ? yv[r] : st.y[r]) : 0.f;
             float dy = rr ? dh[r] : 0.f;                       // dH[rho(r, h)][j = i]
             if (RELU) dy = y > 0.f ? dy : 0.f;
             sdb1 += dy;
@@ -378,16 +425,21 @@ extern "C" int64_t gae_gcn2_bwd_dense_workspace_bytes(int64_t n, int64_t f_in, i
 extern "C" int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, int64_t lddz, const float *Y1, int64_t ldy1,
                                   int act1, const float *M1, int64_t ldm1, const float *W2, int64_t ldw2, int64_t n,
                                   int64_t f_in, int64_t f_mid, int64_t f_out, float *dW1, float *db1, float *dW2,
-                                  float *db2, void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream)
+                                  float *db2, void *workspace, int64_t workspace_bytes, int64_t *layout_out,
+                                  const float *W1, int64_t ldw1, const float *b1, void *stream)
 {
     GAE_REQUIRE(n >= 1 && f_in >= 1 && f_mid >= 1 && f_out >= 1, GAE_E_SIZE, "gae_gcn2_bwd_dense: bad size");
     GAE_REQUIRE(f_in <= 32 && f_mid <= 32 && f_out <= 32, GAE_E_RANGE, "gae_gcn2_bwd_dense: widths above 32");
     GAE_REQUIRE(act1 == GAE_ACT_IDENTITY || act1 == GAE_ACT_RELU, GAE_E_RANGE, "gae_gcn2_bwd_dense: act %d", act1);
-    GAE_REQUIRE(G && dZ && Y1 && M1 && W2 && workspace, GAE_E_NULL, "gae_gcn2_bwd_dense: NULL pointer");
+    GAE_REQUIRE(G && dZ && M1 && W2 && workspace, GAE_E_NULL, "gae_gcn2_bwd_dense: NULL pointer");
+    const bool recomp = Y1 == nullptr;
+    GAE_REQUIRE(!recomp || (W1 && ldw1 >= f_in && ldm1 >= (f_in + 3) / 4 * 4 && ldm1 % 4 == 0 && gae::aligned16(M1)),
+                GAE_E_NULL, "gae_gcn2_bwd_dense: without Y1 the pass recomputes it: W1 and rows of M1 of whole 16-byte "
+                            "vectors are needed");
     const int64_t j24 = (f_out + 3) / 4 * 4;
     GAE_REQUIRE(ldg >= j24 && ldg % 4 == 0 && gae::aligned16(G) && lddz >= j24 && lddz % 4 == 0 && gae::aligned16(dZ),
                 GAE_E_ALIGN, "gae_gcn2_bwd_dense: rows of G / dZ must be whole 16-byte vectors");
-    GAE_REQUIRE(ldy1 >= f_mid && ldm1 >= f_in && ldw2 >= f_mid, GAE_E_SIZE, "gae_gcn2_bwd_dense: leading dimension too small");
+    GAE_REQUIRE((recomp || ldy1 >= f_mid) && ldm1 >= f_in && ldw2 >= f_mid, GAE_E_SIZE, "gae_gcn2_bwd_dense: leading dimension too small");
     GAE_REQUIRE(workspace_bytes >= gae_gcn2_bwd_dense_workspace_bytes(n, f_in, f_mid, f_out) && gae::aligned16(workspace),
                 GAE_E_WORKSPACE, "gae_gcn2_bwd_dense: workspace too small or misaligned");
     int64_t lay[5], tpw = 1;
@@ -397,8 +449,16 @@ extern "C" int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, 
     const dim3 grid{unsigned(lay[0])};
     const int kb2 = int((f_out + 7) / 8);
 #define GAE_G2B(KBV, RL)                                                                                                 \
-    hipLaunchKernelGGL((gcn2_bwd_rows_kernel<KBV, RL>), grid, dim3(256), 0, s, G, ldg, dZ, lddz, Y1, ldy1, M1, ldm1, W2,  \
-                       ldw2, n, int(f_in), int(f_mid), int(f_out), tpw, partial, lay[1])
+    do {                                                                                                                 \
+        if (recomp)                                                                                                      \
+            hipLaunchKernelGGL((gcn2_bwd_rows_kernel<KBV, RL, true>), grid, dim3(256), 0, s, G, ldg, dZ, lddz, Y1, ldy1,  \
+                               M1, ldm1, W2, ldw2, n, int(f_in), int(f_mid), int(f_out), tpw, partial, lay[1], W1, ldw1,  \
+                               b1);                                                                                      \
+        else                                                                                                             \
+            hipLaunchKernelGGL((gcn2_bwd_rows_kernel<KBV, RL, false>), grid, dim3(256), 0, s, G, ldg, dZ, lddz, Y1, ldy1, \
+                               M1, ldm1, W2, ldw2, n, int(f_in), int(f_mid), int(f_out), tpw, partial, lay[1], W1, ldw1,  \
+                               b1);                                                                                      \
+    } while (0)
 #define GAE_G2K(RL)                                                                                                      \
     do { if (kb2 == 1) GAE_G2B(1, RL); else if (kb2 == 2) GAE_G2B(2, RL); else if (kb2 == 3) GAE_G2B(3, RL); else GAE_G2B(4, RL); } while (0)
     if (act1 == GAE_ACT_RELU) GAE_G2K(true); else GAE_G2K(false);

@@ -833,23 +833,40 @@ def linear2_fwd_raw(A, W1, b1, act1, W2, want_y1=True):
     return Y1, T
 
 
-def gcn2_bwd_dense_raw(G, dZ, Y1, act1, M1, W2):
+def gcn2_bwd_dense_raw(G, dZ, Y1, act1, M1, W2, W1=None, b1=None):
     """(dW1, db1, dW2, db2) of a two-layer encoder from G = A^T dZ in ONE pass over G, dZ, Y1, M1 (gae_gcn2_bwd_dense):
     dW2 = G^T Y1, db2 = colsum(dZ), dY1 = (G W2) (.) act1'(Y1), dW1 = dY1^T M1, db1 = colsum(dY1).  Inside
-    ``deferred_grad_reductions()`` the four gradients stay per-block partial sums for optim.Adam.step()."""
+    ``deferred_grad_reductions()`` the four gradients stay per-block partial sums for optim.Adam.step().
+    ``Y1`` None: the pass recomputes Y1 = act1(M1 W1^T + b1) itself (bit-identical to linear2_fwd_raw's), ``W1`` / ``b1``
+    needed."""
     G, ldg = _rowmajor(_f32(_gpu(G, "G"), "gcn2_bwd: G"), "G")
     dZ, lddz = _rowmajor(_f32(_gpu(dZ, "dZ"), "gcn2_bwd: dZ"), "dZ")
     if ldg % 4 or G.data_ptr() % 16:
         G = pad_rows(G); ldg = G.stride(0)
     if lddz % 4 or dZ.data_ptr() % 16:
         dZ = pad_rows(dZ); lddz = dZ.stride(0)
-    Y1, ldy1 = _rowmajor(_f32(Y1, "gcn2_bwd: Y1"), "Y1")
     M1, ldm1 = _rowmajor(_f32(M1, "gcn2_bwd: M1"), "M1")
     W2 = _f32(W2, "gcn2_bwd: W2")
     W2 = W2 if W2.stride(1) == 1 else W2.contiguous()
     n, f_out = G.shape
-    f_mid, f_in = Y1.shape[1], M1.shape[1]
-    if dZ.shape != G.shape or W2.shape != (f_out, f_mid) or Y1.shape[0] != n or M1.shape[0] != n:
+    f_mid, f_in = W2.shape[1], M1.shape[1]
+    ldy1 = ldw1 = 0
+    if Y1 is not None:
+        Y1, ldy1 = _rowmajor(_f32(Y1, "gcn2_bwd: Y1"), "Y1")
+        if Y1.shape != (n, f_mid):
+            raise GaeHipError("gcn2_bwd: operand shapes do not match")
+    else:
+        if W1 is None:
+            raise GaeHipError("gcn2_bwd: recomputing Y1 needs W1")
+        W1 = _f32(_gpu(W1, "W1"), "gcn2_bwd: W1")
+        W1 = W1 if W1.stride(1) == 1 else W1.contiguous()
+        _f32(b1, "gcn2_bwd: b1")
+        ldw1 = W1.stride(0)
+        if W1.shape != (f_mid, f_in):
+            raise GaeHipError("gcn2_bwd: W1 does not match the operands")
+        if ldm1 % 4 or M1.data_ptr() % 16:
+            M1 = pad_rows(M1); ldm1 = M1.stride(0)
+    if dZ.shape != G.shape or W2.shape[0] != f_out or M1.shape[0] != n:
         raise GaeHipError("gcn2_bwd: operand shapes do not match")
     dev = G.device
     dW1 = torch.empty(f_mid, f_in, dtype=torch.float32, device=dev)
@@ -867,7 +884,8 @@ def gcn2_bwd_dense_raw(G, dZ, Y1, act1, M1, W2):
         def launch():
             _lib.call("gae_gcn2_bwd_dense", _ptr(G), ldg, _ptr(dZ), lddz, _ptr(Y1), ldy1, int(act1), _ptr(M1), ldm1,
                       _ptr(W2), W2.stride(0), n, f_in, f_mid, f_out, _ptr(dW1), _ptr(db1), _ptr(dW2), _ptr(db2), _ptr(ws),
-                      ws.numel(), lay if defer else None, _stream())
+                      ws.numel(), lay if defer else None, _ptr(W1) if Y1 is None else None, ldw1,
+                      _ptr(b1) if Y1 is None else None, _stream())
         if profiler is not None:
             profiler.wrap(("gcn2_bwd", n, f_in, f_mid, f_out), launch)
         else:

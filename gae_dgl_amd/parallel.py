@@ -432,10 +432,10 @@ class ShardedEncoder2Function(torch.autograd.Function):
     layer evaluated as A (H1 W2^T) + b2 and the backward pass from G = A^T dZ (csrc/tall.hip):
 
         forward    M1 = A X                       product at the input width (exchange of X: once, if it is constant)
-                   H1, T = gae_linear2_fwd(M1)    one pass: H1 = act1(M1 W1^T + b1), T = H1 W2^T
+                   T = gae_linear2_fwd(M1)        one pass: H1 = act1(M1 W1^T + b1) (registers only), T = H1 W2^T
                    Z = A T + b2                   product at the OUTPUT width, bias in its epilogue (gae_spmm_csr_ep)
         backward   G = A^T dZ                     product at the output width
-                   dW1, db1, dW2, db2 = gae_gcn2_bwd_dense(G, dZ, H1, M1)     one pass, dY1 never stored
+                   dW1, db1, dW2, db2 = gae_gcn2_bwd_dense(G, dZ, M1)     one pass; H1 recomputed (same bits), dY1 never stored
 
     Three products and two dense passes per step instead of three products at the hidden width and five dense
     launches; A H1 is never formed, so two of the three exchanges between ranks move the output width.  Values equal the
@@ -449,21 +449,23 @@ class ShardedEncoder2Function(torch.autograd.Function):
         constant = bool(sg.cache_constant_inputs)
         M1 = _rank_product(sg, x_local.contiguous(), "fwd", constant)
         need = any(ctx.needs_input_grad[1:5])
-        H1, T = sg._timed("dense_fwd", lambda: ops.linear2_fwd_raw(M1, W1, b1, act1, W2, want_y1=need))
+        # H1 is not stored: the backward pass recomputes it, bit for bit, from the tile of M1 it reads anyway
+        _, T = sg._timed("dense_fwd", lambda: ops.linear2_fwd_raw(M1, W1, b1, act1, W2, want_y1=False))
         Z = _rank_product(sg, T, "fwd", bias=b2)
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
         if need:
-            ctx.save_for_backward(M1, H1, W2)
+            ctx.save_for_backward(M1, W1, b1, W2)
         return Z
 
     @staticmethod
     def backward(ctx, dZ):
         from . import ops
-        M1, H1, W2 = ctx.saved_tensors
+        M1, W1, b1, W2 = ctx.saved_tensors
         sg = ctx.sg
         dZc = dZ.contiguous()
         G = _rank_product(sg, dZc, "bwd")
-        dW1, db1, dW2, db2 = sg._timed("dense_bwd", lambda: ops.gcn2_bwd_dense_raw(G, dZc, H1, ctx.act1, M1, W2))
+        dW1, db1, dW2, db2 = sg._timed("dense_bwd",
+                                       lambda: ops.gcn2_bwd_dense_raw(G, dZc, None, ctx.act1, M1, W2, W1=W1, b1=b1))
         return None, dW1, (db1 if ctx.has_b1 else None), dW2, (db2 if ctx.has_b2 else None), None, None
 
 

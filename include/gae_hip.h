@@ -479,7 +479,11 @@ int64_t gae_gcn2_bwd_dense_workspace_bytes(int64_t n, int64_t f_in, int64_t f_mi
 int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, int64_t lddz, const float *Y1, int64_t ldy1,
                        int act1, const float *M1, int64_t ldm1, const float *W2, int64_t ldw2, int64_t n,
                        int64_t f_in, int64_t f_mid, int64_t f_out, float *dW1, float *db1, float *dW2, float *db2,
-                       void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream);
+                       void *workspace, int64_t workspace_bytes, int64_t *layout_out, const float *W1, int64_t ldw1,
+                       const float *b1, void *stream);
+/* (Y1 == NULL: the pass RECOMPUTES Y1 = act1(M1 W1^T + b1) from the tile of M1 it reads anyway -- W1 [f_mid, f_in] (ldw1),
+ *  b1 [f_mid] or NULL -- with gae_linear2_fwd's products in its order, i.e. the same bits: the forward then need not
+ *  store Y1 at all (gae_linear2_fwd with Y1 = NULL) and this pass reads 2 f_mid fewer floats per row.) */
 
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16

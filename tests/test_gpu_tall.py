@@ -124,6 +124,16 @@ def test_gcn2_bwd_dense_matches_fp64(n, f_in, f_mid, f_out, act):
     # deterministic
     again = ops.gcn2_bwd_dense_raw(G.to(DEV), dZ.to(DEV), Y1.to(DEV), act, M1.to(DEV), W2.to(DEV))
     assert all(torch.equal(a, b) for a, b in zip((dW1, db1, dW2, db2), again))
+    # Y1 recomputed inside the pass from M1, W1, b1: the SAME bits as with the Y1 gae_linear2_fwd stored
+    W1 = torch.randn(f_mid, f_in, generator=g) / f_in ** 0.5
+    b1 = torch.randn(f_mid, generator=g)
+    ld = (f_in + 3) // 4 * 4
+    buf = torch.full((n, ld), float("nan"), device=DEV)
+    buf[:, :f_in] = M1.to(DEV)
+    Y1f, _ = ops.linear2_fwd_raw(buf[:, :f_in], W1.to(DEV), b1.to(DEV), act, W2.to(DEV))
+    stored = ops.gcn2_bwd_dense_raw(G.to(DEV), dZ.to(DEV), Y1f, act, buf[:, :f_in], W2.to(DEV))
+    recomp = ops.gcn2_bwd_dense_raw(G.to(DEV), dZ.to(DEV), None, act, buf[:, :f_in], W2.to(DEV), W1=W1.to(DEV), b1=b1.to(DEV))
+    assert all(torch.equal(a, b) for a, b in zip(stored, recomp))
 
 
 def _encoder_reference(src, dst, n, X, Ws, bs, dZ):
