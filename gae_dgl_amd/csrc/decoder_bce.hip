@@ -50,7 +50,7 @@ constexpr int PREP_ROWS = 64;    // rows per block of the prepare kernel
 // tuning knobs (gae_tuning_set): "bce_ri" 16-row subtiles per wave (rows / block = 64 RI),
 // "bce_s_bf16" 1 = bf16x3 S product, 0 = exact fp32 S product
 gae::Knob g_bce_ri{2};
-gae::Knob g_bce_s_bf16{1};
+gae::Knob g_bce_s_bf16{2};        // S = Zt Zt^T: 2 = three bf16 pieces per operand (fp32-grade logits, default), 1 = two pieces (round 1-3), 0 = exact fp32 MFMA
 gae::Knob g_bce_grid{2048};       // "bce_grid": target size of the (row block, column split) grid of the full-square kernel
 constexpr int kChipCus = 256;             // MI355X: the launch-shape heuristics below are written for this part
 gae::Knob g_bce_strip_store{-1};  // "bce_strip_store": -1 auto (non-temporal from 32 k rows on: GBs of strips, 2.93 -> 2.88 ms on a ZINC
@@ -218,7 +218,45 @@ __device__ __forceinline__ void split_bf16x4(const f32x4 &v, s16x4 &hi, s16x4 &l
     lo = __builtin_bit_cast(s16x4, ul);
 }
 
-template <int KS, bool WITH_GRAD, int RI, int MINW, bool SBF16, bool PBF16, bool TRV = false>
+// Three bf16 pieces of fp32 values: v = hi + lo + lo2 with hi = bf16(v), lo = bf16(v - hi), lo2 = bf16(v - hi - lo):
+// 24 mantissa bits, i.e. v itself up to its last bit.  The S product of the fused loss uses all pairs of pieces down to
+// 2^-24 relative (hi.hi, hi.lo, lo.hi, lo.lo, hi.lo2, lo2.hi): an fp32-grade logit on the bf16 matrix pipe (round 4;
+// the two-piece product, 16 mantissa bits per operand, left 8e-5 of the gradient's scale on embeddings whose large
+// components cancel -- tools/r04/loss_condition.py).
+__device__ __forceinline__ void split_bf16x4_3(const f32x4 &v, s16x4 &hi, s16x4 &lo, s16x4 &lo2)
+{
+    unsigned h[2], l[2], l2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2 a = {v[2 * q], v[2 * q + 1]};
+        const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
+        const f32x2 r1 = a - f32x2{__uint_as_float(hu << 16), __uint_as_float(hu & 0xffff0000u)};
+        const unsigned lu = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+        const f32x2 r2 = r1 - f32x2{__uint_as_float(lu << 16), __uint_as_float(lu & 0xffff0000u)};
+        h[q] = hu; l[q] = lu;
+        l2[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+    }
+    struct U { unsigned a, b; } uh{h[0], h[1]}, ul{l[0], l[1]}, ul2{l2[0], l2[1]};
+    hi = __builtin_bit_cast(s16x4, uh);
+    lo = __builtin_bit_cast(s16x4, ul);
+    lo2 = __builtin_bit_cast(s16x4, ul2);
+}
+// third piece of values whose first two pieces are given (the column tiles: Zhi / Zlo come from the prepare step)
+__device__ __forceinline__ s16x4 third_piece(const f32x4 &v, const s16x4 &hi, const s16x4 &lo)
+{
+    unsigned l2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2 a = {v[2 * q], v[2 * q + 1]};
+        const f32x2 fh = {gae::bf16_to_f32((unsigned short)hi[2 * q]), gae::bf16_to_f32((unsigned short)hi[2 * q + 1])};
+        const f32x2 fl = {gae::bf16_to_f32((unsigned short)lo[2 * q]), gae::bf16_to_f32((unsigned short)lo[2 * q + 1])};
+        l2[q] = __builtin_bit_cast(unsigned, __builtin_convertvector((a - fh) - fl, bf16x2));
+    }
+    struct U { unsigned a, b; } u{l2[0], l2[1]};
+    return __builtin_bit_cast(s16x4, u);
+}
+
+template <int KS, bool WITH_GRAD, int RI, int MINW, bool SBF16, bool PBF16, bool TRV = false, bool S3 = false>
 __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     const float *__restrict__ Zt /*[n][16 KS]*/, const unsigned short *__restrict__ Zhi,
     const unsigned short *__restrict__ Zlo, int64_t n, int64_t row_begin, int64_t n_local, int64_t cols_per_split,
@@ -232,13 +270,16 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     constexpr int LDH = DP + 4;          // bf16 LDS row stride (elements): 8-byte aligned rows
     constexpr int V4 = TJ * DP / 4 / 256;  // float4 per thread and staged tile (1, 2, 4)
     constexpr int LDT = TJ + 4;          // transposed bf16 tile row stride (elements), 8-byte aligned rows
+    static_assert(!S3 || SBF16, "the three-piece S product is a bf16 form");
     constexpr bool NEED_F32 = !SBF16 || (WITH_GRAD && !PBF16);
+    constexpr bool LOAD_F32 = NEED_F32 || S3;            // S3: the staged fp32 values give the third piece
     constexpr bool NEED_BF = SBF16 || (WITH_GRAD && PBF16);
     static_assert(!TRV || (SBF16 && PBF16 && WITH_GRAD), "transpose reads take the V fragments from the bf16 [j][k] tiles");
     constexpr bool NEED_T = WITH_GRAD && PBF16 && !TRV;
     __shared__ __attribute__((aligned(16))) float Zs[2][NEED_F32 ? TJ * LDA : 4];            // fp32 column tile [j][k]
     __shared__ __attribute__((aligned(16))) unsigned short Hs[2][SBF16 ? TJ * LDH : 4];      // bf16 hi [j][k]
     __shared__ __attribute__((aligned(16))) unsigned short Ls[2][SBF16 ? TJ * LDH : 4];      // bf16 lo [j][k]
+    __shared__ __attribute__((aligned(16))) unsigned short L2s[2][S3 ? TJ * LDH : 4];        // bf16 lo2 [j][k]
     __shared__ __attribute__((aligned(16))) unsigned short HT[2][NEED_T ? DP * LDT : 4];     // bf16 hi [k][j]
     __shared__ __attribute__((aligned(16))) unsigned short LT[2][NEED_T ? DP * LDT : 4];     // bf16 lo [k][j]
     __shared__ double red[4][2];
@@ -269,6 +310,7 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
     constexpr int K2 = KS == 1 ? 1 : KS / 2;
     f32x4 bfrag[RI][KS];
     s16x8 bhh[RI][K2], bll[RI][K2];
+    s16x8 b3[RI][S3 ? K2 : 1];        // S3: KS == 1: [bhi | blo2]; chunk pairs: [blo2 | blo2']
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri) {
         const int64_t i = row_base + ri * 16 + l15;
@@ -280,14 +322,17 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
             b *= LOG2E;
             bfrag[ri][c] = b;
             if (SBF16) {
-                s16x4 bh, bl;
-                split_bf16x4(b, bh, bl);
+                s16x4 bh, bl, bl2;
+                if (S3) split_bf16x4_3(b, bh, bl, bl2);
+                else split_bf16x4(b, bh, bl);
                 if (KS == 1) {
                     bhh[ri][0] = cat(bh, bh);
                     bll[ri][0] = cat(bl, bl);
+                    if (S3) b3[ri][0] = cat(bh, bl2);
                 } else {
                     put_half(bhh[ri][c / 2], c & 1, bh);
                     put_half(bll[ri][c / 2], c & 1, bl);
+                    if (S3) put_half(b3[ri][c / 2], c & 1, bl2);
                 }
             }
         }
@@ -312,7 +357,7 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
             const int jj = idx / (DP / 4), kk = (idx % (DP / 4)) * 4;
             const bool jv = j0 + jj < col_end;
             const int64_t j = jv ? j0 + jj : col_begin;
-            if (NEED_F32) {
+            if (LOAD_F32) {
                 st.f[q] = *reinterpret_cast<const f32x4 *>(Zt + j * DP + kk);
                 if (!jv) st.f[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -332,6 +377,7 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
             if (SBF16) {
                 *reinterpret_cast<s16x4 *>(&Hs[buf][jj * LDH + kk]) = st.h[q];
                 *reinterpret_cast<s16x4 *>(&Ls[buf][jj * LDH + kk]) = st.l[q];
+                if (S3) *reinterpret_cast<s16x4 *>(&L2s[buf][jj * LDH + kk]) = third_piece(st.f[q], st.h[q], st.l[q]);
             }
             if (NEED_T) {
 #pragma unroll
@@ -364,18 +410,29 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
                     auto frag = [&](const unsigned short *base, int c) {
                         return *reinterpret_cast<const s16x4 *>(&base[(jt * 16 + l15) * LDH + 16 * c + 4 * g]);
                     };
-                    if (KS == 1) {        // S = [ah | al] x [bhi | bhi] + [ah | al] x [blo | blo]
-                        const s16x8 ahl = cat(frag(Hs[buf], 0), frag(Ls[buf], 0));
+                    if (KS == 1) {        // S = [ah | al] x [bhi | bhi] + [ah | al] x [blo | blo]  (+ [al2 | ah] x [bhi | blo2])
+                        const s16x4 fh = frag(Hs[buf], 0);
+                        const s16x8 ahl = cat(fh, frag(Ls[buf], 0));
 #pragma unroll
                         for (int ri = 0; ri < RI; ++ri) {
+                            if (S3) sacc[ri] = mfma32(cat(frag(L2s[buf], 0), fh), b3[ri][0], sacc[ri]);
                             sacc[ri] = mfma32(ahl, bll[ri][0], sacc[ri]);
                             sacc[ri] = mfma32(ahl, bhh[ri][0], sacc[ri]);
                         }
-                    } else {              // chunk pairs: lo.hi + hi.lo + hi.hi, 3 MFMAs per 32 features
+                    } else {              // chunk pairs: lo.hi + hi.lo + hi.hi, 3 MFMAs per 32 features (S3: + lo.lo, hi.lo2, lo2.hi)
 #pragma unroll
                         for (int c2 = 0; c2 < K2; ++c2) {
                             const s16x8 ah = cat(frag(Hs[buf], 2 * c2), frag(Hs[buf], 2 * c2 + 1));
                             const s16x8 al = cat(frag(Ls[buf], 2 * c2), frag(Ls[buf], 2 * c2 + 1));
+                            if (S3) {
+                                const s16x8 al2 = cat(frag(L2s[buf], 2 * c2), frag(L2s[buf], 2 * c2 + 1));
+#pragma unroll
+                                for (int ri = 0; ri < RI; ++ri) {
+                                    sacc[ri] = mfma32(al2, bhh[ri][c2], sacc[ri]);
+                                    sacc[ri] = mfma32(ah, b3[ri][c2], sacc[ri]);
+                                    sacc[ri] = mfma32(al, bll[ri][c2], sacc[ri]);
+                                }
+                            }
 #pragma unroll
                             for (int ri = 0; ri < RI; ++ri) {
                                 sacc[ri] = mfma32(al, bhh[ri][c2], sacc[ri]);
@@ -554,7 +611,7 @@ __host__ __device__ inline int64_t sym_strip_offset(int64_t I, int64_t NP, int64
 // TRV (default): the V fragments of O' += P V come from LDS transpose reads of the [j][k] tiles -- no second,
 // transposed copy of every tile (16 ds_write_b16 per thread and tile, 8.7 KB of LDS): Pubmed 170 -> 166 us, a ZINC
 // batch 2.92 -> 2.88 ms.  TRV = false keeps the round-2 form (knob "bce_sym_tr" = 0).
-template <bool WITH_GRAD, int RI, bool TRV>
+template <bool WITH_GRAD, int RI, bool TRV, bool S3 = false>
 __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     const float *__restrict__ Zt /*[n][16]*/, const unsigned short *__restrict__ Zhi,
     const unsigned short *__restrict__ Zlo, int64_t n, int64_t cols_per_chunk,
@@ -569,6 +626,7 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     constexpr int LDM = TJ + 4;          // mirror tile row stride (floats)
     __shared__ __attribute__((aligned(16))) unsigned short Hs[2][TJ * LDH];       // bf16 hi [j][k]
     __shared__ __attribute__((aligned(16))) unsigned short Ls[2][TJ * LDH];       // bf16 lo [j][k]
+    __shared__ __attribute__((aligned(16))) unsigned short L2s[2][S3 ? TJ * LDH : 4];       // bf16 lo2 [j][k] (three-piece S)
     __shared__ __attribute__((aligned(16))) unsigned short HT[2][TRV ? 4 : DP * LDT];       // bf16 hi [k][j]
     __shared__ __attribute__((aligned(16))) unsigned short LT[2][TRV ? 4 : DP * LDT];       // bf16 lo [k][j]
     __shared__ __attribute__((aligned(16))) float MR[4][16 * LDM];                // mirror tiles [wave][f][j]
@@ -598,6 +656,7 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     static_assert(RI % 2 == 0, "row subtiles are paired into K = 32 mirror products");
     s16x8 bhh[RI];               // B fragments of S^T = Zj Zi^T (row operand, log2(e) folded in): [hi | hi]
     s16x8 bll[RI];               // ... and [lo | lo]: S = (ah + al)(bhi + blo), all four partial products
+    s16x8 b3[S3 ? RI : 1];       // S3: [hi | lo2] against [al2 | ah]: + al2.bhi + ah.blo2
     s16x8 zTh[RI / 2], zTl[RI / 2];   // B fragments of the mirror product, row subtiles (2 rp, 2 rp + 1) concatenated:
                                       // lane (f = l15, g) -> Zt[i = 4 g + r][f]
 #pragma unroll
@@ -606,8 +665,9 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
         f32x4 b = *reinterpret_cast<const f32x4 *>(Zt + (i < n ? i : 0) * DP + 4 * g);
         if (i >= n) b = f32x4{0.f, 0.f, 0.f, 0.f};
         b *= LOG2E;
-        s16x4 bhi, blo;
-        split_bf16x4(b, bhi, blo);
+        s16x4 bhi, blo, blo2;
+        if (S3) { split_bf16x4_3(b, bhi, blo, blo2); b3[ri] = cat(bhi, blo2); }
+        else split_bf16x4(b, bhi, blo);
         bhh[ri] = cat(bhi, bhi);
         bll[ri] = cat(blo, blo);
         s16x4 th, tl;
@@ -627,9 +687,10 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     f32x4 oacc[RI];
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri) oacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
-    double sumA[RI], sumL[RI];
+    double sumA = 0.0, sumL = 0.0;    // over this lane's rows of all RI subtiles (rows >= n excluded as they are added)
+    bool rvalid[RI];
 #pragma unroll
-    for (int ri = 0; ri < RI; ++ri) { sumA[ri] = 0.0; sumL[ri] = 0.0; }
+    for (int ri = 0; ri < RI; ++ri) rvalid[ri] = (row_base + ri * 16 + l15) < n;
     // zero-padded columns (j >= n) exist only in the last tile of the last chunk: their count per lane, once
     const int64_t pad_j0 = (col_end == n && (n % TJ) != 0) ? n / TJ * TJ : -1;
     float pad_lane = 0.f;
@@ -640,7 +701,9 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
             for (int r = 0; r < 4; ++r) pad_lane += (pad_j0 + jt * 16 + 4 * g + r >= n) ? 1.f : 0.f;
     }
 
-    struct Stage { s16x4 h[V4], l[V4]; };
+    // S3: only the fp32 values are staged (4 registers instead of 4 + 4 + 4); hi / lo / lo2 are split off at store time
+    // with the prepare step's own roundings (v_cvt_pk_bf16_f32 = round to nearest even: the same hi / lo bits)
+    struct Stage { s16x4 h[S3 ? 1 : V4], l[S3 ? 1 : V4]; f32x4 f[S3 ? V4 : 1]; };
     auto load_tile = [&](int64_t j0, Stage &st) {
 #pragma unroll
         for (int q = 0; q < V4; ++q) {
@@ -648,9 +711,14 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
             const int jj = idx / (DP / 4), kk = (idx % (DP / 4)) * 4;
             const bool jv = j0 + jj < col_end;
             const int64_t j = jv ? j0 + jj : col_begin;
-            st.h[q] = *reinterpret_cast<const s16x4 *>(Zhi + j * DP + kk);
-            st.l[q] = *reinterpret_cast<const s16x4 *>(Zlo + j * DP + kk);
-            if (!jv) { st.h[q] = s16x4{0, 0, 0, 0}; st.l[q] = s16x4{0, 0, 0, 0}; }
+            if (S3) {
+                st.f[q] = *reinterpret_cast<const f32x4 *>(Zt + j * DP + kk);
+                if (!jv) st.f[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                st.h[q] = *reinterpret_cast<const s16x4 *>(Zhi + j * DP + kk);
+                st.l[q] = *reinterpret_cast<const s16x4 *>(Zlo + j * DP + kk);
+                if (!jv) { st.h[q] = s16x4{0, 0, 0, 0}; st.l[q] = s16x4{0, 0, 0, 0}; }
+            }
         }
     };
     auto store_tile = [&](int buf, const Stage &st) {
@@ -658,13 +726,21 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
         for (int q = 0; q < V4; ++q) {
             const int idx = tid + 256 * q;
             const int jj = idx / (DP / 4), kk = (idx % (DP / 4)) * 4;
-            *reinterpret_cast<s16x4 *>(&Hs[buf][jj * LDH + kk]) = st.h[q];
-            *reinterpret_cast<s16x4 *>(&Ls[buf][jj * LDH + kk]) = st.l[q];
+            s16x4 h4, l4;
+            if (S3) {
+                s16x4 l24;
+                split_bf16x4_3(st.f[q], h4, l4, l24);
+                *reinterpret_cast<s16x4 *>(&L2s[buf][jj * LDH + kk]) = l24;
+            } else {
+                h4 = st.h[q]; l4 = st.l[q];
+            }
+            *reinterpret_cast<s16x4 *>(&Hs[buf][jj * LDH + kk]) = h4;
+            *reinterpret_cast<s16x4 *>(&Ls[buf][jj * LDH + kk]) = l4;
             if (WITH_GRAD && !TRV) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    HT[buf][(kk + e) * LDT + jj] = (unsigned short)st.h[q][e];
-                    LT[buf][(kk + e) * LDT + jj] = (unsigned short)st.l[q][e];
+                    HT[buf][(kk + e) * LDT + jj] = (unsigned short)h4[e];
+                    LT[buf][(kk + e) * LDT + jj] = (unsigned short)l4[e];
                 }
             }
         }
@@ -710,6 +786,9 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
 #pragma unroll
                 for (int ri = 0; ri < RI; ++ri) {
                     sacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (S3)       // the smallest terms first: al2.bhi + ah.blo2
+                        sacc[ri] = mfma32(cat(*reinterpret_cast<const s16x4 *>(&L2s[buf][(jt * 16 + l15) * LDH + 4 * g]), ah),
+                                          b3[ri], sacc[ri]);
                     sacc[ri] = mfma32(ahl, bll[ri], sacc[ri]);
                     sacc[ri] = mfma32(ahl, bhh[ri], sacc[ri]);
                 }
@@ -789,11 +868,14 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
         // zero-padded columns of the last tile (j >= n): each contributed log2(1 + e^0) = 1 per row
         const float padcnt = j0 == pad_j0 ? pad_lane : 0.f;
         const double w = offdiag ? 2.0 : 1.0;
+        float a = 0.f, l = 0.f;
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri) {
-            sumA[ri] += w * double(tA[ri]);
-            sumL[ri] += w * double(__builtin_amdgcn_logf(tP[ri]) - padcnt);
+            a += rvalid[ri] ? tA[ri] : 0.f;
+            l += rvalid[ri] ? __builtin_amdgcn_logf(tP[ri]) - padcnt : 0.f;
         }
+        sumA += w * double(a);
+        sumL += w * double(l);
     };
 
     Stage stage;
@@ -824,13 +906,7 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
                 if (i < n) op[i * DP + l15] = oacc[ri][r];
             }
     }
-    double la = 0.0, ll = 0.0;
-#pragma unroll
-    for (int ri = 0; ri < RI; ++ri) {
-        const bool rv = (row_base + ri * 16 + l15) < n;
-        la += rv ? sumA[ri] * 0.69314718055994531 : 0.0;    // sum |y| / log2(e) = sum |x|
-        ll += rv ? sumL[ri] : 0.0;
-    }
+    double la = sumA * 0.69314718055994531, ll = sumL;     // sum |y| / log2(e) = sum |x|
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { la += __shfl_down(la, off, 64); ll += __shfl_down(ll, off, 64); }
     if (lane == 0) { red[wave][0] = la; red[wave][1] = ll; }
@@ -1169,7 +1245,19 @@ int launch_dense(const BcePlan &p, const float *Zt, const unsigned short *Zhi, c
     const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
 #define GAE_BD(KS, RI, MW, SB)                                                                                     \
     do {                                                                                                           \
-        if (SB && g_bce_pv_bf16 && WITH_GRAD && g_bce_sym_tr)                                                       \
+        if (SB && g_bce_s_bf16 >= 2 && g_bce_pv_bf16 && WITH_GRAD && g_bce_sym_tr)                                  \
+            hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW, SB, SB, SB && WITH_GRAD, SB>), grid, dim3(256), 0, s, \
+                               Zt, Zhi, Zlo, n, row_begin, n_local, p.cols_per_split, O, lp, cs, p.prep_blocks, S, \
+                               S_all_f, unsigned(p.row_blocks));                                                   \
+        else if (SB && g_bce_s_bf16 >= 2 && g_bce_pv_bf16)                                                          \
+            hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW, SB, SB, false, SB>), grid, dim3(256), 0, s, \
+                               Zt, Zhi, Zlo, n, row_begin, n_local, p.cols_per_split, O, lp, cs, p.prep_blocks, S, \
+                               S_all_f, unsigned(p.row_blocks));                                                   \
+        else if (SB && g_bce_s_bf16 >= 2)                                                                           \
+            hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW, SB, false, false, SB>), grid, dim3(256), 0, s, \
+                               Zt, Zhi, Zlo, n, row_begin, n_local, p.cols_per_split, O, lp, cs, p.prep_blocks, S, \
+                               S_all_f, unsigned(p.row_blocks));                                                   \
+        else if (SB && g_bce_pv_bf16 && WITH_GRAD && g_bce_sym_tr)                                                  \
             hipLaunchKernelGGL((bce_dense_kernel<KS, WITH_GRAD, RI, MW, SB, SB, SB && WITH_GRAD>), grid, dim3(256), 0, s, \
                                Zt, Zhi, Zlo, n, row_begin, n_local, p.cols_per_split, O, lp, cs, p.prep_blocks, S, \
                                S_all_f, unsigned(p.row_blocks));                                                   \
@@ -1320,14 +1408,16 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
     int rc;
     if (p.sym) {
         const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
-#define GAE_SYM(WG, R, T)                                                                                           \
-    hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R, T>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
+#define GAE_SYM3(WG, R, T, S3V)                                                                                     \
+    hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R, T, S3V>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
                        lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks),                                    \
                        g_bce_strip_store >= 0 ? g_bce_strip_store : (n >= 32768 ? 1 : 0))
+#define GAE_SYM(WG, R, T) do { if (g_bce_s_bf16 >= 2) GAE_SYM3(WG, R, T, true); else GAE_SYM3(WG, R, T, false); } while (0)
         if (!dZ) { if (p.sym_pr == 256) GAE_SYM(false, 4, false); else GAE_SYM(false, 2, false); }
         else if (g_bce_sym_tr) { if (p.sym_pr == 256) GAE_SYM(true, 4, true); else GAE_SYM(true, 2, true); }
         else { if (p.sym_pr == 256) GAE_SYM(true, 4, false); else GAE_SYM(true, 2, false); }
 #undef GAE_SYM
+#undef GAE_SYM3
         GAE_CHECK_LAUNCH("bce_dense_sym_kernel");
         if (dZ && !(g_bce_fold_mirror && p.LPR == 4)) {     // otherwise the edge kernel folds the strips itself
             hipLaunchKernelGGL(bce_mirror_reduce_kernel, dim3(unsigned((n + TJ - 1) / TJ)), dim3(256), 0, s, Wmir, n,
