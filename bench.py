@@ -291,7 +291,7 @@ class CitationWorkload:
                      "optimizer": "adam lr=1e-2: " + opt_name, "parallelism": "1 GPU",
                      "launch": "hipGraph replay of the captured step" if self.use_graph else "eager",
                      "forward_products": "fp32 MFMA (exact fp32 embeddings)",
-                     "loss_products": "bf16x3 split products on K = 32 MFMAs, fp32 accumulate (knobs bce_s_bf16=1, bce_pv_bf16=1)",
+                     "loss_products": "split-operand products on K = 32 MFMAs, fp32 accumulate (knobs bce_s_bf16=3, bce_pv_bf16=1): N >= 8192 (symmetric kernel): two fp16 pieces per operand for S = Z Z^T and dZ = P Z (22 mantissa bits; embeddings beyond |z| = 32768 fall back to the bf16 form inside the same call); N < 8192: three bf16 pieces for S (24 bits), two for P Z",
                      "dW_products": "bf16x3 split products, fp32 accumulate (knob atb_bf16=1)",
                      "residency": f"operands of the dominant launch ({2 * n * self.F_in * 4 / 1e6:.0f} MB) stay in the "
                                   "256 MB Infinity Cache across the timed replays: its '% of 8 TB/s' is measured "
@@ -537,6 +537,9 @@ class ZincWorkload:
         ip, ix = bg.csr()
         H = bg.ndata['h']
         out = ops.pad_rows(torch.empty(H.shape, device=self.dev))
+        nb, eb = bg.number_of_nodes(), bg.number_of_edges()
+        self.alg_bytes = 4 * (nb + 1) + 4 * eb + 2 * 4 * 39 * nb
+        self.dominant_desc = f"spmm F=39 (layer-1 aggregation of a {self.B}-molecule batch, {nb} rows, {eb} edges)"
         return lambda: ops.spmm_raw(ip, ix, H, bg.number_of_nodes(), out=out, out_padded=True,
                                     blockdiag=bg.block_diag, plan=bg.spmm_plan(False))
 
@@ -757,6 +760,49 @@ def extras(dev):
     r["gather_bytes_no_reuse"] = 4 * (n + 1) + 4 * r["nnz"] + 4 * 32 * r["nnz"] + 4 * 32 * n
     r["achieved_GBs_no_reuse_model"] = r["gather_bytes_no_reuse"] / (r["us_per_launch"] * 1e-6) / 1e9
     out.append(r)
+    return out
+
+
+def extra_steps(args, dev):
+    """whole training steps of the other single-GPU BASELINE configurations, same method as the headline line (captured
+    step, barrier + synchronize around exactly `steps` replays, regions repeated to >= 0.3 s, median region), each with
+    the roofline fraction of its own HBM-dominant launch (back-to-back HIP-event timing on the step's operands)"""
+    out = {}
+    base = argparse.Namespace(**vars(args))
+    base.steps, base.warmup = 20, 5
+    jobs = [("cora", lambda a: CitationWorkload("cora", a, dev), None),
+            ("citeseer", lambda a: CitationWorkload("citeseer", a, dev), None),
+            ("vgae", lambda a: VgaeWorkload(a, dev), None),
+            ("zinc128", lambda a: ZincWorkload(a, dev), 128),
+            ("zinc4096", lambda a: ZincWorkload(a, dev), 4096)]
+    for name, make, B in jobs:
+        t_job = time.perf_counter()
+        a = argparse.Namespace(**vars(base))
+        if B is not None:
+            a.batch_graphs = B
+        wl = make(a)
+        for _ in range(a.warmup):
+            wl.step()
+        if getattr(wl, "use_graph", False):
+            wl.capture()
+            for _ in range(a.warmup):
+                wl.step()
+        regions = timed_regions(wl, a, torch.cuda.synchronize, 1, dev, min_total_s=0.3, max_regions=50)
+        el = float(np.median(regions)) / a.steps
+        dom_fn = wl.dominant_launch()
+        t_dom = time_launches(dom_fn, iters=50, warmup=30)
+        r = {"workload": wl.meta["workload"], "ms_per_step": el * 1e3, "value": wl.edges_per_step / el, "unit": "edges/s",
+             "launch": wl.meta.get("launch"), "timing": {"regions": len(regions), "steps_per_region": a.steps},
+             "dominant": {"kernel": wl.dominant_desc, "avg_launch_us": t_dom * 1e6, "alg_bytes_per_launch": wl.alg_bytes,
+                          "achieved_GBs": wl.alg_bytes / t_dom / 1e9, "frac": wl.alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS,
+                          "traffic": pmc_traffic(getattr(wl, "pmc_key", ""))}}
+        if B is not None:
+            r["epoch_time_s"] = el * wl.meta["batches_per_epoch_at_239455_graphs"]
+            r["batch_graphs"] = B
+        r["wall_s"] = time.perf_counter() - t_job
+        out[name] = r
+        del wl, dom_fn
+        torch.cuda.empty_cache()
     return out
 
 
@@ -1071,7 +1117,7 @@ def main():
         # ---- the same step with exact-fp32 products everywhere (no bf16 x 3 split)
         if graphed and isinstance(wl, CitationWorkload):
             from gae_dgl_amd import _lib
-            knobs = (b"bce_s_bf16", b"bce_pv_bf16", b"atb_bf16")
+            knobs = {b"bce_s_bf16": 3, b"bce_pv_bf16": 1, b"atb_bf16": 1}          # name -> the library's default
             for k in knobs:
                 _lib.call("gae_tuning_set", k, 0)
             try:
@@ -1087,8 +1133,8 @@ def main():
                 line["ms_per_step_exact_fp32"] = (time.perf_counter() - t1) / args.steps * 1e3
                 line["value_exact_fp32"] = wl.edges_per_step / (line["ms_per_step_exact_fp32"] * 1e-3)
             finally:
-                for k in knobs:
-                    _lib.call("gae_tuning_set", k, 1)
+                for k, v in knobs.items():
+                    _lib.call("gae_tuning_set", k, v)
     if "decoder_bce" in {k[0] for k in times}:
         kb = [k for k in times if k[0] == "decoder_bce"]
         tb = float(np.mean([t for k in kb for t in times[k]]))
@@ -1106,7 +1152,7 @@ def main():
     if not args.no_extra and world == 1 and workload not in ("rmat",):
         del wl
         torch.cuda.empty_cache()
-        line["extra"] = {"spmm_kernel_only": extras(dev)}
+        line["extra"] = {"steps": extra_steps(args, dev), "spmm_kernel_only": extras(dev)}
     if dist.is_initialized():
         if world > 1:
             dist.barrier()

@@ -50,7 +50,9 @@ constexpr int PREP_ROWS = 64;    // rows per block of the prepare kernel
 // tuning knobs (gae_tuning_set): "bce_ri" 16-row subtiles per wave (rows / block = 64 RI),
 // "bce_s_bf16" 1 = bf16x3 S product, 0 = exact fp32 S product
 gae::Knob g_bce_ri{2};
-gae::Knob g_bce_s_bf16{2};        // S = Zt Zt^T: 2 = three bf16 pieces per operand (fp32-grade logits, default), 1 = two pieces (round 1-3), 0 = exact fp32 MFMA
+gae::Knob g_bce_s_bf16{3};        // S = Zt Zt^T (and P V of the symmetric kernel): 3 = two fp16 pieces per operand where the symmetric kernel runs
+                                  // (22 mantissa bits, range-guarded; default), three bf16 pieces elsewhere; 2 = three bf16 pieces
+                                  // (24 bits); 1 = two bf16 pieces (16 bits: rounds 1-3); 0 = exact fp32 MFMA
 gae::Knob g_bce_grid{2048};       // "bce_grid": target size of the (row block, column split) grid of the full-square kernel
 constexpr int kChipCus = 256;             // MI355X: the launch-shape heuristics below are written for this part
 gae::Knob g_bce_strip_store{-1};  // "bce_strip_store": -1 auto (non-temporal from 32 k rows on: GBs of strips, 2.93 -> 2.88 ms on a ZINC
@@ -253,6 +255,65 @@ __device__ __forceinline__ s16x4 third_piece(const f32x4 &v, const s16x4 &hi, co
         l2[q] = __builtin_bit_cast(unsigned, __builtin_convertvector((a - fh) - fl, bf16x2));
     }
     struct U { unsigned a, b; } u{l2[0], l2[1]};
+    return __builtin_bit_cast(s16x4, u);
+}
+
+// ---- fp16 pieces (round 4).  v = hi + lo with hi = fp16(v), lo = fp16(v - hi): 22 mantissa bits in TWO pieces (bf16
+// needs three for 24), so all four partial products of S cost two K = 32 MFMAs instead of three, and the split is one
+// v_cvt_pkrtz per pair and piece plus a mixed-precision subtract.  The price is fp16's range: the pieces are exact to
+// 2^-22 |v| only while 2^-14 <= |v| <= 65504 (below: absolute error <= 2^-25, harmless; above: overflow).  The kernels
+// that use them therefore report embeddings beyond kF16Max, and the three-piece bf16 form then recomputes the call's
+// outputs (the range guard of bce_dense_sym_kernel).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+constexpr float kF16Max = 32768.f;      // largest |Zt| the fp16 pieces are used for (Zt log2(e) must fit as well)
+__device__ __forceinline__ f32x4 mfma32h(const s16x8 &a, const s16x8 &b, const f32x4 &c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_k32(const s16x8 &a, const s16x8 &b, const f32x4 &c)
+{
+    if constexpr (F16) return mfma32h(a, b, c);
+    else return mfma32(a, b, c);
+}
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// v - float(half of hh): one mixed-precision FMA (the fp16 half is read in place, no v_cvt_f32_f16)
+__device__ __forceinline__ float minus_f16_lo(float v, unsigned hh)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
+    return r;
+}
+__device__ __forceinline__ float minus_f16_hi(float v, unsigned hh)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
+    return r;
+}
+// hi = fp16(v) and lo = fp16(v - hi), both round-to-nearest-even (v_cvt_pk_f16_f32); v - hi is exact in fp32:
+// |v - hi - lo| <= 2^-22 |v| for 2^-14 <= |v| <= 65504.  4 VALU instructions per pair of values.
+__device__ __forceinline__ void split_f16x4(const f32x4 &v, s16x4 &hi, s16x4 &lo)
+{
+    unsigned h[2], l[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2 a = {v[2 * q], v[2 * q + 1]};
+        const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(a, f16x2));
+        const f32x2 r = {minus_f16_lo(a[0], hu), minus_f16_hi(a[1], hu)};
+        h[q] = hu;
+        l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+    }
+    struct U { unsigned a, b; } uh{h[0], h[1]}, ul{l[0], l[1]};
+    hi = __builtin_bit_cast(s16x4, uh);
+    lo = __builtin_bit_cast(s16x4, ul);
+}
+// fp32 values that ARE fp16 values (outputs of an MFMA against the identity) back to their 16-bit form
+__device__ __forceinline__ s16x4 exact_f16(const f32x4 &d)
+{
+    struct U { unsigned a, b; } u{__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d[0], d[1])),
+                                  __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d[2], d[3]))};
     return __builtin_bit_cast(s16x4, u);
 }
 
@@ -611,14 +672,27 @@ __host__ __device__ inline int64_t sym_strip_offset(int64_t I, int64_t NP, int64
 // TRV (default): the V fragments of O' += P V come from LDS transpose reads of the [j][k] tiles -- no second,
 // transposed copy of every tile (16 ds_write_b16 per thread and tile, 8.7 KB of LDS): Pubmed 170 -> 166 us, a ZINC
 // batch 2.92 -> 2.88 ms.  TRV = false keeps the round-2 form (knob "bce_sym_tr" = 0).
-template <bool WITH_GRAD, int RI, bool TRV, bool S3 = false>
+template <bool WITH_GRAD, int RI, bool TRV, bool S3 = false, bool F16 = false>
 __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     const float *__restrict__ Zt /*[n][16]*/, const unsigned short *__restrict__ Zhi,
     const unsigned short *__restrict__ Zlo, int64_t n, int64_t cols_per_chunk,
     float *__restrict__ O_partial /*[chunks][n][16]*/, float *__restrict__ Wmir,
     double *__restrict__ loss_partial /*[chunks * panels][2]*/, const double *__restrict__ colsum_partial,
-    int64_t n_prep_blocks, double *__restrict__ S, float *__restrict__ S_all_f, unsigned n_panels, int exp_strip)
+    int64_t n_prep_blocks, double *__restrict__ S, float *__restrict__ S_all_f, unsigned n_panels, int exp_strip,
+    unsigned *__restrict__ range_flag, int flag_mode, unsigned ticket)
 {
+    // Range guard of the fp16 pieces.  flag_mode 1 (the F16 launch): a thread that meets |Zt| > kF16Max (or a NaN)
+    // writes this call's ticket to *range_flag; the launch's results are then meaningless.  flag_mode 2 (the
+    // three-piece bf16 launch that follows it): does nothing unless *range_flag holds the ticket, else recomputes every
+    // output of the first launch.  The flag lives in the caller's workspace, which nobody initialises: the ticket (a
+    // process-wide counter, scrambled) tells this call's report from whatever the memory held, and the edge kernel
+    // (always after both launches) clears it, so a replayed HIP graph -- whose ticket is frozen -- starts clean as
+    // well.  A stale match costs one redundant bf16 pass, never a wrong result.  Embeddings beyond 32768 do not
+    // occur in a trained GAE: in practice the second launch costs its empty blocks.
+    if (flag_mode == 2 && *range_flag != ticket) return;
+    static_assert(!(S3 && F16), "three bf16 pieces OR two fp16 pieces");
+    bool out_of_range = false;
+    constexpr bool STAGE32 = S3 || F16;  // the column tiles are staged as fp32 and split at LDS-store time
     constexpr int DP = 16, SYM_PR = 64 * RI;
     constexpr int LDH = DP + 4;          // bf16 LDS row stride (elements): 8-byte aligned rows
     constexpr int V4 = TJ * DP / 4 / 256;  // = 1
@@ -667,7 +741,10 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
         b *= LOG2E;
         s16x4 bhi, blo, blo2;
         if (S3) { split_bf16x4_3(b, bhi, blo, blo2); b3[ri] = cat(bhi, blo2); }
-        else split_bf16x4(b, bhi, blo);
+        else if (F16) {
+            out_of_range |= !(fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3]))) <= kF16Max * LOG2E);
+            split_f16x4(b, bhi, blo);
+        } else split_bf16x4(b, bhi, blo);
         bhh[ri] = cat(bhi, bhi);
         bll[ri] = cat(blo, blo);
         s16x4 th, tl;
@@ -675,15 +752,25 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
         for (int r = 0; r < 4; ++r) {
             const int64_t ir = row_base + ri * 16 + 4 * g + r;
             const bool v = ir < n;
+            if (F16) continue;
             th[r] = v ? short(Zhi[(v ? ir : 0) * DP + l15]) : short(0);
             tl[r] = v ? short(Zlo[(v ? ir : 0) * DP + l15]) : short(0);
+        }
+        if (F16) {                   // fp16 pieces of the rows, from the fp32 values
+            f32x4 zr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t ir = row_base + ri * 16 + 4 * g + r;
+                zr[r] = ir < n ? Zt[ir * DP + l15] : 0.f;
+            }
+            split_f16x4(zr, th, tl);
         }
         put_half(zTh[ri / 2], ri & 1, th);
         put_half(zTl[ri / 2], ri & 1, tl);
     }
     s16x4 ident;                 // B fragment of the 16 x 16 identity: lane (n = l15, g) -> [k = 4 g + r == n]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ident[r] = (4 * g + r == l15) ? short(0x3F80) : short(0);
+    for (int r = 0; r < 4; ++r) ident[r] = (4 * g + r == l15) ? short(F16 ? 0x3C00 : 0x3F80) : short(0);
     f32x4 oacc[RI];
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri) oacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -703,7 +790,7 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
 
     // S3: only the fp32 values are staged (4 registers instead of 4 + 4 + 4); hi / lo / lo2 are split off at store time
     // with the prepare step's own roundings (v_cvt_pk_bf16_f32 = round to nearest even: the same hi / lo bits)
-    struct Stage { s16x4 h[S3 ? 1 : V4], l[S3 ? 1 : V4]; f32x4 f[S3 ? V4 : 1]; };
+    struct Stage { s16x4 h[STAGE32 ? 1 : V4], l[STAGE32 ? 1 : V4]; f32x4 f[STAGE32 ? V4 : 1]; };
     auto load_tile = [&](int64_t j0, Stage &st) {
 #pragma unroll
         for (int q = 0; q < V4; ++q) {
@@ -711,7 +798,7 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
             const int jj = idx / (DP / 4), kk = (idx % (DP / 4)) * 4;
             const bool jv = j0 + jj < col_end;
             const int64_t j = jv ? j0 + jj : col_begin;
-            if (S3) {
+            if (STAGE32) {
                 st.f[q] = *reinterpret_cast<const f32x4 *>(Zt + j * DP + kk);
                 if (!jv) st.f[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             } else {
@@ -731,6 +818,10 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
                 s16x4 l24;
                 split_bf16x4_3(st.f[q], h4, l4, l24);
                 *reinterpret_cast<s16x4 *>(&L2s[buf][jj * LDH + kk]) = l24;
+            } else if (F16) {
+                const f32x4 f = st.f[q];
+                out_of_range |= !(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))) <= kF16Max);
+                split_f16x4(f, h4, l4);
             } else {
                 h4 = st.h[q]; l4 = st.l[q];
             }
@@ -789,8 +880,8 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
                     if (S3)       // the smallest terms first: al2.bhi + ah.blo2
                         sacc[ri] = mfma32(cat(*reinterpret_cast<const s16x4 *>(&L2s[buf][(jt * 16 + l15) * LDH + 4 * g]), ah),
                                           b3[ri], sacc[ri]);
-                    sacc[ri] = mfma32(ahl, bll[ri], sacc[ri]);
-                    sacc[ri] = mfma32(ahl, bhh[ri], sacc[ri]);
+                    sacc[ri] = mfma_k32<F16>(ahl, bll[ri], sacc[ri]);
+                    sacc[ri] = mfma_k32<F16>(ahl, bhh[ri], sacc[ri]);
                 }
                 // sacc[ri][r] = y(i = l15 of subtile ri, j = jt*16 + 4 g + r), y = x log2(e)
 #pragma unroll
@@ -808,7 +899,8 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
                     }
                     if (WITH_GRAD) {
                         s16x4 h4, l4;
-                        split_bf16x4(p, h4, l4);
+                        if (F16) split_f16x4(p, h4, l4);
+                        else split_bf16x4(p, h4, l4);
                         put_half(ph[ri], h, h4);
                         put_half(pl[ri], h, l4);
                     }
@@ -829,9 +921,9 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
                 }
 #pragma unroll
                 for (int ri = 0; ri < RI; ++ri) {
-                    oacc[ri] = mfma32(pl[ri], vh, oacc[ri]);
-                    oacc[ri] = mfma32(ph[ri], vl, oacc[ri]);
-                    oacc[ri] = mfma32(ph[ri], vh, oacc[ri]);
+                    oacc[ri] = mfma_k32<F16>(pl[ri], vh, oacc[ri]);
+                    oacc[ri] = mfma_k32<F16>(ph[ri], vl, oacc[ri]);
+                    oacc[ri] = mfma_k32<F16>(ph[ri], vh, oacc[ri]);
                 }
                 if (offdiag) {
                     // mirror: (P^T Z_I)[j][f] += sum_i P[i][j] Z[i][f] needs P with lane = column j, registers = rows
@@ -850,14 +942,22 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
                             for (int e = 0; e < 2; ++e) {
                                 const int ri = 2 * rp + e;
                                 const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                                const f32x4 dh = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(get_half(ph[ri], h), ident, z4, 0, 0, 0);
-                                const f32x4 dl = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(get_half(pl[ri], h), ident, z4, 0, 0, 0);
-                                put_half(qh, e, upper_halves(dh));
-                                put_half(ql, e, upper_halves(dl));
+                                f32x4 dh, dl;
+                                if constexpr (F16) {
+                                    dh = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, get_half(ph[ri], h)), __builtin_bit_cast(f16x4, ident), z4, 0, 0, 0);
+                                    dl = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, get_half(pl[ri], h)), __builtin_bit_cast(f16x4, ident), z4, 0, 0, 0);
+                                    put_half(qh, e, exact_f16(dh));
+                                    put_half(ql, e, exact_f16(dl));
+                                } else {
+                                    dh = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(get_half(ph[ri], h), ident, z4, 0, 0, 0);
+                                    dl = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(get_half(pl[ri], h), ident, z4, 0, 0, 0);
+                                    put_half(qh, e, upper_halves(dh));
+                                    put_half(ql, e, upper_halves(dl));
+                                }
                             }
-                            macc = mfma32(ql, zTh[rp], macc);
-                            macc = mfma32(qh, zTl[rp], macc);
-                            macc = mfma32(qh, zTh[rp], macc);
+                            macc = mfma_k32<F16>(ql, zTh[rp], macc);
+                            macc = mfma_k32<F16>(qh, zTl[rp], macc);
+                            macc = mfma_k32<F16>(qh, zTh[rp], macc);
                         }
                         // macc[r] = mirror(j = jt*16 + 4 g + r, f = l15)  ->  MR[wave][f][j]
                         *reinterpret_cast<f32x4 *>(&MR[wave][l15 * LDM + (2 * jp + h) * 16 + 4 * g]) = macc;
@@ -915,6 +1015,7 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
         loss_partial[2 * lp_index + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
         loss_partial[2 * lp_index + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
+    if (F16 && flag_mode == 1 && out_of_range) atomicExch(range_flag, ticket);
 }
 
 // O'_mirror[j][f] = sum over the panels left of j's panel, in panel order, of their strip entries.
@@ -959,9 +1060,11 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
     const float *__restrict__ S_all_f, float *__restrict__ dZ, int64_t lddz, double *__restrict__ loss_partial,
     const float *__restrict__ O_mirror /*[n][16] or NULL*/, int64_t sym_cols_per_chunk, int SYM_PR,
     const int64_t *__restrict__ counts, const double *__restrict__ scal,
-    const float *__restrict__ Wmir /*mirror strips: fold them here instead of reading O_mirror (LPR == 4), or NULL*/)
+    const float *__restrict__ Wmir /*mirror strips: fold them here instead of reading O_mirror (LPR == 4), or NULL*/,
+    unsigned *__restrict__ range_flag /*the dense launches' range guard, cleared here for the next call (or NULL)*/)
 {
     static_assert(VEC == 4, "edge kernel reads the padded Zt rows as float4");
+    if (range_flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *range_flag = 0u;
     // ---- symmetric dense kernel, d <= 16: this block's 64 rows are exactly one 64-column tile of the mirror strips.
     //      The strip reduction of bce_mirror_reduce_kernel (same thread mapping, same panel order, same 8-deep
     //      batches: bit-identical sums) runs here and hands its result over through LDS: one kernel node and the
@@ -1291,12 +1394,12 @@ template <int VEC, bool WITH_GRAD>
 int launch_edges(const BcePlan &p, const float *Zt, const float *mask, int64_t ldz, int64_t row_begin, int64_t n, int d,
                  const int32_t *ip, const int32_t *ix, const int32_t *tp, const int32_t *tx, float pw, float inv_n2,
                  const float *O, const float *S_all_f, float *dZ, int64_t lddz, double *lp, const float *Omir,
-                 const int64_t *counts, const double *scal, const float *Wmir, hipStream_t s)
+                 const int64_t *counts, const double *scal, const float *Wmir, unsigned *range_flag, hipStream_t s)
 {
 #define GAE_EDGE(LPR)                                                                                              \
     hipLaunchKernelGGL((bce_edges_kernel<VEC, LPR, WITH_GRAD>), dim3(unsigned(p.edge_blocks)), dim3(256), 0, s, Zt, \
                        mask, ldz, row_begin, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, S_all_f,  \
-                       dZ, lddz, lp, Omir, p.cols_per_split, p.sym_pr, counts, scal, Wmir)
+                       dZ, lddz, lp, Omir, p.cols_per_split, p.sym_pr, counts, scal, Wmir, range_flag)
     switch (p.LPR) {
     case 1: GAE_EDGE(1); break;
     case 2: GAE_EDGE(2); break;
@@ -1389,6 +1492,7 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
     double *S = reinterpret_cast<double *>(w);
     float *S_all_f = reinterpret_cast<float *>(w + 2 * p.DP * 8);
     double *scal = counts ? reinterpret_cast<double *>(w + 2 * p.DP * 8 + ((p.DP * 4 + 7) & ~7)) : nullptr;
+    unsigned *range_flag = reinterpret_cast<unsigned *>(w + 2 * p.DP * 8 + ((p.DP * 4 + 7) & ~7) + 3 * 8);   // the 4th scalar slot
     w += p.s_bytes;
     double *lp = reinterpret_cast<double *>(w); w += align256((2 * p.n_dense + p.edge_blocks) * 8);
     float *Wmir = reinterpret_cast<float *>(w); w += p.wmir_bytes;
@@ -1408,11 +1512,16 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
     int rc;
     if (p.sym) {
         const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
-#define GAE_SYM3(WG, R, T, S3V)                                                                                     \
-    hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R, T, S3V>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
+        static std::atomic<unsigned> call_counter{0};
+        const unsigned ticket = (call_counter.fetch_add(1) * 2654435761u) | 0x80000001u;    // never 0 (= cleared)
+        // fp16 pieces (knob bce_s_bf16 = 3, the default): the F16 launch reports out-of-range embeddings through
+        // range_flag, the three-piece bf16 launch behind it runs only then (see the kernel)
+#define GAE_SYM3(WG, R, T, S3V, F16V, FM)                                                                            \
+    hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R, T, S3V, F16V>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
                        lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks),                                    \
-                       g_bce_strip_store >= 0 ? g_bce_strip_store : (n >= 32768 ? 1 : 0))
-#define GAE_SYM(WG, R, T) do { if (g_bce_s_bf16 >= 2) GAE_SYM3(WG, R, T, true); else GAE_SYM3(WG, R, T, false); } while (0)
+                       g_bce_strip_store >= 0 ? g_bce_strip_store : (n >= 32768 ? 1 : 0), range_flag, FM, ticket)
+#define GAE_SYM(WG, R, T) do { if (g_bce_s_bf16 >= 3) { GAE_SYM3(WG, R, T, false, true, 1); GAE_SYM3(WG, R, T, true, false, 2); } \
+    else if (g_bce_s_bf16 == 2) GAE_SYM3(WG, R, T, true, false, 0); else GAE_SYM3(WG, R, T, false, false, 0); } while (0)
         if (!dZ) { if (p.sym_pr == 256) GAE_SYM(false, 4, false); else GAE_SYM(false, 2, false); }
         else if (g_bce_sym_tr) { if (p.sym_pr == 256) GAE_SYM(true, 4, true); else GAE_SYM(true, 2, true); }
         else { if (p.sym_pr == 256) GAE_SYM(true, 4, false); else GAE_SYM(true, 2, false); }
@@ -1433,10 +1542,11 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
     double *lpe = lp + 2 * p.n_dense;
     rc = dZ ? launch_edges<4, true>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr, t_indices,
                                     pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, p.sym ? Omir : nullptr,
-                                    counts, scal, (p.sym && g_bce_fold_mirror && p.LPR == 4) ? Wmir : nullptr, s)
+                                    counts, scal, (p.sym && g_bce_fold_mirror && p.LPR == 4) ? Wmir : nullptr,
+                                    p.sym ? range_flag : nullptr, s)
             : launch_edges<4, false>(p, Zt, mask, ldz, row_begin, n_local, int(d), indptr, indices, t_indptr,
                                      t_indices, pos_weight, float(inv_n2), O, S_all_f, dZ, lddz, lpe, nullptr, counts,
-                                     scal, nullptr, s);
+                                     scal, nullptr, p.sym ? range_flag : nullptr, s);
     if (rc) return rc;
     gae_bce_tail tail;
     memset(&tail, 0, sizeof(tail));

@@ -95,3 +95,51 @@ def test_adam_checkpoint_loaded_after_capture_matches_eager():
         ref = m0.state_dict()[k]
         assert float((v - ref).abs().max() / ref.abs().max().clamp(min=1e-6)) < 1e-4, k
     assert o1.steps_taken() == 7
+
+
+def _loss_and_grad(Z, g):
+    from gae_dgl_amd import ops
+    Zd = torch.tensor(Z, device=DEV).requires_grad_(True)
+    loss = ops.decoder_bce(Zd, None, g)
+    loss.backward()
+    torch.cuda.synchronize()
+    return float(loss.detach()), Zd.grad.detach().cpu()
+
+
+def test_loss_fp16_pieces_match_fp64_and_fall_back_beyond_their_range():
+    """round 4: where the symmetric dense kernel runs, the products of the fused loss use two fp16 pieces per operand
+    (22 mantissa bits).  (a) against the fp64 oracle on embeddings whose large components cancel; (b) embeddings
+    outside fp16's range make the SAME call fall back to the three-piece bf16 kernel -- bit-identical to that kernel
+    selected by knob; (c) the guard re-arms: the next in-range call is bit-identical to the first."""
+    from gae_dgl_amd import _lib
+    from oracle import gae_oracle as O
+    rng = np.random.default_rng(11)
+    n, d = 1500, 16
+    g, src, dst = sym_graph(rng, n, 4000)
+    Z = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+    sign = rng.choice([-1.0, 1.0], size=n).astype(np.float32)
+    Z[:, 0] = 30.0 * sign + Z[:, 0]; Z[:, 1] = 30.0 + Z[:, 1]
+    adj = O.dense_adjacency(src, dst, n, dtype=torch.float64)
+    Zt = torch.tensor(Z, dtype=torch.float64, requires_grad=True)
+    ref = O.bce_with_logits_mean(O.decoder_logits(Zt, None), adj, O.pos_weight_of(adj))
+    ref.backward()
+    gscale = float(Zt.grad.abs().max())
+    Zbig = Z.copy()
+    Zbig[7, 3] = 1.0e5; Zbig[n - 1, 15] = -3.0e5; Zbig[700, 0] = 7.0e4      # > 65504: no fp16 value
+    _lib.call("gae_tuning_set", b"bce_sym", 2)            # the symmetric kernel from 512 rows on (default: 8192)
+    try:
+        l1, g1 = _loss_and_grad(Z, g)
+        assert abs(l1 - float(ref)) <= 1e-6 * abs(float(ref))
+        err = float((g1.double() - Zt.grad).abs().max()) / gscale
+        assert err <= 1e-5, err                            # measured 2e-6 (two bf16 pieces: 7e-5)
+        lb, gb = _loss_and_grad(Zbig, g)                   # out of range -> the bf16 launch recomputes everything
+        l2, g2 = _loss_and_grad(Z, g)                      # flag cleared by the edge kernel
+        assert l2 == l1 and torch.equal(g1, g2)
+        _lib.call("gae_tuning_set", b"bce_s_bf16", 2)
+        lb3, gb3 = _loss_and_grad(Zbig, g)
+        assert np.isfinite(lb) and lb == lb3 and torch.equal(gb, gb3)
+        l3, g3 = _loss_and_grad(Z, g)
+        assert not torch.equal(g1, g3)                     # (the in-range calls above did run on the fp16 pieces)
+    finally:
+        _lib.call("gae_tuning_set", b"bce_s_bf16", 3)
+        _lib.call("gae_tuning_set", b"bce_sym", 1)

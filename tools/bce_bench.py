@@ -31,7 +31,7 @@ for rnd in range(a.rounds + 1):
     for v in a.variants.split(";"):
         kv = dict(x.split("=") for x in v.split(","))
         _lib.call("gae_tuning_set", b"bce_ri", int(kv.get("ri", 2)))
-        _lib.call("gae_tuning_set", b"bce_s_bf16", int(kv.get("sb", 2)))
+        _lib.call("gae_tuning_set", b"bce_s_bf16", int(kv.get("sb", 3)))
         _lib.call("gae_tuning_set", b"bce_pv_bf16", int(kv.get("pb", 1)))
         _lib.call("gae_tuning_set", b"bce_sym", int(kv.get("sym", 1)))
         _lib.call("gae_tuning_set", b"bce_sym_grid", int(kv.get("grid", 16384)))
