@@ -672,14 +672,14 @@ __host__ __device__ inline int64_t sym_strip_offset(int64_t I, int64_t NP, int64
 // TRV (default): the V fragments of O' += P V come from LDS transpose reads of the [j][k] tiles -- no second,
 // transposed copy of every tile (16 ds_write_b16 per thread and tile, 8.7 KB of LDS): Pubmed 170 -> 166 us, a ZINC
 // batch 2.92 -> 2.88 ms.  TRV = false keeps the round-2 form (knob "bce_sym_tr" = 0).
-template <bool WITH_GRAD, int RI, bool TRV, bool S3 = false, bool F16 = false>
+template <bool WITH_GRAD, int RI, bool TRV, bool S3 = false, bool F16 = false, bool PERSIST = false>
 __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     const float *__restrict__ Zt /*[n][16]*/, const unsigned short *__restrict__ Zhi,
     const unsigned short *__restrict__ Zlo, int64_t n, int64_t cols_per_chunk,
     float *__restrict__ O_partial /*[chunks][n][16]*/, float *__restrict__ Wmir,
     double *__restrict__ loss_partial /*[chunks * panels][2]*/, const double *__restrict__ colsum_partial,
     int64_t n_prep_blocks, double *__restrict__ S, float *__restrict__ S_all_f, unsigned n_panels, int exp_strip,
-    unsigned *__restrict__ range_flag, int flag_mode, unsigned ticket)
+    unsigned *__restrict__ range_flag, int flag_mode, unsigned ticket, unsigned n_chunks)
 {
     // Range guard of the fp16 pieces.  flag_mode 1 (the F16 launch): a thread that meets |Zt| > kF16Max (or a NaN)
     // writes this call's ticket to *range_flag; the launch's results are then meaningless.  flag_mode 2 (the
@@ -688,7 +688,8 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     // process-wide counter, scrambled) tells this call's report from whatever the memory held, and the edge kernel
     // (always after both launches) clears it, so a replayed HIP graph -- whose ticket is frozen -- starts clean as
     // well.  A stale match costs one redundant bf16 pass, never a wrong result.  Embeddings beyond 32768 do not
-    // occur in a trained GAE: in practice the second launch costs its empty blocks.
+    // occur in a trained GAE: in practice the second launch costs the start of its few blocks (PERSIST: a 1-D grid of
+    // a few hundred blocks that would walk the (panel, chunk) units of the first launch's 2-D grid).
     if (flag_mode == 2 && *range_flag != ticket) return;
     static_assert(!(S3 && F16), "three bf16 pieces OR two fp16 pieces");
     bool out_of_range = false;
@@ -706,19 +707,20 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     __shared__ __attribute__((aligned(16))) float MR[4][16 * LDM];                // mirror tiles [wave][f][j]
     __shared__ double red[4][2];
 
-    if (blockIdx.x >= n_panels) {   // the extra block column: column sums of Zt for the kernels that follow
-        if (blockIdx.y == 0)
+  auto unit = [&](const unsigned bx, const unsigned by) {     // one (panel bx, column chunk by) unit of work
+    if (bx >= n_panels) {   // the extra block column: column sums of Zt for the kernels that follow
+        if (by == 0)
             bce_colsum_block(colsum_partial, n_prep_blocks, DP, S, S_all_f, reinterpret_cast<double *>(&MR[0][0]));
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int64_t I = blockIdx.x;
+    const int64_t I = bx;
     const int64_t NP = (n + 63) / 64 * 64;
-    const int64_t col_begin = SYM_PR * I + int64_t(blockIdx.y) * cols_per_chunk;
+    const int64_t col_begin = SYM_PR * I + int64_t(by) * cols_per_chunk;
     int64_t col_end = col_begin + cols_per_chunk;
     if (col_end > n) col_end = n;
-    const int64_t lp_index = int64_t(blockIdx.y) * n_panels + blockIdx.x;
+    const int64_t lp_index = int64_t(by) * n_panels + bx;
     if (col_begin >= n) {            // chunk beyond this panel's columns
         if (tid == 0) { loss_partial[2 * lp_index] = 0.0; loss_partial[2 * lp_index + 1] = 0.0; }
         return;
@@ -997,7 +999,7 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
     }
     // ---- O' partial: oacc[ri][r] = O'(i = 4 g + r, f = l15) of subtile ri
     if (WITH_GRAD) {
-        float *op = O_partial + int64_t(blockIdx.y) * n * DP;
+        float *op = O_partial + int64_t(by) * n * DP;
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri)
 #pragma unroll
@@ -1016,6 +1018,16 @@ __global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
         loss_partial[2 * lp_index + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
     if (F16 && flag_mode == 1 && out_of_range) atomicExch(range_flag, ticket);
+  };
+    if constexpr (PERSIST) {
+        const unsigned nx = n_panels + 1, total = nx * n_chunks;
+        for (unsigned u = blockIdx.x; u < total; u += gridDim.x) {
+            unit(u % nx, u / nx);
+            __syncthreads();                       // the next unit reuses the LDS tiles
+        }
+    } else {
+        unit(blockIdx.x, blockIdx.y);
+    }
 }
 
 // O'_mirror[j][f] = sum over the panels left of j's panel, in panel order, of their strip entries.
@@ -1516,12 +1528,13 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
         const unsigned ticket = (call_counter.fetch_add(1) * 2654435761u) | 0x80000001u;    // never 0 (= cleared)
         // fp16 pieces (knob bce_s_bf16 = 3, the default): the F16 launch reports out-of-range embeddings through
         // range_flag, the three-piece bf16 launch behind it runs only then (see the kernel)
-#define GAE_SYM3(WG, R, T, S3V, F16V, FM)                                                                            \
-    hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R, T, S3V, F16V>), grid, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
+#define GAE_SYM3(WG, R, T, S3V, F16V, FM, PERS, GRID)                                                                \
+    hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R, T, S3V, F16V, PERS>), GRID, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
                        lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks),                                    \
-                       g_bce_strip_store >= 0 ? g_bce_strip_store : (n >= 32768 ? 1 : 0), range_flag, FM, ticket)
-#define GAE_SYM(WG, R, T) do { if (g_bce_s_bf16 >= 3) { GAE_SYM3(WG, R, T, false, true, 1); GAE_SYM3(WG, R, T, true, false, 2); } \
-    else if (g_bce_s_bf16 == 2) GAE_SYM3(WG, R, T, true, false, 0); else GAE_SYM3(WG, R, T, false, false, 0); } while (0)
+                       g_bce_strip_store >= 0 ? g_bce_strip_store : (n >= 32768 ? 1 : 0), range_flag, FM, ticket,  \
+                       unsigned(p.n_splits))
+#define GAE_SYM(WG, R, T) do { if (g_bce_s_bf16 >= 3) { GAE_SYM3(WG, R, T, false, true, 1, false, grid); GAE_SYM3(WG, R, T, true, false, 2, true, dim3(2 * kChipCus)); } \
+    else if (g_bce_s_bf16 == 2) GAE_SYM3(WG, R, T, true, false, 0, false, grid); else GAE_SYM3(WG, R, T, false, false, 0, false, grid); } while (0)
         if (!dZ) { if (p.sym_pr == 256) GAE_SYM(false, 4, false); else GAE_SYM(false, 2, false); }
         else if (g_bce_sym_tr) { if (p.sym_pr == 256) GAE_SYM(true, 4, true); else GAE_SYM(true, 2, true); }
         else { if (p.sym_pr == 256) GAE_SYM(true, 4, false); else GAE_SYM(true, 2, false); }
