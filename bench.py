@@ -50,7 +50,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # On gfx950 a SIMD's MFMA time and VALU time ADD (mfma + 4 v_fma: 11.2 ns against 7.4 + 5.7), so the bound of these
 # kernels is the sum of their instructions' issue costs.  Costs in units of one v_fma_f32 (1.42 ns per wave64
 # instruction and SIMD at 4 waves / SIMD): transcendental 2.5, v_pk_*_f32 1.8, v_cvt_pk_bf16_f32 / v_bfi_b32 1.7,
-# v_perm_b32 1.4, v_lshlrev_b32 1.6, v_mfma_f32_16x16x{16,32}_bf16 5.2.
+# v_perm_b32 1.4, v_lshlrev_b32 1.6, v_mfma_f32_16x16x{16,32}_{bf16,f16} 5.2.
 SPEC_LANE_OPS = 157.3e12 / 2     # MI355X data sheet: 157.3 TFLOP/s fp32 vector = 78.6 T fused lane-operations per second
 SLOT_NS = 1.42
 ISSUE_PEAK_LANE_SLOTS = 256 * 4 * 64 / (SLOT_NS * 1e-9)      # lane-slots per second of the whole chip
@@ -58,8 +58,11 @@ SLOT_COST = {"plain": 1.0, "trans": 2.5, "pk": 1.8, "cvt_pk": 1.7, "bfi": 1.7, "
 # instructions per wave and 64-column tile of a 32-row wave slice (= 32 logits per lane), counted in the ISA of the
 # kernels' main loops (decoder_bce.hip, K = 32 MFMAs); third entry: share of the N^2 logits that is evaluated
 LOSS_ISA = {
-    "symmetric": ({"trans": 64, "pk": 36, "cvt_pk": 32, "bfi": 32, "perm": 32, "lshl": 16, "plain": 120, "mfma": 56}, 0.5),
-    "full": ({"trans": 64, "pk": 36, "cvt_pk": 32, "bfi": 32, "perm": 0, "lshl": 16, "plain": 110, "mfma": 28}, 1.0),
+    # round 4: the symmetric kernel splits into fp16 pieces (v_cvt_pk_f16_f32 / v_cvt_pkrtz_f16_f32 counted as cvt_pk,
+    # v_fma_mix_f32 as plain; tools/isa_hist.sh on its tile loop: 551 instructions), the full-square kernel forms S
+    # from three bf16 pieces (24 + 12 MFMAs)
+    "symmetric": ({"trans": 66, "pk": 21, "cvt_pk": 68, "bfi": 32, "perm": 0, "lshl": 0, "plain": 167, "mfma": 56}, 0.5),
+    "full": ({"trans": 64, "pk": 36, "cvt_pk": 32, "bfi": 32, "perm": 0, "lshl": 16, "plain": 110, "mfma": 36}, 1.0),
 }
 
 
