@@ -591,14 +591,16 @@ class RmatShardedWorkload:
         self.args, self.dev, self.rank, self.world, self.group = args, dev, rank, world, group
         scale = args.rmat_scale
         n = 1 << scale
-        src, dst = W.rmat_edges(scale, 16, seed=0, device=dev)               # same list on every rank (seeded)
-        E = int(src.numel())
+        # every rank generates ITS slice of the edge list (1 / world of the chunks); the row blocks are assembled from
+        # the slices (degree histogram all-reduce + one all-to-all-v of edges per direction): no rank holds the list
+        src, dst = W.rmat_edges(scale, 16, seed=0, device=dev, part=(rank, world))
+        E = 16 << scale
         self.overlap = not args.no_overlap
         # auto = the one-pass encoder (parallel.ShardedEncoder2Function): last layer as A (H W^T) + b, dense halves in two
         # one-pass kernels; "aggregate-first" keeps (A H) W^T for every layer (gae.py:26-31 literally)
         self.transform_first = args.layer_order in ("transform-first", "auto")
-        self.sg = ShardedGraph(n, src, dst, rank=rank, world=world, group=group, mode=args.exchange, device=dev,
-                               balance=args.balance, overlap=self.overlap)
+        self.sg = ShardedGraph.from_edge_slice(n, src, dst, group=group, mode=args.exchange, device=dev,
+                                               balance=args.balance, overlap=self.overlap)
         del src, dst
         self.sg.cache_constant_inputs = not args.no_cache_input_exchange
         p = self.sg.part

@@ -2043,8 +2043,7 @@ class ShardedDecoderBCEFunction(torch.autograd.Function):
 
 def sharded_decoder_bce(z_local, mask_local, sg, n_edges_global=None):
     if n_edges_global is None:
-        t = sg.allreduce_sum(torch.tensor([sg.n_edges("fwd")], dtype=torch.int64, device=z_local.device))
-        n_edges_global = int(t)
+        n_edges_global = sg.n_edges_global()          # (cached: no host read-back per step)
     return ShardedDecoderBCEFunction.apply(z_local, mask_local, sg, n_edges_global)
 
 

@@ -59,11 +59,7 @@ def nnz_balanced_bounds(n, src, dst, world, row_cost=None):
     44 %); a row costs something too (its share of the dense layers, of the product's output and of the exchange)."""
     src = torch.as_tensor(src).to(torch.int64).reshape(-1); dst = torch.as_tensor(dst).to(torch.int64).reshape(-1)
     w = torch.bincount(dst, minlength=n) + torch.bincount(src, minlength=n) + int(ROW_COST if row_cost is None else row_cost)
-    c = torch.cumsum(w, 0)
-    targets = (torch.arange(1, world, device=c.device, dtype=torch.float64) * (float(c[-1]) / world)).to(c.dtype)
-    cuts = torch.searchsorted(c, targets).clamp(max=n).cpu().numpy().astype(np.int64)
-    b = np.concatenate([[0], cuts, [n]]).astype(np.int64)
-    return np.maximum.accumulate(b)
+    return _weights_to_bounds(w, world)
 
 
 class LocalGroup:
@@ -81,28 +77,52 @@ class LocalGroup:
         self.full = full
 
 
+def _weights_to_bounds(w, world):
+    """contiguous blocks of (almost) equal total weight: int64[world + 1]"""
+    n = int(w.numel())
+    c = torch.cumsum(w, 0)
+    targets = (torch.arange(1, world, device=c.device, dtype=torch.float64) * (float(c[-1]) / world)).to(c.dtype)
+    cuts = torch.searchsorted(c, targets).clamp(max=n).cpu().numpy().astype(np.int64)
+    b = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    return np.maximum.accumulate(b)
+
+
 class RowPartition:
     """Host-side plan of one rank's share of a graph (pure index bookkeeping,
-    torch ops on whatever device the edge list lives on)."""
+    torch ops on whatever device the edge list lives on).
 
-    def __init__(self, n, src, dst, rank, world, mode="allgather", balance="rows", overlap=False):
+    ``RowPartition(n, src, dst, rank, world, ...)`` filters the rank's edges out of the WHOLE edge list (virtual ranks,
+    small graphs); ``RowPartition.from_edge_slice`` builds the same plan when every rank holds only a slice of the
+    list (any split of the edges over the ranks): the degree histogram is all-reduced for the block bounds and every
+    edge travels once per direction to the owner of its row."""
+
+    def __init__(self, n, src, dst, rank, world, mode="allgather", balance="rows", overlap=False, _edges=None,
+                 _bounds=None):
         assert mode in ("allgather", "boundary") and balance in ("rows", "nnz")
         self.overlap = bool(overlap)
         self.n, self.rank, self.world, self.mode = int(n), int(rank), int(world), mode
-        self.bounds = block_bounds(self.n, self.world) if balance == "rows" else \
-            nnz_balanced_bounds(self.n, src, dst, self.world)
+        if _bounds is not None:
+            self.bounds = _bounds
+        else:
+            self.bounds = block_bounds(self.n, self.world) if balance == "rows" else \
+                nnz_balanced_bounds(self.n, src, dst, self.world)
         self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
         self.n_local = self.r1 - self.r0
         sizes = np.diff(self.bounds)
         # equal blocks (the last may be short) allow one all_gather_into_tensor on a padded buffer
         self.block = int(sizes[0]) if world > 0 else self.n
         self.uniform = bool(np.all(sizes[:-1] == self.block) and sizes[-1] <= self.block)
-        src = torch.as_tensor(src).to(torch.int64).reshape(-1)
-        dst = torch.as_tensor(dst).to(torch.int64).reshape(-1)
-        fwd = (dst >= self.r0) & (dst < self.r1)        # in-edges of my rows  -> A_p   (rows dst, cols src)
-        bwd = (src >= self.r0) & (src < self.r1)        # out-edges of my rows -> A^T_p (rows src, cols dst)
-        self.fwd_rows, self.fwd_cols = dst[fwd] - self.r0, src[fwd]
-        self.bwd_rows, self.bwd_cols = src[bwd] - self.r0, dst[bwd]
+        if _edges is not None:         # (from_edge_slice) the rank's edges are already here
+            f_dst, f_src, b_src, b_dst = _edges
+            self.fwd_rows, self.fwd_cols = f_dst - self.r0, f_src
+            self.bwd_rows, self.bwd_cols = b_src - self.r0, b_dst
+        else:
+            src = torch.as_tensor(src).to(torch.int64).reshape(-1)
+            dst = torch.as_tensor(dst).to(torch.int64).reshape(-1)
+            fwd = (dst >= self.r0) & (dst < self.r1)        # in-edges of my rows  -> A_p   (rows dst, cols src)
+            bwd = (src >= self.r0) & (src < self.r1)        # out-edges of my rows -> A^T_p (rows src, cols dst)
+            self.fwd_rows, self.fwd_cols = dst[fwd] - self.r0, src[fwd]
+            self.bwd_rows, self.bwd_cols = src[bwd] - self.r0, dst[bwd]
         # GLOBAL column ids of the local rows (the fused loss labels pairs by global id, whatever the exchange mode)
         self.cols_global = {"fwd": self.fwd_cols, "bwd": self.bwd_cols}
         self.n_cols = {"fwd": self.padded_n, "bwd": self.padded_n}
@@ -138,6 +158,53 @@ class RowPartition:
                 self.split[k] = dict(own=(rows[own], cols[own] - self.r0), remote=(rows[~own], rcols),
                                      n_remote_cols=n_rc)
 
+    @classmethod
+    def from_edge_slice(cls, n, src_slice, dst_slice, group=None, mode="allgather", balance="rows", overlap=False,
+                        row_cost=None):
+        """The plan of this rank when the ranks hold DISJOINT slices of the edge list (their union is the graph; any
+        assignment of edges to slices).  Collective over ``group``:
+          1. block bounds: equal rows, or -- "nnz" -- from the all-reduced in+out degree histogram (one int64[n]
+             all-reduce; the same bounds on every rank as nnz_balanced_bounds gives on the whole list);
+          2. every edge goes to the owner of its destination row (forward structure) and to the owner of its source
+             row (backward structure): two all-to-all-v of (src, dst) pairs.
+        The CSR build sorts (row, column) keys, so the structure does not depend on which slice an edge came from: the
+        plan equals RowPartition(n, all src, all dst, rank, world, ...)."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        src = torch.as_tensor(src_slice).to(torch.int64).reshape(-1)
+        dst = torch.as_tensor(dst_slice).to(torch.int64).reshape(-1)
+        n = int(n)
+        if balance == "nnz":
+            w = torch.bincount(dst, minlength=n) + torch.bincount(src, minlength=n)
+            if world > 1:
+                dist.all_reduce(w, group=group)
+            bounds = _weights_to_bounds(w + int(ROW_COST if row_cost is None else row_cost), world)
+            del w
+        else:
+            bounds = block_bounds(n, world)
+        if world == 1:
+            edges = (dst, src, src, dst)
+        else:
+            ends = torch.as_tensor(bounds[1:], device=src.device)
+
+            def to_owner(key):
+                """(src, dst) of the edges whose ``key`` row this rank owns, from every rank's slice"""
+                owner = torch.searchsorted(ends, key.contiguous(), right=True)
+                order = torch.argsort(owner, stable=True)
+                counts = torch.bincount(owner, minlength=world)
+                recv_counts = torch.empty_like(counts)
+                dist.all_to_all_single(recv_counts, counts, group=group)
+                out = []
+                for t in (src, dst):
+                    recv = torch.empty(int(recv_counts.sum()), dtype=torch.int64, device=t.device)
+                    dist.all_to_all_single(recv, t[order].contiguous(), output_split_sizes=recv_counts.tolist(),
+                                           input_split_sizes=counts.tolist(), group=group)
+                    out.append(recv)
+                return out
+            f_src, f_dst = to_owner(dst)
+            b_src, b_dst = to_owner(src)
+            edges = (f_dst, f_src, b_src, b_dst)
+        return cls(n, None, None, rank, world, mode, balance, overlap, _edges=edges, _bounds=bounds)
+
     @property
     def padded_n(self):
         """rows of the assembled matrix an exchange returns in all-gather mode"""
@@ -148,17 +215,18 @@ class ShardedGraph:
     """One rank's row block with its device CSRs and the exchange plan."""
 
     def __init__(self, n, src, dst, rank=None, world=None, group=None, mode="allgather", device=None,
-                 balance="rows", overlap=False):
+                 balance="rows", overlap=False, part=None):
         if isinstance(group, LocalGroup):
             assert rank is not None
             world = group.world
-        else:
+        elif part is None:
             rank = dist.get_rank(group) if rank is None else rank
             world = dist.get_world_size(group) if world is None else world
         self.group = group
-        self.part = RowPartition(n, src, dst, rank, world, mode, balance, overlap)
+        self.part = part if part is not None else RowPartition(n, src, dst, rank, world, mode, balance, overlap)
         self.timers = None         # set to {} to collect HIP-event pairs of the exchange / SpMM parts (bench.py)
-        self.device = torch.device(device) if device is not None else torch.as_tensor(src).device
+        self.device = torch.device(device) if device is not None else self.part.fwd_rows.device
+        self._n_edges_global = None
         self._csr = {}
         self._plan = {}
         self._a2a = {}
@@ -170,6 +238,20 @@ class ShardedGraph:
         self._xcache = {}
         if mode == "boundary":
             self._setup_boundary()
+
+    @classmethod
+    def from_edge_slice(cls, n, src_slice, dst_slice, group=None, mode="allgather", device=None, balance="rows",
+                        overlap=False):
+        """every rank passes ITS slice of the edge list (see RowPartition.from_edge_slice); collective"""
+        part = RowPartition.from_edge_slice(n, src_slice, dst_slice, group, mode, balance, overlap)
+        return cls(n, None, None, group=group, mode=mode, device=device, part=part)
+
+    def n_edges_global(self):
+        """edges of the whole graph (one scalar all-reduce, then cached: the loss's pos_weight needs it every step)"""
+        if self._n_edges_global is None:
+            t = self.allreduce_sum(torch.tensor([self.n_edges("fwd")], dtype=torch.int64, device=self.device))
+            self._n_edges_global = int(t)
+        return self._n_edges_global
 
     # ------------------------------------------------------------------ structure (HIP)
     def csr(self, which="fwd", part=None):
@@ -524,3 +606,63 @@ def allreduce_grads(params, group=None):
     for g in grads:
         g.copy_(flat[off:off + g.numel()].view_as(g))
         off += g.numel()
+
+
+class ShardedTrainStep:
+    """One data-parallel training step of train_transductive.py:56-66 on a row-sharded graph: sharded encoder + row
+    block of the fused loss (scalar all-reduce), backward, all-reduce of the replicated weights' gradients, optimiser.
+    Every rank runs the same sequence and ends with the same weights.
+
+    ``capture=True``: after ``warmup`` eager steps (they create the communicators, the structures, the optimiser
+    state) the step -- collectives included -- is captured into one HIP graph and replayed; RCCL's work is then part
+    of the graph, the host issues one launch per step.  ``mask_local``: the rank's rows of a fixed dropout mask (None
+    = no dropout)."""
+
+    def __init__(self, model, optimizer, sg, x_local, mask_local=None, transform_first=True, capture=False, warmup=2):
+        self.model, self.opt, self.sg, self.x, self.mask = model, optimizer, sg, x_local, mask_local
+        self.transform_first = transform_first
+        self.params = [p for g in optimizer.param_groups for p in g["params"]]
+        self.graph = None
+        self.loss = None
+        sg.n_edges_global()                                # one host read-back, outside the steps
+        if capture:
+            self._capture(warmup)
+
+    def _step(self):
+        from . import ops
+        loss = sharded_loss(self.model, self.sg, self.x, self.mask, self.transform_first)
+        ops.backward(loss, self.params)                    # autograd.grad: no stream-bound AccumulateGrad nodes
+        if not isinstance(self.sg.group, LocalGroup):      # (a 1-rank process group still runs the collective)
+            allreduce_grads(self.params, self.sg.group)
+        self.opt.step()
+        return loss.detach()
+
+    def _capture(self, warmup):
+        import gc
+        from .capture import _state_outside_capture
+        for w in ("fwd", "bwd"):                           # structures and plans: built outside the capture
+            for part in (("own", "remote") if self.sg.part.overlap else (None,)):
+                self.sg.csr(w, part); self.sg.plan(w, part)
+        self.sg.csr_global("fwd"); self.sg.csr_global("bwd")
+        gc.collect()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):           # >= 1: RCCL creates its communicator on first use
+                self.opt.zero_grad(set_to_none=True)
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        _state_outside_capture(self.opt)
+        self.opt.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        # thread_local: the process group's watchdog thread polls events while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.loss = self._step()
+
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+            return self.loss
+        self.opt.zero_grad(set_to_none=True)
+        self.loss = self._step()
+        return self.loss

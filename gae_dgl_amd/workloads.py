@@ -68,16 +68,30 @@ def zinc_like(n_graphs=249455, seed=0):
 
 
 def rmat_edges(scale=24, edge_factor=16, abcd=(0.57, 0.19, 0.19, 0.05), seed=0, device="cuda",
-               chunk=1 << 26):
-    """R-MAT edge list on the device (directed, duplicates kept).  Returns
-    (src, dst) int64 of length edge_factor * 2^scale."""
+               chunk=1 << 22, part=None):
+    """R-MAT edge list on the device (directed, duplicates kept): (src, dst) int64.
+
+    The list is made of chunks of ``chunk`` edges, each drawn from its own generator (seed, chunk index), so any
+    range of chunks can be produced without the ones before it.  ``part`` = (index, count): only the index-th of
+    ``count`` contiguous slices of the list (whole chunks; the slices of all indices concatenate to the full list) --
+    what one rank of ``count`` generates when no process holds the whole edge list (parallel.ShardedGraph.
+    from_edge_slice).  ``part`` None: all edge_factor * 2^scale edges."""
     n_edges = edge_factor << scale
     a, b, c, _ = abcd
-    gen = torch.Generator(device=device).manual_seed(seed)
-    src = torch.empty(n_edges, dtype=torch.int64, device=device)
-    dst = torch.empty(n_edges, dtype=torch.int64, device=device)
-    for lo in range(0, n_edges, chunk):
+    n_chunks = (n_edges + chunk - 1) // chunk
+    if part is None:
+        c0, c1 = 0, n_chunks
+    else:
+        idx, cnt = part
+        c0, c1 = n_chunks * idx // cnt, n_chunks * (idx + 1) // cnt
+    lo_all, hi_all = c0 * chunk, min(c1 * chunk, n_edges)
+    src = torch.empty(max(hi_all - lo_all, 0), dtype=torch.int64, device=device)
+    dst = torch.empty_like(src)
+    gen = torch.Generator(device=device)
+    for ci in range(c0, c1):
+        lo = ci * chunk
         m = min(chunk, n_edges - lo)
+        gen.manual_seed((int(seed) * 0x9E3779B1 + ci) & 0x7FFFFFFFFFFFFFFF)
         s = torch.zeros(m, dtype=torch.int64, device=device)
         d = torch.zeros(m, dtype=torch.int64, device=device)
         for _ in range(scale):
@@ -86,7 +100,7 @@ def rmat_edges(scale=24, edge_factor=16, abcd=(0.57, 0.19, 0.19, 0.05), seed=0, 
             dbit = ((r >= a) & (r < a + b) | (r >= a + b + c)).to(torch.int64)  # quadrants b, d -> col bit 1
             s = (s << 1) | sbit
             d = (d << 1) | dbit
-        src[lo:lo + m] = s; dst[lo:lo + m] = d
+        src[lo - lo_all:lo - lo_all + m] = s; dst[lo - lo_all:lo - lo_all + m] = d
     return src, dst
 
 

@@ -349,3 +349,55 @@ def test_rows_pack_is_an_exact_gather(F):
     Hp = ops.pad_rows(torch.randn(50, 39, device=dev))                  # row-padded source (ld 40)
     assert torch.equal(ops.rows_pack(Hp, idx[:20] % 50), Hp[idx[:20] % 50])
     assert ops.rows_pack(H, idx[:0]).shape == (0, F)
+
+
+def _one_rank_group():
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+    torch.cuda.set_device(0)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    return created
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("transform_first,capture", [(False, False), (True, False), (True, True)])
+def test_sharded_training_step_one_rank_rccl_follows_reference_step(transform_first, capture):
+    """the whole data-parallel step (parallel.ShardedTrainStep: sharded encoder, row block of the fused loss + scalar
+    all-reduce, backward, gradient all-reduce over RCCL, the library's Adam) against oracle.CpuReferenceStep for three
+    steps; ``capture``: the step -- collectives included -- replayed from ONE HIP graph.  The structure comes from
+    the rank's edge slice (ShardedGraph.from_edge_slice)."""
+    import torch.distributed as dist
+    import gae_dgl_amd as G
+    from gae_dgl_amd import optim
+    from gae_dgl_amd.parallel import ShardedGraph, ShardedTrainStep
+    from oracle import gae_oracle as O
+    created = _one_rank_group()
+    try:
+        n, src, dst, X = graph(seed=6, n=800, e=6000, F=32)
+        keys = torch.unique(src * n + dst)
+        src, dst = keys // n, keys % n
+        torch.manual_seed(0)
+        ref = O.CpuReferenceStep(src.cpu().numpy(), dst.cpu().numpy(), n, X.cpu().numpy(), 32, [32, 16], lr=1e-2, seed=0,
+                                 dropout=0.0)
+        model = G.GAE(32, [32, 16]).to(DEV)
+        model.decoder.dropout = 0.0
+        with torch.no_grad():
+            for conv, lin in zip(model.layers, ref.layers):
+                conv.apply_mod.linear.weight.copy_(lin.weight); conv.apply_mod.linear.bias.copy_(lin.bias)
+        sg = ShardedGraph.from_edge_slice(n, src, dst, None, "boundary", DEV, "nnz", overlap=True)
+        opt = optim.Adam(model.parameters(), lr=1e-2)
+        step = ShardedTrainStep(model, opt, sg, X, transform_first=transform_first, capture=capture, warmup=1)
+        k0 = 1 if capture else 0                       # (the capture's warm-up step trained the model once)
+        want = [ref.step() for _ in range(3 + k0)][k0:]
+        got = []
+        for _ in range(3):
+            got.append(float(step()))
+        np.testing.assert_allclose(got, want, rtol=5e-5)
+        for conv, lin in zip(model.layers, ref.layers):
+            w = conv.apply_mod.linear.weight.detach().cpu()
+            assert float((w - lin.weight).abs().max()) <= 5e-4 * float(lin.weight.abs().max())
+    finally:
+        if created:
+            dist.destroy_process_group()
