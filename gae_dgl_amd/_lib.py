@@ -41,7 +41,7 @@ class AdamTensor(ctypes.Structure):
 
 
 class BceTail(ctypes.Structure):
-    """gae_bce_tail: the deferred final reduction of a fused loss call (gae_decoder_bce_defer_finalize)"""
+    """gae_bce_tail: the deferred final reduction of a fused loss call (gae_x_decoder_bce_defer_finalize)"""
     _fields_ = [("dense_partial", _p), ("n_dense", _i64), ("edge_partial", _p), ("n_edge", _i64), ("S", _p),
                 ("DP", _i32), ("reserved", _i32), ("pad_terms", ctypes.c_double), ("inv_n2", ctypes.c_double),
                 ("loss_out", _p), ("bump_draw", _p), ("scal", _p),
@@ -49,7 +49,7 @@ class BceTail(ctypes.Structure):
 
 
 class BcePrep(ctypes.Structure):
-    """gae_bce_prep: where a producer kernel puts the prepare step's outputs (gae_decoder_bce_prep_layout)"""
+    """gae_bce_prep: where a producer kernel puts the prepare step's outputs (gae_x_decoder_bce_prep_layout)"""
     _fields_ = [("Zt", _p), ("Zhi", _p), ("Zlo", _p), ("colsum_partial", _p), ("scal", _p),
                 ("all_pairs", ctypes.c_double), ("max_blocks", _i64), ("DP", _i32), ("reserved", _i32)]
 
@@ -62,16 +62,11 @@ SIGNATURES = {
     "gae_version": (_int, []),
     "gae_last_error": (ctypes.c_char_p, []),
     "gae_device_info_get": (_int, [_int, ctypes.POINTER(DeviceInfo)]),
-    "gae_spmm_col_freq": (_int, [_p, _i64, _i64, _p, _p]),
-    "gae_spmm_tag_hot": (_int, [_p, _i64, _p, _i32, _p, _p]),
     "gae_spmm_csr_ep": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _int, _p, _int, _p]),
     "gae_linear2_fwd": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _i64, _p, _i64, _p, _i64, _p]),
     "gae_gcn2_bwd_dense_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "gae_gcn2_bwd_dense": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p, _p,
                                   _p, _p, _p, _i64, _p, _p, _i64, _p, _p]),
-    "gae_spmm_plan_light_count": (_int, [_p, _i64, _i32, _p, _p]),
-    "gae_spmm_plan_light_workspace_bytes": (_i64, [_i64]),
-    "gae_spmm_plan_light": (_int, [_p, _i64, _i32, _p, _i64, _p, _i64, _p]),
     "gae_spmm_plan_sizes": (_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p]),
     "gae_spmm_plan_scratch_bytes": (_i64, [_i64, _i64, _i64, _i64, _i32]),
     "gae_spmm_plan_build_rows": (_int, [_p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p,
@@ -86,19 +81,16 @@ SIGNATURES = {
     "gae_csr_to_dense": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
     "gae_batch_plan": (_int, [_p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "gae_batch_select": (_int, [_p, _i64, _p, _i64, _p, _p]),
-    "gae_batch_plan_next": (_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p]),
+    "gae_x_batch_plan_next": (_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p]),
     "gae_batch_gather": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _p, _i64, _i64,
                                 _p, _p, _p, _i64, _p, _i32, _i64, _p, _p]),
-    "gae_batch_gather_next": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64,
+    "gae_x_batch_gather_next": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64,
                                      _p, _p, _p, _i64, _p, _i32, _p, _p]),
     "gae_decoder_bce_padded": (_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _f, _u64, _u64, _p, _p, _p, _i64,
                                       _p, _i64, _p]),
     "gae_bce_logits_workspace_bytes": (_i64, []),
     "gae_bce_logits": (_int, [_p, _i64, _p, _i64, _i64, _i64, _f, _p, _p, _i64, _p, _i64, _p]),
     "gae_segment_readout": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),
-    "gae_spmm_plan_count": (_int, [_p, _i64, _i32, _i32, _p, _p]),
-    "gae_spmm_plan_fill": (_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
-    "gae_spmm_plan_desc": (_int, [_p, _p, _p, _p, _i64, _i32, _p, _p]),
     "gae_spmm_ell_build": (_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "gae_spmm_workspace_bytes": (_i64, [ctypes.POINTER(SpmmPlan), _i64]),
     "gae_spmm_csr": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _int, _p, _p,
@@ -120,8 +112,8 @@ SIGNATURES = {
     "gae_linear_fwd_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gae_linear_fwd": (_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _i64, _p]),
     "gae_linear_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64]),
-    "gae_linear_bwd_partials": (_int, [_p, _i64, _p, _i64, _int, _p, _i64, _i64, _i64, _i64, _int, _int, _p, _i64, _p, _p]),
-    "gae_xw_wgrad_partials": (_int, [_p, _i64, _int, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _int, _int,
+    "gae_x_linear_bwd_partials": (_int, [_p, _i64, _p, _i64, _int, _p, _i64, _i64, _i64, _i64, _int, _int, _p, _i64, _p, _p]),
+    "gae_x_xw_wgrad_partials": (_int, [_p, _i64, _int, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _int, _int,
                                      _p, _i64, _p, _p]),
     "gae_linear_bwd": (_int, [_p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _i64, _i64,
                               _p, _p, _p, _i64, _p, _i64, _p]),
@@ -130,28 +122,28 @@ SIGNATURES = {
     "gae_vgae_head_workspace_bytes": (_i64, [_i64]),
     "gae_vgae_head_fwd": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _p]),
     "gae_vgae_head_bwd": (_int, [_p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _p, _p]),
-    "gae_gcn_layer_fused2": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _int, _i64,
+    "gae_x_gcn_layer_fused2": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _int, _i64,
                                     _i64, _p, _p, _i64, _int, _p, _i64, _p]),
     "gae_decoder_dense": (_int, [_p, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "gae_decoder_dense_bwd_workspace_bytes": (_i64, [_i64, _i64]),
     "gae_decoder_dense_bwd": (_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),
     "gae_adam_step": (_int, [ctypes.POINTER(AdamTensor), _i32, _f, _f, _f, _f, _f, _p, _p]),
-    "gae_gcn_layer_fused_wgrad_workspace_bytes": (_i64, [_i64, _i64, _i64]),
-    "gae_gcn_layer_fused_wgrad": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, ctypes.POINTER(SpmmPlan), _p, _i64, _i64, _p,
+    "gae_x_gcn_layer_fused_wgrad_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "gae_x_gcn_layer_fused_wgrad": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, ctypes.POINTER(SpmmPlan), _p, _i64, _i64, _p,
                                          _i64, _p, _i64, _p, _p, _p, _i64, _p, _p]),
-    "gae_decoder_bce_prep_layout": (_int, [_i64, _i64, _p, _i64, ctypes.POINTER(BcePrep)]),
-    "gae_gcn_layer_fused_prep": (_int, [_p, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, ctypes.POINTER(SpmmPlan), _p, _i64,
+    "gae_x_decoder_bce_prep_layout": (_int, [_i64, _i64, _p, _i64, ctypes.POINTER(BcePrep)]),
+    "gae_x_gcn_layer_fused_prep": (_int, [_p, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, ctypes.POINTER(SpmmPlan), _p, _i64,
                                         _i64, _p, _i64, _p, _i64, ctypes.POINTER(BcePrep), _p, _i64, _f, _u64, _u64, _p, _p,
                                         _p, _p]),
-    "gae_decoder_bce_prepared": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f, _p, _f, _p, _i64, _p, _p, _i64, _p, _i64,
+    "gae_x_decoder_bce_prepared": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f, _p, _f, _p, _i64, _p, _p, _i64, _p, _i64,
                                         _p]),
-    "gae_vgae_head_prep": (_int, [_p, _p, _i64, _p, _int, _u64, _u64, _p, _i64, _i64, _p, ctypes.POINTER(BcePrep), _p, _i64,
+    "gae_x_vgae_head_prep": (_int, [_p, _p, _i64, _p, _int, _u64, _u64, _p, _i64, _i64, _p, ctypes.POINTER(BcePrep), _p, _i64,
                                   _p, _p]),
-    "gae_gcn_layer_fused2_wgrad": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, ctypes.POINTER(SpmmPlan), _p, _p, _i64, _i64,
+    "gae_x_gcn_layer_fused2_wgrad": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, ctypes.POINTER(SpmmPlan), _p, _p, _i64, _i64,
                                           _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _p]),
-    "gae_adam_step_tail": (_int, [ctypes.POINTER(AdamTensor), _i32, _f, _f, _f, _f, _f, _p, ctypes.POINTER(BceTail), _p]),
-    "gae_decoder_bce_defer_finalize": (_int, [ctypes.POINTER(BceTail)]),
-    "gae_decoder_bce_finalize": (_int, [ctypes.POINTER(BceTail), _p]),
+    "gae_x_adam_step_tail": (_int, [ctypes.POINTER(AdamTensor), _i32, _f, _f, _f, _f, _f, _p, ctypes.POINTER(BceTail), _p]),
+    "gae_x_decoder_bce_defer_finalize": (_int, [ctypes.POINTER(BceTail)]),
+    "gae_x_decoder_bce_finalize": (_int, [ctypes.POINTER(BceTail), _p]),
     "gae_decoder_bce_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gae_decoder_bce_rows": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _f, _f, _u64, _u64, _p,
                                     _p, _p, _i64, _p, _i64, _p]),

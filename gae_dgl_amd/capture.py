@@ -16,26 +16,16 @@ import torch
 from . import ops
 
 
-class _defer:
-    """ops.deferred_grad_reductions() when the optimiser is the library's Adam (which consumes the partial sums),
-    a no-op for any other optimiser"""
-
-    def __init__(self, opt, loss_too=False):
-        from .optim import Adam
-        ours = isinstance(opt, Adam)
-        # loss_too: the step's loss is the fused decoder + BCE scalar itself and nothing reads it before the optimiser
-        # launch (a loss_fn of the caller's may do arithmetic on it: those steps keep the reduction launch)
-        self.cms = [cm for cm in (ops.deferred_grad_reductions() if ours and DEFER_GRAD_REDUCTIONS else None,
-                                  ops.deferred_loss_finalize() if ours and loss_too and DEFER_LOSS_FINALIZE else None)
-                    if cm is not None]
-
-    def __enter__(self):
-        for cm in self.cms:
-            cm.__enter__()
-
-    def __exit__(self, *exc):
-        for cm in reversed(self.cms):
-            cm.__exit__(*exc)
+def _defer(opt, loss_too=False):
+    """the step's context (ops.StepContext): the weight gradients' reductions -- and, ``loss_too``, the loss's final one
+    -- are left to the optimiser launch when the optimiser is the library's Adam (which consumes them); a context that
+    defers nothing for any other optimiser.  ``loss_too``: the step's loss is the fused decoder + BCE scalar itself and
+    nothing reads it before the optimiser launch (a loss_fn of the caller's may do arithmetic on it: those steps keep
+    the reduction launch)."""
+    from .optim import Adam
+    ours = isinstance(opt, Adam)
+    return ops.StepContext(defer_grads=ours and DEFER_GRAD_REDUCTIONS,
+                           defer_loss=ours and loss_too and DEFER_LOSS_FINALIZE)
 
 
 def _state_outside_capture(opt):
@@ -49,7 +39,7 @@ def _state_outside_capture(opt):
         raise ValueError("capture needs the optimiser's state in place: run at least one step (warmup >= 1) before it")
 
 
-FUSED_COLLATE_MAX_GRAPHS = 1024   # batches up to this size collate in one launch (gae_batch_gather_next); 0 = never
+FUSED_COLLATE_MAX_GRAPHS = 1024   # batches up to this size collate in one launch (gae_x_batch_gather_next); 0 = never
 DEFER_GRAD_REDUCTIONS = True      # False: captured steps keep the separate reduction launches (experiments)
 DEFER_LOSS_FINALIZE = os.environ.get("GAE_DEFER_LOSS_FINALIZE", "1") != "0"   # False: the fused loss keeps its own final-reduction launch (experiments)
 

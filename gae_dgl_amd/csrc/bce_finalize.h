@@ -1,6 +1,6 @@
 // The last reduction of the fused decoder + BCE loss (dense partials, edge partials, analytic terms -> the scalar),
 // as a device function of ONE block: bce_finalize_kernel (decoder_bce.hip) runs it as its own launch, adam_step_kernel
-// (optim.hip) as one extra block of the optimiser launch when the caller deferred it (gae_decoder_bce_defer_finalize):
+// (optim.hip) as one extra block of the optimiser launch when the caller deferred it (gae_x_decoder_bce_defer_finalize):
 // the scalar is not an input of the backward pass, so inside a captured training step the dependent ~5 us launch
 // disappears.  The order of the sums is that of a 1024-thread block whatever the real block size NT (a thread plays
 // 1024 / NT virtual threads, a wave 1024 / NT virtual waves): both forms give the same bits.
@@ -72,7 +72,7 @@ __device__ __forceinline__ void bce_finalize_block(const gae_bce_tail &t, double
         if (lane == 0) { red[0][tid >> 6] = av; red[1][tid >> 6] = lv; red[2][tid >> 6] = ev; }
     }
     __syncthreads();
-    // an additive term on top (VGAE: the KL partials of gae_vgae_head_prep), summed by the first wave: lane l takes
+    // an additive term on top (VGAE: the KL partials of gae_x_vgae_head_prep), summed by the first wave: lane l takes
     // partials l, l + 64, ..., then a fixed shuffle tree
     double extra = 0.0;
     if (t.kl_partial != nullptr && threadIdx.x < 64) {

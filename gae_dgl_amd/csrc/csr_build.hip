@@ -121,7 +121,7 @@ __global__ __launch_bounds__(1024) void batch_plan_kernel(const int64_t *__restr
                                                           const int64_t *__restrict__ graph_ids, int64_t n_graphs,
                                                           int64_t *__restrict__ node_ptr, int64_t *__restrict__ edge_ptr,
                                                           int64_t *__restrict__ t_edge_ptr,
-                                                          // gae_batch_plan_next: the ids come from an epoch order
+                                                          // gae_x_batch_plan_next: the ids come from an epoch order
                                                           const int64_t *__restrict__ order, int64_t n_order,
                                                           int64_t *__restrict__ cursor, int64_t *__restrict__ ids_out)
 {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(
     const int64_t *__restrict__ out_edge_ptr, int32_t *__restrict__ out_indptr,
     int32_t *__restrict__ out_indices, TO *__restrict__ out_feat, int64_t ld_out, int32_t *__restrict__ out_ell,
     int ell_width, int64_t cap_nodes, int64_t cap_edges, int64_t *__restrict__ out_counts,
-    // gae_batch_gather_next (order != NULL): select + plan + gather in ONE launch for batches of a few hundred graphs --
+    // gae_x_batch_gather_next (order != NULL): select + plan + gather in ONE launch for batches of a few hundred graphs --
     // every wave adds up the sizes of the graphs in front of its own itself (two coalesced passes over <= 1024 ids)
     const int64_t *__restrict__ order, int64_t n_order, int64_t *__restrict__ cursor, int64_t *__restrict__ ids_out,
     int64_t *__restrict__ node_ptr_out, int64_t *__restrict__ edge_ptr_out)
@@ -574,14 +574,14 @@ extern "C" int gae_batch_plan(const int64_t *graph_ptr, const int32_t *ds_indptr
     return GAE_OK;
 }
 
-extern "C" int gae_batch_plan_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
+extern "C" int gae_x_batch_plan_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
                                    const int64_t *order, int64_t n_order, int64_t *cursor_dev, int64_t n_graphs,
                                    int64_t *out_ids, int64_t *out_node_ptr, int64_t *out_edge_ptr,
                                    int64_t *out_t_edge_ptr, void *stream)
 {
-    GAE_REQUIRE(n_graphs > 0 && n_order > 0, GAE_E_SIZE, "gae_batch_plan_next: sizes must be positive");
+    GAE_REQUIRE(n_graphs > 0 && n_order > 0, GAE_E_SIZE, "gae_x_batch_plan_next: sizes must be positive");
     GAE_REQUIRE(graph_ptr && ds_indptr && order && cursor_dev && out_ids && out_node_ptr && out_edge_ptr, GAE_E_NULL,
-                "gae_batch_plan_next: NULL pointer");
+                "gae_x_batch_plan_next: NULL pointer");
     hipLaunchKernelGGL(batch_plan_kernel, dim3(1), dim3(1024), 0, gae::as_stream(stream), graph_ptr, ds_indptr,
                        ds_t_indptr, nullptr, n_graphs, out_node_ptr, out_edge_ptr, out_t_edge_ptr, order, n_order,
                        cursor_dev, out_ids);
@@ -634,10 +634,10 @@ extern "C" int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indp
     return GAE_OK;
 }
 
-// gae_batch_plan_next + gae_batch_gather in one launch (fixed-capacity batches of <= 1024 graphs): the captured
+// gae_x_batch_plan_next + gae_batch_gather in one launch (fixed-capacity batches of <= 1024 graphs): the captured
 // inductive step of the reference's default batch (128 molecules, gae_dgl/train_inductive.py:24) is bound by its
 // number of kernel nodes, and the plan of so few graphs is cheaper to recompute in every wave than to launch.
-extern "C" int gae_batch_gather_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_indices,
+extern "C" int gae_x_batch_gather_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_indices,
                                      const void *ds_feat, int64_t ld_feat, int64_t F, int dtype, const int64_t *order,
                                      int64_t n_order, int64_t *cursor_dev, int64_t n_graphs, int64_t *out_ids,
                                      int64_t *out_node_ptr, int64_t *out_edge_ptr, int64_t cap_nodes, int64_t cap_edges,
@@ -645,16 +645,16 @@ extern "C" int gae_batch_gather_next(const int64_t *graph_ptr, const int32_t *ds
                                      int32_t *out_ell, int32_t ell_width, int64_t *out_counts, void *stream)
 {
     GAE_REQUIRE(n_graphs >= 1 && n_graphs <= 1024 && n_order >= 1, GAE_E_RANGE,
-                "gae_batch_gather_next: 1 .. 1024 graphs per batch (larger batches: gae_batch_plan_next + gae_batch_gather)");
-    GAE_REQUIRE(cap_nodes >= 1 && cap_edges >= 0 && F >= 0, GAE_E_SIZE, "gae_batch_gather_next: bad capacities");
-    GAE_REQUIRE(ld_feat >= F && ld_out >= F, GAE_E_SIZE, "gae_batch_gather_next: leading dimension < F");
-    GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16 || dtype == GAE_U8, GAE_E_DTYPE, "gae_batch_gather_next: dtype %d", dtype);
+                "gae_x_batch_gather_next: 1 .. 1024 graphs per batch (larger batches: gae_x_batch_plan_next + gae_batch_gather)");
+    GAE_REQUIRE(cap_nodes >= 1 && cap_edges >= 0 && F >= 0, GAE_E_SIZE, "gae_x_batch_gather_next: bad capacities");
+    GAE_REQUIRE(ld_feat >= F && ld_out >= F, GAE_E_SIZE, "gae_x_batch_gather_next: leading dimension < F");
+    GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16 || dtype == GAE_U8, GAE_E_DTYPE, "gae_x_batch_gather_next: dtype %d", dtype);
     GAE_REQUIRE(graph_ptr && ds_indptr && order && cursor_dev && out_ids && out_node_ptr && out_edge_ptr && out_indptr &&
-                    out_counts, GAE_E_NULL, "gae_batch_gather_next: NULL pointer");
-    GAE_REQUIRE(cap_edges == 0 || (ds_indices && out_indices), GAE_E_NULL, "gae_batch_gather_next: NULL index pointer");
-    GAE_REQUIRE(F == 0 || !out_feat || ds_feat, GAE_E_NULL, "gae_batch_gather_next: NULL feature pointer");
+                    out_counts, GAE_E_NULL, "gae_x_batch_gather_next: NULL pointer");
+    GAE_REQUIRE(cap_edges == 0 || (ds_indices && out_indices), GAE_E_NULL, "gae_x_batch_gather_next: NULL index pointer");
+    GAE_REQUIRE(F == 0 || !out_feat || ds_feat, GAE_E_NULL, "gae_x_batch_gather_next: NULL feature pointer");
     GAE_REQUIRE(!out_ell || ell_width == 4 || ell_width == 8 || ell_width == GAE_SPMM_ELL_WIDTH, GAE_E_RANGE,
-                "gae_batch_gather_next: ell_width must be 4, 8 or %d", GAE_SPMM_ELL_WIDTH);
+                "gae_x_batch_gather_next: ell_width must be 4, 8 or %d", GAE_SPMM_ELL_WIDTH);
     hipStream_t s = gae::as_stream(stream);
     const int64_t blocks = ((n_graphs + 256) * kWave + 255) / 256;       // one wave per graph + 256 padding waves
 #define GAE_BGN(TI, TO)                                                                                              \

@@ -1344,7 +1344,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     p.o_bytes = align256(p.n_splits * n_local * p.DP * 4);
     p.zt_bytes = align256(n * p.DP * 4);
     p.zh_bytes = align256(n * p.DP * 2);
-    p.cs_bytes = align256(((n + 15) / 16 + 1) * 2 * p.DP * 8);    // up to one partial per 16 rows (a producer kernel's blocks: gae_gcn_layer_fused_prep)
+    p.cs_bytes = align256(((n + 15) / 16 + 1) * 2 * p.DP * 8);    // up to one partial per 16 rows (a producer kernel's blocks: gae_x_gcn_layer_fused_prep)
     p.s_bytes = align256(2 * p.DP * 8 + p.DP * 4 + 4 * 8);       // column sums (double x 2, float) + 3 scalars
     p.n_dense = p.row_blocks * p.n_splits;
     p.total_bytes = p.o_bytes + p.zt_bytes + 2 * p.zh_bytes + p.cs_bytes + p.s_bytes +
@@ -1460,7 +1460,7 @@ inline double bce_all_pairs(const BcePlan &p, int64_t n, int64_t n_local)
     return p.sym ? double(n) * double(n) : double(n_local) * double((n + TJ - 1) / TJ * TJ);
 }
 
-thread_local gae_bce_tail *t_tail_out = nullptr;     // gae_decoder_bce_defer_finalize: receives the next call's final reduction
+thread_local gae_bce_tail *t_tail_out = nullptr;     // gae_x_decoder_bce_defer_finalize: receives the next call's final reduction
 
 int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_t d,
                      int64_t row_begin, int64_t n_local, const int32_t *indptr,
@@ -1470,7 +1470,7 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
                      int64_t workspace_bytes, const int64_t *counts, void *stream, int64_t prepared_blocks = -1)
 {
     // prepared_blocks >= 0: Zt / hi / lo / the column-sum partials (that many) / the padded-batch scalars are already
-    // in the workspace (gae_gcn_layer_fused_prep wrote them): no prepare launch, Z is not read
+    // in the workspace (gae_x_gcn_layer_fused_prep wrote them): no prepare launch, Z is not read
     const bool prepared = prepared_blocks >= 0;
     GAE_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GAE_E_RANGE, "gae_decoder_bce: dropout_p = %g outside [0, 1)",
                 double(dropout_p));
@@ -1490,7 +1490,7 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
                 (long long)workspace_bytes, (long long)p.total_bytes);
     if (prepared) {
         GAE_REQUIRE(prepared_blocks >= 1 && prepared_blocks * 2 * p.DP * 8 <= p.cs_bytes, GAE_E_RANGE,
-                    "gae_decoder_bce_prepared: %lld column-sum partials do not fit the workspace", (long long)prepared_blocks);
+                    "gae_x_decoder_bce_prepared: %lld column-sum partials do not fit the workspace", (long long)prepared_blocks);
         p.prep_blocks = prepared_blocks;
     }
     GAE_REQUIRE(gae::aligned16(workspace), GAE_E_ALIGN, "gae_decoder_bce: workspace not 16-byte aligned");
@@ -1568,7 +1568,7 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
     tail.S = S; tail.DP = p.DP;
     tail.pad_terms = p.pad_terms; tail.inv_n2 = inv_n2;
     tail.loss_out = loss_out; tail.bump_draw = dropout_p > 0.f ? draw_dev : nullptr; tail.scal = scal;
-    if (t_tail_out) {               // armed by gae_decoder_bce_defer_finalize: the caller launches (or hands on) the reduction
+    if (t_tail_out) {               // armed by gae_x_decoder_bce_defer_finalize: the caller launches (or hands on) the reduction
         *t_tail_out = tail;
         t_tail_out = nullptr;
         return GAE_OK;
@@ -1579,19 +1579,19 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
 }
 } // namespace
 
-extern "C" int gae_decoder_bce_defer_finalize(gae_bce_tail *tail_out)
+extern "C" int gae_x_decoder_bce_defer_finalize(gae_bce_tail *tail_out)
 {
     t_tail_out = tail_out;          // NULL disarms
     return GAE_OK;
 }
 
-extern "C" int gae_decoder_bce_finalize(const gae_bce_tail *tail, void *stream)
+extern "C" int gae_x_decoder_bce_finalize(const gae_bce_tail *tail, void *stream)
 {
-    GAE_REQUIRE(tail != nullptr, GAE_E_NULL, "gae_decoder_bce_finalize: tail is NULL");
+    GAE_REQUIRE(tail != nullptr, GAE_E_NULL, "gae_x_decoder_bce_finalize: tail is NULL");
     if (tail->loss_out == nullptr) return GAE_OK;
     GAE_REQUIRE(tail->S && (tail->n_dense == 0 || tail->dense_partial) && (tail->n_edge == 0 || tail->edge_partial) &&
                     tail->DP > 0 && tail->n_dense >= 0 && tail->n_edge >= 0,
-                GAE_E_NULL, "gae_decoder_bce_finalize: malformed tail (not one written by gae_decoder_bce*)");
+                GAE_E_NULL, "gae_x_decoder_bce_finalize: malformed tail (not one written by gae_decoder_bce*)");
     hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(1024), 0, gae::as_stream(stream), *tail);
     GAE_CHECK_LAUNCH("bce_finalize_kernel");
     return GAE_OK;
@@ -1630,18 +1630,18 @@ extern "C" int gae_decoder_bce(const float *Z, float *mask, int64_t ldz, int64_t
                                 seed, offset, draw_dev, loss_out, dZ, lddz, workspace, workspace_bytes, stream);
 }
 
-// Where a PRODUCER kernel (gae_gcn_layer_fused_prep: the last encoder layer) puts what bce_prepare_kernel would
-// compute, inside a workspace of gae_decoder_bce_workspace_bytes(n, n, d) bytes: gae_decoder_bce_prepared then starts
+// Where a PRODUCER kernel (gae_x_gcn_layer_fused_prep: the last encoder layer) puts what bce_prepare_kernel would
+// compute, inside a workspace of gae_decoder_bce_workspace_bytes(n, n, d) bytes: gae_x_decoder_bce_prepared then starts
 // at the dense kernel.
-extern "C" int gae_decoder_bce_prep_layout(int64_t n, int64_t d, void *workspace, int64_t workspace_bytes,
+extern "C" int gae_x_decoder_bce_prep_layout(int64_t n, int64_t d, void *workspace, int64_t workspace_bytes,
                                            gae_bce_prep *out)
 {
-    GAE_REQUIRE(out && workspace, GAE_E_NULL, "gae_decoder_bce_prep_layout: NULL pointer");
-    GAE_REQUIRE(n > 0 && d > 0 && d <= 64, GAE_E_RANGE, "gae_decoder_bce_prep_layout: n, d out of range");
+    GAE_REQUIRE(out && workspace, GAE_E_NULL, "gae_x_decoder_bce_prep_layout: NULL pointer");
+    GAE_REQUIRE(n > 0 && d > 0 && d <= 64, GAE_E_RANGE, "gae_x_decoder_bce_prep_layout: n, d out of range");
     BcePlan p;
     bce_plan(n, n, d, true, p);
     GAE_REQUIRE(workspace_bytes >= p.total_bytes && gae::aligned16(workspace), GAE_E_WORKSPACE,
-                "gae_decoder_bce_prep_layout: workspace %lld < %lld bytes (or not 16-byte aligned)",
+                "gae_x_decoder_bce_prep_layout: workspace %lld < %lld bytes (or not 16-byte aligned)",
                 (long long)workspace_bytes, (long long)p.total_bytes);
     char *w = static_cast<char *>(workspace) + p.o_bytes;
     out->Zt = reinterpret_cast<float *>(w); w += p.zt_bytes;
@@ -1656,13 +1656,13 @@ extern "C" int gae_decoder_bce_prep_layout(int64_t n, int64_t d, void *workspace
     return GAE_OK;
 }
 
-extern "C" int gae_decoder_bce_prepared(float *mask, int64_t ldz, int64_t n, int64_t d, const int32_t *indptr,
+extern "C" int gae_x_decoder_bce_prepared(float *mask, int64_t ldz, int64_t n, int64_t d, const int32_t *indptr,
                                         const int32_t *indices, const int32_t *t_indptr, const int32_t *t_indices,
                                         float pos_weight, const int64_t *counts_dev, float dropout_p,
                                         uint64_t *draw_dev, int64_t n_prep_blocks, float *loss_out, float *dZ,
                                         int64_t lddz, void *workspace, int64_t workspace_bytes, void *stream)
 {
-    GAE_REQUIRE(n_prep_blocks >= 1, GAE_E_RANGE, "gae_decoder_bce_prepared: n_prep_blocks must be what the producer reported");
+    GAE_REQUIRE(n_prep_blocks >= 1, GAE_E_RANGE, "gae_x_decoder_bce_prepared: n_prep_blocks must be what the producer reported");
     return decoder_bce_impl(nullptr, mask, ldz, n, d, 0, n, indptr, indices, t_indptr, t_indices, pos_weight, dropout_p,
                             0, 0, draw_dev, loss_out, dZ, lddz, workspace, workspace_bytes, counts_dev, stream,
                             n_prep_blocks);

@@ -1641,20 +1641,20 @@ extern "C" int64_t gae_linear_bwd_workspace_bytes(int64_t n, int64_t f_in, int64
     return align256(pl.n_slots * pl.slot_stride * 4) + 256;
 }
 
-extern "C" int gae_linear_bwd_partials(const float *dY, int64_t lddy, const float *Y, int64_t ldy, int act, const float *M,
+extern "C" int gae_x_linear_bwd_partials(const float *dY, int64_t lddy, const float *Y, int64_t ldy, int act, const float *M,
                                        int64_t ldm, int64_t n, int64_t f_in, int64_t f_out, int want_dW, int want_db,
                                        void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream)
 {
-    GAE_REQUIRE(n > 0 && f_in >= 0 && f_out > 0 && layout_out, GAE_E_SIZE, "gae_linear_bwd_partials: bad sizes");
-    GAE_REQUIRE(f_in < (1 << 24) && f_out < (1 << 24), GAE_E_SIZE, "gae_linear_bwd_partials: feature width too large");
-    GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_DTYPE, "gae_linear_bwd_partials: activation %d", act);
-    GAE_REQUIRE(dY && lddy >= f_out && (want_dW || want_db), GAE_E_NULL, "gae_linear_bwd_partials: dY missing");
-    GAE_REQUIRE(act != GAE_ACT_RELU || (Y && ldy >= f_out), GAE_E_NULL, "gae_linear_bwd_partials: RELU needs Y");
-    GAE_REQUIRE(!want_dW || (M && ldm >= f_in && f_in > 0), GAE_E_NULL, "gae_linear_bwd_partials: dW needs M");
+    GAE_REQUIRE(n > 0 && f_in >= 0 && f_out > 0 && layout_out, GAE_E_SIZE, "gae_x_linear_bwd_partials: bad sizes");
+    GAE_REQUIRE(f_in < (1 << 24) && f_out < (1 << 24), GAE_E_SIZE, "gae_x_linear_bwd_partials: feature width too large");
+    GAE_REQUIRE(act == GAE_ACT_IDENTITY || act == GAE_ACT_RELU, GAE_E_DTYPE, "gae_x_linear_bwd_partials: activation %d", act);
+    GAE_REQUIRE(dY && lddy >= f_out && (want_dW || want_db), GAE_E_NULL, "gae_x_linear_bwd_partials: dY missing");
+    GAE_REQUIRE(act != GAE_ACT_RELU || (Y && ldy >= f_out), GAE_E_NULL, "gae_x_linear_bwd_partials: RELU needs Y");
+    GAE_REQUIRE(!want_dW || (M && ldm >= f_in && f_in > 0), GAE_E_NULL, "gae_x_linear_bwd_partials: dW needs M");
     const AtbPlan pl = atb_plan(n, f_out, f_in);
     const int64_t need = align256(pl.n_slots * pl.slot_stride * 4);
     GAE_REQUIRE(workspace && workspace_bytes >= need && gae::aligned16(workspace), GAE_E_WORKSPACE,
-                "gae_linear_bwd_partials: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+                "gae_x_linear_bwd_partials: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     const bool relu = act == GAE_ACT_RELU;
     const float *Q = want_dW ? M : dY;
     const int64_t ldq = want_dW ? ldm : lddy;
@@ -1840,20 +1840,20 @@ extern "C" int gae_vgae_head_fwd(const float *mu, const float *logstd, int64_t l
 }
 
 // see include/gae_hip.h
-extern "C" int gae_vgae_head_prep(const float *mu, const float *logstd, int64_t ldm, float *eps, int draw_eps,
+extern "C" int gae_x_vgae_head_prep(const float *mu, const float *logstd, int64_t ldm, float *eps, int draw_eps,
                                   uint64_t seed, uint64_t offset, const uint64_t *draw_dev, int64_t n, int64_t d, float *z,
                                   const gae_bce_prep *prep, double *kl_partial, int64_t kl_capacity,
                                   int64_t *n_blocks_out, void *stream)
 {
-    GAE_REQUIRE(d == 16, GAE_E_RANGE, "gae_vgae_head_prep: the fused form takes d = 16 (got %lld): use gae_vgae_head_fwd", (long long)d);
-    GAE_REQUIRE(n > 0 && ldm >= d && ldm % 4 == 0, GAE_E_SIZE, "gae_vgae_head_prep: needs n > 0 and rows of whole 16-byte vectors");
-    GAE_REQUIRE(mu && logstd && eps && z && prep && kl_partial && n_blocks_out, GAE_E_NULL, "gae_vgae_head_prep: NULL pointer");
+    GAE_REQUIRE(d == 16, GAE_E_RANGE, "gae_x_vgae_head_prep: the fused form takes d = 16 (got %lld): use gae_vgae_head_fwd", (long long)d);
+    GAE_REQUIRE(n > 0 && ldm >= d && ldm % 4 == 0, GAE_E_SIZE, "gae_x_vgae_head_prep: needs n > 0 and rows of whole 16-byte vectors");
+    GAE_REQUIRE(mu && logstd && eps && z && prep && kl_partial && n_blocks_out, GAE_E_NULL, "gae_x_vgae_head_prep: NULL pointer");
     GAE_REQUIRE(gae::aligned16(mu) && gae::aligned16(logstd) && gae::aligned16(eps) && gae::aligned16(z), GAE_E_ALIGN,
-                "gae_vgae_head_prep: operands must be 16-byte aligned");
+                "gae_x_vgae_head_prep: operands must be 16-byte aligned");
     const int64_t blocks = (n + 63) / 64;
     GAE_REQUIRE(prep->DP == 16 && blocks <= prep->max_blocks && blocks <= kl_capacity && prep->Zt && prep->Zhi &&
                     prep->Zlo && prep->colsum_partial,
-                GAE_E_WORKSPACE, "gae_vgae_head_prep: layout / KL buffer too small for %lld blocks", (long long)blocks);
+                GAE_E_WORKSPACE, "gae_x_vgae_head_prep: layout / KL buffer too small for %lld blocks", (long long)blocks);
     *n_blocks_out = blocks;
     hipLaunchKernelGGL(vgae_head_prep_kernel, dim3(unsigned(blocks)), dim3(256), 0, gae::as_stream(stream), mu, logstd, ldm,
                        eps, draw_eps, seed, offset, draw_dev, n, z, prep->Zt, prep->Zhi, prep->Zlo, prep->colsum_partial,

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
                                                         const gae_bce_tail tail)
 {
     if constexpr (TAIL) {
-        // one block behind the optimiser's: the deferred final reduction of the loss (gae_adam_step_tail).  It takes
+        // one block behind the optimiser's: the deferred final reduction of the loss (gae_x_adam_step_tail).  It takes
         // no ticket: the step counter waits for the a.n_blocks optimiser blocks only.
         if (blockIdx.x == unsigned(a.n_blocks)) {
             __shared__ double red[3][16];
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
             if (e < t.n) update(e, t.grad[e], t.param[e], t.exp_avg[e], t.exp_avg_sq[e]);
         }
     } else {
-        // ---- deferred reduction: the gradient is still a list of partial sums (what gae_xw_wgrad_partials /
-        //      gae_linear_bwd_partials left in their workspace), added in the library's one order for such lists
+        // ---- deferred reduction: the gradient is still a list of partial sums (what gae_x_xw_wgrad_partials /
+        //      gae_x_linear_bwd_partials left in their workspace), added in the library's one order for such lists
         //      (gae::sum_partials: the stand-alone reduction launches give the same bits); the sum is written to
         //      `grad` and used at once.
         const int L = gae::partial_lanes(t.n_partials);
@@ -137,20 +137,20 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, float lr, fl
 
 } // namespace
 
-extern "C" int gae_adam_step_tail(const gae_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2,
+extern "C" int gae_x_adam_step_tail(const gae_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2,
                                   float eps, float weight_decay, uint64_t *state_dev, const gae_bce_tail *tail,
                                   void *stream)
 {
     const bool with_tail = tail != nullptr && tail->loss_out != nullptr;
     GAE_REQUIRE(!with_tail || (tail->S && (tail->n_dense == 0 || tail->dense_partial) &&
                                (tail->n_edge == 0 || tail->edge_partial) && tail->DP > 0),
-                GAE_E_NULL, "gae_adam_step_tail: malformed tail (not one written by gae_decoder_bce*)");
+                GAE_E_NULL, "gae_x_adam_step_tail: malformed tail (not one written by gae_decoder_bce*)");
     GAE_REQUIRE(n_tensors >= 0 && n_tensors <= kAdamMaxTensors, GAE_E_RANGE,
                 "gae_adam_step: %d tensors per call (at most %d)", n_tensors, kAdamMaxTensors);
     GAE_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f &&
                     weight_decay >= 0.f,
                 GAE_E_RANGE, "gae_adam_step: hyper-parameter out of range");
-    if (n_tensors == 0) return with_tail ? gae_decoder_bce_finalize(tail, stream) : GAE_OK;
+    if (n_tensors == 0) return with_tail ? gae_x_decoder_bce_finalize(tail, stream) : GAE_OK;
     GAE_REQUIRE(tensors && state_dev, GAE_E_NULL, "gae_adam_step: NULL pointer");
     AdamArgs a;
     memset(&a, 0, sizeof(a));
@@ -191,5 +191,5 @@ extern "C" int gae_adam_step_tail(const gae_adam_tensor *tensors, int32_t n_tens
 extern "C" int gae_adam_step(const gae_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2,
                              float eps, float weight_decay, uint64_t *state_dev, void *stream)
 {
-    return gae_adam_step_tail(tensors, n_tensors, lr, beta1, beta2, eps, weight_decay, state_dev, nullptr, stream);
+    return gae_x_adam_step_tail(tensors, n_tensors, lr, beta1, beta2, eps, weight_decay, state_dev, nullptr, stream);
 }

@@ -539,86 +539,6 @@ __global__ __launch_bounds__(256) void spmm_fill_empty_kernel(const int32_t *__r
     }
 }
 
-// ---- light-row list of a plan: deterministic compaction (ascending rows) in three launches
-constexpr int kLightRowsPerBlock = 1024;
-__device__ __forceinline__ bool is_light(const int32_t *indptr, int64_t r, int64_t n_rows, int threshold)
-{
-    if (r >= n_rows) return false;
-    const int d = indptr[r + 1] - indptr[r];
-    return d >= 1 && d <= threshold;
-}
-__global__ __launch_bounds__(256) void light_count_kernel(const int32_t *__restrict__ indptr, int64_t n_rows, int threshold,
-                                                          unsigned long long *__restrict__ block_counts,
-                                                          unsigned long long *__restrict__ total)
-{
-    const int64_t r0 = int64_t(blockIdx.x) * kLightRowsPerBlock;
-    int c = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) c += is_light(indptr, r0 + q * 256 + threadIdx.x, n_rows, threshold) ? 1 : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    __shared__ int wsum[4];
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long t = (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
-        if (block_counts) block_counts[blockIdx.x] = t;
-        if (total && t) atomicAdd(total, t);                      // integer count: order does not matter
-    }
-}
-// exclusive prefix sums of the block counts, in place (one block; n_blocks is a few ten thousand)
-__global__ __launch_bounds__(1024) void light_scan_kernel(unsigned long long *__restrict__ counts, int64_t n_blocks)
-{
-    __shared__ unsigned long long part[1024];
-    const int64_t per = (n_blocks + 1023) / 1024;
-    const int64_t b0 = int64_t(threadIdx.x) * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
-    unsigned long long sum = 0;
-    for (int64_t b = b0; b < b1; ++b) sum += counts[b];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int t = 0; t < 1024; ++t) { const unsigned long long v = part[t]; part[t] = run; run += v; }
-    }
-    __syncthreads();
-    unsigned long long run = part[threadIdx.x];
-    for (int64_t b = b0; b < b1; ++b) { const unsigned long long v = counts[b]; counts[b] = run; run += v; }
-}
-__global__ __launch_bounds__(256) void light_fill_kernel(const int32_t *__restrict__ indptr, int64_t n_rows, int threshold,
-                                                         const unsigned long long *__restrict__ block_offsets,
-                                                         int32_t *__restrict__ light_desc, int64_t n_light)
-{
-    __shared__ int wbase[4][4];
-    const int64_t r0 = int64_t(blockIdx.x) * kLightRowsPerBlock;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    bool f[4];
-    int before[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {          // rows r0 + q * 256 + tid: ascending with (q, wave, lane)
-        f[q] = is_light(indptr, r0 + q * 256 + threadIdx.x, n_rows, threshold);
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(f[q]);
-        before[q] = __builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wbase[q][wave] = __builtin_popcountll(m);
-    }
-    __syncthreads();
-    int base = 0;                          // listed rows of this block in front of (q, wave, lane 0)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int mine = base;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w < wave) mine += wbase[q][w];
-            base += wbase[q][w];
-        }
-        if (f[q]) {
-            const int64_t r = r0 + q * 256 + threadIdx.x;
-            const int64_t slot = int64_t(block_offsets[blockIdx.x]) + mine + before[q];
-            if (slot < n_light)
-                *reinterpret_cast<int4 *>(light_desc + slot * 4) = make_int4(int32_t(r), indptr[r], indptr[r + 1], 0);
-        }
-    }
-}
-
 // tuning knobs (gae_tuning_set): read-mostly process-wide integers
 gae::Knob g_spmm_variant{2};   // 1 = v1 rowgroup, 2 = v2 rowgroup2
 gae::Knob g_spmm_rpg{0};       // rows per lane group (v2): 0 = auto (2 for launches of >= 32768 waves, else 1), 1, 2
@@ -881,74 +801,6 @@ __global__ __launch_bounds__(256) void spmm_blockdiag_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------
-// Degree-skew plan (power-law graphs).  Rows with more than `threshold`
-// in-edges ("heavy") are skipped by the row-group kernel; each is cut into
-// segments of `segment_edges` edges, one wave per segment gathers its edges
-// with all 64/LPR lane groups in parallel (fixed butterfly reduction across
-// the groups), and a combine kernel adds a row's segment partials in segment
-// order.  No float atomics anywhere: the result does not depend on which wave
-// ran which segment.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void plan_count_kernel(const int32_t *__restrict__ indptr, int64_t n_rows,
-                                                         int threshold, int seg, unsigned long long *counts)
-{
-    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    unsigned long long nh = 0, ns = 0, mx = 0;
-    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
-        const int d = indptr[r + 1] - indptr[r];
-        if (d > threshold) { nh += 1; ns += (d + seg - 1) / seg; }
-        mx = max(mx, (unsigned long long)d);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        nh += __shfl_down(nh, off, 64); ns += __shfl_down(ns, off, 64);
-        mx = max(mx, (unsigned long long)__shfl_down(mx, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (nh) { atomicAdd(&counts[0], nh); atomicAdd(&counts[1], ns); }
-        atomicMax(&counts[2], mx);
-    }
-}
-
-__global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t *__restrict__ indptr, int64_t n_rows,
-                                                        int threshold, int seg, unsigned long long *cursors,
-                                                        int32_t *__restrict__ heavy_rows,
-                                                        int32_t *__restrict__ heavy_seg_base,
-                                                        int32_t *__restrict__ seg_heavy)
-{
-    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
-        const int d = indptr[r + 1] - indptr[r];
-        if (d > threshold) {
-            const int ns = (d + seg - 1) / seg;
-            const int h = int(atomicAdd(&cursors[0], 1ull));
-            const int base = int(atomicAdd(&cursors[1], (unsigned long long)ns));
-            heavy_rows[h] = int32_t(r);
-            heavy_seg_base[h] = base;
-            for (int k = 0; k < ns; ++k) seg_heavy[base + k] = h;
-        }
-    }
-}
-
-// seg_desc[s] = {row, first edge, end edge, 1 if the segment is its row's only one}
-__global__ __launch_bounds__(256) void plan_desc_kernel(const int32_t *__restrict__ indptr,
-                                                        const int32_t *__restrict__ heavy_rows,
-                                                        const int32_t *__restrict__ heavy_seg_base,
-                                                        const int32_t *__restrict__ seg_heavy, int64_t n_segments,
-                                                        int seg, int32_t *__restrict__ seg_desc)
-{
-    const int64_t sidx = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (sidx >= n_segments) return;
-    const int h = seg_heavy[sidx];
-    const int32_t row = heavy_rows[h];
-    const int k = int(sidx - heavy_seg_base[h]);
-    const int32_t r_end = indptr[row + 1];
-    const int32_t e0 = indptr[row] + k * seg;
-    const int32_t e1 = min(e0 + seg, r_end);
-    *reinterpret_cast<int4 *>(seg_desc + sidx * 4) = make_int4(row, e0, e1, (k == 0 && e1 == r_end) ? 1 : 0);
-}
-
 // one wave per segment; partial[s][0..F)
 template <typename T, int VEC, int LPR, int CH, bool SCALED>
 __global__ __launch_bounds__(256) void spmm_segment_kernel(
@@ -972,7 +824,7 @@ __global__ __launch_bounds__(256) void spmm_segment_kernel(
     // A wave of this kernel lives for a handful of memory round trips, one of which is the gather itself: the chain
     // segment -> heavy slot -> row -> edge range -> column ids in front of it set the launch time of the 9..256-edge
     // rows of RMAT s24 (2.2 M waves of ~35 edges).  Two shorter forms: the plan's 16-byte segment descriptor {row,
-    // first edge, end edge, only segment of its row} (gae_spmm_plan_desc), or -- heavy_rows == NULL -- segment s IS
+    // first edge, end edge, only segment of its row} (gae_spmm_plan_build_rows), or -- heavy_rows == NULL -- segment s IS
     // row s of the CSR handed in (the virtual rows of the XCD-pinned part).
     int64_t row;
     int32_t e0, e1;
@@ -1323,103 +1175,6 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
 
 } // namespace
 
-extern "C" int gae_spmm_plan_count(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
-                                   uint64_t *counts_dev, void *stream)
-{
-    GAE_REQUIRE(n_rows >= 0, GAE_E_SIZE, "gae_spmm_plan_count: negative n_rows");
-    GAE_REQUIRE(threshold >= 1 && segment_edges >= 64 && segment_edges % 64 == 0, GAE_E_RANGE,
-                "gae_spmm_plan_count: threshold >= 1 and segment_edges a positive multiple of 64 required");
-    GAE_REQUIRE(indptr && counts_dev, GAE_E_NULL, "gae_spmm_plan_count: NULL pointer");
-    hipStream_t s = gae::as_stream(stream);
-    GAE_HIP(hipMemsetAsync(counts_dev, 0, 3 * sizeof(uint64_t), s));
-    if (n_rows == 0) return GAE_OK;
-    int64_t g = (n_rows + 255) / 256;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(plan_count_kernel, dim3(unsigned(g)), dim3(256), 0, s, indptr, n_rows, threshold, segment_edges,
-                       reinterpret_cast<unsigned long long *>(counts_dev));
-    GAE_CHECK_LAUNCH("plan_count_kernel");
-    return GAE_OK;
-}
-
-extern "C" int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
-                                  uint64_t *cursors_dev, int32_t *heavy_rows, int32_t *heavy_seg_base,
-                                  int32_t *seg_heavy, void *stream)
-{
-    GAE_REQUIRE(n_rows >= 0, GAE_E_SIZE, "gae_spmm_plan_fill: negative n_rows");
-    GAE_REQUIRE(threshold >= 1 && segment_edges >= 64 && segment_edges % 64 == 0, GAE_E_RANGE,
-                "gae_spmm_plan_fill: threshold >= 1 and segment_edges a positive multiple of 64 required");
-    GAE_REQUIRE(indptr && cursors_dev && heavy_rows && heavy_seg_base && seg_heavy, GAE_E_NULL,
-                "gae_spmm_plan_fill: NULL pointer");
-    hipStream_t s = gae::as_stream(stream);
-    GAE_HIP(hipMemsetAsync(cursors_dev, 0, 2 * sizeof(uint64_t), s));
-    if (n_rows == 0) return GAE_OK;
-    int64_t g = (n_rows + 255) / 256;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(plan_fill_kernel, dim3(unsigned(g)), dim3(256), 0, s, indptr, n_rows, threshold, segment_edges,
-                       reinterpret_cast<unsigned long long *>(cursors_dev), heavy_rows, heavy_seg_base, seg_heavy);
-    GAE_CHECK_LAUNCH("plan_fill_kernel");
-    return GAE_OK;
-}
-
-extern "C" int gae_spmm_plan_light_count(const int32_t *indptr, int64_t n_rows, int32_t threshold, uint64_t *count_dev,
-                                         void *stream)
-{
-    GAE_REQUIRE(n_rows >= 0 && threshold >= 1, GAE_E_SIZE, "gae_spmm_plan_light_count: bad size");
-    GAE_REQUIRE(count_dev != nullptr, GAE_E_NULL, "gae_spmm_plan_light_count: NULL pointer");
-    hipStream_t s = gae::as_stream(stream);
-    GAE_HIP(hipMemsetAsync(count_dev, 0, sizeof(uint64_t), s));
-    if (n_rows == 0) return GAE_OK;
-    GAE_REQUIRE(indptr != nullptr, GAE_E_NULL, "gae_spmm_plan_light_count: NULL pointer");
-    const int64_t nb = (n_rows + kLightRowsPerBlock - 1) / kLightRowsPerBlock;
-    hipLaunchKernelGGL(light_count_kernel, dim3(unsigned(nb)), dim3(256), 0, s, indptr, n_rows, int(threshold), nullptr,
-                       reinterpret_cast<unsigned long long *>(count_dev));
-    GAE_CHECK_LAUNCH("light_count_kernel");
-    return GAE_OK;
-}
-
-extern "C" int64_t gae_spmm_plan_light_workspace_bytes(int64_t n_rows)
-{
-    if (n_rows < 0) return GAE_E_SIZE;
-    return ((n_rows + kLightRowsPerBlock - 1) / kLightRowsPerBlock + 1) * 8 + 256;
-}
-
-extern "C" int gae_spmm_plan_light(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t *light_desc,
-                                   int64_t n_light, void *workspace, int64_t workspace_bytes, void *stream)
-{
-    GAE_REQUIRE(n_rows >= 0 && threshold >= 1 && n_light >= 0, GAE_E_SIZE, "gae_spmm_plan_light: bad size");
-    if (n_rows == 0 || n_light == 0) return GAE_OK;
-    GAE_REQUIRE(indptr && light_desc && workspace, GAE_E_NULL, "gae_spmm_plan_light: NULL pointer");
-    GAE_REQUIRE(gae::aligned16(light_desc) && gae::aligned16(workspace) &&
-                    workspace_bytes >= gae_spmm_plan_light_workspace_bytes(n_rows), GAE_E_WORKSPACE,
-                "gae_spmm_plan_light: workspace too small or buffers not 16-byte aligned");
-    hipStream_t s = gae::as_stream(stream);
-    unsigned long long *bc = static_cast<unsigned long long *>(workspace);
-    const int64_t nb = (n_rows + kLightRowsPerBlock - 1) / kLightRowsPerBlock;
-    hipLaunchKernelGGL(light_count_kernel, dim3(unsigned(nb)), dim3(256), 0, s, indptr, n_rows, int(threshold), bc, nullptr);
-    hipLaunchKernelGGL(light_scan_kernel, dim3(1), dim3(1024), 0, s, bc, nb);
-    hipLaunchKernelGGL(light_fill_kernel, dim3(unsigned(nb)), dim3(256), 0, s, indptr, n_rows, int(threshold), bc, light_desc,
-                       n_light);
-    GAE_CHECK_LAUNCH("light_fill_kernel");
-    return GAE_OK;
-}
-
-extern "C" int gae_spmm_plan_desc(const int32_t *indptr, const int32_t *heavy_rows, const int32_t *heavy_seg_base,
-                                  const int32_t *seg_heavy, int64_t n_segments, int32_t segment_edges,
-                                  int32_t *seg_desc, void *stream)
-{
-    GAE_REQUIRE(n_segments >= 0, GAE_E_SIZE, "gae_spmm_plan_desc: negative n_segments");
-    GAE_REQUIRE(segment_edges >= 64 && segment_edges % 64 == 0, GAE_E_RANGE,
-                "gae_spmm_plan_desc: segment_edges must be a positive multiple of 64");
-    if (n_segments == 0) return GAE_OK;
-    GAE_REQUIRE(indptr && heavy_rows && heavy_seg_base && seg_heavy && seg_desc, GAE_E_NULL,
-                "gae_spmm_plan_desc: NULL pointer");
-    GAE_REQUIRE(gae::aligned16(seg_desc), GAE_E_ALIGN, "gae_spmm_plan_desc: seg_desc not 16-byte aligned");
-    hipLaunchKernelGGL(plan_desc_kernel, dim3(unsigned((n_segments + 255) / 256)), dim3(256), 0, gae::as_stream(stream),
-                       indptr, heavy_rows, heavy_seg_base, seg_heavy, n_segments, segment_edges, seg_desc);
-    GAE_CHECK_LAUNCH("plan_desc_kernel");
-    return GAE_OK;
-}
-
 extern "C" int gae_spmm_ell_build(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t width,
                                   int32_t skip_degree, int32_t *ell, void *stream)
 {
@@ -1600,52 +1355,7 @@ extern "C" int gae_spmm_csr_blockdiag(const int32_t *indptr, const int32_t *indi
 
 // ---- hot-column tags of a plan: how often every column is gathered, and the ids with the sign bit on the hot ones
 namespace {
-__global__ __launch_bounds__(256) void col_freq_kernel(const int32_t *__restrict__ indices, int64_t n_edges,
-                                                       int32_t *__restrict__ freq)
-{
-    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < n_edges; e += int64_t(gridDim.x) * 256)
-        atomicAdd(&freq[indices[e]], 1);            // integer counts: the result does not depend on the order
-}
-__global__ __launch_bounds__(256) void tag_hot_kernel(const int32_t *__restrict__ indices, int64_t n_edges,
-                                                      const int32_t *__restrict__ freq, int32_t min_freq,
-                                                      int32_t *__restrict__ out)
-{
-    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < n_edges; e += int64_t(gridDim.x) * 256) {
-        const int32_t j = indices[e];
-        out[e] = freq[j] >= min_freq ? int32_t(unsigned(j) | 0x80000000u) : j;
-    }
-}
 } // namespace
-
-extern "C" int gae_spmm_col_freq(const int32_t *indices, int64_t n_edges, int64_t n_cols, int32_t *freq_out,
-                                 void *stream)
-{
-    GAE_REQUIRE(n_edges >= 0 && n_cols >= 0, GAE_E_SIZE, "gae_spmm_col_freq: negative size");
-    hipStream_t s = gae::as_stream(stream);
-    if (n_cols == 0) return GAE_OK;
-    GAE_REQUIRE(freq_out != nullptr, GAE_E_NULL, "gae_spmm_col_freq: freq_out is NULL");
-    GAE_HIP(hipMemsetAsync(freq_out, 0, size_t(n_cols) * sizeof(int32_t), s));
-    if (n_edges == 0) return GAE_OK;
-    GAE_REQUIRE(indices != nullptr, GAE_E_NULL, "gae_spmm_col_freq: indices is NULL");
-    const int64_t want = (n_edges + 255) / 256;
-    hipLaunchKernelGGL(col_freq_kernel, dim3(unsigned(want < 65536 ? want : 65536)), dim3(256), 0, s, indices, n_edges,
-                       freq_out);
-    GAE_CHECK_LAUNCH("col_freq_kernel");
-    return GAE_OK;
-}
-
-extern "C" int gae_spmm_tag_hot(const int32_t *indices, int64_t n_edges, const int32_t *col_freq, int32_t min_freq,
-                                int32_t *hot_indices_out, void *stream)
-{
-    GAE_REQUIRE(n_edges >= 0, GAE_E_SIZE, "gae_spmm_tag_hot: negative size");
-    if (n_edges == 0) return GAE_OK;
-    GAE_REQUIRE(indices && col_freq && hot_indices_out, GAE_E_NULL, "gae_spmm_tag_hot: NULL pointer");
-    const int64_t want = (n_edges + 255) / 256;
-    hipLaunchKernelGGL(tag_hot_kernel, dim3(unsigned(want < 65536 ? want : 65536)), dim3(256), 0,
-                       gae::as_stream(stream), indices, n_edges, col_freq, min_freq, hot_indices_out);
-    GAE_CHECK_LAUNCH("tag_hot_kernel");
-    return GAE_OK;
-}
 
 namespace gae { Knob *dense_knob(const char *name); Knob *bce_knob(const char *name); Knob *xw_knob(const char *name); Knob *optim_knob(const char *name); }
 

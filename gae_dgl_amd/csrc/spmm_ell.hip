@@ -118,7 +118,7 @@ struct Vec16<unsigned short> {   // bf16 storage, fp32 accumulation
 }  // namespace
 namespace gae {
 gae::Knob g_spmm_ell_rpg{0};      // rows per lane group of the ell kernels: 0 = auto (1)
-// "ell_side": how the side work of the fused layer (gae_gcn_layer_fused_wgrad) forms its outer product.  Bit 3: MFMA
+// "ell_side": how the side work of the fused layer (gae_x_gcn_layer_fused_wgrad) forms its outer product.  Bit 3: MFMA
 // operands straight from global memory, no LDS, no barrier, when the output is at most 4 tiles of 16 x 16 (Pubmed:
 // launch 9.0 us; gather alone 7.5); bit 2: on the matrix cores from LDS tiles (9.6 us; the form for larger outputs);
 // neither: scalar LDS loop (10.4 us); bit 1: tile loads without a division per element (off: 11.9 us).  Default: all.
@@ -152,11 +152,11 @@ struct EllArgs {
     // split order -- the value the stand-alone split reduction would have stored, without that launch
     int n_splits;
     unsigned split_bytes, empty_off;   // empty_off: byte offset of an empty table slot (behind every operand)
-    // two-matrix form of the fused layer (gae_gcn_layer_fused2): stored rows >= w_split of the weight come from W2
+    // two-matrix form of the fused layer (gae_x_gcn_layer_fused2): stored rows >= w_split of the weight come from W2
     // (same strides), outputs >= w_split of the bias from bias2 -- two heads on one aggregate, one launch
     const float *W2, *bias2;
     int w_split, w_t;             // w_t: W is addressed transposed (the stored row is the input index k, not the output o)
-    // side work of a fused-layer launch on the block's OWN rows (gae_gcn_layer_fused_wgrad): the weight gradient of the
+    // side work of a fused-layer launch on the block's OWN rows (gae_x_gcn_layer_fused_wgrad): the weight gradient of the
     // layer whose backward this launch is, sw_part[block][o][i] = sum over the block's rows r of P[r][o] Q[r][i]
     // (P = the gathered operand dY, Q = the forward's stored aggregate) and, behind it, the column sums of P (db) --
     // per-block partial sums in row order, added up later (gae_adam_step's deferred reduction or a reduction launch)
@@ -164,7 +164,7 @@ struct EllArgs {
     float *sw_part;
     int64_t sw_ldp, sw_ldq, sw_stride;
     int sw_O, sw_I, sw_variant;
-    // prepare step of the fused loss in the epilogue of the layer that produces Z (gae_gcn_layer_fused_prep, EPI_J =
+    // prepare step of the fused loss in the epilogue of the layer that produces Z (gae_x_gcn_layer_fused_prep, EPI_J =
     // 16): Zt = Y (.) dropout mask padded to 16 columns, its bf16 hi / lo, per-block fp64 column sums -- what
     // bce_prepare_kernel (decoder_bce.hip) computes from the stored Z
     float *pz_t;
@@ -891,16 +891,16 @@ extern "C" int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices
 // stack [W; W2] along its STORED rows (both matrices share the strides; w_split rows belong to W), the bias [b; b2].
 // Forward (w_transposed = 0): Y[:, :w_split] = act(M W^T + b), Y[:, w_split:] = act(M W2^T + b2).  Backward of
 // identity heads (w_transposed = 1, strides swapped as in gae_gcn_layer_fused): dH = (A^T dY) [W; W2].
-extern "C" int gae_gcn_layer_fused2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+extern "C" int gae_x_gcn_layer_fused2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                                     const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
                                     const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
                                     const float *W, const float *W2, int64_t w_split, int w_transposed,
                                     int64_t w_stride_out, int64_t w_stride_in, const float *bias, const float *bias2,
                                     int64_t J, int act, float *Y, int64_t ldy, void *stream)
 {
-    GAE_REQUIRE(W2 != nullptr && w_split >= 1, GAE_E_NULL, "gae_gcn_layer_fused2: W2 / w_split missing");
-    GAE_REQUIRE(w_split < (w_transposed ? F : J), GAE_E_RANGE, "gae_gcn_layer_fused2: w_split outside the stacked rows");
-    GAE_REQUIRE((bias == nullptr) == (bias2 == nullptr), GAE_E_NULL, "gae_gcn_layer_fused2: give both biases or none");
+    GAE_REQUIRE(W2 != nullptr && w_split >= 1, GAE_E_NULL, "gae_x_gcn_layer_fused2: W2 / w_split missing");
+    GAE_REQUIRE(w_split < (w_transposed ? F : J), GAE_E_RANGE, "gae_x_gcn_layer_fused2: w_split outside the stacked rows");
+    GAE_REQUIRE((bias == nullptr) == (bias2 == nullptr), GAE_E_NULL, "gae_x_gcn_layer_fused2: give both biases or none");
     return gcn_layer_fused_impl(indptr, indices, n_rows, n_cols, H, ldh, M, ldm, F, row_scale, col_scale, plan, W,
                                 w_stride_out, w_stride_in, bias, J, act, Y, ldy, W2, bias2, w_split, w_transposed, stream);
 }
@@ -964,8 +964,8 @@ static int gcn_layer_fused_impl(const int32_t *indptr, const int32_t *indices, i
 }
 
 // gae_gcn_layer_fused on the LAST encoder layer of a training step, with the prepare step of the fused loss in its
-// epilogue (see gae_decoder_bce_prep_layout in include/gae_hip.h).
-extern "C" int gae_gcn_layer_fused_prep(const int32_t *indptr, const int32_t *indices, int64_t n, const float *H,
+// epilogue (see gae_x_decoder_bce_prep_layout in include/gae_hip.h).
+extern "C" int gae_x_gcn_layer_fused_prep(const int32_t *indptr, const int32_t *indices, int64_t n, const float *H,
                                         int64_t ldh, float *M, int64_t ldm, int64_t F, const float *row_scale,
                                         const float *col_scale, const gae_spmm_plan *plan, const float *W,
                                         int64_t w_stride_out, int64_t w_stride_in, const float *bias, int64_t J,
@@ -973,16 +973,16 @@ extern "C" int gae_gcn_layer_fused_prep(const int32_t *indptr, const int32_t *in
                                         float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *draw_dev,
                                         const int64_t *counts_dev, int64_t *n_prep_blocks_out, void *stream)
 {
-    GAE_REQUIRE(prep && n_prep_blocks_out, GAE_E_NULL, "gae_gcn_layer_fused_prep: NULL pointer");
+    GAE_REQUIRE(prep && n_prep_blocks_out, GAE_E_NULL, "gae_x_gcn_layer_fused_prep: NULL pointer");
     GAE_REQUIRE(J >= 1 && J <= 16 && prep->DP == 16, GAE_E_RANGE,
-                "gae_gcn_layer_fused_prep: the embedding must be at most 16 wide (got %lld)", (long long)J);
-    GAE_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GAE_E_RANGE, "gae_gcn_layer_fused_prep: dropout_p outside [0, 1)");
-    GAE_REQUIRE(dropout_p == 0.f || mask, GAE_E_NULL, "gae_gcn_layer_fused_prep: dropout_p > 0 needs the mask output buffer");
-    GAE_REQUIRE(!mask || ldmask >= J, GAE_E_SIZE, "gae_gcn_layer_fused_prep: ldmask < J");
-    GAE_REQUIRE(n >= 1, GAE_E_SIZE, "gae_gcn_layer_fused_prep: empty graph");
+                "gae_x_gcn_layer_fused_prep: the embedding must be at most 16 wide (got %lld)", (long long)J);
+    GAE_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GAE_E_RANGE, "gae_x_gcn_layer_fused_prep: dropout_p outside [0, 1)");
+    GAE_REQUIRE(dropout_p == 0.f || mask, GAE_E_NULL, "gae_x_gcn_layer_fused_prep: dropout_p > 0 needs the mask output buffer");
+    GAE_REQUIRE(!mask || ldmask >= J, GAE_E_SIZE, "gae_x_gcn_layer_fused_prep: ldmask < J");
+    GAE_REQUIRE(n >= 1, GAE_E_SIZE, "gae_x_gcn_layer_fused_prep: empty graph");
     const int64_t rpb = (F + 3) / 4 <= 8 ? 32 : 16, blocks = (n + rpb - 1) / rpb;
     GAE_REQUIRE(blocks <= prep->max_blocks && prep->Zt && prep->Zhi && prep->Zlo && prep->colsum_partial, GAE_E_WORKSPACE,
-                "gae_gcn_layer_fused_prep: layout not from gae_decoder_bce_prep_layout for this n");
+                "gae_x_gcn_layer_fused_prep: layout not from gae_x_decoder_bce_prep_layout for this n");
     *n_prep_blocks_out = blocks;
     FusedPrep fp{prep, mask, ldmask, dropout_p, seed, offset, draw_dev, counts_dev};
     return gcn_layer_fused_impl(indptr, indices, n, n, H, ldh, M, ldm, F, row_scale, col_scale, plan, W, w_stride_out,
@@ -994,7 +994,7 @@ extern "C" int gae_gcn_layer_fused_prep(const int32_t *indptr, const int32_t *in
 // dW = dY^T M and db = colsum(dY) (M = the aggregate the forward stored).  rows per block: 32 (F <= 32) or 16.
 static int64_t fused_wgrad_blocks(int64_t n_rows, int64_t F) { const int64_t rpb = (F + 3) / 4 <= 8 ? 32 : 16; return (n_rows + rpb - 1) / rpb; }
 
-extern "C" int64_t gae_gcn_layer_fused_wgrad_workspace_bytes(int64_t n_rows, int64_t F, int64_t I)
+extern "C" int64_t gae_x_gcn_layer_fused_wgrad_workspace_bytes(int64_t n_rows, int64_t F, int64_t I)
 {
     if (n_rows < 0 || F < 1 || F > 32 || I < 1 || I > 64) return GAE_E_SIZE;
     return fused_wgrad_blocks(n_rows, F) * (F * I + F) * 4 + 256;
@@ -1007,17 +1007,17 @@ static int fused_wgrad_impl(const int32_t *t_indptr, const int32_t *t_indices, i
                             int64_t workspace_bytes, int64_t *layout_out, void *stream)
 {
     GAE_REQUIRE(F >= 1 && F <= 32 && I >= 1 && I <= 32, GAE_E_RANGE,
-                "gae_gcn_layer_fused_wgrad: needs 1 <= f_out <= 32 and 1 <= f_in <= 32 (got %lld, %lld)", (long long)F,
+                "gae_x_gcn_layer_fused_wgrad: needs 1 <= f_out <= 32 and 1 <= f_in <= 32 (got %lld, %lld)", (long long)F,
                 (long long)I);
-    const int64_t need = gae_gcn_layer_fused_wgrad_workspace_bytes(n, F, I);
-    GAE_REQUIRE(need >= 0, GAE_E_SIZE, "gae_gcn_layer_fused_wgrad: negative size");
+    const int64_t need = gae_x_gcn_layer_fused_wgrad_workspace_bytes(n, F, I);
+    GAE_REQUIRE(need >= 0, GAE_E_SIZE, "gae_x_gcn_layer_fused_wgrad: negative size");
     const int64_t blocks = fused_wgrad_blocks(n, F), stride = F * I + F;
     if (layout_out) { layout_out[0] = blocks; layout_out[1] = stride; layout_out[2] = F * I; }
     if (n == 0) return GAE_OK;
     GAE_REQUIRE(M && workspace && workspace_bytes >= need && gae::aligned16(workspace), GAE_E_WORKSPACE,
-                "gae_gcn_layer_fused_wgrad: M / workspace missing or smaller than %lld bytes", (long long)need);
-    GAE_REQUIRE(ldm >= I && ldw >= I && lddy >= F, GAE_E_SIZE, "gae_gcn_layer_fused_wgrad: leading dimension too small");
-    GAE_REQUIRE(!W2 || (w_split >= 1 && w_split < F), GAE_E_RANGE, "gae_gcn_layer_fused2_wgrad: w_split outside (0, f_out)");
+                "gae_x_gcn_layer_fused_wgrad: M / workspace missing or smaller than %lld bytes", (long long)need);
+    GAE_REQUIRE(ldm >= I && ldw >= I && lddy >= F, GAE_E_SIZE, "gae_x_gcn_layer_fused_wgrad: leading dimension too small");
+    GAE_REQUIRE(!W2 || (w_split >= 1 && w_split < F), GAE_E_RANGE, "gae_x_gcn_layer_fused2_wgrad: w_split outside (0, f_out)");
     FusedSide side{dY, M, static_cast<float *>(workspace), lddy, ldm, stride, int(F), int(I)};
     // W [F][I] as nn.Linear stores it is the transposed weight of this launch: output j <- W[k][j]
     int rc = gcn_layer_fused_impl(t_indptr, t_indices, n, n, dY, lddy, nullptr, 0, F, row_scale, col_scale, plan_t, W, 1,
@@ -1031,7 +1031,7 @@ static int fused_wgrad_impl(const int32_t *t_indptr, const int32_t *t_indices, i
     return gae::launch_partials_reduce(la, lb, gae::as_stream(stream));
 }
 
-extern "C" int gae_gcn_layer_fused_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
+extern "C" int gae_x_gcn_layer_fused_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
                                          int64_t lddy, int64_t F, const float *row_scale, const float *col_scale,
                                          const gae_spmm_plan *plan_t, const float *W, int64_t ldw, int64_t I, float *dH,
                                          int64_t lddh, const float *M, int64_t ldm, float *dW, float *db,
@@ -1041,17 +1041,17 @@ extern "C" int gae_gcn_layer_fused_wgrad(const int32_t *t_indptr, const int32_t 
                             lddh, M, ldm, dW, db, workspace, workspace_bytes, layout_out, stream);
 }
 
-// ... of gae_gcn_layer_fused2 (two identity heads on one aggregate): dY = [dY1 | dY2] ([n, f_out], f_out = d1 + d2),
+// ... of gae_x_gcn_layer_fused2 (two identity heads on one aggregate): dY = [dY1 | dY2] ([n, f_out], f_out = d1 + d2),
 // the weight is the stack [W; W2] along its stored rows (w_split = d1 rows in W, same ldw), dW [f_out, f_in] stacked
 // alike (rows < w_split = dW1), db [f_out].
-extern "C" int gae_gcn_layer_fused2_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
+extern "C" int gae_x_gcn_layer_fused2_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
                                           int64_t lddy, int64_t F, const float *row_scale, const float *col_scale,
                                           const gae_spmm_plan *plan_t, const float *W, const float *W2, int64_t w_split,
                                           int64_t ldw, int64_t I, float *dH, int64_t lddh, const float *M, int64_t ldm,
                                           float *dW, float *db, void *workspace, int64_t workspace_bytes,
                                           int64_t *layout_out, void *stream)
 {
-    GAE_REQUIRE(W2 != nullptr, GAE_E_NULL, "gae_gcn_layer_fused2_wgrad: W2 is NULL");
+    GAE_REQUIRE(W2 != nullptr, GAE_E_NULL, "gae_x_gcn_layer_fused2_wgrad: W2 is NULL");
     return fused_wgrad_impl(t_indptr, t_indices, n, dY, lddy, F, row_scale, col_scale, plan_t, W, W2, w_split, ldw, I, dH,
                             lddh, M, ldm, dW, db, workspace, workspace_bytes, layout_out, stream);
 }

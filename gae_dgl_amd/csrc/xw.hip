@@ -729,23 +729,23 @@ extern "C" int gae_xw_wgrad(const void *X, int64_t ldx, int dtype, int64_t n, in
                            workspace, workspace_bytes, gae::as_stream(stream));
 }
 
-extern "C" int gae_xw_wgrad_partials(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in, const float *G,
+extern "C" int gae_x_xw_wgrad_partials(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in, const float *G,
                                      int64_t ldg, const float *Gmask, int64_t ldgm, const float *D, int64_t ldd,
                                      const float *Dmask, int64_t lddm, int64_t f_out, int want_dW, int want_db,
                                      void *workspace, int64_t workspace_bytes, int64_t *layout_out, void *stream)
 {
-    GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16, GAE_E_DTYPE, "gae_xw_wgrad_partials: dtype %d", dtype);
-    GAE_REQUIRE(n > 0 && f_in > 0 && f_out > 0 && layout_out, GAE_E_SIZE, "gae_xw_wgrad_partials: bad sizes");
-    GAE_REQUIRE(want_dW || want_db, GAE_E_RANGE, "gae_xw_wgrad_partials: nothing to compute");
-    GAE_REQUIRE(!want_dW || (X && G && ldg >= f_out), GAE_E_NULL, "gae_xw_wgrad_partials: dW needs X and G");
-    GAE_REQUIRE(!Gmask || ldgm >= f_out, GAE_E_SIZE, "gae_xw_wgrad_partials: ldgm < f_out");
-    GAE_REQUIRE(!want_db || (D && ldd >= f_out && (!Dmask || lddm >= f_out)), GAE_E_NULL, "gae_xw_wgrad_partials: db needs D");
+    GAE_REQUIRE(dtype == GAE_F32 || dtype == GAE_BF16, GAE_E_DTYPE, "gae_x_xw_wgrad_partials: dtype %d", dtype);
+    GAE_REQUIRE(n > 0 && f_in > 0 && f_out > 0 && layout_out, GAE_E_SIZE, "gae_x_xw_wgrad_partials: bad sizes");
+    GAE_REQUIRE(want_dW || want_db, GAE_E_RANGE, "gae_x_xw_wgrad_partials: nothing to compute");
+    GAE_REQUIRE(!want_dW || (X && G && ldg >= f_out), GAE_E_NULL, "gae_x_xw_wgrad_partials: dW needs X and G");
+    GAE_REQUIRE(!Gmask || ldgm >= f_out, GAE_E_SIZE, "gae_x_xw_wgrad_partials: ldgm < f_out");
+    GAE_REQUIRE(!want_db || (D && ldd >= f_out && (!Dmask || lddm >= f_out)), GAE_E_NULL, "gae_x_xw_wgrad_partials: db needs D");
     const int elem = dtype == GAE_F32 ? 4 : 2;
     GAE_REQUIRE(!want_dW || gae::xw_usable(X, ldx, n, f_in, f_out, elem), GAE_E_RANGE,
-                "gae_xw_wgrad_partials: operand not accepted (gae_xw_usable)");
+                "gae_x_xw_wgrad_partials: operand not accepted (gae_xw_usable)");
     GAE_REQUIRE(n * ldg * 4 < int64_t(0xE0000000u) && (!Gmask || n * ldgm * 4 < int64_t(0xE0000000u)), GAE_E_SIZE,
-                "gae_xw_wgrad_partials: G larger than a raw buffer resource addresses");
-    GAE_REQUIRE(workspace && gae::aligned16(workspace), GAE_E_ALIGN, "gae_xw_wgrad_partials: workspace missing or unaligned");
+                "gae_x_xw_wgrad_partials: G larger than a raw buffer resource addresses");
+    GAE_REQUIRE(workspace && gae::aligned16(workspace), GAE_E_ALIGN, "gae_x_xw_wgrad_partials: workspace missing or unaligned");
     float flag = 0.f;           // any non-NULL pointer: xtg_launch only tests dW / db for NULL in this mode
     return gae::xtg_launch(X, ldx, n, int(f_in), elem, G, ldg, Gmask, ldgm, D, ldd, Dmask, lddm, int(f_out),
                            want_dW ? &flag : nullptr, f_in, want_db ? &flag : nullptr, workspace, workspace_bytes,

@@ -5,6 +5,7 @@ hand-written HIP kernels from libgae_hip.so on PyTorch's current HIP stream.
 There is no CPU / eager fallback -- a CPU tensor raises."""
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -119,76 +120,153 @@ def _dtype_code(t):
 
 _WS_CACHE = {}
 
-# ------------------------------------------------------------------ deferred gradient reductions
-# Inside ``with deferred_grad_reductions():`` the weight-gradient kernels (gae_xw_wgrad, gae_linear_bwd) leave their
-# per-block partial sums in a private workspace and return UNINITIALISED gradient tensors; gae_dgl_amd.optim.Adam
-# looks every gradient up here, adds its partials inside the optimiser launch (gae_adam_step's deferred reduction)
-# and writes the sum to the gradient tensor.  Two reduction launches less per training step (~5 us each on an
-# MI355X: 4 % of a Pubmed step, 10 % of a Cora or a batch-128 ZINC step).  Only for loops in which that optimiser's
-# step() follows the backward pass directly (capture.CapturedTrainStep / CapturedInductiveStep switch it on for
-# themselves); anything that reads .grad in between would read garbage.
-_DEFER = False
-_PENDING = {}       # grad.data_ptr() -> (keep-alive workspace, partials ptr, n_partials, partial_stride, row_len, row_pitch)
+# ------------------------------------------------------------------ the step context
+# What ONE training step holds between its backward pass and its optimiser launch.  Two things can be left to the
+# optimiser launch of gae_dgl_amd.optim.Adam (round 3: 3 launches less per captured step):
+#   defer_grads  the weight-gradient kernels (gae_xw_wgrad, gae_linear_bwd, the fused layers' side work, gae_gcn2_bwd_dense)
+#                leave their per-block partial sums in a private workspace and return UNINITIALISED gradient tensors; the
+#                optimiser looks every gradient up in the context, adds its partials inside its launch (gae_adam_step's
+#                deferred reduction) and writes the sum to the gradient tensor.  Only for steps in which that optimiser's
+#                step() follows the backward pass directly: anything reading .grad in between reads garbage.
+#   defer_loss   the fused loss (decoder_bce_raw) leaves its last launch -- the reduction of the per-block partial sums
+#                to the scalar, which the backward pass does not read -- to the optimiser launch (gae_x_adam_step_tail).  The
+#                returned loss tensor is filled only then.  A reduction nobody took is launched when the context closes.
+# The context also carries the request of the loss's prepare step (loss_prepare_request).
+#
+# The state lives in the StepContext OBJECT that the step's owner opens (capture.CapturedTrainStep /
+# CapturedInductiveStep per step; ``with ops.StepContext(...)`` / deferred_grad_reductions() in a hand-written loop) -- not
+# in module-level tables: two models whose steps interleave each see their own partial sums, and nothing outlives its
+# step.
+# Inside a context a gradient is found by the address of its storage; the context keeps the tensor alive until the
+# optimiser took the entry (or the context closed), so the address cannot be handed out again while the entry exists.
+class StepContext:
+    def __init__(self, defer_grads=False, defer_loss=False):
+        self.defer_grads, self.defer_loss = bool(defer_grads), bool(defer_loss)
+        self.partials = {}      # storage address -> (gradient tensor, (keep-alive workspace, partials ptr, n_partials,
+        #                                              partial_stride, row_len, row_pitch))
+        self.tails = []         # [(BceTail, keep-alive tensors)]
+        self.prep_req = None
+        self._outer = None
+        self._flags = None
 
+    # -- used by the kernels' wrappers
+    def add_partials(self, grad, entry):
+        self.partials[grad.data_ptr()] = (grad, entry)
 
-class deferred_grad_reductions:
+    def take_partials(self, grad):
+        ent = self.partials.pop(grad.data_ptr(), None) if self.partials else None
+        return None if ent is None else ent[1]
+
+    def take_loss_tail(self):
+        return self.tails.pop() if self.tails else None
+
+    def flush_loss_tails(self):
+        while self.tails:
+            tail, keep = self.tails.pop()
+            with _on_device(keep[0].device):
+                _lib.call("gae_x_decoder_bce_finalize", ctypes.byref(tail), _stream())
+
+    # -- scope
     def __enter__(self):
-        global _DEFER
-        self.prev, _DEFER = _DEFER, True
+        stack = _step_stack()
+        if stack:
+            # a context opened inside another one JOINS it (same step): it shares the outer tables and adds its flags
+            # for its own duration
+            outer = stack[-1]
+            self._outer = outer
+            self._flags = (outer.defer_grads, outer.defer_loss)
+            outer.defer_grads |= self.defer_grads
+            outer.defer_loss |= self.defer_loss
+            stack.append(outer)
+            return outer
+        stack.append(self)
         return self
 
     def __exit__(self, *exc):
-        global _DEFER
-        _DEFER = self.prev
-        if not _DEFER and _PENDING:
-            n = len(_PENDING)
-            _PENDING.clear()
-            if exc[0] is None:
-                raise GaeHipError(f"{n} gradient(s) were left as partial sums: deferred_grad_reductions() needs "
+        stack = _step_stack()
+        top = stack.pop()
+        if self._outer is not None:
+            top.defer_grads, top.defer_loss = self._flags
+            self._outer = self._flags = None
+            if not top.defer_grads and top.partials and exc[0] is None:
+                n = len(top.partials)
+                top.partials.clear()
+                raise GaeHipError(f"{n} gradient(s) were left as partial sums: deferred gradient reductions need "
                                   "gae_dgl_amd.optim.Adam.step() inside the block, after the backward pass")
+            if not top.defer_loss and exc[0] is None:
+                top.flush_loss_tails()
+            return
+        n = len(self.partials)
+        self.partials.clear()
+        if exc[0] is None:
+            self.flush_loss_tails()
+            if n:
+                raise GaeHipError(f"{n} gradient(s) were left as partial sums: deferred gradient reductions need "
+                                  "gae_dgl_amd.optim.Adam.step() inside the block, after the backward pass")
+        else:
+            self.tails.clear()
 
 
-# Inside ``with deferred_loss_finalize():`` the fused loss (decoder_bce_raw) leaves its last launch -- the reduction of
-# the per-block partial sums to the scalar, which the backward pass does not read -- to gae_dgl_amd.optim.Adam.step(),
-# whose launch runs it as one extra block (gae_adam_step_tail).  The returned loss tensor is filled only then.  A
-# reduction nobody took (no optimiser step, a second loss call) is launched on its own.
-_DEFER_LOSS = False
-_PENDING_TAIL = []  # [(BceTail, keep-alive tensors)]
+# The stack of open contexts is process-wide, not thread-local: autograd executes the backward nodes of a step on its
+# own worker thread (one per device), and those nodes must find the context the training loop's thread opened.  One
+# training step is in flight per process at a time (a second thread that trains concurrently needs its own process,
+# like its own GPU).
+_STEP_STACK = []
+_STEP_LOCK = threading.Lock()
+_NO_STEP = StepContext()           # outside every context: nothing is deferred (only the prepare request of an eager
+#                                    step passes through it)
 
 
-def _flush_loss_tail():
-    while _PENDING_TAIL:
-        tail, keep = _PENDING_TAIL.pop()
-        with _on_device(keep[0].device):
-            _lib.call("gae_decoder_bce_finalize", ctypes.byref(tail), _stream())
+class _StackView:
+    """push / pop under the lock (reads of the top need none: list indexing is atomic in CPython)"""
+
+    def __bool__(self):
+        return bool(_STEP_STACK)
+
+    def __getitem__(self, i):
+        return _STEP_STACK[i]
+
+    def append(self, x):
+        with _STEP_LOCK:
+            _STEP_STACK.append(x)
+
+    def pop(self):
+        with _STEP_LOCK:
+            return _STEP_STACK.pop()
 
 
-class deferred_loss_finalize:
-    def __enter__(self):
-        global _DEFER_LOSS
-        self.prev, _DEFER_LOSS = _DEFER_LOSS, True
-        return self
+def _step_stack():
+    return _StackView()
 
-    def __exit__(self, *exc):
-        global _DEFER_LOSS
-        _DEFER_LOSS = self.prev
-        if not _DEFER_LOSS:
-            if exc[0] is None:
-                _flush_loss_tail()
-            else:
-                _PENDING_TAIL.clear()
+
+def current_step():
+    """the innermost open StepContext (one that defers nothing when there is none)"""
+    try:
+        return _STEP_STACK[-1]
+    except IndexError:
+        return _NO_STEP
+
+
+def deferred_grad_reductions():
+    """``with ops.deferred_grad_reductions():`` = a StepContext that defers the weight gradients' reductions"""
+    return StepContext(defer_grads=True)
+
+
+def deferred_loss_finalize():
+    """``with ops.deferred_loss_finalize():`` = a StepContext that defers the loss's final reduction"""
+    return StepContext(defer_loss=True)
 
 
 def pending_loss_tail():
-    """(BceTail, keep-alive) of a loss whose final reduction was deferred (removed from the list), or None"""
-    return _PENDING_TAIL.pop() if _PENDING_TAIL else None
+    """(BceTail, keep-alive) of a loss of the current step whose final reduction was deferred (removed from the
+    context), or None"""
+    return current_step().take_loss_tail()
 
 
 def pending_partials(grad):
-    """(keep-alive, ptr, n_partials, partial_stride, row_len, row_pitch) of a gradient whose reduction was deferred
-    (removed from the table), or None"""
-    return _PENDING.pop(grad.data_ptr(), None) if _PENDING else None
-
+    """(keep-alive, ptr, n_partials, partial_stride, row_len, row_pitch) of a gradient of the current step whose
+    reduction was deferred (removed from the context), or None"""
+    return current_step().take_partials(grad)
 
 
 def _workspace(nbytes, device):
@@ -321,14 +399,14 @@ def batch_select(order, cursor, batch_graphs, out_ids):
 
 
 def batch_plan_next(graph_ptr, ds_indptr, ds_t_indptr, order, cursor, out_ids, out):
-    """batch_select + batch_plan in one launch (gae_batch_plan_next): the ids of batch ``cursor`` of ``order`` go to
+    """batch_select + batch_plan in one launch (gae_x_batch_plan_next): the ids of batch ``cursor`` of ``order`` go to
     ``out_ids`` (int64 [B]), their prefix sums to ``out`` (int64 [3 or 2, B + 1]), the cursor advances"""
     B = out_ids.numel()
     rows = 3 if ds_t_indptr is not None else 2
     if out.shape != (rows, B + 1) or out.dtype != torch.int64 or not out.is_contiguous():
         raise GaeHipError("batch_plan_next: `out` must be a contiguous int64 [rows, B + 1] buffer")
     with _on_device(order.device):
-        _lib.call("gae_batch_plan_next", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_t_indptr), _ptr(order),
+        _lib.call("gae_x_batch_plan_next", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_t_indptr), _ptr(order),
                   order.numel(), _ptr(cursor), B, _ptr(out_ids), _ptr(out[0]), _ptr(out[1]),
                   _ptr(out[2]) if rows == 3 else None, _stream())
     return out[0], out[1], (out[2] if rows == 3 else None)
@@ -387,7 +465,7 @@ def batch_gather(graph_ptr, ds_indptr, ds_indices, ds_feat, graph_ids, node_ptr,
 
 def batch_gather_next(graph_ptr, ds_indptr, ds_indices, ds_feat, order, cursor, out_ids, ptrs, cap_nodes, cap_edges, out,
                       counts, ell_width=0, n_feat=None):
-    """select + plan + gather of the next batch of an uploaded epoch order in ONE launch (gae_batch_gather_next;
+    """select + plan + gather of the next batch of an uploaded epoch order in ONE launch (gae_x_batch_gather_next;
     batches of <= 1024 graphs, symmetric datasets): the ids go to ``out_ids`` (int64 [B]), the prefix sums to ``ptrs``
     (int64 [2, B + 1]), the capacity-padded batch to ``out`` = (indptr, indices, feat, table), the true sizes to
     ``counts`` (int64[4], zero before the first call), the cursor advances"""
@@ -404,7 +482,7 @@ def batch_gather_next(graph_ptr, ds_indptr, ds_indices, ds_feat, order, cursor, 
             out_indices.numel() < cap_edges or (ell_width and table.numel() != cap_nodes * ell_width):
         raise GaeHipError("batch_gather_next: `out` buffers have the wrong shape / dtype")
     with _on_device(order.device):
-        _lib.call("gae_batch_gather_next", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_indices), _ptr(feat), max(ldf, F), F,
+        _lib.call("gae_x_batch_gather_next", _ptr(graph_ptr), _ptr(ds_indptr), _ptr(ds_indices), _ptr(feat), max(ldf, F), F,
                   code, _ptr(order), order.numel(), _ptr(cursor), B, _ptr(out_ids), _ptr(ptrs[0]), _ptr(ptrs[1]),
                   int(cap_nodes), int(cap_edges), _ptr(out_indptr), _ptr(out_indices), _ptr(out_feat), max(ldo, F),
                   _ptr(table) if ell_width else None, int(ell_width), _ptr(counts), _stream())
@@ -877,7 +955,7 @@ def gcn2_bwd_dense_raw(G, dZ, Y1, act1, M1, W2, W1=None, b1=None):
         nbytes = _lib.load().gae_gcn2_bwd_dense_workspace_bytes(n, f_in, f_mid, f_out)
         if nbytes < 0:
             _lib.check(int(nbytes), "gae_gcn2_bwd_dense_workspace_bytes")
-        defer = _DEFER
+        defer = current_step().defer_grads
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev) if defer else _workspace(nbytes, dev)
         lay = (ctypes.c_int64 * 5)()
 
@@ -893,7 +971,7 @@ def gcn2_bwd_dense_raw(G, dZ, Y1, act1, M1, W2, W1=None, b1=None):
     if defer:
         base = ws.data_ptr()
         for t, off, ne in ((dW1, 0, f_mid * f_in), (db1, lay[2], f_mid), (dW2, lay[3], f_out * f_mid), (db2, lay[4], f_out)):
-            _PENDING[t.data_ptr()] = (ws, base + 4 * off, lay[0], lay[1], ne, ne)
+            current_step().add_partials(t, (ws, base + 4 * off, lay[0], lay[1], ne, ne))
     return dW1, db1, dW2, db2
 
 
@@ -930,16 +1008,16 @@ def linear_bwd_raw(dY, Y, act, M, W, need_dW=True, need_db=True, need_dM=True, f
     if Y is not None:
         Y, ldy = _rowmajor(Y, "Y")
     with _on_device(dev):
-        if _DEFER and n > 0 and f_in > 0 and (dW is not None or db is not None):
+        if current_step().defer_grads and n > 0 and f_in > 0 and (dW is not None or db is not None):
             # (dW, db) stay partial sums for the optimiser launch; dM, if wanted, comes from the ordinary entry point
             wsp = torch.empty(_lib.load().gae_linear_bwd_workspace_bytes(n, f_in, f_out), dtype=torch.uint8, device=dev)
             lay = (ctypes.c_int64 * 4)()
-            _lib.call("gae_linear_bwd_partials", _ptr(dY), lddy, _ptr(Y), ldy, act, _ptr(M), ldm, n, f_in, f_out,
+            _lib.call("gae_x_linear_bwd_partials", _ptr(dY), lddy, _ptr(Y), ldy, act, _ptr(M), ldm, n, f_in, f_out,
                       int(dW is not None), int(db is not None), _ptr(wsp), wsp.numel(), lay, _stream())
             if dW is not None:
-                _PENDING[dW.data_ptr()] = (wsp, wsp.data_ptr(), lay[0], lay[1], f_out * f_in, f_out * f_in)
+                current_step().add_partials(dW, (wsp, wsp.data_ptr(), lay[0], lay[1], f_out * f_in, f_out * f_in))
             if db is not None:
-                _PENDING[db.data_ptr()] = (wsp, wsp.data_ptr() + 4 * lay[2], lay[0], lay[1], f_out, f_out)
+                current_step().add_partials(db, (wsp, wsp.data_ptr() + 4 * lay[2], lay[0], lay[1], f_out, f_out))
             if dM is None:
                 return dW, db, dM
             ws = _workspace(_lib.load().gae_linear_bwd_workspace_bytes(n, f_in, f_out), dev)
@@ -1041,8 +1119,8 @@ VGAE_FUSED_LOSS = os.environ.get("GAE_VGAE_FUSED_LOSS", "1") != "0"
 
 class VGAEHeadLossFunction(torch.autograd.Function):
     """The VGAE head, the KL term and the fused reconstruction loss on the PACKED heads [mu | logstd] (d = 16) as
-    three launches: gae_vgae_head_prep (noise of this draw, z, KL partials, the loss's prepare step), then the dense
-    and the edge kernel of gae_decoder_bce_prepared; the scalar rec + KL comes out of the loss's final reduction,
+    three launches: gae_x_vgae_head_prep (noise of this draw, z, KL partials, the loss's prepare step), then the dense
+    and the edge kernel of gae_x_decoder_bce_prepared; the scalar rec + KL comes out of the loss's final reduction,
     which also adds the KL partials (gae_bce_tail::kl_*) -- inside ``deferred_loss_finalize()`` as one block of the
     optimiser launch.  Replaces gae_normal_noise, gae_vgae_head_fwd (2 launches), the prepare and final-reduction
     launches of the loss, the draw-counter increment and the ``rec + kl`` addition: 5 launches instead of 12.
@@ -1074,32 +1152,32 @@ class VGAEHeadLossFunction(torch.autograd.Function):
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
             klp = torch.empty((n + 63) // 64, dtype=torch.float64, device=dev)
             lay = _lib.BcePrep()
-            _lib.call("gae_decoder_bce_prep_layout", n, d, _ptr(ws), ws.numel(), ctypes.byref(lay))
+            _lib.call("gae_x_decoder_bce_prep_layout", n, d, _ptr(ws), ws.numel(), ctypes.byref(lay))
             blocks = ctypes.c_int64(0)
-            if _PENDING_TAIL:
-                _flush_loss_tail()
-            _lib.call("gae_vgae_head_prep", _ptr(ml), _vp(ml.data_ptr() + 4 * d), d2, _ptr(eps_t), 1 if draw else 0,
+            if current_step().tails:
+                current_step().flush_loss_tails()
+            _lib.call("gae_x_vgae_head_prep", _ptr(ml), _vp(ml.data_ptr() + 4 * d), d2, _ptr(eps_t), 1 if draw else 0,
                       int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _ptr(draws) if draw else None, n, d, _ptr(z),
                       ctypes.byref(lay), _ptr(klp), klp.numel(), ctypes.byref(blocks), _stream())
             tail = _lib.BceTail()
-            _lib.call("gae_decoder_bce_defer_finalize", ctypes.byref(tail))
+            _lib.call("gae_x_decoder_bce_defer_finalize", ctypes.byref(tail))
             try:
                 STATS["prepared_losses"] += 1
-                _lib.call("gae_decoder_bce_prepared", None, d, n, d, _ptr(indptr), _ptr(indices), _ptr(t_indptr),
+                _lib.call("gae_x_decoder_bce_prepared", None, d, n, d, _ptr(indptr), _ptr(indices), _ptr(t_indptr),
                           _ptr(t_indices), float(pw), None, 0.0, None, int(blocks.value), _ptr(loss), _ptr(dZ), d, _ptr(ws),
                           ws.numel(), _stream())
             except Exception:
-                _lib.call("gae_decoder_bce_defer_finalize", None)
+                _lib.call("gae_x_decoder_bce_defer_finalize", None)
                 raise
             tail.kl_partial = klp.data_ptr(); tail.n_kl = int(blocks.value); tail.kl_scale = -0.5 / (float(n) * float(n))
             tail.kl_out = kl.data_ptr(); tail.rec_out = rec.data_ptr()
             if draw and draws is not None:
                 tail.bump_draw = draws.data_ptr()          # the noise counter advances with the loss's last block
             keep = (loss, ws, klp, kl, rec, draws)
-            if _DEFER_LOSS and need:
-                _PENDING_TAIL.append((tail, keep))
+            if current_step().defer_loss and need:
+                current_step().tails.append((tail, keep))
             else:
-                _lib.call("gae_decoder_bce_finalize", ctypes.byref(tail), _stream())
+                _lib.call("gae_x_decoder_bce_finalize", ctypes.byref(tail), _stream())
         ctx.save_for_backward(ml, eps_t, dZ)
         kl0, rec0 = kl.reshape(()), rec.reshape(())
         ctx.mark_non_differentiable(z, kl0, rec0, eps_t)     # (the returned objects themselves: autograd would otherwise
@@ -1205,30 +1283,30 @@ def decoder_bce_raw(Z, mask, csr, csc, pos_weight, want_grad=True, row_begin=0, 
             # a deferred final reduction reads the partial sums in the optimiser launch: they must not sit in the
             # per-stream scratch cache, which any launch in between (dM of gae_linear_bwd, a weight-gradient
             # reduction) may hand out again
-            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev) if (_DEFER_LOSS and defer_ok and want_grad) \
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev) if (current_step().defer_loss and defer_ok and want_grad) \
                 else _workspace(nbytes, dev)
 
         def launch():
             tail = None
-            if _PENDING_TAIL:
-                _flush_loss_tail()                 # an earlier loss nobody took: its partial sums may live in the
+            if current_step().tails:
+                current_step().flush_loss_tails()                 # an earlier loss nobody took: its partial sums may live in the
                                                    # cached workspace this call is about to reuse
-            if _DEFER_LOSS and defer_ok and want_grad:
+            if current_step().defer_loss and defer_ok and want_grad:
                 tail = _lib.BceTail()
-                _lib.call("gae_decoder_bce_defer_finalize", ctypes.byref(tail))
+                _lib.call("gae_x_decoder_bce_defer_finalize", ctypes.byref(tail))
             try:
                 launch_kernels()
             except Exception:
                 if tail is not None:
-                    _lib.call("gae_decoder_bce_defer_finalize", None)
+                    _lib.call("gae_x_decoder_bce_defer_finalize", None)
                 raise
             if tail is not None:
-                _PENDING_TAIL.append((tail, (loss, ws, draws, counts)))
+                current_step().tails.append((tail, (loss, ws, draws, counts)))
 
         def launch_kernels():
             if prepared is not None:
                 STATS["prepared_losses"] += 1
-                _lib.call("gae_decoder_bce_prepared", _ptr(mask), max(d, 1), n, d, _ptr(indptr), _ptr(indices),
+                _lib.call("gae_x_decoder_bce_prepared", _ptr(mask), max(d, 1), n, d, _ptr(indptr), _ptr(indices),
                           _ptr(t_indptr), _ptr(t_indices), float(pos_weight), _ptr(counts), float(p_drop), _ptr(draws),
                           prepared["blocks"], _ptr(loss), _ptr(dZ), max(d, 1), _ptr(ws), ws.numel(), _stream())
                 return
@@ -1334,7 +1412,6 @@ def gcn_layer_fused_raw(indptr, indices, H, n_rows, plan, W, bias, act, row_scal
 # column sums (and draws the dropout mask) into a loss workspace, and ``req.token`` describes it for
 # ``decoder_bce(..., prepared=req.token)`` -- the loss then starts at its dense kernel (one kernel node fewer per step).
 FUSE_LOSS_PREPARE = os.environ.get("GAE_FUSE_LOSS_PREPARE", "1") != "0"
-_PREP_REQ = None
 STATS = {"prepared_losses": 0,      # losses that started at the dense kernel (tests read this)
          "xw_fwd": 0, "xw_wgrad": 0}  # launches of the one-pass layer-1 kernels (transform-first order)
 
@@ -1345,18 +1422,17 @@ class loss_prepare_request:
         self.graph, self.d, self.mask, self.dropout, self.token = graph, int(d), mask, dropout, None
 
     def __enter__(self):
-        global _PREP_REQ
-        self.prev = _PREP_REQ
-        _PREP_REQ = self if FUSE_LOSS_PREPARE and self.d <= 16 else None
+        self.step = current_step()             # the request belongs to the step it was made in
+        self.prev = self.step.prep_req
+        self.step.prep_req = self if FUSE_LOSS_PREPARE and self.d <= 16 else None
         return self
 
     def __exit__(self, *exc):
-        global _PREP_REQ
-        _PREP_REQ = self.prev
+        self.step.prep_req = self.prev
 
 
 def gcn_layer_fused_prep_raw(indptr, indices, H, n, plan, W, bias, row_scale, req, want_m=True):
-    """(M or None, Z, token): gae_gcn_layer_fused_prep -- the fused layer (identity activation) with the prepare step
+    """(M or None, Z, token): gae_x_gcn_layer_fused_prep -- the fused layer (identity activation) with the prepare step
     of the loss in its epilogue; ``token`` goes to decoder_bce_raw(prepared=...)"""
     H, ldh = _rowmajor(_f32(_gpu(H, "H"), "gcn_layer_fused_prep: H"), "H")
     W = _f32(_gpu(W, "W"), "gcn_layer_fused_prep: W")
@@ -1380,11 +1456,11 @@ def gcn_layer_fused_prep_raw(indptr, indices, H, n, plan, W, bias, row_scale, re
             _lib.check(int(nbytes), "gae_decoder_bce_workspace_bytes")
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)       # lives until the loss has run: not the scratch cache
         lay = _lib.BcePrep()
-        _lib.call("gae_decoder_bce_prep_layout", n, J, _ptr(ws), ws.numel(), ctypes.byref(lay))
+        _lib.call("gae_x_decoder_bce_prep_layout", n, J, _ptr(ws), ws.numel(), ctypes.byref(lay))
         blocks = ctypes.c_int64(0)
 
         def launch():
-            _lib.call("gae_gcn_layer_fused_prep", _ptr(indptr), _ptr(indices), n, _ptr(H), ldh, _ptr(M),
+            _lib.call("gae_x_gcn_layer_fused_prep", _ptr(indptr), _ptr(indices), n, _ptr(H), ldh, _ptr(M),
                       M.stride(0) if M is not None else 0, F, _ptr(row_scale), _ptr(row_scale), ctypes.byref(plan.c),
                       _ptr(W), W.stride(0), 1, _ptr(bias), J, _ptr(Z), J, ctypes.byref(lay), _ptr(mask), J, float(p_drop),
                       int(seed) & (2 ** 64 - 1), int(offset), _ptr(draws), _ptr(counts), ctypes.byref(blocks), _stream())
@@ -1398,7 +1474,7 @@ def gcn_layer_fused_prep_raw(indptr, indices, H, n, plan, W, bias, row_scale, re
 
 
 def gcn_layer_fused_wgrad_raw(t_indptr, t_indices, dY, n, plan_t, W, M, norm, want_dW=True, want_db=True):
-    """(dH, dW, db): the identity-activation backward of the fused layer in one launch (gae_gcn_layer_fused_wgrad).
+    """(dH, dW, db): the identity-activation backward of the fused layer in one launch (gae_x_gcn_layer_fused_wgrad).
     Inside ``deferred_grad_reductions()`` dW / db are left as per-block partial sums for optim.Adam.step()."""
     dY, lddy = _rowmajor(_f32(_gpu(dY, "dY"), "gcn_layer_fused_wgrad: dY"), "dY")
     W = W if W.stride(1) == 1 else W.contiguous()
@@ -1409,17 +1485,17 @@ def gcn_layer_fused_wgrad_raw(t_indptr, t_indices, dY, n, plan_t, W, M, norm, wa
     dH = torch.empty(n, f_in, dtype=torch.float32, device=dev)
     dW = torch.empty(f_out, f_in, dtype=torch.float32, device=dev) if want_dW else None
     db = torch.empty(f_out, dtype=torch.float32, device=dev) if want_db else None
-    defer = _DEFER and (want_dW or want_db)
+    defer = current_step().defer_grads and (want_dW or want_db)
     with _on_device(dev):
-        nbytes = _lib.load().gae_gcn_layer_fused_wgrad_workspace_bytes(n, f_out, f_in)
+        nbytes = _lib.load().gae_x_gcn_layer_fused_wgrad_workspace_bytes(n, f_out, f_in)
         if nbytes < 0:
-            _lib.check(int(nbytes), "gae_gcn_layer_fused_wgrad_workspace_bytes")
+            _lib.check(int(nbytes), "gae_x_gcn_layer_fused_wgrad_workspace_bytes")
         # deferred partials outlive the call: they must not sit in the per-stream scratch cache
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev) if defer else _workspace(nbytes, dev)
         lay = (ctypes.c_int64 * 3)()
 
         def launch():
-            _lib.call("gae_gcn_layer_fused_wgrad", _ptr(t_indptr), _ptr(t_indices), n, _ptr(dY), lddy, f_out, _ptr(norm),
+            _lib.call("gae_x_gcn_layer_fused_wgrad", _ptr(t_indptr), _ptr(t_indices), n, _ptr(dY), lddy, f_out, _ptr(norm),
                       _ptr(norm), ctypes.byref(plan_t.c), _ptr(W), W.stride(0), f_in, _ptr(dH), f_in, _ptr(M),
                       M.stride(0), None if defer else _ptr(dW), None if defer else _ptr(db), _ptr(ws), ws.numel(), lay,
                       _stream())
@@ -1429,9 +1505,9 @@ def gcn_layer_fused_wgrad_raw(t_indptr, t_indices, dY, n, plan_t, W, M, norm, wa
             launch()
     if defer:
         if dW is not None:
-            _PENDING[dW.data_ptr()] = (ws, ws.data_ptr(), lay[0], lay[1], f_out * f_in, f_out * f_in)
+            current_step().add_partials(dW, (ws, ws.data_ptr(), lay[0], lay[1], f_out * f_in, f_out * f_in))
         if db is not None:
-            _PENDING[db.data_ptr()] = (ws, ws.data_ptr() + 4 * lay[2], lay[0], lay[1], f_out, f_out)
+            current_step().add_partials(db, (ws, ws.data_ptr() + 4 * lay[2], lay[0], lay[1], f_out, f_out))
     return dH, dW, db
 
 
@@ -1449,7 +1525,7 @@ class GCNLayerFusedFunction(torch.autograd.Function):
         norm = graph.norm() if use_norm else None
         n = graph.number_of_nodes()
         need_w = ctx.needs_input_grad[1] or (b is not None and ctx.needs_input_grad[2])
-        req = _PREP_REQ
+        req = current_step().prep_req
         if (req is not None and req.token is None and req.graph is graph and act == ACT_IDENTITY
                 and W.shape[0] == req.d and H.shape[0] == n and n > 0):
             # the last encoder layer of a training step: the loss's prepare step rides in this launch's epilogue
@@ -1494,19 +1570,20 @@ class GCNLayerFusedFunction(torch.autograd.Function):
 def _split_pending(t, rows):
     """a deferred gradient ``t`` [R, ...] handed out as the two row blocks t[:rows], t[rows:]: register the partial
     lists of the halves (same workspace, second one offset)"""
-    ent = _PENDING.pop(t.data_ptr(), None)
+    step = current_step()
+    ent = step.take_partials(t)
     if ent is None:
         return
     ws, ptr, n_part, stride, _, _ = ent
     per_row = t[0].numel() if t.dim() > 1 else 1
     n0, n1 = rows * per_row, (t.shape[0] - rows) * per_row
-    _PENDING[t[:rows].data_ptr()] = (ws, ptr, n_part, stride, max(n0, 1), max(n0, 1))
-    _PENDING[t[rows:].data_ptr()] = (ws, ptr + 4 * n0, n_part, stride, max(n1, 1), max(n1, 1))
+    current_step().add_partials(t[:rows], (ws, ptr, n_part, stride, max(n0, 1), max(n0, 1)))
+    current_step().add_partials(t[rows:], (ws, ptr + 4 * n0, n_part, stride, max(n1, 1), max(n1, 1)))
 
 
 class GCNTwoHeadFunction(torch.autograd.Function):
     """two identity-activation GCN layers on the same input (VGAE's mu and log sigma heads) as ONE fused launch
-    (gae_gcn_layer_fused2): ML = [(A H) W1^T + b1 | (A H) W2^T + b2].  Backward: one dW launch for both heads
+    (gae_x_gcn_layer_fused2): ML = [(A H) W1^T + b1 | (A H) W2^T + b2].  Backward: one dW launch for both heads
     (dML^T M, split by rows), one fused launch dH = (A^T dML) [W1; W2] -- instead of two of each plus an add."""
 
     @staticmethod
@@ -1523,7 +1600,7 @@ class GCNTwoHeadFunction(torch.autograd.Function):
         M = torch.empty(n, padded_ld(F, torch.float32), dtype=torch.float32, device=Hc.device)[:, :F] if need_w else None
         Y = torch.empty(n, d1 + d2, dtype=torch.float32, device=Hc.device)
         with _on_device(Hc.device):
-            _lib.call("gae_gcn_layer_fused2", _ptr(indptr), _ptr(indices), n, Hc.shape[0], _ptr(Hc), ldh, _ptr(M),
+            _lib.call("gae_x_gcn_layer_fused2", _ptr(indptr), _ptr(indices), n, Hc.shape[0], _ptr(Hc), ldh, _ptr(M),
                       M.stride(0) if M is not None else 0, F, _ptr(norm), _ptr(norm), ctypes.byref(plan.c), _ptr(W1),
                       _ptr(W2), d1, 0, W1.stride(0), 1, _ptr(b1), _ptr(b2), d1 + d2, ACT_IDENTITY, _ptr(Y), d1 + d2,
                       _stream())
@@ -1542,27 +1619,27 @@ class GCNTwoHeadFunction(torch.autograd.Function):
         dYc = dY.contiguous()
         if (FUSED_LAYER_WGRAD and need_dH and need_dW and M is not None and d1 + d2 <= 32 and W1.shape[1] <= 32
                 and M.stride(1) == 1):
-            # dH, dW and db of both heads from ONE launch (gae_gcn_layer_fused2_wgrad: side work of the gather's blocks)
+            # dH, dW and db of both heads from ONE launch (gae_x_gcn_layer_fused2_wgrad: side work of the gather's blocks)
             f_out, f_in = d1 + d2, W1.shape[1]
             dev = dYc.device
             dH = torch.empty(n, f_in, dtype=torch.float32, device=dev)
             dW = torch.empty(f_out, f_in, dtype=torch.float32, device=dev)
             db = torch.empty(f_out, dtype=torch.float32, device=dev) if need_db else None
-            defer = _DEFER
+            defer = current_step().defer_grads
             with _on_device(dev):
-                nbytes = _lib.load().gae_gcn_layer_fused_wgrad_workspace_bytes(n, f_out, f_in)
+                nbytes = _lib.load().gae_x_gcn_layer_fused_wgrad_workspace_bytes(n, f_out, f_in)
                 if nbytes < 0:
-                    _lib.check(int(nbytes), "gae_gcn_layer_fused_wgrad_workspace_bytes")
+                    _lib.check(int(nbytes), "gae_x_gcn_layer_fused_wgrad_workspace_bytes")
                 ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev) if defer else _workspace(nbytes, dev)
                 lay = (ctypes.c_int64 * 3)()
-                _lib.call("gae_gcn_layer_fused2_wgrad", _ptr(t_indptr), _ptr(t_indices), n, _ptr(dYc), f_out, f_out,
+                _lib.call("gae_x_gcn_layer_fused2_wgrad", _ptr(t_indptr), _ptr(t_indices), n, _ptr(dYc), f_out, f_out,
                           _ptr(norm), _ptr(norm), ctypes.byref(plan_t.c), _ptr(W1), _ptr(W2), d1, W1.stride(0), f_in,
                           _ptr(dH), f_in, _ptr(M), M.stride(0), None if defer else _ptr(dW), None if defer else _ptr(db),
                           _ptr(ws), ws.numel(), lay, _stream())
             if defer:
-                _PENDING[dW.data_ptr()] = (ws, ws.data_ptr(), lay[0], lay[1], f_out * f_in, f_out * f_in)
+                current_step().add_partials(dW, (ws, ws.data_ptr(), lay[0], lay[1], f_out * f_in, f_out * f_in))
                 if db is not None:
-                    _PENDING[db.data_ptr()] = (ws, ws.data_ptr() + 4 * lay[2], lay[0], lay[1], f_out, f_out)
+                    current_step().add_partials(db, (ws, ws.data_ptr() + 4 * lay[2], lay[0], lay[1], f_out, f_out))
             _split_pending(dW, d1)
             dW1, dW2 = dW[:d1], dW[d1:]
             if db is not None:
@@ -1582,7 +1659,7 @@ class GCNTwoHeadFunction(torch.autograd.Function):
             dH = torch.empty(n, F, dtype=torch.float32, device=dYc.device)
             with _on_device(dYc.device):
                 # dH = (A^T dY) [W1; W2]: the stacked matrix addressed transposed (element (o, k) at row k, column o)
-                _lib.call("gae_gcn_layer_fused2", _ptr(t_indptr), _ptr(t_indices), n, n, _ptr(dYc), d1 + d2, None, 0,
+                _lib.call("gae_x_gcn_layer_fused2", _ptr(t_indptr), _ptr(t_indices), n, n, _ptr(dYc), d1 + d2, None, 0,
                           d1 + d2, _ptr(norm), _ptr(norm), ctypes.byref(plan_t.c), _ptr(W1), _ptr(W2), d1, 1, 1,
                           W1.stride(0), None, None, F, ACT_IDENTITY, _ptr(dH), F, _stream())
         return dH, dW1, db1, dW2, db2, None, None
@@ -1602,7 +1679,7 @@ def gcn_two_heads(graph, H, lin1, lin2, use_norm=False):
         return None
     if not gcn_layer_fused_usable(Hc, d1 + d2, plan) or not _table_only(plan_t) or d1 + d2 > FUSED_LAYER_MAX_IN:
         return None
-    # the backward is gae_gcn_layer_fused2(_wgrad) on the CSR of A^T with dML [n, d1 + d2] as the gathered operand and
+    # the backward is gae_x_gcn_layer_fused2(_wgrad) on the CSR of A^T with dML [n, d1 + d2] as the gathered operand and
     # the heads' INPUT width as its output: rows of whole 16-byte vectors and <= 32 outputs, or the two separate
     # layers (which have their own fallbacks) must run instead
     if lin1.weight.shape[1] > FUSED_LAYER_MAX_OUT or (d1 + d2) % 4 != 0:
@@ -1700,17 +1777,17 @@ def xw_wgrad_raw(X, G, Gmask, D, Dmask, f_out, need_dW=True, need_db=True):
         Dmask, lddm = _rowmajor(_f32(Dmask, "xw_wgrad: Dmask"), "Dmask")
     dW = torch.empty(f_out, f_in, dtype=torch.float32, device=dev) if need_dW else None
     db = torch.empty(f_out, dtype=torch.float32, device=dev) if need_db and D is not None else None
-    if _DEFER and (dW is not None or db is not None):
+    if current_step().defer_grads and (dW is not None or db is not None):
         with _on_device(dev):
             ws = torch.empty(_lib.load().gae_xw_wgrad_workspace_bytes(n, f_in, code), dtype=torch.uint8, device=dev)
             lay = (ctypes.c_int64 * 8)()
-            _lib.call("gae_xw_wgrad_partials", _ptr(X), X.stride(0), code, n, f_in, _ptr(G), ldg, _ptr(Gmask), ldgm,
+            _lib.call("gae_x_xw_wgrad_partials", _ptr(X), X.stride(0), code, n, f_in, _ptr(G), ldg, _ptr(Gmask), ldgm,
                       _ptr(D), ldd, _ptr(Dmask), lddm, int(f_out), int(dW is not None), int(db is not None), _ptr(ws),
                       ws.numel(), lay, _stream())
         if dW is not None:
-            _PENDING[dW.data_ptr()] = (ws, ws.data_ptr(), lay[0], lay[1], f_in, lay[2])
+            current_step().add_partials(dW, (ws, ws.data_ptr(), lay[0], lay[1], f_in, lay[2]))
         if db is not None:
-            _PENDING[db.data_ptr()] = (ws, ws.data_ptr() + 4 * lay[3], lay[4], lay[5], f_out, f_out)
+            current_step().add_partials(db, (ws, ws.data_ptr() + 4 * lay[3], lay[4], lay[5], f_out, f_out))
         return dW, db
     with _on_device(dev):
         ws = _workspace(_lib.load().gae_xw_wgrad_workspace_bytes(n, f_in, code), dev)

@@ -123,7 +123,7 @@ class Adam(torch.optim.Optimizer):
                         raise _lib.GaeHipError("gae_dgl_amd.optim.Adam: dense fp32 gradients only")
                     m, v = self._moments(p)
                     keep.append(g)
-                    pend = ops.pending_partials(p.grad)       # deferred reduction (ops.deferred_grad_reductions)
+                    pend = ops.current_step().take_partials(p.grad)       # deferred reduction (ops.StepContext)
                     if pend is not None:
                         keep.append(pend[0])
                         arr[k] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
@@ -135,12 +135,13 @@ class Adam(torch.optim.Optimizer):
                 self._counter(key[0], key[1], dev)
                 counters = self._counters
                 # the step's loss may have left its final reduction to this launch (ops.deferred_loss_finalize)
-                pend_tail = ops.pending_loss_tail()
+                step = ops.current_step()
+                pend_tail = step.take_loss_tail()
                 if pend_tail is not None and pend_tail[1][0].device != dev:
-                    ops._PENDING_TAIL.append(pend_tail)
+                    step.tails.append(pend_tail)
                     pend_tail = None
                 with _on_device(dev):
-                    _lib.call("gae_adam_step_tail", arr, len(chunk), float(group["lr"]), float(group["betas"][0]),
+                    _lib.call("gae_x_adam_step_tail", arr, len(chunk), float(group["lr"]), float(group["betas"][0]),
                               float(group["betas"][1]), float(group["eps"]), float(group["weight_decay"]),
                               ctypes.c_void_p(counters[key].data_ptr()),
                               ctypes.byref(pend_tail[0]) if pend_tail is not None else None, _stream())

@@ -15,7 +15,7 @@ from . import ops
 from .gae import GCN, InnerProductDecoder, identity
 
 
-# mu and log sigma heads as ONE fused launch on the shared aggregate (gae_gcn_layer_fused2) and one packed gradient
+# mu and log sigma heads as ONE fused launch on the shared aggregate (gae_x_gcn_layer_fused2) and one packed gradient
 # path; False runs them as two GCN layers (same values up to the fp32 rounding of the dW summation order)
 FUSE_HEADS = True
 

@@ -19,6 +19,20 @@
  *   - row-major matrices with an explicit leading dimension (elements);
  *   - sparse structure is CSR with int32 `indptr[n_rows+1]`, int32 `indices[nnz]`;
  *     rows = destination nodes, columns = source nodes (in-edge aggregation).
+ *
+ * Two tiers of entry points:
+ *   gae_*    THE SURFACE a maintainer binds: one entry point per operator of the reference's path --
+ *            structure (gae_csr_from_coo, gae_batch_gather / _plan / _select, gae_degree_norm, gae_csr_to_dense,
+ *            gae_rows_pack), aggregation (gae_spmm_csr / _ep / _epilogue / _blockdiag with their plan builders),
+ *            node-apply (gae_linear_fwd / _bwd, gae_gcn_layer_fused, gae_xw_fwd / _wgrad, gae_linear2_fwd,
+ *            gae_gcn2_bwd_dense), decoder + loss (gae_decoder_dense / _bwd, gae_bce_logits, gae_decoder_bce / _rows /
+ *            _padded, gae_dropout_mask), the VGAE head, gae_segment_readout, gae_adam_step.  Stable names and
+ *            argument meaning.
+ *   gae_x_*  EXPERIMENTAL step fusions: the same arithmetic cut along the launch boundaries of one particular
+ *            training step (a producer kernel that also runs the loss's prepare step, reductions that ride in the
+ *            optimiser launch, two heads in one launch, collate + cursor in one launch).  They exist to take launches
+ *            out of the captured step of gae_dgl_amd/capture.py, are paired in ways the comments spell out, and may
+ *            change or disappear between rounds; every one of them has a gae_* sequence with the same result.
  */
 #ifndef GAE_HIP_H
 #define GAE_HIP_H
@@ -149,20 +163,20 @@ int gae_batch_select(const int64_t *order, int64_t n_order, int64_t *cursor_dev,
                      int64_t *out_ids, void *stream);
 /* gae_batch_select + gae_batch_plan in one launch (the step of a captured HIP graph): ids of batch *cursor_dev of the
  * epoch order -> out_ids, their prefix sums -> out_*_ptr, *cursor_dev += 1. */
-int gae_batch_plan_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
+int gae_x_batch_plan_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
                         const int64_t *order, int64_t n_order, int64_t *cursor_dev, int64_t n_graphs,
                         int64_t *out_ids, int64_t *out_node_ptr, int64_t *out_edge_ptr, int64_t *out_t_edge_ptr,
                         void *stream);
 int gae_batch_plan(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_t_indptr,
                    const int64_t *graph_ids, int64_t n_graphs, int64_t *out_node_ptr, int64_t *out_edge_ptr,
                    int64_t *out_t_edge_ptr, void *stream);
-/* gae_batch_plan_next + gae_batch_gather (fixed-capacity form) in ONE launch, for batches of <= 1024 graphs: the ids
+/* gae_x_batch_plan_next + gae_batch_gather (fixed-capacity form) in ONE launch, for batches of <= 1024 graphs: the ids
  * of batch *cursor_dev of the epoch order, their prefix sums (out_ids [n_graphs], out_node_ptr / out_edge_ptr
  * [n_graphs + 1]) and the gathered, capacity-padded batch; *cursor_dev += 1.  out_counts: int64[4], ZERO before the
  * first call -- [0..2] as gae_batch_gather, [3] is the launch's block ticket (left zero).  The CSR of the batch is
  * used for the transposed structure as well (symmetric datasets: every bond stored in both directions,
  * gae_dgl/prepare_data.py:61-64). */
-int gae_batch_gather_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_indices,
+int gae_x_batch_gather_next(const int64_t *graph_ptr, const int32_t *ds_indptr, const int32_t *ds_indices,
                           const void *ds_feat, int64_t ld_feat, int64_t F, int dtype,
                           const int64_t *order, int64_t n_order, int64_t *cursor_dev, int64_t n_graphs,
                           int64_t *out_ids, int64_t *out_node_ptr, int64_t *out_edge_ptr,
@@ -191,9 +205,9 @@ int gae_batch_gather(const int64_t *graph_ptr, const int32_t *ds_indptr, const i
  * Degree-skew plan (optional, for power-law graphs): rows with more than
  * `threshold` edges are cut into segments of `segment_edges` edges that
  * separate waves gather; segment partial sums are added in segment order.
- * Build: gae_spmm_plan_count -> read the two counters -> allocate ->
- * gae_spmm_plan_fill; the plan is valid as long as indptr is.  plan = NULL (or
- * n_heavy = 0): every row is summed by one lane group in CSR order. */
+ * Build: gae_spmm_plan_sizes -> allocate -> gae_spmm_plan_build_rows (-> gae_spmm_plan_build_pinned), all on the
+ * device; the plan is valid as long as indptr is.  plan = NULL (or n_heavy = 0): every row is summed by one lane
+ * group in CSR order. */
 typedef struct gae_spmm_plan {
     int32_t threshold;              /* rows with degree > threshold are heavy */
     int32_t segment_edges;          /* multiple of 64 */
@@ -206,7 +220,7 @@ typedef struct gae_spmm_plan {
     int32_t ell_width;              /* 4, 8 or GAE_SPMM_ELL_WIDTH when `ell` is given, else 0 */
     int32_t reserved;
     const int32_t *hot_indices;     /* [n_edges] the CSR's column ids with the sign bit set on the most gathered
-                                       columns (gae_spmm_tag_hot), or NULL: the heavy-row kernel then loads the
+                                       columns, or NULL: the heavy-row kernel then loads the
                                        rows of all OTHER columns with the streaming hint, which keeps the hub
                                        rows of a power-law graph in L2.  A cache hint only: values unchanged. */
     /* XCD-pinned ("homed") part, optional (vh_n_virtual = 0: none).  The rows in vh_rows -- the very long rows of a
@@ -226,12 +240,12 @@ typedef struct gae_spmm_plan {
     const int32_t *vh_part_ptr;     /* [vh_n_rows + 1] */
     const int32_t *vh_part_pos;     /* [vh_part_ptr[vh_n_rows]] */
     const int32_t *seg_desc;        /* [n_segments][4] {row, first edge, end edge, 1 = the row's only segment}
-                                       (gae_spmm_plan_desc; 16-byte aligned) or NULL: one load in front of a
+                                       (16-byte aligned) or NULL: one load in front of a
                                        segment's column ids instead of the chain seg_heavy -> heavy_rows /
                                        heavy_seg_base -> indptr (a wave of the heavy-row kernel lives for a handful
                                        of round trips: RMAT s24 launch 5.05 -> 4.85 ms).  Same sums. */
     /* Light-row list of a skew plan, optional (round 4): {row, first edge, end edge, 0} of every row with 1 ..
-     * threshold in-edges, ascending rows (gae_spmm_plan_light; 16-byte aligned).  On a power-law graph most rows are
+     * threshold in-edges, ascending rows (gae_spmm_plan_build_rows; 16-byte aligned).  On a power-law graph most rows are
      * EMPTY (R-MAT s24: 11.7 M of 16.8 M): with the list the light rows are produced by waves whose every lane group
      * has edges to gather (one descriptor load instead of two row-pointer loads in front of the column ids), and the
      * empty rows by a pure stream that writes act(bias).  Same sums, same bits. */
@@ -247,18 +261,6 @@ typedef struct gae_spmm_plan {
                                        vh_indices holds the pinned rows' ids in (row, home, column) order. */
 } gae_spmm_plan;
 
-/* Hot-column tags for a plan with heavy rows: gae_spmm_col_freq counts how often every column occurs in `indices`
- * (int32 [n_cols], device); the caller picks min_freq (e.g. the frequency of the 65536th most frequent column) and gae_spmm_tag_hot writes the tagged copy of `indices` (int32 [n_edges]). */
-int gae_spmm_col_freq(const int32_t *indices, int64_t n_edges, int64_t n_cols, int32_t *freq_out, void *stream);
-int gae_spmm_tag_hot(const int32_t *indices, int64_t n_edges, const int32_t *col_freq, int32_t min_freq,
-                     int32_t *hot_indices_out, void *stream);
-/* counts_dev[0] = number of heavy rows, [1] = number of segments, [2] = maximum row degree (3 x uint64, device) */
-int gae_spmm_plan_count(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
-                        uint64_t *counts_dev, void *stream);
-/* cursors_dev: 2 x uint64 scratch (zeroed by the call); output arrays sized from the counts */
-int gae_spmm_plan_fill(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t segment_edges,
-                       uint64_t *cursors_dev, int32_t *heavy_rows, int32_t *heavy_seg_base,
-                       int32_t *seg_heavy, void *stream);
 /* ---- plan construction on the device (csrc/plan_build.hip): classification of the rows, descriptors, compact tagged
  * ids of the mid rows, XCD-pinned regrouping of the very long rows -- integer work, deterministic (ascending rows, stable
  * partition, stable sort).  Every call synchronises `stream` once to hand counters to the host.
@@ -284,17 +286,6 @@ int gae_spmm_plan_build_pinned(const int32_t *indptr, const int32_t *indices, in
                                int32_t segment_edges, const int64_t *sizes, const int32_t *vh_rows, int32_t *vh_cols,
                                int32_t *vh_desc, int32_t *vh_part_pos, void *scratch, int64_t scratch_bytes,
                                int64_t *pinned_host_out, void *stream);
-/* optional: the light-row list of a plan (gae_spmm_plan::light_desc).  gae_spmm_plan_light_count: *count_dev (uint64,
- * device) = rows with 1 .. threshold in-edges; gae_spmm_plan_light fills light_desc [count][4] in ascending row order
- * (workspace: gae_spmm_plan_light_workspace_bytes(n_rows), 16-byte aligned). */
-int gae_spmm_plan_light_count(const int32_t *indptr, int64_t n_rows, int32_t threshold, uint64_t *count_dev, void *stream);
-int64_t gae_spmm_plan_light_workspace_bytes(int64_t n_rows);
-int gae_spmm_plan_light(const int32_t *indptr, int64_t n_rows, int32_t threshold, int32_t *light_desc, int64_t n_light,
-                        void *workspace, int64_t workspace_bytes, void *stream);
-/* optional: the segment descriptors of a filled plan (int32 [n_segments][4], see gae_spmm_plan::seg_desc) */
-int gae_spmm_plan_desc(const int32_t *indptr, const int32_t *heavy_rows, const int32_t *heavy_seg_base,
-                       const int32_t *seg_heavy, int64_t n_segments, int32_t segment_edges, int32_t *seg_desc,
-                       void *stream);
 /* Packed neighbour table (optional, for launches of a few 10 MB): slot k of row r at ell[r * width + k] holds the
  * row's k-th column id in CSR order; -1 = empty; a row with more than `width` ids keeps width - 1 of them and the
  * marker -2 in its last slot (the kernel continues from indptr / indices); rows with more than `skip_degree` ids
@@ -400,7 +391,7 @@ int gae_xw_wgrad(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in,
  *   layout_out[0] = partials of dW, [1] = floats between two of them, [2] = row pitch (floats) of a partial's [f_out]
  *   rows (element (j, k) of partial q: workspace[q * [1] + j * [2] + k]); [3] = float offset of the db partials,
  *   [4] = their count, [5] = floats between two of them (element j of partial q: workspace[[3] + q * [5] + j]). */
-int gae_xw_wgrad_partials(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in,
+int gae_x_xw_wgrad_partials(const void *X, int64_t ldx, int dtype, int64_t n, int64_t f_in,
                           const float *G, int64_t ldg, const float *Gmask, int64_t ldgm,
                           const float *D, int64_t ldd, const float *Dmask, int64_t lddm, int64_t f_out,
                           int want_dW, int want_db, void *workspace, int64_t workspace_bytes,
@@ -415,7 +406,7 @@ int gae_spmm_csr_epilogue(const int32_t *indptr, const int32_t *indices, int64_t
  * STORED rows ([W; W2], w_split rows in W, same strides) and the bias as [bias; bias2].  Forward (w_transposed = 0):
  * Y = [act(M W^T + b) | act(M W2^T + b2)].  Backward of identity heads (w_transposed = 1, strides swapped as in
  * gae_gcn_layer_fused): dH = (A^T dY) [W; W2]. */
-int gae_gcn_layer_fused2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+int gae_x_gcn_layer_fused2(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                          const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
                          const float *row_scale, const float *col_scale, const gae_spmm_plan *plan,
                          const float *W, const float *W2, int64_t w_split, int w_transposed,
@@ -428,21 +419,21 @@ int gae_gcn_layer_fused2(const int32_t *indptr, const int32_t *indices, int64_t 
  *   dW [f_out, f_in] = dY^T M,  db [f_out] = colsum(dY)     side work of the same thread blocks on their own 32 (16)
  *                                            rows: M [n, f_in] (ldm) is the aggregate the forward stored.
  * dY [n, f_out] (lddy: whole 16-byte vectors), f_out <= 32, f_in <= 32, square graph.  The weight gradient leaves the
- * launch as per-block partial sums in `workspace` (gae_gcn_layer_fused_wgrad_workspace_bytes(n, f_out, f_in)):
+ * launch as per-block partial sums in `workspace` (gae_x_gcn_layer_fused_wgrad_workspace_bytes(n, f_out, f_in)):
  * layout_out[0] = number of partials, [1] = floats between two partials, [2] = float offset of the db partials inside
  * one (dW partial: element o * f_in + i).  dW / db != NULL: a second, small launch adds them up (the library's one
  * order for partial lists); both NULL: the caller hands the list to gae_adam_step (gae_adam_tensor.partials) -- no
  * weight-gradient launch at all in a captured training step. */
-int64_t gae_gcn_layer_fused_wgrad_workspace_bytes(int64_t n_rows, int64_t f_out, int64_t f_in);
-int gae_gcn_layer_fused_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
+int64_t gae_x_gcn_layer_fused_wgrad_workspace_bytes(int64_t n_rows, int64_t f_out, int64_t f_in);
+int gae_x_gcn_layer_fused_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
                               int64_t lddy, int64_t f_out, const float *row_scale, const float *col_scale,
                               const gae_spmm_plan *plan_t, const float *W, int64_t ldw, int64_t f_in, float *dH,
                               int64_t lddh, const float *M, int64_t ldm, float *dW, float *db, void *workspace,
                               int64_t workspace_bytes, int64_t *layout_out, void *stream);
-/* ... and of gae_gcn_layer_fused2 (two identity heads on one aggregate): dY = [dY1 | dY2] ([n, f_out], f_out = d1 + d2),
+/* ... and of gae_x_gcn_layer_fused2 (two identity heads on one aggregate): dY = [dY1 | dY2] ([n, f_out], f_out = d1 + d2),
  * the weight is the stack [W; W2] along its stored rows (w_split = d1 rows come from W; both ldw apart), dW [f_out, f_in]
  * is stacked alike (rows < w_split = dW1), db [f_out]. */
-int gae_gcn_layer_fused2_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
+int gae_x_gcn_layer_fused2_wgrad(const int32_t *t_indptr, const int32_t *t_indices, int64_t n, const float *dY,
                                int64_t lddy, int64_t f_out, const float *row_scale, const float *col_scale,
                                const gae_spmm_plan *plan_t, const float *W, const float *W2, int64_t w_split,
                                int64_t ldw, int64_t f_in, float *dH, int64_t lddh, const float *M, int64_t ldm, float *dW,
@@ -506,7 +497,7 @@ int64_t gae_linear_bwd_workspace_bytes(int64_t n, int64_t f_in, int64_t f_out);
 /* The first half of gae_linear_bwd's (dW, db): the per-row-slot partial products stay in `workspace` for
  * gae_adam_step's deferred reduction.  layout_out[0] = slots, [1] = floats between two slots (element e = o * f_in + i
  * of slot q: workspace[q * [1] + e]), [2] = float offset of a slot's f_out column sums (db) inside the slot. */
-int gae_linear_bwd_partials(const float *dY, int64_t lddy, const float *Y, int64_t ldy, int act,
+int gae_x_linear_bwd_partials(const float *dY, int64_t lddy, const float *Y, int64_t ldy, int act,
                             const float *M, int64_t ldm, int64_t n, int64_t f_in, int64_t f_out,
                             int want_dW, int want_db, void *workspace, int64_t workspace_bytes,
                             int64_t *layout_out, void *stream);
@@ -543,7 +534,7 @@ int gae_decoder_dense_bwd(const float *G, int64_t ldg, const float *Z, const flo
  * gae_vgae_head_fwd: z = mu + eps * exp(logstd);  kl_out = -(0.5/N) * mean_i sum_j (1 + 2 logstd - mu^2 -
  *                    exp(2 logstd))   (one fp32 on the device); eps / z contiguous [n, d]; the rows of mu and of
  *                    logstd (and of their gradients in gae_vgae_head_bwd) are ldm floats apart -- ldm = d for
- *                    separate matrices, 2 d when both heads come packed as [mu | logstd] from gae_gcn_layer_fused2.
+ *                    separate matrices, 2 d when both heads come packed as [mu | logstd] from gae_x_gcn_layer_fused2.
  * gae_vgae_head_bwd: dmu = dz + gkl * dKL/dmu, dlogstd = dz * eps * exp(logstd) + gkl * dKL/dlogstd, with
  *                    gkl = *gkl_dev (upstream gradient of the KL scalar; NULL = 1), dz may be NULL (= 0). */
 int gae_normal_noise(float *out, int64_t n_elems, uint64_t seed, uint64_t offset, const uint64_t *draw_dev,
@@ -611,10 +602,10 @@ int gae_decoder_bce_padded(const float *Z, float *mask, int64_t ldz, int64_t n_c
  * mask to Z, pads it to 16 columns, splits it into bf16 hi / lo and adds up its columns.  When Z comes out of
  * gae_gcn_layer_fused (the last encoder layer of gae_dgl/gae.py:55-57 followed by the loss of
  * train_inductive.py:44-48), that launch can do the same work in its epilogue:
- *   gae_decoder_bce_prep_layout(n, d, ws, bytes, &prep)   where the pieces go inside the loss workspace `ws`
+ *   gae_x_decoder_bce_prep_layout(n, d, ws, bytes, &prep)   where the pieces go inside the loss workspace `ws`
  *                                                         (gae_decoder_bce_workspace_bytes(n, n, d) bytes), d <= 16;
- *   gae_gcn_layer_fused_prep(..., &prep, mask, ...)       the layer + the prepare work (see there);
- *   gae_decoder_bce_prepared(..., n_prep_blocks, ..., ws) the loss from the dense kernel on: same arguments as
+ *   gae_x_gcn_layer_fused_prep(..., &prep, mask, ...)       the layer + the prepare work (see there);
+ *   gae_x_decoder_bce_prepared(..., n_prep_blocks, ..., ws) the loss from the dense kernel on: same arguments as
  *                                                         gae_decoder_bce / _padded (counts_dev != NULL: padded batch,
  *                                                         pos_weight ignored) minus Z / seed / offset.
  * One kernel node fewer per training step; the values are those of the three-launch form up to the order of the
@@ -628,19 +619,19 @@ typedef struct gae_bce_prep {
     int64_t max_blocks;          /* room in colsum_partial */
     int32_t DP, reserved;
 } gae_bce_prep;
-int gae_decoder_bce_prep_layout(int64_t n, int64_t d, void *workspace, int64_t workspace_bytes, gae_bce_prep *out);
+int gae_x_decoder_bce_prep_layout(int64_t n, int64_t d, void *workspace, int64_t workspace_bytes, gae_bce_prep *out);
 /* gae_gcn_layer_fused (identity activation, square graph, J <= 16 outputs = the embedding Z [n, J], ldz) + the prepare
  * work of the loss that follows: mask [n, J] (ldmask) is the dropout multiplier -- drawn here (dropout_p > 0: the
  * Philox stream of gae_dropout_mask with *draw_dev as the draw index, written to `mask`) or given (dropout_p == 0, mask
  * may be NULL = all ones); counts_dev != NULL: fixed-capacity batch, rows >= counts_dev[0] are padding.
- * *n_prep_blocks_out = the number of column-sum partials written (pass it to gae_decoder_bce_prepared). */
-int gae_gcn_layer_fused_prep(const int32_t *indptr, const int32_t *indices, int64_t n, const float *H, int64_t ldh,
+ * *n_prep_blocks_out = the number of column-sum partials written (pass it to gae_x_decoder_bce_prepared). */
+int gae_x_gcn_layer_fused_prep(const int32_t *indptr, const int32_t *indices, int64_t n, const float *H, int64_t ldh,
                              float *M, int64_t ldm, int64_t F, const float *row_scale, const float *col_scale,
                              const gae_spmm_plan *plan, const float *W, int64_t w_stride_out, int64_t w_stride_in,
                              const float *bias, int64_t J, float *Z, int64_t ldz, const gae_bce_prep *prep, float *mask,
                              int64_t ldmask, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t *draw_dev,
                              const int64_t *counts_dev, int64_t *n_prep_blocks_out, void *stream);
-int gae_decoder_bce_prepared(float *mask, int64_t ldz, int64_t n, int64_t d, const int32_t *indptr,
+int gae_x_decoder_bce_prepared(float *mask, int64_t ldz, int64_t n, int64_t d, const int32_t *indptr,
                              const int32_t *indices, const int32_t *t_indptr, const int32_t *t_indices,
                              float pos_weight, const int64_t *counts_dev, float dropout_p, uint64_t *draw_dev,
                              int64_t n_prep_blocks, float *loss_out, float *dZ, int64_t lddz, void *workspace,
@@ -650,19 +641,19 @@ int gae_decoder_bce_prepared(float *mask, int64_t ldz, int64_t n, int64_t d, con
  * (draw_eps != 0: generated with gae_normal_noise's stream -- seed, offset, *draw_dev -- and WRITTEN to eps [n, d];
  * draw_eps == 0: eps is read), z = mu + eps exp(logstd) [n, d], the KL term as one partial per block of 64 rows in
  * kl_partial (capacity kl_capacity >= ceil(n / 64) doubles; scale -0.5 / n^2: put both into gae_bce_tail::kl_*), and
- * the prepare step of gae_decoder_bce on z without dropout (prep: gae_decoder_bce_prep_layout; then
- * gae_decoder_bce_prepared with *n_blocks_out).  mu / logstd: rows ldm floats apart (packed [mu | logstd]: ldm = 2 d). */
-int gae_vgae_head_prep(const float *mu, const float *logstd, int64_t ldm, float *eps, int draw_eps, uint64_t seed,
+ * the prepare step of gae_decoder_bce on z without dropout (prep: gae_x_decoder_bce_prep_layout; then
+ * gae_x_decoder_bce_prepared with *n_blocks_out).  mu / logstd: rows ldm floats apart (packed [mu | logstd]: ldm = 2 d). */
+int gae_x_vgae_head_prep(const float *mu, const float *logstd, int64_t ldm, float *eps, int draw_eps, uint64_t seed,
                        uint64_t offset, const uint64_t *draw_dev, int64_t n, int64_t d, float *z, const gae_bce_prep *prep,
                        double *kl_partial, int64_t kl_capacity, int64_t *n_blocks_out, void *stream);
 
 /* Deferred final reduction.  The last launch of gae_decoder_bce* adds the per-block partial sums to the scalar; the
  * backward pass does not read that scalar, so a training step may run the reduction later, next to other work:
- *   gae_decoder_bce_defer_finalize(&tail)  arms the calling thread: its NEXT gae_decoder_bce / _rows / _padded call
+ *   gae_x_decoder_bce_defer_finalize(&tail)  arms the calling thread: its NEXT gae_decoder_bce / _rows / _padded call
  *                                          launches everything but the reduction and describes it in `tail` (pointers
  *                                          into that call's workspace and outputs: keep them alive); NULL disarms.
- *   gae_adam_step_tail(..., &tail, stream) runs it as one extra block of the optimiser launch (same bits as below),
- *   gae_decoder_bce_finalize(&tail, stream) as a launch of its own (e.g. no optimiser step follows).
+ *   gae_x_adam_step_tail(..., &tail, stream) runs it as one extra block of the optimiser launch (same bits as below),
+ *   gae_x_decoder_bce_finalize(&tail, stream) as a launch of its own (e.g. no optimiser step follows).
  * Until one of the two has run on the stream, loss_out is not written and draw_dev not advanced.  A tail with
  * loss_out == NULL (written for an empty row window) is a no-op. */
 typedef struct gae_bce_tail {
@@ -676,12 +667,12 @@ typedef struct gae_bce_tail {
     const double *scal;                               /* device-side {pos_weight, 1 / N^2, pad pairs} of a padded batch, or NULL */
     /* optional additive term (set by the caller after the loss call filled the rest; all zero = none): the block also
      * adds kl_partial[0 .. n_kl) (doubles), scales the sum, and writes loss_out = rec + kl, kl_out, rec_out -- the KL
-     * term of a VGAE (gae_vgae_head_prep) without launches of its own */
+     * term of a VGAE (gae_x_vgae_head_prep) without launches of its own */
     const double *kl_partial; int64_t n_kl; double kl_scale;
     float *kl_out, *rec_out;                          /* may be NULL */
 } gae_bce_tail;
-int gae_decoder_bce_defer_finalize(gae_bce_tail *tail_out);
-int gae_decoder_bce_finalize(const gae_bce_tail *tail, void *stream);
+int gae_x_decoder_bce_defer_finalize(gae_bce_tail *tail_out);
+int gae_x_decoder_bce_finalize(const gae_bce_tail *tail, void *stream);
 
 /* Reference-shaped loss on MATERIALISED logits: F.binary_cross_entropy_with_logits(adj_logits, adj,
  * pos_weight=pos_weight) with the default mean reduction (gae_dgl/train_inductive.py:48) and dLoss/dLogits.  Used
@@ -721,7 +712,7 @@ typedef struct gae_adam_tensor {
     float *exp_avg_sq;     /* [n] second moment, in place      (device) */
     int64_t n;
     /* Deferred reduction (n_partials > 0): the gradient has not been added up yet -- it is the list of partial sums
-     * gae_xw_wgrad_partials / gae_linear_bwd_partials left in their workspace,
+     * gae_x_xw_wgrad_partials / gae_x_linear_bwd_partials left in their workspace,
      *     grad[e] = sum over q < n_partials, in order, of partials[q * partial_stride + (e / row_len) * row_pitch + e % row_len].
      * The kernel adds the list (deterministic order), WRITES the sum to grad[e] and applies the update: the separate
      * reduction launch of every weight gradient disappears from a training step (two kernel nodes of ~5 us each).
@@ -731,9 +722,9 @@ typedef struct gae_adam_tensor {
 } gae_adam_tensor;
 int gae_adam_step(const gae_adam_tensor *tensors_host, int32_t n_tensors, float lr, float beta1, float beta2,
                   float eps, float weight_decay, uint64_t *state_dev, void *stream);
-/* ... plus the deferred final reduction of the step's loss (gae_decoder_bce_defer_finalize; tail may be NULL) as one
+/* ... plus the deferred final reduction of the step's loss (gae_x_decoder_bce_defer_finalize; tail may be NULL) as one
  * more block of the same launch: one kernel node fewer in a captured training step. */
-int gae_adam_step_tail(const gae_adam_tensor *tensors_host, int32_t n_tensors, float lr, float beta1, float beta2,
+int gae_x_adam_step_tail(const gae_adam_tensor *tensors_host, int32_t n_tensors, float lr, float beta1, float beta2,
                        float eps, float weight_decay, uint64_t *state_dev, const gae_bce_tail *tail, void *stream);
 
 #ifdef __cplusplus

@@ -46,7 +46,7 @@ def test_argument_errors_do_not_need_a_gpu():
     rc = lib.gae_spmm_csr(None, None, 4, 4, None, 8, None, 8, 8, 7, None, None, None, None, 0, 0, None)
     assert rc == -4
     assert lib.gae_spmm_workspace_bytes(None, 32) == 0
-    assert lib.gae_spmm_plan_count(None, 8, 0, 512, None, None) == -6
+    assert lib.gae_spmm_plan_sizes(None, 8, 0, 256, 512, None, None, 0, None) == -6
     rc = lib.gae_linear_fwd(None, 4, 4, 4, None, None, 4, 9, None, 4, None, 0, None)
     assert rc == -4
     rc = lib.gae_dropout_mask(None, 8, ctypes.c_float(1.5), 0, 0, None, None)

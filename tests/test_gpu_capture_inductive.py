@@ -150,7 +150,7 @@ def test_captured_step_grows_and_rejects():
 
 
 def test_batch_select_and_plan_next_walk_an_epoch_order():
-    """gae_batch_select and the fused gae_batch_plan_next: ids of batch `cursor` of an uploaded order, the cursor
+    """gae_batch_select and the fused gae_x_batch_plan_next: ids of batch `cursor` of an uploaded order, the cursor
     advances on the device, prefix sums equal gae_batch_plan's on the same ids (bit-exact integer work)"""
     from gae_dgl_amd import ops
     ds, _ = _dataset(200)
@@ -292,7 +292,7 @@ def test_adam_resume_survives_reload_and_capture():
 
 @pytest.mark.parametrize("B", [24, 128, 1000])
 def test_one_launch_collate_equals_plan_then_gather(B):
-    """gae_batch_gather_next (select + plan + gather in one launch) == gae_batch_plan_next followed by gae_batch_gather:
+    """gae_x_batch_gather_next (select + plan + gather in one launch) == gae_x_batch_plan_next followed by gae_batch_gather:
     ids, prefix sums, CSR, features, packed table and counts bit for bit over consecutive batches of an epoch order; the
     device cursor advances once per launch; a batch that does not fit is cut to the prefix that does"""
     from gae_dgl_amd import ops

@@ -1,5 +1,5 @@
-"""The deferred final reduction of the fused loss (gae_decoder_bce_defer_finalize / gae_decoder_bce_finalize /
-gae_adam_step_tail): the same bits as the loss's own last launch, whoever runs it."""
+"""The deferred final reduction of the fused loss (gae_x_decoder_bce_defer_finalize / gae_x_decoder_bce_finalize /
+gae_x_adam_step_tail): the same bits as the loss's own last launch, whoever runs it."""
 import copy
 import ctypes
 
@@ -22,7 +22,7 @@ def _graph(n, seed=0, deg=4):
 
 @pytest.mark.parametrize("n,sym", [(700, 1), (2500, 2), (9000, 1)])
 def test_standalone_finalize_gives_the_same_loss(n, sym, tuning):
-    """armed call + gae_decoder_bce_finalize == plain call (loss bits, gradient bits, draw counter); the armed call
+    """armed call + gae_x_decoder_bce_finalize == plain call (loss bits, gradient bits, draw counter); the armed call
     itself leaves the scalar and the counter alone"""
     from gae_dgl_amd import _lib, ops
     tuning("bce_sym", sym)
@@ -42,7 +42,7 @@ def test_standalone_finalize_gives_the_same_loss(n, sym, tuning):
         assert float(loss_b) == -7.0 and int(draws_b) == 0
         tail, keep = ops.pending_loss_tail()
         assert ops.pending_loss_tail() is None
-        _lib.call("gae_decoder_bce_finalize", ctypes.byref(tail), ops._stream())
+        _lib.call("gae_x_decoder_bce_finalize", ctypes.byref(tail), ops._stream())
     torch.cuda.synchronize()
     assert int(draws_a) == int(draws_b) == 1
     assert torch.equal(loss_a, loss_b) and torch.equal(dz_a, dz_b) and torch.equal(mask_a, mask_b)
@@ -95,7 +95,7 @@ def test_adam_tail_block_equals_the_separate_launch(n):
     assert runs[False][2] == runs[True][2] == 6
     for a, b in zip(runs[False][1], runs[True][1]):
         assert torch.equal(a, b)
-    assert not ops._PENDING_TAIL
+    assert not ops.current_step().tails and not ops.current_step().partials
 
 
 def test_a_loss_fn_of_the_callers_keeps_its_reduction_launch():
@@ -121,8 +121,8 @@ def test_a_loss_fn_of_the_callers_keeps_its_reduction_launch():
 @pytest.mark.parametrize("n,dims,dropout", [(900, [32, 16], 0.1), (900, [32, 16], 0.0), (8700, [32, 16], 0.1),
                                              (1500, [32, 8], 0.1), (1300, [16], 0.1), (2100, [48, 24, 12], 0.2)])
 def test_prepare_step_in_the_last_layers_epilogue(n, dims, dropout):
-    """reconstruction_loss with the loss's prepare step folded into the last encoder launch (gae_gcn_layer_fused_prep
-    + gae_decoder_bce_prepared) against the three-launch form: same mask bits, same loss and gradients up to the
+    """reconstruction_loss with the loss's prepare step folded into the last encoder launch (gae_x_gcn_layer_fused_prep
+    + gae_x_decoder_bce_prepared) against the three-launch form: same mask bits, same loss and gradients up to the
     order of the fp64 column sums"""
     import gae_dgl_amd as G
     from gae_dgl_amd import ops
@@ -293,4 +293,4 @@ def test_vgae_captured_step_with_the_loss_tail_in_adam():
     assert runs["eager"][0][2:] == runs["captured"][0][2:]
     for a, b in zip(runs["eager"][1], runs["captured"][1]):
         assert torch.equal(a, b)
-    assert not ops._PENDING_TAIL
+    assert not ops.current_step().tails and not ops.current_step().partials

@@ -1074,7 +1074,7 @@ def test_vgae_matches_oracle(dtype, tol, n_small, dev):
 
 
 def test_vgae_fused_heads_equal_two_layers(dev):
-    """mu and log sigma heads as ONE fused launch (gae_gcn_layer_fused2 + the packed head kernels) == the two GCN layers
+    """mu and log sigma heads as ONE fused launch (gae_x_gcn_layer_fused2 + the packed head kernels) == the two GCN layers
     they replace: forward values bit for bit (same aggregation order, same per-output product), every parameter gradient
     within the fp32 tolerance (one dW launch for both heads, another summation order for dH)"""
     import gae_dgl_amd as G

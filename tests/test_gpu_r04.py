@@ -143,3 +143,52 @@ def test_loss_fp16_pieces_match_fp64_and_fall_back_beyond_their_range():
     finally:
         _lib.call("gae_tuning_set", b"bce_s_bf16", 3)
         _lib.call("gae_tuning_set", b"bce_sym", 1)
+
+
+def test_two_models_interleaved_in_one_step_context():
+    """the deferred partial sums / loss reductions live in the step's context object (ops.StepContext),
+    not in address-keyed module tables.  Two models whose forward, backward and optimiser launches INTERLEAVE inside one
+    context end exactly where each ends when it trains alone without any deferral; a context that is left with
+    unconsumed partial sums raises, and nothing survives the context."""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, optim
+    rng = np.random.default_rng(21)
+    ga, _, _ = sym_graph(rng, 3000, 9000)
+    gb, _, _ = sym_graph(rng, 1700, 6000)
+    Xa = torch.from_numpy(rng.standard_normal((3000, 300)).astype(np.float32)).to(DEV)     # transform-first layer 1
+    Xb = torch.from_numpy(rng.standard_normal((1700, 40)).astype(np.float32)).to(DEV)      # fused narrow layers
+
+    def make():
+        torch.manual_seed(2)
+        a = G.GAE(300, [32, 16]).to(DEV); b = G.GAE(40, [32, 16]).to(DEV)
+        a.decoder.dropout = b.decoder.dropout = 0.0
+        return a, b, optim.Adam(a.parameters(), lr=1e-2), optim.Adam(b.parameters(), lr=1e-2)
+
+    a0, b0, oa0, ob0 = make()                                   # each alone, nothing deferred
+    for _ in range(2):
+        for m, o, g, X in ((a0, oa0, ga, Xa), (b0, ob0, gb, Xb)):
+            g.ndata['h'] = X
+            loss = m.reconstruction_loss(g); o.zero_grad(); ops.backward(loss, list(m.parameters())); o.step()
+    a1, b1, oa1, ob1 = make()
+    losses = []
+    for _ in range(2):
+        with ops.StepContext(defer_grads=True, defer_loss=True) as step:
+            ga.ndata['h'] = Xa; la = a1.reconstruction_loss(ga)
+            gb.ndata['h'] = Xb; lb = b1.reconstruction_loss(gb)
+            ops.backward(la, list(a1.parameters()))
+            ops.backward(lb, list(b1.parameters()))
+            assert len(step.partials) >= 4                      # both models' weight gradients wait in THIS context
+            ob1.step()                                          # the other order than the backward passes
+            oa1.step()
+            assert not step.partials
+        assert not ops.current_step().partials and not ops.current_step().tails
+        losses.append((float(la), float(lb)))
+    for m0, m1 in ((a0, a1), (b0, b1)):
+        for p0, p1 in zip(m0.parameters(), m1.parameters()):
+            assert torch.equal(p0, p1)
+    assert all(np.isfinite(v) for pair in losses for v in pair)
+    with pytest.raises(ops.GaeHipError):
+        with ops.StepContext(defer_grads=True):
+            gb.ndata['h'] = Xb
+            ops.backward(b1.reconstruction_loss(gb), list(b1.parameters()))     # no optimiser step inside
+    assert not ops.current_step().partials
