@@ -320,7 +320,7 @@ __global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
             const int64_t row = rbeg + 4 * (wave + 8 * (U * it + u)) + g;
             const bool ok = row < rend;
             s.x[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (ok && DBG != 2) ? unsigned(row) * a.ldx_bytes + xcol : kBehind, 0, 0);
-            const unsigned go = (ok && j_ok) ? unsigned(row) * a.ldg_bytes + gcol : kBehind;
+            const unsigned go = (ok && j_ok && DBG != 3) ? unsigned(row) * a.ldg_bytes + gcol : kBehind;
             const unsigned mo = (ok && j_ok) ? unsigned(row) * a.ldgm_bytes + gcol : kBehind;
             if constexpr (NH == 2) {
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
     const int64_t my_groups = groups > wave ? (groups - wave + 7) / 8 : 0;       // ... of this wave
     const int64_t iters = (my_groups + U - 1) / U;
 #define GAE_PIN() __builtin_amdgcn_sched_barrier(0)
-    if (iters > 0) {
+    if (iters > 0 && DBG != 4) {
         Stage st[NS];
 #pragma unroll
         for (int d = 0; d < NS - 1; ++d) issue(st[d], d);
@@ -457,7 +457,7 @@ gae::Knob g_xw{1};            // "xw": 0 = never use this family (dense.hip kern
 gae::Knob g_xw_depth{0};      // "xw_depth" (experiments): other ring depths of the fp32 kernels (forward 3 / 4 / 5 tiles, default 2;
                               // backward (stages, groups) (2, 4) / (3, 4) / (4, 4) / (6, 2), default (4, 2))
 gae::Knob g_xw_xcd{1};        // "xw_xcd": XCD-aware block order of the backward (1) or slice-major ids (0); same sums
-gae::Knob g_xw_dbg{0};        // "xw_dbg" (experiments, wrong results): 1 = forward without MFMAs, 2 = without X loads
+gae::Knob g_xw_dbg{0};        // "xw_dbg" (experiments, wrong results): 1 = without MFMAs, 2 = without X loads; backward also 3 = without G loads, 4 = without its main loop
 
 FwdPlan fwd_plan(int64_t n, int K, int elem)
 {
@@ -638,6 +638,8 @@ int xtg_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const flo
     if (elem == 4) {
         if (wide && g_xw_dbg == 1) GAE_XTG(float, 2, 1);
         else if (wide && g_xw_dbg == 2) GAE_XTG(float, 2, 2);
+        else if (wide && g_xw_dbg == 3) GAE_XTG(float, 2, 3);
+        else if (wide && g_xw_dbg == 4) GAE_XTG(float, 2, 4);
         else if (wide && g_xw_depth == 2) GAE_XTG(float, 2, 0, 2, 4);
         else if (wide && g_xw_depth == 4) GAE_XTG(float, 2, 0, 4, 4);
         else if (wide && g_xw_depth == 3) GAE_XTG(float, 2, 0, 3, 4);
