@@ -27,6 +27,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// 8 fp32 values -> bf16 hi and bf16 lo = bf16(v - hi) fragments (K = 8 consecutive steps of a 32x32x16 MFMA)
+__device__ __forceinline__ void split8(const float *v, s16x8 &hi, s16x8 &lo)
+{
+    gae::v4s h0, l0, h1, l1;
+    gae::split_bf16x4(gae::v4f{v[0], v[1], v[2], v[3]}, h0, l0);
+    gae::split_bf16x4(gae::v4f{v[4], v[5], v[6], v[7]}, h1, l1);
+    hi = s16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    lo = s16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+}
+// D += A B with A = ah + al, B = bh + bl on the bf16 matrix pipe, the three leading terms (the library's rule for
+// weight-gradient products, knob atb_bf16: 16 mantissa bits per operand, fp32 accumulation), smallest terms first
+__device__ __forceinline__ f32x16 mfma_split3(const s16x8 &ah, const s16x8 &al, const s16x8 &bh, const s16x8 &bl, f32x16 c)
+{
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
+    return c;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // gae_linear2_fwd:  Y1 = act(A W1^T + b1) [n, J1],  T = Y1 W2^T [n, J2];  K1 <= 64, J1 <= 32, J2 <= 32.
 // Both products are evaluated TRANSPOSED (D1[j][row], D2[j2][row]): the rows of the tile sit in the lanes, so
@@ -166,7 +187,7 @@ __global__ __launch_bounds__(256) void linear2_rows_kernel(const float *__restri
 // RECOMP: Y1 is not read but RECOMPUTED from the tile of M1 that the pass reads anyway, Y1 = act1(M1 W1^T + b1), with
 // the forward's own products in the forward's own order (gae_linear2_fwd: same k sequence, same fma chain -> the same
 // bits): the forward then never stores Y1 (2 GiB per step on R-MAT s24) and this pass never reads it.
-template <int KB2, bool RELU, bool RECOMP>
+template <int KB2, bool RELU, bool RECOMP, bool BF = false>
 __global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restrict__ G, int64_t ldg,
                                                             const float *__restrict__ dZ, int64_t lddz,
                                                             const float *__restrict__ Y1, int64_t ldy1,
@@ -177,7 +198,15 @@ __global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restr
                                                             const float *__restrict__ W1, int64_t ldw1,
                                                             const float *__restrict__ b1)
 {
-    __shared__ float red[2][34 * 64];
+    // RECOMP: the tile's rows of M1 and G arrive once, rows in the lanes (16-byte loads); the column layout the two
+    // weight-gradient products need (lane = column, registers = rows) comes out of a per-wave LDS slab instead of 32 more
+    // 4-byte loads per tile -- those kept the CU's address unit busier than its matrix pipes.  The slabs share their
+    // memory with the buffers of the final reduction.
+    constexpr int LDS_LD = 36;                          // floats per slab row: 32 + 4 (bank spread, 16-byte aligned)
+    constexpr int SLAB = 2 * 32 * LDS_LD;               // M1 tile + G tile of one wave
+    constexpr int RED = 2 * 34 * 64;
+    __shared__ __attribute__((aligned(16))) float lds_all[(RECOMP && 4 * SLAB > RED) ? 4 * SLAB : RED];
+    float (*red)[34 * 64] = reinterpret_cast<float (*)[34 * 64]>(lds_all);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -222,7 +251,7 @@ __global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restr
 
     const int J24 = (J2 + 3) & ~3;
     const int jy = i < J1 ? i : J1 - 1, km = i < K1 ? i : K1 - 1, jg = i < J2 ? i : J2 - 1;
-    struct Stage { float g[KB2][4], z[KB2][4], y[16], m[16], gc[16]; };
+    struct Stage { float g[KB2][4], z[KB2][4], y[16], m[RECOMP ? 1 : 16], gc[RECOMP ? 1 : 16]; };
     auto load = [&](Stage &st, int64_t row0) {
         const int64_t row = row0 + i < n ? row0 + i : n - 1;
 #pragma unroll
@@ -241,16 +270,41 @@ __global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restr
                 st.y[4 * kb] = m4.x; st.y[4 * kb + 1] = m4.y; st.y[4 * kb + 2] = m4.z; st.y[4 * kb + 3] = m4.w;
             }
         }
+        if (!RECOMP) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t rr = row0 + rho(r, h) < n ? row0 + rho(r, h) : n - 1;
-            if (!RECOMP) st.y[r] = Y1[rr * ldy1 + jy];
-            st.m[r] = M1[rr * ldm1 + km];
-            st.gc[r] = G[rr * ldg + jg];
+            for (int r = 0; r < 16; ++r) {
+                const int64_t rr = row0 + rho(r, h) < n ? row0 + rho(r, h) : n - 1;
+                st.y[r] = Y1[rr * ldy1 + jy];
+                st.m[r] = M1[rr * ldm1 + km];
+                st.gc[r] = G[rr * ldg + jg];
+            }
         }
     };
     auto tile = [&](const Stage &st, int64_t row0) {
         const bool rv = row0 + i < n;
+        float mcol[16], gcol[16];                        // column layout: M1[rho(r, h)][k = i], G[rho(r, h)][j2 = i]
+        if (!RECOMP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { mcol[r] = st.m[r]; gcol[r] = st.gc[r]; }
+        }
+        if (RECOMP) {
+            float *lm = lds_all + wave * SLAB, *lg = lm + 32 * LDS_LD;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+                *reinterpret_cast<float4 *>(lm + i * LDS_LD + 8 * kb + 4 * h) =
+                    make_float4(st.y[4 * kb], st.y[4 * kb + 1], st.y[4 * kb + 2], st.y[4 * kb + 3]);
+#pragma unroll
+            for (int kb = 0; kb < KB2; ++kb)
+                *reinterpret_cast<float4 *>(lg + i * LDS_LD + 8 * kb + 4 * h) =
+                    make_float4(st.g[kb][0], st.g[kb][1], st.g[kb][2], st.g[kb][3]);
+            __builtin_amdgcn_wave_barrier();             // (one wave writes and reads its own slab: LDS operations of a
+#pragma unroll                                           //  wave execute in order, no block barrier)
+            for (int r = 0; r < 16; ++r) {
+                mcol[r] = lm[rho(r, h) * LDS_LD + km];
+                gcol[r] = lg[rho(r, h) * LDS_LD + jg];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         f32x16 dh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = 0.f;
@@ -280,15 +334,36 @@ __global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restr
                 yv[r] = y;
             }
         }
+        // BF: the two weight-gradient products of the tile (K = its 32 rows) as 2 x 3 bf16 MFMAs of K = 16 each instead of
+        // 2 x 16 fp32 MFMAs of K = 2 (1024 -> 192 matrix-pipe cycles per product and tile): the pass is then bound by
+        // its operand stream, not by the matrix pipe.  A lane's 8 K-steps of MFMA t are its rows rho(8 t + 0..7, h) in
+        // BOTH operands, so no data moves between lanes.
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool rr = row0 + rho(r, h) < n;
-            const float y = (rr && i < J1) ? (RECOMP ? yv[r] : st.y[r]) : 0.f;
-            float dy = rr ? dh[r] : 0.f;                       // dH[rho(r, h)][j = i]
-            if (RELU) dy = y > 0.f ? dy : 0.f;
-            sdb1 += dy;
-            accW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dy, (rr && i < K1) ? st.m[r] : 0.f, accW1, 0, 0, 0);
-            accW2 = __builtin_amdgcn_mfma_f32_32x32x2f32((rr && i < J2) ? st.gc[r] : 0.f, y, accW2, 0, 0, 0);
+        for (int t = 0; t < 2; ++t) {
+            float dyv[8], yy[8], mv[8], gv[8];
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = 8 * t + r8;
+                const bool rr = row0 + rho(r, h) < n;
+                const float y = (rr && i < J1) ? (RECOMP ? yv[r] : st.y[r]) : 0.f;
+                float dy = rr ? dh[r] : 0.f;                       // dH[rho(r, h)][j = i]
+                if (RELU) dy = y > 0.f ? dy : 0.f;
+                sdb1 += dy;
+                const float m = (rr && i < K1) ? mcol[r] : 0.f, g = (rr && i < J2) ? gcol[r] : 0.f;
+                if (BF) {
+                    dyv[r8] = dy; yy[r8] = y; mv[r8] = m; gv[r8] = g;
+                } else {
+                    accW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dy, m, accW1, 0, 0, 0);
+                    accW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(g, y, accW2, 0, 0, 0);
+                }
+            }
+            if (BF) {
+                s16x8 ah, al, bh, bl;
+                split8(dyv, ah, al); split8(mv, bh, bl);
+                accW1 = mfma_split3(ah, al, bh, bl, accW1);
+                split8(gv, ah, al); split8(yy, bh, bl);
+                accW2 = mfma_split3(ah, al, bh, bl, accW2);
+            }
         }
     };
     const int64_t n_tiles = (n + 31) / 32;
@@ -322,6 +397,7 @@ __global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restr
             }
         }
     }
+    if (RECOMP) __syncthreads();       // the slabs become the reduction buffers
     // ---- column sums: db1 over the two halves; db2 over the 32 rows-in-lanes (fixed shuffle tree)
     sdb1 += __shfl_xor(sdb1, 32, 64);
 #pragma unroll
@@ -461,22 +537,22 @@ extern "C" int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, 
     float *partial = static_cast<float *>(workspace);
     const dim3 grid{unsigned(lay[0])};
     const int kb2 = int((f_out + 7) / 8);
+    int64_t bfk = 1;
+    gae_tuning_get("atb_bf16", &bfk);       // the library's switch for weight-gradient products on the bf16 matrix pipe
+#define GAE_G2L(KBV, RL, RC, BFV)                                                                                        \
+    hipLaunchKernelGGL((gcn2_bwd_rows_kernel<KBV, RL, RC, BFV>), grid, dim3(256), 0, s, G, ldg, dZ, lddz, Y1, ldy1, M1,   \
+                       ldm1, W2, ldw2, n, int(f_in), int(f_mid), int(f_out), tpw, partial, lay[1], W1, ldw1, b1)
 #define GAE_G2B(KBV, RL)                                                                                                 \
     do {                                                                                                                 \
-        if (recomp)                                                                                                      \
-            hipLaunchKernelGGL((gcn2_bwd_rows_kernel<KBV, RL, true>), grid, dim3(256), 0, s, G, ldg, dZ, lddz, Y1, ldy1,  \
-                               M1, ldm1, W2, ldw2, n, int(f_in), int(f_mid), int(f_out), tpw, partial, lay[1], W1, ldw1,  \
-                               b1);                                                                                      \
-        else                                                                                                             \
-            hipLaunchKernelGGL((gcn2_bwd_rows_kernel<KBV, RL, false>), grid, dim3(256), 0, s, G, ldg, dZ, lddz, Y1, ldy1, \
-                               M1, ldm1, W2, ldw2, n, int(f_in), int(f_mid), int(f_out), tpw, partial, lay[1], W1, ldw1,  \
-                               b1);                                                                                      \
+        if (recomp) { if (bfk) GAE_G2L(KBV, RL, true, true); else GAE_G2L(KBV, RL, true, false); }                       \
+        else { if (bfk) GAE_G2L(KBV, RL, false, true); else GAE_G2L(KBV, RL, false, false); }                            \
     } while (0)
 #define GAE_G2K(RL)                                                                                                      \
     do { if (kb2 == 1) GAE_G2B(1, RL); else if (kb2 == 2) GAE_G2B(2, RL); else if (kb2 == 3) GAE_G2B(3, RL); else GAE_G2B(4, RL); } while (0)
     if (act1 == GAE_ACT_RELU) GAE_G2K(true); else GAE_G2K(false);
 #undef GAE_G2K
 #undef GAE_G2B
+#undef GAE_G2L
     GAE_CHECK_LAUNCH("gcn2_bwd_rows_kernel");
     if (layout_out) {
         for (int k = 0; k < 5; ++k) layout_out[k] = lay[k];
