@@ -12,6 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
+if TAG == "r04c":          # round 4 collects into gpurun_out/r04c (r04/ holds the working measurements); files are r04_*
+    TAG = "r04"
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -33,7 +35,7 @@ def pmc_means(d, needles=("spmm",)):
 
 benches = {}
 for name in ("pubmed", "pubmed_reference_order", "cora", "citeseer", "vgae", "zinc", "zinc128", "zinc_eager", "zinc128_eager",
-             "rmat_s24_1gpu"):
+             "rmat_s24_1gpu", "rmat_s24_1gpu_aggregate_first"):
     p = os.path.join(SRC, f"bench_{name}.json")
     if os.path.exists(p):
         benches[name] = last_json(p)
@@ -43,7 +45,7 @@ for w in ("pubmed", "cora", "citeseer", "vgae", "zinc", "zinc128", "rmat"):
     if os.path.exists(st):
         shutil.copy(st, os.path.join(DST, f"{TAG}_{w}_step_kernel_stats.csv"))
         shutil.copy(os.path.join(SRC, f"{w}_step_kernel_stats_top.txt"), os.path.join(DST, f"{TAG}_{w}_step_kernel_stats_top.txt"))
-for f in ("xw_bench.txt", "xw_sweep_pubmed.txt", "linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt", "bce_bench_zinc.txt",
+for f in ("xtg_probe.txt", "zinc_l1.txt", "loss_condition.txt", "bce_bench_cora.txt", "plan_build_time.txt", "xw_bench.txt", "xw_sweep_pubmed.txt", "linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt", "bce_bench_zinc.txt",
           "probe_gather_l2.txt", "probe_gather_l2b.txt", "probe_valu_rate.txt", "probe_inst_cost.txt",
           "probe_mfma32_check.txt"):
     if os.path.exists(os.path.join(SRC, f)):
@@ -60,7 +62,7 @@ shapes = {"pubmed500": ("pubmed-F500", "pubmed", 500), "pubmed500_plain": ("pubm
           "pubmed32": ("pubmed-F32", "pubmed", 32), "citeseer3703": ("citeseer-F3703", "citeseer", 3703),
           "cora1433": ("cora-F1433", "cora", 1433), "zincb39": ("zinc-batch4096-F39", "zinc", 39),
           "zinc32": ("zinc250k-F32", "zinc", 32), "zinc39": ("zinc250k-F39-ld40", "zinc", 39),
-          "rmat32": ("rmat-s24-F32", "rmat", 32)}
+          "rmat32": ("rmat-s24-F32", "rmat", 32), "rmat16": ("rmat-s24-F16", "rmat", 16)}
 for sh, (key, graph, F) in shapes.items():
     d = os.path.join(SRC, f"pmc_{sh}")
     if not os.path.isdir(d):
