@@ -22,6 +22,19 @@ def last_json(path):
     return json.loads(lines[-1])
 
 
+def pmc_sums(d, needles=("spmm",)):
+    """(kernel, counter) -> (sum over all recorded launches, number of launches)"""
+    out = {}
+    for f in sorted(glob.glob(os.path.join(d, "p*", "pmc_counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            if not any(t in r["Kernel_Name"] for t in needles):
+                continue
+            k = (r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0], r["Counter_Name"])
+            a = out.setdefault(k, [0.0, 0])
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    return out
+
+
 def pmc_means(d, needles=("spmm",)):
     out = {}
     for f in sorted(glob.glob(os.path.join(d, "p*", "pmc_counter_collection.csv"))):
@@ -74,7 +87,16 @@ for sh, (key, graph, F) in shapes.items():
     log = open(os.path.join(SRC, f"pmc_{sh}.txt")).read() if os.path.exists(os.path.join(SRC, f"pmc_{sh}.txt")) else ""
     done = [l for l in open(os.path.join(d, "p1.log")).read().splitlines() if l.startswith("done")]
     n, nnz = (int(done[0].split()[2]), int(done[0].split()[3])) if done else (0, 0)
-    traffic[key] = {"kernel": main, "launch": done[0] if done else "", "fetch_kib_raw": fetch, "write_kib": write,
+    # a product on a skew plan is SEVERAL kernels (empty-row fill, light rows, two segment launches, two combines):
+    # its traffic is the sum over all of them per call of the product (round 3 filed one mean segment launch: half)
+    sums = pmc_sums(d)
+    calls = min(v[1] for (k, c), v in sums.items() if c == "FETCH_SIZE") if sums else 1
+    fetch_all = sum(v[0] for (k, c), v in sums.items() if c == "FETCH_SIZE") / calls
+    write_all = sum(v[0] for (k, c), v in sums.items() if c == "WRITE_SIZE") / calls
+    if len(kernels) > 1:
+        fetch, write = fetch_all, write_all
+    traffic[key] = {"kernel": main if len(kernels) == 1 else "all %d kernels of the product: " % len(kernels) + ", ".join(kernels),
+                    "launch": done[0] if done else "", "fetch_kib_raw": fetch, "write_kib": write,
                     "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
                     "alg_bytes": W.spmm_alg_bytes(n, n, nnz, F, 4) if n else None,
                     "tcc_hit": m.get((main, "TCC_HIT_sum")), "tcc_miss": m.get((main, "TCC_MISS_sum"))}

@@ -36,7 +36,9 @@ elif name in ("zinc", "zincb"):              # whole set / the first 4096 molecu
     s, d = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
     bd = None if a.plain else ops.BlockDiag(gp, dev)
 else:
-    s, d = W.rmat_edges(a.rmat_scale, 16, device=dev)
+    # (few large chunks: rocprofv3 --pmc segfaults on the ~10^4 generator dispatches of the default chunking; the
+    #  graph has the same parameters, not the same edges, as the bench's)
+    s, d = W.rmat_edges(a.rmat_scale, 16, device=dev, chunk=1 << 26)
     n = 1 << a.rmat_scale
 ip, ix = ops.csr_from_coo(d, s, n, n)
 H = ops.pad_rows(torch.rand(n, F, device=dev))
