@@ -673,7 +673,7 @@ __host__ __device__ inline int64_t sym_strip_offset(int64_t I, int64_t NP, int64
 // transposed copy of every tile (16 ds_write_b16 per thread and tile, 8.7 KB of LDS): Pubmed 170 -> 166 us, a ZINC
 // batch 2.92 -> 2.88 ms.  TRV = false keeps the round-2 form (knob "bce_sym_tr" = 0).
 template <bool WITH_GRAD, int RI, bool TRV, bool S3 = false, bool F16 = false, bool PERSIST = false>
-__global__ __launch_bounds__(256, RI == 2 ? 3 : 2) void bce_dense_sym_kernel(
+__global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_sym_kernel(
     const float *__restrict__ Zt /*[n][16]*/, const unsigned short *__restrict__ Zhi,
     const unsigned short *__restrict__ Zlo, int64_t n, int64_t cols_per_chunk,
     float *__restrict__ O_partial /*[chunks][n][16]*/, float *__restrict__ Wmir,
@@ -1533,7 +1533,8 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
                        lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks),                                    \
                        g_bce_strip_store >= 0 ? g_bce_strip_store : (n >= 32768 ? 1 : 0), range_flag, FM, ticket,  \
                        unsigned(p.n_splits))
-#define GAE_SYM(WG, R, T) do { if (g_bce_s_bf16 >= 3) { GAE_SYM3(WG, R, T, false, true, 1, false, grid); GAE_SYM3(WG, R, T, true, false, 2, true, dim3(2 * kChipCus)); } \
+#define GAE_SYM(WG, R, T) do { if (g_bce_s_bf16 == 4) GAE_SYM3(WG, R, T, false, true, 0, false, grid);   /* experiments: fp16 pieces WITHOUT the range guard */ \
+    else if (g_bce_s_bf16 >= 3) { GAE_SYM3(WG, R, T, false, true, 1, false, grid); GAE_SYM3(WG, R, T, true, false, 2, true, dim3(2 * kChipCus)); } \
     else if (g_bce_s_bf16 == 2) GAE_SYM3(WG, R, T, true, false, 0, false, grid); else GAE_SYM3(WG, R, T, false, false, 0, false, grid); } while (0)
         if (!dZ) { if (p.sym_pr == 256) GAE_SYM(false, 4, false); else GAE_SYM(false, 2, false); }
         else if (g_bce_sym_tr) { if (p.sym_pr == 256) GAE_SYM(true, 4, true); else GAE_SYM(true, 2, true); }
