@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Experiment: does pinning the gathers of the very long rows of a power-law graph to the L2 that 'owns' the column
+"""[historical: round-2 experiment; ops.hot_indices_for / the torch plan builder are gone -- the device builder of csrc/plan_build.hip writes the tags]
+Experiment: does pinning the gathers of the very long rows of a power-law graph to the L2 that 'owns' the column
 (home = column % 8 = XCD of the block that gathers it) raise the hit rate?  Uses only the existing C ABI: the edges
 of rows with more than T2 in-edges are regrouped into VIRTUAL rows (row, home, chunk of <= SEG edges) and the plan
 arrays are written so that segment s is handled by block s / 4, i.e. XCD (s / 4) % 8 == home of the segment.

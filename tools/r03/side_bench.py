@@ -23,6 +23,6 @@ for name in sys.argv[1:] or ["pubmed", "cora"]:
         _lib.call("gae_tuning_set", b"ell_side", v)
         with ops.deferred_grad_reductions():
             t = time_launches(lambda: ops.gcn_layer_fused_wgrad_raw(ti, tx, dY, n, plan_t, Wt, M, None))
-            ops._PENDING.clear()
+            ops.current_step().partials.clear()
         print(f"   ell_side {v}: with dW / db side work {t*1e6:6.2f} us")
     _lib.call("gae_tuning_set", b"ell_side", 14)
