@@ -54,7 +54,7 @@ __device__ __forceinline__ f32x16 mfma_split3(const s16x8 &ah, const s16x8 &al, 
 // the accumulator registers of the first product ARE the B operands of the second (step r, half h <-> j = rho(r, h)).
 // ---------------------------------------------------------------------------------------------------------------
 template <int KB>
-__global__ __launch_bounds__(256) void linear2_rows_kernel(const float *__restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, 3) void linear2_rows_kernel(const float *__restrict__ A, int64_t lda,
                                                            const float *__restrict__ W1, int64_t ldw1,
                                                            const float *__restrict__ b1, int act1,
                                                            const float *__restrict__ W2, int64_t ldw2,
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void linear2_rows_kernel(const float *__restri
 // the forward's own products in the forward's own order (gae_linear2_fwd: same k sequence, same fma chain -> the same
 // bits): the forward then never stores Y1 (2 GiB per step on R-MAT s24) and this pass never reads it.
 template <int KB2, bool RELU, bool RECOMP, bool BF = false>
-__global__ __launch_bounds__(256) void gcn2_bwd_rows_kernel(const float *__restrict__ G, int64_t ldg,
+__global__ __launch_bounds__(256, (RECOMP && BF) ? 3 : 2) void gcn2_bwd_rows_kernel(const float *__restrict__ G, int64_t ldg,
                                                             const float *__restrict__ dZ, int64_t lddz,
                                                             const float *__restrict__ Y1, int64_t ldy1,
                                                             const float *__restrict__ M1, int64_t ldm1,
