@@ -13,6 +13,7 @@ F32, BF16, U8 = 0, 1, 2
 SPMM_STORE_PAD = 1
 SPMM_TILE = 2
 SPMM_ACCUMULATE = 4
+SPMM_SKIP_ROWS = 8
 SPMM_ELL_WIDTH = 16
 ACT_IDENTITY, ACT_RELU = 0, 1
 
@@ -32,7 +33,7 @@ class SpmmPlan(ctypes.Structure):
                 ("reserved", _i32), ("hot_indices", _p), ("vh_n_rows", _i64), ("vh_n_virtual", _i64), ("vh_rows", _p),
                 ("vh_indptr", _p), ("vh_indices", _p), ("vh_hot_indices", _p), ("vh_identity", _p),
                 ("vh_part_ptr", _p), ("vh_part_pos", _p), ("seg_desc", _p), ("light_desc", _p), ("n_light", _i64),
-                ("mid_indices", _p), ("mid_tagged", _i32), ("reserved2", _i32), ("vh_desc", _p)]
+                ("mid_indices", _p), ("mid_tagged", _i32), ("reserved2", _i32), ("vh_desc", _p), ("skip_rows", _p)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -63,10 +64,12 @@ SIGNATURES = {
     "gae_last_error": (ctypes.c_char_p, []),
     "gae_device_info_get": (_int, [_int, ctypes.POINTER(DeviceInfo)]),
     "gae_spmm_csr_ep": (_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _int, _p, _int, _p]),
-    "gae_linear2_fwd": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _i64, _p, _i64, _p, _i64, _p]),
+    "gae_linear2_fwd": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _p,
+                               _i64, _p]),
+    "gae_linear2_fill_dead": (_int, [_p, _i64, _int, _p, _i64, _i64, _p, _i64, _p, _i64, _p]),
     "gae_gcn2_bwd_dense_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "gae_gcn2_bwd_dense": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p, _p,
-                                  _p, _p, _p, _i64, _p, _p, _i64, _p, _p]),
+                                  _p, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _p, _p]),
     "gae_spmm_plan_sizes": (_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _i64, _p]),
     "gae_spmm_plan_scratch_bytes": (_i64, [_i64, _i64, _i64, _i64, _i32]),
     "gae_spmm_plan_build_rows": (_int, [_p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p,

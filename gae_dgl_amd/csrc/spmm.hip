@@ -516,13 +516,20 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void spmm_fill_empty_kernel(const int32_t *__restrict__ indptr, int64_t n_rows,
                                                               T *__restrict__ M, int64_t ldm, int F, int nvec,
                                                               int store_pad, int accumulate,
-                                                              const float *__restrict__ ep_bias, int ep_act)
+                                                              const float *__restrict__ ep_bias, int ep_act,
+                                                              const uint8_t *__restrict__ skip_rows)
 {
-    const int64_t stride = int64_t(gridDim.x) * 256;
-    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_rows * nvec; t += stride) {
-        const int64_t row = t / nvec;
-        const int f = int(t - row * nvec) * VEC;
+    // one lane group of G = 2^k >= nvec lanes per row (G <= 16; wider rows: the group walks them): the row's two
+    // pointers are read once per group, the stores of a group are one contiguous piece of the row
+    int G = 1;
+    while (G < nvec && G < 16) G <<= 1;
+    const int lig = int(threadIdx.x) % G;
+    const int64_t stride = int64_t(gridDim.x) * (256 / G);
+    for (int64_t row = int64_t(blockIdx.x) * (256 / G) + threadIdx.x / G; row < n_rows; row += stride) {
         if (indptr[row + 1] != indptr[row]) continue;
+        if (skip_rows != nullptr && skip_rows[row]) continue;        // GAE_SPMM_SKIP_ROWS: nobody reads this row
+      for (int fv = lig; fv < nvec; fv += G) {
+        const int f = fv * VEC;
         T *mp = M + row * ldm + f;
         float v[VEC];
 #pragma unroll
@@ -536,6 +543,7 @@ __global__ __launch_bounds__(256) void spmm_fill_empty_kernel(const int32_t *__r
             for (int i = 0; i < VEC; ++i)
                 if (f + i < F) store_scalar(mp + i, v[i]);
         }
+      }
     }
 }
 
@@ -1105,10 +1113,15 @@ int run_spmm(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int6
         const int nvec = (f + VEC - 1) / VEC;
         const int store_pad = ((flags & GAE_SPMM_STORE_PAD) && int64_t(nvec) * VEC <= ldm) ? 1 : 0;
         const int acc_f = (flags & GAE_SPMM_ACCUMULATE) ? 1 : 0;
-        if (!acc_f || epi) {
-            const int64_t want = (n_rows * nvec + 255) / 256;
+        // (skip_rows covering EVERY row without edges -- plan->reserved2 = 1, the caller's word -- leaves the stream nothing)
+        const bool nothing_to_fill = (flags & GAE_SPMM_SKIP_ROWS) && plan->skip_rows != nullptr && plan->reserved2 == 1;
+        if ((!acc_f || epi) && !nothing_to_fill) {
+            int fg = 1;
+            while (fg < nvec && fg < 16) fg <<= 1;
+            const int64_t want = (n_rows + 256 / fg - 1) / (256 / fg);
             hipLaunchKernelGGL((spmm_fill_empty_kernel<T, VEC>), dim3(unsigned(want < 16384 ? want : 16384)), dim3(256), 0, s,
-                               indptr, n_rows, m, ldm, f, nvec, store_pad, acc_f, ep_bias, ep_act);
+                               indptr, n_rows, m, ldm, f, nvec, store_pad, acc_f, ep_bias, ep_act,
+                               (flags & GAE_SPMM_SKIP_ROWS) ? plan->skip_rows : nullptr);
             GAE_CHECK_LAUNCH("spmm_fill_empty_kernel");
         }
         rc = dispatch_rowgroup2<T, VEC>(indptr, indices, n_rows, h, ldh, m, ldm, f, rs, cs, g_spmm_rpg, g_spmm_nt, n_cols,

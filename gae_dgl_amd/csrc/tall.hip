@@ -60,8 +60,13 @@ __global__ __launch_bounds__(256, 3) void linear2_rows_kernel(const float *__res
                                                            const float *__restrict__ W2, int64_t ldw2,
                                                            float *__restrict__ Y1, int64_t ldy1, float *__restrict__ T,
                                                            int64_t ldt, int64_t n, int K1, int J1, int J2,
-                                                           int tiles_per_wave)
+                                                           int tiles_per_wave, const uint8_t *__restrict__ a_dead,
+                                                           const int32_t *__restrict__ rows)
 {
+    // rows != NULL (list mode): n counts LIST ENTRIES; entry p stands for row rows[p] of A / Y1 / T (ascending).  On a
+    // power-law graph most rows of an aggregate are zero rows (no in-edges): the pass then runs its two products on the
+    // rows that have edges only -- it is bound by the fp32 matrix pipe, not by bytes -- and gae_linear2_fill_dead writes
+    // the one row all the others share.
     constexpr int LDY = 36, LDT = 36;           // floats per LDS row: 32 + 4 (bank spread, 16-byte aligned)
     __shared__ __attribute__((aligned(16))) float lds[4 * (32 * LDY + 32 * LDT)];
     const int lane = threadIdx.x & 63;
@@ -91,14 +96,27 @@ __global__ __launch_bounds__(256, 3) void linear2_rows_kernel(const float *__res
         }
     }
     const int K4 = (K1 + 3) & ~3;
-    struct Stage { float a[KB][4]; };
-    auto load = [&](Stage &st, int64_t row0) {
+    struct Stage { float a[KB][4]; unsigned rid; };
+    // a_dead: rows of A that ARE zero and were never written (an aggregate's rows without edges, GAE_SPMM_SKIP_ROWS):
+    // not read -- on a power-law graph most rows, i.e. most of this pass's input bytes.  The mask byte of a tile is
+    // requested one tile AHEAD of the tile's row loads (in front of them it would add a round trip to every tile).
+    // what a tile needs to know about its row BEFORE its loads: bit 31 = dead (a_dead), bits 0..30 = the row id
+    auto dead_of = [&](int64_t row0) -> unsigned {
         const int64_t row = row0 + i;
-        const float *ap = A + (row < n ? row : n - 1) * lda;
+        const int64_t rc = row < n ? row : n - 1;
+        const unsigned rid = rows != nullptr ? unsigned(rows[rc]) : unsigned(rc);
+        return rid | ((a_dead != nullptr && rows == nullptr && a_dead[rc]) ? 0x80000000u : 0u);
+    };
+    auto load = [&](Stage &st, int64_t row0, unsigned dinfo) {
+        const bool dead = (dinfo >> 31) != 0;
+        const int64_t rc = int64_t(dinfo & 0x7fffffffu);
+        st.rid = unsigned(rc);
+        const float *ap = A + rc * lda;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const int k = kb * 8 + 4 * h;
-            const float4 t4 = *reinterpret_cast<const float4 *>(ap + (k <= K4 - 4 ? k : K4 - 4));
+            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!dead) t4 = *reinterpret_cast<const float4 *>(ap + (k <= K4 - 4 ? k : K4 - 4));
             st.a[kb][0] = t4.x; st.a[kb][1] = t4.y; st.a[kb][2] = t4.z; st.a[kb][3] = t4.w;
         }
     };
@@ -142,10 +160,10 @@ __global__ __launch_bounds__(256, 3) void linear2_rows_kernel(const float *__res
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int r = p * 8 + rsub;
-            const int64_t orow = row0 + r;
+            const int64_t orow = int64_t(__shfl(st.rid, r, 64));     // lane r (h = 0) holds the id of the tile's row r
             const float4 y4 = *reinterpret_cast<const float4 *>(ly + r * LDY + c4);
             const float4 t4 = *reinterpret_cast<const float4 *>(lt + r * LDT + c4);
-            if (orow < n) {
+            if (row0 + r < n) {
                 if (Y1 != nullptr) {
                     float *yp = Y1 + orow * ldy1 + c4;
                     if (c4 + 4 <= J1) *reinterpret_cast<float4 *>(yp) = y4;
@@ -163,12 +181,15 @@ __global__ __launch_bounds__(256, 3) void linear2_rows_kernel(const float *__res
     if (t0 >= n_tiles) return;
     const int64_t t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
     Stage s0, s1;
-    load(s0, t0 * 32);
+    unsigned d1 = dead_of((t0 + 1) * 32), d2;
+    load(s0, t0 * 32, dead_of(t0 * 32));
     for (int64_t tt = t0; tt < t1; tt += 2) {
-        if (tt + 1 < t1) load(s1, (tt + 1) * 32);
+        d2 = dead_of((tt + 2) * 32);
+        if (tt + 1 < t1) load(s1, (tt + 1) * 32, d1);
         tile(s0, tt * 32);
         if (tt + 1 >= t1) break;
-        if (tt + 2 < t1) load(s0, (tt + 2) * 32);
+        d1 = dead_of((tt + 3) * 32);
+        if (tt + 2 < t1) load(s0, (tt + 2) * 32, d2);
         tile(s1, (tt + 1) * 32);
     }
 }
@@ -196,8 +217,14 @@ __global__ __launch_bounds__(256, (RECOMP && BF) ? 3 : 2) void gcn2_bwd_rows_ker
                                                             int K1, int J1, int J2, int64_t tiles_per_wave,
                                                             float *__restrict__ partial, int64_t stride,
                                                             const float *__restrict__ W1, int64_t ldw1,
-                                                            const float *__restrict__ b1)
+                                                            const float *__restrict__ b1,
+                                                            const uint8_t *__restrict__ m1_dead,
+                                                            const uint8_t *__restrict__ g_dead,
+                                                            const int32_t *__restrict__ rows)
 {
+    // rows != NULL (list mode, RECOMP only): n counts LIST ENTRIES, entry p stands for row rows[p] of G / dZ / M1, and
+    // g_dead is indexed by ENTRY (m1_dead is not read: listed rows have an M1 row).  The rows left out are zero rows of
+    // M1; their share of the gradients comes from gcn2_dead_sums_kernel / gcn2_dead_terms_kernel.
     // RECOMP: the tile's rows of M1 and G arrive once, rows in the lanes (16-byte loads); the column layout the two
     // weight-gradient products need (lane = column, registers = rows) comes out of a per-wave LDS slab instead of 32 more
     // 4-byte loads per tile -- those kept the CU's address unit busier than its matrix pipes.  The slabs share their
@@ -252,12 +279,25 @@ __global__ __launch_bounds__(256, (RECOMP && BF) ? 3 : 2) void gcn2_bwd_rows_ker
     const int J24 = (J2 + 3) & ~3;
     const int jy = i < J1 ? i : J1 - 1, km = i < K1 ? i : K1 - 1, jg = i < J2 ? i : J2 - 1;
     struct Stage { float g[KB2][4], z[KB2][4], y[16], m[RECOMP ? 1 : 16], gc[RECOMP ? 1 : 16]; };
-    auto load = [&](Stage &st, int64_t row0) {
-        const int64_t row = row0 + i < n ? row0 + i : n - 1;
+    // (RECOMP) m1_dead / g_dead: rows of M1 / G that ARE zero and were never written (GAE_SPMM_SKIP_ROWS): not read.
+    // dead_of: bit 0 = M1 row dead, bit 1 = G row dead; requested one tile ahead of the tile's loads.
+    // bits 0..29: the row id, bit 30 = M1 row dead, bit 31 = G row dead
+    auto dead_of = [&](int64_t row0) -> unsigned {
+        const int64_t pos = row0 + i < n ? row0 + i : n - 1;
+        unsigned d = (RECOMP && rows != nullptr) ? unsigned(rows[pos]) : unsigned(pos);
+        if (RECOMP && rows == nullptr && m1_dead != nullptr) d |= m1_dead[pos] ? 0x40000000u : 0u;
+        if (RECOMP && g_dead != nullptr) d |= g_dead[pos] ? 0x80000000u : 0u;
+        return d;
+    };
+    auto load = [&](Stage &st, int64_t row0, unsigned dead = 0xffffffffu) {
+        if (dead == 0xffffffffu) dead = unsigned(row0 + i < n ? row0 + i : n - 1);      // (callers without masks / lists)
+        const int64_t row = int64_t(dead & 0x3fffffffu);
+        const bool mdead = (dead & 0x40000000u) != 0, gdead = (dead & 0x80000000u) != 0;
 #pragma unroll
         for (int kb = 0; kb < KB2; ++kb) {
             const int k = kb * 8 + 4 * h, kc = k <= J24 - 4 ? k : J24 - 4;
-            const float4 g4 = *reinterpret_cast<const float4 *>(G + row * ldg + kc);
+            float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!gdead) g4 = *reinterpret_cast<const float4 *>(G + row * ldg + kc);
             const float4 z4 = *reinterpret_cast<const float4 *>(dZ + row * lddz + kc);
             st.g[kb][0] = g4.x; st.g[kb][1] = g4.y; st.g[kb][2] = g4.z; st.g[kb][3] = g4.w;
             st.z[kb][0] = z4.x; st.z[kb][1] = z4.y; st.z[kb][2] = z4.z; st.z[kb][3] = z4.w;
@@ -266,7 +306,8 @@ __global__ __launch_bounds__(256, (RECOMP && BF) ? 3 : 2) void gcn2_bwd_rows_ker
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 const int k = kb * 8 + 4 * h;
-                const float4 m4 = *reinterpret_cast<const float4 *>(M1 + row * ldm1 + (k <= K4 - 4 ? k : K4 - 4));
+                float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!mdead) m4 = *reinterpret_cast<const float4 *>(M1 + row * ldm1 + (k <= K4 - 4 ? k : K4 - 4));
                 st.y[4 * kb] = m4.x; st.y[4 * kb + 1] = m4.y; st.y[4 * kb + 2] = m4.z; st.y[4 * kb + 3] = m4.w;
             }
         }
@@ -375,8 +416,11 @@ __global__ __launch_bounds__(256, (RECOMP && BF) ? 3 : 2) void gcn2_bwd_rows_ker
             // leave one wave per SIMD (252 VGPRs) and nothing to overlap the loads with (measured: 2.28 ms vs 1.36 ms
             // for the form that reads Y1).  Two waves per SIMD cover each other's loads instead.
             Stage s0;
+            unsigned dn = dead_of(t0 * 32);
             for (int64_t tt = t0; tt < t1; ++tt) {
-                load(s0, tt * 32);
+                const unsigned dc = dn;
+                dn = dead_of((tt + 1) * 32);             // (next tile's mask: in flight under this tile)
+                load(s0, tt * 32, dc);
                 __builtin_amdgcn_sched_barrier(0);
                 tile(s0, tt * 32);
                 __builtin_amdgcn_sched_barrier(0);
@@ -449,6 +493,145 @@ __global__ __launch_bounds__(256, (RECOMP && BF) ? 3 : 2) void gcn2_bwd_rows_ker
     if (h == 0 && i < J2) pb2[i] = b2;
 }
 
+// T[r][:] = act1(b1) W2^T for the rows r with dead[r] != 0: the image of a zero row of A under gae_linear2_fwd -- what
+// every row without in-edges shares (list mode of the forward pass).  The vector is computed once per block.
+__global__ __launch_bounds__(256) void linear2_fill_dead_kernel(const float *__restrict__ b1, int act1,
+                                                                const float *__restrict__ W2, int64_t ldw2, int J1, int J2,
+                                                                const uint8_t *__restrict__ dead, int64_t n,
+                                                                float *__restrict__ T, int64_t ldt)
+{
+    __shared__ float t0[32];
+    if (threadIdx.x < 32) {
+        float acc = 0.f;
+        if (int(threadIdx.x) < J2) {
+            for (int j = 0; j < J1; ++j) {               // j ascending: one fma chain per output, as everywhere
+                float y = b1 ? b1[j] : 0.f;
+                if (act1 == GAE_ACT_RELU) y = fmaxf(y, 0.f);
+                acc = fmaf(y, W2[int64_t(threadIdx.x) * ldw2 + j], acc);
+            }
+        }
+        t0[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    const int nvec = (J2 + 3) / 4;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n * nvec; t += stride) {
+        const int64_t row = t / nvec;
+        const int c4 = int(t - row * nvec) * 4;
+        if (!dead[row]) continue;
+        float *tp = T + row * ldt + c4;
+        if (c4 + 4 <= J2) *reinterpret_cast<float4 *>(tp) = make_float4(t0[c4], t0[c4 + 1], t0[c4 + 2], t0[c4 + 3]);
+        else for (int q = 0; c4 + q < J2; ++q) tp[q] = t0[c4 + q];
+    }
+}
+
+// Backward of the rows gae_gcn2_bwd_dense does not visit in list mode (M1 row = 0, so H1 row = act1(b1) =: y0):
+//   dW1 += 0,  db1 += (s_G W2) (.) act1'(y0),  dW2 += s_G (x) y0,  db2 += s_Z,   s_G = sum of their G rows (rows marked
+//   in g_dead are zero rows that were never written: not read), s_Z = sum of their dZ rows.
+// Stage 1: fixed grid, each block owns a contiguous range of rows, thread (row slot, 4 columns), tree in LDS -> [2][32].
+constexpr int kDeadBlocks = 2048;
+__global__ __launch_bounds__(256) void gcn2_dead_sums_kernel(const float *__restrict__ G, int64_t ldg,
+                                                             const float *__restrict__ dZ, int64_t lddz, int J2,
+                                                             const uint8_t *__restrict__ m1_dead,
+                                                             const uint8_t *__restrict__ g_dead, int64_t n,
+                                                             float *__restrict__ part /*[blocks][64]*/)
+{
+    // a byte stream (the dZ rows of most rows of the graph): 4 rows per thread and trip, all requested before the first add
+    __shared__ float red[2][32][33];
+    const int J24 = (J2 + 3) & ~3, nv = J24 / 4;                 // threads per row
+    const int slots = 256 / nv;                                  // rows per sweep of the block
+    const int c4 = (int(threadIdx.x) % nv) * 4, slot = int(threadIdx.x) / nv;
+    const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 3) / 4 * 4;
+    const int64_t r0 = int64_t(blockIdx.x) * per, r1 = r0 + per < n ? r0 + per : n;
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sz[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    for (int64_t rb = r0 + slot; rb < r1; rb += int64_t(U) * slots) {
+        float4 z[U], g[U];
+        bool zl[U], gl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = rb + int64_t(u) * slots;
+            const bool in = r < r1 && slot < slots;
+            const unsigned md = in ? m1_dead[r] : 0u;
+            zl[u] = in && md != 0;
+            gl[u] = zl[u] && (g_dead == nullptr || g_dead[r] == 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = rb + int64_t(u) * slots;
+            z[u] = make_float4(0.f, 0.f, 0.f, 0.f); g[u] = z[u];
+            if (zl[u]) z[u] = *reinterpret_cast<const float4 *>(dZ + r * lddz + c4);
+            if (gl[u]) g[u] = *reinterpret_cast<const float4 *>(G + r * ldg + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                             // row order per thread: deterministic
+            sz[0] += z[u].x; sz[1] += z[u].y; sz[2] += z[u].z; sz[3] += z[u].w;
+            sg[0] += g[u].x; sg[1] += g[u].y; sg[2] += g[u].z; sg[3] += g[u].w;
+        }
+    }
+    // columns c4 .. c4 + 3 of row slot `slot`: the slots meet in LDS, added in slot order
+    for (int k = threadIdx.x; k < 2 * 32 * 33; k += 256) (&red[0][0][0])[k] = 0.f;
+    __syncthreads();
+    // (slots may exceed 32: fold slot s into LDS column s % 32 in two rounds, low slots first)
+    for (int round = 0; round * 32 < slots; ++round) {
+        if (slot / 32 == round) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { red[0][c4 + q][slot % 32] += sg[q]; red[1][c4 + q][slot % 32] += sz[q]; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 64) {
+        const int w = threadIdx.x >> 5, c = threadIdx.x & 31;
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += red[w][c][k];
+        part[int64_t(blockIdx.x) * 64 + threadIdx.x] = (c < J2) ? t : 0.f;
+    }
+}
+
+// Stage 2 (one block): the block sums in block order, then the four gradient terms as ONE more partial block of the
+// pass's partial list ([dW1 J1 x K1 | db1 J1 | dW2 J2 x J1 | db2 J2], gae_gcn2_bwd_dense's layout)
+__global__ __launch_bounds__(256) void gcn2_dead_terms_kernel(const float *__restrict__ part, int n_blocks,
+                                                              const float *__restrict__ b1, int act1,
+                                                              const float *__restrict__ W2, int64_t ldw2, int K1, int J1,
+                                                              int J2, float *__restrict__ out)
+{
+    __shared__ float s4[4][64], s[64], y0[32];
+    {   // 4 threads per output, each adds every 4th block's partial (8 loads in flight), then the four meet in order
+        const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+        float t = 0.f;
+        int b = q;
+        for (; b + 28 < n_blocks; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[int64_t(b + 4 * u) * 64 + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; b < n_blocks; b += 4) t += part[int64_t(b) * 64 + o];
+        s4[q][o] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) s[threadIdx.x] = (s4[0][threadIdx.x] + s4[1][threadIdx.x]) + (s4[2][threadIdx.x] + s4[3][threadIdx.x]);
+    if (threadIdx.x >= 64 && threadIdx.x < 96) {
+        const int j = threadIdx.x - 64;
+        float y = (b1 && j < J1) ? b1[j] : 0.f;
+        if (act1 == GAE_ACT_RELU) y = fmaxf(y, 0.f);
+        y0[j] = j < J1 ? y : 0.f;
+    }
+    __syncthreads();
+    float *pW1 = out, *pb1 = out + J1 * K1, *pW2 = pb1 + J1, *pb2 = pW2 + J2 * J1;
+    for (int e = threadIdx.x; e < J1 * K1; e += 256) pW1[e] = 0.f;
+    if (int(threadIdx.x) < J1) {
+        const int j = threadIdx.x;
+        float v = 0.f;
+        for (int j2 = 0; j2 < J2; ++j2) v = fmaf(s[j2], W2[int64_t(j2) * ldw2 + j], v);
+        if (act1 == GAE_ACT_RELU && !(y0[j] > 0.f)) v = 0.f;
+        pb1[j] = v;
+    }
+    for (int e = threadIdx.x; e < J2 * J1; e += 256) pW2[e] = s[e / J1] * y0[e % J1];
+    if (int(threadIdx.x) < J2) pb2[threadIdx.x] = s[32 + threadIdx.x];
+}
+
 inline int64_t tall_tiles_per_wave(int64_t n, int64_t max_blocks)
 {
     const int64_t n_tiles = (n + 31) / 32;
@@ -460,8 +643,15 @@ inline int64_t tall_tiles_per_wave(int64_t n, int64_t max_blocks)
 
 extern "C" int gae_linear2_fwd(const float *A, int64_t lda, int64_t n, int64_t f_in, const float *W1, int64_t ldw1,
                                const float *b1, int64_t f_mid, int act1, const float *W2, int64_t ldw2, int64_t f_out,
-                               float *Y1, int64_t ldy1, float *T, int64_t ldt, void *stream)
+                               float *Y1, int64_t ldy1, float *T, int64_t ldt, const uint8_t *a_dead,
+                               const int32_t *rows, int64_t n_listed, void *stream)
 {
+    GAE_REQUIRE(rows == nullptr || (n_listed >= 0 && n_listed <= n && a_dead == nullptr), GAE_E_SIZE,
+                "gae_linear2_fwd: a row list has 0 .. n entries and replaces a_dead");
+    GAE_REQUIRE(n < (int64_t(1) << 31), GAE_E_SIZE, "gae_linear2_fwd: n too large");
+    const int64_t n_all = n;
+    if (rows != nullptr) n = n_listed;            // the kernel counts list entries
+    (void)n_all;
     GAE_REQUIRE(n >= 0 && f_in >= 1 && f_mid >= 1 && f_out >= 1, GAE_E_SIZE, "gae_linear2_fwd: bad size");
     GAE_REQUIRE(f_in <= 64 && f_mid <= 32 && f_out <= 32, GAE_E_RANGE,
                 "gae_linear2_fwd: needs f_in <= 64, f_mid <= 32, f_out <= 32 (use two gae_linear_fwd calls)");
@@ -480,13 +670,29 @@ extern "C" int gae_linear2_fwd(const float *A, int64_t lda, int64_t n, int64_t f
     const int kb = int((f_in + 7) / 8);
 #define GAE_L2F(KBV)                                                                                                     \
     hipLaunchKernelGGL((linear2_rows_kernel<KBV>), grid, dim3(256), 0, s, A, lda, W1, ldw1, b1, act1, W2, ldw2, Y1, ldy1, \
-                       T, ldt, n, int(f_in), int(f_mid), int(f_out), int(tpw))
+                       T, ldt, n, int(f_in), int(f_mid), int(f_out), int(tpw), a_dead, rows)
     switch (kb) {
     case 1: GAE_L2F(1); break; case 2: GAE_L2F(2); break; case 3: GAE_L2F(3); break; case 4: GAE_L2F(4); break;
     case 5: GAE_L2F(5); break; case 6: GAE_L2F(6); break; case 7: GAE_L2F(7); break; default: GAE_L2F(8); break;
     }
 #undef GAE_L2F
     GAE_CHECK_LAUNCH("linear2_rows_kernel");
+    return GAE_OK;
+}
+
+extern "C" int gae_linear2_fill_dead(const float *b1, int64_t f_mid, int act1, const float *W2, int64_t ldw2, int64_t f_out,
+                                     const uint8_t *dead, int64_t n, float *T, int64_t ldt, void *stream)
+{
+    GAE_REQUIRE(n >= 0 && f_mid >= 1 && f_mid <= 32 && f_out >= 1 && f_out <= 32, GAE_E_SIZE, "gae_linear2_fill_dead: bad size");
+    GAE_REQUIRE(act1 == GAE_ACT_IDENTITY || act1 == GAE_ACT_RELU, GAE_E_RANGE, "gae_linear2_fill_dead: act %d", act1);
+    if (n == 0) return GAE_OK;
+    GAE_REQUIRE(W2 && dead && T, GAE_E_NULL, "gae_linear2_fill_dead: NULL pointer");
+    GAE_REQUIRE(ldw2 >= f_mid && ldt >= f_out && ldt % 4 == 0 && gae::aligned16(T), GAE_E_ALIGN,
+                "gae_linear2_fill_dead: rows of T must be whole 16-byte vectors");
+    const int64_t want = (n * ((f_out + 3) / 4) + 255) / 256;
+    hipLaunchKernelGGL(linear2_fill_dead_kernel, dim3(unsigned(want < 8192 ? want : 8192)), dim3(256), 0,
+                       gae::as_stream(stream), b1, act1, W2, ldw2, int(f_mid), int(f_out), dead, n, T, ldt);
+    GAE_CHECK_LAUNCH("linear2_fill_dead_kernel");
     return GAE_OK;
 }
 
@@ -508,16 +714,23 @@ extern "C" int64_t gae_gcn2_bwd_dense_workspace_bytes(int64_t n, int64_t f_in, i
     if (n < 0 || f_in < 1 || f_mid < 1 || f_out < 1 || f_in > 32 || f_mid > 32 || f_out > 32) return GAE_E_SIZE;
     int64_t lay[5];
     gcn2_layout(n > 0 ? n : 1, f_in, f_mid, f_out, lay, nullptr);
-    return lay[0] * lay[1] * 4 + 256;
+    return (lay[0] + 1) * lay[1] * 4 + kDeadBlocks * 64 * 4 + 256;       // (+ list mode: one more partial, the dead-row sums)
 }
 
 extern "C" int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, int64_t lddz, const float *Y1, int64_t ldy1,
                                   int act1, const float *M1, int64_t ldm1, const float *W2, int64_t ldw2, int64_t n,
                                   int64_t f_in, int64_t f_mid, int64_t f_out, float *dW1, float *db1, float *dW2,
                                   float *db2, void *workspace, int64_t workspace_bytes, int64_t *layout_out,
-                                  const float *W1, int64_t ldw1, const float *b1, void *stream)
+                                  const float *W1, int64_t ldw1, const float *b1, const uint8_t *m1_dead,
+                                  const uint8_t *g_dead, const int32_t *rows, int64_t n_listed,
+                                  const uint8_t *g_dead_listed, void *stream)
 {
     GAE_REQUIRE(n >= 1 && f_in >= 1 && f_mid >= 1 && f_out >= 1, GAE_E_SIZE, "gae_gcn2_bwd_dense: bad size");
+    GAE_REQUIRE(Y1 == nullptr || (m1_dead == nullptr && g_dead == nullptr && rows == nullptr), GAE_E_RANGE,
+                "gae_gcn2_bwd_dense: dead-row masks / row lists belong to the recomputing form (Y1 == NULL)");
+    GAE_REQUIRE(rows == nullptr || (m1_dead != nullptr && n_listed >= 0 && n_listed <= n), GAE_E_RANGE,
+                "gae_gcn2_bwd_dense: a row list (the rows with an M1 row) comes with m1_dead (all the others)");
+    GAE_REQUIRE(n < (int64_t(1) << 30), GAE_E_SIZE, "gae_gcn2_bwd_dense: n too large");
     GAE_REQUIRE(f_in <= 32 && f_mid <= 32 && f_out <= 32, GAE_E_RANGE, "gae_gcn2_bwd_dense: widths above 32");
     GAE_REQUIRE(act1 == GAE_ACT_IDENTITY || act1 == GAE_ACT_RELU, GAE_E_RANGE, "gae_gcn2_bwd_dense: act %d", act1);
     GAE_REQUIRE(G && dZ && M1 && W2 && workspace, GAE_E_NULL, "gae_gcn2_bwd_dense: NULL pointer");
@@ -532,16 +745,24 @@ extern "C" int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, 
     GAE_REQUIRE(workspace_bytes >= gae_gcn2_bwd_dense_workspace_bytes(n, f_in, f_mid, f_out) && gae::aligned16(workspace),
                 GAE_E_WORKSPACE, "gae_gcn2_bwd_dense: workspace too small or misaligned");
     int64_t lay[5], tpw = 1;
+    const bool listed = rows != nullptr;
+    const int64_t n_all = n;
+    const uint8_t *g_dead_rows = g_dead;  // (row-indexed: the dead-row sums read it)
+    if (listed) {                         // the main kernel walks the list; its masks are indexed by list entry
+        n = n_listed > 0 ? n_listed : 1;
+        g_dead = g_dead_listed;
+    }
     gcn2_layout(n, f_in, f_mid, f_out, lay, &tpw);
     hipStream_t s = gae::as_stream(stream);
     float *partial = static_cast<float *>(workspace);
-    const dim3 grid{unsigned(lay[0])};
+    if (listed && n_listed == 0) { lay[0] = 0; }
+    const dim3 grid{unsigned(lay[0] > 0 ? lay[0] : 1)};
     const int kb2 = int((f_out + 7) / 8);
     int64_t bfk = 1;
     gae_tuning_get("atb_bf16", &bfk);       // the library's switch for weight-gradient products on the bf16 matrix pipe
 #define GAE_G2L(KBV, RL, RC, BFV)                                                                                        \
     hipLaunchKernelGGL((gcn2_bwd_rows_kernel<KBV, RL, RC, BFV>), grid, dim3(256), 0, s, G, ldg, dZ, lddz, Y1, ldy1, M1,   \
-                       ldm1, W2, ldw2, n, int(f_in), int(f_mid), int(f_out), tpw, partial, lay[1], W1, ldw1, b1)
+                       ldm1, W2, ldw2, n, int(f_in), int(f_mid), int(f_out), tpw, partial, lay[1], W1, ldw1, b1, m1_dead, g_dead, rows)
 #define GAE_G2B(KBV, RL)                                                                                                 \
     do {                                                                                                                 \
         if (recomp) { if (bfk) GAE_G2L(KBV, RL, true, true); else GAE_G2L(KBV, RL, true, false); }                       \
@@ -549,11 +770,22 @@ extern "C" int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, 
     } while (0)
 #define GAE_G2K(RL)                                                                                                      \
     do { if (kb2 == 1) GAE_G2B(1, RL); else if (kb2 == 2) GAE_G2B(2, RL); else if (kb2 == 3) GAE_G2B(3, RL); else GAE_G2B(4, RL); } while (0)
-    if (act1 == GAE_ACT_RELU) GAE_G2K(true); else GAE_G2K(false);
+    if (lay[0] > 0) { if (act1 == GAE_ACT_RELU) GAE_G2K(true); else GAE_G2K(false); }
 #undef GAE_G2K
 #undef GAE_G2B
 #undef GAE_G2L
     GAE_CHECK_LAUNCH("gcn2_bwd_rows_kernel");
+    if (listed) {
+        // the rows that are not listed: column sums of their G / dZ rows, turned into one more partial of the list
+        float *sums = partial + (lay[0] + 1) * lay[1];
+        hipLaunchKernelGGL(gcn2_dead_sums_kernel, dim3(kDeadBlocks), dim3(256), 0, s, G, ldg, dZ, lddz, int(f_out), m1_dead,
+                           g_dead_rows, n_all, sums);
+        GAE_CHECK_LAUNCH("gcn2_dead_sums_kernel");
+        hipLaunchKernelGGL(gcn2_dead_terms_kernel, dim3(1), dim3(256), 0, s, sums, kDeadBlocks, b1, act1, W2, ldw2,
+                           int(f_in), int(f_mid), int(f_out), partial + lay[0] * lay[1]);
+        GAE_CHECK_LAUNCH("gcn2_dead_terms_kernel");
+        lay[0] += 1;
+    }
     if (layout_out) {
         for (int k = 0; k < 5; ++k) layout_out[k] = lay[k];
         return GAE_OK;                   // partials only: the caller (gae_adam_step's deferred reduction) adds them

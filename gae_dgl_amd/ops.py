@@ -589,6 +589,14 @@ class SpmmPlan:
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self.tensors if t is not None)
 
+    def set_skip_rows(self, mask, covers_all_empty=False):
+        """uint8 [n_rows] (or None): rows WITHOUT edges that a product launched with ``skip_dead=True`` need not write
+        (gae_spmm_plan::skip_rows, GAE_SPMM_SKIP_ROWS) -- the caller's consumers treat them as zero without reading them.
+        ``covers_all_empty``: the mask marks EVERY row without edges of this CSR (the empty-row stream is then not launched)"""
+        self.skip_rows = mask
+        self.c.skip_rows = None if mask is None else mask.data_ptr()
+        self.c.reserved2 = 1 if (mask is not None and covers_all_empty) else 0
+
 
 def ell_width_for(max_deg):
     """narrowest packed-table width (4, 8 or 16 slots) that holds every row of a graph whose longest (light) row
@@ -789,7 +797,7 @@ class BlockDiag:
 
 
 def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=None, plan=None, blockdiag=None,
-             out_padded=False, scattered=False, accumulate=False):
+             out_padded=False, scattered=False, accumulate=False, skip_dead=False):
     """M = diag(row_scale) A diag(col_scale) H  (K1/K2).  ``out_padded``: the caller's ``out`` is a view of a
     row-padded buffer whose pad columns may be overwritten (always true for the buffer allocated here).
     ``scattered``: the graph's column ids lie far from the row ids (GAE_SPMM_TILE).
@@ -805,6 +813,8 @@ def spmm_raw(indptr, indices, H, n_rows, row_scale=None, col_scale=None, out=Non
         raise GaeHipError("spmm: accumulate=True adds to `out`")
     flags = (_lib.SPMM_STORE_PAD if out_padded else 0) | (_lib.SPMM_TILE if scattered else 0) | \
         (_lib.SPMM_ACCUMULATE if accumulate else 0)
+    if skip_dead and plan is not None and getattr(plan, "skip_rows", None) is not None:
+        flags |= _lib.SPMM_SKIP_ROWS        # the rows marked in the plan's mask stay UNWRITTEN (see SpmmPlan.set_skip_rows)
     if accumulate:
         blockdiag = None
     out2, ldm = _rowmajor(out, "out")
@@ -882,9 +892,21 @@ def linear2_usable(A, f_mid, f_out):
             and 1 <= A.shape[1] <= 32 and 1 <= f_mid <= 32 and 1 <= f_out <= 32)
 
 
-def linear2_fwd_raw(A, W1, b1, act1, W2, want_y1=True):
+def _dead_mask(t, n, what):
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.dim() == 1 and t.numel() == n
+            and t.is_contiguous()):
+        raise GaeHipError(f"{what}: a dead-row mask is a contiguous uint8 device tensor with one entry per row")
+    return t
+
+
+def linear2_fwd_raw(A, W1, b1, act1, W2, want_y1=True, a_dead=None, rows=None):
     """(Y1, T): Y1 = act1(A W1^T + b1), T = Y1 W2^T in ONE pass over A (gae_linear2_fwd); Y1 None when not wanted.
-    Both outputs have rows of whole 16-byte vectors."""
+    Both outputs have rows of whole 16-byte vectors.  ``a_dead`` (uint8 [n]): rows of A that are zero and were never
+    written (spmm_raw(skip_dead=True)) -- not read.  ``rows`` (int32, ascending; with ``a_dead`` marking all the others):
+    list mode -- the two products run on the listed rows only, the other rows of T get their common value
+    act1(b1) W2^T (gae_linear2_fill_dead); Y1 is not available then."""
     A, lda = _rowmajor(_f32(_gpu(A, "A"), "linear2: A"), "A")
     if lda % 4 or A.data_ptr() % 16:
         A = pad_rows(A); lda = A.stride(0)
@@ -900,10 +922,21 @@ def linear2_fwd_raw(A, W1, b1, act1, W2, want_y1=True):
     ld1, ld2 = (f_mid + 3) // 4 * 4, (f_out + 3) // 4 * 4
     Y1 = torch.empty(n, ld1, dtype=torch.float32, device=dev)[:, :f_mid] if want_y1 else None
     T = torch.empty(n, ld2, dtype=torch.float32, device=dev)[:, :f_out]
+    a_dead = _dead_mask(a_dead, n, "linear2")
+    if rows is not None:
+        if a_dead is None or want_y1 or rows.dtype != torch.int32 or not rows.is_cuda or not rows.is_contiguous():
+            raise GaeHipError("linear2: list mode takes an int32 device list, the dead-row mask of all other rows, and no Y1")
     with _on_device(dev):
         def launch():
+            if rows is not None:
+                _lib.call("gae_linear2_fwd", _ptr(A), lda, n, f_in, _ptr(W1), W1.stride(0), _ptr(b1), f_mid, int(act1),
+                          _ptr(W2), W2.stride(0), f_out, None, ld1, _ptr(T), ld2, None, _ptr(rows), int(rows.numel()),
+                          _stream())
+                _lib.call("gae_linear2_fill_dead", _ptr(b1), f_mid, int(act1), _ptr(W2), W2.stride(0), f_out, _ptr(a_dead), n,
+                          _ptr(T), ld2, _stream())
+                return
             _lib.call("gae_linear2_fwd", _ptr(A), lda, n, f_in, _ptr(W1), W1.stride(0), _ptr(b1), f_mid, int(act1),
-                      _ptr(W2), W2.stride(0), f_out, _ptr(Y1), ld1, _ptr(T), ld2, _stream())
+                      _ptr(W2), W2.stride(0), f_out, _ptr(Y1), ld1, _ptr(T), ld2, _ptr(a_dead), None, 0, _stream())
         if profiler is not None:
             profiler.wrap(("linear2", n, f_in, f_mid, f_out), launch)
         else:
@@ -911,12 +944,16 @@ def linear2_fwd_raw(A, W1, b1, act1, W2, want_y1=True):
     return Y1, T
 
 
-def gcn2_bwd_dense_raw(G, dZ, Y1, act1, M1, W2, W1=None, b1=None):
+def gcn2_bwd_dense_raw(G, dZ, Y1, act1, M1, W2, W1=None, b1=None, m1_dead=None, g_dead=None, rows=None,
+                       g_dead_listed=None):
     """(dW1, db1, dW2, db2) of a two-layer encoder from G = A^T dZ in ONE pass over G, dZ, Y1, M1 (gae_gcn2_bwd_dense):
     dW2 = G^T Y1, db2 = colsum(dZ), dY1 = (G W2) (.) act1'(Y1), dW1 = dY1^T M1, db1 = colsum(dY1).  Inside
     ``deferred_grad_reductions()`` the four gradients stay per-block partial sums for optim.Adam.step().
     ``Y1`` None: the pass recomputes Y1 = act1(M1 W1^T + b1) itself (bit-identical to linear2_fwd_raw's), ``W1`` / ``b1``
-    needed."""
+    needed; then ``m1_dead`` / ``g_dead`` (uint8 [n]) mark rows of M1 / G that are zero and were never written: not read.
+    ``rows`` (int32, ascending = the rows that have an M1 row; ``m1_dead`` marks exactly the others; ``g_dead_listed`` =
+    g_dead at the listed rows): list mode -- the pass visits the listed rows, the share of the others (a rank-one term of
+    the column sums of their G / dZ rows) is one more partial of the list."""
     G, ldg = _rowmajor(_f32(_gpu(G, "G"), "gcn2_bwd: G"), "G")
     dZ, lddz = _rowmajor(_f32(_gpu(dZ, "dZ"), "gcn2_bwd: dZ"), "dZ")
     if ldg % 4 or G.data_ptr() % 16:
@@ -947,6 +984,13 @@ def gcn2_bwd_dense_raw(G, dZ, Y1, act1, M1, W2, W1=None, b1=None):
     if dZ.shape != G.shape or W2.shape[0] != f_out or M1.shape[0] != n:
         raise GaeHipError("gcn2_bwd: operand shapes do not match")
     dev = G.device
+    m1_dead, g_dead = _dead_mask(m1_dead, n, "gcn2_bwd"), _dead_mask(g_dead, n, "gcn2_bwd")
+    if Y1 is not None and (m1_dead is not None or g_dead is not None or rows is not None):
+        raise GaeHipError("gcn2_bwd: dead-row masks / row lists go with the recomputing form (Y1 = None)")
+    if rows is not None:
+        if m1_dead is None or rows.dtype != torch.int32 or not rows.is_cuda or not rows.is_contiguous():
+            raise GaeHipError("gcn2_bwd: list mode takes an int32 device list and the dead-row mask of all other rows")
+        g_dead_listed = _dead_mask(g_dead_listed, int(rows.numel()), "gcn2_bwd")
     dW1 = torch.empty(f_mid, f_in, dtype=torch.float32, device=dev)
     db1 = torch.empty(f_mid, dtype=torch.float32, device=dev)
     dW2 = torch.empty(f_out, f_mid, dtype=torch.float32, device=dev)
@@ -963,7 +1007,8 @@ def gcn2_bwd_dense_raw(G, dZ, Y1, act1, M1, W2, W1=None, b1=None):
             _lib.call("gae_gcn2_bwd_dense", _ptr(G), ldg, _ptr(dZ), lddz, _ptr(Y1), ldy1, int(act1), _ptr(M1), ldm1,
                       _ptr(W2), W2.stride(0), n, f_in, f_mid, f_out, _ptr(dW1), _ptr(db1), _ptr(dW2), _ptr(db2), _ptr(ws),
                       ws.numel(), lay if defer else None, _ptr(W1) if Y1 is None else None, ldw1,
-                      _ptr(b1) if Y1 is None else None, _stream())
+                      _ptr(b1) if Y1 is None else None, _ptr(m1_dead), _ptr(g_dead), _ptr(rows),
+                      0 if rows is None else int(rows.numel()), _ptr(g_dead_listed), _stream())
         if profiler is not None:
             profiler.wrap(("gcn2_bwd", n, f_in, f_mid, f_out), launch)
         else:

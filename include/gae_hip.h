@@ -255,10 +255,12 @@ typedef struct gae_spmm_plan {
     const int32_t *mid_indices;     /* compact copy of the column ids of the rows in heavy_rows, or NULL.  When given,
                                        seg_desc (mandatory then) indexes THIS array instead of the CSR's `indices`; */
     int32_t mid_tagged;             /* 1: its ids carry hot-column tags (sign bit), like hot_indices */
-    int32_t reserved2;
+    int32_t reserved2;              /* 1: skip_rows marks EVERY row without edges (the empty-row stream is not launched) */
     const int32_t *vh_desc;         /* [vh_n_virtual][4] {p, first, end, 0} into vh_indices for virtual row p (empty
                                        positions: zeros), or NULL.  When given, vh_indptr / vh_identity are not read and
                                        vh_indices holds the pinned rows' ids in (row, home, column) order. */
+    const uint8_t *skip_rows;       /* [n_rows] or NULL; with GAE_SPMM_SKIP_ROWS: rows r WITHOUT edges whose
+                                       skip_rows[r] != 0 are not written at all (see the flag) */
 } gae_spmm_plan;
 
 /* ---- plan construction on the device (csrc/plan_build.hip): classification of the rows, descriptors, compact tagged
@@ -317,6 +319,11 @@ int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, 
                  const void *H, int64_t ldh, void *M, int64_t ldm, int64_t F, int dtype,
                  const float *row_scale, const float *col_scale,
                  const gae_spmm_plan *plan_host, void *workspace, int64_t workspace_bytes, int flags, void *stream);
+#define GAE_SPMM_SKIP_ROWS 8  /* plans with a light-row list only: the stream that writes act(bias) to the rows without
+                              * edges leaves out the rows marked in plan->skip_rows -- rows the caller KNOWS its
+                              * consumers treat as zero without reading them (gae_linear2_fwd / gae_gcn2_bwd_dense take
+                              * the same mask).  On R-MAT s24 70 % of the rows have no in-edges: their 1.5 GB of zeros are
+                              * then neither written nor read back.  Ignored by every other kernel (they write all rows). */
 
 /* Block-diagonal form of the same product (the batched molecule graphs of gae_dgl/train_inductive.py:31-35):
  * block_ptr[n_blocks + 1] (int32, device) cuts the rows into runs that are CLOSED under adjacency (whole member
@@ -457,7 +464,16 @@ int gae_spmm_csr_ep(const int32_t *indptr, const int32_t *indices, int64_t n_row
  * f_mid] (ldw2) as nn.Linear stores them; b1 may be NULL; Y1 may be NULL (inference: only T is wanted). */
 int gae_linear2_fwd(const float *A, int64_t lda, int64_t n, int64_t f_in, const float *W1, int64_t ldw1,
                     const float *b1, int64_t f_mid, int act1, const float *W2, int64_t ldw2, int64_t f_out,
-                    float *Y1, int64_t ldy1, float *T, int64_t ldt, void *stream);
+                    float *Y1, int64_t ldy1, float *T, int64_t ldt, const uint8_t *a_dead, const int32_t *rows,
+                    int64_t n_listed, void *stream);
+/* a_dead [n] (or NULL): rows of A that ARE zero and were never written -- the rows without edges of an aggregate
+ * produced with GAE_SPMM_SKIP_ROWS -- are not read (their outputs are act1(b1) and its image under W2).
+ * rows [n_listed] (or NULL; replaces a_dead): LIST MODE -- only the listed rows (ascending ids < n) are read, computed
+ * and written; the pass is bound by the fp32 matrix pipe, so on a power-law graph, where most rows of an aggregate
+ * have no in-edges, it does a fraction of the work.  gae_linear2_fill_dead writes T for all the other rows (their
+ * common value act1(b1) W2^T; `dead` [n] marks them). */
+int gae_linear2_fill_dead(const float *b1, int64_t f_mid, int act1, const float *W2, int64_t ldw2, int64_t f_out,
+                          const uint8_t *dead, int64_t n, float *T, int64_t ldt, void *stream);
 /* gae_gcn2_bwd_dense: every dense product of that encoder's backward pass in ONE pass over its four tall operands
  * (train_inductive.py:51 for the model of gae.py:36-45 with two layers), given G = A^T dZ [n, f_out]:
  *     dW2 = G^T Y1,  db2 = colsum(dZ),  dY1 = (G W2) (.) act1'(Y1),  dW1 = dY1^T M1,  db1 = colsum(dY1)
@@ -471,7 +487,14 @@ int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, int64_t ldd
                        int act1, const float *M1, int64_t ldm1, const float *W2, int64_t ldw2, int64_t n,
                        int64_t f_in, int64_t f_mid, int64_t f_out, float *dW1, float *db1, float *dW2, float *db2,
                        void *workspace, int64_t workspace_bytes, int64_t *layout_out, const float *W1, int64_t ldw1,
-                       const float *b1, void *stream);
+                       const float *b1, const uint8_t *m1_dead, const uint8_t *g_dead, const int32_t *rows,
+                       int64_t n_listed, const uint8_t *g_dead_listed, void *stream);
+/* m1_dead / g_dead [n] (or NULL; recomputing form only): rows of M1 / G that ARE zero and were never written
+ * (GAE_SPMM_SKIP_ROWS) are not read.
+ * rows [n_listed] (or NULL): LIST MODE -- the rows that HAVE an M1 row, ascending; m1_dead must then mark exactly the
+ * others.  The pass visits the listed rows only (g_dead_listed [n_listed]: the G mask by list entry, or NULL); the
+ * others' share -- their H1 row is act1(b1), so it is a rank-one term of the column sums of their G and dZ rows --
+ * is computed by two small launches and appended to the partial list as one more partial (workspace sized for it). */
 /* (Y1 == NULL: the pass RECOMPUTES Y1 = act1(M1 W1^T + b1) from the tile of M1 it reads anyway -- W1 [f_mid, f_in] (ldw1),
  *  b1 [f_mid] or NULL -- with gae_linear2_fwd's products in its order, i.e. the same bits: the forward then need not
  *  store Y1 at all (gae_linear2_fwd with Y1 = NULL) and this pass reads 2 f_mid fewer floats per row.) */

@@ -253,3 +253,84 @@ def test_light_row_list_is_bit_identical(F, pinned, tuning):
         outs[light] = (ops.spmm_raw(ip, ix, H, n, plan=plan), ops.spmm_ep_raw(ip, ix, H, n, plan, b, 1), o_acc, o_ep)
     for a, c in zip(outs[1], outs[0]):
         assert torch.equal(a, c)
+
+
+def test_dead_rows_are_neither_written_nor_read():
+    """round 4: rows of an aggregate without edges (R-MAT: most rows).  gae_spmm_csr with GAE_SPMM_SKIP_ROWS leaves the
+    rows marked in the plan's mask untouched; gae_linear2_fwd / gae_gcn2_bwd_dense with the same mask never read them:
+    NaN-poisoned dead rows give the bits that zero rows give without the mask."""
+    from gae_dgl_amd import ops
+    n, e, F = 6000, 200000, 32
+    rng, src, dst = skew_graph(5, n, e)
+    # + a sprinkle of edges into the upper half of the rows: rows of 1 .. 8 edges (the light list) next to empty rows
+    extra = torch.from_numpy(rng.integers(n // 2, n, 2500)).to(DEV)
+    dst = torch.cat([dst, extra]); src = torch.cat([src, torch.from_numpy(rng.integers(0, n, 2500)).to(DEV)])
+    ip, ix = ops.csr_from_coo(dst, src, n, n)
+    plan = ops.spmm_plan(ip, threshold=8, segment=128, indices=ix, ell=False, hot=True, n_cols=n, homed=True)
+    assert plan is not None and plan.n_light > 0
+    dead = (ip[1:] == ip[:-1]).to(torch.uint8).contiguous()
+    assert 0 < int(dead.sum()) < n
+    plan.set_skip_rows(dead)
+    H = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(DEV)
+    ref = ops.spmm_raw(ip, ix, H, n, plan=plan)                        # every row written (zeros in the dead rows)
+    out = torch.full_like(ref, float("nan"))
+    ops.spmm_raw(ip, ix, H, n, out=out, plan=plan, skip_dead=True)
+    live = dead == 0
+    assert torch.equal(out[live], ref[live]) and bool(torch.isnan(out[~live]).all()) and float(ref[~live].abs().max()) == 0.0
+    # the dense passes on the poisoned aggregate
+    g = torch.Generator().manual_seed(3)
+    W1 = (torch.randn(32, F, generator=g) / F ** 0.5).to(DEV); b1 = torch.randn(32, generator=g).to(DEV)
+    W2 = (torch.randn(16, 32, generator=g) / 32 ** 0.5).to(DEV)
+    _, T_ref = ops.linear2_fwd_raw(ref, W1, b1, 1, W2, want_y1=False)
+    _, T = ops.linear2_fwd_raw(out, W1, b1, 1, W2, want_y1=False, a_dead=dead)
+    assert torch.equal(T, T_ref)
+    Gm = torch.randn(n, 16, generator=g).to(DEV); dZ = torch.randn(n, 16, generator=g).to(DEV)
+    gdead = (torch.rand(n, generator=g) < 0.5).to(torch.uint8).to(DEV)
+    G0 = Gm.clone(); G0[gdead.bool()] = 0
+    Gp = Gm.clone(); Gp[gdead.bool()] = float("nan")
+    want = ops.gcn2_bwd_dense_raw(G0, dZ, None, 1, ref, W2, W1=W1, b1=b1)
+    got = ops.gcn2_bwd_dense_raw(Gp, dZ, None, 1, out, W2, W1=W1, b1=b1, m1_dead=dead, g_dead=gdead)
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+
+
+@pytest.mark.parametrize("act", [1, 0])
+def test_list_mode_of_the_dense_passes(act):
+    """round 4: the dense passes visit only the rows that have an M1 row.  Forward: listed rows bit-identical to the
+    full pass, every other row = act(b1) W2^T; backward: the four gradients equal those of the full pass on an M1 / G
+    with zeros in the dead rows (another summation order: 1e-5 of the scale)."""
+    from gae_dgl_amd import ops
+    n, F = 20011, 32
+    g = torch.Generator().manual_seed(17)
+    m1_dead = (torch.rand(n, generator=g) < 0.7)
+    g_dead = (torch.rand(n, generator=g) < 0.6)
+    M1 = torch.randn(n, F, generator=g); M1[m1_dead] = 0
+    Gm = torch.randn(n, 16, generator=g); Gm[g_dead] = 0
+    dZ = torch.randn(n, 16, generator=g)
+    W1 = torch.randn(32, F, generator=g) / F ** 0.5; b1 = torch.randn(32, generator=g)
+    W2 = torch.randn(16, 32, generator=g) / 32 ** 0.5
+    d = lambda t: t.to(DEV)
+    M1p, Gp = M1.clone(), Gm.clone()
+    M1p[m1_dead] = float("nan"); Gp[g_dead] = float("nan")          # dead rows were "never written"
+    md, gd = d(m1_dead.to(torch.uint8)), d(g_dead.to(torch.uint8))
+    rows = torch.nonzero(~m1_dead).reshape(-1).to(torch.int32).to(DEV)
+    gdl = gd[rows.long()].contiguous()
+    _, T_full = ops.linear2_fwd_raw(d(M1), d(W1), d(b1), act, d(W2), want_y1=False)
+    _, T_list = ops.linear2_fwd_raw(d(M1p), d(W1), d(b1), act, d(W2), want_y1=False, a_dead=md, rows=rows)
+    live = ~m1_dead
+    assert torch.equal(T_list.cpu()[live], T_full.cpu()[live])
+    y0 = torch.relu(b1.double()) if act else b1.double()
+    t0 = y0 @ W2.double().t()
+    assert float((T_list.cpu()[m1_dead].double() - t0).abs().max()) <= 1e-6 * float(t0.abs().max())
+    assert rel(T_list, T_full) < 1e-6
+    want = ops.gcn2_bwd_dense_raw(d(Gm), d(dZ), None, act, d(M1), d(W2), W1=d(W1), b1=d(b1))
+    got = ops.gcn2_bwd_dense_raw(d(Gp), d(dZ), None, act, d(M1p), d(W2), W1=d(W1), b1=d(b1), m1_dead=md, g_dead=gd,
+                                 rows=rows, g_dead_listed=gdl)
+    for a, b in zip(got, want):
+        assert rel(a, b) < TOL
+    # fp64 check of the dead rows' share as well
+    Gd, Yd = Gm.double(), (torch.relu(M1.double() @ W1.double().t() + b1.double()) if act else M1.double() @ W1.double().t() + b1.double())
+    dY1 = Gd @ W2.double()
+    if act:
+        dY1 = dY1 * (Yd > 0)
+    assert rel(got[2], Gd.t() @ Yd) < TOL and rel(got[1], dY1.sum(0)) < TOL and rel(got[3], dZ.double().sum(0)) < TOL
+    assert rel(got[0], dY1.t() @ M1.double()) < TOL
