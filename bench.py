@@ -110,6 +110,13 @@ def parse():
                          "library's default for layers that narrow wide features (X read once per direction, the 40 MB "
                          "aggregate A X never exists; value of gae.py:26-31 up to fp32 rounding); reference = "
                          "act((A X) W^T + b) in the reference's order (the F_in-wide SpMM is then the dominant launch)")
+    ap.add_argument("--features", choices=["auto", "dense", "sparse"], default="auto",
+                    help="citation workloads, the constant input features X: dense = as the reference holds them, a dense "
+                         "FloatTensor (gae_xw_fwd / gae_xw_wgrad stream it once per direction); sparse = compressed once at "
+                         "set-up (gae_dgl_amd.SparseFeatures: the non-zeros of the bag-of-words rows), layer 1 from the "
+                         "non-zeros (gae_spx_fwd / gae_spx_wgrad, same values); auto (default) = SparseFeatures."
+                         "maybe_from_dense: compressed only where that is faster (wide and very sparse X: Citeseer, Cora; "
+                         "Pubmed -- the headline -- stays dense)")
     ap.add_argument("--no-fused-layers", action="store_true",
                     help="run narrow GCN layers as two launches (update_all, apply_nodes) instead of gae_gcn_layer_fused")
     ap.add_argument("--no-hipgraph", action="store_true",
@@ -286,6 +293,12 @@ class CitationWorkload:
         self.opt, opt_name = make_adam(self.model.parameters(), 1e-2, args, self.use_graph)  # train_transductive.py:43
         self.g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
         self.Xd = ops.pad_rows(torch.from_numpy(X).to(dev))                  # rows padded to whole 128-B lines
+        feats = getattr(args, "features", "auto")
+        if feats == "sparse":
+            self.Xd = G.SparseFeatures.from_dense(self.Xd)                   # once: X is constant across epochs
+        elif feats == "auto" and args.layer1 == "transform-first":
+            self.Xd = G.SparseFeatures.maybe_from_dense(self.Xd, self.hidden[0])    # (train_transductive.py:37-38: loaded once)
+        self.sparse = isinstance(self.Xd, G.SparseFeatures)
         self.g.csr(); self.g.csc(); self.g.spmm_plan(False); self.g.spmm_plan(True); self.g.scattered()   # static
         E = self.g.number_of_edges()
         self.edges_per_step = E * (2 * len(self.hidden) - 1)                   # L fwd + (L-1) bwd SpMM launches
@@ -303,7 +316,17 @@ class CitationWorkload:
         self.dtype = DTYPE_SPLIT if args.loss == "fused" else "f32"
         self.tf = args.layer1 == "transform-first"
         J = self.hidden[0]
-        if self.tf:
+        if self.sparse:
+            nnz = self.Xd.nnz
+            self.dominant = ("spx_fwd", n, self.F_in, J, nnz)
+            self.dominant_desc = (f"spx_fwd P = X W^T from the {nnz} non-zeros of X ({100.0 * nnz / (n * self.F_in):.1f} % "
+                                  f"of {n} x {self.F_in}; X is constant across steps and was compressed once at set-up)")
+            self.alg_bytes = 8 * nnz + 4 * (n + 1) + 4 * (n * J + J * self.F_in)
+            self.pmc_key = ""
+            self.meta["layer1"] = ("act(A (X W^T) + b) with X W^T and dW = G^T X from the non-zeros of the constant input "
+                                   "features (gae_dgl_amd.SparseFeatures, compressed once at set-up: --features "
+                                   f"{feats}; gae_spx_fwd / gae_spx_wgrad; same values as the dense kernels)")
+        elif self.tf:
             # the step's HBM-dominant launch is the dense pass over X (gae_xw_fwd); its compulsory bytes: X + P + W
             self.dominant = ("xw_fwd", n, self.F_in, J, "torch.float32")
             self.dominant_desc = (f"xw_fwd P = X W^T, {n} x {self.F_in} -> {J} (layer 1 in transform-first order: the "
@@ -324,6 +347,9 @@ class CitationWorkload:
     def dominant_launch(self):
         """the step's dominant HBM launch on its real operands: X W^T (transform-first) or the aggregation A X"""
         from gae_dgl_amd import ops
+        if self.sparse:
+            W1 = self.model.layers[0].apply_mod.linear.weight.detach()
+            return lambda: ops.spx_fwd_raw(self.Xd, W1)
         if self.tf:
             W1 = self.model.layers[0].apply_mod.linear.weight.detach()
             return lambda: ops.xw_fwd_raw(self.Xd, W1, None, 0, keep_splits=True)      # as the step launches it
@@ -799,6 +825,9 @@ def extra_steps(args, dev):
         r = {"workload": wl.meta["workload"], "ms_per_step": el * 1e3, "value": wl.edges_per_step / el, "unit": "edges/s",
              "launch": wl.meta.get("launch"), "timing": {"regions": len(regions), "steps_per_region": a.steps},
              "dominant": {"kernel": wl.dominant_desc, "avg_launch_us": t_dom * 1e6, "alg_bytes_per_launch": wl.alg_bytes,
+                          **({"note": "a launch on the non-zeros moves 1-3 MB: it is bound by its chain of dependent round trips "
+                                      "(row pointers -> ids / values -> gathered rows), not by bytes; `frac` is small by "
+                                      "construction"} if getattr(wl, "sparse", False) else {}),
                           "achieved_GBs": wl.alg_bytes / t_dom / 1e9, "frac": wl.alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS,
                           "traffic": pmc_traffic(getattr(wl, "pmc_key", ""))}}
         if B is not None:

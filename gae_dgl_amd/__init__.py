@@ -7,5 +7,6 @@ streams, autograd plumbing and torch.distributed."""
 from . import function, init  # noqa: F401
 from .graph import DGLGraph, Graph, batch, readout_nodes  # noqa: F401
 from .gae import GAE, GCN, InnerProductDecoder, NodeApplyModule, gcn_msg, gcn_reduce  # noqa: F401
+from .sparse import SparseFeatures  # noqa: F401
 
 __version__ = "0.1.0"

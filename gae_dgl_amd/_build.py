@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(LIBDIR, "libgae_hip.so")
-SOURCES = ["api.hip", "csr_build.hip", "plan_build.hip", "spmm.hip", "spmm_ell.hip", "dense.hip", "xw.hip", "tall.hip", "decoder_bce.hip", "optim.hip", "readout.hip", "bce_dense.hip"]
+SOURCES = ["api.hip", "csr_build.hip", "plan_build.hip", "spmm.hip", "spmm_ell.hip", "dense.hip", "xw.hip", "tall.hip", "spfeat.hip", "decoder_bce.hip", "optim.hip", "readout.hip", "bce_dense.hip"]
 ARCH = "gfx950"
 # per-file extra flags.  decoder_bce: let MFMA accumulators live in VGPRs (gfx950 has a unified file) so the
 # VALU epilogue of every tile does not pay one v_accvgpr_read per logit.

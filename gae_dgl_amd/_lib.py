@@ -112,6 +112,13 @@ SIGNATURES = {
     "gae_xw_wgrad_workspace_bytes": (_i64, [_i64, _i64, _int]),
     "gae_xw_wgrad": (_int, [_p, _i64, _int, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _p,
                             _p, _i64, _p]),
+    "gae_dense_to_csr_count": (_int, [_p, _i64, _i64, _i64, _p, _p]),
+    "gae_dense_to_csr_fill": (_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p]),
+    "gae_spx_fwd_workspace_bytes": (_i64, [_i64]),
+    "gae_spx_fwd": (_int, [_p, _p, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p]),
+    "gae_spx_wgrad_layout": (_int, [_i64, _i64, _i64, _p]),
+    "gae_spx_wgrad": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _i64,
+                             _p, _int, _p, _i64, _p]),
     "gae_linear_fwd_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "gae_linear_fwd": (_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _int, _p, _i64, _p, _i64, _p]),
     "gae_linear_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64]),

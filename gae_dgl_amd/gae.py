@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 from . import function as fn
 from . import ops
+from .sparse import SparseFeatures
 from ._lib import ACT_IDENTITY, ACT_RELU
 
 
@@ -107,7 +108,25 @@ class GCN(nn.Module):
         lin = self.apply_mod.linear
         return ops.gcn_layer_transform_first(g, feature, lin.weight, lin.bias, code, use_norm=(mode == "both"))
 
+    def _forward_sparse_input(self, g, sf):
+        """``feature`` is a sparse.SparseFeatures (compressed input): the layer from its non-zeros, or from its dense
+        form when the one-pass route does not apply"""
+        code = _act_code(self.apply_mod.activation)
+        if sf.device != g.device and sf.device.type == "cuda":
+            g.to(sf.device)
+        mode = g.norm_mode if self.norm is None else self.norm
+        lin = self.apply_mod.linear
+        if code is not None and mode in ("none", "both"):
+            g.ndata['h'] = sf                    # same traffic on g.ndata['h'] as the dense path (gae.py:27,30)
+            out = ops.gcn_layer_sparse_input(g, sf, lin.weight, lin.bias, code, use_norm=(mode == "both"))
+            if out is not None:
+                g.ndata.pop('h')
+                return out
+        return self.forward(g, sf.to_dense())
+
     def forward(self, g, feature):
+        if isinstance(feature, SparseFeatures):
+            return self._forward_sparse_input(g, feature)
         # same traffic on g.ndata['h'] as the reference: set (gae.py:27), reduced in place (:28), transformed in
         # place (:29), removed (:30)
         g.ndata['h'] = feature

@@ -1958,6 +1958,109 @@ def gcn_layer_transform_first(graph, H, W, b, act, use_norm=False):
     return GCNTransformFirstFunction.apply(H, W, b, graph, use_norm, act)
 
 
+# ------------------------------------------------------------------ layer 1 on sparse input features (opt-in)
+def spx_fwd_raw(sf, W):
+    """P = X W^T from the compressed rows of X (gae_spx_fwd); sf: sparse.SparseFeatures"""
+    W = _f32(_gpu(W, "W"), "spx_fwd: W")
+    if W.stride(1) != 1:
+        W = W.contiguous()
+    n, K = sf.shape
+    J = W.shape[0]
+    ldp = (J + 3) // 4 * 4
+    P = torch.empty(n, ldp, dtype=torch.float32, device=W.device)[:, :J]
+    with _on_device(W.device):
+        ws = _workspace(K * 32 * 4 + 256, W.device)
+
+        def launch():
+            _lib.call("gae_spx_fwd", _ptr(sf.rowptr), _ptr(sf.col), _ptr(sf.val), n, K, _ptr(W), W.stride(0), J, _ptr(P),
+                      ldp, _ptr(ws), ws.numel(), _stream())
+        if profiler is not None:
+            profiler.wrap(("spx_fwd", n, K, J, sf.nnz), launch)
+        else:
+            launch()
+    return P
+
+
+def spx_wgrad_raw(sf, G, D, Dmask, f_out, need_dW=True, need_db=True):
+    """(dW = G^T X from the compressed rows of X^T, db = colsum(D (.) [Dmask > 0])) -- gae_spx_wgrad; inside
+    deferred_grad_reductions() the sums stay partial lists for the optimiser launch"""
+    n, K = sf.shape
+    dev = G.device
+    G, ldg = _rowmajor(_f32(G, "spx_wgrad: G"), "G")
+    ldd = lddm = 0
+    if D is not None:
+        D, ldd = _rowmajor(_f32(D, "spx_wgrad: D"), "D")
+    if Dmask is not None:
+        Dmask, lddm = _rowmajor(_f32(Dmask, "spx_wgrad: Dmask"), "Dmask")
+    dW = torch.empty(f_out, K, dtype=torch.float32, device=dev) if need_dW else None
+    db = torch.empty(f_out, dtype=torch.float32, device=dev) if need_db and D is not None else None
+    lay = (ctypes.c_int64 * 5)()
+    _lib.call("gae_spx_wgrad_layout", n, K, sf.max_segments, lay)
+    defer = current_step().defer_grads and (dW is not None or db is not None)
+    with _on_device(dev):
+        ws = torch.empty(lay[4], dtype=torch.uint8, device=dev) if defer else _workspace(lay[4], dev)
+
+        def launch():
+            _lib.call("gae_spx_wgrad", _ptr(sf.t_rowptr), _ptr(sf.t_row), _ptr(sf.t_val), _ptr(sf.seg_feat),
+                      _ptr(sf.seg_e0), _ptr(sf.seg_slot), sf.seg_feat.numel(), sf.max_segments, n, K, _ptr(G), ldg,
+                      _ptr(D), ldd, _ptr(Dmask), lddm, int(f_out), _ptr(dW), max(K, 1), _ptr(db), 0 if defer else 1,
+                      _ptr(ws), ws.numel(), _stream())
+        if profiler is not None:
+            profiler.wrap(("spx_wgrad", n, K, f_out, sf.nnz), launch)
+        else:
+            launch()
+    if defer:
+        if dW is not None:
+            current_step().add_partials(dW, (ws, ws.data_ptr(), lay[0], lay[1], f_out * K, f_out * K))
+        if db is not None:
+            current_step().add_partials(db, (ws, ws.data_ptr() + 4 * lay[2], lay[3], 32, f_out, f_out))
+    return dW, db
+
+
+class GCNSparseInputFunction(torch.autograd.Function):
+    """GCNTransformFirstFunction on compressed input features: P = X W^T and dW = G^T X come from the non-zeros of X
+    (gae_spx_fwd / gae_spx_wgrad); the sparse halves (gae_spmm_csr_epilogue) are the same launches"""
+
+    @staticmethod
+    def forward(ctx, W, b, sf, graph, use_norm, act):
+        indptr, indices = graph.csr()
+        norm = graph.norm() if use_norm else None
+        n = graph.number_of_nodes()
+        P = spx_fwd_raw(sf, W)
+        Y = spmm_epilogue_raw(indptr, indices, P, n, graph.spmm_plan(False), b, act, None, norm, norm)
+        ctx.act, ctx.has_bias, ctx.sf, ctx.f_out = act, b is not None, sf, W.shape[0]
+        ctx.bwd = (graph.csc(), n, norm, graph.spmm_plan(True))
+        ctx.save_for_backward(Y if act == ACT_RELU else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        (Y,) = ctx.saved_tensors
+        (t_indptr, t_indices), n, norm, plan_t = ctx.bwd
+        need_dW = ctx.needs_input_grad[0]
+        need_db = ctx.has_bias and ctx.needs_input_grad[1]
+        dW = db = None
+        dYc, _ = _rowmajor(_f32(dY, "dY"), "dY")
+        if need_dW or need_db:
+            G = spmm_epilogue_raw(t_indptr, t_indices, dYc, n, plan_t, None, ACT_IDENTITY, Y, norm, norm) \
+                if need_dW else dYc
+            dW, db = spx_wgrad_raw(ctx.sf, G, dYc if need_db else None, Y, ctx.f_out, need_dW=need_dW, need_db=need_db)
+        return dW, db, None, None, None, None
+
+
+def gcn_layer_sparse_input(graph, sf, W, b, act, use_norm=False):
+    """the layer on sparse.SparseFeatures input, or None when graph / widths do not allow it (the caller then
+    densifies)"""
+    n = graph.number_of_nodes()
+    if sf.shape[0] != n or W.shape[0] > 32 or W.shape[1] != sf.shape[1] or graph.number_of_edges() == 0:
+        return None
+    if n * ((W.shape[0] + 3) // 4 * 4) * 4 + (1 << 16) >= (1 << 32):
+        return None
+    if not (_table_only(graph.spmm_plan(False)) and _table_only(graph.spmm_plan(True))):
+        return None
+    return GCNSparseInputFunction.apply(W, b, sf, graph, use_norm, act)
+
+
 class LinearFunction(torch.autograd.Function):
     """NodeApplyModule: act(M W^T + b)  (gae.py:13-16)."""
 

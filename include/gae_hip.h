@@ -499,6 +499,39 @@ int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, int64_t ldd
  *  b1 [f_mid] or NULL -- with gae_linear2_fwd's products in its order, i.e. the same bits: the forward then need not
  *  store Y1 at all (gae_linear2_fwd with Y1 = NULL) and this pass reads 2 f_mid fewer floats per row.) */
 
+/* ---- layer 1 on SPARSE input features (opt-in; gae_dgl_amd.SparseFeatures) -------
+ * The citation features the reference loads as a dense FloatTensor (gae_dgl/train_transductive.py:37-38) are
+ * bag-of-words rows with 1-10 % non-zeros.  Handed over in compressed form they give the same layer-1 values
+ * (the skipped terms are exact zeros) from 8 bytes per non-zero instead of 4 bytes per entry:
+ *   gae_dense_to_csr_count / _fill: compressed rows of a dense [n, K] matrix, columns ascending (count the non-zeros
+ *       per row, prefix-sum them on the caller's side into rowptr[n + 1], fill col / val); used for X and for X^T.
+ *   gae_spx_fwd:   P [n, f_out] = X W^T from the compressed rows of X (f_out <= 32), ascending-column order; the weight
+ *       is first transposed into `workspace` (gae_spx_fwd_workspace_bytes(f_in): f_in rows of one 128-byte line), so that a
+ *       non-zero gathers ONE line.  Measured (tools/r04/spx_bench.py, pair fwd + wgrad against gae_xw_fwd + gae_xw_wgrad):
+ *       Citeseer 17.5 vs 34.7 us, Cora 15.0 vs 16.8 us, Pubmed 27.7 vs 26.4 us -- worth it for wide, very sparse X only
+ *       (SparseFeatures.maybe_from_dense applies that rule).
+ *   gae_spx_wgrad: dW [f_out, f_in] = G^T X from the compressed rows of X^T cut into SEGMENTS of <= 64 entries of
+ *       one feature (seg_feat / seg_e0 / seg_slot [n_segments]: feature, first entry, index of the segment inside its
+ *       feature; every feature has at least one -- possibly empty -- segment), and db = colsum(D (.) [Dmask > 0]).
+ *       reduce = 1: dW / db are finished by a second launch; reduce = 0: the partial lists stay in `workspace`
+ *       (gae_spx_wgrad_layout: [0] partials per element of dW, [1] floats between them (element (j, k) at j * f_in + k),
+ *       [2] float offset of the db partials, [3] their count (32 floats apart), [4] workspace bytes) for
+ *       gae_adam_step's deferred reduction. */
+int gae_dense_to_csr_count(const float *X, int64_t ldx, int64_t n, int64_t K, int32_t *row_nnz, void *stream);
+int gae_dense_to_csr_fill(const float *X, int64_t ldx, int64_t n, int64_t K, const int32_t *rowptr, int32_t *col,
+                          float *val, void *stream);
+int64_t gae_spx_fwd_workspace_bytes(int64_t f_in);
+int gae_spx_fwd(const int32_t *rowptr, const int32_t *col, const float *val, int64_t n, int64_t f_in,
+                const float *W, int64_t ldw, int64_t f_out, float *P, int64_t ldp, void *workspace,
+                int64_t workspace_bytes, void *stream);
+int gae_spx_wgrad_layout(int64_t n, int64_t f_in, int64_t max_segments_per_feature, int64_t *out);
+int gae_spx_wgrad(const int32_t *t_rowptr, const int32_t *t_row, const float *t_val,
+                  const int32_t *seg_feat, const int32_t *seg_e0, const int32_t *seg_slot, int64_t n_segments,
+                  int64_t max_segments_per_feature, int64_t n, int64_t f_in,
+                  const float *G, int64_t ldg, const float *D, int64_t ldd, const float *Dmask, int64_t lddm,
+                  int64_t f_out, float *dW, int64_t lddw, float *db, int reduce,
+                  void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16
  * M [n, f_in] (ldm), W [f_out, f_in] row-major contiguous (nn.Linear.weight,
