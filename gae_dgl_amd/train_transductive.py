@@ -37,6 +37,10 @@ def build_parser():
     ap.add_argument("--norm", choices=["none", "both"], default="none")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--log_every", type=int, default=50)
+    ap.add_argument("--features", choices=["auto", "dense"], default="auto",
+                    help="auto: the features are loaded once and stay constant (the reference's train_transductive.py:37-38), "
+                         "so they are compressed at load time WHERE layer 1 runs faster from their non-zeros "
+                         "(SparseFeatures.maybe_from_dense: Citeseer, Cora); dense: always the dense FloatTensor")
     ap.add_argument("--no_hipgraph", action="store_true",
                     help="launch every kernel from Python instead of replaying the captured step")
     ap.add_argument("--eval", action="store_true",
@@ -60,6 +64,9 @@ def main(argv=None):
     from gae_dgl_amd.optim import Adam
     data = load_data(args)
     features = ops.pad_rows(torch.as_tensor(data.features, dtype=torch.float32).to(device))   # 16 / 128-byte rows
+    if args.features == "auto" and device.type == "cuda":
+        from gae_dgl_amd import SparseFeatures
+        features = SparseFeatures.maybe_from_dense(features, args.hidden_dims[0])
     n_nodes = data.graph.number_of_nodes()
     held_out = None
     if args.eval:

@@ -47,7 +47,7 @@ def pmc_means(d, needles=("spmm",)):
 
 
 benches = {}
-for name in ("pubmed", "pubmed_reference_order", "cora", "citeseer", "vgae", "zinc", "zinc128", "zinc_eager", "zinc128_eager",
+for name in ("pubmed", "pubmed_reference_order", "cora", "citeseer", "cora_dense_features", "citeseer_dense_features", "vgae", "zinc", "zinc128", "zinc_eager", "zinc128_eager",
              "rmat_s24_1gpu", "rmat_s24_1gpu_aggregate_first"):
     p = os.path.join(SRC, f"bench_{name}.json")
     if os.path.exists(p):
@@ -58,7 +58,7 @@ for w in ("pubmed", "cora", "citeseer", "vgae", "zinc", "zinc128", "rmat"):
     if os.path.exists(st):
         shutil.copy(st, os.path.join(DST, f"{TAG}_{w}_step_kernel_stats.csv"))
         shutil.copy(os.path.join(SRC, f"{w}_step_kernel_stats_top.txt"), os.path.join(DST, f"{TAG}_{w}_step_kernel_stats_top.txt"))
-for f in ("tall_bench.txt", "xtg_probe.txt", "zinc_l1.txt", "loss_condition.txt", "bce_bench_cora.txt", "plan_build_time.txt", "xw_bench.txt", "xw_sweep_pubmed.txt", "linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt", "bce_bench_zinc.txt",
+for f in ("spx_bench.txt", "tall_bench.txt", "xtg_probe.txt", "zinc_l1.txt", "loss_condition.txt", "bce_bench_cora.txt", "plan_build_time.txt", "xw_bench.txt", "xw_sweep_pubmed.txt", "linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt", "bce_bench_zinc.txt",
           "probe_gather_l2.txt", "probe_gather_l2b.txt", "probe_valu_rate.txt", "probe_inst_cost.txt",
           "probe_mfma32_check.txt"):
     if os.path.exists(os.path.join(SRC, f)):

@@ -12,6 +12,8 @@ bench)
   timeout 900 python bench.py > $O/bench_pubmed.json 2> $O/bench_pubmed.err
   timeout 600 python bench.py --layer1 reference --no-extra --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_pubmed_reference_order.json
   for w in cora citeseer zinc vgae; do timeout 600 python bench.py --workload $w --no-extra 2>/dev/null | tail -1 > $O/bench_$w.json; done
+  # (cora / citeseer: --features auto compresses their constant input features; the same steps on the dense features:)
+  for w in cora citeseer; do timeout 600 python bench.py --workload $w --features dense --no-extra --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_${w}_dense_features.json; done
   timeout 600 python bench.py --workload zinc --batch-graphs 128 --steps 300 --warmup 30 --no-extra 2>/dev/null | tail -1 > $O/bench_zinc128.json
   MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 timeout 900 python bench.py --workload rmat --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_rmat_s24_1gpu.json
   MASTER_ADDR=127.0.0.1 MASTER_PORT=29535 timeout 900 python bench.py --workload rmat --steps 5 --warmup 2 --no-cpu-baseline --layer-order aggregate-first 2>/dev/null | tail -1 > $O/bench_rmat_s24_1gpu_aggregate_first.json
@@ -40,6 +42,8 @@ pmc)
 micro)
   timeout 300 python tools/r03/xw_bench.py 2>/dev/null > $O/xw_bench.txt
   timeout 300 python tools/r04/xtg_probe.py 2>/dev/null > $O/xtg_probe.txt
+  timeout 300 python tools/r04/spx_bench.py 2>/dev/null > $O/spx_bench.txt
+  timeout 300 python tools/r04/tall_bench.py 2>/dev/null > $O/tall_bench.txt
   timeout 300 python tools/r04/zinc_l1.py 2>/dev/null > $O/zinc_l1.txt
   timeout 300 python tools/r04/loss_condition.py --sym 2>/dev/null > $O/loss_condition.txt
   timeout 300 python tools/bce_bench.py --variants "sym=1,sb=3;sym=1,sb=2;sym=1,sb=1;sym=1,sb=0;sym=0,sb=0,pb=0" --rounds 5 2>/dev/null > $O/bce_bench_pubmed.txt
