@@ -679,8 +679,9 @@ class RmatShardedWorkload:
                      "layer_order": "(A H) W^T for every layer (gae.py:26-31)" if not self.transform_first else
                                     "32 -> 32 layer: (A X) W1^T; 32 -> 16 layer: A (H1 W2^T) + b2, its backward from "
                                     "G = A^T dZ: two of the three aggregations (and exchanges) run at width 16; dense "
-                                    "halves: gae_linear2_fwd + gae_gcn2_bwd_dense, one pass each (value of gae.py:26-31 "
-                                    "up to fp32 rounding)",
+                                    "halves: gae_linear2_fwd + gae_gcn2_bwd_dense, one pass each over the rows that have in-edges (the "
+                                    "others' aggregate is zero: not written, not read; their share is a constant row / "
+                                    "a rank-one term) (value of gae.py:26-31 up to fp32 rounding)",
                      "local_rows": p.n_local, "local_edges_fwd": e_local,
                      "csr_build_ms": self.csr_build_ms, "plan_build_ms": self.plan_build_ms,
                      "plan_bytes": self.plan_bytes,
