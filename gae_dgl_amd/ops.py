@@ -901,12 +901,14 @@ def _dead_mask(t, n, what):
     return t
 
 
-def linear2_fwd_raw(A, W1, b1, act1, W2, want_y1=True, a_dead=None, rows=None):
+def linear2_fwd_raw(A, W1, b1, act1, W2, want_y1=True, a_dead=None, rows=None, fill=None):
     """(Y1, T): Y1 = act1(A W1^T + b1), T = Y1 W2^T in ONE pass over A (gae_linear2_fwd); Y1 None when not wanted.
     Both outputs have rows of whole 16-byte vectors.  ``a_dead`` (uint8 [n]): rows of A that are zero and were never
     written (spmm_raw(skip_dead=True)) -- not read.  ``rows`` (int32, ascending; with ``a_dead`` marking all the others):
     list mode -- the two products run on the listed rows only, the other rows of T get their common value
-    act1(b1) W2^T (gae_linear2_fill_dead); Y1 is not available then."""
+    act1(b1) W2^T (gae_linear2_fill_dead); Y1 is not available then.  ``fill`` (uint8 [n], default ``a_dead``): the
+    rows that receive that value -- a caller who knows that some dead rows of T are never read (T as the gather operand
+    of the next aggregation: nodes without out-edges) leaves them unwritten."""
     A, lda = _rowmajor(_f32(_gpu(A, "A"), "linear2: A"), "A")
     if lda % 4 or A.data_ptr() % 16:
         A = pad_rows(A); lda = A.stride(0)
@@ -932,8 +934,8 @@ def linear2_fwd_raw(A, W1, b1, act1, W2, want_y1=True, a_dead=None, rows=None):
                 _lib.call("gae_linear2_fwd", _ptr(A), lda, n, f_in, _ptr(W1), W1.stride(0), _ptr(b1), f_mid, int(act1),
                           _ptr(W2), W2.stride(0), f_out, None, ld1, _ptr(T), ld2, None, _ptr(rows), int(rows.numel()),
                           _stream())
-                _lib.call("gae_linear2_fill_dead", _ptr(b1), f_mid, int(act1), _ptr(W2), W2.stride(0), f_out, _ptr(a_dead), n,
-                          _ptr(T), ld2, _stream())
+                _lib.call("gae_linear2_fill_dead", _ptr(b1), f_mid, int(act1), _ptr(W2), W2.stride(0), f_out,
+                          _ptr(a_dead if fill is None else _dead_mask(fill, n, "linear2")), n, _ptr(T), ld2, _stream())
                 return
             _lib.call("gae_linear2_fwd", _ptr(A), lda, n, f_in, _ptr(W1), W1.stride(0), _ptr(b1), f_mid, int(act1),
                       _ptr(W2), W2.stride(0), f_out, _ptr(Y1), ld1, _ptr(T), ld2, _ptr(a_dead), None, 0, _stream())

@@ -319,6 +319,14 @@ class ShardedGraph:
             self._csr[key] = dead.to(torch.uint8).contiguous()
         return self._csr[key]
 
+    def read_dead_rows(self):
+        """uint8 [n_local]: rows without in-edges that HAVE out-edges (their row of a forward operand is gathered by
+        somebody, so it must hold the value all zero-aggregate rows share)"""
+        key = ("dead", "read")
+        if key not in self._csr:
+            self._csr[key] = (self.dead_rows("fwd").bool() & ~self.dead_rows("bwd").bool()).to(torch.uint8).contiguous()
+        return self._csr[key]
+
     def live_rows(self, which="fwd"):
         """(int32 list of the rows WITH edges in ``which`` direction, ascending; the other direction's dead mask at those
         rows) -- the rows the dense passes of the one-pass encoder visit (list mode)"""
@@ -569,8 +577,11 @@ class ShardedEncoder2Function(torch.autograd.Function):
         need = any(ctx.needs_input_grad[1:5])
         # H1 is not stored: the backward pass recomputes it, bit for bit, from the tile of M1 it reads anyway
         rows = sg.live_rows("fwd")[0] if (dead is not None and LIST_MODE) else None
+        # T is the gather operand of the next aggregation and nothing else: of the rows without in-edges only those WITH
+        # out-edges are ever read (here or, after the exchange, on another rank) -- isolated nodes stay unwritten
+        fill = sg.read_dead_rows() if rows is not None else None
         _, T = sg._timed("dense_fwd", lambda: ops.linear2_fwd_raw(M1, W1, b1, act1, W2, want_y1=False, a_dead=dead,
-                                                                  rows=rows))
+                                                                  rows=rows, fill=fill))
         Z = _rank_product(sg, T, "fwd", bias=b2)
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
         if need:
