@@ -75,6 +75,38 @@ __device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
     sg = (x >= 0.f ? 1.0f : e) * r;
 }
 
+
+// The per-logit terms of four logits y_r = x_r log2(e) from ONE reciprocal.  With t_r = 1 + 2^-|y_r| in [1, 2]:
+//   sum log2(t) rides in the running product (tP *= t0 t1 t2 t3), sum |y| in tA, and
+//   sigmoid(x_r) - 1/2 = copysign(1 / t_r - 1/2, x_r),  1 / t_0 = (R t2 t3) t1 with R = 1 / (t0 t1 t2 t3), ...
+// i.e. 1 v_rcp + 2 products + 4 FMAs (the -1/2 rides in them) where the straight form issues 4 v_rcp + 4 adds -- a
+// transcendental costs 2.5 issue slots of a v_fma (tools/probes/inst_cost.hip), and the products t0 t1, t2 t3 are
+// the first level of the product tree anyway.  Error of 1 / t_r: the reciprocal's 1 ulp + three roundings, ~3e-7.
+__device__ __forceinline__ f32x4 quad_terms(const f32x4 &y, float &tP, float &tA)
+{
+    float t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        t[r] = 1.0f + __builtin_amdgcn_exp2f(-fabsf(y[r]));
+        tA += fabsf(y[r]);
+    }
+    const float t01 = t[0] * t[1], t23 = t[2] * t[3], q = t01 * t23;
+    tP *= q;
+    const float R = __builtin_amdgcn_rcpf(q);
+    // (scalar VALU instructions on purpose: left to itself the compiler pairs these into v_pk_mul / v_pk_fma, which
+    //  cost what two scalar ones cost AND need a v_mov per operand to line the register pairs up -- the saving was gone)
+    // (the two products that READ the reciprocal stay with the compiler: a VALU instruction that uses a transcendental's
+    //  result needs wait states, which the hazard recogniser does not insert in front of inline assembly -- as inline
+    //  assembly they read a stale R in the rolled 256-row-panel loop)
+    const float r01 = R * t23, r23 = R * t01;
+    float s0, s1, s2, s3;
+    asm("v_fma_f32 %0, %1, %2, -0.5" : "=v"(s0) : "v"(r01), "v"(t[1]));
+    asm("v_fma_f32 %0, %1, %2, -0.5" : "=v"(s1) : "v"(r01), "v"(t[0]));
+    asm("v_fma_f32 %0, %1, %2, -0.5" : "=v"(s2) : "v"(r23), "v"(t[3]));
+    asm("v_fma_f32 %0, %1, %2, -0.5" : "=v"(s3) : "v"(r23), "v"(t[2]));
+    return f32x4{copysignf(s0, y[0]), copysignf(s1, y[1]), copysignf(s2, y[2]), copysignf(s3, y[3])};
+}
+
 // ---------------------------------------------------------------------------
 // prepare: Zt[n][DP] = Z (.) mask zero padded to DP = 16 KS columns (clean 16-byte rows, no mask loads or
 // feature bounds checks downstream), its bf16 hi / lo split, and per-block fp64 column sums of Zt over all
@@ -294,6 +326,8 @@ __device__ __forceinline__ float minus_f16_hi(float v, unsigned hh)
 }
 // hi = fp16(v) and lo = fp16(v - hi), both round-to-nearest-even (v_cvt_pk_f16_f32); v - hi is exact in fp32:
 // |v - hi - lo| <= 2^-22 |v| for 2^-14 <= |v| <= 65504.  4 VALU instructions per pair of values.
+// (v_fma_mixlo / mixhi_f16 would round v - hi straight into the fp16 halves, one instruction less per pair: measured
+//  SLOWER -- ZINC-95 k step 2.92 -> 3.01 ms -- and not the same bits; not used.)
 __device__ __forceinline__ void split_f16x4(const f32x4 &v, s16x4 &hi, s16x4 &lo)
 {
     unsigned h[2], l[2];
@@ -516,18 +550,7 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
                 // sacc[ri][r] = x(i = l15 of subtile ri, j = jt*16 + 4 g + r)
                 f32x4 p[RI];
 #pragma unroll
-                for (int ri = 0; ri < RI; ++ri) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float x = sacc[ri][r];                 // = x_ij * log2(e)
-                        const float e = __builtin_amdgcn_exp2f(-fabsf(x));
-                        const float t = 1.0f + e;
-                        tP[ri] *= t;
-                        tA[ri] += fabsf(x);
-                        const float sg = __builtin_amdgcn_rcpf(t) - 0.5f;   // in [0, 1/2]
-                        p[ri][r] = copysignf(sg, x);             // sigmoid(x) - 1/2
-                    }
-                }
+                for (int ri = 0; ri < RI; ++ri) p[ri] = quad_terms(sacc[ri], tP[ri], tA[ri]);   // sigmoid(x) - 1/2 (sacc = x_ij * log2(e))
                 if (WITH_GRAD && PBF16) {     // P = hi + lo (bf16) on the fly
 #pragma unroll
                     for (int ri = 0; ri < RI; ++ri) {
@@ -888,17 +911,7 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
                 // sacc[ri][r] = y(i = l15 of subtile ri, j = jt*16 + 4 g + r), y = x log2(e)
 #pragma unroll
                 for (int ri = 0; ri < RI; ++ri) {
-                    f32x4 p;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float x = sacc[ri][r];
-                        const float e = __builtin_amdgcn_exp2f(-fabsf(x));
-                        const float t = 1.0f + e;
-                        tP[ri] *= t;
-                        tA[ri] += fabsf(x);
-                        const float sg = __builtin_amdgcn_rcpf(t) - 0.5f;   // in [0, 1/2]
-                        p[r] = copysignf(sg, x);                            // sigmoid(x) - 1/2
-                    }
+                    const f32x4 p = quad_terms(sacc[ri], tP[ri], tA[ri]);     // sigmoid(x) - 1/2
                     if (WITH_GRAD) {
                         s16x4 h4, l4;
                         if (F16) split_f16x4(p, h4, l4);
