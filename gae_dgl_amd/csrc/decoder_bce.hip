@@ -82,6 +82,11 @@ __device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
 // i.e. 1 v_rcp + 2 products + 4 FMAs (the -1/2 rides in them) where the straight form issues 4 v_rcp + 4 adds -- a
 // transcendental costs 2.5 issue slots of a v_fma (tools/probes/inst_cost.hip), and the products t0 t1, t2 t3 are
 // the first level of the product tree anyway.  Error of 1 / t_r: the reciprocal's 1 ulp + three roundings, ~3e-7.
+// SCALAR_TREE: the three products of the tree as plain v_mul_f32 as well (same values).  Measured on one box, whole
+// training steps: 128-row panels (RI = 2, Pubmed) 0.2233 -> 0.2218 ms with the compiler's pairing, -> 0.2172 ms with
+// scalar products; 256-row panels (RI = 4, ZINC batch of 4096, rolled column loop) 2.952 -> 2.880 ms with the compiler's
+// pairing, 2.957 ms with scalar products -- each kernel takes the form that is faster for it.
+template <bool SCALAR_TREE>
 __device__ __forceinline__ f32x4 quad_terms(const f32x4 &y, float &tP, float &tA)
 {
     float t[4];
@@ -90,7 +95,14 @@ __device__ __forceinline__ f32x4 quad_terms(const f32x4 &y, float &tP, float &tA
         t[r] = 1.0f + __builtin_amdgcn_exp2f(-fabsf(y[r]));
         tA += fabsf(y[r]);
     }
-    const float t01 = t[0] * t[1], t23 = t[2] * t[3], q = t01 * t23;
+    float t01, t23, q;
+    if constexpr (SCALAR_TREE) {    // (paired, the compiler spends two v_mov and two v_pk_mul on these three products)
+        asm("v_mul_f32 %0, %1, %2" : "=v"(t01) : "v"(t[0]), "v"(t[1]));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(t23) : "v"(t[2]), "v"(t[3]));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(t01), "v"(t23));
+    } else {
+        t01 = t[0] * t[1]; t23 = t[2] * t[3]; q = t01 * t23;
+    }
     tP *= q;
     const float R = __builtin_amdgcn_rcpf(q);
     // (scalar VALU instructions on purpose: left to itself the compiler pairs these into v_pk_mul / v_pk_fma, which
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
                 // sacc[ri][r] = x(i = l15 of subtile ri, j = jt*16 + 4 g + r)
                 f32x4 p[RI];
 #pragma unroll
-                for (int ri = 0; ri < RI; ++ri) p[ri] = quad_terms(sacc[ri], tP[ri], tA[ri]);   // sigmoid(x) - 1/2 (sacc = x_ij * log2(e))
+                for (int ri = 0; ri < RI; ++ri) p[ri] = quad_terms<RI == 2>(sacc[ri], tP[ri], tA[ri]);   // sigmoid(x) - 1/2 (sacc = x_ij * log2(e))
                 if (WITH_GRAD && PBF16) {     // P = hi + lo (bf16) on the fly
 #pragma unroll
                     for (int ri = 0; ri < RI; ++ri) {
@@ -911,7 +923,7 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
                 // sacc[ri][r] = y(i = l15 of subtile ri, j = jt*16 + 4 g + r), y = x log2(e)
 #pragma unroll
                 for (int ri = 0; ri < RI; ++ri) {
-                    const f32x4 p = quad_terms(sacc[ri], tP[ri], tA[ri]);     // sigmoid(x) - 1/2
+                    const f32x4 p = quad_terms<RI == 2>(sacc[ri], tP[ri], tA[ri]);     // sigmoid(x) - 1/2
                     if (WITH_GRAD) {
                         s16x4 h4, l4;
                         if (F16) split_f16x4(p, h4, l4);
