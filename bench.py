@@ -59,10 +59,11 @@ SLOT_COST = {"plain": 1.0, "trans": 2.5, "pk": 1.8, "cvt_pk": 1.7, "bfi": 1.7, "
 # kernels' main loops (decoder_bce.hip, K = 32 MFMAs); third entry: share of the N^2 logits that is evaluated
 LOSS_ISA = {
     # round 4: the symmetric kernel splits into fp16 pieces (v_cvt_pk_f16_f32 / v_cvt_pkrtz_f16_f32 counted as cvt_pk,
-    # v_fma_mix_f32 as plain; tools/isa_hist.sh on its tile loop: 551 instructions), the full-square kernel forms S
-    # from three bf16 pieces (24 + 12 MFMAs)
-    "symmetric": ({"trans": 66, "pk": 21, "cvt_pk": 68, "bfi": 32, "perm": 0, "lshl": 0, "plain": 167, "mfma": 56}, 0.5),
-    "full": ({"trans": 64, "pk": 36, "cvt_pk": 32, "bfi": 32, "perm": 0, "lshl": 16, "plain": 110, "mfma": 36}, 1.0),
+    # v_fma_mix_f32 as plain), the full-square kernel forms S from three bf16 pieces (24 + 12 MFMAs); since the
+    # one-reciprocal-per-four-logits form 10 instead of 34 transcendentals behind the 32 v_exp (tile loops of the
+    # gfx950 assembly, instruction classes counted by script: 424 / 344 vector instructions per tile)
+    "symmetric": ({"trans": 42, "pk": 6, "cvt_pk": 68, "bfi": 32, "perm": 0, "lshl": 3, "plain": 217, "mfma": 56}, 0.5),
+    "full": ({"trans": 40, "pk": 14, "cvt_pk": 32, "bfi": 32, "perm": 0, "lshl": 22, "plain": 168, "mfma": 36}, 1.0),
 }
 
 
