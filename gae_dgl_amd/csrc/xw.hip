@@ -256,7 +256,14 @@ struct XtgArgs {
     int64_t rows_per_part;             // multiple of 32
 };
 
-template <typename TX, int NH, bool MASKED, int DBG = 0, int NS = 4, int U = 2>
+// rows of G a block of the GLDS form can stage (16 NH floats each): 128 KB of the CU's 160 KB
+constexpr int kXtgGldsBytes = 128 * 1024;
+
+// GLDS: the partition's rows of G (gated by Gmask) are staged in LDS once per block and the A operands are read from
+// there -- the main loop requests nothing but X.  (Round 4 took the kernel apart: X loads + MFMAs without the G loads
+// 9.8 us, everything 12.9 us on Pubmed -- the 8-byte G requests, one more per row group in the same in-order queue as
+// the X stream, cost the last 3 us although they all hit L2.)
+template <typename TX, int NH, bool MASKED, int DBG = 0, int NS = 4, int U = 2, bool GLDS = false>
 __global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
 {
     constexpr int ES = int(sizeof(TX));
@@ -264,7 +271,12 @@ __global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
     constexpr int SW = 16 * NQ;                     // columns of a block's slice (64 / 128)
     // U: 4-row groups per pipeline stage, NS: stages (NS - 1 of them in flight while one is multiplied)
     constexpr int DBU = 8;                          // db: elements per thread in flight
-    __shared__ __attribute__((aligned(16))) float red[8][16 * NH][SW + 4];
+    constexpr int GW = 16 * NH;                     // floats per staged row of G
+    constexpr int RED_FLOATS = 8 * 16 * NH * (SW + 4);
+    constexpr int SMEM_FLOATS = GLDS ? (RED_FLOATS > kXtgGldsBytes / 4 ? RED_FLOATS : kXtgGldsBytes / 4) : RED_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];       // Gs during the main loop, then the waves' tiles
+    float (*red)[16 * NH][SW + 4] = reinterpret_cast<float (*)[16 * NH][SW + 4]>(smem);
+    float *Gs = smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
@@ -320,6 +332,7 @@ __global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
             const int64_t row = rbeg + 4 * (wave + 8 * (U * it + u)) + g;
             const bool ok = row < rend;
             s.x[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (ok && DBG != 2) ? unsigned(row) * a.ldx_bytes + xcol : kBehind, 0, 0);
+            if constexpr (GLDS) continue;           // the A operands come from LDS (compute)
             const unsigned go = (ok && j_ok && DBG != 3) ? unsigned(row) * a.ldg_bytes + gcol : kBehind;
             const unsigned mo = (ok && j_ok) ? unsigned(row) * a.ldgm_bytes + gcol : kBehind;
             if constexpr (NH == 2) {
@@ -336,7 +349,20 @@ __global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
             }
         }
     };
-    auto compute = [&](const Stage &s) {
+    auto compute = [&](const Stage &s, int64_t it) {
+        float gl[U][NH];
+        if constexpr (GLDS) {                       // all of the stage's A operands requested before the first MFMA
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float *gp = Gs + (4 * (wave + 8 * (U * int(it) + u)) + g) * GW + NH * l15;
+                if constexpr (NH == 2) {
+                    const gae::v2f t = *reinterpret_cast<const gae::v2f *>(gp);
+                    gl[u][0] = t[0]; gl[u][1] = t[1];
+                } else {
+                    gl[u][0] = *gp;
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float xv[NQ];
@@ -352,8 +378,13 @@ __global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
             }
 #pragma unroll
             for (int mh = 0; mh < NH; ++mh) {
-                const bool on = NH * l15 + mh < a.J && (!masked || __uint_as_float(s.gm[u][mh]) > 0.f);
-                const float gval = on ? __uint_as_float(s.gv[u][mh]) : 0.f;
+                float gval;
+                if constexpr (GLDS) {
+                    gval = gl[u][mh];               // (gated and zero-padded when it was staged)
+                } else {
+                    const bool on = NH * l15 + mh < a.J && (!masked || __uint_as_float(s.gm[u][mh]) > 0.f);
+                    gval = on ? __uint_as_float(s.gv[u][mh]) : 0.f;
+                }
                 if constexpr (DBG == 1) {
                     acc[mh][0][0] += gval * (xv[0] + xv[NQ - 1]);
                 } else {
@@ -368,23 +399,67 @@ __global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
     const int64_t my_groups = groups > wave ? (groups - wave + 7) / 8 : 0;       // ... of this wave
     const int64_t iters = (my_groups + U - 1) / U;
 #define GAE_PIN() __builtin_amdgcn_sched_barrier(0)
-    if (iters > 0 && DBG != 4) {
-        Stage st[NS];
+    // GLDS: rows the waves read from LDS = those of wave 0's stages (the longest list), staged with zeros behind the
+    // partition: 16-byte pieces, requested BEFORE the first X stages and written to LDS behind them (the vector-memory
+    // counter is in order: waiting for the G pieces leaves the X stages in flight)
+    constexpr int GPT = 8;                          // 16-byte pieces per thread and trip
+    const int cap_rows = int((((groups + 7) / 8 + U - 1) / U) * U * 32);
+    const int n_pieces = GLDS ? cap_rows * (GW / 4) : 0;
+    u32x4 gq[GLDS ? GPT : 1], gmq[(GLDS && MASKED) ? GPT : 1];
+    auto g_request = [&](int e0) {
+#pragma unroll
+        for (int t = 0; t < GPT; ++t) {
+            const int e = e0 + 512 * t + tid;
+            const int64_t row = rbeg + e / (GW / 4);
+            const unsigned c4 = unsigned(e % (GW / 4)) * 16u;
+            const bool ok = e < n_pieces && row < rend && DBG != 3;
+            gq[t] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? unsigned(row) * a.ldg_bytes + c4 : kBehind, 0, 0);
+            if constexpr (MASKED)
+                gmq[t] = __builtin_amdgcn_raw_buffer_load_b128(rm, ok ? unsigned(row) * a.ldgm_bytes + c4 : kBehind, 0, 0);
+        }
+    };
+    auto g_store = [&](int e0) {
+#pragma unroll
+        for (int t = 0; t < GPT; ++t) {
+            const int e = e0 + 512 * t + tid;
+            if (e >= n_pieces) continue;
+            const int j0 = (e % (GW / 4)) * 4;
+            v4f v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool on = j0 + q < a.J && (!masked || __uint_as_float(gmq[MASKED ? t : 0][q]) > 0.f);
+                v[q] = on ? __uint_as_float(gq[t][q]) : 0.f;
+            }
+            *reinterpret_cast<v4f *>(Gs + int64_t(e) * 4) = v;
+        }
+    };
+    Stage st[NS];
+    const bool run = iters > 0 && DBG != 4;
+    if constexpr (GLDS) g_request(0);               // (every wave stages, also one without row groups of its own)
+    if (run) {
 #pragma unroll
         for (int d = 0; d < NS - 1; ++d) issue(st[d], d);
-        GAE_PIN();
+    }
+    GAE_PIN();
+    if constexpr (GLDS) {
+        g_store(0);
+        for (int e0 = 512 * GPT; e0 < n_pieces; e0 += 512 * GPT) { g_request(e0); g_store(e0); }
+        lds_barrier();
+    }
+    if (run) {
         for (int64_t it = 0; it < iters; it += NS) {
             bool more = true;
 #pragma unroll
             for (int d = 0; d < NS; ++d) {
                 if (more) {
-                    issue(st[(d + NS - 1) % NS], it + d + NS - 1); GAE_PIN(); compute(st[d]); GAE_PIN();
+                    issue(st[(d + NS - 1) % NS], it + d + NS - 1); GAE_PIN(); compute(st[d], it + d); GAE_PIN();
                     more = it + d + 1 < iters;
                 }
             }
         }
     }
 #undef GAE_PIN
+    if constexpr (GLDS) lds_barrier();              // the waves' tiles below overwrite the staged rows
     // ---- the 8 waves' tiles meet in LDS: acc[mh][q][r] = dW[NH (4 g + r) + mh][slice SW + NQ l15 + q]
 #pragma unroll
     for (int mh = 0; mh < NH; ++mh)
@@ -456,6 +531,7 @@ gae::Knob g_xw_parts{0};      // "xw_parts": row partitions of the backward (0 =
 gae::Knob g_xw{1};            // "xw": 0 = never use this family (dense.hip kernels instead)
 gae::Knob g_xw_depth{0};      // "xw_depth" (experiments): other ring depths of the fp32 kernels (forward 3 / 4 / 5 tiles, default 2;
                               // backward (stages, groups) (2, 4) / (3, 4) / (4, 4) / (6, 2), default (4, 2))
+gae::Knob g_xw_glds{1};       // "xw_glds": 1 = the backward stages its partition's rows of G in LDS (J > 16), 0 = loads them per row group
 gae::Knob g_xw_xcd{1};        // "xw_xcd": XCD-aware block order of the backward (1) or slice-major ids (0); same sums
 gae::Knob g_xw_dbg{0};        // "xw_dbg" (experiments, wrong results): 1 = without MFMAs, 2 = without X loads; backward also 3 = without G loads, 4 = without its main loop
 
@@ -523,6 +599,7 @@ Knob *xw_knob(const char *name)
     if (strcmp(name, "xw") == 0) return &g_xw;
     if (strcmp(name, "xw_dbg") == 0) return &g_xw_dbg;
     if (strcmp(name, "xw_xcd") == 0) return &g_xw_xcd;
+    if (strcmp(name, "xw_glds") == 0) return &g_xw_glds;
     if (strcmp(name, "xw_depth") == 0) return &g_xw_depth;
     return nullptr;
 }
@@ -633,6 +710,9 @@ int xtg_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const flo
     a.xcd_map = g_xw_xcd != 0;
     const dim3 grid(unsigned(p.n_slices) * unsigned(p.parts));
     const bool wide = J > 16;
+    // staged G ("xw_glds", default on): the rows the waves read -- wave 0's stages of 2 x 32 rows -- must fit 128 KB
+    const int64_t groups_max = (p.rows_per_part + 3) / 4, cap_rows = (((groups_max + 7) / 8 + 1) / 2) * 2 * 32;
+    const bool glds = g_xw_glds != 0 && want_dw && cap_rows * 32 * 4 <= kXtgGldsBytes;
 #define GAE_XTG(TX, NH, ...) do { if (a.Gmask) hipLaunchKernelGGL((xtg_kernel<TX, NH, true, __VA_ARGS__>), grid, dim3(512), 0, s, a); \
                                    else hipLaunchKernelGGL((xtg_kernel<TX, NH, false, __VA_ARGS__>), grid, dim3(512), 0, s, a); } while (0)
     if (elem == 4) {
@@ -644,10 +724,13 @@ int xtg_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const flo
         else if (wide && g_xw_depth == 4) GAE_XTG(float, 2, 0, 4, 4);
         else if (wide && g_xw_depth == 3) GAE_XTG(float, 2, 0, 3, 4);
         else if (wide && g_xw_depth == 6) GAE_XTG(float, 2, 0, 6, 2);
+        else if (wide && glds) GAE_XTG(float, 2, 0, 4, 2, true);
         else if (wide) GAE_XTG(float, 2, 0);
         else GAE_XTG(float, 1, 0);
     } else {
-        if (wide) GAE_XTG(unsigned short, 2, 0); else GAE_XTG(unsigned short, 1, 0);
+        if (wide && glds) GAE_XTG(unsigned short, 2, 0, 4, 2, true);
+        else if (wide) GAE_XTG(unsigned short, 2, 0);
+        else GAE_XTG(unsigned short, 1, 0);
     }
 #undef GAE_XTG
     GAE_CHECK_LAUNCH("xtg_kernel");

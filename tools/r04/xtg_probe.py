@@ -18,6 +18,13 @@ Wt = torch.randn(J, K, device=dev) / K ** 0.5
 with ops.deferred_grad_reductions() as step:
   for il in (0,):
     print(f"xw_fwd {t(lambda: ops.xw_fwd_raw(Xd, Wt, None, 0)):6.2f} us")
+    for glds in (1, 0):          # G staged in LDS once per block | loaded per row group
+        _lib.call("gae_tuning_set", b"xw_glds", glds)
+        a = t(lambda: ops.xw_wgrad_raw(Xd, G, None, None, None, J))
+        b = t(lambda: ops.xw_wgrad_raw(Xd, G, None, G, Y, J))
+        c = t(lambda: ops.xw_wgrad_raw(Xd, G, Y, G, Y, J))
+        print(f"  xw_glds {glds}: dW only {a:6.2f}  with db {b:6.2f}  masked {c:6.2f} us", flush=True)
+    _lib.call("gae_tuning_set", b"xw_glds", 0)
     for dbg in (0, 1, 2, 3, 4):
         _lib.call("gae_tuning_set", b"xw_dbg", dbg)
         a = t(lambda: ops.xw_wgrad_raw(Xd, G, None, None, None, J))
@@ -25,4 +32,5 @@ with ops.deferred_grad_reductions() as step:
         c = t(lambda: ops.xw_wgrad_raw(Xd, G, Y, G, Y, J))
         print(f"  dbg{dbg}: dW only {a:6.2f}  with db {b:6.2f}  masked {c:6.2f} us", flush=True)
     _lib.call("gae_tuning_set", b"xw_dbg", 0)
+    _lib.call("gae_tuning_set", b"xw_glds", 1)
   step.partials.clear()
