@@ -82,7 +82,16 @@ def test_xw_wgrad_matches_fp64(n, K, J, dtype, tuning):
     assert none is None and torch.equal(dW3, dW2)
     _, db4 = ops.xw_wgrad_raw(Xp, Gd, None, Dd, Md, J, need_dW=False)
     assert torch.equal(db4, db)
-    tuning("xw_parts", 3)
+    # G staged in LDS once per block (default where the partition's rows fit, J > 16) == G loaded per row group: the same
+    # products in the same order, bit for bit; with NaN behind the rows' J columns of a wider G (the staging must gate
+    # them as the per-group loads do)
+    Gw = torch.full((n, J + 4), float("nan"), device=DEV); Gw[:, :J] = Gd
+    tuning("xw_glds", 0)
+    dW6, db6 = ops.xw_wgrad_raw(Xp, Gw[:, :J], Md, Dd, Md, J)
+    tuning("xw_glds", 1)
+    dW7, db7 = ops.xw_wgrad_raw(Xp, Gw[:, :J], Md, Dd, Md, J)
+    assert torch.equal(dW6, dW) and torch.equal(db6, db) and torch.equal(dW7, dW) and torch.equal(db7, db)
+    tuning("xw_parts", 3)                 # (Pubmed: 6573 rows per partition do not fit the LDS stage: per-group loads)
     dW5, _ = ops.xw_wgrad_raw(Xp, Gd, Md, Dd, Md, J)
     assert rel(dW5, gm.t() @ ref_x) < TOL
 
