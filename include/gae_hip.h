@@ -86,8 +86,9 @@ int gae_device_info_get(int device, gae_device_info *out_host);
  *    "bce_sym_grid", "bce_sym_tiles", "bce_grid"; a skew
  *    plan (gae_spmm_plan with heavy rows) and GAE_SPMM_ACCUMULATE do the same for the rows they touch;
  *    "xw" (0 = the layer-1 stream kernels of gae_xw_fwd are never used by gae_linear_fwd), "xw_rows" (rows per block
- *    of gae_xw_fwd, 0 = auto), "xw_parts" (row partitions of gae_xw_wgrad, 0 = auto) likewise; "xw_depth" / "xw_xcd"
- *    select pipeline depths / the block order of those kernels (same sums); "xw_dbg" (experiments: WRONG results --
+ *    of gae_xw_fwd, 0 = auto), "xw_parts" (row partitions of gae_xw_wgrad, 0 = auto) likewise; "xw_depth" / "xw_xcd" /
+ *    "xw_glds" select pipeline depths / the block order of those kernels / whether gae_xw_wgrad stages its rows of G
+ *    in LDS (same sums, bit for bit); "xw_dbg" (experiments: WRONG results --
  *    1 = no MFMAs, 2 = no loads of X);
  *  - select the ARITHMETIC of matrix-core products: "bce_s_bf16" / "bce_pv_bf16" / "atb_bf16" (1 = bf16 x 3 split
  *    products, default; 0 = exact fp32 MFMA) and "linear_bf16" (default 0 = exact fp32 forward Linear). */
