@@ -407,8 +407,9 @@ __global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
     const int n_pieces = GLDS ? cap_rows * (GW / 4) : 0;
     u32x4 gq[GLDS ? GPT : 1], gmq[(GLDS && MASKED) ? GPT : 1];
     auto g_request = [&](int e0) {
+        if constexpr (!GLDS) return;
 #pragma unroll
-        for (int t = 0; t < GPT; ++t) {
+        for (int t = 0; t < (GLDS ? GPT : 1); ++t) {
             const int e = e0 + 512 * t + tid;
             const int64_t row = rbeg + e / (GW / 4);
             const unsigned c4 = unsigned(e % (GW / 4)) * 16u;
@@ -419,8 +420,9 @@ __global__ __launch_bounds__(512) void xtg_kernel(const XtgArgs a)
         }
     };
     auto g_store = [&](int e0) {
+        if constexpr (!GLDS) return;
 #pragma unroll
-        for (int t = 0; t < GPT; ++t) {
+        for (int t = 0; t < (GLDS ? GPT : 1); ++t) {
             const int e = e0 + 512 * t + tid;
             if (e >= n_pieces) continue;
             const int j0 = (e % (GW / 4)) * 4;
