@@ -84,8 +84,10 @@ __device__ __forceinline__ void softplus_sigmoid(float x, float &sp, float &sg)
 // the first level of the product tree anyway.  Error of 1 / t_r: the reciprocal's 1 ulp + three roundings, ~3e-7.
 // SCALAR_TREE: the three products of the tree as plain v_mul_f32 as well (same values).  Measured on one box, whole
 // training steps: 128-row panels (RI = 2, Pubmed) 0.2233 -> 0.2218 ms with the compiler's pairing, -> 0.2172 ms with
-// scalar products; 256-row panels (RI = 4, ZINC batch of 4096, rolled column loop) 2.952 -> 2.880 ms with the compiler's
-// pairing, 2.957 ms with scalar products -- each kernel takes the form that is faster for it.
+// scalar products.  256-row panels (RI = 4, ZINC batch of 4096): with the ROLLED column loop 2.952 -> 2.880 ms with the
+// compiler's pairing and 2.957 ms with scalar products; the four-logit form freed enough registers to UNROLL that loop
+// (250 VGPRs, no spill: 2.853 -> 2.794 ms), and unrolled the scalar products win there as well (234 VGPRs, 2.81 -> 2.72 ms).
+// The symmetric kernels therefore all take the scalar form; the full-square kernel (small graphs) follows its RI.
 template <bool SCALAR_TREE>
 __device__ __forceinline__ f32x4 quad_terms(const f32x4 &y, float &tP, float &tA)
 {
@@ -684,8 +686,9 @@ __global__ __launch_bounds__(256, MINW) void bce_dense_kernel(
 // rows per panel = 64 RI (4 waves x RI subtiles of 16 rows); "bce_sym_ri" = 0 (auto) | 2 | 4.  Taller panels halve
 // the mirror strips (N^2 / 8 bytes: 2.2 -> 1.1 GB written and read back on a ZINC batch) at the price of registers
 // (2 waves per SIMD): they pay from ~32 k rows on (ZINC batch of 95 k rows: 3.00 -> 2.92 ms; Pubmed, 20 k rows:
-// 185 -> 194 us).  With the K = 32 fragments the fully unrolled 256-row body spilled 43 VGPRs (3.48 ms); its
-// column-pair loop is therefore left rolled (238 VGPRs, no spill).
+// 185 -> 194 us).  With the K = 32 fragments the fully unrolled 256-row body spilled 43 VGPRs (3.48 ms) and its
+// column-pair loop was left rolled (238 VGPRs) -- until the one-reciprocal-per-four-logits form (quad_terms) freed
+// enough registers: unrolled it now takes 234 VGPRs without a spill (ZINC step 2.853 -> 2.72 ms).
 gae::Knob g_bce_sym_ri{0};
 gae::Knob g_bce_sym_tr{1};    // "bce_sym_tr": 1 = V fragments by LDS transpose reads (ds_read_b64_tr_b16), 0 = from transposed tile copies
 
@@ -901,7 +904,8 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
         float tA[RI], tP[RI];
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri) { tA[ri] = 0.f; tP[ri] = 1.f; }
-#pragma unroll(RI == 4 ? 1 : TJ / 32)
+        // (256-row panels: unrolled since the four-logit form -- 234 VGPRs; the three-piece fallback stays rolled: it spills unrolled)
+#pragma unroll((RI == 4 && S3) ? 1 : TJ / 32)
         for (int jp = 0; jp < TJ / 32; ++jp) {           // pairs of 16-column subtiles
             s16x8 ph[RI], pl[RI];                        // P of the pair: [subtile 2 jp | subtile 2 jp + 1]
 #pragma unroll
@@ -923,7 +927,7 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
                 // sacc[ri][r] = y(i = l15 of subtile ri, j = jt*16 + 4 g + r), y = x log2(e)
 #pragma unroll
                 for (int ri = 0; ri < RI; ++ri) {
-                    const f32x4 p = quad_terms<RI == 2>(sacc[ri], tP[ri], tA[ri]);     // sigmoid(x) - 1/2
+                    const f32x4 p = quad_terms<true>(sacc[ri], tP[ri], tA[ri]);     // sigmoid(x) - 1/2
                     if (WITH_GRAD) {
                         s16x4 h4, l4;
                         if (F16) split_f16x4(p, h4, l4);
