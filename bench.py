@@ -63,6 +63,9 @@ LOSS_ISA = {
     # one-reciprocal-per-four-logits form 10 instead of 34 transcendentals behind the 32 v_exp (tile loops of the
     # gfx950 assembly, instruction classes counted by script: 424 / 344 vector instructions per tile)
     "symmetric": ({"trans": 42, "pk": 6, "cvt_pk": 68, "bfi": 32, "perm": 0, "lshl": 3, "plain": 217, "mfma": 56}, 0.5),
+    # the 256-row-panel form of the symmetric kernel (from 32 k rows on; unrolled tile loop: 711 vector instructions per
+    # 64 logits and lane, halved here)
+    "symmetric256": ({"trans": 40, "pk": 3, "cvt_pk": 66, "bfi": 32, "perm": 0, "lshl": 1.5, "plain": 157, "mfma": 56}, 0.5),
     "full": ({"trans": 40, "pk": 14, "cvt_pk": 32, "bfi": 32, "perm": 0, "lshl": 22, "plain": 168, "mfma": 36}, 1.0),
 }
 
@@ -1126,7 +1129,7 @@ def main():
         loss_fn = wl.loss_launch()                  # (sets wl.n for the molecule batches)
         n = wl.n
         t_loss = time_launches(loss_fn, iters=20 if n < 50000 else 5, warmup=5 if n < 50000 else 2)
-        kind = "symmetric" if n >= 8192 else "full"          # gae_decoder_bce's own rule (bce_sym, d <= 16)
+        kind = "symmetric256" if n >= 32768 else "symmetric" if n >= 8192 else "full"     # gae_decoder_bce's own rules (bce_sym, bce_sym_ri; d <= 16)
         per_logit, frac_eval = loss_slots_per_logit(kind)
         units = per_logit * frac_eval * float(n) * n
         isa = LOSS_ISA[kind][0]
