@@ -742,13 +742,17 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
     __shared__ __attribute__((aligned(16))) unsigned short L2s[2][S3 ? TJ * LDH : 4];       // bf16 lo2 [j][k] (three-piece S)
     __shared__ __attribute__((aligned(16))) unsigned short HT[2][TRV ? 4 : DP * LDT];       // bf16 hi [k][j]
     __shared__ __attribute__((aligned(16))) unsigned short LT[2][TRV ? 4 : DP * LDT];       // bf16 lo [k][j]
-    __shared__ __attribute__((aligned(16))) float MR[4][16 * LDM];                // mirror tiles [wave][f][j]
+    // mirror tiles [buffer][wave][f][j].  Two buffers (round 4): the tile after next rewrites a buffer only behind the NEXT tile's
+    // barrier, which every thread passes after it has flushed this one -- the second block barrier per tile is gone.  (Round 2
+    // tried this with the transposed tile copies still in LDS: 54 KB per block, 2 instead of 3 blocks per CU, 157 -> 179 us; since
+    // the LDS transpose reads the block holds 45 KB and three still fit.)
+    __shared__ __attribute__((aligned(16))) float MR[2][4][16 * LDM];
     __shared__ double red[4][2];
 
   auto unit = [&](const unsigned bx, const unsigned by) {     // one (panel bx, column chunk by) unit of work
     if (bx >= n_panels) {   // the extra block column: column sums of Zt for the kernels that follow
         if (by == 0)
-            bce_colsum_block(colsum_partial, n_prep_blocks, DP, S, S_all_f, reinterpret_cast<double *>(&MR[0][0]));
+            bce_colsum_block(colsum_partial, n_prep_blocks, DP, S, S_all_f, reinterpret_cast<double *>(&MR[0][0][0]));
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -878,11 +882,11 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
     };
     // sum the 4 waves' mirror tiles of the tile that started at column j0 and store it to this panel's strip
     float *strip = Wmir + sym_strip_offset(I, NP, SYM_PR);
-    auto flush_mirror = [&](int64_t j0) {
+    auto flush_mirror = [&](int64_t j0, int mb) {
         const int f = tid >> 4, jq = (tid & 15) * 4;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(&MR[0][f * LDM + jq]);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&MR[mb][0][f * LDM + jq]);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(&MR[w][f * LDM + jq]);
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(&MR[mb][w][f * LDM + jq]);
         // tile-major strip: the 16 x 64 block of one column tile is 4 KB of contiguous memory (written here by one
         // block, read back by one block of the reduction) instead of 16 pieces of 256 bytes
         f32x4 *sp = reinterpret_cast<f32x4 *>(strip + (j0 - diag_end) * 16 + f * TJ + jq);
@@ -991,7 +995,7 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
                             macc = mfma_k32<F16>(qh, zTh[rp], macc);
                         }
                         // macc[r] = mirror(j = jt*16 + 4 g + r, f = l15)  ->  MR[wave][f][j]
-                        *reinterpret_cast<f32x4 *>(&MR[wave][l15 * LDM + (2 * jp + h) * 16 + 4 * g]) = macc;
+                        *reinterpret_cast<f32x4 *>(&MR[buf][wave][l15 * LDM + (2 * jp + h) * 16 + 4 * g]) = macc;
                     }
                 }
             }
@@ -1021,10 +1025,7 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
         compute_tile(buf, j0, offdiag);
         if (more) store_tile(buf ^ 1, stage);
         __syncthreads();
-        if (WITH_GRAD && offdiag) {                 // block-uniform
-            flush_mirror(j0);
-            __syncthreads();                        // MR is rewritten by the next tile
-        }
+        if (WITH_GRAD && offdiag) flush_mirror(j0, buf);    // block-uniform; (the next tile writes the other mirror buffer)
     }
     // ---- O' partial: oacc[ri][r] = O'(i = 4 g + r, f = l15) of subtile ri
     if (WITH_GRAD) {
