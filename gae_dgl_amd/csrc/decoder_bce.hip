@@ -737,8 +737,12 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
     constexpr int V4 = TJ * DP / 4 / 256;  // = 1
     constexpr int LDT = TJ + 4;          // transposed bf16 tile row stride (elements)
     constexpr int LDM = TJ + 4;          // mirror tile row stride (floats)
-    __shared__ __attribute__((aligned(16))) unsigned short Hs[2][TJ * LDH];       // bf16 hi [j][k]
-    __shared__ __attribute__((aligned(16))) unsigned short Ls[2][TJ * LDH];       // bf16 lo [j][k]
+    // hi and lo pieces of a column tile INTERLEAVED per row: [hi k 0..3 | lo k 0..3 | hi k 4..7 | lo k 4..7 | ...], rows of
+    // 2 DP + 8 elements (80 bytes: the 16-byte pieces of 16 consecutive rows fall on disjoint banks).  A lane's [ah | al]
+    // operand of the S product is ONE ds_read_b128 straight into four consecutive registers (two 8-byte reads from two
+    // arrays needed four v_mov per subtile to line them up); the LDS transpose reads take the pieces at stride 16 bytes.
+    constexpr int LDHL = 2 * DP + 8;
+    __shared__ __attribute__((aligned(16))) unsigned short HLs[2][TJ * LDHL];
     __shared__ __attribute__((aligned(16))) unsigned short L2s[2][S3 ? TJ * LDH : 4];       // bf16 lo2 [j][k] (three-piece S)
     __shared__ __attribute__((aligned(16))) unsigned short HT[2][TRV ? 4 : DP * LDT];       // bf16 hi [k][j]
     __shared__ __attribute__((aligned(16))) unsigned short LT[2][TRV ? 4 : DP * LDT];       // bf16 lo [k][j]
@@ -869,8 +873,7 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
             } else {
                 h4 = st.h[q]; l4 = st.l[q];
             }
-            *reinterpret_cast<s16x4 *>(&Hs[buf][jj * LDH + kk]) = h4;
-            *reinterpret_cast<s16x4 *>(&Ls[buf][jj * LDH + kk]) = l4;
+            *reinterpret_cast<s16x8 *>(&HLs[buf][jj * LDHL + 2 * kk]) = cat(h4, l4);
             if (WITH_GRAD && !TRV) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -915,9 +918,8 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int jt = 2 * jp + h;
-                const s16x4 ah = *reinterpret_cast<const s16x4 *>(&Hs[buf][(jt * 16 + l15) * LDH + 4 * g]);
-                const s16x4 al = *reinterpret_cast<const s16x4 *>(&Ls[buf][(jt * 16 + l15) * LDH + 4 * g]);
-                const s16x8 ahl = cat(ah, al);
+                const s16x8 ahl = *reinterpret_cast<const s16x8 *>(&HLs[buf][(jt * 16 + l15) * LDHL + 8 * g]);
+                const s16x4 ah = get_half(ahl, 0);
                 f32x4 sacc[RI];
 #pragma unroll
                 for (int ri = 0; ri < RI; ++ri) {
@@ -945,9 +947,9 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
                 const int jc = jp * 32 + 4 * g;
                 s16x8 vh, vl;                // lane (f = l15, g): Z[j = jc + r][f] | Z[j = jc + 16 + r][f]
                 if constexpr (TRV) {
-                    const int o = (jc + (l15 >> 2)) * LDH + 4 * (l15 & 3);
-                    vh = cat(lds_read_tr(&Hs[buf][o]), lds_read_tr(&Hs[buf][o + 16 * LDH]));
-                    vl = cat(lds_read_tr(&Ls[buf][o]), lds_read_tr(&Ls[buf][o + 16 * LDH]));
+                    const int o = (jc + (l15 >> 2)) * LDHL + 8 * (l15 & 3);
+                    vh = cat(lds_read_tr(&HLs[buf][o]), lds_read_tr(&HLs[buf][o + 16 * LDHL]));
+                    vl = cat(lds_read_tr(&HLs[buf][o + 4]), lds_read_tr(&HLs[buf][o + 4 + 16 * LDHL]));
                 } else {
                     vh = cat(*reinterpret_cast<const s16x4 *>(&HT[buf][l15 * LDT + jc]),
                              *reinterpret_cast<const s16x4 *>(&HT[buf][l15 * LDT + jc + 16]));
