@@ -121,6 +121,11 @@ def parse():
                          "non-zeros (gae_spx_fwd / gae_spx_wgrad, same values); auto (default) = SparseFeatures."
                          "maybe_from_dense: compressed only where that is faster (wide and very sparse X: Citeseer, Cora; "
                          "Pubmed -- the headline -- stays dense)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="N > 1 on a box with fewer than N GPUs: the ranks SHARE the visible device(s) (rank r on GPU "
+                         "r mod #GPUs) and the collectives travel over gloo, staged through host memory (RCCL refuses "
+                         "two ranks on one device).  A functional rehearsal of the N-rank launch with the real kernels; "
+                         "the line says so in config.transport and its numbers are NOT a scaling measurement")
     ap.add_argument("--no-fused-layers", action="store_true",
                     help="run narrow GCN layers as two launches (update_all, apply_nodes) instead of gae_gcn_layer_fused")
     ap.add_argument("--no-hipgraph", action="store_true",
@@ -877,7 +882,7 @@ def launch_ranks(args):
     Refuses -- exit code 2, nothing measured -- when fewer than N GPUs are visible."""
     import subprocess
     n = args.gpus
-    if args.workload != "mock":
+    if args.workload != "mock" and not args.oversubscribe:
         have = torch.cuda.device_count()
         if have < n:
             print(f"[bench] --gpus {n}: only {have} GPU(s) visible on this box; refusing to report a {n}-GPU number "
@@ -904,8 +909,9 @@ def timed_regions(wl, args, barrier, world, dev, min_total_s=0.5, max_regions=20
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
+            from gae_dgl_amd import transport
             tt = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            transport.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt)
         out.append(el)
         if sum(out) >= min_total_s or len(out) >= max_regions:      # same decision on every rank (max-reduced times)
@@ -939,6 +945,8 @@ def main():
     if mock:
         dev = torch.device("cpu")
     else:
+        if args.oversubscribe and torch.cuda.is_available():
+            local_rank = local_rank % torch.cuda.device_count()
         if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
             print(f"[bench] rank {rank}: needs GPU {local_rank}, {torch.cuda.device_count()} visible (bench.py "
                   f"measures MI355X GPUs only)", file=sys.stderr, flush=True)
@@ -951,7 +959,7 @@ def main():
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29500")
         # long timeout: after the N-rank regions rank 0 times the same workload on ONE GPU while the others wait
-        dist.init_process_group("gloo" if mock else "nccl", rank=rank, world_size=world,
+        dist.init_process_group("gloo" if (mock or args.oversubscribe) else "nccl", rank=rank, world_size=world,
                                 timeout=datetime.timedelta(minutes=60))
     n_gpus = dist.get_world_size() if dist.is_initialized() else 1       # from the LIVE process group
 
@@ -1002,6 +1010,9 @@ def main():
         wl = RmatShardedWorkload(args, dev, rank, world, group)
         torch.cuda.synchronize()
         wl.meta["workload_build_s"] = time.perf_counter() - t_build0
+        wl.meta["transport"] = ("RCCL (backend nccl), one process per GPU" if not args.oversubscribe else
+                                f"oversubscribed: {world} ranks share {torch.cuda.device_count()} GPU(s), collectives over gloo "
+                                f"staged through host memory -- functional rehearsal, not a scaling measurement")
     elif workload == "zinc":
         wl = ZincWorkload(args, dev)
     elif workload == "vgae":

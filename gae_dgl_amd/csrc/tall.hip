@@ -714,6 +714,11 @@ extern "C" int64_t gae_gcn2_bwd_dense_workspace_bytes(int64_t n, int64_t f_in, i
     if (n < 0 || f_in < 1 || f_mid < 1 || f_out < 1 || f_in > 32 || f_mid > 32 || f_out > 32) return GAE_E_SIZE;
     int64_t lay[5];
     gcn2_layout(n > 0 ? n : 1, f_in, f_mid, f_out, lay, nullptr);
+    // list mode lays the partials out for n_listed <= n rows, and the block count is NOT monotone in the row count
+    // once tiles-per-wave exceeds 1 (n = 300000 -> 782 blocks, 131072 -> 1024): size for the most any m <= n can take
+    const int64_t n_tiles = ((n > 0 ? n : 1) + 31) / 32;
+    const int64_t lay0_max = (n_tiles + 3) / 4 < 1024 ? (n_tiles + 3) / 4 : 1024;
+    if (lay[0] < lay0_max) lay[0] = lay0_max;
     return (lay[0] + 1) * lay[1] * 4 + kDeadBlocks * 64 * 4 + 256;       // (+ list mode: one more partial, the dead-row sums)
 }
 
@@ -753,6 +758,8 @@ extern "C" int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, 
         g_dead = g_dead_listed;
     }
     gcn2_layout(n, f_in, f_mid, f_out, lay, &tpw);
+    GAE_REQUIRE(workspace_bytes >= (lay[0] + 1) * lay[1] * 4 + kDeadBlocks * 64 * 4 + 256, GAE_E_WORKSPACE,
+                "gae_gcn2_bwd_dense: workspace too small for the listed rows' partials");
     hipStream_t s = gae::as_stream(stream);
     float *partial = static_cast<float *>(workspace);
     if (listed && n_listed == 0) { lay[0] = 0; }

@@ -35,6 +35,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import transport as comm
+
 
 def block_bounds(n, world):
     """equal row blocks (last one may be short): returns int64[world+1]"""
@@ -176,7 +178,7 @@ class RowPartition:
         if balance == "nnz":
             w = torch.bincount(dst, minlength=n) + torch.bincount(src, minlength=n)
             if world > 1:
-                dist.all_reduce(w, group=group)
+                comm.all_reduce(w, group=group)
             bounds = _weights_to_bounds(w + int(ROW_COST if row_cost is None else row_cost), world)
             del w
         else:
@@ -192,11 +194,11 @@ class RowPartition:
                 order = torch.argsort(owner, stable=True)
                 counts = torch.bincount(owner, minlength=world)
                 recv_counts = torch.empty_like(counts)
-                dist.all_to_all_single(recv_counts, counts, group=group)
+                comm.all_to_all_single(recv_counts, counts, group=group)
                 out = []
                 for t in (src, dst):
                     recv = torch.empty(int(recv_counts.sum()), dtype=torch.int64, device=t.device)
-                    dist.all_to_all_single(recv, t[order].contiguous(), output_split_sizes=recv_counts.tolist(),
+                    comm.all_to_all_single(recv, t[order].contiguous(), output_split_sizes=recv_counts.tolist(),
                                            input_split_sizes=counts.tolist(), group=group)
                     out.append(recv)
                 return out
@@ -363,9 +365,9 @@ class ShardedGraph:
                 continue
             dev = need.device
             send_counts = torch.zeros(p.world, dtype=torch.int64, device=dev)
-            dist.all_to_all_single(send_counts, counts, group=self.group)
+            comm.all_to_all_single(send_counts, counts, group=self.group)
             req = torch.empty(int(send_counts.sum()), dtype=torch.int64, device=dev)
-            dist.all_to_all_single(req, need, output_split_sizes=send_counts.tolist(),
+            comm.all_to_all_single(req, need, output_split_sizes=send_counts.tolist(),
                                    input_split_sizes=counts.tolist(), group=self.group)
             self._a2a[k] = dict(need=need, recv_counts=counts.tolist(), send_counts=send_counts.tolist(),
                                 send_idx=(req - p.r0).to(self.device))
@@ -388,7 +390,7 @@ class ShardedGraph:
             return self.allgather_rows(h_local)
         a = self._a2a[which]
         nb = p.n_before[which]          # rows owned by lower ranks arrive first (ascending global id)
-        if h_local.is_cuda and h_local.dtype == torch.float32 and dist.get_backend(self.group) == "nccl":
+        if h_local.is_cuda and h_local.dtype == torch.float32 and comm.backend(self.group) == "nccl":
             # HIP pack kernels + receive views: the rows to send go straight into the send buffer, the own rows
             # straight into their slot of the assembled buffer, and every peer's rows land where the local CSR
             # indexes them -- no ATen index_select / cat between two products
@@ -405,9 +407,9 @@ class ShardedGraph:
             return full
         send = h_local.index_select(0, a["send_idx"].to(h_local.device))
         recv = h_local.new_empty(sum(a["recv_counts"]), F)
-        dist.all_to_all_single(recv, send, output_split_sizes=a["recv_counts"], input_split_sizes=a["send_counts"],
+        comm.all_to_all_single(recv, send, output_split_sizes=a["recv_counts"], input_split_sizes=a["send_counts"],
                                group=self.group)
-        return torch.cat([recv[:nb], h_local, recv[nb:]])          # (gloo, CPU host-logic tests)
+        return torch.cat([recv[:nb], h_local, recv[nb:]])          # (gloo: CPU host-logic tests, ranks sharing a GPU)
 
     def exchange_start(self, h_local, which="fwd"):
         """overlap: start the exchange of the REMOTE rows and return (buffer the remote CSR indexes, wait()).  The
@@ -431,7 +433,7 @@ class ShardedGraph:
         else:
             send = h_local.index_select(0, a["send_idx"].to(h_local.device))
         recv = h_local.new_empty(sum(a["recv_counts"]), F)
-        work = dist.all_to_all_single(recv, send, output_split_sizes=a["recv_counts"],
+        work = comm.all_to_all_single(recv, send, output_split_sizes=a["recv_counts"],
                                       input_split_sizes=a["send_counts"], group=self.group, async_op=True)
         return recv, work.wait
 
@@ -450,15 +452,10 @@ class ShardedGraph:
             else:
                 mine = torch.cat([t_local, t_local.new_zeros(pad, t_local.shape[1])])
             full = t_local.new_empty(p.padded_n, t_local.shape[1])
-            return full, [dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group, async_op=True)]
+            return full, [comm.all_gather_into_tensor(full, mine.contiguous(), group=self.group, async_op=True)]
         full = t_local.new_empty(p.n, t_local.shape[1])
         views = [full[int(p.bounds[q]):int(p.bounds[q + 1])] for q in range(p.world)]
-        if dist.get_backend(self.group) == "nccl":
-            return full, [dist.all_gather(views, t_local.contiguous(), group=self.group, async_op=True)]
-        full[p.r0:p.r1] = t_local
-        return full, [dist.broadcast(views[q], src=dist.get_global_rank(self.group, q) if self.group is not None else q,
-                                     group=self.group, async_op=True)
-                      for q in range(p.world) if p.bounds[q + 1] > p.bounds[q]]
+        return full, comm.all_gather_uneven(views, t_local, p.rank, self.group)
 
     def allgather_rows(self, t_local):
         """[padded_n, F] matrix of every rank's row block (all-gather; rows >= n are zero padding)"""
@@ -474,7 +471,7 @@ class ShardedGraph:
 
     def allreduce_sum(self, t):
         if not isinstance(self.group, LocalGroup):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            comm.all_reduce(t, group=self.group)
         return t
 
     def exchange_bytes(self, F, elem=4, which="fwd"):
@@ -613,6 +610,8 @@ def encoder2_usable(model, x_local):
     l1, l2 = (m.apply_mod for m in model.layers)
     if _act_code(l1.activation) is None or _act_code(l2.activation) != 0:
         return False
+    if x_local.requires_grad:           # the one-pass encoder returns no dX (input features: train_transductive.py:38)
+        return False
     return ops.linear2_usable(x_local, l1.linear.weight.shape[0], l2.linear.weight.shape[0])
 
 
@@ -654,7 +653,7 @@ def allreduce_grads(params, group=None):
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    comm.all_reduce(flat, group=group)
     off = 0
     for g in grads:
         g.copy_(flat[off:off + g.numel()].view_as(g))
@@ -692,6 +691,9 @@ class ShardedTrainStep:
 
     def _capture(self, warmup):
         import gc
+        if not isinstance(self.sg.group, LocalGroup) and comm.staged(self.x, self.sg.group):
+            raise RuntimeError("ShardedTrainStep(capture=True) needs RCCL (backend nccl): a collective staged through "
+                               "host memory synchronises the stream, which a stream capture forbids")
         from .capture import _state_outside_capture
         for w in ("fwd", "bwd"):                           # structures and plans: built outside the capture
             for part in (("own", "remote") if self.sg.part.overlap else (None,)):

@@ -164,3 +164,124 @@ def test_rmat_spmm_skew_plan_full_size(scale, dev):
     assert float((np.abs(got - ref64) / sc).max()) < TOL
     assert float((np.abs(ref - ref64) / sc).max()) < 2e-4                # what one fp32 chain of 10^5 terms costs
     assert int(d.max()) > 100000                                          # the sample does contain the hubs
+
+
+def _aggregate64(rows, cols, H64, n, chunk=1 << 24):
+    """out[r] = sum over edges (r, c) of H64[c] in fp64 with ATen's index_add_ (independent of the library's kernels)"""
+    out = torch.zeros(n, H64.shape[1], dtype=torch.float64, device=H64.device)
+    for c0 in range(0, int(rows.numel()), chunk):
+        out.index_add_(0, rows[c0:c0 + chunk], H64[cols[c0:c0 + chunk]])
+    return out
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("scale", [24])
+def test_rmat_rank_step_full_size(scale, dev):
+    """BASELINE configs[3], the STEP `bench.py --workload rmat` times, at the size it times it: the
+    one-pass encoder of parallel.ShardedEncoder2Function on 2^24 rows / 2^28 edges under a real (1-rank RCCL) process
+    group, structure from the edge slice, boundary exchange + overlap + nnz-balanced blocks as bench.py builds it --
+    gae_spmm_csr with GAE_SPMM_SKIP_ROWS, list-mode gae_linear2_fwd + gae_linear2_fill_dead, gae_spmm_csr_ep with the bias,
+    backward: gae_spmm_csr on A^T with skipped rows, list-mode gae_gcn2_bwd_dense with the dead rows' rank-one terms.
+    Against the reference order (gae.py:26-31,36-45) evaluated in fp64 with plain ATen ops:
+      * Z on EVERY row to 1e-5 of the largest |Z|, and on 8000 sampled rows (the heaviest, random heavy, random light,
+        rows without in-edges) to 1e-5 of the row's own scale (sum of |terms|);
+      * dW1, db1, dW2, db2 to 5e-5 of each gradient's scale; with atb_bf16 = 0 (exact fp32 products) the same;
+      * run-to-run bit-stable (forward and backward)."""
+    import os
+    import torch.distributed as dist
+    import gae_dgl_amd as G
+    from gae_dgl_amd import _lib, ops, workloads as W
+    from gae_dgl_amd.parallel import ShardedGraph, sharded_encode, encoder2_usable
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29671")
+    torch.cuda.set_device(0)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        n, F = 1 << scale, 32
+        src, dst = W.rmat_edges(scale, 16, seed=0, device=dev)
+        E = int(src.numel())
+        sg = ShardedGraph.from_edge_slice(n, src, dst, None, "boundary", dev, "nnz", overlap=True)
+        sg.cache_constant_inputs = True
+        gen = torch.Generator(device=dev).manual_seed(1234)
+        X = torch.rand(n, F, device=dev, generator=gen)
+        dZ = torch.randn(n, 16, device=dev, generator=gen) / n
+        torch.manual_seed(0)
+        model = G.GAE(F, [32, 16]).to(dev)
+        assert encoder2_usable(model, X)
+        seen = {}
+        inner = _lib.call
+
+        def call(name, *a):
+            seen[name] = seen.get(name, 0) + 1
+            return inner(name, *a)
+        _lib.call = call
+        try:
+            runs = []
+            for rep in range(2):
+                model.zero_grad()
+                z = sharded_encode(model, sg, X, transform_first=True)
+                z.backward(dZ)
+                runs.append((z.detach(), [p.grad.clone() for p in model.parameters()]))
+        finally:
+            _lib.call = inner
+        for name in ("gae_spmm_csr", "gae_spmm_csr_ep", "gae_linear2_fwd", "gae_linear2_fill_dead", "gae_gcn2_bwd_dense"):
+            assert seen.get(name, 0) >= 2, f"{name}: {seen}"
+        assert torch.equal(runs[0][0], runs[1][0]) and all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
+        Z, grads = runs[0]
+        dead_f, dead_b = sg.dead_rows("fwd").bool(), sg.dead_rows("bwd").bool()
+        assert 0.5 < float(dead_f.float().mean()) < 0.9            # R-MAT: most rows have no in-edge (list mode matters)
+        assert sg.live_rows("fwd")[0].numel() == int((~dead_f).sum())
+        del runs, sg
+        torch.cuda.empty_cache()
+        # ---- fp64, reference order, ATen only
+        W1, b1, W2, b2 = (t.detach().double() for t in (model.layers[0].apply_mod.linear.weight, model.layers[0].apply_mod.linear.bias,
+                                                        model.layers[1].apply_mod.linear.weight, model.layers[1].apply_mod.linear.bias))
+        M1 = _aggregate64(dst, src, X.double(), n)
+        H1 = torch.relu(M1 @ W1.t() + b1)
+        M2 = _aggregate64(dst, src, H1, n)
+        Zr = M2 @ W2.t() + b2
+        zs = float(Zr.abs().max())
+        assert float((Z.double() - Zr).abs().max()) / zs < TOL
+        # per-row scale of the sampled rows: sum of |terms| of the row's last product
+        absM2 = _aggregate64(dst, src, H1.abs(), n) @ W2.abs().t() + b2.abs()
+        deg = torch.bincount(dst, minlength=n)
+        order = torch.argsort(deg, descending=True)
+        g2 = torch.Generator(device=dev).manual_seed(6)
+        pick = lambda idx, k: idx[torch.randint(0, idx.numel(), (k,), device=dev, generator=g2)]
+        rows = torch.cat([order[:64], pick(torch.nonzero(deg > ops.SKEW_THRESHOLD).flatten(), 3000),
+                          pick(torch.nonzero((deg > 0) & (deg <= ops.SKEW_THRESHOLD)).flatten(), 3000),
+                          pick(torch.nonzero(deg == 0).flatten(), 2000)]).unique()
+        row_err = ((Z[rows].double() - Zr[rows]).abs() / absM2[rows].clamp(min=1e-30)).max()
+        assert float(row_err) < TOL, float(row_err)
+        assert int(deg[rows].max()) > 100000
+        del M2, absM2, Zr
+        # backward
+        G64 = _aggregate64(src, dst, dZ.double(), n)                    # A^T dZ
+        dW2r = G64.t() @ H1
+        db2r = dZ.double().sum(0)
+        dY1 = (G64 @ W2) * (H1 > 0)
+        dW1r = dY1.t() @ M1
+        db1r = dY1.sum(0)
+        want = [dW1r, db1r, dW2r, db2r]
+        for a, b in zip(grads, want):
+            assert rel_err(a, b) < 5 * TOL, (a.shape, rel_err(a, b))
+        del G64, dY1, M1, H1
+        torch.cuda.empty_cache()
+        # exact fp32 products in the weight-gradient pass: same bound, and close to the default
+        sg = ShardedGraph.from_edge_slice(n, src, dst, None, "boundary", dev, "nnz", overlap=True)
+        _lib.call("gae_tuning_set", b"atb_bf16", 0)
+        try:
+            model.zero_grad()
+            z = sharded_encode(model, sg, X, transform_first=True)
+            z.backward(dZ)
+        finally:
+            _lib.call("gae_tuning_set", b"atb_bf16", 1)
+        assert torch.equal(z.detach(), Z)
+        for p, a, b in zip(model.parameters(), grads, want):
+            assert rel_err(p.grad, b) < 5 * TOL
+            assert rel_err(a, p.grad) < 2 * TOL
+    finally:
+        sg = None
+        if created:
+            dist.destroy_process_group()

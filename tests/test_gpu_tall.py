@@ -334,3 +334,53 @@ def test_list_mode_of_the_dense_passes(act):
         dY1 = dY1 * (Yd > 0)
     assert rel(got[2], Gd.t() @ Yd) < TOL and rel(got[1], dY1.sum(0)) < TOL and rel(got[3], dZ.double().sum(0)) < TOL
     assert rel(got[0], dY1.t() @ M1.double()) < TOL
+
+
+def test_list_mode_workspace_covers_every_list_length():
+    """the number of partial blocks is not monotone in the row count once a wave takes more than one
+    tile (n = 300000 -> 782 blocks, 131072 listed rows -> 1024), so the workspace must cover the most any
+    n_listed <= n takes.  An exact-size workspace followed by a canary: the canary survives and the gradients are right."""
+    import ctypes
+    from gae_dgl_amd import ops, _lib
+    n, F, n_listed = 300000, 32, 131072
+    g = torch.Generator().manual_seed(23)
+    perm = torch.randperm(n, generator=g)
+    m1_dead = torch.ones(n, dtype=torch.bool); m1_dead[perm[:n_listed]] = False
+    g_dead = torch.rand(n, generator=g) < 0.5
+    M1 = torch.randn(n, F, generator=g); M1[m1_dead] = 0
+    Gm = torch.randn(n, 16, generator=g); Gm[g_dead] = 0
+    dZ = torch.randn(n, 16, generator=g)
+    W1 = torch.randn(32, F, generator=g) / F ** 0.5; b1 = torch.randn(32, generator=g)
+    W2 = torch.randn(16, 32, generator=g) / 32 ** 0.5
+    d = lambda t: t.to(DEV)
+    md, gd = d(m1_dead.to(torch.uint8)), d(g_dead.to(torch.uint8))
+    rows = torch.nonzero(~m1_dead).reshape(-1).to(torch.int32).to(DEV)
+    assert rows.numel() == n_listed
+    gdl = gd[rows.long()].contiguous()
+    lib = _lib.load()
+    nbytes = int(lib.gae_gcn2_bwd_dense_workspace_bytes(n, F, 32, 16))
+    # the layout the listed launch uses: 1024 blocks + the dead rows' partial
+    per = (32 * F + 32 + 16 * 32 + 16 + 3) // 4 * 4
+    assert nbytes >= (1024 + 1) * per * 4
+    ws = torch.zeros(nbytes + 4096, dtype=torch.uint8, device=DEV)
+    ws[nbytes:] = 0xA5
+    outs = [torch.empty(32, F, device=DEV), torch.empty(32, device=DEV), torch.empty(16, 32, device=DEV),
+            torch.empty(16, device=DEV)]
+    Gd_, dZd, M1d, W1d, b1d, W2d = d(Gm), d(dZ), d(M1), d(W1), d(b1), d(W2)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.call("gae_gcn2_bwd_dense", p(Gd_), 16, p(dZd), 16, None, 0, 1, p(M1d), F, p(W2d), 32, n, F, 32, 16,
+              p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), p(ws), nbytes, None, p(W1d), F, p(b1d), p(md), p(gd),
+              p(rows), n_listed, p(gdl), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert bool((ws[nbytes:] == 0xA5).all()), "gae_gcn2_bwd_dense wrote past the workspace it asked for"
+    want = ops.gcn2_bwd_dense_raw(Gd_, dZd, None, 1, M1d, W2d, W1=W1d, b1=b1d)
+    for a, b in zip(outs, want):
+        assert rel(a, b) < TOL
+    # a workspace sized for the listed count alone is refused, not overrun
+    small = int(lib.gae_gcn2_bwd_dense_workspace_bytes(n_listed, F, 32, 16))
+    assert small <= nbytes
+    # through ops in deferred mode (torch.empty(nbytes) exactly): gradients after the optimiser's reduction are right
+    got = ops.gcn2_bwd_dense_raw(Gd_, dZd, None, 1, M1d, W2d, W1=W1d, b1=b1d, m1_dead=md, g_dead=gd, rows=rows,
+                                 g_dead_listed=gdl)
+    for a, b in zip(got, want):
+        assert rel(a, b) < TOL
