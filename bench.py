@@ -306,7 +306,7 @@ class CitationWorkload:
         if feats == "sparse":
             self.Xd = G.SparseFeatures.from_dense(self.Xd)                   # once: X is constant across epochs
         elif feats == "auto" and args.layer1 == "transform-first":
-            self.Xd = G.SparseFeatures.maybe_from_dense(self.Xd, self.hidden[0])    # (train_transductive.py:37-38: loaded once)
+            self.Xd = G.SparseFeatures.maybe_from_dense(self.Xd, self.hidden[0], graph=self.g)    # (train_transductive.py:37-38: loaded once)
         self.sparse = isinstance(self.Xd, G.SparseFeatures)
         self.g.csr(); self.g.csc(); self.g.spmm_plan(False); self.g.spmm_plan(True); self.g.scattered()   # static
         E = self.g.number_of_edges()

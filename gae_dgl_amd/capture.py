@@ -28,14 +28,17 @@ def _defer(opt, loss_too=False):
                            defer_loss=ours and loss_too and DEFER_LOSS_FINALIZE)
 
 
-def _state_outside_capture(opt):
+def _state_outside_capture(opt, steps_taken=0):
     """optimiser state (moments, step counters) must exist BEFORE the capture: created lazily inside it, it would sit in
     the graph's private pool and be zero-filled again by every replay.  The library's Adam creates it on request; any
-    other optimiser must have taken a step (warm-up or the caller's own eager steps)."""
+    other optimiser must have taken a step (warm-up or the caller's own eager steps).  ``steps_taken``: warm-up steps
+    the caller itself just ran -- an optimiser that still has no state after a step keeps none (plain SGD), which is
+    fine."""
     from .optim import Adam
     if isinstance(opt, Adam):
         opt.materialize_state()
-    elif any(p.requires_grad and len(opt.state.get(p, {})) == 0 for g in opt.param_groups for p in g["params"]):
+    elif steps_taken == 0 and any(p.requires_grad and len(opt.state.get(p, {})) == 0
+                                  for g in opt.param_groups for p in g["params"]):
         raise ValueError("capture needs the optimiser's state in place: run at least one step (warmup >= 1) before it")
 
 
@@ -73,7 +76,7 @@ class CapturedTrainStep:
             for _ in range(warmup):
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
-        _state_outside_capture(optimizer)
+        _state_outside_capture(optimizer, warmup)
         for m in model.modules():          # device-side draw counters (dropout mask, VGAE noise): same rule
             if getattr(m, "_draws", False) is None:
                 m._draws = torch.zeros(1, dtype=torch.int64, device=features.device)

@@ -122,7 +122,7 @@ class GCN(nn.Module):
             if out is not None:
                 g.ndata.pop('h')
                 return out
-        return self.forward(g, sf.to_dense())
+        return self.forward(g, sf.to_dense(cache=True))      # (constant features: densified once, then reused)
 
     def forward(self, g, feature):
         if isinstance(feature, SparseFeatures):

@@ -2050,15 +2050,20 @@ class GCNSparseInputFunction(torch.autograd.Function):
         return dW, db, None, None, None, None
 
 
+def sparse_input_usable(graph, n, K, f_out):
+    """can GCNSparseInputFunction run a K -> f_out layer on ``graph`` with compressed [n, K] features?  (the check
+    sparse.SparseFeatures.maybe_from_dense makes BEFORE compressing)"""
+    if graph.number_of_nodes() != n or f_out > 32 or graph.number_of_edges() == 0:
+        return False
+    if n * ((f_out + 3) // 4 * 4) * 4 + (1 << 16) >= (1 << 32):
+        return False
+    return _table_only(graph.spmm_plan(False)) and _table_only(graph.spmm_plan(True))
+
+
 def gcn_layer_sparse_input(graph, sf, W, b, act, use_norm=False):
     """the layer on sparse.SparseFeatures input, or None when graph / widths do not allow it (the caller then
-    densifies)"""
-    n = graph.number_of_nodes()
-    if sf.shape[0] != n or W.shape[0] > 32 or W.shape[1] != sf.shape[1] or graph.number_of_edges() == 0:
-        return None
-    if n * ((W.shape[0] + 3) // 4 * 4) * 4 + (1 << 16) >= (1 << 32):
-        return None
-    if not (_table_only(graph.spmm_plan(False)) and _table_only(graph.spmm_plan(True))):
+    densifies, once: SparseFeatures.to_dense(cache=True))"""
+    if W.shape[1] != sf.shape[1] or not sparse_input_usable(graph, sf.shape[0], sf.shape[1], W.shape[0]):
         return None
     return GCNSparseInputFunction.apply(W, b, sf, graph, use_norm, act)
 

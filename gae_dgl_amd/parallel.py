@@ -707,7 +707,7 @@ class ShardedTrainStep:
                 self.opt.zero_grad(set_to_none=True)
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
-        _state_outside_capture(self.opt)
+        _state_outside_capture(self.opt, max(int(warmup), 1))
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: the process group's watchdog thread polls events while this thread captures

@@ -65,13 +65,20 @@ class SparseFeatures:
     # 15.0 vs 16.8 us) and lose on Pubmed (500 columns at 9.5 %: 27.7 vs 26.4 us).
     BYTES_PER_NONZERO = 136
     WORTH_IT = 0.5
+    MAX_SEGMENTS = 256      # densest column: at most 16384 non-zeros (workspace 32 K floats per slot)
 
     @classmethod
-    def maybe_from_dense(cls, X, f_out=32):
+    def maybe_from_dense(cls, X, f_out=32, graph=None):
         """``X`` itself, or its compressed form when layer 1 runs faster from the non-zeros (one count pass over X; the
-        compression only if it pays).  For features that stay CONSTANT across the steps that use the result."""
+        compression only if it pays).  For features that stay CONSTANT across the steps that use the result.
+        ``graph``: the graph the features will be set on -- the kernels on the non-zeros need plans that carry only a
+        packed neighbour table (ops.sparse_input_usable: no row longer than ops.SKEW_MIN_MAXDEG, e.g. NOT the real
+        Planetoid graphs with hubs of 100-170 neighbours); on any other graph the layer would densify the features
+        again in every step, so X stays dense."""
         X = ops._gpu(X, "X")
         if X.dtype != torch.float32 or X.dim() != 2 or f_out > 32 or X.shape[1] < 193 or X.shape[0] == 0:
+            return X
+        if graph is not None and not ops.sparse_input_usable(graph, X.shape[0], X.shape[1], f_out):
             return X
         n, K = X.shape
         Xc = X if X.stride(1) == 1 else X.contiguous()
@@ -82,7 +89,12 @@ class SparseFeatures:
         nnz = int(cnt.sum())
         if nnz * cls.BYTES_PER_NONZERO >= cls.WORTH_IT * 4.0 * n * K:
             return X
-        return cls.from_dense(X)
+        sf = cls.from_dense(X)
+        # gae_spx_wgrad's workspace and zero-fill scale with the DENSEST column (max_segments slots of 32 K floats): one
+        # near-dense column (a bias feature, a stop word) on many rows would cost more than the dense pass it replaces
+        if sf.max_segments > cls.MAX_SEGMENTS:
+            return X
+        return sf
 
     @classmethod
     def from_dense(cls, X):
@@ -122,12 +134,19 @@ class SparseFeatures:
         moved = [t.to(dev) for t in (self.rowptr, self.col, self.val, self.t_rowptr, self.t_row, self.t_val)]
         return SparseFeatures(self.shape, *moved)
 
-    def to_dense(self):
+    def to_dense(self, cache=False):
+        """the dense [n, K] matrix.  ``cache``: keep it on the object (the features are constant) -- what a layer does
+        that cannot run from the non-zeros, so that it densifies once, outside any stream capture, not per step"""
+        if getattr(self, "_dense", None) is not None:
+            return self._dense
         n, K = self.shape
         out = torch.zeros(n, K, dtype=torch.float32, device=self.device)
-        rows = torch.repeat_interleave(torch.arange(n, device=self.device),
-                                       (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64))
-        out[rows, self.col.to(torch.int64)] = self.val
+        if self.nnz:
+            rows = torch.repeat_interleave(torch.arange(n, device=self.device),
+                                           (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64), output_size=self.nnz)
+            out[rows, self.col.to(torch.int64)] = self.val
+        if cache:
+            self._dense = out
         return out
 
     def __repr__(self):

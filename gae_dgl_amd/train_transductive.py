@@ -64,9 +64,6 @@ def main(argv=None):
     from gae_dgl_amd.optim import Adam
     data = load_data(args)
     features = ops.pad_rows(torch.as_tensor(data.features, dtype=torch.float32).to(device))   # 16 / 128-byte rows
-    if args.features == "auto" and device.type == "cuda":
-        from gae_dgl_amd import SparseFeatures
-        features = SparseFeatures.maybe_from_dense(features, args.hidden_dims[0])
     n_nodes = data.graph.number_of_nodes()
     held_out = None
     if args.eval:
@@ -78,6 +75,11 @@ def main(argv=None):
     else:
         g = DGLGraph(data.graph).to(device)
     g.ndata['norm'] = g.norm().unsqueeze(1)    # train_transductive.py:55-58; parameter independent: once, not per epoch
+    if args.features == "auto" and device.type == "cuda":
+        # decided per GRAPH: the kernels on the non-zeros need a graph without long rows (real Cora / Citeseer have hubs
+        # of 168 / 99 neighbours: their features stay dense)
+        from gae_dgl_amd import SparseFeatures
+        features = SparseFeatures.maybe_from_dense(features, args.hidden_dims[0], graph=g)
 
     model = GAE(features.shape[1], args.hidden_dims, norm=args.norm).to(device).train()
     optimiser = Adam(model.parameters(), lr=args.lr)      # torch.optim.Adam's rule, one HIP launch

@@ -268,3 +268,73 @@ def test_bench_refuses_more_gpus_than_visible():
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 2 and "refusing" in r.stderr
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def _planetoid_like(n=2708, K=1433, hub_deg=168, seed=0):
+    """Cora's N / F with the degree profile of the REAL Planetoid graph: a few hubs of 100-170 neighbours (the synthetic
+    stand-in of workloads.citation_graph has none), bag-of-words rows at 1.3 % density"""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, n, 4500); b = rng.integers(0, n, 4500)
+    hubs = rng.choice(n, 5, replace=False)
+    for h, d in zip(hubs, (hub_deg, 99, 78, 74, 65)):
+        a = np.concatenate([a, np.full(d, h)]); b = np.concatenate([b, rng.choice(n, d, replace=False)])
+    keep = a != b
+    a, b = a[keep], b[keep]
+    X = np.zeros((n, K), np.float32)
+    cols = rng.integers(0, K, (n, 18))
+    np.put_along_axis(X, cols, 1.0, axis=1)
+    X /= X.sum(1, keepdims=True)
+    return n, np.concatenate([a, b]), np.concatenate([b, a]), X
+
+
+def test_train_transductive_default_flags_on_a_graph_with_hubs(tmp_path):
+    """real Cora / Citeseer have rows of 168 / 99 neighbours, so their plans carry heavy rows and
+    the kernels on the non-zeros of X do not apply.  `--features auto` must then keep X dense (decided per graph), the
+    default captured step must run, and its losses equal those of `--features dense --no_hipgraph`."""
+    import os
+    import gae_dgl_amd as G
+    from gae_dgl_amd import ops, train_transductive as TT
+    n, src, dst, X = _planetoid_like()
+    os.makedirs(tmp_path / "data", exist_ok=True)
+    np.savez(tmp_path / "data" / "cora.npz", src=src, dst=dst, features=X, n=n)
+    common = ["--dataset", "cora", "--data_root", str(tmp_path / "data"), "-e", "6", "-s", str(tmp_path), "--seed", "0",
+              "--log_every", "100"]
+    auto = TT.main(common)
+    dense = TT.main(common + ["--features", "dense", "--no_hipgraph"])
+    assert np.isfinite(auto).all() and len(auto) == 6
+    np.testing.assert_allclose(auto, dense, rtol=1e-5)
+    # the decision itself, and the explicit opt-in on such a graph: densified ONCE, usable inside a stream capture
+    dev = torch.device("cuda:0")
+    g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+    Xd = ops.pad_rows(torch.from_numpy(X).to(dev))
+    assert not ops.sparse_input_usable(g, n, X.shape[1], 32)
+    assert G.SparseFeatures.maybe_from_dense(Xd, 32, graph=g) is Xd
+    assert isinstance(G.SparseFeatures.maybe_from_dense(Xd, 32), G.SparseFeatures)      # (no graph given: X alone decides)
+    sf = G.SparseFeatures.from_dense(Xd)
+    from gae_dgl_amd.capture import CapturedTrainStep
+    from gae_dgl_amd.optim import Adam
+    torch.manual_seed(0)
+    model = G.GAE(X.shape[1], [32, 16]).to(dev)
+    model.decoder.dropout = 0.0
+    opt = Adam(model.parameters(), lr=1e-2)
+    g.ndata['h'] = sf
+    l0 = model.reconstruction_loss(g); opt.zero_grad(); ops.backward(l0); opt.step()     # eager epoch 0 (densifies, caches)
+    d0 = sf.to_dense()
+    step = CapturedTrainStep(model, opt, g, sf, warmup=0)
+    l1 = float(step()); l2 = float(step())
+    assert sf.to_dense() is d0 and np.isfinite([l1, l2]).all() and l2 < float(l0)
+
+
+def test_sparse_features_refuse_a_near_dense_column():
+    """gae_spx_wgrad's workspace scales with the densest column; maybe_from_dense keeps X dense when
+    one column alone would take more than SparseFeatures.MAX_SEGMENTS slots"""
+    import gae_dgl_amd as G
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1)
+    n, K = 40000, 1024
+    X = np.zeros((n, K), np.float32)
+    np.put_along_axis(X, rng.integers(1, K, (n, 8)), 1.0, axis=1)
+    Xd = torch.from_numpy(X).to(dev)
+    assert isinstance(G.SparseFeatures.maybe_from_dense(Xd), G.SparseFeatures)
+    Xd[:, 0] = 1.0                                            # a bias feature: 40000 non-zeros in one column
+    assert G.SparseFeatures.maybe_from_dense(Xd) is Xd
