@@ -88,6 +88,7 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f)
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef short v4s __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
 
 // split 4 fp32 values into bf16 hi and bf16 lo = bf16(v - hi): v_cvt_pk_bf16_f32 x 4, ~5 VALU ops per pair
@@ -104,6 +105,29 @@ __device__ __forceinline__ void split_bf16x4(const v4f &v, v4s &hi, v4s &lo)
     }
     struct U { unsigned a, b; } uh{h[0], h[1]}, ul{l[0], l[1]};
     hi = __builtin_bit_cast(v4s, uh);
+    lo = __builtin_bit_cast(v4s, ul);
+}
+
+// Three bf16 pieces of 4 fp32 values: v = hi + mid + lo EXACTLY (hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid):
+// 8 + 8 + 8 mantissa bits).  A product of two such operands over the six piece pairs down to 2^-24 relative
+// (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi) is an fp32-grade product on the bf16 matrix pipe: every pair is exact in
+// the fp32 accumulator, the dropped pairs are below one ulp of the term.
+__device__ __forceinline__ void split_bf16x4_3(const v4f &v, v4s &hi, v4s &mid, v4s &lo)
+{
+    unsigned h[2], m[2], l[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const v2f a = {v[2 * q], v[2 * q + 1]};
+        const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(a, v2bf));
+        const v2f r1 = a - v2f{__uint_as_float(hu << 16), __uint_as_float(hu & 0xffff0000u)};
+        const unsigned mu = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, v2bf));
+        const v2f r2 = r1 - v2f{__uint_as_float(mu << 16), __uint_as_float(mu & 0xffff0000u)};
+        h[q] = hu; m[q] = mu;
+        l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, v2bf));
+    }
+    struct U { unsigned a, b; } uh{h[0], h[1]}, um{m[0], m[1]}, ul{l[0], l[1]};
+    hi = __builtin_bit_cast(v4s, uh);
+    mid = __builtin_bit_cast(v4s, um);
     lo = __builtin_bit_cast(v4s, ul);
 }
 

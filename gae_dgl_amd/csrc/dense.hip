@@ -31,7 +31,8 @@ gae::Knob g_linear_wlds{1};  // tuning knob: 0 = never use linear_fwd_wlds_kerne
 gae::Knob g_linear_bf16{0};  // tuning knob: 0 = exact fp32 forward Linear (default: embeddings within 2e-7 of fp64 instead of
                         // 7e-6, tools/encode_error.py), 1 = bf16 x 3 forward where measured faster (Pubmed L1 15.4 -> 13.0 us),
                         // 2 = wherever it applies
-gae::Knob g_atb_bf16{1};     // tuning knob: 1 = bf16 x 3 matrix-core products in the dW kernel where the layout allows
+gae::Knob g_atb_bf16{1};     // "atb_bf16", weight-gradient products (dW kernel where the layout allows; gae_gcn2_bwd_dense): 0 = exact fp32
+                             // MFMAs, 1 = three bf16 pieces per operand, six pairs (fp32-grade; default), 2 = two pieces, three pairs (16 bits)
 gae::Knob g_atb_rows{0};     // tuning knob: rows per block (= per partial) of the dW kernel; 0 = auto (atb_plan)
 
 // ---------------------------------------------------------------------------
@@ -1059,7 +1060,11 @@ __global__ __launch_bounds__(NW * 64) void atb_partial_kernel(
 // float4 Q[row 4g + r][c0 + 4 l15 ..] for r = 0..3 -- column 4 l15 + t belongs to output tile t -- and
 // P[row][16 mt + l15]; accumulators acc[mt][t][r] = out[16 mt + 4 g + r][c0 + 4 l15 + t].
 // ---------------------------------------------------------------------------
-template <int PRO_P>
+// P3 (knob atb_bf16 = 1, the default): three bf16 pieces per operand and the six piece pairs down to 2^-24
+// (gae::split_bf16x4_3) -- an fp32-grade product; the two-piece form (knob 2: 16 mantissa bits per operand) left
+// 1e-4 .. 3e-4 of the gradient's scale on operands whose large columns cancel, ten times the exact fp32 kernel's
+// error (tests/test_gpu_wgrad_condition.py).
+template <int PRO_P, bool P3>
 __global__ __launch_bounds__(512) void atb_bf16_kernel(
     const float *__restrict__ P, int64_t ldp, const float *__restrict__ Pmask, int64_t ldpm,
     const float *__restrict__ Q, int64_t ldq, int64_t n, int O, int I, int64_t rows_per_slot,
@@ -1109,7 +1114,7 @@ __global__ __launch_bounds__(512) void atb_bf16_kernel(
         bool rv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) rv[r] = r0 + 4 * g + r < r_end;
-        gae::v4s ah[2], al[2], bh[4], bl[4];
+        gae::v4s ah[2], al[2], bh[4], bl[4], am[P3 ? 2 : 1], bm[P3 ? 4 : 1];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             gae::v4f av;
@@ -1121,7 +1126,8 @@ __global__ __launch_bounds__(512) void atb_bf16_kernel(
                 av[r] = v;
                 csum[mt] += v;
             }
-            gae::split_bf16x4(av, ah[mt], al[mt]);
+            if constexpr (P3) gae::split_bf16x4_3(av, ah[mt], am[mt], al[mt]);
+            else gae::split_bf16x4(av, ah[mt], al[mt]);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -1132,15 +1138,22 @@ __global__ __launch_bounds__(512) void atb_bf16_kernel(
             const bool cv = col + t < I;
             const gae::v4f bv = {(rv[0] && cv) ? b0 : 0.f, (rv[1] && cv) ? b1 : 0.f, (rv[2] && cv) ? b2 : 0.f,
                                  (rv[3] && cv) ? b3 : 0.f};
-            gae::split_bf16x4(bv, bh[t], bl[t]);
+            if constexpr (P3) gae::split_bf16x4_3(bv, bh[t], bm[t], bl[t]);
+            else gae::split_bf16x4(bv, bh[t], bl[t]);
         }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[mt], bh[t], acc[mt][t], 0, 0, 0);
-                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], bl[t], acc[mt][t], 0, 0, 0);
-                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], bh[t], acc[mt][t], 0, 0, 0);
+                gae::v4f c = acc[mt][t];             // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[mt], bh[t], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], bl[t], c, 0, 0, 0);
+                if constexpr (P3) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(am[mt], bm[t], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(am[mt], bh[t], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], bm[t], c, 0, 0, 0);
+                }
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], bh[t], c, 0, 0, 0);
             }
     };
     if (r_begin < r_end) {
@@ -1317,8 +1330,12 @@ int launch_atb(const float *P, int64_t ldp, const float *Pmask, int64_t ldpm, co
     if (g_atb_bf16 && !narrow && O <= 32 && (ldq % 4 == 0) && gae::aligned16(Q) && ldq >= ((I + 3) & ~3) && I >= 4 &&
         gae::aligned16(partial) && pl.rows_per_slot % 128 == 0) {
         const dim3 grid(unsigned(pl.blocks), unsigned((I + 63) / 64), 1);
-        hipLaunchKernelGGL((atb_bf16_kernel<PRO_P>), grid, dim3(512), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n, O, I,
-                           pl.rows_per_slot, partial, pl.slot_stride, colsum ? int64_t(O) * I : int64_t(-1));
+        if (g_atb_bf16 == 2)
+            hipLaunchKernelGGL((atb_bf16_kernel<PRO_P, false>), grid, dim3(512), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n, O, I,
+                               pl.rows_per_slot, partial, pl.slot_stride, colsum ? int64_t(O) * I : int64_t(-1));
+        else
+            hipLaunchKernelGGL((atb_bf16_kernel<PRO_P, true>), grid, dim3(512), 0, s, P, ldp, Pmask, ldpm, Q, ldq, n, O, I,
+                               pl.rows_per_slot, partial, pl.slot_stride, colsum ? int64_t(O) * I : int64_t(-1));
         GAE_CHECK_LAUNCH("atb_bf16_kernel");
         return GAE_OK;
     }

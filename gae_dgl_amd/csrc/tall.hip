@@ -38,6 +38,29 @@ __device__ __forceinline__ void split8(const float *v, s16x8 &hi, s16x8 &lo)
     hi = s16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
     lo = s16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
 }
+// three pieces: v = hi + mid + lo exactly (gae::split_bf16x4_3)
+__device__ __forceinline__ void split8_3(const float *v, s16x8 &hi, s16x8 &mid, s16x8 &lo)
+{
+    gae::v4s h0, m0, l0, h1, m1, l1;
+    gae::split_bf16x4_3(gae::v4f{v[0], v[1], v[2], v[3]}, h0, m0, l0);
+    gae::split_bf16x4_3(gae::v4f{v[4], v[5], v[6], v[7]}, h1, m1, l1);
+    hi = s16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    mid = s16x8{m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+    lo = s16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+}
+__device__ __forceinline__ f32x16 mfma16(const s16x8 &a, const s16x8 &b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// D += A B with A = ah + am + al, B = bh + bm + bl: the six piece pairs down to 2^-24 relative, smallest first -- an
+// fp32-grade product on the bf16 matrix pipe (knob atb_bf16 = 1, the default of the weight-gradient products)
+__device__ __forceinline__ f32x16 mfma_split6(const s16x8 &ah, const s16x8 &am, const s16x8 &al, const s16x8 &bh,
+                                              const s16x8 &bm, const s16x8 &bl, f32x16 c)
+{
+    c = mfma16(al, bh, c); c = mfma16(ah, bl, c); c = mfma16(am, bm, c);
+    c = mfma16(am, bh, c); c = mfma16(ah, bm, c); c = mfma16(ah, bh, c);
+    return c;
+}
 // D += A B with A = ah + al, B = bh + bl on the bf16 matrix pipe, the three leading terms (the library's rule for
 // weight-gradient products, knob atb_bf16: 16 mantissa bits per operand, fp32 accumulation), smallest terms first
 __device__ __forceinline__ f32x16 mfma_split3(const s16x8 &ah, const s16x8 &al, const s16x8 &bh, const s16x8 &bl, f32x16 c)
@@ -208,7 +231,7 @@ __global__ __launch_bounds__(256, 3) void linear2_rows_kernel(const float *__res
 // RECOMP: Y1 is not read but RECOMPUTED from the tile of M1 that the pass reads anyway, Y1 = act1(M1 W1^T + b1), with
 // the forward's own products in the forward's own order (gae_linear2_fwd: same k sequence, same fma chain -> the same
 // bits): the forward then never stores Y1 (2 GiB per step on R-MAT s24) and this pass never reads it.
-template <int KB2, bool RELU, bool RECOMP, bool BF = false>
+template <int KB2, bool RELU, bool RECOMP, int BF = 0>     // BF: 0 exact fp32 MFMAs, 1 three bf16 pieces (six pairs), 2 two pieces (three pairs)
 __global__ __launch_bounds__(256, (RECOMP && BF) ? 3 : 2) void gcn2_bwd_rows_kernel(const float *__restrict__ G, int64_t ldg,
                                                             const float *__restrict__ dZ, int64_t lddz,
                                                             const float *__restrict__ Y1, int64_t ldy1,
@@ -398,12 +421,18 @@ __global__ __launch_bounds__(256, (RECOMP && BF) ? 3 : 2) void gcn2_bwd_rows_ker
                     accW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(g, y, accW2, 0, 0, 0);
                 }
             }
-            if (BF) {
+            if (BF == 2) {
                 s16x8 ah, al, bh, bl;
                 split8(dyv, ah, al); split8(mv, bh, bl);
                 accW1 = mfma_split3(ah, al, bh, bl, accW1);
                 split8(gv, ah, al); split8(yy, bh, bl);
                 accW2 = mfma_split3(ah, al, bh, bl, accW2);
+            } else if (BF) {
+                s16x8 ah, am, al, bh, bm, bl;
+                split8_3(dyv, ah, am, al); split8_3(mv, bh, bm, bl);
+                accW1 = mfma_split6(ah, am, al, bh, bm, bl, accW1);
+                split8_3(gv, ah, am, al); split8_3(yy, bh, bm, bl);
+                accW2 = mfma_split6(ah, am, al, bh, bm, bl, accW2);
             }
         }
     };
@@ -772,8 +801,8 @@ extern "C" int gae_gcn2_bwd_dense(const float *G, int64_t ldg, const float *dZ, 
                        ldm1, W2, ldw2, n, int(f_in), int(f_mid), int(f_out), tpw, partial, lay[1], W1, ldw1, b1, m1_dead, g_dead, rows)
 #define GAE_G2B(KBV, RL)                                                                                                 \
     do {                                                                                                                 \
-        if (recomp) { if (bfk) GAE_G2L(KBV, RL, true, true); else GAE_G2L(KBV, RL, true, false); }                       \
-        else { if (bfk) GAE_G2L(KBV, RL, false, true); else GAE_G2L(KBV, RL, false, false); }                            \
+        if (recomp) { if (bfk == 2) GAE_G2L(KBV, RL, true, 2); else if (bfk) GAE_G2L(KBV, RL, true, 1); else GAE_G2L(KBV, RL, true, 0); } \
+        else { if (bfk == 2) GAE_G2L(KBV, RL, false, 2); else if (bfk) GAE_G2L(KBV, RL, false, 1); else GAE_G2L(KBV, RL, false, 0); }    \
     } while (0)
 #define GAE_G2K(RL)                                                                                                      \
     do { if (kb2 == 1) GAE_G2B(1, RL); else if (kb2 == 2) GAE_G2B(2, RL); else if (kb2 == 3) GAE_G2B(3, RL); else GAE_G2B(4, RL); } while (0)

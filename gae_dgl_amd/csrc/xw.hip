@@ -48,6 +48,7 @@ struct XwFwdArgs {
     unsigned x_bytes, ldx_bytes, w_bytes;
     int K, J, ldw, act;
     int tiles_per_block, k_per_block;  // columns per (block, split)
+    unsigned long long *stamps;        // (experiments, DBG = 3) [block][wave][16] s_memtime stamps
 };
 
 // workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the vector-memory
@@ -73,9 +74,13 @@ __device__ __forceinline__ u32x4 mask_tail(u32x4 v, int left)
 }
 
 // ---------------------------------------------------------------------------------------------------- forward
-template <typename TX, int NH, int SLICE_BYTES, int DBG = 0, int DEPTH = 2>
+template <typename TX, int NH, int SLICE_BYTES, int DBG = 0, int DEPTH = 2, bool P3 = false, int TCV = 6>
 __global__ __launch_bounds__(64 * kXwMaxWaves) void xw_fwd_kernel(const XwFwdArgs a)
 {
+    // P3 (fp32 storage): the products on the bf16 matrix pipe from three bf16 pieces per operand, six piece pairs
+    // (gae::split_bf16x4_3: fp32-grade, every term to 2^-24) -- 12 v_mfma_f32_16x16x32_bf16 per 64 columns and NH
+    // instead of 16 v_mfma_f32_16x16x4_f32 that take four times as long each on the fp32 lanes.
+    static_assert(!P3 || sizeof(TX) == 4, "P3 splits fp32 storage");
     constexpr int ES = int(sizeof(TX));
     constexpr int NL = SLICE_BYTES / 64;            // 16-byte loads per lane and row tile
     constexpr int KW = SLICE_BYTES / ES;            // columns of a wave's slice
@@ -85,12 +90,19 @@ __global__ __launch_bounds__(64 * kXwMaxWaves) void xw_fwd_kernel(const XwFwdArg
     // partial tiles of up to TC row tiles x 8 waves: the waves run their tiles WITHOUT meeting (a barrier per tile kept
     // the two waves of a SIMD in lockstep and the matrix pipe idle while they reduced: 11 us for the MFMAs alone on
     // Pubmed, 4.3 us of which is issue time); one barrier and one reduction per chunk of TC tiles
-    constexpr int TC = 6;
+    constexpr int TC = TCV;
     __shared__ __attribute__((aligned(16))) float red[TC][kXwMaxWaves][NH * 256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = int(blockDim.x >> 6);
     const int l15 = lane & 15, g = lane >> 4;
+    auto stamp = [&](int k) {
+        if constexpr (DBG == 3) {
+            if (lane == 0 && k < 16)
+                a.stamps[(int64_t(blockIdx.x) * kXwMaxWaves + wave) * 16 + k] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    stamp(0);
     const int kb = int(blockIdx.y) * a.k_per_block + wave * KW;     // first column of this wave's slice
     const bool has_k = wave * KW < a.k_per_block && kb < a.K;
 
@@ -98,8 +110,26 @@ __global__ __launch_bounds__(64 * kXwMaxWaves) void xw_fwd_kernel(const XwFwdArg
     //      fp32: wf[i][r][nh] = W[16 nh + l15][kb + 16 i + 4 g + r]                      (MFMA (i, r) contracts those k)
     //      bf16: whi / wlo[i][nh] = 8 consecutive k of row 16 nh + l15 from kb + 32 i + 8 g, W = hi + lo
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W), 0, int(a.w_bytes), 0x00020000);
-    float wf[sizeof(TX) == 4 ? NL : 1][4][NH];
+    float wf[(sizeof(TX) == 4 && !P3) ? NL : 1][4][NH];
     bf16x8 whi[sizeof(TX) == 2 ? NL : 1][NH], wlo[sizeof(TX) == 2 ? NL : 1][NH];
+    // P3: step s = loads (2 s, 2 s + 1); lane (l15, g) contracts k in {16 (2 s) + 4 g + r} U {16 (2 s + 1) + 4 g + r}
+    gae::v4s w3[P3 ? NL : 1][3][NH];                 // [load i][piece][nh]: 4 of the 8 k of step i / 2 (half i % 2)
+    u32x4 wraw[P3 ? NL : 1][NH];                     // P3: the raw vectors; shifted and split AFTER the first row tiles
+    int wsh[P3 ? NL : 1];                            //     are requested (the split needs the data, the requests do not)
+    if constexpr (P3) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int k = kb + i * 16 + 4 * g;
+            const int ku = k <= a.K - 4 ? k : a.K - 4;
+            wsh[i] = k - ku;
+#pragma unroll
+            for (int nh = 0; nh < NH; ++nh) {
+                const int j = 16 * nh + l15;
+                const bool in = has_k && j < a.J && k < a.K;
+                wraw[i][nh] = __builtin_amdgcn_raw_buffer_load_b128(rw, in ? unsigned(j * a.ldw + ku) * 4u : kBehind, 0, 0);
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < NL; ++i)
 #pragma unroll
@@ -154,11 +184,47 @@ __global__ __launch_bounds__(64 * kXwMaxWaves) void xw_fwd_kernel(const XwFwdArg
     };
     float *out = a.out + int64_t(blockIdx.y) * a.split_stride;
     const bool final_pass = a.bias != nullptr || a.act != GAE_ACT_IDENTITY;     // (split launches pass neither)
+    const bool out_vec = (a.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
 
     auto tile = [&](const u32x4 (&s)[NL], int t) {
         v4f acc[NH];
 #pragma unroll
         for (int nh = 0; nh < NH; ++nh) acc[nh] = v4f{0.f, 0.f, 0.f, 0.f};
+        if constexpr (P3) {
+            struct P8 { gae::v4s a, b; };
+#pragma unroll
+            for (int i = 0; i < NL; i += 2) {
+                gae::v4s xp[2][3];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 x = mask_tail<TX>(s[i + h], left[i + h]);
+                    gae::split_bf16x4_3(v4f{__uint_as_float(x[0]), __uint_as_float(x[1]), __uint_as_float(x[2]),
+                                            __uint_as_float(x[3])}, xp[h][0], xp[h][1], xp[h][2]);
+                }
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, (P8{xp[0][0], xp[1][0]}));
+                const bf16x8 xm = __builtin_bit_cast(bf16x8, (P8{xp[0][1], xp[1][1]}));
+                const bf16x8 xl = __builtin_bit_cast(bf16x8, (P8{xp[0][2], xp[1][2]}));
+                if constexpr (DBG == 1) {            // (experiment: the loads and the split, no MFMAs)
+#pragma unroll
+                    for (int nh = 0; nh < NH; ++nh)
+                        acc[nh][0] += __builtin_bit_cast(float, int(xh[0]) ^ int(xm[1]) ^ int(xl[2]));
+                } else
+#pragma unroll
+                for (int nh = 0; nh < NH; ++nh) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, (P8{w3[i][0][nh], w3[i + 1][0][nh]}));
+                    const bf16x8 wm = __builtin_bit_cast(bf16x8, (P8{w3[i][1][nh], w3[i + 1][1][nh]}));
+                    const bf16x8 wl = __builtin_bit_cast(bf16x8, (P8{w3[i][2][nh], w3[i + 1][2][nh]}));
+                    v4f c = acc[nh];                 // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, wm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, wh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh, c, 0, 0, 0);
+                    acc[nh] = c;
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const u32x4 x = mask_tail<TX>(s[i], left[i]);
@@ -180,40 +246,73 @@ __global__ __launch_bounds__(64 * kXwMaxWaves) void xw_fwd_kernel(const XwFwdArg
                 }
             }
         }
-        // ---- the partial tile goes to this wave's LDS slot; chunks of TC tiles are added in wave order
+        // ---- the partial tile goes to this wave's LDS slot as a [16 rows][OUTW] image (4-byte stores: the two row groups
+        //      a half-wave holds meet on the same banks, a 2-way conflict that costs a ds_write_b32 nothing); chunks of TC
+        //      tiles are then added in wave order by 16-byte reads of consecutive lanes and leave as ONE 16-byte store per
+        //      thread (four dword stores per thread from one register were serialised by a vmcnt(0) each: 3000 cycles)
         float *mine = &red[t % TC][wave][0];
 #pragma unroll
-        for (int nh = 0; nh < NH; ++nh) *reinterpret_cast<v4f *>(mine + (nh * 64 + lane) * 4) = acc[nh];
+        for (int nh = 0; nh < NH; ++nh)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mine[(4 * g + q) * OUTW + 16 * nh + l15] = acc[nh][q];
+        stamp(2 + t);
         if ((t + 1) % TC == 0 || t + 1 == nt) {
             const int c0 = t / TC * TC, cnt = t + 1 - c0;
             lds_barrier();
-            for (int e = tid; e < cnt * 16 * OUTW; e += int(blockDim.x)) {
-                const int tt = e / (16 * OUTW), o = e % (16 * OUTW);
-                const int orow = o / OUTW, ocol = o % OUTW;
-                const int idx = (((ocol >> 4) * 64) + (orow >> 2) * 16 + (ocol & 15)) * 4 + (orow & 3);
-                float v[kXwMaxWaves];
+            constexpr int QPR = OUTW / 4;               // column quads per row
+            for (int e = tid; e < cnt * 16 * QPR; e += int(blockDim.x)) {
+                const int tt = e / (16 * QPR), sl = e % (16 * QPR);       // sl = row * QPR + quad: consecutive 16 bytes
+                const int orow = sl / QPR, oc0 = (sl % QPR) * 4;
+                v4f v[kXwMaxWaves];
 #pragma unroll
-                for (int w = 0; w < kXwMaxWaves; ++w) v[w] = red[tt][w < nw ? w : 0][idx];      // all requested together
-                float y = v[0];
+                for (int w = 0; w < kXwMaxWaves; ++w)                                          // all requested together
+                    v[w] = *reinterpret_cast<const v4f *>(&red[tt][w < nw ? w : 0][sl * 4]);
+                v4f y = v[0];
 #pragma unroll
-                for (int w = 1; w < kXwMaxWaves; ++w) y += w < nw ? v[w] : 0.f;                 // wave order
+                for (int w = 1; w < kXwMaxWaves; ++w) y += w < nw ? v[w] : v4f{0.f, 0.f, 0.f, 0.f};     // wave order
                 const int64_t r = (tile0 + c0 + tt) * 16 + orow;
-                if (r < a.n && ocol < a.J) {
+                if (r < a.n && oc0 < a.J) {
                     if (final_pass) {
-                        if (a.bias) y += a.bias[ocol];
-                        if (a.act == GAE_ACT_RELU) y = fmaxf(y, 0.f);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (a.bias && oc0 + q < a.J) y[q] += a.bias[oc0 + q];
+                            if (a.act == GAE_ACT_RELU) y[q] = fmaxf(y[q], 0.f);
+                        }
                     }
-                    out[r * a.ldo + ocol] = y;
+                    float *dst = out + r * a.ldo + oc0;
+                    if (out_vec && oc0 + 4 <= a.J) *reinterpret_cast<v4f *>(dst) = y;
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (oc0 + q < a.J) dst[q] = y[q];
+                    }
                 }
             }
             if (t + 1 < nt) lds_barrier();          // the next chunk overwrites the slots
+            stamp(12);
         }
     };
 
 #define GAE_PIN() __builtin_amdgcn_sched_barrier(0)
+    if constexpr (P3) GAE_PIN();
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) issue(st[d], d);
     GAE_PIN();
+    stamp(1);
+    if constexpr (P3) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+#pragma unroll
+            for (int nh = 0; nh < NH; ++nh) {
+                const u32x4 l = wraw[i][nh];
+                const int sh = wsh[i];                        // 0 except in the row's last, partial vector (then 1..3)
+                const v4f v = {__uint_as_float(sh == 0 ? l[0] : sh == 1 ? l[1] : sh == 2 ? l[2] : l[3]),
+                               __uint_as_float(sh == 0 ? l[1] : sh == 1 ? l[2] : sh == 2 ? l[3] : 0u),
+                               __uint_as_float(sh == 0 ? l[2] : sh == 1 ? l[3] : 0u), __uint_as_float(sh == 0 ? l[3] : 0u)};
+                gae::split_bf16x4_3(v, w3[i][0][nh], w3[i][1][nh], w3[i][2][nh]);
+            }
+        GAE_PIN();
+    }
     for (int t = 0; t < nt; t += DEPTH) {
         bool more = true;
 #pragma unroll
@@ -535,6 +634,10 @@ gae::Knob g_xw_depth{0};      // "xw_depth" (experiments): other ring depths of 
                               // backward (stages, groups) (2, 4) / (3, 4) / (4, 4) / (6, 2), default (4, 2))
 gae::Knob g_xw_glds{1};       // "xw_glds": 1 = the backward stages its partition's rows of G in LDS (J > 16), 0 = loads them per row group
 gae::Knob g_xw_xcd{1};        // "xw_xcd": XCD-aware block order of the backward (1) or slice-major ids (0); same sums
+gae::Knob g_xw_stamps{0}, g_xw_stamps_hi{0};     // "xw_stamps" / "xw_stamps_hi" (experiments, with xw_dbg = 3): low / high half of the device address of [blocks][8][16] uint64 time stamps
+gae::Knob g_xw_tc{0};         // "xw_tc" (experiments): row tiles per reduction chunk of the forward (LDS: 16 KB each; 0 = 6)
+gae::Knob g_xw_bpc{1};        // "xw_bpc": blocks per CU the forward's grid is sized for
+gae::Knob g_xw_p3{1};         // "xw_p3": fp32-stored X, forward: 1 = bf16 x 3-piece products on the matrix pipe (six pairs, fp32-grade), 0 = exact fp32 MFMAs
 gae::Knob g_xw_dbg{0};        // "xw_dbg" (experiments, wrong results): 1 = without MFMAs, 2 = without X loads; backward also 3 = without G loads, 4 = without its main loop
 
 FwdPlan fwd_plan(int64_t n, int K, int elem)
@@ -546,7 +649,8 @@ FwdPlan fwd_plan(int64_t n, int K, int elem)
     // tiles per block and are split along K over blocks instead (partials added in split order by a second launch).
     FwdPlan p{};
     const int64_t tiles = (n + 15) / 16;
-    int64_t t = g_xw_rows > 0 ? (g_xw_rows + 15) / 16 : (tiles + 255) / 256;
+    const int64_t slots = 256 * (g_xw_bpc > 0 ? int64_t(g_xw_bpc) : 1);
+    int64_t t = g_xw_rows > 0 ? (g_xw_rows + 15) / 16 : (tiles + slots - 1) / slots;
     if (g_xw_rows == 0 && t < 4) t = tiles < 4 ? tiles : 4;
     if (t < 1) t = 1;
     if (t > (1 << 20)) t = 1 << 20;
@@ -603,6 +707,11 @@ Knob *xw_knob(const char *name)
     if (strcmp(name, "xw_xcd") == 0) return &g_xw_xcd;
     if (strcmp(name, "xw_glds") == 0) return &g_xw_glds;
     if (strcmp(name, "xw_depth") == 0) return &g_xw_depth;
+    if (strcmp(name, "xw_p3") == 0) return &g_xw_p3;
+    if (strcmp(name, "xw_tc") == 0) return &g_xw_tc;
+    if (strcmp(name, "xw_stamps") == 0) return &g_xw_stamps;
+    if (strcmp(name, "xw_stamps_hi") == 0) return &g_xw_stamps_hi;
+    if (strcmp(name, "xw_bpc") == 0) return &g_xw_bpc;
     return nullptr;
 }
 
@@ -634,13 +743,27 @@ int xw_fwd_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const 
     a.x_bytes = unsigned(n * ldx * elem); a.ldx_bytes = unsigned(ldx * elem);
     a.w_bytes = unsigned(((int64_t(J) - 1) * ldw + K) * 4);
     a.tiles_per_block = p.tiles_per_block; a.k_per_block = p.k_per_block;
+    a.stamps = reinterpret_cast<unsigned long long *>((uint64_t(uint32_t(int(g_xw_stamps_hi))) << 32) | uint32_t(int(g_xw_stamps)));
     if (p.splits > 1) { a.bias = nullptr; a.act = GAE_ACT_IDENTITY; a.out = static_cast<float *>(ws); a.ldo = J; a.split_stride = n * J; }
     else { a.bias = bias; a.act = act; a.out = out; a.ldo = ldo; a.split_stride = 0; }
     const dim3 grid(unsigned(p.row_blocks), unsigned(p.splits)), block(unsigned(64 * p.nw));
 #define GAE_XW(TX, NH, SB) hipLaunchKernelGGL((xw_fwd_kernel<TX, NH, SB>), grid, block, 0, s, a)
     const bool wide = J > 16;
     if (elem == 4) {
-        if (p.slice_bytes == 256 && wide && g_xw_depth == 4) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, 0, 4>), grid, block, 0, s, a);
+        if (g_xw_p3 != 0 && p.slice_bytes == 256 && wide && (g_xw_dbg || g_xw_depth || g_xw_tc)) {     // experiments
+            const int dp = g_xw_depth ? int(g_xw_depth) : 2, tc = g_xw_tc ? int(g_xw_tc) : 6, dbg = int(g_xw_dbg);
+#define GAE_XWE(DB, DP, TC) if (dbg == DB && dp == DP && tc == TC) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, DB, DP, true, TC>), grid, block, 0, s, a)
+            GAE_XWE(0, 2, 6); GAE_XWE(0, 3, 6); GAE_XWE(0, 4, 6); GAE_XWE(0, 2, 3); GAE_XWE(0, 3, 3); GAE_XWE(0, 4, 3);
+            GAE_XWE(1, 2, 6); GAE_XWE(2, 2, 6); GAE_XWE(1, 4, 3); GAE_XWE(2, 4, 3); GAE_XWE(3, 2, 6);
+#undef GAE_XWE
+        }
+        else if (g_xw_p3 != 0) {
+#define GAE_XW3(NH, SB) hipLaunchKernelGGL((xw_fwd_kernel<float, NH, SB, 0, 2, true>), grid, block, 0, s, a)
+            if (p.slice_bytes == 256) { if (wide) GAE_XW3(2, 256); else GAE_XW3(1, 256); }
+            else { if (wide) GAE_XW3(2, 512); else GAE_XW3(1, 512); }
+#undef GAE_XW3
+        }
+        else if (p.slice_bytes == 256 && wide && g_xw_depth == 4) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, 0, 4>), grid, block, 0, s, a);
         else if (p.slice_bytes == 256 && wide && g_xw_depth == 5) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, 0, 5>), grid, block, 0, s, a);
         else if (p.slice_bytes == 256 && wide && g_xw_depth == 3) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, 0, 3>), grid, block, 0, s, a);
         else if (p.slice_bytes == 256 && wide && g_xw_dbg == 1) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, 1>), grid, block, 0, s, a);

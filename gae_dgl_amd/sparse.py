@@ -140,7 +140,7 @@ class SparseFeatures:
         if getattr(self, "_dense", None) is not None:
             return self._dense
         n, K = self.shape
-        out = torch.zeros(n, K, dtype=torch.float32, device=self.device)
+        out = ops.pad_rows(torch.zeros(n, K, dtype=torch.float32, device=self.device))     # rows as the loaders pad them
         if self.nnz:
             rows = torch.repeat_interleave(torch.arange(n, device=self.device),
                                            (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64), output_size=self.nnz)

@@ -317,12 +317,16 @@ def test_train_transductive_default_flags_on_a_graph_with_hubs(tmp_path):
     model = G.GAE(X.shape[1], [32, 16]).to(dev)
     model.decoder.dropout = 0.0
     opt = Adam(model.parameters(), lr=1e-2)
-    g.ndata['h'] = sf
-    l0 = model.reconstruction_loss(g); opt.zero_grad(); ops.backward(l0); opt.step()     # eager epoch 0 (densifies, caches)
+
+    def eager_epoch():                     # (the loss tensor must not outlive the step: it keeps the autograd graph, whose
+        g.ndata['h'] = sf                  #  stream-bound AccumulateGrad nodes would invalidate the capture -- capture.py)
+        loss = model.reconstruction_loss(g); opt.zero_grad(); ops.backward(loss); opt.step()
+        return float(loss)
+    l0 = eager_epoch()                     # densifies, caches
     d0 = sf.to_dense()
     step = CapturedTrainStep(model, opt, g, sf, warmup=0)
     l1 = float(step()); l2 = float(step())
-    assert sf.to_dense() is d0 and np.isfinite([l1, l2]).all() and l2 < float(l0)
+    assert sf.to_dense() is d0 and np.isfinite([l1, l2]).all() and l2 < l0
 
 
 def test_sparse_features_refuse_a_near_dense_column():

@@ -67,25 +67,41 @@ def operands(kind, n, f_in, f_out, seed):
 CASES = [("cancel", 20000), ("cancel", 200000), ("long", 1000000)]
 
 
+def bound(kind, n):
+    """what exact fp32 products with the kernels' blocked fp32 accumulation reach on these operands (measured 0.3 .. 1.8e-5
+    at 200000 cancelling rows: the condition number grows like sqrt(n))"""
+    return TOL * max(1.0, (n / 20000) ** 0.5) if kind == "cancel" else TOL
+
+
+def check(errs, kind, n, what):
+    """errs: {atb knob: error against fp64}.  Exact fp32 products (0) stay inside the bound; the default (1, three
+    bf16 pieces) is fp32-grade: inside the bound as well and at most twice the exact form's error (or below 2e-6)"""
+    assert errs[0] < bound(kind, n), (what, kind, n, errs)
+    assert errs[1] < bound(kind, n) and errs[1] <= max(2.0 * errs[0], 2e-6), (what, kind, n, errs)
+
+
 @pytest.mark.parametrize("kind,n", CASES)
 @pytest.mark.parametrize("f_in,f_out", [(64, 32), (500, 32), (39, 32)])
-@pytest.mark.parametrize("atb", [1, 0])
-def test_linear_bwd_wgrad_on_ill_conditioned_operands(kind, n, f_in, f_out, atb, knob):
+def test_linear_bwd_wgrad_on_ill_conditioned_operands(kind, n, f_in, f_out, knob):
     """gae_linear_bwd (dense.hip: atb_bf16_kernel / atb_partial_kernel): dW = dY^T M, db = colsum(dY)"""
     from gae_dgl_amd import ops
     if kind == "long" and f_in == 500:
         n = 200000
     dY, M = operands(kind, n, f_in, f_out, seed=n + f_in)
-    knob("atb_bf16", atb)
-    dW, db, _ = ops.linear_bwd_raw(dY.to(DEV), None, 0, ops.pad_rows(M.to(DEV)), None, need_dM=False, f_out=f_out)
     ref = dY.double().t() @ M.double()
-    assert rel(dW, ref) < TOL, (kind, n, f_in, atb, rel(dW, ref))
-    assert rel(db, dY.double().sum(0)) < TOL
+    errs = {}
+    for atb in (1, 0, 2):
+        knob("atb_bf16", atb)
+        dW, db, _ = ops.linear_bwd_raw(dY.to(DEV), None, 0, ops.pad_rows(M.to(DEV)), None, need_dM=False, f_out=f_out)
+        errs[atb] = rel(dW, ref)
+        assert rel(db, dY.double().sum(0)) < bound(kind, n)
+    check(errs, kind, n, f"linear_bwd {f_in}")
+    if kind == "cancel":
+        assert errs[2] > 3 * errs[1], errs            # (the two-piece form is what this test exists for)
 
 
 @pytest.mark.parametrize("kind,n", CASES)
-@pytest.mark.parametrize("atb", [1, 0])
-def test_gcn2_bwd_dense_on_ill_conditioned_operands(kind, n, atb, knob):
+def test_gcn2_bwd_dense_on_ill_conditioned_operands(kind, n, knob):
     """gae_gcn2_bwd_dense (tall.hip): dW2 = G^T H1, dW1 = ((G W2) (.) relu')^T M1, with H1 recomputed from M1"""
     from gae_dgl_amd import ops
     G, M1 = operands(kind, n, 32, 16, seed=n + 5)
@@ -93,39 +109,53 @@ def test_gcn2_bwd_dense_on_ill_conditioned_operands(kind, n, atb, knob):
     dZ = torch.randn(n, 16, generator=g)
     W1 = torch.randn(32, 32, generator=g) / 32 ** 0.5; b1 = torch.randn(32, generator=g)
     W2 = torch.randn(16, 32, generator=g) / 32 ** 0.5
-    knob("atb_bf16", atb)
     d = lambda t: t.to(DEV)
-    dW1, db1, dW2, db2 = ops.gcn2_bwd_dense_raw(d(G), d(dZ), None, 1, d(M1), d(W2), W1=d(W1), b1=d(b1))
-    # H1 as the kernel forms it (fp32 M1 W1^T + b1, relu), then everything else in fp64
+    # (a handful of pre-activations lie within fp32 rounding of zero and may gate differently than in fp64: one term of
+    #  10^4 .. 10^6 per sum, far below the bounds)
     H1 = torch.relu(M1.double() @ W1.double().t() + b1.double())
     dY1 = (G.double() @ W2.double()) * (H1 > 0)
-    # rows whose pre-activation is within fp32 rounding of zero may flip their gate: leave them out of the reference
-    # the same way for both (measure-zero for these operands; asserted)
-    pre = M1.double() @ W1.double().t() + b1.double()
-    assert int((pre.abs() < 1e-6 * pre.abs().max()).sum()) < 5
-    assert rel(dW2, G.double().t() @ H1) < TOL, (kind, n, atb, "dW2", rel(dW2, G.double().t() @ H1))
-    assert rel(dW1, dY1.t() @ M1.double()) < TOL, (kind, n, atb, "dW1", rel(dW1, dY1.t() @ M1.double()))
-    assert rel(db1, dY1.sum(0)) < TOL and rel(db2, dZ.double().sum(0)) < TOL
+    want = {"dW2": G.double().t() @ H1, "dW1": dY1.t() @ M1.double()}
+    errs = {"dW1": {}, "dW2": {}}
+    for atb in (1, 0):
+        knob("atb_bf16", atb)
+        dW1, db1, dW2, db2 = ops.gcn2_bwd_dense_raw(d(G), d(dZ), None, 1, d(M1), d(W2), W1=d(W1), b1=d(b1))
+        errs["dW1"][atb] = rel(dW1, want["dW1"]); errs["dW2"][atb] = rel(dW2, want["dW2"])
+        assert rel(db1, dY1.sum(0)) < bound(kind, n) and rel(db2, dZ.double().sum(0)) < TOL
+    check(errs["dW2"], kind, n, "gcn2 dW2")
+    check(errs["dW1"], kind, n, "gcn2 dW1")
 
 
 @pytest.mark.parametrize("kind,n", [("cancel", 20000), ("cancel", 200000), ("long", 200000)])
 @pytest.mark.parametrize("f_in", [500, 1433])
 def test_xw_wgrad_and_spx_wgrad_on_ill_conditioned_operands(kind, n, f_in):
-    """gae_xw_wgrad (exact fp32 MFMAs, one pass over X) and gae_spx_wgrad (the same product from the non-zeros of X)"""
+    """gae_xw_wgrad (exact fp32 MFMAs, one pass over X) and gae_spx_wgrad (the same product from the non-zeros of X);
+    gae_xw_fwd (knob xw_p3: three bf16 pieces, six pairs -- the default -- against the exact fp32 MFMAs)"""
     import gae_dgl_amd as Gm
-    from gae_dgl_amd import ops
+    from gae_dgl_amd import _lib, ops
     G, X = operands(kind, n, f_in, 32, seed=n + f_in + 1)
     gen = torch.Generator().manual_seed(3)
     X = X * (torch.rand(n, f_in, generator=gen) < 0.05)               # bag-of-words sparsity; the +-30 column thinned alike
     ref = G.double().t() @ X.double()
     Xd = ops.pad_rows(X.to(DEV))
     dW, db = ops.xw_wgrad_raw(Xd, G.to(DEV), None, G.to(DEV), None, 32)
-    assert rel(dW, ref) < TOL, (kind, n, f_in, rel(dW, ref))
-    assert rel(db, G.double().sum(0)) < TOL
+    assert rel(dW, ref) < bound(kind, n), (kind, n, f_in, rel(dW, ref))
+    assert rel(db, G.double().sum(0)) < bound(kind, n)
     sf = Gm.SparseFeatures.from_dense(Xd)
     dWs, dbs = ops.spx_wgrad_raw(sf, G.to(DEV), G.to(DEV), None, 32)
-    assert rel(dWs, ref) < TOL, (kind, n, f_in, "spx", rel(dWs, ref))
-    assert rel(dbs, G.double().sum(0)) < TOL
+    assert rel(dWs, ref) < bound(kind, n), (kind, n, f_in, "spx", rel(dWs, ref))
+    assert rel(dbs, G.double().sum(0)) < bound(kind, n)
+    # forward on the same X: rows of W with a +-30 pair that cancels against X's constant column
+    Wt = 0.3 * torch.randn(32, f_in, generator=gen)
+    Wt[:, 0] += 30.0; Wt[:, 1] -= 30.0
+    reff = X.double() @ Wt.double().t()
+    errs = {}
+    for p3 in (1, 0):
+        _lib.call("gae_tuning_set", b"xw_p3", p3)
+        try:
+            errs[p3] = rel(ops.xw_fwd_raw(Xd, Wt.to(DEV), None, 0), reff)
+        finally:
+            _lib.call("gae_tuning_set", b"xw_p3", 1)
+    assert errs[0] < TOL and errs[1] <= max(2.0 * errs[0], 2e-6), errs
 
 
 @pytest.mark.timeout(600)
@@ -156,6 +186,7 @@ def test_cora_model_after_200_steps_gradients_match_fp64(layer1, knob):
         errs = {}
         for atb in (1, 0):
             knob("atb_bf16", atb)
+            knob("xw_p3", atb)
             model.zero_grad()
             g.ndata['h'] = Xd
             loss = model.reconstruction_loss(g)
