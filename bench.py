@@ -140,7 +140,7 @@ def parse():
 def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/pmc_traffic_r02.json, else _r01: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)."""
-    for name in ("pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic_r01.json"):
+    for name in ("pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic_r01.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
@@ -285,7 +285,7 @@ def spmm_probe(indptr, indices, n, F, ld=None, plan=None, label="", iters=50, bl
 # accumulation are fp32; the products of the fused loss and of the weight gradients run on the bf16 matrix pipe as
 # split-operand products (see config.loss_products / dW_products; `value_exact_fp32` is the same step with exact
 # fp32 products everywhere)
-DTYPE_SPLIT = "f32 (loss / dW products: bf16 split operands on the matrix cores, f32 accumulate)"
+DTYPE_SPLIT = ("f32 (storage, aggregations, accumulators; the dense products run on the 16-bit matrix pipe from split operands with fp32 accumulation: X W^T and dW from three bf16 pieces per operand / six pairs, the loss from two fp16 pieces (N >= 8192) or three bf16 pieces -- all fp32-grade, see ms_per_step_exact_fp32 for fp32 MFMAs everywhere)")
 
 
 class CitationWorkload:
@@ -315,9 +315,9 @@ class CitationWorkload:
                      "hidden_dims": self.hidden, "norm": "none", "loss": args.loss + "-bce",
                      "optimizer": "adam lr=1e-2: " + opt_name, "parallelism": "1 GPU",
                      "launch": "hipGraph replay of the captured step" if self.use_graph else "eager",
-                     "forward_products": "fp32 MFMA (exact fp32 embeddings)",
+                     "forward_products": "layer 1 X W^T: three bf16 pieces per operand, six pairs (knob xw_p3=1: 1.5e-7 of fp64, as the fp32 MFMAs it replaces); narrow layers: fp32 MFMA",
                      "loss_products": "split-operand products on K = 32 MFMAs, fp32 accumulate (knobs bce_s_bf16=3, bce_pv_bf16=1): N >= 8192 (symmetric kernel): two fp16 pieces per operand for S = Z Z^T and dZ = P Z (22 mantissa bits; embeddings beyond |z| = 32768 fall back to the bf16 form inside the same call); N < 8192: three bf16 pieces for S (24 bits), two for P Z",
-                     "dW_products": "bf16x3 split products, fp32 accumulate (knob atb_bf16=1)",
+                     "dW_products": "three bf16 pieces per operand, six piece pairs down to 2^-24, fp32 accumulate (knob atb_bf16=1; gae_xw_wgrad: exact fp32 MFMAs)",
                      "residency": f"operands of the dominant launch ({2 * n * self.F_in * 4 / 1e6:.0f} MB) stay in the "
                                   "256 MB Infinity Cache across the timed replays: its '% of 8 TB/s' is measured "
                                   "against the on-die fabric, not DRAM"}
@@ -367,6 +367,17 @@ class CitationWorkload:
         plan = self.g.spmm_plan(False)
         sc = self.Xd.shape[1] > ops.TILE_MIN_F and self.g.scattered(self.Xd.shape[1] * 4)
         return lambda: ops.spmm_raw(ip, ix, self.Xd, self.n, out=out, plan=plan, out_padded=True, scattered=sc)
+
+    def aggregation_launch(self):
+        """the DEFAULT step's layer-1 aggregation on its real operands: act(A P + b) at F = 32 with P = X W^T as
+        gae_xw_fwd leaves it (gae_spmm_csr_epilogue) -- the SpMM the step actually runs (SURVEY 8(d)'s unit)"""
+        from gae_dgl_amd import ops
+        lin = self.model.layers[0].apply_mod.linear
+        W1, b1 = lin.weight.detach(), lin.bias.detach()
+        P, _ = ops.xw_fwd_raw(self.Xd, W1, None, 0, keep_splits=True)
+        ip, ix = self.g.csr()
+        plan = self.g.spmm_plan(False)
+        return lambda: ops.spmm_epilogue_raw(ip, ix, P, self.n, plan, b1, 1)
 
     def capture(self):
         from gae_dgl_amd.capture import CapturedTrainStep
@@ -1167,7 +1178,7 @@ def main():
         # ---- the same step with exact-fp32 products everywhere (no bf16 x 3 split)
         if graphed and isinstance(wl, CitationWorkload):
             from gae_dgl_amd import _lib
-            knobs = {b"bce_s_bf16": 3, b"bce_pv_bf16": 1, b"atb_bf16": 1}          # name -> the library's default
+            knobs = {b"bce_s_bf16": 3, b"bce_pv_bf16": 1, b"atb_bf16": 1, b"xw_p3": 1}          # name -> the library's default
             for k in knobs:
                 _lib.call("gae_tuning_set", k, 0)
             try:
@@ -1185,6 +1196,37 @@ def main():
             finally:
                 for k, v in knobs.items():
                     _lib.call("gae_tuning_set", k, v)
+    if world == 1 and isinstance(wl, CitationWorkload) and getattr(wl, "tf", False) and not wl.sparse \
+            and type(wl) is CitationWorkload:
+        # ---- SURVEY 8(d)'s unit, the SpMM aggregation itself: (1) the aggregation the DEFAULT step runs,
+        #      act(A P + b) at F = 32 on the step's own operands; (2) the reference-order layer-1 aggregation A X at the
+        #      input width (the north-star's SpMM; not in the default step).  Both kernel-only, back-to-back launches
+        #      between HIP events on the launch stream, with the copy rate of the same bytes as second denominator.
+        from gae_dgl_amd import workloads as Wl
+        agg = wl.aggregation_launch()
+        t_agg = time_launches(agg, iters=50, warmup=30)
+        E_ = wl.g.number_of_edges()
+        b_agg = Wl.spmm_alg_bytes(wl.n, wl.n, E_, wl.hidden[0], 4)
+        c_agg = copy_bandwidth(b_agg, dev)
+        ref = citation_spmm_probe(wl.meta["workload"].split("-")[0], dev)
+        c_ref = copy_bandwidth(ref["alg_bytes"], dev)
+        line["roofline_spmm"] = {
+            "default_step_aggregation": {
+                "kernel": f"gae_spmm_csr_epilogue: act(A (X W^T) + b), F = {wl.hidden[0]}, {wl.n} rows, {E_} edges (in the default step)",
+                "alg_bytes": b_agg, "avg_launch_us": t_agg * 1e6, "achieved_GBs": b_agg / t_agg / 1e9,
+                "frac": b_agg / t_agg / 1e9 / HBM_PEAK_GBS, "copy_GBs": c_agg, "frac_of_copy": b_agg / t_agg / 1e9 / c_agg,
+                "edges_per_s": E_ / t_agg,
+                "note": "5.5 MB of compulsory traffic: at 8 TB/s the launch would last 0.7 us -- it is bound by its chain of "
+                        "dependent round trips (row pointers -> neighbour ids -> gathered rows), not by bytes"},
+            "reference_order_layer1": {
+                "kernel": ref["shape"], "F": ref["F"], "alg_bytes": ref["alg_bytes"], "avg_launch_us": ref["us_per_launch"],
+                "achieved_GBs": ref["achieved_GBs"], "frac": ref["frac_hbm_peak"], "copy_GBs": c_ref,
+                "frac_of_copy": ref["achieved_GBs"] / c_ref, "edges_per_s": ref["edges_per_s"], "traffic": ref["traffic"]}}
+        line["roofline"]["spmm"] = {k: {kk: v[kk] for kk in ("alg_bytes", "avg_launch_us", "frac", "frac_of_copy")}
+                                    for k, v in line["roofline_spmm"].items()}
+    if "ms_per_step_exact_fp32" in line:        # (the driver keeps `config` whole: the same-arithmetic figure travels there too)
+        line["config"]["ms_per_step_exact_fp32"] = line["ms_per_step_exact_fp32"]
+        line["config"]["value_exact_fp32"] = line["value_exact_fp32"]
     if "decoder_bce" in {k[0] for k in times}:
         kb = [k for k in times if k[0] == "decoder_bce"]
         tb = float(np.mean([t for k in kb for t in times[k]]))
@@ -1214,6 +1256,9 @@ def main():
     except Exception:
         pass
     sys.stdout.flush()
+    for k in ("ms_per_step_exact_fp32", "value_exact_fp32", "roofline_spmm"):       # last in the line: inside any tail of it
+        if k in line:
+            line[k] = line.pop(k)
     print(json.dumps(line), flush=True)
 
 
