@@ -547,11 +547,12 @@ class VgaeWorkload(CitationWorkload):
 class ZincWorkload:
     """inductive step, batch of B molecules gathered on the device (train_inductive.py:31-53)"""
 
-    def __init__(self, args, dev, n_graphs=None):
+    def __init__(self, args, dev, n_graphs=None, rank=0, world=1, group=None):
         import gae_dgl_amd as G
         from gae_dgl_amd import workloads as W
         from gae_dgl_amd.dataset import DeviceGraphDataset
         self.args, self.dev = args, dev
+        self.rank, self.world, self.group = rank, world, group
         B = args.batch_graphs
         n_graphs = n_graphs or max(4 * B, 32768)
         self.ds = DeviceGraphDataset.synthetic_zinc(n_graphs, seed=0, device=dev)
@@ -563,13 +564,23 @@ class ZincWorkload:
         self.runner = None
         self.rng = np.random.default_rng(0)
         self.perm = self.rng.permutation(n_graphs)
+        if world > 1:          # data-parallel replicas: every rank holds the dataset and trains on its share of the order
+            from gae_dgl_amd.dataset import shard_order
+            self.perm = shard_order(self.perm, rank, world)
+            self.use_graph = self.use_graph and not args.oversubscribe     # (staged collectives cannot be captured)
         self.d_perm = torch.from_numpy(self.perm).to(dev)      # the epoch order lives on the device (ds.epoch())
+
         self.cursor = 0
         nb = int(self.ds.sizes_host[:B].sum()); eb = int(self.ds.edges_host[:B].sum())
-        self.edges_per_step = 3 * eb                                          # nominal (batch 0); varies < 1 % per batch
+        self.edges_per_step = 3 * eb * world                                  # nominal (batch 0; all replicas); varies < 1 % per batch
         self.meta = {"workload": "zinc250k-inductive-gae", "batch_graphs": B, "nodes_per_batch~": nb,
                      "edges_per_batch~": eb, "in_dim": 39, "hidden_dims": [32, 16], "loss": "fused-bce",
-                     "optimizer": "adam lr=1e-3: " + opt_name, "dataset_graphs": n_graphs, "parallelism": "1 GPU",
+                     "optimizer": "adam lr=1e-3: " + opt_name, "dataset_graphs": n_graphs,
+                     "parallelism": "1 GPU" if world == 1 else
+                                    f"data-parallel x{world}: every replica trains on its share of the epoch order, ONE "
+                                    f"all-reduce of the 1 808 parameter gradients per step (averaged; inside the "
+                                    f"captured step) -- train_inductive.py:84-96 on {world} GPUs, global batch "
+                                    f"{B * world} molecules",
                      "launch": "hipGraph replay per batch (collate + step on a fixed-capacity batch, "
                                "capture.CapturedInductiveStep)" if self.use_graph else "eager",
                      "batches_per_epoch_at_239455_graphs": int(np.ceil(239455 / B))}
@@ -608,7 +619,8 @@ class ZincWorkload:
 
     def capture(self):
         from gae_dgl_amd.capture import CapturedInductiveStep
-        self.runner = CapturedInductiveStep(self.model, self.opt, self.ds, self.B)
+        self.runner = CapturedInductiveStep(self.model, self.opt, self.ds, self.B, group=self.group,
+                                            replicas=self.world > 1)
         self._left = 0
         self.meta["capacity"] = None
 
@@ -625,7 +637,11 @@ class ZincWorkload:
         bg = self.ds._assemble(self.d_perm[self._lo:self._lo + self.B], ids)   # dgl.batch on the device (K10), no H2D
         loss = self.model.reconstruction_loss(bg)
         from gae_dgl_amd import ops
-        self.opt.zero_grad(); ops.backward(loss); self.opt.step()
+        self.opt.zero_grad(); ops.backward(loss)
+        if self.world > 1:
+            from gae_dgl_amd.parallel import allreduce_grads
+            allreduce_grads(list(self.model.parameters()), self.group, average=True)
+        self.opt.step()
         return loss
 
 
@@ -1025,7 +1041,11 @@ def main():
                                 f"oversubscribed: {world} ranks share {torch.cuda.device_count()} GPU(s), collectives over gloo "
                                 f"staged through host memory -- functional rehearsal, not a scaling measurement")
     elif workload == "zinc":
-        wl = ZincWorkload(args, dev)
+        wl = ZincWorkload(args, dev, rank=rank, world=world, group=group)
+        wl.meta["transport"] = ("RCCL (backend nccl), one process per GPU" if not args.oversubscribe else
+                                f"oversubscribed: {world} ranks share {torch.cuda.device_count()} GPU(s), collectives over gloo "
+                                f"staged through host memory -- functional rehearsal, not a scaling measurement") \
+            if world > 1 else "none (1 GPU)"
     elif workload == "vgae":
         wl = VgaeWorkload(args, dev)
     else:
@@ -1090,7 +1110,7 @@ def main():
     elif wl.dominant is None and spmm_keys:   # zinc: batch shapes vary slightly; take the F=39 launches
         dom = [t for k in spmm_keys if k[3] == 39 for t in times[k]]
         k39 = [k for k in spmm_keys if k[3] == 39]
-        nb = int(np.mean([k[1] for k in k39])); eb = wl.edges_per_step // 3
+        nb = int(np.mean([k[1] for k in k39])); eb = wl.edges_per_step // 3 // max(world, 1)
         wl.alg_bytes = 4 * (nb + 1) + 4 * eb + 2 * 4 * 39 * nb
         wl.dominant_desc = f"spmm F=39 (layer-1 aggregation of a {wl.B}-molecule batch, ~{nb} rows, ~{eb} edges)"
     else:
@@ -1236,7 +1256,7 @@ def main():
                                 "bound": "issue: 2 transcendentals + ~10 VALU ops + 0.9 (full kernel) / 1.75 "
                                          "(symmetric) bf16 MFMAs per 32 logits and lane; rocprofv3 kernel time in "
                                          "profiles/"}
-    if not args.no_cpu_baseline and hasattr(wl, "cpu_baseline"):
+    if not args.no_cpu_baseline and hasattr(wl, "cpu_baseline") and world == 1:      # (rank 0 at N = 1 only)
         line["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
         line["cpu_baseline"]["cpu_model"] = cpu_model_name()
         # the SpMM metric alone on the host cores: forward and backward, all cores and one thread

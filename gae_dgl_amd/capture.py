@@ -16,15 +16,16 @@ import torch
 from . import ops
 
 
-def _defer(opt, loss_too=False):
+def _defer(opt, loss_too=False, grads=True):
     """the step's context (ops.StepContext): the weight gradients' reductions -- and, ``loss_too``, the loss's final one
     -- are left to the optimiser launch when the optimiser is the library's Adam (which consumes them); a context that
     defers nothing for any other optimiser.  ``loss_too``: the step's loss is the fused decoder + BCE scalar itself and
     nothing reads it before the optimiser launch (a loss_fn of the caller's may do arithmetic on it: those steps keep
-    the reduction launch)."""
+    the reduction launch).  ``grads`` False: the gradients must be finished before the optimiser launch (data-parallel
+    replicas all-reduce them in between)."""
     from .optim import Adam
     ours = isinstance(opt, Adam)
-    return ops.StepContext(defer_grads=ours and DEFER_GRAD_REDUCTIONS,
+    return ops.StepContext(defer_grads=ours and grads and DEFER_GRAD_REDUCTIONS,
                            defer_loss=ours and loss_too and DEFER_LOSS_FINALIZE)
 
 
@@ -140,7 +141,21 @@ class CapturedInductiveStep:
                 ...
     """
 
-    def __init__(self, model, optimizer, dataset, batch_size, warmup=2, margin=1.005):
+    def __init__(self, model, optimizer, dataset, batch_size, warmup=2, margin=1.005, group=None, replicas=False):
+        """``replicas`` (with ``group``, default process group when None): data-parallel replicas -- every rank replays
+        its own batches; the parameter gradients are averaged over the ranks by ONE all-reduce (RCCL, part of the
+        captured graph) between the backward pass and the optimiser launch, and the batch capacities are agreed on
+        (all-reduce MAX) so that every rank captures at the same steps.  Every rank must run the same number of
+        steps per epoch (dataset.shard_order)."""
+        self.group, self.replicas = group, bool(replicas)
+        if self.replicas:
+            import torch.distributed as dist
+            from . import transport
+            if not dist.is_initialized():
+                raise ValueError("replicas=True needs an initialised process group")
+            if transport.backend(group) != "nccl":
+                raise RuntimeError("a captured data-parallel step needs RCCL (backend nccl): collectives staged through "
+                                   "host memory synchronise the stream, which a capture forbids -- use the eager step")
         if not dataset.ell_width or not dataset.no_heavy_rows:
             raise ops.GaeHipError("CapturedInductiveStep needs a dataset of low-degree graphs (packed neighbour "
                                   "table); skewed graphs take the eager path")
@@ -222,9 +237,12 @@ class CapturedInductiveStep:
             g._cache.pop(key, None)
         g.ndata.clear()
         g.ndata['h'] = self.x
-        with _defer(self.opt, True):
+        with _defer(self.opt, True, grads=not self.replicas):
             loss = self.model.reconstruction_loss(g)
             ops.backward(loss, self._params)      # autograd.grad: no AccumulateGrad nodes (stream-bound) in the capture
+            if self.replicas:                     # 1 808 floats for the 39 -> 32 -> 16 model: one small all-reduce
+                from .parallel import allreduce_grads
+                allreduce_grads(self._params, self.group, average=True)
             self.opt.step()
         return loss.detach()
 
@@ -305,6 +323,12 @@ class CapturedInductiveStep:
             need_n = int(np.add.reduceat(self.ds.sizes_host[head], starts).max())
             need_e = int(max(np.add.reduceat(self.ds.edges_host[head], starts).max(),
                              np.add.reduceat(self.ds.t_edges_host[head], starts).max()))
+            if self.replicas:      # the replicas must (re)capture together: the warm-up steps hold collectives
+                import torch.distributed as dist
+                from . import transport
+                need = torch.tensor([need_n, need_e], dtype=torch.int64, device=self.ds.device)
+                transport.all_reduce(need, op=dist.ReduceOp.MAX, group=self.group)
+                need_n, need_e = (int(v) for v in need.tolist())
             if self.graph is None or need_n > self.cap_nodes or need_e > self.cap_edges:
                 # round the capacities up (whole row blocks of the kernels, headroom for later epochs)
                 cap_n = max(-(-int(need_n * self.margin) // 64) * 64, self.cap_nodes)
@@ -348,6 +372,9 @@ class CapturedInductiveStep:
         self.opt.zero_grad(set_to_none=True)
         loss = self.model.reconstruction_loss(bg)
         ops.backward(loss)
+        if self.replicas:
+            from .parallel import allreduce_grads
+            allreduce_grads(self._params, self.group, average=True)
         self.opt.step()
         return loss.detach()
 

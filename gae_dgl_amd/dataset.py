@@ -261,13 +261,16 @@ class DeviceGraphDataset(Dataset):
             slot[1].record()
         return self._assemble(d_gids, gids)
 
-    def epoch(self, batch_size, shuffle=True, rng=None, drop_last=False):
+    def epoch(self, batch_size, shuffle=True, rng=None, drop_last=False, shard=None):
         """iterate over the batches of one epoch with NO host <-> device copy per batch: the epoch's order is
         uploaded once, every batch slices it on the device (what DataLoader(shuffle=True, collate_fn=collate) of
-        train_inductive.py:84-85 does per batch on the host)"""
+        train_inductive.py:84-85 does per batch on the host).  ``shard`` = (rank, world): this replica's share of the
+        epoch (shard_order)"""
         order = self.ids.copy()
         if shuffle:
             (rng or np.random.default_rng()).shuffle(order)
+        if shard is not None:
+            order = shard_order(order, *shard)
         d_order = torch.from_numpy(order).to(self.device)
         n = len(order)
         stop = n - n % batch_size if drop_last else n
@@ -275,10 +278,11 @@ class DeviceGraphDataset(Dataset):
             hi = min(lo + batch_size, n)
             yield self._assemble(d_order[lo:hi], order[lo:hi])
 
-    def loader(self, batch_size, shuffle=False, seed=None):
+    def loader(self, batch_size, shuffle=False, seed=None, shard=None):
         """DataLoader(dataset, batch_size, shuffle, collate_fn=collate) of train_inductive.py:84-85 for a resident
-        dataset: an iterable with len() whose batches come from epoch()"""
-        return DeviceLoader(self, batch_size, shuffle, seed)
+        dataset: an iterable with len() whose batches come from epoch().  ``shard`` = (rank, world): data-parallel
+        replicas -- every replica draws the SAME epoch order (same seed) and keeps its share of it"""
+        return DeviceLoader(self, batch_size, shuffle, seed, shard)
 
     # -------------------------------------------------------------- flat on-disk format
     @staticmethod
@@ -308,24 +312,40 @@ class DeviceGraphDataset(Dataset):
         return cls(gp, s, d, X, device=device, **kw)
 
 
+def shard_order(order, rank, world):
+    """replica ``rank``'s share of an epoch order for data-parallel training (train_inductive.py:84-96 on ``world``
+    GPUs): global batch k of B graphs is made of the replicas' k-th batches, so the order is dealt in blocks --
+    replica r takes the graphs at positions r, r + world, ...; the ragged remainder (len(order) % world graphs) is
+    dropped so that every replica runs the same number of steps (the collectives of a step must pair up)."""
+    n = len(order) // world * world
+    return np.ascontiguousarray(order[:n][rank::world])
+
+
 class DeviceLoader:
     """what the reference builds with DataLoader(..., collate_fn=collate) (train_inductive.py:84-85), for a
     DeviceGraphDataset: iterating yields the block-diagonal batches of one epoch (fresh shuffle per epoch, the last
     short batch kept like DataLoader's default); no worker processes, no per-batch host -> device copy"""
 
-    def __init__(self, dataset, batch_size, shuffle=False, seed=None):
+    def __init__(self, dataset, batch_size, shuffle=False, seed=None, shard=None):
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), bool(shuffle)
         self.rng = np.random.default_rng(seed)
+        self.shard = shard
+        if shard is not None and shuffle and seed is None:
+            raise ValueError("data-parallel replicas must draw the same epoch orders: give the loader a seed")
+
+    def _n_graphs(self):
+        n = len(self.dataset)
+        return n if self.shard is None else n // self.shard[1]
 
     def __len__(self):
-        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+        return (self._n_graphs() + self.batch_size - 1) // self.batch_size
 
     def next_order(self):
         """the graph ids of the next epoch, in batch order (consumes the same random numbers as __iter__)"""
         order = self.dataset.ids.copy()
         if self.shuffle:
             self.rng.shuffle(order)
-        return order
+        return order if self.shard is None else shard_order(order, *self.shard)
 
     def __iter__(self):
-        return self.dataset.epoch(self.batch_size, shuffle=self.shuffle, rng=self.rng)
+        return self.dataset.epoch(self.batch_size, shuffle=self.shuffle, rng=self.rng, shard=self.shard)

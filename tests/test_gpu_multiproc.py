@@ -239,3 +239,87 @@ def test_bench_two_ranks_oversubscribed_prints_a_valid_line():
     one = line["same_workload_1gpu"]
     assert one["value"] > 0 and one["ms_per_step"] > 0 and "speedup" in one
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+
+
+# ------------------------------------------------------------------------------------------ data-parallel replicas
+def _dp_worker(rank, world, port, q, save_dir):
+    dist = _init(rank, world, port)
+    try:
+        seen = _record_calls()
+        import gae_dgl_amd as G
+        from gae_dgl_amd import train_inductive as TI
+        from gae_dgl_amd.dataset import DeviceGraphDataset
+        import argparse
+        B, steps = 64, 5
+        ds = DeviceGraphDataset.synthetic_zinc(B * world * steps + 37, seed=3, device=DEV)
+
+        def make(replicas):
+            torch.manual_seed(0)
+            model = G.GAE(39, [32, 16]).to(DEV)
+            model.decoder.dropout = 0.0                       # (one draw stream per process: the comparison below needs none)
+            TI.device = torch.device(DEV)
+            return model, TI.Trainer(model, argparse.Namespace(lr=1e-3), fused=True, replicas=replicas)
+
+        # ---- the replicas: this rank's share of a seeded epoch order, gradients averaged by one all-reduce per step
+        model, tr = make(True)
+        loader = ds.loader(B, shuffle=True, seed=5, shard=(rank, world))
+        assert len(loader) == steps + 1                      # 5 full batches + the ragged share of the 37
+        losses = [float(tr.iteration(bg, train=True, as_tensor=True)) for bg in loader]
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+        other = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        assert all(torch.equal(o, flat) for o in other), "replicas ended the epoch with different weights"
+        # ---- ONE process fed every replica's batch of a step, loss = their mean (train_inductive.py:44-53 once)
+        ref, tr1 = make(False)
+        iters = [iter(ds.loader(B, shuffle=True, seed=5, shard=(r, world))) for r in range(world)]
+        from gae_dgl_amd import ops
+        for _ in range(len(loader)):
+            loss = sum(ref.reconstruction_loss(next(it)) for it in iters) / world
+            tr1.optim.zero_grad(); ops.backward(loss); tr1.optim.step()
+        for a, b in zip(model.parameters(), ref.parameters()):
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), "replicas != one process fed all batches"
+        for name in ("gae_batch_gather", "gae_decoder_bce", "gae_x_adam_step_tail"):
+            assert any(k.startswith(name) for k in seen), f"{name}* was never called: {sorted(seen)}"
+        # ---- the script itself: `train_inductive --distributed` (eager here: staged collectives cannot be captured)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), GAE_DIST_SHARE_GPUS="1")
+        tl, vl = TI.main(["--distributed", "--synthetic", "700", "-b", "64", "--hidden_dims", "32", "16", "-e", "2",
+                          "--no_plot", "--val_size", "100", "-s", save_dir, "--capture", "auto"])
+        assert np.isfinite(tl).all() and np.isfinite(vl).all() and len(tl) == 2
+        flat = torch.cat([v.reshape(-1).float() for v in TI.main.final_state.values()]).cpu()
+        other = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        assert all(torch.equal(o, flat) for o in other)
+        q.put((rank, "ok", {"losses": losses, "script": (tl, vl)}))
+    except Exception:
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc(), None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_data_parallel_replicas_in_separate_processes_equal_one_process(world, tmp_path):
+    """the data-parallel half of SURVEY 8(e) on the real kernels: `world` processes (sharing cuda:0, gloo staged) train
+    replicas on their shares of an epoch; they end with bit-identical weights, equal to one process fed all the batches
+    of a step; `train_inductive --distributed` runs end to end and every rank reports the same epoch means"""
+    res = _run(_dp_worker, world, (str(tmp_path),), 35500 + 11 * world)
+    for r in res[1:]:
+        assert r[2]["script"] == res[0][2]["script"]
+    assert os.path.exists(tmp_path / "ep01.pkl")
+
+
+@pytest.mark.timeout(1500)
+def test_bench_zinc_two_replicas_oversubscribed_prints_a_valid_line():
+    """`bench.py --workload zinc --gpus 2` (data-parallel replicas, weak scaling), rehearsed on the one GPU"""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "zinc",
+                        "--batch-graphs", "128", "--oversubscribe", "--steps", "5", "--warmup", "2", "--no-extra"],
+                       capture_output=True, text=True, timeout=1400, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["unit"] == "edges/s" and line["value"] > 0
+    assert line["config"]["parallelism"].startswith("data-parallel x2")
+    assert "oversubscribed" in line["config"]["transport"] and "cpu_baseline" not in line
