@@ -33,7 +33,8 @@ def _newer(target, deps):
 def build_library(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "gae_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "gae_hip.h"),
+               os.path.join(ROOT, "include", "gae_hip_experimental.h")]
     headers += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.abspath(__file__))
     objs, rebuilt = [], False

@@ -7,6 +7,7 @@
 #include <atomic>
 
 #include "gae_hip.h"
+#include "gae_hip_experimental.h"
 
 namespace gae {
 

@@ -9,13 +9,32 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "gae_hip.h")
+HEADER = os.path.join(ROOT, "include", "gae_hip.h")                      # the boundary a maintainer binds
+SEAMS = os.path.join(ROOT, "include", "gae_hip_experimental.h")          # the library's own seams (its host mirror only)
+
+
+def _symbols_of(path):
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gae_[a-z0-9_]+)\s*\(", src)))
 
 
 def declared_symbols():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(gae_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(_symbols_of(HEADER)) | set(_symbols_of(SEAMS)))
+
+
+def test_the_boundary_header_stays_small():
+    """include/gae_hip.h is what a maintainer binds -- at most 45 entry points, none of them a gae_x_*
+    seam; the seams live in gae_hip_experimental.h, and no symbol is declared twice"""
+    core, seams = _symbols_of(HEADER), _symbols_of(SEAMS)
+    assert len(core) <= 45, len(core)
+    assert not any(s.startswith("gae_x_") for s in core)
+    assert not set(core) & set(seams)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    ask = text[:text.index("### Seams of the library's own host mirror")]      # the part a maintainer follows
+    for s in seams:
+        if s.startswith("gae_x_"):
+            assert s not in ask, f"INTEGRATION.md asks a maintainer to bind the seam {s}"
 
 
 def test_header_declares_entry_points():
