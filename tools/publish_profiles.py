@@ -12,8 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
-if TAG == "r04c":          # round 4 collects into gpurun_out/r04c (r04/ holds the working measurements); files are r04_*
-    TAG = "r04"
+if TAG in ("r04c", "r05c"):          # rounds 4, 5 collect into gpurun_out/r0Nc; files are r0N_*
+    TAG = TAG[:3]
 DST = os.path.join(ROOT, "profiles")
 
 
