@@ -70,6 +70,23 @@ LOSS_ISA = {
 }
 
 
+# The ALGORITHMICALLY REQUIRED part of those instruction mixes: the S product and the two P V products
+# (row side and mirror) at the chosen piece count, one exp per logit, one reciprocal per four, the log of the running
+# product, and the fp32 arithmetic between them (|y| sum, 1 + e, product tree, R t, the fma that forms sigma - 1/2).
+# Everything else the kernels issue -- splitting P into 16-bit pieces, copysign, re-laying P out for the mirror product
+# (identity MFMAs + conversions), LDS traffic, loop overhead -- is emulation overhead of running fp32-grade products on
+# the 16-bit matrix pipe.  The full-square kernel has no mirror product.
+LOSS_ALG = {
+    "symmetric": {"mfma": 16 + 12 + 12, "trans": 32 + 8 + 2, "plain": 32 + 32 + 32 + 16 + 32},
+    "symmetric256": {"mfma": 16 + 12 + 12, "trans": 32 + 8 + 2, "plain": 32 + 32 + 32 + 16 + 32},
+    "full": {"mfma": 24 + 12, "trans": 32 + 8 + 2, "plain": 32 + 32 + 32 + 16 + 32},
+}
+
+
+def loss_alg_slots_per_logit(kind):
+    return sum(SLOT_COST[k] * v for k, v in LOSS_ALG[kind].items()) / 32.0
+
+
 def loss_slots_per_logit(kind):
     isa, frac_eval = LOSS_ISA[kind]
     return sum(SLOT_COST[k] * v for k, v in isa.items()) / 32.0, frac_eval
@@ -1181,6 +1198,12 @@ def main():
             "achieved": units / t_loss / 1e12, "peak": ISSUE_PEAK_LANE_SLOTS / 1e12, "unit": "T lane-slots/s",
             "frac": units / t_loss / ISSUE_PEAK_LANE_SLOTS, "avg_launch_us": t_loss * 1e6,
             "peak_spec": SPEC_LANE_OPS / 1e12, "frac_spec": units / t_loss / SPEC_LANE_OPS,
+            "frac_alg": loss_alg_slots_per_logit(kind) * frac_eval * float(n) * n / t_loss / ISSUE_PEAK_LANE_SLOTS,
+            "alg_note": f"frac_alg counts only the algorithmically required issue slots ({loss_alg_slots_per_logit(kind):.1f} of the "
+                        f"{per_logit:.1f} per logit: {LOSS_ALG[kind]} per 32 logits -- S and the two P V products at the chosen "
+                        "piece count, exp, one reciprocal per four logits, the log of the running product, the fp32 arithmetic "
+                        "between them); the rest (splitting P into 16-bit pieces, copysign, re-laying P out for the mirror "
+                        "product, LDS traffic) is the price of fp32-grade products on the 16-bit matrix pipe",
             "peak_note": "peak = the issue rate tools/probes/inst_cost.hip measures at 4 waves / SIMD (self-measured); "
                          "peak_spec = the data sheet's fp32 vector rate, 157.3 TFLOP/s / 2 = 78.6 T lane-operations/s",
             "logits_per_s": float(n) * n / t_loss,
