@@ -1131,7 +1131,9 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
             return *reinterpret_cast<const f32x4 *>(Wmir + sym_strip_offset(I, NP, SYM_PR) + (j0 - de) * 16 + f * TJ + jq);
         };
         // (16 strips in flight and the ragged tail requested as one predicated batch were measured: Pubmed 28.6 -> 35.8 us,
-        //  a ZINC batch 236 -> 245 us -- eight plain loads per batch it stays)
+        //  a ZINC batch 236 -> 245 us -- eight plain loads per batch it stays.  The fold is a byte stream, not a latency chain:
+        //  as a launch of its own, cut into four pieces per column tile (1232 blocks), it takes 18.0 us = 97 MB at 5.4 TB/s
+        //  and the edge kernel 13.2 us behind it -- 31.2 us against 28.6 us fused; profiles/r05_loss_fold.txt)
         int64_t I = 0;
         for (; I + 8 <= n_left; I += 8) {
             f32x4 v[8];
