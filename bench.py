@@ -1239,8 +1239,7 @@ def main():
             finally:
                 for k, v in knobs.items():
                     _lib.call("gae_tuning_set", k, v)
-    if world == 1 and isinstance(wl, CitationWorkload) and getattr(wl, "tf", False) and not wl.sparse \
-            and type(wl) is CitationWorkload:
+    if world == 1 and type(wl) is CitationWorkload and getattr(wl, "tf", False) and not wl.sparse:
         # ---- SURVEY 8(d)'s unit, the SpMM aggregation itself: (1) the aggregation the DEFAULT step runs,
         #      act(A P + b) at F = 32 on the step's own operands; (2) the reference-order layer-1 aggregation A X at the
         #      input width (the north-star's SpMM; not in the default step).  Both kernel-only, back-to-back launches
