@@ -18,6 +18,15 @@ encodes DGL's documented semantics at the reference's call sites:
 
 Only DATA is written (inputs and expected outputs, .npz); no reference source
 or bytecode is copied.  Usage:  python tests/golden/make_golden.py
+
+Reproducibility: main() pins torch to ONE thread.  ATen's threaded fp32 GEMMs
+split their reductions by thread count, so with 8 threads the wide cases'
+layer-1 gradients (f_in 300 / 2003) move in their last bits from run to run
+and the three Adam steps amplify that to 1e-5 .. 7e-5 of the weights wherever
+a gradient entry is near zero (Adam's first steps are lr * sign-like).  On one
+thread two runs in this container write bit-identical files (checked for every
+array of every fixture); across machines or torch builds only the tolerance
+the tests state holds.
 """
 import importlib.util
 import os
@@ -248,6 +257,7 @@ def run_case(ref, name, n, src, dst, X, hidden, seed):
 
 
 def main():
+    torch.set_num_threads(1)          # see "Reproducibility" above
     ref = load_reference()
     assert ref.gcn_msg == ("copy_src", "h", "m") and ref.gcn_reduce == ("sum", "m", "h")
     cases, mols = build_cases()
