@@ -131,6 +131,10 @@ def parse():
                          "library's default for layers that narrow wide features (X read once per direction, the 40 MB "
                          "aggregate A X never exists; value of gae.py:26-31 up to fp32 rounding); reference = "
                          "act((A X) W^T + b) in the reference's order (the F_in-wide SpMM is then the dominant launch)")
+    ap.add_argument("--degrees", choices=["uniform", "planetoid"], default="uniform",
+                    help="citation workloads, the synthetic graph's degree sequence: uniform = pairs sampled uniformly "
+                         "(longest row ~ 16; every round's headline), planetoid = heavy-tailed with the real graph's "
+                         "longest row (hubs of 100 - 170 neighbours: workloads.citation_graph)")
     ap.add_argument("--features", choices=["auto", "dense", "sparse"], default="auto",
                     help="citation workloads, the constant input features X: dense = as the reference holds them, a dense "
                          "FloatTensor (gae_xw_fwd / gae_xw_wgrad stream it once per direction); sparse = compressed once at "
@@ -310,7 +314,7 @@ class CitationWorkload:
         import gae_dgl_amd as G
         from gae_dgl_amd import ops, workloads as W
         self.args, self.dev = args, dev
-        n, src, dst, X = W.citation_graph(name, seed=0)
+        n, src, dst, X = W.citation_graph(name, seed=0, degrees=getattr(args, "degrees", "uniform"))
         self.n, self.src, self.dst, self.X = n, src, dst, X
         self.F_in, self.hidden = X.shape[1], [32, 16]
         torch.manual_seed(0)
@@ -328,7 +332,8 @@ class CitationWorkload:
         self.g.csr(); self.g.csc(); self.g.spmm_plan(False); self.g.spmm_plan(True); self.g.scattered()   # static
         E = self.g.number_of_edges()
         self.edges_per_step = E * (2 * len(self.hidden) - 1)                   # L fwd + (L-1) bwd SpMM launches
-        self.meta = {"workload": f"{name}-transductive-gae", "n_nodes": n, "n_edges": E, "in_dim": self.F_in,
+        self.meta = {"workload": f"{name}-transductive-gae" + ("" if getattr(args, "degrees", "uniform") == "uniform" else "[planetoid degrees]"),
+                     "longest_row": int(np.bincount(dst, minlength=n).max()), "n_nodes": n, "n_edges": E, "in_dim": self.F_in,
                      "hidden_dims": self.hidden, "norm": "none", "loss": args.loss + "-bce",
                      "optimizer": "adam lr=1e-2: " + opt_name, "parallelism": "1 GPU",
                      "launch": "hipGraph replay of the captured step" if self.use_graph else "eager",
@@ -855,8 +860,15 @@ def extra_steps(args, dev):
     out = {}
     base = argparse.Namespace(**vars(args))
     base.steps, base.warmup = 20, 5
+    def hubbed(name):
+        def make(a):
+            a.degrees = "planetoid"        # the real graph's hubs (100 - 170 neighbours): what a user's data looks like
+            return CitationWorkload(name, a, dev)
+        return make
     jobs = [("cora", lambda a: CitationWorkload("cora", a, dev), None),
             ("citeseer", lambda a: CitationWorkload("citeseer", a, dev), None),
+            ("pubmed_planetoid_degrees", hubbed("pubmed"), None),
+            ("cora_planetoid_degrees", hubbed("cora"), None),
             ("vgae", lambda a: VgaeWorkload(a, dev), None),
             ("zinc128", lambda a: ZincWorkload(a, dev), 128),
             ("zinc4096", lambda a: ZincWorkload(a, dev), 4096)]
@@ -876,7 +888,8 @@ def extra_steps(args, dev):
         el = float(np.median(regions)) / a.steps
         dom_fn = wl.dominant_launch()
         t_dom = time_launches(dom_fn, iters=50, warmup=30)
-        r = {"workload": wl.meta["workload"], "ms_per_step": el * 1e3, "value": wl.edges_per_step / el, "unit": "edges/s",
+        r = {"workload": wl.meta["workload"], **({"longest_row": wl.meta["longest_row"]} if "longest_row" in wl.meta else {}),
+             "ms_per_step": el * 1e3, "value": wl.edges_per_step / el, "unit": "edges/s",
              "launch": wl.meta.get("launch"), "timing": {"regions": len(regions), "steps_per_region": a.steps},
              "dominant": {"kernel": wl.dominant_desc, "avg_launch_us": t_dom * 1e6, "alg_bytes_per_launch": wl.alg_bytes,
                           **({"note": "a launch on the non-zeros moves 1-3 MB: it is bound by its chain of dependent round trips "

@@ -1170,9 +1170,16 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
         for (int q = 0; q < VEC; ++q) { acc_in[q] = acc_out[q] = 0.f; zi[q] = t[q]; }
     }
     int32_t posA = rowv ? indptr[i] : 0;
-    const int32_t endA = rowv ? indptr[i + 1] : 0;
+    int32_t endA = rowv ? indptr[i + 1] : 0;
     int32_t posB = (WITH_GRAD && rowv) ? t_indptr[i] : 0;
-    const int32_t endB = (WITH_GRAD && rowv) ? t_indptr[i + 1] : 0;
+    int32_t endB = (WITH_GRAD && rowv) ? t_indptr[i + 1] : 0;
+    // rows with more than kLongRow edges in a list (the hubs of the real citation graphs: 100 - 170) are left out of the
+    // lane group's own walk below -- 8 edges per pair of round trips: a 156-edge row held its block for 40 us -- and
+    // taken by the whole wave afterwards, one row at a time
+    constexpr int kLongRow = 16;
+    const bool is_long = max(endA - posA, endB - posB) > kLongRow;
+    const int32_t longA0 = posA, longA1 = endA, longB0 = posB, longB1 = endB;
+    if (is_long) { endA = posA; endB = posB; }
     f32x4 osum = zero4;
     if (WITH_GRAD && rowv && fv) {
         const float *op = O_partial + i * DP + f0;
@@ -1259,6 +1266,81 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
         }
         posA = min(posA + NE, endA);
         posB = min(posB + NE, endB);
+    }
+    // ---- long rows: CH edges of each list per trip (ids: one coalesced load per list), lane group g takes ids g,
+    //      g + G, ... -- up to 4 of each list, 8 rows of Zt in flight per lane --, its shares of the two sums meet in a
+    //      butterfly over the lane bits above the group; the loss terms stay where they were computed (lsum is summed
+    //      over the wave below anyway).  Same terms as the walk above, added in another order.
+    {
+        // (requesting the first long row's first ids in front of the short rows' walk: measured, no gain)
+        constexpr int G = 64 / LPR, CU = LPR < 4 ? LPR : 4, CH = CU * G;      // CH <= 64: one id per lane
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(is_long && lig == 0);
+        const int grp = lane / LPR;
+        while (todo != 0) {                                            // scalar
+            const int hl = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int32_t eA = __builtin_amdgcn_readlane(longA1, hl), eB = __builtin_amdgcn_readlane(longB1, hl);
+            int32_t a0 = __builtin_amdgcn_readlane(longA0, hl), b0 = __builtin_amdgcn_readlane(longB0, hl);
+            float zr[VEC], pin[VEC], pout[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                zr[q] = __shfl(zi[q], hl + lig, 64);
+                pin[q] = pout[q] = 0.f;
+            }
+            for (; a0 < eA || b0 < eB; a0 += CH, b0 += CH) {
+                const int32_t idA = (lane < CH && a0 + lane < eA) ? indices[a0 + lane] : 0;
+                const int32_t idB = (WITH_GRAD && lane < CH && b0 + lane < eB) ? t_indices[b0 + lane] : 0;
+                float zj[2 * CU][VEC], dot[2 * CU];
+#pragma unroll
+                for (int u = 0; u < 2 * CU; ++u) {
+                    const bool second = u >= CU;
+                    dot[u] = 0.f;
+                    if (second && !WITH_GRAD) continue;
+                    const int slot = grp + G * (u % CU);
+                    const int32_t j = __shfl(second ? idB : idA, slot, 64);
+                    const bool ev = (second ? b0 : a0) + slot < (second ? eB : eA);
+                    const f32x4 t = (ev && fv) ? *reinterpret_cast<const f32x4 *>(Zt + int64_t(j) * DP + f0) : zero4;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        zj[u][q] = t[q];
+                        dot[u] = fmaf(zr[q], t[q], dot[u]);
+                    }
+                }
+#pragma unroll
+                for (int off = LPR / 2; off > 0; off >>= 1)
+#pragma unroll
+                    for (int u = 0; u < (WITH_GRAD ? 2 * CU : CU); ++u) dot[u] += __shfl_xor(dot[u], off, 64);
+#pragma unroll
+                for (int u = 0; u < (WITH_GRAD ? 2 * CU : CU); ++u) {
+                    const bool second = u >= CU;
+                    const int slot = grp + G * (u % CU);
+                    if ((second ? b0 : a0) + slot < (second ? eB : eA)) {
+                        const float x = dot[u];
+                        float spn, sgn;
+                        softplus_sigmoid(-x, spn, sgn);
+                        const float sg = 1.0f - sgn;
+                        if (!second && lig == 0) lsum += double(-x + (pw - 1.0f) * spn);
+                        const float c = (pw - 1.0f) * sg - pw;
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            if (second) pout[q] = fmaf(c, zj[u][q], pout[q]);
+                            else pin[q] = fmaf(c, zj[u][q], pin[q]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    pin[q] += __shfl_xor(pin[q], off, 64);
+                    if (WITH_GRAD) pout[q] += __shfl_xor(pout[q], off, 64);
+                }
+            if ((lane & ~(LPR - 1)) == hl) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) { acc_in[q] += pin[q]; acc_out[q] += pout[q]; }
+            }
+        }
     }
     if (WITH_GRAD && rowv) {
 #pragma unroll

@@ -298,6 +298,77 @@ __device__ __forceinline__ void ell_batch(__amdgpu_buffer_rsrc_t rs_h, __amdgpu_
     }
 }
 
+// Edges [c0, e1) of a row (those behind its table slots), gathered by the whole wave: 64 column ids per coalesced load (the next 64
+// requested before the rows of these are), lane group g of the 64 / LPR takes ids g, g + G, ... of the chunk -- up to
+// 8 rows of H in flight per lane --, the groups' partial sums meet in a butterfly over the lane bits above the group.
+// Every lane returns the row's sum for ITS 16-byte vector (lanes that are not `live` return zeros).  The order of the
+// additions differs from the CSR order of the table slots: a long row's sum agrees with the oracle's to rounding,
+// not to the bit.
+template <typename T, int LPR, bool SCALED, int MODE, typename Args>
+__device__ __forceinline__ void ell_long_row(const Args &a, __amdgpu_buffer_rsrc_t rs_h, __amdgpu_buffer_rsrc_t rs_c,
+                                             __amdgpu_buffer_rsrc_t rs_m, int c0, int e1, int lane, unsigned lane_off,
+                                             bool live, float (&part)[Vec16<T>::NV])
+{
+    constexpr int NV = Vec16<T>::NV, G = 64 / LPR, U = LPR;   // U ids of a chunk per group
+    constexpr int UB = U < 8 ? U : 8;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) part[i] = 0.f;
+    const int gi = lane / LPR;
+    // (requesting the first 64 ids in front of the slot batches -- the row's edge range loaded next to its table row --
+    //  was measured: no gain, Pubmed with hubs 0.2253 -> 0.2279 ms per step)
+    int32_t ids = (c0 + lane < e1) ? a.indices[c0 + lane] : -1;
+    while (c0 < e1) {
+        const int cnt = min(64, e1 - c0);                                  // scalar
+        const int32_t cur = ids;
+        if (c0 + 64 < e1) ids = (c0 + 64 + lane < e1) ? a.indices[c0 + 64 + lane] : -1;
+#pragma unroll
+        for (int u0 = 0; u0 < U; u0 += UB) {
+            if (u0 * G < cnt) {                                            // scalar
+                unsigned vo[UB], co[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int32_t j = __shfl(cur, gi + (u0 + u) * G);
+                    vo[u] = unsigned(j) < a.n_cols ? unsigned(j) * a.ldh_bytes + lane_off : a.empty_off;
+                    co[u] = min(unsigned(j), a.n_cols) * 4u;
+                }
+                if (live) {
+                    u32x4 raw[UB], msk[MODE == 1 ? UB : 1];
+                    float cs[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        raw[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_h, vo[u], 0, 0);
+                        if (MODE == 1) msk[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, vo[u], 0, 0);
+                        if (SCALED) cs[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, co[u], 0, 0));
+                    }
+                    if constexpr (MODE == 2) {
+                        for (int sp = 1; sp < a.n_splits; ++sp) {
+#pragma unroll
+                            for (int u = 0; u < UB; ++u) {
+                                const u32x4 more = __builtin_amdgcn_raw_buffer_load_b128(
+                                    rs_h, vo[u] + unsigned(sp) * a.split_bytes, 0, 0);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    raw[u][i] = __float_as_uint(__uint_as_float(raw[u][i]) + __uint_as_float(more[i]));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        if (MODE == 1) raw[u] = relu_gate(raw[u], msk[u]);
+                        if (SCALED) Vec16<T>::fma(part, raw[u], cs[u]);
+                        else Vec16<T>::add(part, raw[u]);
+                    }
+                }
+            }
+        }
+        c0 += 64;
+    }
+#pragma unroll
+    for (int sft = LPR; sft < 64; sft <<= 1)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) part[i] += __shfl_xor(part[i], sft);
+}
+
 // One wave = 64 / LPR lane groups x RPG rows of one feature tile.  (A persistent variant -- waves looping over
 // their items with the next item's table rows prefetched -- was measured and is 10 % SLOWER on every shape: the
 // stores of item i sit in front of the gathers of item i + 1 in the wave's in-order memory queue.)
@@ -541,31 +612,25 @@ __global__ __launch_bounds__(256) void spmm_ell_kernel(const EllArgs a)
     GAE_ELL_BATCH(3 * NB)
 #undef GAE_ELL_BATCH
 slots_done:
-    // ---- rare: rows longer than the table continue from the CSR arrays (same order: slots 0 .. W-2 came first)
+    // ---- rows longer than the table continue from the CSR arrays, the WHOLE WAVE on one such row at a time
+    //      (ell_long_row): the real citation graphs have hubs of 100 - 170 neighbours
 #pragma unroll
     for (int r = 0; r < RPG; ++r) {
         const int holder0 = lane & ~(LPR - 1);                            // lane holding slot 0 of this group
-        const int holderL = holder0 + ((W - 1) % LP16);                   // ... and slot W - 1 (first DPP row of the group)
         if ((skipm[r] >> holder0) & 1ull) row[r] = a.n_rows;              // heavy row: not produced here
-        if (ovfm[r] != 0) {                                               // scalar test first: almost never taken
-            if (((ovfm[r] >> holderL) & 1ull) && row[r] < a.n_rows && live) {
-                const int32_t e1 = a.indptr[row[r] + 1];
-                for (int32_t e = a.indptr[row[r]] + (W - 1); e < e1; ++e) {
-                    const unsigned j = unsigned(a.indices[e]);
-                    u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_h, j * a.ldh_bytes + lane_off, 0, 0);
-                    if constexpr (MODE == 2)
-                        for (int sp = 1; sp < a.n_splits; ++sp) {
-                            const u32x4 more = __builtin_amdgcn_raw_buffer_load_b128(
-                                rs_h, j * a.ldh_bytes + lane_off + unsigned(sp) * a.split_bytes, 0, 0);
+        // one bit per lane group whose row continues (the lane of its first DPP row that holds slot W - 1)
+        unsigned long long todo = ovfm[r] & holder_mask<LPR, (W - 1) % LP16>();
+        while (todo != 0) {                                               // scalar: almost never entered
+            const int hl = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int g0 = hl & ~(LPR - 1);
+            const int rw = __builtin_amdgcn_readlane(int(row[r]), g0);    // (tables exist for < 2^31 rows)
+            float part[NV];
+            ell_long_row<T, LPR, SCALED, MODE>(a, rs_h, rs_c, rs_m, a.indptr[rw] + (W - 1), a.indptr[rw + 1], lane, lane_off,
+                                               live, part);
+            if ((lane & ~(LPR - 1)) == g0) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                raw[i] = __float_as_uint(__uint_as_float(raw[i]) + __uint_as_float(more[i]));
-                        }
-                    if (MASKED)
-                        raw = relu_gate(raw, __builtin_amdgcn_raw_buffer_load_b128(rs_m, j * a.ldh_bytes + lane_off, 0, 0));
-                    if (SCALED) Vec16<T>::fma(acc[r], raw, a.col_scale[j]);
-                    else Vec16<T>::add(acc[r], raw);
-                }
+                for (int i = 0; i < NV; ++i) acc[r][i] += part[i];
             }
         }
     }

@@ -533,6 +533,11 @@ profiler = None  # set to an EventProfiler to time launches
 SKEW_THRESHOLD = 8       # rows with more in-edges than this go through the segment kernels
 SKEW_SEGMENT = 512       # edges per segment (multiple of 64; RMAT s24: 256 -> 6.81 ms, 512 -> 6.65, 1024 -> 6.59)
 SKEW_MIN_MAXDEG = 64     # graphs whose longest row is shorter need no plan (3 extra launches would not pay)
+# ... and graphs small enough for a packed neighbour table (ELL_MAX_ROWS) none up to this row length: the table kernels
+# take a row that outgrows its 16 slots with the whole wave (spmm_ell.hip: ell_long_row; 64 column ids per load, 8 rows
+# in flight per lane), the fused loss's edge kernel likewise -- the real Planetoid graphs (longest rows 168 / 99 / 171)
+# run the same launches as the uniform synthetic ones (tools/r05/hubs.sh: step + 7 .. 12 %).  GAE_TABLE_MAXDEG overrides.
+TABLE_MAX_ROW = int(os.environ.get("GAE_TABLE_MAXDEG", 1024))
 
 
 TILE_MIN_F = 64          # XCD feature tiles are only considered for rows wider than one lane group (16 vectors)
@@ -645,7 +650,7 @@ def column_home(cols):
 def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_width=None, hot=None, n_cols=None, homed=None):
     """Build the plan of a CSR on the device (gae_spmm_plan_sizes / _build_rows / _build_pinned; no torch kernels), or
     None when it needs none.  Skew part: with the default threshold only for graphs whose longest row has more than
-    SKEW_MIN_MAXDEG edges.  Packed neighbour table: when ``indices`` is given and the graph has at most ELL_MAX_ROWS
+    SKEW_MIN_MAXDEG edges (TABLE_MAX_ROW for graphs that get a packed neighbour table).  Packed neighbour table: when ``indices`` is given and the graph has at most ELL_MAX_ROWS
     rows (``ell`` = True / False overrides); ``ell_width`` 4 / 8 / 16 slots per row, default: the narrowest that holds
     the longest light row.  ``hot`` (default: skew plans of graphs with at least HOT_MIN_EDGES edges when ``indices``
     is given; ``n_cols`` = columns of the CSR, default: its rows): the mid rows read a compact copy of their column
@@ -670,7 +675,7 @@ def spmm_plan(indptr, threshold=None, segment=None, indices=None, ell=None, ell_
         t2 = max(HOMED_MIN_DEGREE, threshold) if (indices is not None and homed is not False) else INT32_MAX
         _lib.call("gae_spmm_plan_sizes", _ptr(indptr), n, threshold, t2, segment, sizes, _ptr(tiny), tiny.numel(), _stream())
         nl, nm, sm, em, npin, epin, max_deg = (int(sizes[k]) for k in range(7))
-        heavy = (nm + npin) > 0 and not (auto and max_deg <= SKEW_MIN_MAXDEG)
+        heavy = (nm + npin) > 0 and not (auto and max_deg <= (TABLE_MAX_ROW if want_ell else SKEW_MIN_MAXDEG))
         if not heavy and not want_ell:
             return None
         pin = heavy and npin > 0 and t2 != INT32_MAX and (bool(homed) or epin >= HOMED_MIN_EDGES)

@@ -72,8 +72,8 @@ class SparseFeatures:
         """``X`` itself, or its compressed form when layer 1 runs faster from the non-zeros (one count pass over X; the
         compression only if it pays).  For features that stay CONSTANT across the steps that use the result.
         ``graph``: the graph the features will be set on -- the kernels on the non-zeros need plans that carry only a
-        packed neighbour table (ops.sparse_input_usable: no row longer than ops.SKEW_MIN_MAXDEG, e.g. NOT the real
-        Planetoid graphs with hubs of 100-170 neighbours); on any other graph the layer would densify the features
+        packed neighbour table (ops.sparse_input_usable: at most ops.ELL_MAX_ROWS rows, none longer than
+        ops.TABLE_MAX_ROW -- the real Planetoid graphs with their hubs of 100-170 neighbours qualify); on any other graph the layer would densify the features
         again in every step, so X stays dense."""
         X = ops._gpu(X, "X")
         if X.dtype != torch.float32 or X.dim() != 2 or f_out > 32 or X.shape[1] < 193 or X.shape[0] == 0:

@@ -12,13 +12,55 @@ CITATION = {  # N, E (directed, symmetric), F
 }
 
 
-def citation_graph(name, seed=0):
-    """E/2 undirected pairs sampled uniformly, mirrored, no self-loops; X =
-    sparse non-negative rows normalised to sum 1 (as DGL's citation loader)."""
+PLANETOID_MAX_DEGREE = {"cora": 168, "citeseer": 99, "pubmed": 171}     # longest rows of the real Planetoid graphs
+
+
+def _planetoid_pairs(n, half, dmax, rng):
+    """``half`` undirected pairs whose degree sequence is heavy-tailed like the real citation graphs': degrees drawn
+    from P(d) ~ (d + d0)^-3.5 on 1 .. dmax (d0 fitted to the mean degree: about 40 % of the nodes have one neighbour,
+    0.1 - 0.2 % more than 64 -- Cora's real graph: 168, 78, 74, 65 ...), the largest forced to dmax, stubs paired at
+    random (configuration model); self-pairs and repeated pairs are redrawn uniformly."""
+    d = np.arange(1, dmax + 1, dtype=np.float64)
+    target = 2.0 * half / n
+    lo, hi = -0.99, 50.0
+    for _ in range(60):                                   # the mean degree grows with the shift
+        d0 = 0.5 * (lo + hi)
+        w = (d + d0) ** -3.5
+        lo, hi = (d0, hi) if (w * d).sum() / w.sum() < target else (lo, d0)
+    w = (d + d0) ** -3.5
+    deg = rng.choice(np.arange(1, dmax + 1), size=n, p=w / w.sum())
+    deg[rng.integers(0, n)] = dmax
+    stubs = np.repeat(np.arange(n), deg)
+    rng.shuffle(stubs)
+    m = min(half, stubs.size // 2)
+    a, b = stubs[:m].copy(), stubs[m:2 * m].copy()
+    if m < half:                                          # (the draw came out short: the rest uniformly)
+        a = np.concatenate([a, rng.integers(0, n, half - m)]); b = np.concatenate([b, rng.integers(0, n, half - m)])
+    for _ in range(8):
+        key = np.minimum(a, b) * n + np.maximum(a, b)
+        _, first = np.unique(key, return_index=True)
+        bad = np.ones(half, bool); bad[first] = False
+        bad |= a == b
+        if not bad.any():
+            break
+        a[bad] = rng.integers(0, n, int(bad.sum())); b[bad] = rng.integers(0, n, int(bad.sum()))
+    return a, b
+
+
+def citation_graph(name, seed=0, degrees="uniform"):
+    """E/2 undirected pairs, mirrored, no self-loops; X = sparse non-negative rows normalised to sum 1 (as DGL's
+    citation loader).  ``degrees``: "uniform" (pairs sampled uniformly: longest row ~ 20) or "planetoid" (heavy-tailed
+    degree sequence with the real graph's longest row: a few hubs of 100 - 170 neighbours)."""
     n, e, f = CITATION[name]
     rng = np.random.default_rng(seed)
     half = e // 2
-    a = rng.integers(0, n, half); b = rng.integers(0, n, half)
+    if degrees == "planetoid":
+        a, b = _planetoid_pairs(n, half, PLANETOID_MAX_DEGREE[name], np.random.default_rng(seed + 7919))
+        rng.integers(0, n, half); rng.integers(0, n, half)              # (X below: the same draws as "uniform")
+    else:
+        if degrees != "uniform":
+            raise ValueError(f"degrees: 'uniform' or 'planetoid', not {degrees!r}")
+        a = rng.integers(0, n, half); b = rng.integers(0, n, half)
     same = a == b
     b[same] = (b[same] + 1 + rng.integers(0, n - 1, int(same.sum()))) % n
     src = np.concatenate([a, b]); dst = np.concatenate([b, a])

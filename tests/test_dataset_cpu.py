@@ -50,3 +50,30 @@ def test_reference_checkpoint_file_fixture():
                         "layers.1.apply_mod.linear.weight", "layers.1.apply_mod.linear.bias"]
     for k, v in sd.items():
         assert v.dtype == torch.float32 and np.array_equal(v.numpy(), g["sd/" + k])
+
+
+def test_citation_graph_degree_profiles():
+    """workloads.citation_graph: the published N / E / F either way; "planetoid" has the real graphs' hubs (longest row
+    close to the published maximum, a heavy tail of rows beyond the 16-slot packed table), "uniform" has none; both are
+    symmetric, without self-loops, and reproducible from the seed"""
+    import numpy as np
+    from gae_dgl_amd import workloads as W
+    for name, (n, e, f) in W.CITATION.items():
+        for degrees in ("uniform", "planetoid"):
+            n2, src, dst, X = W.citation_graph(name, seed=0, degrees=degrees)
+            assert n2 == n and src.size == e == dst.size and X.shape == (n, f)
+            assert (src != dst).all()
+            half = e // 2
+            assert np.array_equal(src[:half], dst[half:2 * half]) and np.array_equal(dst[:half], src[half:2 * half])
+            deg = np.bincount(dst, minlength=n)
+            if degrees == "uniform":
+                assert deg.max() <= 24
+            else:
+                dmax = W.PLANETOID_MAX_DEGREE[name]
+                assert 0.85 * dmax <= deg.max() <= dmax + 8
+                assert 0.005 * n < (deg > 16).sum() < 0.06 * n and (deg == 1).sum() > 0.25 * n
+            again = W.citation_graph(name, seed=0, degrees=degrees)
+            assert np.array_equal(again[1], src) and np.array_equal(again[2], dst) and np.array_equal(again[3], X)
+    import pytest
+    with pytest.raises(ValueError):
+        W.citation_graph("cora", degrees="zipf")

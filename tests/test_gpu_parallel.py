@@ -254,8 +254,8 @@ def test_one_rank_rccl_group_end_to_end():
         ref = model.reconstruction_loss(g)
         ref.backward()
         assert abs(float(loss.detach()) - float(ref.detach())) < 1e-6 * abs(float(ref.detach()))
-        for a, p in zip(g1, model.parameters()):
-            assert float((a - p.grad).abs().max()) <= 1e-6 * float(p.grad.abs().max())
+        for a, p in zip(g1, model.parameters()):      # (fp32 rounding: the plain graph's table kernels add a hub row's
+            assert float((a - p.grad).abs().max()) <= 5e-6 * float(p.grad.abs().max())    # terms in another order)
         # narrowing layers as A (H W^T): aggregation (and its backward, and the exchange) at the output width --
         # the same loss and gradients up to fp32 rounding
         for mode in ("allgather", "boundary"):

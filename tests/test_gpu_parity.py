@@ -172,27 +172,41 @@ def test_spmm_packed_table_bit_identical(F, dtype, dev):
     assert both.ell_width == 8                                            # light rows have at most 8 edges
     assert int(both.ell.view(n, 8)[11, 0]) == -3
     narrow = ops.spmm_plan(dip, indices=dix, ell_width=4)                 # most rows overflow into the CSR arrays
+
+    def same(out, base, width):
+        """bit-identical on the rows that fit the table; a row that outgrows it is gathered by the whole wave (round 5,
+        spmm_ell.hip: ell_long_row): the same terms added in another order"""
+        o, b = out.float().cpu().numpy(), base.float().cpu().numpy()
+        fits = deg <= width
+        assert np.array_equal(o[fits], b[fits])
+        tol = 1e-2 if dtype == torch.bfloat16 else 2e-6
+        assert np.abs(o[~fits] - b[~fits]).max() <= tol * np.abs(b).max()
+
     for scaled in (False, True):
         sc = t(norm, dev) if scaled else None
         base = ops.spmm_raw(dip, dix, Hd, n, sc, sc)
         for rpg in (1, 2):
             _lib.call("gae_tuning_set", b"spmm_rpg", rpg)
             try:
-                out = ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=table)
-                assert torch.equal(out, base)
-                assert torch.equal(ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=narrow), base)
+                same(ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=table), base, W)
+                same(ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=narrow), base, 4)
                 for ell_kernels in (2, 1):        # 2 = row-group kernel reads the table, 1 = spmm_ell.hip kernels
                     _lib.call("gae_tuning_set", b"spmm_ell", ell_kernels)
                     _lib.call("gae_tuning_set", b"spmm_ell_rpg", rpg)
-                    assert torch.equal(ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=table), base)
+                    out = ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=table)
+                    if ell_kernels == 2:
+                        assert torch.equal(out, base)             # (CSR order throughout)
+                    else:
+                        same(out, base, W)
                 _lib.call("gae_tuning_set", b"spmm_ell_rpg", 0)
                 heavy = ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=ops.spmm_plan(dip, threshold=8, segment=64))
                 assert torch.equal(ops.spmm_raw(dip, dix, Hd, n, sc, sc, plan=both), heavy)
             finally:
                 _lib.call("gae_tuning_set", b"spmm_rpg", 0)
+                _lib.call("gae_tuning_set", b"spmm_ell", 1)
     if dtype == torch.float32:
         from oracle import c_oracle
-        assert np.array_equal(ops.spmm_raw(dip, dix, Hd, n, plan=table).cpu().numpy(), c_oracle.spmm_csr(ip, ix, H))
+        same(ops.spmm_raw(dip, dix, Hd, n, plan=table), torch.from_numpy(c_oracle.spmm_csr(ip, ix, H)), W)
 
 
 @pytest.mark.parametrize("F", [100, 500, 1433, 3703])
@@ -210,7 +224,7 @@ def test_spmm_feature_tiles_bit_identical(F, n, dev):
     base = ops.spmm_raw(dip, dix, Hp, n)
     from oracle import c_oracle
     assert np.array_equal(base.cpu().numpy(), c_oracle.spmm_csr(ip, ix, H))
-    plan = ops.spmm_plan(dip, indices=dix)          # hub row -> skew plan (segment sums: own order) + packed table
+    plan = ops.spmm_plan(dip, indices=dix, threshold=ops.SKEW_THRESHOLD)   # hub row -> skew plan (segment sums: own order) + packed table
     assert plan.n_heavy > 0 and plan.ell is not None
     planned = ops.spmm_raw(dip, dix, Hp, n, plan=plan)
     assert rel_err(planned, base.double().cpu()) < TOL
@@ -391,7 +405,8 @@ def test_spmm_baseline_full_sizes(dev):
 def test_spmm_dispatch_fuzz(seed, dev):
     """random (graph, width, leading dimension, dtype, scales, plan / packed table / feature tiles / rows-per-group /
     store-pad) combinations: every dispatch branch of gae_spmm_csr gives the CSR-order sums -- bit-identical to the
-    C oracle for un-normalised fp32, bit-identical across the variants otherwise"""
+    C oracle for un-normalised fp32, bit-identical across the variants otherwise (rows that outgrow a packed table: to
+    rounding, the table kernels gather them with the whole wave)"""
     from gae_dgl_amd import ops, _lib
     from oracle import c_oracle
     rng = np.random.default_rng(1000 + seed)
@@ -436,7 +451,14 @@ def test_spmm_dispatch_fuzz(seed, dev):
         finally:
             _lib.call("gae_tuning_set", b"spmm_rpg", 0); _lib.call("gae_tuning_set", b"spmm_tile_vecs", 0)
             _lib.call("gae_tuning_set", b"spmm_ell_rpg", 0); _lib.call("gae_tuning_set", b"spmm_ell", 1)
-        assert torch.equal(got, base), (n, e, F, dtype, scaled, pad_mode, rpg, tv, use_table, scattered)
+        what = (n, e, F, dtype, scaled, pad_mode, rpg, tv, use_table, scattered)
+        if use_table:      # rows beyond the table: gathered by the whole wave in the table kernels, same terms, other order
+            fits = t(np.diff(ip) <= table.ell_width, dev)
+            assert torch.equal(got[fits], base[fits]), what
+            assert float((got.float() - base.float()).abs().max()) <= (2e-6 if dtype == torch.float32 else 1e-2) * \
+                max(float(base.float().abs().max()), 1e-30), what
+        else:
+            assert torch.equal(got, base), what
     if heavy is not None and F > 12:                  # segment sums have their own (fixed) order: tolerance, stable
         a = ops.spmm_raw(dip, dix, Hd, n, norm, norm, plan=heavy)
         assert rel_err(a.float(), base.float().double().cpu()) < (TOL if dtype == torch.float32 else 2e-2)

@@ -287,14 +287,17 @@ def _planetoid_like(n=2708, K=1433, hub_deg=168, seed=0):
     return n, np.concatenate([a, b]), np.concatenate([b, a]), X
 
 
-def test_train_transductive_default_flags_on_a_graph_with_hubs(tmp_path):
-    """real Cora / Citeseer have rows of 168 / 99 neighbours, so their plans carry heavy rows and
-    the kernels on the non-zeros of X do not apply.  `--features auto` must then keep X dense (decided per graph), the
-    default captured step must run, and its losses equal those of `--features dense --no_hipgraph`."""
+@pytest.mark.parametrize("hub_deg", [168, 1500])
+def test_train_transductive_default_flags_on_a_graph_with_hubs(tmp_path, hub_deg):
+    """real Cora / Citeseer have rows of 168 / 99 neighbours.  Round 5: the packed-table kernels take
+    such rows with the whole wave, so their plans stay table-only (ops.TABLE_MAX_ROW) and `--features auto` may compress
+    X; a graph with a hub beyond that (1500) gets a skew plan with heavy rows, the kernels on the non-zeros of X do not
+    apply and `--features auto` must keep X dense (decided per graph).  Either way the default captured step must run,
+    and its losses equal those of `--features dense --no_hipgraph`."""
     import os
     import gae_dgl_amd as G
     from gae_dgl_amd import ops, train_transductive as TT
-    n, src, dst, X = _planetoid_like()
+    n, src, dst, X = _planetoid_like(hub_deg=hub_deg)
     os.makedirs(tmp_path / "data", exist_ok=True)
     np.savez(tmp_path / "data" / "cora.npz", src=src, dst=dst, features=X, n=n)
     common = ["--dataset", "cora", "--data_root", str(tmp_path / "data"), "-e", "6", "-s", str(tmp_path), "--seed", "0",
@@ -307,8 +310,13 @@ def test_train_transductive_default_flags_on_a_graph_with_hubs(tmp_path):
     dev = torch.device("cuda:0")
     g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
     Xd = ops.pad_rows(torch.from_numpy(X).to(dev))
-    assert not ops.sparse_input_usable(g, n, X.shape[1], 32)
-    assert G.SparseFeatures.maybe_from_dense(Xd, 32, graph=g) is Xd
+    table_only = hub_deg <= ops.TABLE_MAX_ROW
+    assert ops.sparse_input_usable(g, n, X.shape[1], 32) == table_only
+    assert ops.gcn_transform_first_usable(g, Xd, 32) == table_only
+    assert (g.spmm_plan(False).n_heavy == 0) == table_only
+    assert isinstance(G.SparseFeatures.maybe_from_dense(Xd, 32, graph=g), G.SparseFeatures) == table_only
+    if not table_only:
+        assert G.SparseFeatures.maybe_from_dense(Xd, 32, graph=g) is Xd
     assert isinstance(G.SparseFeatures.maybe_from_dense(Xd, 32), G.SparseFeatures)      # (no graph given: X alone decides)
     sf = G.SparseFeatures.from_dense(Xd)
     from gae_dgl_amd.capture import CapturedTrainStep
@@ -332,8 +340,9 @@ def test_train_transductive_default_flags_on_a_graph_with_hubs(tmp_path):
             out += [eager_epoch(), eager_epoch()]
         return out
     got = run(sf, True)
-    d0 = sf.to_dense()
-    assert sf.to_dense() is d0 and d0.stride(0) % 4 == 0            # one cached, row-padded dense copy
+    if not table_only:
+        d0 = sf.to_dense(cache=True)
+        assert sf.to_dense() is d0 and d0.stride(0) % 4 == 0        # one cached, row-padded dense copy
     np.testing.assert_allclose(got, run(Xd, False), rtol=1e-5)
 
 

@@ -100,7 +100,8 @@ def test_xw_wgrad_matches_fp64(n, K, J, dtype, tuning):
 @pytest.mark.parametrize("norm", [False, True])
 def test_spmm_epilogue_bias_act_and_gate(F, norm):
     """gae_spmm_csr_epilogue: act(rs A cs H + b) equals the plain product followed by bias / ReLU bit for bit, and the
-    gated gather equals the plain product of the pre-gated operand bit for bit (CSR-order sums in both)"""
+    gated gather equals the plain product of the pre-gated operand bit for bit on every row that fits the table
+    (CSR-order sums in both), to rounding on the longer ones"""
     import gae_dgl_amd as G
     from gae_dgl_amd import ops
     rng = np.random.default_rng(F)
@@ -114,14 +115,23 @@ def test_spmm_epilogue_bias_act_and_gate(F, norm):
     ip, ix = gr.csr()
     tp, tx = gr.csc()
     nv = gr.norm() if norm else None
+    def same(a, b, indptr, plan, long_row=None):
+        """bit for bit on the rows that fit the packed table; a row that outgrows it is gathered by the whole wave in
+        the table kernels (round 5) -- the same terms in another order than the row-group kernel's, which spmm_raw
+        falls back to for narrow F: to rounding there"""
+        fits = (indptr[1:] - indptr[:-1]) <= plan.ell_width
+        assert int((~fits).sum()) < 60 and (long_row is None or not bool(fits[long_row]))
+        assert torch.equal(a[fits], b[fits])
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
     plain = ops.spmm_raw(ip, ix, ops.pad_rows(H), n, nv, nv, plan=gr.spmm_plan(False))
     out = ops.spmm_epilogue_raw(ip, ix, H, n, gr.spmm_plan(False), b, 1, None, nv, nv)
-    assert torch.equal(out, torch.relu(plain + b))
+    same(out, torch.relu(plain + b), ip, gr.spmm_plan(False))
     out = ops.spmm_epilogue_raw(ip, ix, H, n, gr.spmm_plan(False), None, 0, None, nv, nv)
-    assert torch.equal(out, plain)
+    same(out, plain, ip, gr.spmm_plan(False))
     gated = ops.spmm_epilogue_raw(tp, tx, H, n, gr.spmm_plan(True), None, 0, Y, nv, nv)
     ref = ops.spmm_raw(tp, tx, ops.pad_rows(H * (Y > 0)), n, nv, nv, plan=gr.spmm_plan(True))
-    assert torch.equal(gated, ref)
+    same(gated, ref, tp, gr.spmm_plan(True), long_row=5)
 
 
 @pytest.mark.parametrize("hidden,F_in", [([32, 16], 300), ([24], 260), ([32, 20, 8], 500)])
