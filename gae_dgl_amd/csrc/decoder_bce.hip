@@ -1169,6 +1169,15 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
 #pragma unroll
         for (int q = 0; q < VEC; ++q) { acc_in[q] = acc_out[q] = 0.f; zi[q] = t[q]; }
     }
+    // ... and what the LAST lines of the kernel need (the column sums' share of dZ, the dropout multipliers): asked for
+    // there, inside `if (f < d)`, they came out as eight dependent round trips at the end of every wave
+    float sall[VEC], mk[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        const bool in = WITH_GRAD && rowv && f0 + q < d;
+        sall[q] = WITH_GRAD ? S_all_f[in ? f0 + q : 0] : 0.f;
+        mk[q] = (WITH_GRAD && mask != nullptr) ? mask[in ? gi * ldz + f0 + q : 0] : 1.f;
+    }
     int32_t posA = rowv ? indptr[i] : 0;
     int32_t endA = rowv ? indptr[i + 1] : 0;
     int32_t posB = (WITH_GRAD && rowv) ? t_indptr[i] : 0;
@@ -1347,9 +1356,9 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
         for (int q = 0; q < VEC; ++q) {
             const int f = f0 + q;
             if (f < d) {
-                const float o = 0.5f * S_all_f[f] + osum[q];
+                const float o = 0.5f * sall[q] + osum[q];
                 float v = (2.0f * o + (acc_in[q] + acc_out[q])) * inv_n2;
-                if (mask) v *= mask[gi * ldz + f];
+                if (mask) v *= mk[q];
                 if (i >= n_valid) v = 0.f;                     // padding rows receive no gradient
                 dZ[i * lddz + f] = v;
             }

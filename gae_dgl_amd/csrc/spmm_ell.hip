@@ -340,6 +340,10 @@ __device__ __forceinline__ void ell_long_row(const Args &a, __amdgpu_buffer_rsrc
                         if (MODE == 1) msk[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, vo[u], 0, 0);
                         if (SCALED) cs[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, co[u], 0, 0));
                     }
+                    // (every request above is issued before the first sum below: left alone, the scheduler pulls the
+                    //  additions up between the loads and waits for the first before it issues the second -- three
+                    //  round trips per chunk instead of one)
+                    __builtin_amdgcn_sched_barrier(0);
                     if constexpr (MODE == 2) {
                         for (int sp = 1; sp < a.n_splits; ++sp) {
 #pragma unroll
@@ -625,9 +629,12 @@ slots_done:
             todo &= todo - 1;
             const int g0 = hl & ~(LPR - 1);
             const int rw = __builtin_amdgcn_readlane(int(row[r]), g0);    // (tables exist for < 2^31 rows)
+            // both ends of the row's edge range in ONE round trip (lanes 0 and 1; two scalar loads came out one
+            // behind the other)
+            const int32_t ends = lane < 2 ? a.indptr[rw + lane] : 0;
             float part[NV];
-            ell_long_row<T, LPR, SCALED, MODE>(a, rs_h, rs_c, rs_m, a.indptr[rw] + (W - 1), a.indptr[rw + 1], lane, lane_off,
-                                               live, part);
+            ell_long_row<T, LPR, SCALED, MODE>(a, rs_h, rs_c, rs_m, __builtin_amdgcn_readlane(ends, 0) + (W - 1),
+                                               __builtin_amdgcn_readlane(ends, 1), lane, lane_off, live, part);
             if ((lane & ~(LPR - 1)) == g0) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) acc[r][i] += part[i];

@@ -178,3 +178,41 @@ def test_captured_step_on_a_planetoid_degree_graph_equals_eager_steps():
             out.append(float(loss.detach()))
         return out
     np.testing.assert_allclose(run(True), run(False), rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_vgae_step_on_a_planetoid_degree_graph_matches_oracle(dtype, tol):
+    """the VGAE step (fused mu / log-sigma heads: gae_x_gcn_layer_fused2, sampled decoder, BCE + KL) on the hubbed
+    Citeseer profile, fp32 and bf16-stored features, against the CPU restatement"""
+    import gae_dgl_amd as G
+    from gae_dgl_amd import workloads as W
+    from gae_dgl_amd.vgae import VGAE
+    n, src, dst, X = W.citation_graph("citeseer", seed=0, degrees="planetoid")
+    torch.manual_seed(0)
+    model = VGAE(X.shape[1], [32, 16], seed=11).to(DEV)
+    g = G.DGLGraph((src, dst), num_nodes=n).to(DEV)
+    assert g.spmm_plan(False).n_heavy == 0 and int((g.csr()[0][1:] - g.csr()[0][:-1]).max()) > 64
+    Xd = torch.from_numpy(X).to(DEV).to(dtype)
+    g.ndata['h'] = Xd
+    loss = model.loss(g)
+    loss.backward()
+    last = {k: v.detach().cpu() for k, v in model.last.items()}
+    Xo = Xd.float().cpu()
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    ip, ix = O().csr_from_coo(src, dst, n)
+    mu, ls, z = O().vgae_forward(ip, ix, Xo, P["shared.apply_mod.linear.weight"], P["shared.apply_mod.linear.bias"],
+                                 P["mu_head.apply_mod.linear.weight"], P["mu_head.apply_mod.linear.bias"],
+                                 P["logstd_head.apply_mod.linear.weight"], P["logstd_head.apply_mod.linear.bias"],
+                                 last["eps"])
+    adj = O().dense_adjacency(src, dst, n)
+    rec = O().bce_with_logits_mean(z @ z.t(), adj, O().pos_weight_of(adj))
+    kl = O().vgae_kl(mu, ls)
+    (rec + kl).backward()
+
+    def rel1(a, b):      # (as tests/test_gpu_parity.py: against max(|b|, 1))
+        a = torch.as_tensor(a).detach().double().cpu(); b = torch.as_tensor(b).detach().double().cpu()
+        return float((a - b).abs().max() / b.abs().max().clamp(min=1.0))
+    assert rel1(last["mu"], mu) < tol and rel1(last["logstd"], ls) < tol and rel1(last["z"], z) < tol
+    assert rel1(loss, rec + kl) < max(tol, 1e-5)
+    for k, p in model.named_parameters():
+        assert rel1(p.grad, P[k].grad) < 10 * tol, k
