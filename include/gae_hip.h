@@ -251,7 +251,9 @@ typedef struct gae_spmm_plan {
  * marker -2 in its last slot (the kernel continues from indptr / indices); rows with more than `skip_degree` ids
  * (the plan's threshold when it has heavy rows, else INT32_MAX) hold the marker -3 in slot 0.  With the table ONE
  * load replaces the dependent indptr -> indices chain in front of the gather; short launches are bounded by that
- * chain, not by bytes (Pubmed F = 500: 21 -> 15 us).  Same summation order, bit-identical results.  The table
+ * chain, not by bytes (Pubmed F = 500: 21 -> 15 us).  Rows that fit the table: same summation order, bit-identical
+ * results.  A row that continues from indptr / indices (marker -2) is gathered by the whole wave, 64 ids per trip:
+ * the same terms in another (fixed) order -- equal to the CSR-order sum up to fp32 rounding.  The table
  * costs width * 4 bytes per row of extra traffic: leave plan->ell NULL for graphs of millions of rows. */
 #define GAE_SPMM_ELL_WIDTH 16
 /* bytes of workspace gae_spmm_csr needs with this plan (0 without one) */
@@ -286,7 +288,7 @@ int gae_spmm_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, 
  * packed neighbour table and no heavy rows.  W is addressed as W[o * w_stride_out + k * w_stride_in] (o < J, k < F):
  * (ld, 1) for nn.Linear's [J][F] weight, (1, ld) for its transpose -- the backward of an identity-activation layer
  * is the same launch on the CSR of A^T: dH = (A^T dY) W.  M (may be NULL) receives the aggregate the backward's
- * dW = dY^T M needs.  Sums run in CSR order per row; Y differs from the two-launch chain by fp32 rounding only
+ * dW = dY^T M needs.  Sums run in CSR order per row (rows beyond the table: see the table's note); Y differs from the two-launch chain by fp32 rounding only
  * (the 4 + LPR-lane tree of the epilogue instead of the k-ordered chain of gae_linear_fwd). */
 int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                         const float *H, int64_t ldh, float *M, int64_t ldm, int64_t F,
@@ -314,7 +316,8 @@ int gae_gcn_layer_fused(const int32_t *indptr, const int32_t *indices, int64_t n
  *                 db [f_out] = colsum(D (.) [Dmask > 0])              (db / D / Dmask may be NULL)
  *                 partial sums per (row partition, column slice) are added in partition order: deterministic.
  *   gae_spmm_csr_epilogue: Y = act(rs A cs (H (.) [Hmask > 0]) + bias); Hmask (may be NULL) has the layout of H;
- *                 F <= 64, fp32, a plan with a packed neighbour table and no heavy / XCD-pinned rows; CSR-order sums.
+ *                 F <= 64, fp32, a plan with a packed neighbour table and no heavy / XCD-pinned rows; CSR-order sums
+ *                 (rows beyond the table: the same terms, whole-wave order).
  *                 n_splits > 1: H is the first of n_splits partial matrices split_stride floats apart -- what
  *                 gae_xw_fwd leaves with keep_splits = 1 when it splits a long f_in over thread blocks -- and a gathered
  *                 row is the sum of its partial rows in split order: the value the split reduction would have stored,
