@@ -218,6 +218,32 @@ def bce_with_logits_mean(logits, adj, pos_weight):
     return loss.mean()
 
 
+def mse_mean(logits, adj):
+    """optuna_gae.py:16,21 -- the hyper-parameter search's criterion, ``nn.MSELoss()(model.forward(g),
+    g.adjacency_matrix().to_dense())`` (mean over all N^2 ordered pairs) on the logits GAE.forward returns."""
+    x = torch.as_tensor(logits)
+    y = torch.as_tensor(adj).to(x.dtype)
+    return ((x - y) ** 2).mean()
+
+
+def mse_closed_form(Zt, indptr, indices):
+    """The same number without the N x N matrices (what ops.decoder_mse evaluates on the device):
+        sum_ij (s_ij - a_ij)^2 = ||Zt^T Zt||_F^2 - 2 <Zt, A Zt> + sum_ij a_ij^2,   s = Zt Zt^T,
+    and its gradient  dL/dZt = (2 / N^2) (2 Zt (Zt^T Zt) - A Zt - A^T Zt).  ``indptr`` / ``indices``: CSR of A (rows =
+    destination); duplicate edges count (a_ij = multiplicity).  Returns (loss, dZt) in Zt's dtype."""
+    Zt = torch.as_tensor(Zt)
+    ip = np.asarray(indptr, dtype=np.int64); ix = np.asarray(indices, dtype=np.int64)
+    n = Zt.shape[0]
+    rows = np.repeat(np.arange(n), np.diff(ip))
+    A = torch.zeros(n, n, dtype=Zt.dtype)
+    A.index_put_((torch.as_tensor(rows), torch.as_tensor(ix)), torch.ones(ix.size, dtype=Zt.dtype), accumulate=True)
+    G = Zt.t() @ Zt
+    AZ = A @ Zt
+    loss = ((G * G).sum() - 2 * (Zt * AZ).sum() + (A * A).sum()) / (n * n)
+    dZt = (2.0 / (n * n)) * (2 * Zt @ G - AZ - A.t() @ Zt)
+    return loss, dZt
+
+
 def bce_row_window(Zt, r0, r1, indptr, indices, t_indptr, t_indices, pos_weight):
     """Rows ``[r0, r1)`` of the loss of train_inductive.py:44-48 for graphs whose
     dense N x N label does not fit (ZINC batch of 4096 molecules: 9e9 logits).
