@@ -187,13 +187,22 @@ class GAE(nn.Module):
     def encode(self, g):
         return self._embed(g, write_back=False)
 
-    def reconstruction_loss(self, g):
+    def reconstruction_loss(self, g, criterion="bce"):
         """The training loss of train_inductive.py:44-48 (dense label from g,
         pos_weight, BCE-with-logits mean over all N^2 ordered pairs) evaluated
         by the fused HIP kernel: numerically the same quantity as
         ``BCELoss(self.forward(g), adj, pos_weight)`` without the N x N logits /
-        label matrices.  Side effect on ``g.ndata['h']`` as in forward()."""
+        label matrices.  Side effect on ``g.ndata['h']`` as in forward().
+        ``criterion="mse"``: the hyper-parameter search's ``nn.MSELoss()(self.forward(g), adj)``
+        (optuna_gae.py:16,21), likewise without the N x N matrices (ops.decoder_mse)."""
         z = g.ndata['h']
+        if criterion == "mse":
+            for layer in self.layers:
+                z = layer(g, z)
+            g.ndata['h'] = z
+            return self.decoder.loss_mse(z, g)
+        if criterion != "bce":
+            raise ValueError(f"criterion: 'bce' or 'mse', not {criterion!r}")
         for layer in self.layers[:-1]:
             z = layer(g, z)
         # the last layer may run the loss's prepare step in its epilogue (ops.loss_prepare_request)
@@ -247,6 +256,14 @@ class InnerProductDecoder(nn.Module):
         """the request a producer of Z answers by running this loss's prepare step in its own launch"""
         on_gpu = isinstance(h, torch.Tensor) and h.is_cuda
         return ops.loss_prepare_request(g if on_gpu else None, d, self.mask, self._loss_dropout(h.device) if on_gpu else None)
+
+    def loss_mse(self, z, g):
+        """nn.MSELoss()(self.forward(z), adj) (optuna_gae.py:16,21; identity activation) without the N x N matrices; the
+        dropout mask is drawn as forward() draws it and kept in ``last_mask``"""
+        if not (isinstance(z, torch.Tensor) and z.is_cuda):
+            raise ops.GaeHipError("InnerProductDecoder.loss_mse: the HIP path needs device tensors")
+        self.last_mask = self._draw_mask(z)
+        return ops.decoder_mse(z, self.last_mask, g)
 
     def loss(self, z, g, prepared=None):
         """fused decoder + weighted BCE (identity activation = logits, gae.py:47).  The dropout mask of this call

@@ -229,6 +229,23 @@ class Graph:
         vals = torch.ones(r.numel(), dtype=torch.float32, device=self._device)
         return torch.sparse_coo_tensor(torch.stack([r, c]), vals, (self._n, self._n))
 
+    def adjacency_sq_sum(self):
+        """sum_ij a_ij^2 of the label ``adjacency_matrix().to_dense()`` (a_ij = multiplicity of the edge j -> i; E on a
+        graph without repeated edges) as a float64 scalar on the device: the constant term of ops.decoder_mse.  Counted
+        once per graph from the CSR (its rows hold their column ids sorted: repeated edges are neighbours)."""
+        if "adj_sq" not in self._cache:
+            indptr, indices = self.csr()
+            e = int(indices.numel())
+            if e == 0:
+                self._cache["adj_sq"] = torch.zeros((), dtype=torch.float64, device=indices.device)
+            else:
+                rows = torch.repeat_interleave(torch.arange(self._n, device=indices.device),
+                                               (indptr[1:] - indptr[:-1]).to(torch.int64), output_size=e)
+                keys = rows * self._n + indices.to(torch.int64)
+                _, cnt = torch.unique_consecutive(keys, return_counts=True)
+                self._cache["adj_sq"] = (cnt.to(torch.float64) ** 2).sum()
+        return self._cache["adj_sq"]
+
     def dense_adjacency(self):
         """the same label through the HIP kernel (duplicates add)"""
         from . import ops

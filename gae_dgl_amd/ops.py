@@ -2249,6 +2249,65 @@ def decoder_bce(Z, mask, graph, dropout=None, prepared=None):
     return DecoderBCEFunction.apply(Z, mask, graph, dropout)
 
 
+def gram_raw(M):
+    """M^T M ([f, f], fp32-grade products) through gae_linear_bwd's weight-gradient kernel (dW = dY^T M with dY = M);
+    never deferred to an optimiser launch (it is a value of the forward pass, not a parameter gradient)"""
+    M, ldm = _rowmajor(_f32(_gpu(M, "M"), "gram: M"), "M")
+    n, f = M.shape
+    G = torch.empty(f, f, dtype=torch.float32, device=M.device)
+    with _on_device(M.device):
+        ws = _workspace(_lib.load().gae_linear_bwd_workspace_bytes(n, f, f), M.device)
+        _lib.call("gae_linear_bwd", _ptr(M), ldm, None, 0, ACT_IDENTITY, _ptr(M), ldm, None, n, f, f,
+                  _ptr(G), None, None, max(f, 1), _ptr(ws), ws.numel(), _stream())
+    return G
+
+
+class DecoderMSEFunction(torch.autograd.Function):
+    """The criterion of the reference's hyper-parameter search, optuna_gae.py:16,21: ``nn.MSELoss()(model.forward(g),
+    g.adjacency_matrix().to_dense())`` -- the mean over all N^2 ordered pairs of (s_ij - a_ij)^2, s = Zt Zt^T,
+    Zt = Z (.) mask -- WITHOUT the N x N matrices:
+        sum_ij (s_ij - a_ij)^2 = ||Zt^T Zt||_F^2 - 2 <Zt, A Zt> + sum_ij a_ij^2
+        dL/dZt = (2 / N^2) (2 Zt (Zt^T Zt) - A Zt - A^T Zt)
+    (oracle/gae_oracle.py: mse_closed_form): O(N d^2 + E d) work from launches the library already has --
+    gae_spmm_csr on A and on A^T, gae_linear_bwd for the d x d Gram matrix (fp32-grade products), gae_linear_fwd for
+    Zt G -- and two sums of N d products, taken in fp64."""
+
+    @staticmethod
+    def forward(ctx, Z, mask, graph):
+        if getattr(graph, "batch_counts", None) is not None:
+            raise GaeHipError("decoder_mse: fixed-capacity batches are not supported (the BCE loss's captured step only)")
+        n = graph.number_of_nodes()
+        Z = _f32(_gpu(Z, "Z"), "decoder_mse: Z")
+        if Z.shape[0] != n:
+            raise GaeHipError(f"decoder_mse: Z has {Z.shape[0]} rows, the graph {n} nodes")
+        d = Z.shape[1]
+        Zt = pad_rows(Z if mask is None else Z * mask)
+        ip, ix = graph.csr()
+        AZ = spmm_raw(ip, ix, Zt, n, plan=graph.spmm_plan(False))
+        G = gram_raw(Zt)                                                      # Zt^T Zt
+        inv = 1.0 / (float(n) * float(n))
+        loss = ((G.double() ** 2).sum() - 2.0 * (Zt.double() * AZ.double()).sum() + graph.adjacency_sq_sum()) * inv
+        if ctx.needs_input_grad[0]:
+            tp, tx = graph.csc()
+            AtZ = spmm_raw(tp, tx, Zt, n, plan=graph.spmm_plan(True))
+            ZG = linear_fwd_raw(Zt, G, None, ACT_IDENTITY)                   # Zt G (G is symmetric)
+            dZ = (2.0 * ZG - AZ - AtZ) * (2.0 * inv)
+            if mask is not None:
+                dZ = dZ * mask
+            ctx.save_for_backward(dZ)
+        return loss.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dZ,) = ctx.saved_tensors
+        return (dZ if _is_unit(g) else dZ * g), None, None
+
+
+def decoder_mse(Z, mask, graph):
+    """mean((Zt Zt^T - A)^2) over all N^2 ordered pairs, Zt = Z (.) mask (optuna_gae.py:16,21), never materialised"""
+    return DecoderMSEFunction.apply(Z, mask, graph)
+
+
 class ShardedDecoderBCEFunction(torch.autograd.Function):
     """Row block of the fused loss on a row-sharded graph (parallel.ShardedGraph):
     Zt = Z (.) mask is all-gathered (N x d, small), each rank evaluates its rows

@@ -47,6 +47,9 @@ def build_parser():
                     help="generate G ZINC-shaped molecules instead of reading --data_file")
     ap.add_argument("--val_size", type=int, default=10000, help="validation graphs (train_inductive.py:79)")
     ap.add_argument("--loss", choices=["fused", "dense"], default="fused")
+    ap.add_argument("--criterion", choices=["bce", "mse"], default="bce",
+                    help="bce = train_inductive.py:44-48 (weighted BCE with logits); mse = the hyper-parameter search's "
+                         "nn.MSELoss() on the same logits and label (optuna_gae.py:16,21), eager steps only")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no_plot", action="store_true")
     ap.add_argument("--capture", choices=["auto", "on", "off"], default="auto",
@@ -87,6 +90,7 @@ class Trainer:
         """``replicas``: data-parallel training -- iteration() averages the parameter gradients over the ranks of
         ``group`` before the optimiser step"""
         self.model, self.fused = model, fused
+        self.criterion = getattr(args, "criterion", "bce")
         self.replicas, self.group = bool(replicas), group
         self.optim = optim.Adam(model.parameters(), lr=args.lr)     # torch.optim.Adam's rule, one HIP launch
         self._params = list(model.parameters())
@@ -95,9 +99,11 @@ class Trainer:
 
     def loss(self, g):
         if self.fused:
-            return self.model.reconstruction_loss(g)
+            return self.model.reconstruction_loss(g, criterion=self.criterion)
         # the reference-shaped path (train_inductive.py:44-48): dense label, pos_weight against the imbalance, N x N logits
         label = g.adjacency_matrix().to_dense().to(device)
+        if self.criterion == "mse":
+            return torch.nn.MSELoss()(self.model(g), label)                                  # optuna_gae.py:16,21
         n_pairs, n_pos = label.numel(), label.sum()
         return ops.bce_with_logits(self.model(g), label, pos_weight=(n_pairs - n_pos) / n_pos)   # gae_bce_logits
 
@@ -229,7 +235,8 @@ def main(argv=None):
         raise ValueError("--distributed uses the device-resident iterator (its epoch orders are seeded and sharded)")
     trainer = Trainer(model, args, fused=(args.loss == "fused"), replicas=shard is not None)
     captured = None
-    can_capture = (args.loss == "fused" and not args.dataloader and len(loaders["train"].dataset) >= args.batch_size
+    can_capture = (args.loss == "fused" and args.criterion == "bce" and not args.dataloader
+                   and len(loaders["train"].dataset) >= args.batch_size
                    and loaders["train"].dataset.ell_width and loaders["train"].dataset.no_heavy_rows
                    and args.hidden_dims[-1] <= ops.FUSED_MAX_D)
     if args.capture == "on" and not can_capture:

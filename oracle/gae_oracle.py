@@ -290,11 +290,12 @@ def segment_readout(Z, graph_ptr):
     return out
 
 
-def gae_loss_and_grads(src, dst, n, X, weights, biases, mask=None, norm=None):
+def gae_loss_and_grads(src, dst, n, X, weights, biases, mask=None, norm=None, criterion="bce"):
     """One reference training step up to the gradients
     (train_inductive.py:44-51): dense label, pos_weight, GAE.forward with an
     injected dropout mask, BCE-with-logits mean, backward.  Returns
-    ``(loss, Z, logits, dW list, db list)``; dtype follows ``X``."""
+    ``(loss, Z, logits, dW list, db list)``; dtype follows ``X``.
+    ``criterion="mse"``: nn.MSELoss() on the same logits and label (optuna_gae.py:16,21)."""
     indptr, indices = csr_from_coo(src, dst, n)
     X = torch.as_tensor(X)
     Ws = [torch.as_tensor(w).to(X.dtype).clone().requires_grad_(True) for w in weights]
@@ -303,7 +304,7 @@ def gae_loss_and_grads(src, dst, n, X, weights, biases, mask=None, norm=None):
     logits = decoder_logits(Z, mask)
     adj = dense_adjacency(src, dst, n, dtype=X.dtype)
     pw = pos_weight_of(adj)
-    loss = bce_with_logits_mean(logits, adj, pw)
+    loss = bce_with_logits_mean(logits, adj, pw) if criterion == "bce" else mse_mean(logits, adj)
     grads = torch.autograd.grad(loss, Ws + bs)
     L = len(Ws)
     return (loss.detach(), Z.detach(), logits.detach(),

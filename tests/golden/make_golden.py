@@ -222,6 +222,12 @@ def run_case(ref, name, n, src, dst, X, hidden, seed):
     out["adj"] = adj.numpy(); out["pos_weight"] = pw.numpy(); out["loss_p0"] = loss.detach().numpy()
     for k, p in model.named_parameters():
         out["grad_p0/" + k] = p.grad.detach().numpy().copy()
+    # the hyper-parameter search's criterion at dropout 0 (optuna_gae.py:16,21: nn.MSELoss()(model.forward(g), adj))
+    lm = torch.nn.MSELoss()(model(fresh()), adj)
+    model.zero_grad(); lm.backward()
+    out["mse_p0"] = lm.detach().numpy()
+    for k, p in model.named_parameters():
+        out["grad_mse_p0/" + k] = p.grad.detach().numpy().copy()
     # forward with the reference's always-on dropout p=0.1 (gae.py:47,64,70):
     # replay the RNG to capture the mask the reference drew.
     model.decoder.dropout = 0.1

@@ -191,6 +191,29 @@ def test_fused_and_dense_trainers_agree(tmp_path):
     assert abs(losses[0][1] - losses[1][1]) < 2e-5 * abs(losses[1][1])
 
 
+def test_train_inductive_with_the_mse_criterion(tmp_path):
+    """`--criterion mse` (optuna_gae.py:16,21): the never-materialised loss trains; one Trainer iteration equals the
+    reference-shaped chain (N x N logits, dense label, nn.MSELoss)"""
+    import argparse
+    import gae_dgl_amd as G
+    from gae_dgl_amd import train_inductive as TI
+    from gae_dgl_amd.dataset import DeviceGraphDataset
+    tr, va = TI.main(["--hidden_dims", "32", "16", "--synthetic", "2000", "-b", "256", "-e", "3", "--lr", "1e-2",
+                      "--val_size", "300", "--seed", "0", "-s", str(tmp_path), "--no_plot", "--criterion", "mse"])
+    assert len(tr) == 3 and np.isfinite(tr).all() and np.isfinite(va).all() and tr[-1] < tr[0]
+    TI.device = torch.device("cuda:0")
+    ds = DeviceGraphDataset.synthetic_zinc(64, seed=1, device="cuda:0")
+    losses = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        model = G.GAE(39, [32, 16]).to("cuda:0")
+        model.decoder.dropout = 0.0
+        t = TI.Trainer(model, argparse.Namespace(lr=1e-3, criterion="mse"), fused=fused)
+        losses.append((t.iteration(ds.batch(list(range(64)))), t.iteration(ds.batch(list(range(64))), train=False)))
+    assert abs(losses[0][0] - losses[1][0]) < 1e-5 * abs(losses[1][0])
+    assert abs(losses[0][1] - losses[1][1]) < 2e-5 * abs(losses[1][1])
+
+
 def test_train_transductive_runs(tmp_path):
     from gae_dgl_amd import train_transductive as TT
     losses = TT.main(["--dataset", "cora", "-e", "30", "-s", str(tmp_path), "--seed", "0", "--log_every", "100"])

@@ -66,6 +66,29 @@ def test_grads(golden):
             close(db[i], g[f"grad_{tag}/layers.{i}.apply_mod.linear.bias"])
 
 
+def test_mse_criterion(golden):
+    """optuna_gae.py:16,21: nn.MSELoss() on the logits of GAE.forward -- value and parameter gradients the reference
+    model produced (dropout 0), the dense restatement and the closed form the device path evaluates"""
+    g = golden
+    Ws, bs = golden_params(g)
+    n = int(g["n"])
+    adj = O.dense_adjacency(g["src"], g["dst"], n)
+    close(O.mse_mean(g["logits_p0"], adj), g["mse_p0"], 1e-6)
+    loss, Z, logits, dW, db = O.gae_loss_and_grads(g["src"], g["dst"], n, g["X"], Ws, bs, criterion="mse")
+    close(loss, g["mse_p0"], 1e-6)
+    for i in range(len(Ws)):
+        close(dW[i], g[f"grad_mse_p0/layers.{i}.apply_mod.linear.weight"])
+        close(db[i], g[f"grad_mse_p0/layers.{i}.apply_mod.linear.bias"])
+    ip, ix = O.csr_from_coo(g["src"], g["dst"], n)
+    Zt = torch.tensor(np.asarray(g["Z"]), dtype=torch.float64, requires_grad=True)
+    ref = O.mse_mean(O.decoder_logits(Zt), adj.double())
+    ref.backward()
+    l2, dZ = O.mse_closed_form(Zt.detach(), ip, ix)
+    close(l2, ref.detach(), 1e-12)
+    close(dZ, Zt.grad, 1e-12)
+    close(l2, g["mse_p0"], 1e-5)
+
+
 def test_degrees_norm(golden):
     g = golden
     deg = O.in_degrees(g["dst"], int(g["n"]))
