@@ -369,6 +369,40 @@ def test_train_transductive_default_flags_on_a_graph_with_hubs(tmp_path, hub_deg
     np.testing.assert_allclose(got, run(Xd, False), rtol=1e-5)
 
 
+def test_train_transductive_reads_planetoid_files(tmp_path):
+    """`--data_root` with the Planetoid files themselves (ind.cora.{allx,tx,graph,test.index}: data.load_planetoid) --
+    a Cora-sized graph with the real graph's hubs --: the default script trains on it and gives the losses of the
+    same data handed over as <name>.npz"""
+    import os
+    import pickle
+    from collections import defaultdict
+    import scipy.sparse as sp
+    from gae_dgl_amd import data as D, train_transductive as TT
+    n, src, dst, X = _planetoid_like()
+    root = tmp_path / "raw" / "cora"
+    os.makedirs(root)
+    g = defaultdict(list)
+    for u, v in zip(src.tolist(), dst.tolist()):
+        g[u].append(v)
+    for u in range(n):
+        g[u] += []
+    n_all = n - 1000
+    order = np.random.default_rng(0).permutation(np.arange(n_all, n))
+    for ext, obj in (("allx", sp.csr_matrix(X[:n_all])), ("tx", sp.csr_matrix(X[order])), ("graph", g)):
+        with open(root / f"ind.cora.{ext}", "wb") as f:
+            pickle.dump(obj, f, protocol=2)
+    (root / "ind.cora.test.index").write_text("\n".join(str(i) for i in order.tolist()) + "\n")
+    n2, s2, d2, X2 = D.load_planetoid(str(root), "cora")
+    assert n2 == n and X2.shape == X.shape and np.abs(X2 - X).max() < 1e-6
+    assert int(np.bincount(d2, minlength=n).max()) >= 160
+    os.makedirs(tmp_path / "npz")
+    np.savez(tmp_path / "npz" / "cora.npz", src=s2, dst=d2, features=X2, n=n)
+    common = ["--dataset", "cora", "-e", "5", "-s", str(tmp_path), "--seed", "0", "--log_every", "100"]
+    a = TT.main(common + ["--data_root", str(tmp_path / "raw")])
+    b = TT.main(common + ["--data_root", str(tmp_path / "npz")])
+    assert len(a) == 5 and np.isfinite(a).all() and a == b
+
+
 def test_sparse_features_refuse_a_near_dense_column():
     """gae_spx_wgrad's workspace scales with the densest column; maybe_from_dense keeps X dense when
     one column alone would take more than SparseFeatures.MAX_SEGMENTS slots"""
