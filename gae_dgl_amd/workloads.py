@@ -54,15 +54,16 @@ def citation_graph(name, seed=0, degrees="uniform"):
     n, e, f = CITATION[name]
     rng = np.random.default_rng(seed)
     half = e // 2
-    if degrees == "planetoid":
-        a, b = _planetoid_pairs(n, half, PLANETOID_MAX_DEGREE[name], np.random.default_rng(seed + 7919))
-        rng.integers(0, n, half); rng.integers(0, n, half)              # (X below: the same draws as "uniform")
-    else:
-        if degrees != "uniform":
-            raise ValueError(f"degrees: 'uniform' or 'planetoid', not {degrees!r}")
-        a = rng.integers(0, n, half); b = rng.integers(0, n, half)
+    if degrees not in ("uniform", "planetoid"):
+        raise ValueError(f"degrees: 'uniform' or 'planetoid', not {degrees!r}")
+    a = rng.integers(0, n, half); b = rng.integers(0, n, half)
     same = a == b
     b[same] = (b[same] + 1 + rng.integers(0, n - 1, int(same.sum()))) % n
+    if degrees == "planetoid":      # (its own generator: X below is the same matrix for both degree profiles)
+        prng = np.random.default_rng(seed + 7919)
+        a, b = _planetoid_pairs(n, half, PLANETOID_MAX_DEGREE[name], prng)
+        same = a == b
+        b[same] = (b[same] + 1 + prng.integers(0, n - 1, int(same.sum()))) % n
     src = np.concatenate([a, b]); dst = np.concatenate([b, a])
     if e % 2:  # Pubmed's directed count is odd: one extra directed edge
         src = np.append(src, a[0]); dst = np.append(dst, (a[0] + 1) % n)

@@ -72,6 +72,7 @@ def test_citation_graph_degree_profiles():
                 dmax = W.PLANETOID_MAX_DEGREE[name]
                 assert 0.85 * dmax <= deg.max() <= dmax + 8
                 assert 0.005 * n < (deg > 16).sum() < 0.06 * n and (deg == 1).sum() > 0.25 * n
+            assert np.array_equal(X, W.citation_graph(name, seed=0)[3])          # the same features for both profiles
             again = W.citation_graph(name, seed=0, degrees=degrees)
             assert np.array_equal(again[1], src) and np.array_equal(again[2], dst) and np.array_equal(again[3], X)
     import pytest
