@@ -206,6 +206,72 @@ def time_launches(fn, iters=50, warmup=5):
     return t
 
 
+COLD_BYTES = 512 << 20     # operand copies a cold measurement rotates over: twice the 256 MB Infinity Cache (MALL)
+
+
+def time_rotation(fns, iters=None):
+    """average duration of one launch when ``fns`` (the same kernel on DISJOINT operand copies) are launched in
+    rotation: every launch finds operands that 511+ MB of other traffic have pushed out of the L2s and the Infinity
+    Cache since it last touched them -- the MALL-cold figure (VERDICT r05 #2b).  Same method as time_launches: one HIP
+    event pair on the launch stream around a HIP-graph replay of the whole rotation."""
+    K = len(fns)
+    iters = iters or max(3 * K, 48)
+    iters = (iters + K - 1) // K * K
+    for f in fns:
+        f()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            # (results kept alive through the capture: a launch that allocates its output gets a block of its own
+            #  instead of the one the previous launch just freed -- which would be a warm write)
+            keep = [fns[i % K]() for i in range(iters)]
+        g.replay()
+        torch.cuda.synchronize()
+        best = float("inf")
+        for _ in range(3):
+            e0.record(); g.replay(); e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e-3 / iters)
+        return best
+    except Exception as ex:
+        print(f"[bench] graph-replay timing of the rotation unavailable: {ex}", file=sys.stderr)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(iters):
+            fns[i % K]()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def cold_copies(working_set_bytes, cap=160):
+    """how many disjoint operand copies a rotation needs so that >= COLD_BYTES pass between two uses of one copy"""
+    return int(min(cap, max(2, -(-COLD_BYTES // max(int(working_set_bytes), 1)) + 1)))
+
+
+def copy_bandwidth_cold(nbytes, dev):
+    """copy_bandwidth on MALL-cold operands: the same copy rotating over disjoint buffer pairs that add up to
+    >= COLD_BYTES (GB/s, read + write counted).  Working sets beyond the cache are cold anyway."""
+    half = max(int(nbytes) // 2 // 16 * 16, 1 << 16)
+    if 2 * half >= COLD_BYTES:
+        return copy_bandwidth(nbytes, dev)
+    K = cold_copies(2 * half)
+    bufs = [(torch.zeros(half, dtype=torch.uint8, device=dev), torch.empty(half, dtype=torch.uint8, device=dev))
+            for _ in range(K)]
+    t = time_rotation([(lambda s=s_, d=d_: d.copy_(s)) for s_, d_ in bufs])
+    return 2 * half / t / 1e9
+
+
+def cold_fields(alg_bytes, t_cold, dev, copies):
+    """the MALL-cold companions of a roofline entry"""
+    c = copy_bandwidth_cold(alg_bytes, dev)
+    return {"avg_launch_us_cold": t_cold * 1e6, "achieved_GBs_cold": alg_bytes / t_cold / 1e9,
+            "frac_cold": alg_bytes / t_cold / 1e9 / HBM_PEAK_GBS, "copy_GBs_cold": c,
+            "frac_of_copy_cold": alg_bytes / t_cold / 1e9 / c, "cold_copies": copies}
+
+
 def copy_bandwidth(nbytes, dev):
     """measured device-copy rate (GB/s, read + write counted) of a copy that moves ``nbytes`` in total: SURVEY 8(d)'s
     second denominator -- what the memory system delivers to the simplest possible kernel at this size"""
@@ -284,8 +350,11 @@ def make_adam(params, lr, args, capturable=False):
     return Adam(params, lr=lr), "gae_adam_step (torch.optim.Adam rule, one launch)"
 
 
-def spmm_probe(indptr, indices, n, F, ld=None, plan=None, label="", iters=50, blockdiag=None):
-    """kernel-only SpMM throughput for one shape (row-padded operands as every op of the package produces)"""
+def spmm_probe(indptr, indices, n, F, ld=None, plan=None, label="", iters=50, blockdiag=None, plan_factory=None):
+    """kernel-only SpMM throughput for one shape (row-padded operands as every op of the package produces).
+    ``plan_factory(indptr, indices)`` -> plan: also time the launch MALL-cold, rotating over disjoint copies of ALL its
+    operands (CSR arrays, plan tables, H, M) that add up to >= COLD_BYTES; launches whose operands exceed the 256 MB
+    Infinity Cache anyway report their one figure as both"""
     from gae_dgl_amd import ops, workloads as W
     ld = ld or F
     H = torch.rand(n, ld, device=indptr.device)[:, :F]
@@ -296,9 +365,25 @@ def spmm_probe(indptr, indices, n, F, ld=None, plan=None, label="", iters=50, bl
                                            out_padded=True), iters=iters, warmup=30)
     nnz = int(indices.numel())
     b = W.spmm_alg_bytes(n, n, nnz, F, 4)
-    return {"shape": label, "n": n, "nnz": nnz, "F": F, "ld": ld, "dtype": "float32", "us_per_launch": t * 1e6,
-            "edges_per_s": nnz / t, "alg_bytes": b, "achieved_GBs": b / t / 1e9,
-            "frac_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS}
+    r = {"shape": label, "n": n, "nnz": nnz, "F": F, "ld": ld, "dtype": "float32", "us_per_launch": t * 1e6,
+         "edges_per_s": nnz / t, "alg_bytes": b, "achieved_GBs": b / t / 1e9,
+         "frac_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS}
+    if b >= COLD_BYTES // 2:
+        r.update({"frac_cold": r["frac_hbm_peak"], "cold_note": "operands exceed the 256 MB Infinity Cache: every launch reads DRAM"})
+    elif plan_factory is not None:
+        K = cold_copies(b)
+        fns = []
+        for _ in range(K):
+            ip_, ix_ = indptr.clone(), indices.clone()
+            pl_ = plan_factory(ip_, ix_)
+            H_ = torch.rand(n, ld, device=indptr.device)[:, :F]
+            o_ = torch.empty(n, ld, device=indptr.device)[:, :F]
+            fns.append(lambda ip_=ip_, ix_=ix_, pl_=pl_, H_=H_, o_=o_: ops.spmm_raw(ip_, ix_, H_, n, out=o_, plan=pl_,
+                                                                                   out_padded=True))
+        r.update(cold_fields(b, time_rotation(fns), indptr.device, K))
+        del fns
+        torch.cuda.empty_cache()
+    return r
 
 
 # ---------------------------------------------------------------------------------------------- workloads
@@ -400,6 +485,31 @@ class CitationWorkload:
         ip, ix = self.g.csr()
         plan = self.g.spmm_plan(False)
         return lambda: ops.spmm_epilogue_raw(ip, ix, P, self.n, plan, b1, 1)
+
+    def layer1_launches(self, fresh=False):
+        """the three layer-1 launches of the DEFAULT step on operands shaped like the step's own -- 'xw_fwd' (P = X W^T),
+        'agg' (relu(A P + b), gae_spmm_csr_epilogue at F = 32) and 'xtg' (dW1 = G^T X, db1: gae_xw_wgrad) -- as closures.
+        ``fresh``: on private copies of EVERY operand (graph arrays, plan tables, X, P, G ...): one member of a
+        MALL-cold rotation"""
+        import gae_dgl_amd as G
+        from gae_dgl_amd import ops
+        lin = self.model.layers[0].apply_mod.linear
+        W1, b1 = lin.weight.detach(), lin.bias.detach()
+        g, Xd = self.g, self.Xd
+        if fresh:
+            g = G.DGLGraph((self.src, self.dst), num_nodes=self.n).to(self.dev)
+            Xd = ops.pad_rows(torch.from_numpy(self.X).to(self.dev))
+            W1, b1 = W1.clone(), b1.clone()
+        ip, ix = g.csr()
+        plan = g.spmm_plan(False)
+        P, _ = ops.xw_fwd_raw(Xd, W1, None, 0, keep_splits=True)
+        J = self.hidden[0]
+        Gm = torch.randn(self.n, J, device=self.dev)          # G = gate(A^T dM2), dY and the ReLU mask Y of the backward
+        D = torch.randn(self.n, J, device=self.dev)
+        Y = torch.relu(torch.randn(self.n, J, device=self.dev))
+        return {"xw_fwd": lambda: ops.xw_fwd_raw(Xd, W1, None, 0, keep_splits=True),
+                "agg": lambda: ops.spmm_epilogue_raw(ip, ix, P, self.n, plan, b1, 1),
+                "xtg": lambda: ops.xw_wgrad_raw(Xd, Gm, None, D, Y, J)}
 
     def capture(self):
         from gae_dgl_amd.capture import CapturedTrainStep
@@ -797,28 +907,40 @@ class RmatShardedWorkload:
         return z
 
 
-def citation_spmm_probe(name, dev):
+def citation_spmm_probe(name, dev, cold=True):
     """the reference-order layer-1 aggregation A X of a citation shape at its input width (the north-star's SpMM;
     not part of the default step, which aggregates at the output width): kernel-only, operands as
-    `--layer1 reference` launches them"""
+    `--layer1 reference` launches them; warm (operands resident in the Infinity Cache across the back-to-back launches)
+    and MALL-cold (rotation over disjoint copies of graph, plan, X and M adding up to >= COLD_BYTES)"""
     import gae_dgl_amd as G
     from gae_dgl_amd import ops, workloads as W
     n, src, dst, X = W.citation_graph(name, seed=0)
-    g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
-    ip, ix = g.csr()
-    Xd = ops.pad_rows(torch.from_numpy(X).to(dev))
     F = X.shape[1]
-    out = ops.pad_rows(torch.empty(Xd.shape, device=dev))
-    plan = g.spmm_plan(False)
-    sc = F > ops.TILE_MIN_F and g.scattered(F * 4)
-    t = time_launches(lambda: ops.spmm_raw(ip, ix, Xd, n, out=out, plan=plan, out_padded=True, scattered=sc), iters=50,
-                      warmup=30)
-    E = int(ix.numel())
+    E = int(src.size)
     b = W.spmm_alg_bytes(n, n, E, F, 4)
-    return {"shape": f"{name} layer-1 aggregation A*X in the reference's order (not in the default step)", "n": n, "nnz": E,
-            "F": F, "ld": Xd.stride(0), "dtype": "float32", "us_per_launch": t * 1e6, "edges_per_s": E / t, "alg_bytes": b,
-            "achieved_GBs": b / t / 1e9, "frac_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(f"{name}-F{F}")}
+
+    def make():
+        g = G.DGLGraph((src, dst), num_nodes=n).to(dev)
+        ip, ix = g.csr()
+        Xd = ops.pad_rows(torch.from_numpy(X).to(dev))
+        out = ops.pad_rows(torch.empty(Xd.shape, device=dev))
+        plan = g.spmm_plan(False)
+        sc = F > ops.TILE_MIN_F and g.scattered(F * 4)
+        return (lambda: ops.spmm_raw(ip, ix, Xd, n, out=out, plan=plan, out_padded=True, scattered=sc)), Xd.stride(0)
+    fn, ld = make()
+    t = time_launches(fn, iters=50, warmup=30)
+    r = {"shape": f"{name} layer-1 aggregation A*X in the reference's order (not in the default step)", "n": n, "nnz": E,
+         "F": F, "ld": ld, "dtype": "float32", "us_per_launch": t * 1e6, "edges_per_s": E / t, "alg_bytes": b,
+         "achieved_GBs": b / t / 1e9, "frac_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS,
+         "traffic": pmc_traffic(f"{name}-F{F}")}
+    if cold:
+        K = cold_copies(b)
+        fns = [fn] + [make()[0] for _ in range(K - 1)]
+        r.update(cold_fields(b, time_rotation(fns), dev, K))
+        r["edges_per_s_cold"] = E / (r["avg_launch_us_cold"] * 1e-6)
+        del fns
+        torch.cuda.empty_cache()
+    return r
 
 
 def extras(dev):
@@ -833,8 +955,9 @@ def extras(dev):
     ipb, ixb = ip[:nb + 1].clone(), ix[:eb].clone()
     # as the product launches it: the packed neighbour table of the batch comes out of the batch gather
     pb = ops.spmm_plan(ipb, indices=ixb, ell=True, ell_width=ops.ell_width_for_degrees(ipb[1:] - ipb[:-1]))
-    out.append(spmm_probe(ipb, ixb, nb, 39, ld=40, plan=pb, label="zinc-batch4096 layer1"))
-    out.append(spmm_probe(ipb, ixb, nb, 32, plan=pb, label="zinc-batch4096 layer2"))
+    pf = lambda ip_, ix_: ops.spmm_plan(ip_, indices=ix_, ell=True, ell_width=ops.ell_width_for_degrees(ip_[1:] - ip_[:-1]))
+    out.append(spmm_probe(ipb, ixb, nb, 39, ld=40, plan=pb, label="zinc-batch4096 layer1", plan_factory=pf))
+    out.append(spmm_probe(ipb, ixb, nb, 32, plan=pb, label="zinc-batch4096 layer2", plan_factory=pf))
     bd = ops.BlockDiag(gptr, dev)     # whole molecules per thread block: LDS-staged block-diagonal kernel
     out.append(spmm_probe(ip, ix, N, 39, ld=40, label="zinc-250k whole set, one launch, layer1", iters=20,
                           blockdiag=bd))
@@ -1160,6 +1283,10 @@ def main():
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": getattr(wl, "dtype", "f32"), "data": "synthetic",
         "config": wl.meta,
+        "value_spmm_only": wl.edges_per_step / max(world, 1) * args.steps / spmm_t if spmm_t else None,
+        "value_note": "value = SpMM edges of a step / WHOLE-step time (encoder + fused N^2 loss + backward + Adam: the loss is "
+                      "two thirds of a Pubmed step); value_spmm_only = the same edges / the HIP-event time of the step's SpMM "
+                      "launches alone (see spmm_only) -- the figure to set beside an SpMM-only CPU rate (cpu_baseline.spmm)",
         "epoch_time_s": elapsed / args.steps * (wl.meta.get("batches_per_epoch_at_239455_graphs", 1)),
         "spmm_only": {"edges_per_s": wl.edges_per_step / max(world, 1) * args.steps / spmm_t if spmm_t else None,
                       "sum_event_time_s": spmm_t, "launches": sum(len(times[k]) for k in spmm_keys),
@@ -1253,32 +1380,63 @@ def main():
                 for k, v in knobs.items():
                     _lib.call("gae_tuning_set", k, v)
     if world == 1 and type(wl) is CitationWorkload and getattr(wl, "tf", False) and not wl.sparse:
-        # ---- SURVEY 8(d)'s unit, the SpMM aggregation itself: (1) the aggregation the DEFAULT step runs,
-        #      act(A P + b) at F = 32 on the step's own operands; (2) the reference-order layer-1 aggregation A X at the
-        #      input width (the north-star's SpMM; not in the default step).  Both kernel-only, back-to-back launches
-        #      between HIP events on the launch stream, with the copy rate of the same bytes as second denominator.
+        # ---- The metric's kernel is the SpMM AGGREGATION: the top-level `roofline` is
+        #      (1) the reference-order layer-1 aggregation A X at the input width -- the north-star's SpMM, the launch
+        #      its 60 % target is quoted on; `--layer1 reference` runs it inside the step -- with (2) the aggregation the
+        #      DEFAULT step runs, act(A P + b) at F = 32 on the step's own operands, beside it as `in_step`.  The dense
+        #      layer-1 pair of the default step (xw_fwd, xtg) moves to `roofline_dense`.  Every entry: kernel-only,
+        #      back-to-back launches between HIP events on the launch stream; WARM (operands stay in the 256 MB Infinity
+        #      Cache between launches, as they do between the replays of the timed region) and MALL-COLD (rotation over
+        #      disjoint operand copies adding up to >= 512 MB: every launch reads DRAM), each with the copy rate of the
+        #      same bytes measured the same way as second denominator.
         from gae_dgl_amd import workloads as Wl
-        agg = wl.aggregation_launch()
-        t_agg = time_launches(agg, iters=50, warmup=30)
-        E_ = wl.g.number_of_edges()
-        b_agg = Wl.spmm_alg_bytes(wl.n, wl.n, E_, wl.hidden[0], 4)
-        c_agg = copy_bandwidth(b_agg, dev)
-        ref = citation_spmm_probe(wl.meta["workload"].split("-")[0], dev)
+        name = wl.meta["workload"].split("-")[0]
+        J, E_ = wl.hidden[0], wl.g.number_of_edges()
+        dense_entry = dict(line["roofline"])          # the xw_fwd entry computed above
+        warm = wl.layer1_launches()
+        b_agg = Wl.spmm_alg_bytes(wl.n, wl.n, E_, J, 4)
+        b_xtg = 4 * (wl.n * wl.F_in + 3 * wl.n * J + J * wl.F_in + J)
+        Kc = {"xw_fwd": cold_copies(wl.alg_bytes), "agg": cold_copies(b_agg), "xtg": cold_copies(b_xtg)}
+        rot = [wl.layer1_launches(fresh=True) for _ in range(max(Kc.values()))]
+        t_warm = {k: time_launches(warm[k], iters=50, warmup=30) for k in ("agg", "xtg")}
+        t_cold = {k: time_rotation([r[k] for r in rot[:Kc[k]]]) for k in ("xw_fwd", "agg", "xtg")}
+        del rot
+        torch.cuda.empty_cache()
+        ref = citation_spmm_probe(name, dev)
         c_ref = copy_bandwidth(ref["alg_bytes"], dev)
-        line["roofline_spmm"] = {
-            "default_step_aggregation": {
-                "kernel": f"gae_spmm_csr_epilogue: act(A (X W^T) + b), F = {wl.hidden[0]}, {wl.n} rows, {E_} edges (in the default step)",
-                "alg_bytes": b_agg, "avg_launch_us": t_agg * 1e6, "achieved_GBs": b_agg / t_agg / 1e9,
-                "frac": b_agg / t_agg / 1e9 / HBM_PEAK_GBS, "copy_GBs": c_agg, "frac_of_copy": b_agg / t_agg / 1e9 / c_agg,
-                "edges_per_s": E_ / t_agg,
-                "note": "5.5 MB of compulsory traffic: at 8 TB/s the launch would last 0.7 us -- it is bound by its chain of "
-                        "dependent round trips (row pointers -> neighbour ids -> gathered rows), not by bytes"},
-            "reference_order_layer1": {
-                "kernel": ref["shape"], "F": ref["F"], "alg_bytes": ref["alg_bytes"], "avg_launch_us": ref["us_per_launch"],
-                "achieved_GBs": ref["achieved_GBs"], "frac": ref["frac_hbm_peak"], "copy_GBs": c_ref,
-                "frac_of_copy": ref["achieved_GBs"] / c_ref, "edges_per_s": ref["edges_per_s"], "traffic": ref["traffic"]}}
-        line["roofline"]["spmm"] = {k: {kk: v[kk] for kk in ("alg_bytes", "avg_launch_us", "frac", "frac_of_copy")}
-                                    for k, v in line["roofline_spmm"].items()}
+        c_agg = copy_bandwidth(b_agg, dev)
+        in_step = {
+            "kernel": f"gae_spmm_csr_epilogue: act(A (X W^T) + b), F = {J}, {wl.n} rows, {E_} edges (the aggregation of the default step)",
+            "alg_bytes_per_launch": b_agg, "avg_launch_us": t_warm["agg"] * 1e6, "achieved": b_agg / t_warm["agg"] / 1e9,
+            "frac": b_agg / t_warm["agg"] / 1e9 / HBM_PEAK_GBS, "copy_GBs": c_agg,
+            "frac_of_copy": b_agg / t_warm["agg"] / 1e9 / c_agg, "edges_per_s": E_ / t_warm["agg"],
+            **cold_fields(b_agg, t_cold["agg"], dev, Kc["agg"]), "edges_per_s_cold": E_ / t_cold["agg"],
+            "note": "5.5 MB of compulsory traffic: at 8 TB/s the launch would last 0.7 us -- it is bound by its chain of "
+                    "dependent round trips (row pointers -> neighbour ids -> gathered rows), not by bytes"}
+        line["roofline"] = {
+            "bound": "hbm", "kernel": ref["shape"] + f": gae_spmm_csr, F = {ref['F']}, {wl.n} rows, {E_} edges",
+            "achieved": ref["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ref["frac_hbm_peak"],
+            "traffic": ref["traffic"],
+            "traffic_note": "HBM bytes/launch from separate rocprofv3 --pmc passes of the same kernel and shape "
+                            "(profiles/pmc_traffic_r0N.json; FETCH_SIZE / WRITE_SIZE, gfx950 corrections), not collected in this run",
+            "alg_bytes_per_launch": ref["alg_bytes"], "avg_launch_us": ref["us_per_launch"], "edges_per_s": ref["edges_per_s"],
+            "copy_GBs": c_ref, "frac_of_copy": ref["achieved_GBs"] / c_ref,
+            **{k: ref[k] for k in ("avg_launch_us_cold", "achieved_GBs_cold", "frac_cold", "copy_GBs_cold",
+                                   "frac_of_copy_cold", "cold_copies", "edges_per_s_cold") if k in ref},
+            "residency_note": "frac: back-to-back launches on ONE operand set (79 MB: resident in the 256 MB Infinity Cache, "
+                              "so '% of 8 TB/s' is against the on-die fabric); frac_cold: the same launch rotating over "
+                              "disjoint operand sets adding up to >= 512 MB, so every launch reads DRAM",
+            "in_step": in_step}
+        dense_entry.pop("spmm", None)
+        dense_entry.update(cold_fields(wl.alg_bytes, t_cold["xw_fwd"], dev, Kc["xw_fwd"]))
+        c_xtg = copy_bandwidth(b_xtg, dev)
+        line["roofline_dense"] = {
+            "xw_fwd": dense_entry,
+            "xtg": {"bound": "hbm", "kernel": f"xtg (gae_xw_wgrad) dW1 = G^T X, db1, {wl.n} x {wl.F_in} -> {J} x {wl.F_in} (X read once)",
+                    "alg_bytes_per_launch": b_xtg, "avg_launch_us": t_warm["xtg"] * 1e6, "achieved": b_xtg / t_warm["xtg"] / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_xtg / t_warm["xtg"] / 1e9 / HBM_PEAK_GBS,
+                    "copy_GBs": c_xtg, "frac_of_copy": b_xtg / t_warm["xtg"] / 1e9 / c_xtg,
+                    **cold_fields(b_xtg, t_cold["xtg"], dev, Kc["xtg"])}}
     if "ms_per_step_exact_fp32" in line:        # (the driver keeps `config` whole: the same-arithmetic figure travels there too)
         line["config"]["ms_per_step_exact_fp32"] = line["ms_per_step_exact_fp32"]
         line["config"]["value_exact_fp32"] = line["value_exact_fp32"]
@@ -1311,7 +1469,7 @@ def main():
     except Exception:
         pass
     sys.stdout.flush()
-    for k in ("ms_per_step_exact_fp32", "value_exact_fp32", "roofline_spmm"):       # last in the line: inside any tail of it
+    for k in ("ms_per_step_exact_fp32", "value_exact_fp32", "roofline_dense", "roofline"):       # last in the line: inside any tail of it
         if k in line:
             line[k] = line.pop(k)
     print(json.dumps(line), flush=True)

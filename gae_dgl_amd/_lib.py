@@ -2,6 +2,7 @@
 
 There is NO fallback: if the shared library is missing or cannot be loaded
 every op raises -- the product path never routes through PyTorch/CPU code."""
+import collections
 import ctypes
 import os
 
@@ -195,5 +196,17 @@ def check(rc, what):
         raise GaeHipError(f"{what} failed ({kind} {rc}): {msg}")
 
 
+CALLS = collections.Counter()      # entry point -> calls made through call() by this process (tests assert on it: which
+                                   # kernels a step really went through; a HIP-graph replay makes none)
+
+
 def call(name, *args):
+    CALLS[name] += 1
     check(getattr(load(), name)(*args), name)
+
+
+def tuning_get(name):
+    """current value of a gae_tuning_set knob (or of a telemetry value such as "bce_last_kind")"""
+    out = ctypes.c_int64(0)
+    check(load().gae_tuning_get(name.encode(), ctypes.byref(out)), "gae_tuning_get")
+    return int(out.value)

@@ -61,6 +61,8 @@ gae::Knob g_bce_fold_mirror{1};   // "bce_fold_mirror": 1 = the edge kernel fold
 gae::Knob g_bce_sym_tiles{0};     // "bce_sym_tiles": 64-column tiles per block of the symmetric kernel (0 = auto)
 gae::Knob g_bce_sym_grid{16384};  // "bce_sym_grid": target size of the (panel, chunk) grid of the symmetric kernel
                              // (many short blocks even out the triangular work: ZINC batch 3.64 -> 3.35 ms)
+gae::Knob g_bce_last_kind{0}; // "bce_last_kind" (telemetry, read with gae_tuning_get): dense kernel of the last loss call on this
+                               // process -- 0 none yet, 1 full square, 2 symmetric 128-row panels, 3 symmetric 256-row panels
 gae::Knob g_bce_sym{1};       // "bce_sym": 1 = symmetric dense kernel for full-square launches with d <= 16
 gae::Knob g_bce_pv_bf16{1};   // "bce_pv_bf16": 1 = bf16x3 for O' += P V as well (P split on the fly), 0 = exact fp32
 
@@ -1565,6 +1567,7 @@ Knob *bce_knob(const char *name)
     if (strcmp(name, "bce_s_bf16") == 0) return &g_bce_s_bf16;
     if (strcmp(name, "bce_pv_bf16") == 0) return &g_bce_pv_bf16;
     if (strcmp(name, "bce_sym") == 0) return &g_bce_sym;
+    if (strcmp(name, "bce_last_kind") == 0) return &g_bce_last_kind;
     if (strcmp(name, "bce_sym_grid") == 0) return &g_bce_sym_grid;
     if (strcmp(name, "bce_grid") == 0) return &g_bce_grid;
     if (strcmp(name, "bce_sym_tiles") == 0) return &g_bce_sym_tiles;
@@ -1654,6 +1657,7 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
         GAE_CHECK_LAUNCH("bce_prepare_kernel");
     }
     int rc;
+    g_bce_last_kind = p.sym ? (p.sym_pr == 256 ? 3 : 2) : 1;
     if (p.sym) {
         const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
         static std::atomic<unsigned> call_counter{0};

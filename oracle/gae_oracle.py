@@ -311,6 +311,36 @@ def gae_loss_and_grads(src, dst, n, X, weights, biases, mask=None, norm=None, cr
             [g.detach() for g in grads[:L]], [g.detach() for g in grads[L:]])
 
 
+def gae_loss_and_grads_windowed(src, dst, n, X, weights, biases, mask=None, norm=None, window=1024):
+    """:func:`gae_loss_and_grads` (criterion "bce") for graphs whose dense fp64 N x N label / logits / autograd
+    temporaries do not fit comfortably (Pubmed: 3.1 GB each): the same step -- train_transductive.py:59-66 on
+    gae.py:49-55 -- with the N x N part evaluated ``window`` rows at a time by :func:`bce_row_window` (loss share and
+    dLoss/dZt of those rows) and the encoder differentiated by autograd from the assembled dLoss/dZ.  Always fp64.
+    Returns ``(loss, Z, dZ, dW list, db list)`` (no logits: they are never whole).  tests/test_oracle_golden.py
+    pins it against :func:`gae_loss_and_grads` on the golden graphs."""
+    indptr, indices = csr_from_coo(src, dst, n)
+    t_indptr, t_indices = csc_from_coo(src, dst, n)
+    X = torch.as_tensor(X).double()
+    Ws = [torch.as_tensor(w).double().clone().requires_grad_(True) for w in weights]
+    bs = [torch.as_tensor(b).double().clone().requires_grad_(True) for b in biases]
+    Z = gae_encode(indptr, indices, X, Ws, bs, None if norm is None else torch.as_tensor(norm).double())
+    m = None if mask is None else torch.as_tensor(mask).double()
+    Zt = (Z if m is None else Z * m).detach()
+    e = float(len(indices))
+    pw = (float(n) * n - e) / e                       # train_inductive.py:46 on the label's sum (duplicates add)
+    loss = torch.zeros((), dtype=torch.float64)
+    dZt = torch.empty_like(Zt)
+    for r0 in range(0, n, window):
+        r1 = min(r0 + window, n)
+        share, g = bce_row_window(Zt, r0, r1, indptr, indices, t_indptr, t_indices, pw)
+        loss += share
+        dZt[r0:r1] = g
+    dZ = dZt if m is None else dZt * m
+    grads = torch.autograd.grad(Z, Ws + bs, grad_outputs=dZ)
+    L = len(Ws)
+    return loss, Z.detach(), dZ, [g.detach() for g in grads[:L]], [g.detach() for g in grads[L:]]
+
+
 def dense_restatement_encode(src, dst, n, X, weights, biases, norm=None):
     """Independent fp64 dense-matrix restatement
     ``Z = A relu((A X) W1^T + b1) W2^T + b2 ...`` used to cross-check the CSR

@@ -66,6 +66,22 @@ def test_grads(golden):
             close(db[i], g[f"grad_{tag}/layers.{i}.apply_mod.linear.bias"])
 
 
+def test_windowed_grads_match_reference_vectors(golden):
+    """the row-window form of the step (what the full-size Pubmed parity test checks the device against): same loss
+    and parameter gradients as the reference-generated vectors, with windows that divide the graph unevenly"""
+    g = golden
+    Ws, bs = golden_params(g)
+    n = int(g["n"])
+    for tag, mask in (("p0", None), ("p01", g["mask"])):
+        for window in (max(1, n // 3 + 1), n + 5):
+            loss, Z, dZ, dW, db = O.gae_loss_and_grads_windowed(g["src"], g["dst"], n, g["X"], Ws, bs, mask, window=window)
+            close(loss, g["loss_" + tag], 1e-6)
+            close(Z, g["Z"])
+            for i in range(len(Ws)):
+                close(dW[i], g[f"grad_{tag}/layers.{i}.apply_mod.linear.weight"])
+                close(db[i], g[f"grad_{tag}/layers.{i}.apply_mod.linear.bias"])
+
+
 def test_mse_criterion(golden):
     """optuna_gae.py:16,21: nn.MSELoss() on the logits of GAE.forward -- value and parameter gradients the reference
     model produced (dropout 0), the dense restatement and the closed form the device path evaluates"""
