@@ -112,6 +112,10 @@ def parse():
     ap.add_argument("--balance", choices=["rows", "nnz"], default="nnz",
                     help="rmat: row blocks of equal row count or of equal edge count (RMAT puts 44 %% of the edges "
                          "into the first of 8 equal row blocks)")
+    ap.add_argument("--row-cost", type=int, default=None,
+                    help="rmat, --balance nnz: cost of one ROW of a block in units of one edge visit (default: "
+                         "parallel.ROW_COST = 16, from the byte model there: ~1.5 KB of dense-pass traffic per row and step "
+                         "against ~90 B of measured HBM traffic per edge visit)")
     ap.add_argument("--layer-order", choices=["auto", "aggregate-first", "transform-first"], default="auto",
                     help="rmat workload: aggregate-first = every layer as (A H) W^T like gae.py:26-31; transform-first "
                          "(= auto) = the 32 -> 16 layer as A (H W^T) + b and its backward from G = A^T dZ (same values up to "
@@ -507,9 +511,17 @@ class CitationWorkload:
         Gm = torch.randn(self.n, J, device=self.dev)          # G = gate(A^T dM2), dY and the ReLU mask Y of the backward
         D = torch.randn(self.n, J, device=self.dev)
         Y = torch.relu(torch.randn(self.n, J, device=self.dev))
+
+        def xtg():
+            # as the captured step launches it: per-block partial sums only (gae_x_xw_wgrad_partials) -- their reduction
+            # rides in the Adam launch (ops.StepContext) -- so this closure times the one-pass kernel alone
+            with ops.StepContext(defer_grads=True) as c:
+                out = ops.xw_wgrad_raw(Xd, Gm, None, D, Y, J)
+                c.partials.clear()
+            return out
         return {"xw_fwd": lambda: ops.xw_fwd_raw(Xd, W1, None, 0, keep_splits=True),
                 "agg": lambda: ops.spmm_epilogue_raw(ip, ix, P, self.n, plan, b1, 1),
-                "xtg": lambda: ops.xw_wgrad_raw(Xd, Gm, None, D, Y, J)}
+                "xtg": xtg}
 
     def capture(self):
         from gae_dgl_amd.capture import CapturedTrainStep
@@ -1049,6 +1061,104 @@ class MockWorkload:
         return t
 
 
+def collective_preflight(rank, world, dev, group=None):
+    """Every collective primitive the N-rank paths use, once, on small tensors with KNOWN answers, before any workload
+    is built (VERDICT r05 #7a): a primitive that fails or returns wrong values on this node is named in the line
+    (`preflight`) and on stderr instead of surfacing as a hang or a wrong edge count an hour into the run.  Returns
+    {primitive: "ok" | "FAILED: ..."}.  Also switches parallel.py's RCCL-only fast paths (receive views for the
+    all-to-all, grouped uneven all-gather) back to their portable forms when those fail."""
+    import torch.distributed as dist
+    from gae_dgl_amd import parallel, transport
+    res = {}
+
+    def run(name, fn):
+        try:
+            fn()
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            res[name] = "ok"
+        except Exception as ex:      # noqa: BLE001 -- reported, never swallowed silently
+            res[name] = f"FAILED: {type(ex).__name__}: {ex}"[:300]
+
+    def all_reduce_sum():
+        t = torch.full((1808,), float(rank + 1), device=dev)              # the 39 -> 32 -> 16 model's gradient bucket
+        transport.all_reduce(t, group=group)
+        assert float(t[0]) == world * (world + 1) / 2 and bool((t == t[0]).all())
+
+    def all_reduce_max():
+        t = torch.tensor([1000 + 13 * ((rank * 5) % world), 5000 - 7 * rank], dtype=torch.int64, device=dev)
+        transport.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        assert t.tolist() == [1000 + 13 * max((r * 5) % world for r in range(world)), 5000]
+
+    def a2a_tables():
+        # rank r sends (r + q) % 3 + (q != r) rows of 16 floats to rank q: uneven, with empty pairs on the diagonal
+        send_counts = [((rank + q) % 3 + 1) * (q != rank) for q in range(world)]
+        recv_counts = [((q + rank) % 3 + 1) * (q != rank) for q in range(world)]
+        return send_counts, recv_counts
+
+    def all_to_all_uneven():
+        sc, rc = a2a_tables()
+        send = torch.cat([torch.full((c, 16), float(100 * rank + q), device=dev) for q, c in enumerate(sc)])
+        recv = torch.empty(sum(rc), 16, device=dev)
+        transport.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        want = torch.cat([torch.full((c, 16), float(100 * q + rank), device=dev) for q, c in enumerate(rc)])
+        assert torch.equal(recv, want)
+        cnt = torch.tensor(sc, dtype=torch.int64, device=dev); got = torch.empty_like(cnt)
+        transport.all_to_all_single(got, cnt, group=group)                  # the count exchange of the plan builders
+        assert got.tolist() == rc
+
+    def all_to_all_views():
+        sc, rc = a2a_tables()
+        send = torch.cat([torch.full((c, 16), float(100 * rank + q), device=dev) for q, c in enumerate(sc)])
+        full = torch.full((sum(rc) + 5, 16), -1.0, device=dev)              # receive views into one assembled buffer
+        outs, ins, so, ro = [], [], 0, 0
+        for q in range(world):
+            ins.append(send[so:so + sc[q]]); so += sc[q]
+            at = ro if q < rank else ro + 5
+            outs.append(full[at:at + rc[q]]); ro += rc[q]
+        dist.all_to_all(outs, ins, group=group)
+        for q in range(world):
+            assert bool((outs[q] == float(100 * q + rank)).all())
+
+    def all_gather_even():
+        mine = torch.full((7, 16), float(rank), device=dev)
+        full = torch.empty(7 * world, 16, device=dev)
+        transport.all_gather_into_tensor(full, mine, group=group)
+        assert torch.equal(full[::7, 0], torch.arange(world, device=dev, dtype=full.dtype))
+
+    def all_gather_uneven():
+        sizes = [3 + (q % 4) for q in range(world)]
+        full = torch.empty(sum(sizes), 16, device=dev)
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        views = [full[int(offs[q]):int(offs[q + 1])] for q in range(world)]
+        for w in transport.all_gather_uneven(views, torch.full((sizes[rank], 16), float(rank), device=dev), rank, group):
+            w.wait()
+        for q in range(world):
+            assert bool((views[q] == float(q)).all())
+
+    run("all_reduce_sum", all_reduce_sum)
+    run("all_reduce_max", all_reduce_max)
+    run("all_to_all_single_uneven", all_to_all_uneven)
+    run("all_gather_into_tensor", all_gather_even)
+    run("all_gather_uneven", all_gather_uneven)
+    if dev.type == "cuda" and transport.backend(group) == "nccl":
+        run("all_to_all_receive_views", all_to_all_views)
+        if res["all_to_all_receive_views"] != "ok":
+            parallel.A2A_RECEIVE_VIEWS = False
+            res["all_to_all_receive_views"] += " -> parallel.A2A_RECEIVE_VIEWS = False (all_to_all_single + cat instead)"
+    if res["all_gather_uneven"] != "ok" and transport.backend(group) == "nccl":
+        transport.GROUPED_UNEVEN_ALLGATHER = False
+        run("all_gather_uneven_by_broadcasts", all_gather_uneven)
+    # every rank must agree on the outcome: a primitive that failed anywhere is failed everywhere
+    bad = torch.tensor([sum(v != "ok" and not v.startswith("ok") for v in res.values())], dtype=torch.int64, device=dev)
+    try:
+        transport.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        res["ranks_agree_all_ok"] = bool(int(bad) == 0)
+    except Exception as ex:      # noqa: BLE001
+        res["ranks_agree_all_ok"] = f"FAILED: {ex}"[:200]
+    return res
+
+
 def free_port():
     import socket
     with socket.socket() as s:
@@ -1142,6 +1252,20 @@ def main():
         dist.init_process_group("gloo" if (mock or args.oversubscribe) else "nccl", rank=rank, world_size=world,
                                 timeout=datetime.timedelta(minutes=60))
     n_gpus = dist.get_world_size() if dist.is_initialized() else 1       # from the LIVE process group
+    preflight = None
+    if dist.is_initialized():
+        assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus, world)
+        if args.row_cost is not None:
+            from gae_dgl_amd import parallel as _par
+            _par.ROW_COST = int(args.row_cost)
+        name = torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu"
+        print(f"[bench] rank {rank}/{world}: device {dev} ({name}), backend {dist.get_backend()}, "
+              f"rccl_ranks {dist.get_world_size()}", file=sys.stderr, flush=True)
+        t_pf = time.perf_counter()
+        preflight = collective_preflight(rank, world, dev)
+        preflight["seconds"] = time.perf_counter() - t_pf
+        if rank == 0:
+            print(f"[bench] collective preflight: {preflight}", file=sys.stderr, flush=True)
 
     def barrier():
         if world > 1:
@@ -1163,7 +1287,8 @@ def main():
                               "value": wl.edges_per_step * args.steps / elapsed, "unit": "edges/s", "n_gpus": n_gpus,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                               "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": "f32",
-                              "data": "synthetic", "config": wl.meta, "timing": region_stats(regions, args.steps)}),
+                              "data": "synthetic", "config": wl.meta, "timing": region_stats(regions, args.steps),
+                              "rccl_ranks": n_gpus, "preflight": preflight}),
                   flush=True)
         return
 
@@ -1217,7 +1342,29 @@ def main():
             wl.step()
         torch.cuda.synchronize()
         ops.profiler = None
-        wl.capture()
+        try:
+            wl.capture()
+        except Exception as ex:      # noqa: BLE001 -- a capture holding collectives is the first thing to fail on new hardware
+            if world == 1:
+                raise
+            # every rank must take the same branch: the warm-up steps inside the capture hold collectives
+            print(f"[bench] rank {rank}: capturing the step failed ({type(ex).__name__}: {ex}); eager steps instead",
+                  file=sys.stderr, flush=True)
+            wl.captured = None
+            if hasattr(wl, "runner"):
+                wl.runner = None
+            wl.meta["launch"] = f"eager (capturing the step with its collectives failed: {type(ex).__name__}: {str(ex)[:200]})"
+            graphed = False
+    if world > 1 and getattr(wl, "use_graph", False):
+        # all ranks or none: a rank that fell back to eager steps cannot pair its collectives with replaying peers
+        flag = torch.tensor([0 if graphed else 1], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag) and graphed:
+            wl.captured = None
+            if hasattr(wl, "runner"):
+                wl.runner = None
+            wl.meta["launch"] = "eager (another rank could not capture the step with its collectives)"
+            graphed = False
     for _ in range(args.warmup):
         wl.step()
     if not graphed:
@@ -1281,6 +1428,7 @@ def main():
     line = {
         "metric": "edges aggregated/sec (SpMM fwd+bwd)", "value": value, "unit": "edges/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "rccl_ranks": n_gpus if dist.is_initialized() else 0, "preflight": preflight,
         "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": getattr(wl, "dtype", "f32"), "data": "synthetic",
         "config": wl.meta,
         "value_spmm_only": wl.edges_per_step / max(world, 1) * args.steps / spmm_t if spmm_t else None,

@@ -113,6 +113,11 @@ __device__ __forceinline__ void split_bf16x4(const v4f &v, v4s &hi, v4s &lo)
 // 8 + 8 + 8 mantissa bits).  A product of two such operands over the six piece pairs down to 2^-24 relative
 // (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi) is an fp32-grade product on the bf16 matrix pipe: every pair is exact in
 // the fp32 accumulator, the dropped pairs are below one ulp of the term.
+// NON-FINITE / OVERFLOW (documented behaviour, include/gae_hip.h "numerical contract"): for v = +-Inf, and for finite
+// |v| > 3.3895e38 (the largest bf16; rounding to bf16 overflows to Inf -- the top 0.4 % of the fp32 exponent range), the
+// residual v - hi is Inf - Inf = NaN, so a product that an fp32 MFMA would return as +-Inf (or as a huge finite number)
+// comes back as NaN.  NaN inputs stay NaN.  Either way the result is non-finite and torch's anomaly checks fire; a
+// select per element that would keep Inf as Inf costs two VALU ops per value in loops that are issue-bound.
 __device__ __forceinline__ void split_bf16x4_3(const v4f &v, v4s &hi, v4s &mid, v4s &lo)
 {
     unsigned h[2], m[2], l[2];

@@ -752,10 +752,16 @@ int xw_fwd_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const 
     if (elem == 4) {
         if (g_xw_p3 != 0 && p.slice_bytes == 256 && wide && (g_xw_dbg || g_xw_depth || g_xw_tc)) {     // experiments
             const int dp = g_xw_depth ? int(g_xw_depth) : 2, tc = g_xw_tc ? int(g_xw_tc) : 6, dbg = int(g_xw_dbg);
-#define GAE_XWE(DB, DP, TC) if (dbg == DB && dp == DP && tc == TC) hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, DB, DP, true, TC>), grid, block, 0, s, a)
+            bool launched = false;
+#define GAE_XWE(DB, DP, TC) if (dbg == DB && dp == DP && tc == TC) { hipLaunchKernelGGL((xw_fwd_kernel<float, 2, 256, DB, DP, true, TC>), grid, block, 0, s, a); launched = true; }
             GAE_XWE(0, 2, 6); GAE_XWE(0, 3, 6); GAE_XWE(0, 4, 6); GAE_XWE(0, 2, 3); GAE_XWE(0, 3, 3); GAE_XWE(0, 4, 3);
             GAE_XWE(1, 2, 6); GAE_XWE(2, 2, 6); GAE_XWE(1, 4, 3); GAE_XWE(2, 4, 3); GAE_XWE(3, 2, 6);
 #undef GAE_XWE
+            if (!launched) {      // only the instantiated (xw_dbg, xw_depth, xw_tc) combinations exist: never return uninitialised output
+                set_error("xw_fwd: no kernel for the knob combination xw_dbg=%d xw_depth=%d xw_tc=%d (with xw_p3=1: depth 2|3|4 x "
+                          "tc 3|6 at dbg 0; dbg 1|2 at (2,6) and (4,3); dbg 3 at (2,6))", dbg, dp, tc);
+                return GAE_E_RANGE;
+            }
         }
         else if (g_xw_p3 != 0) {
 #define GAE_XW3(NH, SB) hipLaunchKernelGGL((xw_fwd_kernel<float, NH, SB, 0, 2, true>), grid, block, 0, s, a)

@@ -52,7 +52,15 @@ def block_bounds(n, world):
 # boundary rows the higher the cost (rank 0: 0.92 -> 1.08 GB per step from 1 to 24 when X is sent every step, half
 # of that with cache_constant_inputs), which at 150-300 GB/s of all-to-all bandwidth evens the ranks out between 16
 # and 24.
+# The same figure from bytes (round 6, no virtual-rank timing involved): per step a row with in-edges costs its M1 row
+# read twice and written once (3 x 128 B), its T / Z / G / dZ rows (4 x 64 B written, 4 x 64 B read) and its CSR pointers
+# in four structures (~32 B): ~1.4 KB; an edge visit costs what the PMC passes measure on the RMAT s24 product,
+# 23.5 GB / 2^28 edges = 88 B (profiles/pmc_traffic_r05.json: the gathered row is re-fetched 4.3 x more often than the
+# compulsory count).  1.4 KB / 88 B = 16.  bench.py --row-cost overrides it for a sweep on real xGMI ranks.
 ROW_COST = 16
+# RCCL fast path of the boundary exchange: dist.all_to_all on views of the assembled receive buffer (no cat).  bench.py's
+# collective preflight sets it to False when that primitive misbehaves on the node (all_to_all_single + cat instead).
+A2A_RECEIVE_VIEWS = True
 
 
 def nnz_balanced_bounds(n, src, dst, world, row_cost=None):
@@ -390,7 +398,7 @@ class ShardedGraph:
             return self.allgather_rows(h_local)
         a = self._a2a[which]
         nb = p.n_before[which]          # rows owned by lower ranks arrive first (ascending global id)
-        if h_local.is_cuda and h_local.dtype == torch.float32 and comm.backend(self.group) == "nccl":
+        if h_local.is_cuda and h_local.dtype == torch.float32 and comm.backend(self.group) == "nccl" and A2A_RECEIVE_VIEWS:
             # HIP pack kernels + receive views: the rows to send go straight into the send buffer, the own rows
             # straight into their slot of the assembled buffer, and every peer's rows land where the local CSR
             # indexes them -- no ATen index_select / cat between two products

@@ -218,6 +218,11 @@ def main(argv=None):
         os.makedirs(args.save_dir, exist_ok=True)
 
     model = GAE(args.in_dim, args.hidden_dims).to(device)
+    if shard:
+        # The replicas share ONE seed for the split, the initial weights and the epoch orders -- but each draws its own
+        # dropout masks (its own Philox stream): replicas with identical masks on different batches would correlate the
+        # dropout noise across the global batch, unlike one process drawing a mask per batch (gae.py:70)
+        model.decoder.seed = int(args.seed) + 1000003 * shard[0]
     say = print if _rank() == 0 else (lambda *a, **k: None)
     say("Loading data")
     graphs = load_dataset(args)
@@ -239,14 +244,20 @@ def main(argv=None):
                    and len(loaders["train"].dataset) >= args.batch_size
                    and loaders["train"].dataset.ell_width and loaders["train"].dataset.no_heavy_rows
                    and args.hidden_dims[-1] <= ops.FUSED_MAX_D)
-    if args.capture == "on" and not can_capture:
-        raise ValueError("--capture on needs the fused loss, the device-resident iterator, a low-degree dataset with "
-                         "at least one full batch and an embedding width <= %d" % ops.FUSED_MAX_D)
+    why = ""
     if shard:
         from gae_dgl_amd import transport
-        can_capture = can_capture and transport.backend(None) == "nccl"      # staged collectives cannot be captured
+        if transport.backend(None) != "nccl":                                # staged collectives cannot be captured
+            can_capture, why = False, "; --distributed: the RCCL backend (collectives staged through the host cannot be captured)"
         if loaders["train"]._n_graphs() < args.batch_size:
-            can_capture = False
+            can_capture, why = False, "; --distributed: at least one full batch in every replica's share of the epoch"
+        dropped = len(loaders["val"].dataset) % shard[1]
+        if dropped:
+            say(f"note: {dropped} of the {len(loaders['val'].dataset)} validation molecules fall outside the replicas' "
+                f"equal shares and are not evaluated")
+    if args.capture == "on" and not can_capture:
+        raise ValueError("--capture on needs the fused loss, the device-resident iterator, a low-degree dataset with "
+                         "at least one full batch and an embedding width <= %d%s" % (ops.FUSED_MAX_D, why))
     if args.capture != "off" and can_capture:
         from gae_dgl_amd.capture import CapturedInductiveStep
         captured = CapturedInductiveStep(model, trainer.optim, loaders["train"].dataset, args.batch_size,

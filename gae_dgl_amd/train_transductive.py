@@ -76,8 +76,8 @@ def main(argv=None):
         g = DGLGraph(data.graph).to(device)
     g.ndata['norm'] = g.norm().unsqueeze(1)    # train_transductive.py:55-58; parameter independent: once, not per epoch
     if args.features == "auto" and device.type == "cuda":
-        # decided per GRAPH: the kernels on the non-zeros need a graph without long rows (real Cora / Citeseer have hubs
-        # of 168 / 99 neighbours: their features stay dense)
+        # decided per GRAPH: the kernels on the non-zeros need a table-only plan, which every graph whose longest row
+        # has <= ops.TABLE_MAX_ROW (1024) edges gets -- real Cora / Citeseer (hubs of 168 / 99 neighbours) qualify
         from gae_dgl_amd import SparseFeatures
         features = SparseFeatures.maybe_from_dense(features, args.hidden_dims[0], graph=g)
 

@@ -15,6 +15,10 @@ import torch
 import torch.distributed as dist
 
 
+GROUPED_UNEVEN_ALLGATHER = True    # RCCL: one grouped all_gather into uneven views; False: one broadcast per owner
+                                   # (bench.py's collective preflight switches it off when the grouped form fails)
+
+
 def backend(group=None):
     return dist.get_backend(group)
 
@@ -93,7 +97,7 @@ def all_gather_uneven(views, t_local, rank, group=None):
     """every rank's block into ``views[q]`` (blocks of different lengths; ``views[rank]`` receives ``t_local``).
     RCCL: ONE grouped all_gather into the views; gloo has no uneven all_gather: one broadcast per owner.  Returns the
     list of pending works."""
-    if backend(group) == "nccl":
+    if backend(group) == "nccl" and GROUPED_UNEVEN_ALLGATHER:
         return [dist.all_gather(views, t_local.contiguous(), group=group, async_op=True)]
     views[rank].copy_(t_local)
     works = []

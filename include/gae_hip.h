@@ -33,6 +33,14 @@
  *            optimiser launch, two heads in one launch, collate + cursor in one launch).  They exist to take launches
  *            out of the captured step of gae_dgl_amd/capture.py, are paired in ways the comments spell out, and may
  *            change or disappear between rounds; every one of them has a gae_* sequence with the same result.
+ *
+ * Numerical contract of the dense products (gae_xw_fwd, the weight gradients, the fused loss): fp32 storage and fp32
+ * accumulation; by default the multiplications run on the 16-bit matrix pipe from split operands (three bf16 pieces per
+ * operand, six piece pairs; two fp16 pieces behind a range guard in the loss) -- within 1.5e-7 of fp64, as the fp32 MFMAs
+ * they replace (knobs xw_p3 / atb_bf16 / bce_s_bf16 = 0 select exact fp32 MFMAs).  NON-FINITE INPUTS differ from an fp32
+ * product: an operand entry that is +-Inf, or finite with |v| > 3.3895e38 (beyond the largest bf16), makes the affected
+ * outputs NaN where an fp32 product would give +-Inf or a huge finite value (the residual v - bf16(v) is Inf - Inf).
+ * Results are non-finite either way; NaN inputs give NaN in both forms.
  */
 #ifndef GAE_HIP_H
 #define GAE_HIP_H
@@ -245,7 +253,10 @@ typedef struct gae_spmm_plan {
                                        skip_rows[r] != 0 are not written at all (see the flag) */
 } gae_spmm_plan;
 
-/* (plan construction on the device -- gae_spmm_plan_sizes / _build_rows / _build_pinned / gae_spmm_ell_build: gae_hip_experimental.h) */
+/* A binder of THIS header alone passes plan == NULL everywhere (every product is then the plain CSR-order launch: correct
+ * on any graph, the fastest form only for graphs without long rows).  Filling a gae_spmm_plan -- the packed neighbour table
+ * `ell`, the heavy-row segments, the XCD-pinned regrouping -- takes the device-side builders gae_spmm_plan_sizes /
+ * _build_rows / _build_pinned / gae_spmm_ell_build, which are declared in gae_hip_experimental.h: plans REQUIRE that header. */
 /* Packed neighbour table (optional, for launches of a few 10 MB): slot k of row r at ell[r * width + k] holds the
  * row's k-th column id in CSR order; -1 = empty; a row with more than `width` ids keeps width - 1 of them and the
  * marker -2 in its last slot (the kernel continues from indptr / indices); rows with more than `skip_degree` ids
@@ -347,53 +358,9 @@ int gae_spmm_csr_ep(const int32_t *indptr, const int32_t *indices, int64_t n_row
                     const float *col_scale, const gae_spmm_plan *plan, void *workspace, int64_t workspace_bytes,
                     int flags, const float *bias, int act, void *stream);
 
-/* ---- dense halves of a two-layer encoder on very tall operands (csrc/tall.hip) ---------------------------------
- * gae_linear2_fwd:  Y1 = act1(A W1^T + b1) [n, f_mid],  T = Y1 W2^T [n, f_out]  in ONE pass over A [n, f_in]:
- * NodeApplyModule of layer 1 (gae_dgl/gae.py:13-16) and the dense half of layer 2 evaluated transform-first.
- * f_in <= 64, f_mid <= 32, f_out <= 32; rows of A, Y1, T whole 16-byte vectors; W1 [f_mid, f_in] (ldw1), W2 [f_out,
- * f_mid] (ldw2) as nn.Linear stores them; b1 may be NULL; Y1 may be NULL (inference: only T is wanted). */
-/* a_dead [n] (or NULL): rows of A that ARE zero and were never written -- the rows without edges of an aggregate
- * produced with GAE_SPMM_SKIP_ROWS -- are not read (their outputs are act1(b1) and its image under W2).
- * rows [n_listed] (or NULL; replaces a_dead): LIST MODE -- only the listed rows (ascending ids < n) are read, computed
- * and written; the pass is bound by the fp32 matrix pipe, so on a power-law graph, where most rows of an aggregate
- * have no in-edges, it does a fraction of the work.  gae_linear2_fill_dead writes T for all the other rows (their
- * common value act1(b1) W2^T; `dead` [n] marks them). */
-/* gae_gcn2_bwd_dense: every dense product of that encoder's backward pass in ONE pass over its four tall operands
- * (train_inductive.py:51 for the model of gae.py:36-45 with two layers), given G = A^T dZ [n, f_out]:
- *     dW2 = G^T Y1,  db2 = colsum(dZ),  dY1 = (G W2) (.) act1'(Y1),  dW1 = dY1^T M1,  db1 = colsum(dY1)
- * Y1 [n, f_mid] = the output of layer 1, M1 [n, f_in] = its stored aggregate A X; widths <= 32; rows of G and dZ whole
- * 16-byte vectors.  dY1 is never stored.  Per-block partial sums go to `workspace` (gae_gcn2_bwd_dense_workspace_bytes)
- * and are added in block order (deterministic).  layout_out != NULL: stop after the partials (dW1 .. db2 are not
- * written) and report {n_partials, floats per partial, offset of db1, of dW2, of db2} (dW1 at 0) for gae_adam_step's
- * deferred reduction. */
-/* m1_dead / g_dead [n] (or NULL; recomputing form only): rows of M1 / G that ARE zero and were never written
- * (GAE_SPMM_SKIP_ROWS) are not read.
- * rows [n_listed] (or NULL): LIST MODE -- the rows that HAVE an M1 row, ascending; m1_dead must then mark exactly the
- * others.  The pass visits the listed rows only (g_dead_listed [n_listed]: the G mask by list entry, or NULL); the
- * others' share -- their H1 row is act1(b1), so it is a rank-one term of the column sums of their G and dZ rows --
- * is computed by two small launches and appended to the partial list as one more partial (workspace sized for it). */
-/* (Y1 == NULL: the pass RECOMPUTES Y1 = act1(M1 W1^T + b1) from the tile of M1 it reads anyway -- W1 [f_mid, f_in] (ldw1),
- *  b1 [f_mid] or NULL -- with gae_linear2_fwd's products in its order, i.e. the same bits: the forward then need not
- *  store Y1 at all (gae_linear2_fwd with Y1 = NULL) and this pass reads 2 f_mid fewer floats per row.) */
-
-/* ---- layer 1 on SPARSE input features (opt-in; gae_dgl_amd.SparseFeatures) -------
- * The citation features the reference loads as a dense FloatTensor (gae_dgl/train_transductive.py:37-38) are
- * bag-of-words rows with 1-10 % non-zeros.  Handed over in compressed form they give the same layer-1 values
- * (the skipped terms are exact zeros) from 8 bytes per non-zero instead of 4 bytes per entry:
- *   gae_dense_to_csr_count / _fill: compressed rows of a dense [n, K] matrix, columns ascending (count the non-zeros
- *       per row, prefix-sum them on the caller's side into rowptr[n + 1], fill col / val); used for X and for X^T.
- *   gae_spx_fwd:   P [n, f_out] = X W^T from the compressed rows of X (f_out <= 32), ascending-column order; the weight
- *       is first transposed into `workspace` (gae_spx_fwd_workspace_bytes(f_in): f_in rows of one 128-byte line), so that a
- *       non-zero gathers ONE line.  Measured (tools/r04/spx_bench.py, pair fwd + wgrad against gae_xw_fwd + gae_xw_wgrad):
- *       Citeseer 17.5 vs 34.7 us, Cora 15.0 vs 16.8 us, Pubmed 27.7 vs 26.4 us -- worth it for wide, very sparse X only
- *       (SparseFeatures.maybe_from_dense applies that rule).
- *   gae_spx_wgrad: dW [f_out, f_in] = G^T X from the compressed rows of X^T cut into SEGMENTS of <= 64 entries of
- *       one feature (seg_feat / seg_e0 / seg_slot [n_segments]: feature, first entry, index of the segment inside its
- *       feature; every feature has at least one -- possibly empty -- segment), and db = colsum(D (.) [Dmask > 0]).
- *       reduce = 1: dW / db are finished by a second launch; reduce = 0: the partial lists stay in `workspace`
- *       (gae_spx_wgrad_layout: [0] partials per element of dW, [1] floats between them (element (j, k) at j * f_in + k),
- *       [2] float offset of the db partials, [3] their count (32 floats apart), [4] workspace bytes) for
- *       gae_adam_step's deferred reduction. */
+/* (dense halves of the two-layer encoder on very tall operands -- gae_linear2_fwd, gae_linear2_fill_dead,
+ * gae_gcn2_bwd_dense -- and layer 1 on sparse input features -- gae_dense_to_csr_*, gae_spx_*: declared and documented in
+ * gae_hip_experimental.h) */
 
 /* ---- K3-K5: node-apply (Linear + activation) -------------------------------
  * Y = act(M W^T + b)      NodeApplyModule.forward, gae_dgl/gae.py:13-16

@@ -50,3 +50,23 @@ def test_world_size_mismatch_is_refused():
     r = _run(["--gpus", "4", "--steps", "1", "--warmup", "0", "--workload", "mock"],
              env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "refusing" in r.stderr
+
+
+def test_gpus8_line_schema_and_collective_preflight():
+    """the N = 8 launch the driver runs at round end, rehearsed on gloo: eight ranks, ONE line with n_gpus = rccl_ranks = 8,
+    and every collective primitive of the sharded paths (uneven all_to_all_single, uneven all-gather, all-reduce SUM /
+    MAX) verified against known answers before the workload starts"""
+    r = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--workload", "mock"], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in line, k
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["config"]["parallelism"] == "x8"
+    pf = line["preflight"]
+    for k in ("all_reduce_sum", "all_reduce_max", "all_to_all_single_uneven", "all_gather_into_tensor", "all_gather_uneven"):
+        assert pf[k] == "ok", (k, pf[k])
+    assert pf["ranks_agree_all_ok"] is True
+    assert sum("rccl_ranks 8" in l for l in r.stderr.splitlines()) == 8       # every rank reported its device

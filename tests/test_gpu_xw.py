@@ -285,3 +285,33 @@ def test_deferred_grad_reductions_match_the_separate_launches():
         with ops.deferred_grad_reductions():
             gr.ndata['h'] = X
             ops.backward(m_b.reconstruction_loss(gr), list(m_b.parameters()))      # no optimiser step inside
+
+
+@pytest.mark.parametrize("p3", [1, 0])
+def test_xw_fwd_every_knob_setting_launches_a_kernel_or_errors(p3, tuning):
+    """the experiment knobs xw_dbg / xw_depth / xw_tc select among INSTANTIATED kernels only -- a combination
+    without a kernel must come back as an argument error, never as GAE_OK over uninitialised output.  dbg 0 settings
+    must equal the default launch; dbg 1..3 (partial kernels for timing experiments) must launch or raise."""
+    from gae_dgl_amd import ops, _lib
+    g = torch.Generator(device="cpu").manual_seed(7)
+    n, K, J = 4100, 500, 32
+    Xp = ops.pad_rows(torch.randn(n, K, generator=g).to(DEV))
+    W = (torch.randn(J, K, generator=g) / K ** 0.5).to(DEV)
+    tuning("xw_p3", p3)
+    P0 = ops.xw_fwd_raw(Xp, W, None, 0)
+    launched = refused = 0
+    for dbg in (0, 1, 2, 3):
+        for depth in (0, 2, 3, 4, 5, 7):
+            for tc in (0, 3, 4, 6):
+                tuning("xw_dbg", dbg); tuning("xw_depth", depth); tuning("xw_tc", tc)
+                try:
+                    P = ops.xw_fwd_raw(Xp, W, None, 0)
+                except _lib.GaeHipError as e:
+                    assert "knob combination" in str(e)
+                    refused += 1
+                    continue
+                launched += 1
+                if dbg == 0:
+                    assert rel(P, P0) < 2e-6, (dbg, depth, tc)
+    tuning("xw_dbg", 0); tuning("xw_depth", 0); tuning("xw_tc", 0)
+    assert launched > 0 and (refused > 0) == (p3 == 1)

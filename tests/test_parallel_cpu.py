@@ -144,3 +144,111 @@ def test_partition_plan_covers_graph_exactly():
                     need = p.need["fwd"].numpy()
                     assert np.all((need < p.r0) | (need >= p.r1)) and np.all(np.diff(need) > 0)
         assert tot_f == 2 * len(src) and tot_b == 2 * len(src)
+
+
+# ------------------------------------------------------------------------------------------------ world 8 (round 6)
+def _hand_graph_world8():
+    """a 64-node graph built by hand for 8 ranks of 8 rows: block 0 is a hub block (every other block references rows
+    0..2), block 3 references nobody outside itself, block 5 has NO edges at all (empty need lists, empty send lists),
+    block 7 references one row of every block; plus a ring between neighbouring blocks.  Directed on purpose: the
+    forward (in-edge) and backward (out-edge) tables differ."""
+    src, dst = [], []
+    for b in range(1, 8):
+        if b in (3, 5):
+            continue
+        for k in range(3):
+            src.append(k); dst.append(8 * b + k)             # rows of block b read rows 0..2 of block 0
+    for i in range(24, 32):
+        src.append(24 + (i + 1) % 8); dst.append(i)          # block 3: edges inside the block only
+    for b in range(7):
+        if b != 5:
+            src.append(8 * b + 4); dst.append(63)            # row 63 (block 7) reads one row of each block
+    for b in (0, 1, 2, 6):                                   # ring: last row of block b -> first row of the next used block
+        nb = {0: 1, 1: 2, 2: 4, 6: 7}[b]
+        src.append(8 * b + 7); dst.append(8 * nb)
+    return 64, np.asarray(src, np.int64), np.asarray(dst, np.int64)
+
+
+def _worker8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from gae_dgl_amd import transport
+        from gae_dgl_amd.parallel import RowPartition, ShardedGraph
+        n, src, dst = _hand_graph_world8()
+        X = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3)
+        sg = ShardedGraph(n, torch.from_numpy(src), torch.from_numpy(dst), mode="boundary", device="cpu")
+        p = sg.part
+        assert (p.r0, p.r1) == (8 * rank, 8 * rank + 8)
+        for which, key_rows, key_cols in (("fwd", dst, src), ("bwd", src, dst)):
+            a = sg._a2a[which]
+            # ---- the tables against the hand-built graph: what this rank needs = remote columns of its rows
+            mine = (key_rows >= p.r0) & (key_rows < p.r1)
+            remote = np.unique(key_cols[mine & ((key_cols < p.r0) | (key_cols >= p.r1))])
+            assert a["need"].tolist() == remote.tolist()
+            assert a["recv_counts"] == [int(((remote >= 8 * r) & (remote < 8 * r + 8)).sum()) for r in range(world)]
+            assert a["recv_counts"][rank] == 0 and a["send_counts"][rank] == 0
+            # ---- pairwise agreement: what q expects from me is what I send to q (the uneven split tables of
+            #      all_to_all_single must be each other's transpose, or RCCL deadlocks / corrupts)
+            tables = [None] * world
+            dist.all_gather_object(tables, (a["send_counts"], a["recv_counts"]))
+            for r in range(world):
+                for s in range(world):
+                    assert tables[r][0][s] == tables[s][1][r], (which, r, s)
+            # ---- the rows arrive where the local CSR indexes them
+            full = sg.exchange(X[p.r0:p.r1].contiguous(), which)
+            nb = p.n_before[which]
+            want = torch.cat([X[remote[remote < p.r0]], X[p.r0:p.r1], X[remote[remote >= p.r1]]])
+            assert full.shape[0] == p.n_local + len(remote) and nb == int((remote < p.r0).sum())
+            assert torch.equal(full, want), (which, rank)
+        if rank == 5:      # the edge-less block exchanges nothing in either direction
+            assert sum(sg._a2a["fwd"]["recv_counts"]) == 0 and sum(sg._a2a["bwd"]["send_counts"]) == 0
+        if rank == 3:
+            # reads nothing remote; row 63 reads its row 28, so the gradient of row 28 needs row 63's in the backward
+            assert sum(sg._a2a["fwd"]["recv_counts"]) == 0 and sg._a2a["fwd"]["send_counts"][7] == 1
+            assert sg._a2a["bwd"]["recv_counts"] == [0, 0, 0, 0, 0, 0, 0, 1] and sum(sg._a2a["bwd"]["send_counts"]) == 0
+        if rank == 0:      # the hub block sends rows 0..2 to five blocks, row 7 to block 1 (ring) and row 4 to block 7
+            assert sg._a2a["fwd"]["send_counts"] == [0, 4, 3, 0, 3, 0, 3, 4]
+        # ---- every rank holding only a SLICE of the edge list builds the same plan (two all-to-all-v of edge pairs)
+        sl = slice(rank, None, world)
+        ps = RowPartition.from_edge_slice(n, torch.from_numpy(src[sl]), torch.from_numpy(dst[sl]), None, "boundary")
+        for k in ("fwd", "bwd"):
+            assert torch.equal(ps.need[k], p.need[k])
+            a_rows, a_cols = (ps.fwd_rows, ps.fwd_cols) if k == "fwd" else (ps.bwd_rows, ps.bwd_cols)
+            b_rows, b_cols = (p.fwd_rows, p.fwd_cols) if k == "fwd" else (p.bwd_rows, p.bwd_cols)
+            assert sorted(zip(a_rows.tolist(), a_cols.tolist())) == sorted(zip(b_rows.tolist(), b_cols.tolist()))
+        # ---- uneven all-gather (nnz-balanced blocks): every rank's block lands in its slice
+        sgn = ShardedGraph(n, torch.from_numpy(src), torch.from_numpy(dst), mode="allgather", device="cpu", balance="nnz")
+        pn = sgn.part
+        assert not pn.uniform and int(pn.bounds[-1]) == n
+        got = sgn.allgather_rows(X[pn.r0:pn.r1].contiguous())
+        assert torch.equal(got, X)
+        # ---- capacity agreement of the data-parallel capture (capture.CapturedInductiveStep.begin_epoch): all-reduce
+        #      MAX of (nodes, edges) -- every rank must come out with the same pair, the element-wise maximum
+        need = torch.tensor([1000 + 13 * ((rank * 5) % 8), 5000 - 7 * rank], dtype=torch.int64)
+        transport.all_reduce(need, op=dist.ReduceOp.MAX)
+        assert need.tolist() == [1000 + 13 * 7, 5000]
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_boundary_exchange_tables_world8_hand_built():
+    """VERDICT r05 #7b: the uneven all_to_all_single split tables, the receive layout, the uneven all-gather and the
+    all-reduce-MAX capacity agreement on a hand-built 8-rank partition with an empty block, a self-contained block
+    and a hub block (gloo, 8 CPU processes)"""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30900 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]
