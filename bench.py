@@ -395,7 +395,7 @@ def spmm_probe(indptr, indices, n, F, ld=None, plan=None, label="", iters=50, bl
 # accumulation are fp32; the products of the fused loss and of the weight gradients run on the bf16 matrix pipe as
 # split-operand products (see config.loss_products / dW_products; `value_exact_fp32` is the same step with exact
 # fp32 products everywhere)
-DTYPE_SPLIT = ("f32 (storage, aggregations, accumulators; the dense products run on the 16-bit matrix pipe from split operands with fp32 accumulation: X W^T and dW from three bf16 pieces per operand / six pairs, the loss from two fp16 pieces (N >= 8192) or three bf16 pieces -- all fp32-grade, see ms_per_step_exact_fp32 for fp32 MFMAs everywhere)")
+DTYPE_SPLIT = ("f32 (storage, aggregations, accumulators; the dense products run on the 16-bit matrix pipe from split operands with fp32 accumulation: X W^T and dW from three bf16 pieces per operand / six pairs, the loss from two fp16 pieces (N >= 5120) or three bf16 pieces -- all fp32-grade, see ms_per_step_exact_fp32 for fp32 MFMAs everywhere)")
 
 
 class CitationWorkload:
@@ -427,7 +427,7 @@ class CitationWorkload:
                      "optimizer": "adam lr=1e-2: " + opt_name, "parallelism": "1 GPU",
                      "launch": "hipGraph replay of the captured step" if self.use_graph else "eager",
                      "forward_products": "layer 1 X W^T: three bf16 pieces per operand, six pairs (knob xw_p3=1: 1.5e-7 of fp64, as the fp32 MFMAs it replaces); narrow layers: fp32 MFMA",
-                     "loss_products": "split-operand products on K = 32 MFMAs, fp32 accumulate (knobs bce_s_bf16=3, bce_pv_bf16=1): N >= 8192 (symmetric kernel): two fp16 pieces per operand for S = Z Z^T and dZ = P Z (22 mantissa bits; embeddings beyond |z| = 32768 fall back to the bf16 form inside the same call); N < 8192: three bf16 pieces for S (24 bits), two for P Z",
+                     "loss_products": "split-operand products on K = 32 MFMAs, fp32 accumulate (knobs bce_s_bf16=3, bce_pv_bf16=1): N >= 5120 (symmetric kernel, 256-row panels; balanced schedule below 65 536 rows): two fp16 pieces per operand for S = Z Z^T and dZ = P Z (22 mantissa bits; embeddings beyond |z| = 32768 fall back to the bf16 form inside the same call); N < 5120: three bf16 pieces for S (24 bits), two for P Z",
                      "dW_products": "three bf16 pieces per operand, six piece pairs down to 2^-24, fp32 accumulate (knob atb_bf16=1; gae_xw_wgrad: exact fp32 MFMAs)",
                      "residency": f"operands of the dominant launch ({2 * n * self.F_in * 4 / 1e6:.0f} MB) stay in the "
                                   "256 MB Infinity Cache across the timed replays: its '% of 8 TB/s' is measured "
@@ -1476,7 +1476,8 @@ def main():
         loss_fn = wl.loss_launch()                  # (sets wl.n for the molecule batches)
         n = wl.n
         t_loss = time_launches(loss_fn, iters=20 if n < 50000 else 5, warmup=5 if n < 50000 else 2)
-        kind = "symmetric256" if n >= 32768 else "symmetric" if n >= 8192 else "full"     # gae_decoder_bce's own rules (bce_sym, bce_sym_ri; d <= 16)
+        from gae_dgl_amd import _lib as _l
+        kind = {1: "full", 2: "symmetric", 3: "symmetric256"}[_l.tuning_get("bce_last_kind")]     # what the launches above ran on
         per_logit, frac_eval = loss_slots_per_logit(kind)
         units = per_logit * frac_eval * float(n) * n
         isa = LOSS_ISA[kind][0]

@@ -63,6 +63,9 @@ gae::Knob g_bce_sym_grid{16384};  // "bce_sym_grid": target size of the (panel, 
                              // (many short blocks even out the triangular work: ZINC batch 3.64 -> 3.35 ms)
 gae::Knob g_bce_last_kind{0}; // "bce_last_kind" (telemetry, read with gae_tuning_get): dense kernel of the last loss call on this
                                // process -- 0 none yet, 1 full square, 2 symmetric 128-row panels, 3 symmetric 256-row panels
+gae::Knob g_bce_sym_bal{1};   // "bce_sym_bal": balanced schedule of the symmetric kernel (every block the same number of column
+                              // tiles, one resident round): 1 = below 65 536 rows, 2 = always, 0 = never (the 2-D (panel, column
+                              // chunk) grid of rounds 2-5)
 gae::Knob g_bce_sym{1};       // "bce_sym": 1 = symmetric dense kernel for full-square launches with d <= 16
 gae::Knob g_bce_pv_bf16{1};   // "bce_pv_bf16": 1 = bf16x3 for O' += P V as well (P split on the fly), 0 = exact fp32
 
@@ -712,14 +715,14 @@ __host__ __device__ inline int64_t sym_strip_offset(int64_t I, int64_t NP, int64
 // TRV (default): the V fragments of O' += P V come from LDS transpose reads of the [j][k] tiles -- no second,
 // transposed copy of every tile (16 ds_write_b16 per thread and tile, 8.7 KB of LDS): Pubmed 170 -> 166 us, a ZINC
 // batch 2.92 -> 2.88 ms.  TRV = false keeps the round-2 form (knob "bce_sym_tr" = 0).
-template <bool WITH_GRAD, int RI, bool TRV, bool S3 = false, bool F16 = false, bool PERSIST = false>
+template <bool WITH_GRAD, int RI, bool TRV, bool S3 = false, bool F16 = false, bool PERSIST = false, bool BAL = false>
 __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_sym_kernel(
     const float *__restrict__ Zt /*[n][16]*/, const unsigned short *__restrict__ Zhi,
     const unsigned short *__restrict__ Zlo, int64_t n, int64_t cols_per_chunk,
     float *__restrict__ O_partial /*[chunks][n][16]*/, float *__restrict__ Wmir,
     double *__restrict__ loss_partial /*[chunks * panels][2]*/, const double *__restrict__ colsum_partial,
     int64_t n_prep_blocks, double *__restrict__ S, float *__restrict__ S_all_f, unsigned n_panels, int exp_strip,
-    unsigned *__restrict__ range_flag, int flag_mode, unsigned ticket, unsigned n_chunks)
+    unsigned *__restrict__ range_flag, int flag_mode, unsigned ticket, unsigned n_chunks, int bal_tpb)
 {
     // Range guard of the fp16 pieces.  flag_mode 1 (the F16 launch): a thread that meets |Zt| > kF16Max (or a NaN)
     // writes this call's ticket to *range_flag; the launch's results are then meaningless.  flag_mode 2 (the
@@ -755,24 +758,15 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
     __shared__ __attribute__((aligned(16))) float MR[2][4][16 * LDM];
     __shared__ double red[4][2];
 
-  auto unit = [&](const unsigned bx, const unsigned by) {     // one (panel bx, column chunk by) unit of work
-    if (bx >= n_panels) {   // the extra block column: column sums of Zt for the kernels that follow
-        if (by == 0)
-            bce_colsum_block(colsum_partial, n_prep_blocks, DP, S, S_all_f, reinterpret_cast<double *>(&MR[0][0][0]));
-        return;
-    }
+  double sumA = 0.0, sumL = 0.0;    // loss sums over this lane's rows of all RI subtiles (rows >= n excluded as they are added): of one
+                                    // unit (2-D grid) or of all the units of the block (balanced schedule)
+  // one unit of work: panel I (rows [SYM_PR I, SYM_PR (I + 1))) against the columns [col_begin, col_end) at or right of it; its
+  // O' partial goes to slot op_slot of the panel's rows; lp_index >= 0: its loss sums to loss_partial[2 lp_index ..], < 0: added
+  // carried on in sumA / sumL
+  auto unit = [&](const int64_t I, const int64_t col_begin, const int64_t col_end, const int64_t op_slot, const int64_t lp_index) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int64_t I = bx;
     const int64_t NP = (n + 63) / 64 * 64;
-    const int64_t col_begin = SYM_PR * I + int64_t(by) * cols_per_chunk;
-    int64_t col_end = col_begin + cols_per_chunk;
-    if (col_end > n) col_end = n;
-    const int64_t lp_index = int64_t(by) * n_panels + bx;
-    if (col_begin >= n) {            // chunk beyond this panel's columns
-        if (tid == 0) { loss_partial[2 * lp_index] = 0.0; loss_partial[2 * lp_index + 1] = 0.0; }
-        return;
-    }
     const int64_t row_base = SYM_PR * I + wave * (RI * 16);
     const int64_t diag_end = SYM_PR * (I + 1);      // tiles starting below this column lie in the panel's own square
 
@@ -824,7 +818,7 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
     f32x4 oacc[RI];
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri) oacc[ri] = f32x4{0.f, 0.f, 0.f, 0.f};
-    double sumA = 0.0, sumL = 0.0;    // over this lane's rows of all RI subtiles (rows >= n excluded as they are added)
+    if (!BAL) { sumA = 0.0; sumL = 0.0; }
     bool rvalid[RI];
 #pragma unroll
     for (int ri = 0; ri < RI; ++ri) rvalid[ri] = (row_base + ri * 16 + l15) < n;
@@ -1033,7 +1027,7 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
     }
     // ---- O' partial: oacc[ri][r] = O'(i = 4 g + r, f = l15) of subtile ri
     if (WITH_GRAD) {
-        float *op = O_partial + int64_t(by) * n * DP;
+        float *op = O_partial + op_slot * n * DP;
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri)
 #pragma unroll
@@ -1042,6 +1036,8 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
                 if (i < n) op[i * DP + l15] = oacc[ri][r];
             }
     }
+    if (F16 && flag_mode == 1 && out_of_range) atomicExch(range_flag, ticket);
+    if (BAL) return;
     double la = sumA * 0.69314718055994531, ll = sumL;     // sum |y| / log2(e) = sum |x|
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { la += __shfl_down(la, off, 64); ll += __shfl_down(ll, off, 64); }
@@ -1051,16 +1047,82 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
         loss_partial[2 * lp_index + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
         loss_partial[2 * lp_index + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
-    if (F16 && flag_mode == 1 && out_of_range) atomicExch(range_flag, ticket);
   };
-    if constexpr (PERSIST) {
+  // the (panel bx, column chunk by) unit of the 2-D grid
+  auto unit_xy = [&](const unsigned bx, const unsigned by) {
+    if (bx >= n_panels) {   // the extra block column: column sums of Zt for the kernels that follow
+        if (by == 0)
+            bce_colsum_block(colsum_partial, n_prep_blocks, DP, S, S_all_f, reinterpret_cast<double *>(&MR[0][0][0]));
+        return;
+    }
+    const int64_t col_begin = SYM_PR * int64_t(bx) + int64_t(by) * cols_per_chunk;
+    const int64_t lp_index = int64_t(by) * n_panels + bx;
+    if (col_begin >= n) {            // chunk beyond this panel's columns
+        if (threadIdx.x == 0) { loss_partial[2 * lp_index] = 0.0; loss_partial[2 * lp_index + 1] = 0.0; }
+        return;
+    }
+    const int64_t ce = col_begin + cols_per_chunk;
+    unit(bx, col_begin, ce > n ? n : ce, by, lp_index);
+  };
+    if constexpr (BAL) {
+        // ---- BALANCED schedule (round 6): the column tiles of all panels form ONE sequence (panel-major; panel I has
+        //      NT - TPP I tiles, NT = NP / 64); block b takes tiles [b tpb, (b + 1) tpb) of it -- every block the same number
+        //      of tiles, all blocks resident at once (grid = 2 or 3 per CU), none waits for a second round.  A block's share
+        //      of panel I is one unit; its O' partial goes to slot (b - first block of panel I): a panel has
+        //      <= tiles / tpb + 2 partials (Pubmed <= 11, mean 5; a ZINC batch 4) where the 2-D grid wrote up to 29.
+        //      One loss partial per block.  The last block of the grid does the column sums.
+        if (blockIdx.x + 1 == gridDim.x) {
+            bce_colsum_block(colsum_partial, n_prep_blocks, DP, S, S_all_f, reinterpret_cast<double *>(&MR[0][0][0]));
+            return;
+        }
+        // (32-bit tile arithmetic: W < 2^31 for every n whose strips fit the 8 GiB cap)
+        constexpr int TPP = SYM_PR / 64;
+        const int NT = int((n + 63) / 64), T = int(n_panels);
+        auto prefix = [&](int I) { return I * NT - TPP * (I * (I - 1) / 2); };      // tiles of the panels before I
+        const int W = prefix(T);
+        int t0 = int(blockIdx.x) * bal_tpb, t1 = t0 + bal_tpb;
+        if (t1 > W) t1 = W;
+        if (t0 < t1) {
+            // panel of tile t0: prefix(I) <= t0 < prefix(I + 1) -- from the quadratic's root, then exact
+            const float hb = float(NT) + 0.5f * float(TPP);
+            int I = int((hb - sqrtf(fmaxf(hb * hb - 2.0f * float(TPP) * float(t0), 0.0f))) / float(TPP));
+            if (I < 0) I = 0;
+            if (I > T - 1) I = T - 1;
+            I = __builtin_amdgcn_readfirstlane(I);     // (the float root left it in a vector register: everything derived
+                                                       //  from it -- column range, strip pointer, slot -- would follow)
+            while (I > 0 && prefix(I) > t0) --I;
+            while (I + 1 < T && prefix(I + 1) <= t0) ++I;
+            while (t0 < t1) {
+                const int pI = prefix(I), tiles = NT - TPP * I;
+                const int lt = t0 - pI;
+                int cnt = tiles - lt;
+                if (cnt > t1 - t0) cnt = t1 - t0;
+                const int64_t cb = int64_t(SYM_PR) * I + int64_t(lt) * 64;
+                int64_t ce = cb + int64_t(cnt) * 64;
+                if (ce > n) ce = n;
+                if (cb < n) unit(I, cb, ce, int(blockIdx.x) - int(unsigned(pI) / unsigned(bal_tpb)), -1);
+                __syncthreads();                   // the next unit reuses the LDS tiles
+                t0 += cnt; ++I;
+            }
+        }
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        double la = sumA * 0.69314718055994531, ll = sumL;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { la += __shfl_down(la, off, 64); ll += __shfl_down(ll, off, 64); }
+        if (lane == 0) { red[wave][0] = la; red[wave][1] = ll; }
+        __syncthreads();
+        if (tid == 0) {
+            loss_partial[2 * blockIdx.x + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+            loss_partial[2 * blockIdx.x + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        }
+    } else if constexpr (PERSIST) {
         const unsigned nx = n_panels + 1, total = nx * n_chunks;
         for (unsigned u = blockIdx.x; u < total; u += gridDim.x) {
-            unit(u % nx, u / nx);
+            unit_xy(u % nx, u / nx);
             __syncthreads();                       // the next unit reuses the LDS tiles
         }
     } else {
-        unit(blockIdx.x, blockIdx.y);
+        unit_xy(blockIdx.x, blockIdx.y);
     }
 }
 
@@ -1196,8 +1258,14 @@ __global__ __launch_bounds__(256) void bce_edges_kernel(
         const float *op = O_partial + i * DP + f0;
         const int64_t sstride = n * DP;
         if (O_mirror) {     // symmetric dense kernel: row i's panel wrote ceil((n - panel start) / chunk) partials
-            const int64_t rem = n - (i / SYM_PR) * SYM_PR;
-            n_splits = int((rem + sym_cols_per_chunk - 1) / sym_cols_per_chunk);
+            if (sym_cols_per_chunk < 0) {      // balanced schedule, -sym_cols_per_chunk column tiles per block: the blocks
+                const int64_t tpb = -sym_cols_per_chunk, I = i / SYM_PR, TPP = SYM_PR / 64, NT = (n + 63) / 64;   // that hold tiles of panel I
+                const int64_t pI = I * NT - TPP * (I * (I - 1) / 2), pI1 = pI + NT - TPP * I;
+                n_splits = int((pI1 - 1) / tpb - pI / tpb + 1);
+            } else {
+                const int64_t rem = n - (i / SYM_PR) * SYM_PR;
+                n_splits = int((rem + sym_cols_per_chunk - 1) / sym_cols_per_chunk);
+            }
             osum = fold ? *reinterpret_cast<const f32x4 *>(&Om[(tid / LPR) * 20 + f0])
                         : *reinterpret_cast<const f32x4 *>(O_mirror + i * DP + f0);
         }
@@ -1388,6 +1456,8 @@ struct BcePlan {
     double pad_terms;
     bool sym;                     // symmetric dense kernel (full square, d <= 16, bf16x3 products)
     int sym_pr;                   // its panel height (rows)
+    int bal_tpb;                  // balanced schedule: column tiles per block (0 = the 2-D grid)
+    int64_t bal_blocks;           // ... and the blocks that have tiles
     int64_t wmir_bytes, omir_bytes;
 };
 
@@ -1427,10 +1497,19 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     // Symmetric form: every tile right of the block diagonal is evaluated once for both halves.
     p.sym = false;
     p.sym_pr = 128;
+    p.bal_tpb = 0;
+    p.bal_blocks = 0;
     p.wmir_bytes = p.omir_bytes = 0;
+    // balanced schedule (round 6): every block the same number of column tiles, one resident round.  It removes the
+    // quantisation of the 2-D grid into rounds of blocks, which is what kept 256-row panels from paying below ~32 k rows:
+    // with it they win from ~5 k rows on (whole loss sequence, 2-D grid + 128-row panels -> balanced + 256-row panels:
+    // N = 8000 63.3 -> 53.8 us, Pubmed 161.8 -> 144.4 us, 26 k 247.7 -> 220.8 us, 40 k 521.8 -> 466.4 us; N = 5000 43.7 ->
+    // 42.5 us; below that the full-square kernel wins: N = 3327 32.7 vs 37.3 us).  Launches of ten rounds and more keep the
+    // 2-D grid (N = 95 k: 2470 vs 2520 us -- the balanced instantiation of the 256-row kernel spills 4 VGPRs).
+    const bool bal = g_bce_sym_bal == 2 || (g_bce_sym_bal == 1 && n < 65536);
     if (g_bce_sym && n_local == n && p.KS == 1 && g_bce_s_bf16 && g_bce_pv_bf16 &&
-        n >= (g_bce_sym > 1 ? 512 : 8192)) {           // below ~8 k rows the extra launch costs more than it saves
-        const int64_t SYM_PR = (g_bce_sym_ri == 4 || (g_bce_sym_ri == 0 && n >= 32768)) ? 256 : 128;
+        n >= (g_bce_sym > 1 ? 512 : (bal ? 5120 : 8192))) {   // below that the extra launch costs more than it saves
+        const int64_t SYM_PR = (g_bce_sym_ri == 4 || (g_bce_sym_ri == 0 && (n >= 32768 || bal))) ? 256 : 128;
         p.sym_pr = int(SYM_PR);
         const int64_t T = (n + SYM_PR - 1) / SYM_PR, NP = (n + 63) / 64 * 64;
         int64_t chunks = (g_bce_sym_grid + T - 1) / T; // half of the (panel, chunk) grid is live
@@ -1473,6 +1552,23 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
             p.pad_terms = 0.0;                         // padded columns are corrected inside the kernel
             p.wmir_bytes = align256(wfloats * 4);
             p.omir_bytes = align256(n * 16 * 4);
+            if (bal) {
+                // balanced schedule (see the kernel): one sequence of W column tiles, tpb of them per block, all blocks
+                // resident at once; n_splits = the most partials any panel gets (the edge kernel derives a row's count
+                // from the same integers)
+                const int64_t TPP = SYM_PR / TJ, NT = NP / TJ;
+                auto prefix = [&](int64_t I) { return I * NT - TPP * (I * (I - 1) / 2); };
+                const int64_t W = prefix(T), slots = int64_t(kChipCus) * (SYM_PR == 128 ? 3 : 2);
+                const int64_t tpb = (W + slots - 1) / slots;
+                int64_t most = 1;
+                for (int64_t I = 0; I < T; ++I) {
+                    const int64_t pieces = (prefix(I + 1) - 1) / tpb - prefix(I) / tpb + 1;
+                    if (pieces > most) most = pieces;
+                }
+                p.bal_tpb = int(tpb);
+                p.bal_blocks = (W + tpb - 1) / tpb;
+                p.n_splits = most;
+            }
         }
     }
     p.o_bytes = align256(p.n_splits * n_local * p.DP * 4);
@@ -1480,7 +1576,7 @@ bool bce_plan(int64_t n, int64_t n_local, int64_t d, bool vec_ok, BcePlan &p)
     p.zh_bytes = align256(n * p.DP * 2);
     p.cs_bytes = align256(((n + 15) / 16 + 1) * 2 * p.DP * 8);    // up to one partial per 16 rows (a producer kernel's blocks: gae_x_gcn_layer_fused_prep)
     p.s_bytes = align256(2 * p.DP * 8 + p.DP * 4 + 4 * 8);       // column sums (double x 2, float) + 3 scalars
-    p.n_dense = p.row_blocks * p.n_splits;
+    p.n_dense = p.bal_tpb ? p.bal_blocks : p.row_blocks * p.n_splits;
     p.total_bytes = p.o_bytes + p.zt_bytes + 2 * p.zh_bytes + p.cs_bytes + p.s_bytes +
                     align256((2 * p.n_dense + p.edge_blocks) * 8) + p.wmir_bytes + p.omir_bytes;
     return true;
@@ -1545,7 +1641,7 @@ int launch_edges(const BcePlan &p, const float *Zt, const float *mask, int64_t l
 #define GAE_EDGE(LPR)                                                                                              \
     hipLaunchKernelGGL((bce_edges_kernel<VEC, LPR, WITH_GRAD>), dim3(unsigned(p.edge_blocks)), dim3(256), 0, s, Zt, \
                        mask, ldz, row_begin, n, d, ip, ix, tp, tx, pw, inv_n2, O, int(p.n_splits), p.DP, S_all_f,  \
-                       dZ, lddz, lp, Omir, p.cols_per_split, p.sym_pr, counts, scal, Wmir, range_flag)
+                       dZ, lddz, lp, Omir, (p.bal_tpb ? -int64_t(p.bal_tpb) : p.cols_per_split), p.sym_pr, counts, scal, Wmir, range_flag)
     switch (p.LPR) {
     case 1: GAE_EDGE(1); break;
     case 2: GAE_EDGE(2); break;
@@ -1567,6 +1663,7 @@ Knob *bce_knob(const char *name)
     if (strcmp(name, "bce_s_bf16") == 0) return &g_bce_s_bf16;
     if (strcmp(name, "bce_pv_bf16") == 0) return &g_bce_pv_bf16;
     if (strcmp(name, "bce_sym") == 0) return &g_bce_sym;
+    if (strcmp(name, "bce_sym_bal") == 0) return &g_bce_sym_bal;
     if (strcmp(name, "bce_last_kind") == 0) return &g_bce_last_kind;
     if (strcmp(name, "bce_sym_grid") == 0) return &g_bce_sym_grid;
     if (strcmp(name, "bce_grid") == 0) return &g_bce_grid;
@@ -1659,24 +1756,28 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
     int rc;
     g_bce_last_kind = p.sym ? (p.sym_pr == 256 ? 3 : 2) : 1;
     if (p.sym) {
-        const dim3 grid(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));   // + 1: the column-sum block
+        // 2-D grid: + 1 block column for the column sums; balanced schedule: 1-D, + 1 block for them
+        const dim3 grid = p.bal_tpb ? dim3(unsigned(p.bal_blocks) + 1) : dim3(unsigned(p.row_blocks) + 1, unsigned(p.n_splits));
         static std::atomic<unsigned> call_counter{0};
         const unsigned ticket = (call_counter.fetch_add(1) * 2654435761u) | 0x80000001u;    // never 0 (= cleared)
         // fp16 pieces (knob bce_s_bf16 = 3, the default): the F16 launch reports out-of-range embeddings through
         // range_flag, the three-piece bf16 launch behind it runs only then (see the kernel)
 #define GAE_SYM3(WG, R, T, S3V, F16V, FM, PERS, GRID)                                                                \
-    hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R, T, S3V, F16V, PERS>), GRID, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
+    do { if (p.bal_tpb) GAE_SYM4(WG, R, T, S3V, F16V, FM, false, true, GRID); else GAE_SYM4(WG, R, T, S3V, F16V, FM, PERS, false, GRID); } while (0)
+#define GAE_SYM4(WG, R, T, S3V, F16V, FM, PERS, BALV, GRID)                                                          \
+    hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R, T, S3V, F16V, PERS, BALV>), GRID, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
                        lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks),                                    \
                        g_bce_strip_store >= 0 ? g_bce_strip_store : (n >= 32768 ? 1 : 0), range_flag, FM, ticket,  \
-                       unsigned(p.n_splits))
+                       unsigned(p.n_splits), p.bal_tpb)
 #define GAE_SYM(WG, R, T) do { if (g_bce_s_bf16 == 4) GAE_SYM3(WG, R, T, false, true, 0, false, grid);   /* experiments: fp16 pieces WITHOUT the range guard */ \
-    else if (g_bce_s_bf16 >= 3) { GAE_SYM3(WG, R, T, false, true, 1, false, grid); GAE_SYM3(WG, R, T, true, false, 2, true, dim3(2 * kChipCus)); } \
+    else if (g_bce_s_bf16 >= 3) { GAE_SYM3(WG, R, T, false, true, 1, false, grid); GAE_SYM3(WG, R, T, true, false, 2, true, (p.bal_tpb ? grid : dim3(2 * kChipCus))); } \
     else if (g_bce_s_bf16 == 2) GAE_SYM3(WG, R, T, true, false, 0, false, grid); else GAE_SYM3(WG, R, T, false, false, 0, false, grid); } while (0)
         if (!dZ) { if (p.sym_pr == 256) GAE_SYM(false, 4, false); else GAE_SYM(false, 2, false); }
         else if (g_bce_sym_tr) { if (p.sym_pr == 256) GAE_SYM(true, 4, true); else GAE_SYM(true, 2, true); }
         else { if (p.sym_pr == 256) GAE_SYM(true, 4, false); else GAE_SYM(true, 2, false); }
 #undef GAE_SYM
 #undef GAE_SYM3
+#undef GAE_SYM4
         GAE_CHECK_LAUNCH("bce_dense_sym_kernel");
         if (dZ && !(g_bce_fold_mirror && p.LPR == 4)) {     // otherwise the edge kernel folds the strips itself
             hipLaunchKernelGGL(bce_mirror_reduce_kernel, dim3(unsigned((n + TJ - 1) / TJ)), dim3(256), 0, s, Wmir, n,

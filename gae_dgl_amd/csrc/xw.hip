@@ -744,6 +744,10 @@ int xw_fwd_launch(const void *X, int64_t ldx, int64_t n, int K, int elem, const 
     a.w_bytes = unsigned(((int64_t(J) - 1) * ldw + K) * 4);
     a.tiles_per_block = p.tiles_per_block; a.k_per_block = p.k_per_block;
     a.stamps = reinterpret_cast<unsigned long long *>((uint64_t(uint32_t(int(g_xw_stamps_hi))) << 32) | uint32_t(int(g_xw_stamps)));
+    if (g_xw_dbg == 3 && a.stamps == nullptr) {      // the stamping variant writes through this pointer
+        set_error("xw_fwd: xw_dbg=3 (s_memtime stamps) needs the stamp buffer's address in xw_stamps / xw_stamps_hi");
+        return GAE_E_NULL;
+    }
     if (p.splits > 1) { a.bias = nullptr; a.act = GAE_ACT_IDENTITY; a.out = static_cast<float *>(ws); a.ldo = J; a.split_stride = n * J; }
     else { a.bias = bias; a.act = act; a.out = out; a.ldo = ldo; a.split_stride = 0; }
     const dim3 grid(unsigned(p.row_blocks), unsigned(p.splits)), block(unsigned(64 * p.nw));

@@ -1,4 +1,4 @@
-/* gae_hip_experimental.h -- the SEAMS of libgae_hip.so that its own host mirror (gae_dgl_amd/ops.py, capture.py,
+/* gae_hip_experimental.h -- the SEAMS of libgae_hip.so that its own host mirror (gae_dgl_amd/ops/, capture.py,
  * sparse.py, parallel.py) uses to fuse launches, build plans and defer reductions.  A maintainer who binds the library
  * behind the reference's call sites needs gae_hip.h only; nothing here changes a result -- every entry
  * point is a faster composition of, or a set-up step for, an entry point of gae_hip.h:

@@ -27,7 +27,7 @@ def test_padded_loss_matches_unpadded(dropout, sym, tuning):
     gradient 1e-5 of its scale; padding rows get an exactly zero gradient) and == the fp64 oracle"""
     from gae_dgl_amd import ops
     from oracle import gae_oracle as O
-    tuning("bce_sym", sym)            # 2: the symmetric dense kernel already from 512 rows on (default: 8192)
+    tuning("bce_sym", sym)            # 2: the symmetric dense kernel already from 512 rows on (default: 5120)
     ds, _ = _dataset()
     ids = np.arange(40, 104)
     bg = ds.batch(ids)

@@ -741,7 +741,7 @@ def test_gae_three_adam_steps(golden, dev):
 
 @pytest.mark.parametrize("n,captured", [(1500, False), (8300, True)])
 def test_training_trajectory_matches_cpu_reference_step(n, captured, dev):
-    """12 full training steps (encoder, fused loss -- full-square below 8192 rows, symmetric above --, backward,
+    """12 full training steps (encoder, fused loss -- full-square below 5120 rows, symmetric above --, backward,
     one-launch Adam; eagerly or replayed from the captured HIP graph) against oracle.CpuReferenceStep, the
     reference step in plain PyTorch CPU with torch.optim.Adam: same loss trajectory, same final weights"""
     import gae_dgl_amd as G
@@ -857,7 +857,8 @@ def test_fused_loss_vs_oracle_random(n, d, e, dev):
 
 @pytest.mark.parametrize("n,d", [(512, 16), (513, 16), (700, 7), (1000, 3), (1025, 16), (4096, 16), (5000, 12),
                                  (8193, 16)])
-def test_fused_loss_symmetric_kernel(n, d, dev):
+@pytest.mark.parametrize("bal", [2, 0])
+def test_fused_loss_symmetric_kernel(n, d, bal, dev):
     """symmetric dense kernel (tiles right of the block diagonal evaluated once, mirror product, strip reduction)
     == the full-square kernel == the oracle; panels / tiles / chunks with tails in every dimension"""
     import gae_dgl_amd as G
@@ -868,9 +869,10 @@ def test_fused_loss_symmetric_kernel(n, d, dev):
     mask = ((rng.random((n, d)) >= 0.1) / 0.9).astype(np.float32)
     gr = G.DGLGraph((src, dst), num_nodes=n).to(dev)
     out = {}
-    for sym in (2, 0):                       # 2 = symmetric kernel from 512 rows on (default: from 8192)
+    for sym in (2, 0):                       # 2 = symmetric kernel from 512 rows on (default: from 5120)
         _lib.call("gae_tuning_set", b"bce_sym", sym)
         _lib.call("gae_tuning_set", b"bce_sym_ri", 4 if n % 2 else 2)      # both panel heights across the cases
+        _lib.call("gae_tuning_set", b"bce_sym_bal", bal)                    # balanced schedule (round 6) / the 2-D grid
         try:
             Zd = t(Z, dev).requires_grad_(True)
             loss = ops.decoder_bce(Zd, t(mask, dev), gr)
@@ -882,6 +884,7 @@ def test_fused_loss_symmetric_kernel(n, d, dev):
         finally:
             _lib.call("gae_tuning_set", b"bce_sym", 1)
             _lib.call("gae_tuning_set", b"bce_sym_ri", 0)
+            _lib.call("gae_tuning_set", b"bce_sym_bal", 1)
     assert rel_err(out[2][0], out[0][0].double().cpu()) < 2e-6
     assert rel_err(out[2][1], out[0][1].double().cpu()) < TOL
     assert rel_err(out[2][2], out[0][0].double().cpu()) < 2e-6
@@ -915,8 +918,9 @@ def test_fused_loss_fuzz(seed, dev):
     ref = O().bce_with_logits_mean(O().decoder_logits(Zt, mk), adj, O().pos_weight_of(adj))
     ref.backward()
     gr = G.DGLGraph((src, dst), num_nodes=n).to(dev)
-    sym = int(rng.choice([0, 1, 2])); sri = int(rng.choice([0, 2, 4]))
+    sym = int(rng.choice([0, 1, 2])); sri = int(rng.choice([0, 2, 4])); bal = int(rng.choice([0, 1, 2]))
     _lib.call("gae_tuning_set", b"bce_sym", sym); _lib.call("gae_tuning_set", b"bce_sym_ri", sri)
+    _lib.call("gae_tuning_set", b"bce_sym_bal", bal)
     try:
         Zd = t(Z, dev).requires_grad_(True)
         loss = ops.decoder_bce(Zd, None if mask is None else t(mask, dev), gr)
@@ -925,7 +929,8 @@ def test_fused_loss_fuzz(seed, dev):
             loss_only = ops.decoder_bce(t(Z, dev), None if mask is None else t(mask, dev), gr)
     finally:
         _lib.call("gae_tuning_set", b"bce_sym", 1); _lib.call("gae_tuning_set", b"bce_sym_ri", 0)
-    assert rel_err(loss, ref) < TOL and rel_err(loss_only, ref) < TOL, (n, d, e, sym, sri)
+        _lib.call("gae_tuning_set", b"bce_sym_bal", 1)
+    assert rel_err(loss, ref) < TOL and rel_err(loss_only, ref) < TOL, (n, d, e, sym, sri, bal)
     assert rel_err(Zd.grad, Zt.grad) < 5 * TOL, (n, d, e, sym, sri)
 
 

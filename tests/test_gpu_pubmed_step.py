@@ -3,7 +3,7 @@ configs[1], 19 717 nodes x 500 features, hidden 32 / 16 -- against the oracle at
 
 The step (train_transductive.py:41-68 on gae.py:26-31,49-55) as the library runs it by default: gae_xw_fwd (P = X W1^T)
 -> gae_spmm_csr_epilogue (relu(A P + b1)) -> the fused narrow layer 2 with the loss's prepare step in its epilogue ->
-the symmetric fused decoder + BCE kernel (128-row panels) -> ReLU-gated gather of the backward aggregation ->
+the symmetric fused decoder + BCE kernel (256-row panels, balanced schedule) -> ReLU-gated gather of the backward aggregation ->
 gae_xw_wgrad -> Adam.  The oracle evaluates the SAME step in fp64 in the reference's order ((A X) W^T), the N x N part
 1024 rows at a time (oracle.gae_loss_and_grads_windowed, pinned against the reference-generated vectors by
 tests/test_oracle_golden.py): Z on all rows, the loss, every parameter gradient, then three Adam steps of the captured
@@ -71,7 +71,7 @@ def calls_since(before):
 
 def assert_default_kernels(delta):
     """the launches of the default wide-layer step: one-pass X W^T, epilogue SpMM forward and (ReLU-gated) backward,
-    one-pass dW1, the symmetric loss kernel with 128-row panels"""
+    one-pass dW1, the symmetric loss kernel (256-row panels, balanced schedule)"""
     from gae_dgl_amd import _lib
     assert delta.get("gae_xw_fwd", 0) == 1, delta
     assert delta.get("gae_spmm_csr_epilogue", 0) == 2, delta          # relu(A P + b1); G = gate(A^T dM2)
@@ -79,7 +79,7 @@ def assert_default_kernels(delta):
     assert delta.get("gae_x_gcn_layer_fused_prep", 0) == 1, delta     # layer 2 + the loss's prepare step
     assert delta.get("gae_x_decoder_bce_prepared", 0) == 1, delta
     assert "gae_spmm_csr" not in delta and "gae_linear_fwd" not in delta, delta   # no F = 500 aggregation, no separate Linear
-    assert _lib.tuning_get("bce_last_kind") == 2, "the loss did not run on the symmetric 128-row-panel kernel"
+    assert _lib.tuning_get("bce_last_kind") == 3, "the loss did not run on the symmetric kernel (256-row panels)"
 
 
 @pytest.mark.parametrize("degrees", ["uniform", "planetoid"])

@@ -126,7 +126,7 @@ def test_loss_fp16_pieces_match_fp64_and_fall_back_beyond_their_range():
     gscale = float(Zt.grad.abs().max())
     Zbig = Z.copy()
     Zbig[7, 3] = 1.0e5; Zbig[n - 1, 15] = -3.0e5; Zbig[700, 0] = 7.0e4      # > 65504: no fp16 value
-    _lib.call("gae_tuning_set", b"bce_sym", 2)            # the symmetric kernel from 512 rows on (default: 8192)
+    _lib.call("gae_tuning_set", b"bce_sym", 2)            # the symmetric kernel from 512 rows on (default: 5120)
     try:
         l1, g1 = _loss_and_grad(Z, g)
         assert abs(l1 - float(ref)) <= 1e-6 * abs(float(ref))

@@ -307,11 +307,11 @@ def test_xw_fwd_every_knob_setting_launches_a_kernel_or_errors(p3, tuning):
                 try:
                     P = ops.xw_fwd_raw(Xp, W, None, 0)
                 except _lib.GaeHipError as e:
-                    assert "knob combination" in str(e)
+                    assert "knob combination" in str(e) or (dbg == 3 and "stamp buffer" in str(e)), str(e)
                     refused += 1
                     continue
                 launched += 1
                 if dbg == 0:
                     assert rel(P, P0) < 2e-6, (dbg, depth, tc)
     tuning("xw_dbg", 0); tuning("xw_depth", 0); tuning("xw_tc", 0)
-    assert launched > 0 and (refused > 0) == (p3 == 1)
+    assert launched > 0 and refused > 0

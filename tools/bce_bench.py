@@ -41,6 +41,7 @@ for rnd in range(a.rounds + 1):
         _lib.call("gae_tuning_set", b"bce_strip_store", int(kv.get("strip", -1)))
         _lib.call("gae_tuning_set", b"bce_fold_mirror", int(kv.get("fold", 1)))
         _lib.call("gae_tuning_set", b"bce_sym_tr", int(kv.get("tr", 1)))
+        _lib.call("gae_tuning_set", b"bce_sym_bal", int(kv.get("bal", 1)))
         fn = lambda: ops.decoder_bce_raw(Z, mask, g.csr(), g.csc(), pw, True)
         loss, dz = fn(); torch.cuda.synchronize()
         if rnd == 0:
