@@ -1070,17 +1070,22 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
         //      of tiles, all blocks resident at once (grid = 2 or 3 per CU), none waits for a second round.  A block's share
         //      of panel I is one unit; its O' partial goes to slot (b - first block of panel I): a panel has
         //      <= tiles / tpb + 2 partials (Pubmed <= 11, mean 5; a ZINC batch 4) where the 2-D grid wrote up to 29.
-        //      One loss partial per block.  The last block of the grid does the column sums.
-        if (blockIdx.x + 1 == gridDim.x) {
+        //      One loss partial per block.  The last (virtual) block does the column sums.
+        // Virtual blocks: the launch that does the work has one block per tile range (+ 1: the column sums); the fp16 range
+        // guard's fallback launch walks the same ranges with a few blocks (it returns at once unless the guard fired).
+        const unsigned n_vb = n_chunks;
+        auto vblock = [&](const unsigned vb) {
+        if (vb + 1 == n_vb) {
             bce_colsum_block(colsum_partial, n_prep_blocks, DP, S, S_all_f, reinterpret_cast<double *>(&MR[0][0][0]));
             return;
         }
+        sumA = 0.0; sumL = 0.0;
         // (32-bit tile arithmetic: W < 2^31 for every n whose strips fit the 8 GiB cap)
         constexpr int TPP = SYM_PR / 64;
         const int NT = int((n + 63) / 64), T = int(n_panels);
         auto prefix = [&](int I) { return I * NT - TPP * (I * (I - 1) / 2); };      // tiles of the panels before I
         const int W = prefix(T);
-        int t0 = int(blockIdx.x) * bal_tpb, t1 = t0 + bal_tpb;
+        int t0 = int(vb) * bal_tpb, t1 = t0 + bal_tpb;
         if (t1 > W) t1 = W;
         if (t0 < t1) {
             // panel of tile t0: prefix(I) <= t0 < prefix(I + 1) -- from the quadratic's root, then exact
@@ -1100,7 +1105,7 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
                 const int64_t cb = int64_t(SYM_PR) * I + int64_t(lt) * 64;
                 int64_t ce = cb + int64_t(cnt) * 64;
                 if (ce > n) ce = n;
-                if (cb < n) unit(I, cb, ce, int(blockIdx.x) - int(unsigned(pI) / unsigned(bal_tpb)), -1);
+                if (cb < n) unit(I, cb, ce, int(vb) - int(unsigned(pI) / unsigned(bal_tpb)), -1);
                 __syncthreads();                   // the next unit reuses the LDS tiles
                 t0 += cnt; ++I;
             }
@@ -1112,8 +1117,17 @@ __global__ __launch_bounds__(256, (RI == 2 && !PERSIST) ? 3 : 2) void bce_dense_
         if (lane == 0) { red[wave][0] = la; red[wave][1] = ll; }
         __syncthreads();
         if (tid == 0) {
-            loss_partial[2 * blockIdx.x + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-            loss_partial[2 * blockIdx.x + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+            loss_partial[2 * vb + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+            loss_partial[2 * vb + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        }
+        };
+        if constexpr (PERSIST) {                       // (the guard's fallback launch: a few blocks walk all the ranges)
+            for (unsigned vb = blockIdx.x; vb < n_vb; vb += gridDim.x) {
+                vblock(vb);
+                __syncthreads();                       // red and the LDS tiles are reused by the next virtual block
+            }
+        } else {
+            vblock(blockIdx.x);
         }
     } else if constexpr (PERSIST) {
         const unsigned nx = n_panels + 1, total = nx * n_chunks;
@@ -1763,14 +1777,14 @@ int decoder_bce_impl(const float *Z, float *mask, int64_t ldz, int64_t n, int64_
         // fp16 pieces (knob bce_s_bf16 = 3, the default): the F16 launch reports out-of-range embeddings through
         // range_flag, the three-piece bf16 launch behind it runs only then (see the kernel)
 #define GAE_SYM3(WG, R, T, S3V, F16V, FM, PERS, GRID)                                                                \
-    do { if (p.bal_tpb) GAE_SYM4(WG, R, T, S3V, F16V, FM, false, true, GRID); else GAE_SYM4(WG, R, T, S3V, F16V, FM, PERS, false, GRID); } while (0)
+    do { if (p.bal_tpb) GAE_SYM4(WG, R, T, S3V, F16V, FM, PERS, true, GRID); else GAE_SYM4(WG, R, T, S3V, F16V, FM, PERS, false, GRID); } while (0)
 #define GAE_SYM4(WG, R, T, S3V, F16V, FM, PERS, BALV, GRID)                                                          \
     hipLaunchKernelGGL((bce_dense_sym_kernel<WG, R, T, S3V, F16V, PERS, BALV>), GRID, dim3(256), 0, s, Zt, Zhi, Zlo, n, p.cols_per_split, O, Wmir, \
                        lp, cs, p.prep_blocks, S, S_all_f, unsigned(p.row_blocks),                                    \
                        g_bce_strip_store >= 0 ? g_bce_strip_store : (n >= 32768 ? 1 : 0), range_flag, FM, ticket,  \
-                       unsigned(p.n_splits), p.bal_tpb)
+                       (p.bal_tpb ? unsigned(p.bal_blocks) + 1u : unsigned(p.n_splits)), p.bal_tpb)
 #define GAE_SYM(WG, R, T) do { if (g_bce_s_bf16 == 4) GAE_SYM3(WG, R, T, false, true, 0, false, grid);   /* experiments: fp16 pieces WITHOUT the range guard */ \
-    else if (g_bce_s_bf16 >= 3) { GAE_SYM3(WG, R, T, false, true, 1, false, grid); GAE_SYM3(WG, R, T, true, false, 2, true, (p.bal_tpb ? grid : dim3(2 * kChipCus))); } \
+    else if (g_bce_s_bf16 >= 3) { GAE_SYM3(WG, R, T, false, true, 1, false, grid); GAE_SYM3(WG, R, T, true, false, 2, true, (p.bal_tpb ? dim3(64) : dim3(2 * kChipCus))); } \
     else if (g_bce_s_bf16 == 2) GAE_SYM3(WG, R, T, true, false, 0, false, grid); else GAE_SYM3(WG, R, T, false, false, 0, false, grid); } while (0)
         if (!dZ) { if (p.sym_pr == 256) GAE_SYM(false, 4, false); else GAE_SYM(false, 2, false); }
         else if (g_bce_sym_tr) { if (p.sym_pr == 256) GAE_SYM(true, 4, true); else GAE_SYM(true, 2, true); }

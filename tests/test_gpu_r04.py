@@ -106,7 +106,8 @@ def _loss_and_grad(Z, g):
     return float(loss.detach()), Zd.grad.detach().cpu()
 
 
-def test_loss_fp16_pieces_match_fp64_and_fall_back_beyond_their_range():
+@pytest.mark.parametrize("bal", [2, 0])
+def test_loss_fp16_pieces_match_fp64_and_fall_back_beyond_their_range(bal, tuning):
     """round 4: where the symmetric dense kernel runs, the products of the fused loss use two fp16 pieces per operand
     (22 mantissa bits).  (a) against the fp64 oracle on embeddings whose large components cancel; (b) embeddings
     outside fp16's range make the SAME call fall back to the three-piece bf16 kernel -- bit-identical to that kernel
@@ -127,6 +128,7 @@ def test_loss_fp16_pieces_match_fp64_and_fall_back_beyond_their_range():
     Zbig = Z.copy()
     Zbig[7, 3] = 1.0e5; Zbig[n - 1, 15] = -3.0e5; Zbig[700, 0] = 7.0e4      # > 65504: no fp16 value
     _lib.call("gae_tuning_set", b"bce_sym", 2)            # the symmetric kernel from 512 rows on (default: 5120)
+    tuning("bce_sym_bal", bal)                            # balanced schedule (the fallback walks its tile ranges with 64 blocks) / 2-D grid
     try:
         l1, g1 = _loss_and_grad(Z, g)
         assert abs(l1 - float(ref)) <= 1e-6 * abs(float(ref))
