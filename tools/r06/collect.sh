@@ -30,6 +30,10 @@ pmc)
   for sh in pubmed500 pubmed32 zincb39; do
     tools/pmc.sh r06c/pmc_$sh tools/spmm_one.py --shape $sh --iters 5 > $O/pmc_$sh.txt
   done
+  # the Pubmed F = 500 aggregation under other XCD feature-tile widths (TCC_HIT / MISS and FETCH_SIZE per variant)
+  for tv in 8 24 -1; do
+    tools/pmc.sh r06c/pmc_pubmed500_tv$tv tools/spmm_one.py --shape pubmed500 --iters 5 --knobs spmm_tile_vecs=$tv > $O/pmc_pubmed500_tv$tv.txt
+  done
   PMC_TIMEOUT=400 tools/pmc.sh r06c/pmc_rmat32 tools/spmm_one.py --shape rmat32 --rmat-scale 24 --iters 3 > $O/pmc_rmat32.txt
   ;;
 losssq)
@@ -43,7 +47,12 @@ micro)
   timeout 300 python tools/bce_bench.py --n 95000 --variants "sri=2,bal=0;sri=2,bal=2;sri=4,bal=0;sri=4,bal=2" --rounds 3 2>/dev/null > $O/bce_bench_zinc.txt
   timeout 600 python tools/r06/spmm_tile_sweep.py --shape pubmed 2>/dev/null > $O/spmm_tile_sweep_pubmed.txt
   timeout 600 python tools/r06/spmm_tile_sweep.py --shape cora --tiles 0,8,16,32,64,-1 --stores -1 2>/dev/null > $O/spmm_tile_sweep_cora.txt
-  timeout 900 python tools/r06/rmat_windows.py 2>/dev/null > $O/rmat_windows.txt
+  [ -s $O/rmat_windows.txt ] || timeout 900 python tools/r06/rmat_windows.py 2>/dev/null > $O/rmat_windows.txt
   ;;
 esac
 done
+# gpurun copies back at most 64 MiB: the per-dispatch traces are not needed (the stats tables are)
+find $O $R/gpurun_out/r06 -name "*kernel_trace.csv" -delete 2>/dev/null
+find $O $R/gpurun_out/r06 -name "*.db" -delete 2>/dev/null
+find $R/gpurun_out/r06 -name "*counter_collection.csv" -size +4M -delete 2>/dev/null
+du -sh $O
