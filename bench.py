@@ -165,7 +165,7 @@ def parse():
 def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/pmc_traffic_r02.json, else _r01: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)."""
-    for name in ("pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic_r01.json"):
+    for name in ("pmc_traffic_r06.json", "pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic_r01.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get(key, {}).get("hbm_bytes_per_launch")

@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
-if TAG in ("r04c", "r05c"):          # rounds 4, 5 collect into gpurun_out/r0Nc; files are r0N_*
+if TAG in ("r04c", "r05c", "r06c"):  # rounds 4-6 collect into gpurun_out/r0Nc; files are r0N_*
     TAG = TAG[:3]
 DST = os.path.join(ROOT, "profiles")
 
@@ -58,7 +58,8 @@ for w in ("pubmed", "cora", "citeseer", "vgae", "zinc", "zinc128", "rmat"):
     if os.path.exists(st):
         shutil.copy(st, os.path.join(DST, f"{TAG}_{w}_step_kernel_stats.csv"))
         shutil.copy(os.path.join(SRC, f"{w}_step_kernel_stats_top.txt"), os.path.join(DST, f"{TAG}_{w}_step_kernel_stats_top.txt"))
-for f in ("spx_bench.txt", "tall_bench.txt", "xtg_probe.txt", "zinc_l1.txt", "loss_condition.txt", "bce_bench_cora.txt", "plan_build_time.txt", "xw_bench.txt", "xw_sweep_pubmed.txt", "linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt", "bce_bench_zinc.txt",
+for f in ("loss_sq.txt", "probe_wave_spec_overlap.txt", "bce_bench_sizes.txt", "spmm_tile_sweep_pubmed.txt", "spmm_tile_sweep_cora.txt",
+          "rmat_windows.txt", "spx_bench.txt", "tall_bench.txt", "xtg_probe.txt", "zinc_l1.txt", "loss_condition.txt", "bce_bench_cora.txt", "plan_build_time.txt", "xw_bench.txt", "xw_sweep_pubmed.txt", "linear_bench.txt", "spmm_bench_pubmed.txt", "spmm_bench_diag.txt", "bce_bench_pubmed.txt", "bce_bench_zinc.txt",
           "probe_gather_l2.txt", "probe_gather_l2b.txt", "probe_valu_rate.txt", "probe_inst_cost.txt",
           "probe_mfma32_check.txt"):
     if os.path.exists(os.path.join(SRC, f)):
@@ -71,7 +72,9 @@ traffic = {"_how": "rocprofv3 --pmc, one counter set per pass (tools/pmc.sh: FET
                    "package launches them).  FETCH_SIZE is in KiB and doubled as MI355X_MICROARCH.md prescribes for "
                    "16-B/lane coalesced reads on gfx950 (calibrated on the zinc-250k F=32 launch, whose compulsory "
                    "read bytes are known); WRITE_SIZE is used as reported (matches the output bytes to 0.1 %)."}
-shapes = {"pubmed500": ("pubmed-F500", "pubmed", 500), "pubmed500_plain": ("pubmed-F500-untiled", "pubmed", 500),
+shapes = {"pubmed500": ("pubmed-F500", "pubmed", 500), "pubmed500_tv8": ("pubmed-F500-tile_vecs8", "pubmed", 500),
+          "pubmed500_tv24": ("pubmed-F500-tile_vecs24", "pubmed", 500), "pubmed500_tv-1": ("pubmed-F500-tile_vecs-1", "pubmed", 500),
+          "pubmed500_plain": ("pubmed-F500-untiled", "pubmed", 500),
           "pubmed32": ("pubmed-F32", "pubmed", 32), "citeseer3703": ("citeseer-F3703", "citeseer", 3703),
           "cora1433": ("cora-F1433", "cora", 1433), "zincb39": ("zinc-batch4096-F39", "zinc", 39),
           "zinc32": ("zinc250k-F32", "zinc", 32), "zinc39": ("zinc250k-F39-ld40", "zinc", 39),
@@ -131,6 +134,28 @@ for sh, (key, needle, elem) in xw.items():
         shutil.copy(f, os.path.join(dd, f"pass{i}.csv"))
 json.dump(traffic, open(os.path.join(DST, f"pmc_traffic_{TAG}.json"), "w"), indent=1)
 
+if "pubmed" in benches and "roofline_dense" in benches["pubmed"]:
+    b = benches["pubmed"]
+    rows = [("Pubmed A X, F = 500 (reference-order layer 1; the metric's SpMM)", b["roofline"]),
+            ("Pubmed act(A P + b), F = 32 (the default step's aggregation)", b["roofline"]["in_step"]),
+            ("Pubmed xw_fwd P = X W^T (default step, layer 1 forward)", b["roofline_dense"]["xw_fwd"]),
+            ("Pubmed xtg dW1 = G^T X (default step, layer 1 backward)", b["roofline_dense"]["xtg"])]
+    for e in b.get("extra", {}).get("spmm_kernel_only", []):
+        if "frac_cold" in e:
+            rows.append((e["shape"] + f", F = {e['F']}", {"alg_bytes_per_launch": e["alg_bytes"], "avg_launch_us": e["us_per_launch"], "frac": e["frac_hbm_peak"],
+                                                      "avg_launch_us_cold": e.get("avg_launch_us_cold"), "frac_cold": e["frac_cold"],
+                                                      "copy_GBs_cold": e.get("copy_GBs_cold"), "cold_copies": e.get("cold_copies")}))
+    with open(os.path.join(DST, f"{TAG}_cold.txt"), "w") as f:
+        f.write("MALL-warm vs MALL-cold roofline fractions (bench.py, round 6; VERDICT r05 #2b).  warm = back-to-back launches on ONE operand set\n"
+                "(working sets below 256 MB stay in the Infinity Cache between launches, as they do between the replays of the timed region);\n"
+                "cold = the same launch rotating over disjoint operand sets (CSR arrays, plan tables, H / X, outputs) that add up to >= 512 MB, so\n"
+                "every launch reads DRAM.  Same timing method for both: one HIP event pair around a HIP-graph replay; frac = B_alg / t / 8 TB/s.\n"
+                "copy cold = a device copy of the same byte count rotating the same way (GB/s, read + write).\n\n")
+        f.write(f"{'launch':78s} {'B_alg MB':>9s} {'warm us':>8s} {'frac':>6s} {'cold us':>8s} {'frac_cold':>9s} {'copy cold GB/s':>14s} {'sets':>4s}\n")
+        for name, r in rows:
+            cu, fc = r.get("avg_launch_us_cold"), r.get("frac_cold")
+            f.write(f"{name[:78]:78s} {r['alg_bytes_per_launch'] / 1e6:9.1f} {r['avg_launch_us']:8.2f} {r['frac']:6.3f} "
+                    f"{(cu if cu is not None else float('nan')):8.2f} {fc:9.3f} {(r.get('copy_GBs_cold') or float('nan')):14.0f} {str(r.get('cold_copies') or '-'):>4s}\n")
 print("| workload | ms/step | edges/s | dominant launch | us | % of 8 TB/s | CPU port ms/step |")
 print("|---|---|---|---|---|---|---|")
 for name, d in benches.items():
