@@ -24,11 +24,22 @@ A "step" is one pass of the hot path over one batch of synthetic input:
       upstream gradient dZ is a fixed synthetic tensor.  Strong scaling.
 
 value = SpMM edges aggregated per step (forward + backward launches, all ranks)
-/ step time: whole-job, inputs resident in HBM, max over ranks.
-`roofline`  : the step's dominant SpMM launch, HIP-event timed inside the timed
-              region on the launch stream, against SURVEY.md 8(d)'s B_alg.
+/ step time: whole-job, inputs resident in HBM, max over ranks.  `value_spmm_only`
+= the same edges / the HIP-event time of the step's SpMM launches alone.
+`roofline`  : the metric's kernel, the SpMM aggregation, HIP-event timed on the
+              launch stream against SURVEY.md 8(d)'s B_alg.  Pubmed (default): the
+              reference-order layer-1 product A X at F = 500 (what `--layer1 reference`
+              runs inside the step), with `in_step` = the aggregation the default step
+              runs (F = 32).  `frac` = back-to-back launches on one operand set (below
+              256 MB: resident in the Infinity Cache); `frac_cold` = the same launch
+              rotating over >= 512 MB of disjoint operand sets (every launch reads DRAM).
+`roofline_dense`: the dense layer-1 pair of the default step (xw_fwd, xtg), same fields.
+`roofline_step_dominant`: the fused decoder + BCE against the measured issue rate.
 `cpu_baseline`: the CPU oracle's restatement of the same step on this host.
-`extra`     : kernel-only SpMM numbers for the other BASELINE shapes.
+`extra`     : kernel-only SpMM numbers (warm and cold) for the other BASELINE shapes,
+              whole steps of the other single-GPU configurations.
+N > 1: `rccl_ranks`, `preflight` (every collective primitive checked against known
+answers before the workload is built), `comm` (exchange vs SpMM time per step).
 """
 import argparse
 import json
