@@ -76,7 +76,7 @@ __device__ __forceinline__ f32x16 mfma_split3(const s16x8 &ah, const s16x8 &al, 
 // Both products are evaluated TRANSPOSED (D1[j][row], D2[j2][row]): the rows of the tile sit in the lanes, so
 // the accumulator registers of the first product ARE the B operands of the second (step r, half h <-> j = rho(r, h)).
 // ---------------------------------------------------------------------------------------------------------------
-template <int KB>
+template <int KB, int NS = 2>
 __global__ __launch_bounds__(256, 3) void linear2_rows_kernel(const float *__restrict__ A, int64_t lda,
                                                            const float *__restrict__ W1, int64_t ldw1,
                                                            const float *__restrict__ b1, int act1,
@@ -203,17 +203,29 @@ __global__ __launch_bounds__(256, 3) void linear2_rows_kernel(const float *__res
     const int64_t n_tiles = (n + 31) / 32;
     if (t0 >= n_tiles) return;
     const int64_t t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
-    Stage s0, s1;
-    unsigned d1 = dead_of((t0 + 1) * 32), d2;
-    load(s0, t0 * 32, dead_of(t0 * 32));
-    for (int64_t tt = t0; tt < t1; tt += 2) {
-        d2 = dead_of((tt + 2) * 32);
-        if (tt + 1 < t1) load(s1, (tt + 1) * 32, d1);
-        tile(s0, tt * 32);
-        if (tt + 1 >= t1) break;
-        d1 = dead_of((tt + 3) * 32);
-        if (tt + 2 < t1) load(s0, (tt + 2) * 32, d2);
-        tile(s1, (tt + 1) * 32);
+    // Ring of NS stages: NS - 1 tiles of row loads are in flight while one is multiplied; the row id / dead bit of a tile is
+    // requested one tile ahead of its loads.  Round 6 (tools/r06/tall_sq.sh: 38 - 54 % of the fp32 matrix pipe, the waves parked
+    // at s_waitcnt for 35 - 50 % of their time): scheduling barriers keep the next tile's loads IN FRONT of this tile's MFMAs --
+    // same-box A/B, same bits: list mode 0.638 -> 0.630 ms, a contiguous 5 M rows 0.324 -> 0.300 - 0.319, all 2^24 rows 1.00 ->
+    // 0.82 or 1.00 (bimodal from run to run).  NS = 3 / 4 (152 -> 168 VGPRs with 4 / 14 spilled) are slower: 1.04 ms / 0.34 -
+    // 0.39 / 0.66 - 0.71 ms.  The pass is neither a clean stream nor pipe-bound; see MEASUREMENTS.md, round 6.
+    Stage st[NS];
+    unsigned dnext = dead_of((t0 + NS - 1) * 32);
+#pragma unroll
+    for (int d = 0; d < NS - 1; ++d)
+        if (t0 + d < t1) load(st[d], (t0 + d) * 32, dead_of((t0 + d) * 32));
+    for (int64_t tt = t0; tt < t1; tt += NS) {
+#pragma unroll
+        for (int d = 0; d < NS; ++d) {
+            if (tt + d < t1) {
+                const unsigned dcur = dnext;
+                dnext = dead_of((tt + d + NS) * 32);
+                if (tt + d + NS - 1 < t1) load(st[(d + NS - 1) % NS], (tt + d + NS - 1) * 32, dcur);
+                __builtin_amdgcn_sched_barrier(0);
+                tile(st[d], (tt + d) * 32);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 }
 
