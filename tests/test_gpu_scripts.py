@@ -416,3 +416,38 @@ def test_sparse_features_refuse_a_near_dense_column():
     assert isinstance(G.SparseFeatures.maybe_from_dense(Xd), G.SparseFeatures)
     Xd[:, 0] = 1.0                                            # a bias feature: 40000 non-zeros in one column
     assert G.SparseFeatures.maybe_from_dense(Xd) is Xd
+
+
+def test_default_bench_line_carries_the_contract_fields():
+    """`python bench.py` (N = 1, the headline Pubmed step; short run without the extras): ONE JSON line with the contract's
+    keys; `roofline` is the SpMM aggregation with a MALL-cold fraction beside the warm one, `roofline_dense` the dense
+    layer-1 pair, `cpu_baseline` a timed CPU restatement on this host's cores"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "3", "--no-extra",
+                        "--cpu-seconds", "2"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0]           # the LAST line of stdout
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 10 and line["warmup"] == 3 and line["vs_baseline"] is None
+    assert line["config"]["workload"].startswith("pubmed") and line["data"] == "synthetic" and line["unit"] == "edges/s"
+    assert 0.05 < line["ms_per_step"] < 5 and line["value_spmm_only"] > line["value"] > 0
+    rf = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_cold", "copy_GBs_cold", "in_step"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "F = 500" in rf["kernel"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac_cold"] < rf["frac"] < 1
+    assert rf["alg_bytes_per_launch"] == 4 * (19717 + 1) + 4 * 88651 + 2 * 4 * 500 * 19717            # SURVEY 8(d)'s B_alg
+    assert 0 < rf["in_step"]["frac_cold"] <= rf["in_step"]["frac"] < 1
+    for k in ("xw_fwd", "xtg"):
+        d = line["roofline_dense"][k]
+        assert 0 < d["frac_cold"] < 1 and 0 < d["frac"] < 1
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "edges/s" and cb["sample"]
+    assert line["roofline_step_dominant"]["kernel"].startswith("fused decoder + BCE")
